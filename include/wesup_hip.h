@@ -1,0 +1,159 @@
+/*
+ * libwesup_hip.so -- C ABI of the MI355X (gfx950) WESUP training-step hot path.
+ *
+ * Drop-in boundary: the reference is pure Python on stock
+ * ATen ops (no native layer), so each entry below replaces the ATen op
+ * sequence at the cited reference lines.  A maintainer binds them with ctypes
+ * (see INTEGRATION.md); no torch types appear in any signature.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless marked "host";
+ *   - activations are NHWC fp32 ([B][H][W][C], C contiguous), index tensors int32;
+ *   - `stream` is a hipStream_t passed as void*; entries never synchronise,
+ *     never allocate, never throw; scratch comes in through (ws, ws_bytes) with
+ *     a matching *_workspace_bytes() query;
+ *   - return 0 (WESUP_OK) or a negative WESUP_ERR_* code (wesup_strerror()).
+ */
+#ifndef WESUP_HIP_H
+#define WESUP_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define WESUP_OK 0
+#define WESUP_ERR_INVALID (-1)   /* bad shape / null pointer / unsupported size */
+#define WESUP_ERR_LAUNCH (-2)    /* hipLaunch failed */
+#define WESUP_ERR_WORKSPACE (-3) /* workspace too small */
+
+/* flags for wesup_gemm_nt */
+#define WESUP_RELU_IN 1    /* A := max(A, 0) while loading */
+#define WESUP_RELU_OUT 2   /* C := max(C, 0) */
+#define WESUP_ACCUM 4      /* C += result */
+#define WESUP_MASK 8       /* result := mask > 0 ? result : 0 (ReLU backward) */
+
+int wesup_abi_version(void);
+const char* wesup_strerror(int code);
+
+/* ------------------------------------------------------------------ layout packing
+ * models/wesup.py:263-279 feeds NCHW (1,3,H,W); the kernels want NHWC with the
+ * 3 image channels padded to 4.  Conv weights stay in torch's (Co,Ci,3,3) layout
+ * in the state_dict; they are re-packed per step. */
+int wesup_pack_input(const float* img_nchw, float* out_nhwc4, int B, int H, int W, void* stream);
+/* w_fwd  [Co][Kf], Kf = wesup_conv3x3_kpad(Ci): k = (kh*3+kw)*Cip + ci, Cip = max(Ci,4), zero padded
+ * w_dgrad[Ci][9*Co]: k = ((2-kh)*3+(2-kw))*Co + co   (may be NULL) */
+int wesup_conv3x3_kpad(int Ci);
+int wesup_pack_conv3x3_weight(const float* w_kcrs, float* w_fwd, float* w_dgrad, int Co, int Ci, void* stream);
+int wesup_transpose(const float* in, float* out, int rows, int cols, void* stream);
+
+/* ------------------------------------------------------------------ VGG16 3x3 convs (K1/K2/K12)
+ * replaces torchvision VGG16 Conv2d(k=3,pad=1)+ReLU (models/wesup.py:199,279) and its autograd.
+ * y is the PRE-ReLU output (the hook taps it, models/wesup.py:246-253); the next
+ * layer applies ReLU while loading (relu_in).  x has Cin channels (4 for the image). */
+int wesup_conv3x3_fwd(const float* x, const float* w_fwd, const float* bias, float* y,
+                      int B, int H, int W, int Cin, int Cout, int relu_in, void* stream);
+/* dx = conv_transpose(dy) ; if mask_src: dx = mask_src > 0 ? dx : 0 ; if accumulate: dx += old dx */
+int wesup_conv3x3_dgrad(const float* dy, const float* w_dgrad, const float* mask_src, float* dx,
+                        int B, int H, int W, int Cin, int Cout, int accumulate, void* stream);
+/* dw in torch layout (Co,Ci,3,3); db (Co).  Ci is the TRUE channel count (3 for the image,
+ * whose tensor has 4); relu_in applies ReLU to x while loading. */
+size_t wesup_conv3x3_wgrad_workspace_bytes(int B, int H, int W, int Ci, int Cout);
+int wesup_conv3x3_wgrad(const float* x, const float* dy, float* dw_kcrs, float* db,
+                        int B, int H, int W, int Ci, int Cout, int relu_in,
+                        void* ws, size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------ generic fp32 MFMA GEMMs
+ * side 1x1 convs (models/wesup.py:208-209,253), fc_layers (models/wesup.py:213-220,288) and their grads.
+ * nt:  C[M][N] = epilogue( A[M][K] . B[N][K]^T + bias[N] )      (K % 32 == 0, rows 16B aligned)
+ * tn:  C[M][N] = A[K][M]^T . B[K][N]      (weight gradients; deterministic split-K)
+ * colsum: out[N] = sum_m A[m][n]          (bias gradients) */
+int wesup_gemm_nt(const float* A, int lda, const float* B, int ldb, const float* bias,
+                  float* C, int ldc, const float* mask, int ldmask,
+                  int M, int N, int K, int flags, void* stream);
+size_t wesup_gemm_tn_workspace_bytes(int M, int N, int K);
+int wesup_gemm_tn(const float* A, int lda, const float* B, int ldb, float* C, int ldc,
+                  int M, int N, int K, int relu_b, void* ws, size_t ws_bytes, void* stream);
+size_t wesup_colsum_workspace_bytes(int M, int N);
+int wesup_colsum(const float* A, int lda, float* out, int M, int N, void* ws, size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------ pooling / upsampling (K2/K4)
+ * maxpool: nn.MaxPool2d(2,2) after ReLU == ReLU after maxpool; operates on pre-ReLU y. */
+int wesup_maxpool2_fwd(const float* y, float* yp, int B, int H, int W, int C, void* stream);
+/* dy[p] = (p is the first max of its window and y[p] > 0 ? dyp[window] : 0) (+ dy[p] if accumulate) */
+int wesup_maxpool2_bwd(const float* y, const float* dyp, float* dy, int B, int H, int W, int C,
+                       int accumulate, void* stream);
+/* F.interpolate(bilinear, align_corners=True) (models/wesup.py:254-255) into channel slice
+ * [coff, coff+C) of the feature-map tensor fm [B][H][W][ldf]. */
+int wesup_upsample_fwd(const float* s, float* fm, int B, int h, int w, int H, int W, int C,
+                       int ldf, int coff, void* stream);
+/* ds[q][c] = sum_p wgt(p,q) * src(p)[coff+c].  src(p) = dfm[b][p][.] when new_row == NULL; otherwise the
+ * pooling backward is fused in: src(p) = g[b][new_row[b][p]][.] / area[b][new_row[b][p]]  (ldf = row stride) */
+int wesup_upsample_bwd(const float* dfm_or_g, const int32_t* new_row, const int32_t* area_new,
+                       float* ds, int B, int h, int w, int H, int W, int C, int ldf, int coff,
+                       int Kmax, void* stream);
+
+/* ------------------------------------------------------------------ superpixels (K6/K8/K9)
+ * wesup_sp_preprocess replaces _preprocess_superpixels (models/wesup.py:18-63) without dense maps.
+ *   labels [B][HW] ids 0..n-1 (contiguous), mask [B][C][HW] uint8 {0,1} or NULL, Kmax >= max id+1
+ * outputs (all [B][Kmax...] padded; rows are in the reference's order: labelled ids ascending, then unlabelled):
+ *   n_sp[B], n_l[B], perm[B][Kmax] (row->id), inv_perm[B][Kmax] (id->row), area_new[B][Kmax] (by row),
+ *   sp_labels[B][Kmax][C] f32 multi-hot (rows >= n_l zero), new_row[B][HW], row_start[B][Kmax+1],
+ *   pix_sorted[B][HW] (pixels grouped by row, ascending pixel index inside a row),
+ *   status[B]: 0 ok, 1 = label id >= Kmax, 2 = empty id below max (the reference would produce NaN). */
+size_t wesup_sp_preprocess_workspace_bytes(int B, int HW, int C, int Kmax);
+int wesup_sp_preprocess(const int32_t* labels, const uint8_t* mask, int B, int HW, int C, int Kmax,
+                        int32_t* n_sp, int32_t* n_l, int32_t* perm, int32_t* inv_perm, int32_t* area_new,
+                        float* sp_labels, int32_t* new_row, int32_t* row_start, int32_t* pix_sorted,
+                        int32_t* status, void* ws, size_t ws_bytes, void* stream);
+/* dense compat: labels[p] = argmax_n sp_maps[n][p] (first max), as models/wesup.py:295 does */
+int wesup_spmaps_to_labels(const float* sp_maps, int32_t* labels, int N, int HW, void* stream);
+/* scatter-mean: sp_feat[b][r][c] = (1/area_r) sum_{p in row r} fm[b][p][c]   (torch.mm, models/wesup.py:283-285) */
+int wesup_sp_pool_fwd(const float* fm, const int32_t* pix_sorted, const int32_t* row_start,
+                      float* sp_feat, int B, int HW, int ldf, int C, int Kmax, void* stream);
+/* dfm[b][p][c] = g[b][new_row[p]][c] / area[new_row[p]] */
+int wesup_sp_pool_bwd(const float* g, const int32_t* new_row, const int32_t* area_new, float* dfm,
+                      int B, int HW, int ldf, int C, int Kmax, void* stream);
+/* paint-back (models/wesup.py:294-304): pred[b][p] = sp_pred[b][new_row[p]][cls] */
+int wesup_paint_fwd(const float* sp_pred, const int32_t* new_row, float* pred, int B, int HW, int Kmax,
+                    int C, int cls, void* stream);
+
+/* ------------------------------------------------------------------ head, loss, optimiser (K7/K10/K11/K13)
+ * classifier Linear(D,2)+Softmax(dim=1) (models/wesup.py:229-232,292) */
+int wesup_classifier_fwd(const float* feat, const float* Wc, const float* bc, float* pred, int R, int D, void* stream);
+/* given dpred: dfeat[R][D] (masked by feat > 0: fc_layers' last ReLU), dWc[2][D], dbc[2] */
+size_t wesup_classifier_bwd_workspace_bytes(int R, int D);
+int wesup_classifier_bwd(const float* feat, const float* Wc, const float* pred, const float* dpred,
+                         const float* dfeat_extra, float* dfeat, float* dWc, float* dbc, int R, int D,
+                         void* ws, size_t ws_bytes, void* stream);
+/* _label_propagate (models/wesup.py:99-139) per image on padded rows.  y_all[b][r][:] = sp_labels for
+ * r < n_l, propagated pseudo label for n_l <= r < n_sp (zeros if max similarity <= threshold), 0 beyond.
+ * src_idx/max_sim [B][Kmax] (entries for unlabelled rows; -1/0 elsewhere). */
+int wesup_propagate(const float* feat, const float* sp_labels, const int32_t* n_sp, const int32_t* n_l,
+                    float threshold, int enable, float* y_all, int32_t* src_idx, float* max_sim,
+                    int B, int Kmax, int D, int C, void* stream);
+/* _cross_entropy + compute_loss (models/wesup.py:66-96,492-531), per image then mean over images:
+ * terms[b] = {sup_sum, sup_cnt, prop_sum, prop_cnt, prop_label_sum, loss_b, 0, 0}; loss[0] = mean_b loss_b */
+int wesup_loss_fwd(const float* pred, const float* y_all, const int32_t* n_sp, const int32_t* n_l,
+                   float eps, float prop_weight, float* terms, float* loss, int B, int Kmax, int C, void* stream);
+/* dpred = dloss[0] * d loss / d pred */
+int wesup_loss_bwd(const float* pred, const float* y_all, const int32_t* n_sp, const int32_t* n_l,
+                   const float* terms, const float* dloss, float eps, float prop_weight, float* dpred,
+                   int B, int Kmax, int C, void* stream);
+/* generic _cross_entropy (models/wesup.py:66-96) on (n, C): out = {sum(-y log clamp(yhat)), #rows with sum(y) > 0} */
+int wesup_cross_entropy_fwd(const float* y_hat, const float* y_true, float eps, float* out2, int n, int C, void* stream);
+int wesup_cross_entropy_bwd(const float* y_hat, const float* y_true, const float* out2, const float* dloss,
+                            float eps, float* dy_hat, int n, int C, void* stream);
+/* torch.optim.SGD step (models/wesup.py:445-451): g' = g*grad_scale + wd*p; v = first ? g' : mu*v + g'; p -= lr*v */
+int wesup_sgd_step(float* p, const float* g, float* v, size_t n, float lr, float momentum, float weight_decay,
+                   float grad_scale, int first_step, void* stream);
+/* accuracy / dice inputs (utils/metrics.py:31-45,112-135): out[b] = {#(P==G), sum(P*G), sum(P), sum(G)} with
+ * P = round(pred) (half to even, models/wesup.py:534), G = argmax_c mask (first max) */
+int wesup_seg_metrics(const float* pred, const uint8_t* mask, float* out4, int B, int HW, int C, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WESUP_HIP_H */

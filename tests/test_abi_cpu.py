@@ -1,0 +1,62 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads and exports every
+symbol include/wesup_hip.h declares, with the argument lists the ctypes binding uses.
+No compute entry is called (no GPU here)."""
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_decls():
+    hdr = open(os.path.join(ROOT, 'include', 'wesup_hip.h')).read()
+    hdr = re.sub(r'/\*.*?\*/', '', hdr, flags=re.S)
+    return re.findall(r'\n\s*(?:int|size_t|const char\*)\s+(wesup_\w+)\s*\(([^;]*?)\)\s*;', hdr, flags=re.S)
+
+
+@pytest.fixture(scope='module')
+def lib():
+    from wesup_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        _lib.build()
+    return _lib
+
+
+def test_library_exports_every_declared_symbol(lib):
+    decls = _header_decls()
+    assert len(decls) >= 30
+    handle = lib.load()
+    for name, _ in decls:
+        assert hasattr(handle, name), f'{name} declared in include/wesup_hip.h but not exported'
+    assert sorted(n for n, _ in decls) == lib.EXPORTS
+
+
+def test_ctypes_signatures_match_header(lib):
+    for name, args in _header_decls():
+        sig = ''
+        for a in [a.strip() for a in args.replace('\n', ' ').split(',')]:
+            if a in ('void', ''):
+                continue
+            sig += 'p' if '*' in a else 'z' if a.startswith('size_t') else 'f' if a.startswith('float') else 'i'
+        assert lib._SIGS[name][1] == sig, name
+
+
+def test_host_side_queries(lib):
+    h = lib.load()
+    assert h.wesup_abi_version() == 1
+    assert h.wesup_conv3x3_kpad(3) == 64 and h.wesup_conv3x3_kpad(64) == 576 and h.wesup_conv3x3_kpad(512) == 4608
+    assert h.wesup_strerror(0) == b'ok' and b'workspace' in h.wesup_strerror(-3)
+    assert h.wesup_conv3x3_wgrad_workspace_bytes(4, 480, 480, 64, 64) > 0
+    assert h.wesup_gemm_tn_workspace_bytes(1024, 2112, 2400) >= 1024 * 2112 * 4
+    assert h.wesup_sp_preprocess_workspace_bytes(4, 480 * 480, 2, 640) > 0
+    # invalid arguments are rejected on the host before any launch
+    assert h.wesup_conv3x3_fwd(None, None, None, None, 1, 8, 8, 64, 64, 0, None) == -1
+    assert h.wesup_gemm_nt(None, 0, None, 0, None, None, 0, None, 0, 1, 1, 32, 0, None) == -1
+
+
+def test_product_path_fails_loudly_without_gpu_tensors(lib):
+    import torch
+    from wesup_amd import ops
+    with pytest.raises(lib.WesupHipError):
+        ops.pack_input(torch.zeros(1, 3, 4, 4))          # CPU tensor: no fallback

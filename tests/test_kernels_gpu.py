@@ -1,0 +1,399 @@
+"""Per-kernel parity on a real MI355X, through the C ABI (wesup_amd.ops -> libwesup_hip.so).
+
+Integer / index outputs must be bit-exact; fp32 outputs within 1e-4 relative
+(BASELINE.json north_star).  References: the CPU oracle (oracle/wesup_oracle.py)
+where it restates the op, plain torch fp32 CPU ops for generic conv/GEMM kernels.
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4
+
+
+def dev():
+    assert torch.cuda.is_available(), 'GPU tests need a GPU'
+    return torch.device('cuda:0')
+
+
+def rel_err(a, b):
+    a = a.detach().double().cpu()
+    b = b.detach().double().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+def nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous()
+
+
+def nchw(t):
+    return t.permute(0, 3, 1, 2).contiguous()
+
+
+@pytest.fixture(scope='module')
+def ops():
+    from wesup_amd import ops as o
+    return o
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).float()
+
+
+# ---------------------------------------------------------------- conv 3x3
+CONV_CASES = [
+    # B, H, W, Cin, Cout
+    (2, 12, 10, 64, 64),
+    (1, 6, 6, 128, 256),
+    (3, 5, 7, 256, 128),
+    (1, 2, 2, 512, 512),
+    (2, 16, 12, 3, 64),
+    (1, 224, 224, 64, 64),      # 128x64 tiles
+    (1, 224, 224, 64, 128),     # 128x128 tiles
+    (1, 230, 218, 3, 64),       # image layer, 128x64 tiles, ragged M
+]
+
+
+@pytest.mark.parametrize('B,H,W,Cin,Cout', CONV_CASES)
+@pytest.mark.parametrize('relu_in', [False, True])
+def test_conv3x3_fwd(ops, B, H, W, Cin, Cout, relu_in):
+    d = dev()
+    x = rnd(B, Cin, H, W, seed=1)
+    w = rnd(Cout, Cin, 3, 3, seed=2, scale=(2.0 / (9 * Cin)) ** 0.5)
+    b = rnd(Cout, seed=3, scale=0.1)
+    ref = F.conv2d(F.relu(x) if relu_in else x, w, b, padding=1)
+    if Cin == 3:
+        xg = ops.pack_input(x.to(d))
+    else:
+        xg = nhwc(x).to(d)
+    wf, _ = ops.pack_conv3x3_weight(w.to(d), need_dgrad=False)
+    y = ops.conv3x3_fwd(xg, wf, b.to(d), Cout, relu_in)
+    assert rel_err(nchw(y), ref) < TOL
+
+
+@pytest.mark.parametrize('B,H,W,Cin,Cout', [c for c in CONV_CASES if c[3] != 3])
+def test_conv3x3_dgrad(ops, B, H, W, Cin, Cout):
+    d = dev()
+    x = rnd(B, Cin, H, W, seed=1).requires_grad_(True)
+    w = rnd(Cout, Cin, 3, 3, seed=2, scale=(2.0 / (9 * Cin)) ** 0.5)
+    dy = rnd(B, Cout, H, W, seed=4)
+    y = F.conv2d(F.relu(x), w, None, padding=1)
+    y.backward(dy)
+    ref = x.grad                                   # includes the ReLU mask (x > 0)
+    _, wd = ops.pack_conv3x3_weight(w.to(d))
+    base = rnd(B, H, W, Cin, seed=5)
+    out = base.clone().to(d)
+    ops.conv3x3_dgrad(nhwc(dy).to(d), wd, Cin, mask_src=nhwc(x.detach()).to(d), out=out, accumulate=True)
+    assert rel_err(nchw(out.cpu() - base), ref) < TOL
+    # plain (no mask, no accumulate)
+    x2 = rnd(B, Cin, H, W, seed=1).requires_grad_(True)
+    F.conv2d(x2, w, None, padding=1).backward(dy)
+    out2 = ops.conv3x3_dgrad(nhwc(dy).to(d), wd, Cin)
+    assert rel_err(nchw(out2), x2.grad) < TOL
+
+
+@pytest.mark.parametrize('B,H,W,Cin,Cout', CONV_CASES[:5] + [(1, 120, 96, 64, 64), (2, 60, 60, 128, 128), (1, 100, 90, 3, 64)])
+@pytest.mark.parametrize('relu_in', [False, True])
+def test_conv3x3_wgrad(ops, B, H, W, Cin, Cout, relu_in):
+    d = dev()
+    x = rnd(B, Cin, H, W, seed=1)
+    w = rnd(Cout, Cin, 3, 3, seed=2, scale=0.05).requires_grad_(True)
+    b = torch.zeros(Cout, requires_grad=True)
+    dy = rnd(B, Cout, H, W, seed=4)
+    F.conv2d(F.relu(x) if relu_in else x, w, b, padding=1).backward(dy)
+    xg = ops.pack_input(x.to(d)) if Cin == 3 else nhwc(x).to(d)
+    dw, db = ops.conv3x3_wgrad(xg, nhwc(dy).to(d), Cin, relu_in)
+    assert rel_err(dw, w.grad) < TOL
+    assert rel_err(db, b.grad) < TOL
+    dw2, db2 = ops.conv3x3_wgrad(xg, nhwc(dy).to(d), Cin, relu_in)      # deterministic split-K
+    assert torch.equal(dw, dw2) and torch.equal(db, db2)
+
+
+# ---------------------------------------------------------------- GEMMs
+@pytest.mark.parametrize('M,N,K', [(100, 32, 64), (2400, 1024, 2112), (600, 2112, 1024), (57600, 64, 128),
+                                   (50000, 256, 64), (37, 32, 1024), (49160, 32, 64)])
+def test_gemm_nt(ops, M, N, K):
+    d = dev()
+    A = rnd(M, K, seed=1)
+    Bw = rnd(N, K, seed=2, scale=K ** -0.5)
+    bias = rnd(N, seed=3)
+    ref = A @ Bw.t() + bias
+    out = ops.gemm_nt(A.to(d), Bw.to(d), bias.to(d))
+    assert rel_err(out, ref) < TOL
+    out = ops.gemm_nt(A.to(d), Bw.to(d), bias.to(d), flags=ops.RELU_OUT | ops.RELU_IN)
+    assert rel_err(out, F.relu(F.relu(A) @ Bw.t() + bias)) < TOL
+    # mask + accumulate into a strided (column-slice) output
+    big = rnd(M, N + 64, seed=4).to(d)
+    base = big.clone()
+    mask = rnd(M, N, seed=5)
+    ops.gemm_nt(A.to(d), Bw.to(d), None, out=big[:, 32:32 + N], mask=mask.to(d), flags=ops.ACCUM)
+    ref2 = base.cpu()
+    ref2[:, 32:32 + N] += torch.where(mask > 0, A @ Bw.t(), torch.zeros(()))
+    assert rel_err(big, ref2) < TOL
+
+
+@pytest.mark.parametrize('M,N,K', [(32, 1024, 2400), (1024, 2112, 600), (64, 128, 57600), (256, 512, 3601), (32, 64, 230400)])
+def test_gemm_tn_colsum(ops, M, N, K):
+    d = dev()
+    A = rnd(K, M, seed=1)
+    Bm = rnd(K, N, seed=2)
+    out = ops.gemm_tn(A.to(d), Bm.to(d))
+    ref = (A.double().t() @ Bm.double()).float()
+    assert rel_err(out, ref) < TOL
+    out_r = ops.gemm_tn(A.to(d), Bm.to(d), relu_b=True)
+    assert rel_err(out_r, (A.double().t() @ F.relu(Bm).double()).float()) < TOL
+    assert torch.equal(out, ops.gemm_tn(A.to(d), Bm.to(d)))
+    cs = ops.colsum(A.to(d))
+    assert rel_err(cs, A.double().sum(0).float()) < TOL
+    assert rel_err(ops.transpose(Bm.to(d)), Bm.t()) == 0.0
+
+
+# ---------------------------------------------------------------- maxpool / upsample
+@pytest.mark.parametrize('B,H,W,C', [(2, 8, 6, 64), (1, 30, 30, 512), (1, 10, 14, 128)])
+def test_maxpool(ops, B, H, W, C):
+    d = dev()
+    y = rnd(B, C, H, W, seed=1)
+    y[:, :, 0:2, 0:2] = 0.5                       # exact ties -> first max takes the gradient
+    yr = y.clone().requires_grad_(True)
+    p = F.max_pool2d(F.relu(yr), 2, 2)
+    dyp = rnd(*p.shape, seed=2)
+    p.backward(dyp)
+    yp = ops.maxpool2_fwd(nhwc(y).to(d))
+    assert torch.equal(F.relu(nchw(yp)).cpu(), p.detach())
+    base = rnd(B, H, W, C, seed=3)
+    out = base.clone().to(d)
+    ops.maxpool2_bwd(nhwc(y).to(d), nhwc(dyp).to(d), out, accumulate=True)
+    assert rel_err(nchw(out.cpu() - base), yr.grad) < 1e-6
+
+
+@pytest.mark.parametrize('B,h,w,H,W,C', [(2, 4, 4, 8, 8, 32), (1, 2, 2, 32, 32, 256), (1, 15, 15, 240, 240, 64),
+                                          (2, 6, 5, 96, 80, 64), (1, 8, 8, 8, 8, 32), (1, 1, 1, 16, 16, 32)])
+def test_upsample(ops, B, h, w, H, W, C):
+    d = dev()
+    s = rnd(B, C, h, w, seed=1).requires_grad_(True)
+    up = F.interpolate(s, (H, W), mode='bilinear', align_corners=True)
+    ldf, coff = C + 64, 32
+    fm = torch.zeros(B, H, W, ldf, device=d)
+    ops.upsample_fwd(nhwc(s.detach()).to(d), fm, coff)
+    assert rel_err(nchw(fm[..., coff:coff + C]), up) < 1e-5
+    assert float(fm[..., :coff].abs().max()) == 0.0 and float(fm[..., coff + C:].abs().max()) == 0.0
+    dfm = rnd(B, H, W, ldf, seed=2)
+    up.backward(nchw(dfm[..., coff:coff + C]))
+    ds = ops.upsample_bwd(dfm.to(d), coff, h, w, C)
+    assert rel_err(nchw(ds), s.grad) < 1e-5
+
+
+# ---------------------------------------------------------------- superpixel preprocessing + pooling
+def _sp_case(seed, B, H, W, g, mode='point'):
+    from wesup_amd import synth
+    labs = np.stack([synth.voronoi_labels(seed + b, H, W, g) for b in range(B)])
+    if mode == 'point':
+        masks = np.stack([synth.point_mask(seed + b, labs[b], 0.25, 2, tie_every=3) for b in range(B)])
+    elif mode == 'full':
+        masks = np.stack([synth.pixel_mask(seed + b, H, W) for b in range(B)])
+    else:
+        masks = None
+    return labs, masks
+
+
+@pytest.mark.parametrize('B,H,W,g,mode,Kpad', [(2, 32, 32, 4, 'point', 0), (1, 96, 80, 7, 'point', 11), (2, 64, 64, 6, 'full', 0),
+                                                 (1, 64, 64, 6, 'none', 3), (1, 480, 480, 24, 'point', 0)])
+def test_sp_preprocess(ops, B, H, W, g, mode, Kpad):
+    from oracle import wesup_oracle as orc
+    d = dev()
+    labs, masks = _sp_case(7, B, H, W, g, mode)
+    Kmax = g * g + Kpad
+    m = ops.sp_preprocess(torch.from_numpy(labs).to(d), None if masks is None else torch.from_numpy(masks).to(d), Kmax)
+    m.check()
+    for b in range(B):
+        pp = orc.preprocess_superpixels(torch.from_numpy(labs[b]).long(),
+                                        None if masks is None else torch.from_numpy(masks[b]).long())
+        K, n_l = pp['K'], pp['n_l']
+        assert int(m.n_sp[b]) == K and int(m.n_l[b]) == n_l
+        assert torch.equal(m.perm[b, :K].cpu().long(), pp['perm'])
+        assert torch.equal(m.inv_perm[b, :K].cpu().long(), pp['inv_perm'])
+        assert torch.equal(m.area_new[b, :K].cpu().long(), pp['area'][pp['perm']])
+        assert int(m.area_new[b, K:].abs().sum()) == 0
+        assert torch.equal(m.sp_labels[b, :n_l].cpu(), pp['sp_labels'][:, :2] if n_l else m.sp_labels[b, :0].cpu())
+        assert float(m.sp_labels[b, n_l:].abs().sum()) == 0.0
+        new_row = pp['inv_perm'][torch.from_numpy(labs[b]).long().reshape(-1)]
+        assert torch.equal(m.new_row[b].cpu().long(), new_row)
+        # stable counting sort: pixels grouped by row, ascending inside a row
+        order = torch.argsort(new_row, stable=True)
+        assert torch.equal(m.pix_sorted[b].cpu().long(), order)
+        rs = torch.zeros(Kmax + 1, dtype=torch.long)
+        rs[1:K + 1] = torch.cumsum(pp['area'][pp['perm']], 0)
+        rs[K + 1:] = H * W
+        assert torch.equal(m.row_start[b].cpu().long(), rs)
+
+
+def test_sp_preprocess_rejects_bad_maps(ops):
+    d = dev()
+    lab = torch.zeros(1, 8, 8, dtype=torch.int32)
+    lab[0, 4:] = 2                                    # id 1 is empty
+    m = ops.sp_preprocess(lab.to(d), None, 4)
+    with pytest.raises(ValueError):
+        m.check()
+    lab[0, 0, 0] = 9                                  # id >= Kmax
+    m = ops.sp_preprocess(lab.to(d), None, 4)
+    with pytest.raises(ValueError):
+        m.check()
+
+
+@pytest.mark.parametrize('B,H,W,g,C', [(2, 32, 32, 4, 2112), (1, 96, 80, 7, 2112), (1, 64, 64, 6, 256), (1, 120, 120, 12, 2112)])
+def test_sp_pool(ops, B, H, W, g, C):
+    from oracle import wesup_oracle as orc
+    d = dev()
+    labs, masks = _sp_case(11, B, H, W, g)
+    Kmax = g * g + 5
+    m = ops.sp_preprocess(torch.from_numpy(labs).to(d), torch.from_numpy(masks).to(d), Kmax)
+    fm = rnd(B, H, W, C, seed=3)
+    out = ops.sp_pool_fwd(fm.to(d), m)
+    gup = rnd(B, Kmax, C, seed=4)
+    dfm = ops.sp_pool_bwd(gup.to(d), m)
+    for b in range(B):
+        pp = orc.preprocess_superpixels(torch.from_numpy(labs[b]).long(), torch.from_numpy(masks[b]).long())
+        K = pp['K']
+        seg_new = pp['inv_perm'][torch.from_numpy(labs[b]).long().reshape(-1)]
+        area_new = pp['area'][pp['perm']]
+        fmc = fm[b].reshape(H * W, C).t().contiguous().requires_grad_(True)        # (C, HW) as the reference holds it
+        ref = orc.pool_labelmap(fmc, seg_new, area_new, K)
+        assert rel_err(out[b, :K], ref) < TOL
+        assert float(out[b, K:].abs().max()) == 0.0
+        ref.backward(gup[b, :K])
+        assert rel_err(dfm[b].reshape(H * W, C), fmc.grad.t()) < TOL
+    assert torch.equal(out, ops.sp_pool_fwd(fm.to(d), m))          # bitwise reproducible
+    # fused pool-backward + upsample-backward == unfused
+    for (h, w, Cs, coff) in [(H, W, 32, 0), (H // 2, W // 2, 64, 64), (max(1, H // 16), max(1, W // 16), 64, 128)]:
+        if coff + Cs > C:
+            continue
+        a = ops.upsample_bwd(dfm, coff, h, w, Cs)
+        f = ops.upsample_bwd_fused(gup.to(d), m.new_row, m.area_new, H, W, coff, h, w, Cs)
+        assert rel_err(f, a) < 1e-5
+
+
+def test_paint_and_dense_compat(ops):
+    from oracle import wesup_oracle as orc
+    d = dev()
+    H = W = 32
+    labs, masks = _sp_case(5, 1, H, W, 4)
+    seg = torch.from_numpy(labs[0]).long()
+    sp_maps, sp_labels = orc.preprocess_superpixels_dense(seg, torch.from_numpy(masks[0]).long())
+    new_lab = ops.spmaps_to_labels(sp_maps.to(d))
+    assert torch.equal(new_lab[0].cpu().long(), sp_maps.argmax(dim=0))
+    m = ops.sp_preprocess(torch.from_numpy(labs).to(d), torch.from_numpy(masks).to(d), 16)
+    sp_pred = torch.rand(1, 16, 2)
+    pred = ops.paint_fwd(sp_pred.to(d), m)
+    ref = sp_pred[0][sp_maps.argmax(dim=0).reshape(-1), 1].reshape(H, W)
+    assert torch.equal(pred[0].cpu(), ref)
+
+
+# ---------------------------------------------------------------- head, propagation, loss
+def test_classifier(ops):
+    d = dev()
+    R, D = 700, 32
+    feat = F.relu(rnd(R, D, seed=1)).requires_grad_(True)
+    Wc = rnd(2, D, seed=2, scale=0.3).requires_grad_(True)
+    bc = rnd(2, seed=3).requires_grad_(True)
+    pre = rnd(R, D, seed=6).requires_grad_(True)              # feat = relu(pre) to check the ReLU mask
+    featr = F.relu(pre)
+    pred = F.softmax(F.linear(featr, Wc, bc), dim=1)
+    dpred = rnd(R, 2, seed=4)
+    extra = rnd(R, D, seed=5)
+    (pred * dpred).sum().backward(retain_graph=True)
+    (featr * extra).sum().backward()
+    pg = ops.classifier_fwd(featr.detach().to(d), Wc.detach().to(d), bc.detach().to(d))
+    assert rel_err(pg, pred) < 1e-5
+    dfeat, dWc, dbc = ops.classifier_bwd(featr.detach().to(d), Wc.detach().to(d), pg, dpred.to(d), extra.to(d))
+    assert rel_err(dfeat, pre.grad) < TOL
+    assert rel_err(dWc, Wc.grad) < TOL and rel_err(dbc, bc.grad) < TOL
+
+
+@pytest.mark.parametrize('seed,scale,ident', [(1, 0.08, False), (2, 0.5, False), (3, 0.12, False), (4, 0.0, True)])
+def test_propagate_and_loss(ops, seed, scale, ident):
+    from oracle import wesup_oracle as orc
+    d = dev()
+    B, H, W, g, D = 3, 64, 64, 6, 32
+    labs, masks = _sp_case(20 + seed, B, H, W, g)
+    Kmax = g * g + 4
+    m = ops.sp_preprocess(torch.from_numpy(labs).to(d), torch.from_numpy(masks).to(d), Kmax)
+    feat = F.relu(rnd(B, Kmax, D, seed=seed, scale=scale))
+    if ident:
+        feat = torch.zeros(B, Kmax, D) + 0.25                 # identical features: W = 1 everywhere -> first index
+    pred = F.softmax(rnd(B, Kmax, 2, seed=seed + 50, scale=2.0), dim=2)
+    pred[0, 0, 0], pred[0, 0, 1] = 1.0, 0.0                   # clamp edge: zero gradient outside [eps, 1-eps]
+    y_all, src, sim = ops.propagate(feat.to(d), m, 0.8)
+    loss, terms = ops.loss_fwd(pred.to(d), y_all, m, 1e-7, 0.5)
+    dloss = torch.tensor([1.7], device=d)
+    dpred = ops.loss_bwd(pred.to(d), y_all, m, terms, dloss, 1e-7, 0.5)
+    ref_losses = []
+    pr = pred.clone().requires_grad_(True)
+    for b in range(B):
+        pp = orc.preprocess_superpixels(torch.from_numpy(labs[b]).long(), torch.from_numpy(masks[b]).long())
+        K, n_l = pp['K'], pp['n_l']
+        y_u, W_ul, max_sim, s = orc.label_propagate(feat[b, :K], pp['sp_labels'], 0.8, return_aux=True)
+        assert torch.equal(src[b, n_l:K].cpu().long(), s)                      # argmax indices bit-exact
+        assert torch.equal(y_all[b, n_l:K].cpu(), y_u)
+        assert torch.equal(y_all[b, :n_l].cpu(), pp['sp_labels'])
+        assert rel_err(sim[b, n_l:K], max_sim) < 1e-5
+        mets = {}
+        ref_losses.append(orc.compute_loss(pr[b, :K], feat[b, :K], pp['sp_labels'], metrics=mets))
+        assert abs(float(terms[b, 4]) - mets['propagated_labels']) == 0.0
+        assert abs(float(terms[b, 2] / max(float(terms[b, 3]), 1.0)) - mets['propagate_loss']) < 1e-5
+    ref = torch.stack(ref_losses).mean()
+    assert abs(float(loss) - float(ref)) < 1e-5 * max(1.0, abs(float(ref)))
+    (ref * 1.7).backward()
+    assert rel_err(dpred, pr.grad) < TOL
+    # propagation disabled -> no pseudo labels
+    y_off, _, _ = ops.propagate(feat.to(d), m, 0.8, enable=False)
+    for b in range(B):
+        assert float(y_off[b, int(m.n_l[b]):].abs().sum()) == 0.0
+
+
+def test_cross_entropy_generic(ops):
+    from oracle import wesup_oracle as orc
+    d = dev()
+    y_hat = F.softmax(rnd(50, 2, seed=1), dim=1).requires_grad_(True)
+    y_true = torch.zeros(50, 2)
+    y_true[::3, 0] = 1
+    y_true[1::7, 1] = 1
+    ref = orc.cross_entropy(y_hat, y_true)
+    ref.backward()
+    out2 = ops.cross_entropy_fwd(y_hat.detach().to(d), y_true.to(d), 1e-7)
+    assert abs(float(out2[0] / out2[1]) - float(ref)) < 1e-5
+    dy = ops.cross_entropy_bwd(y_hat.detach().to(d), y_true.to(d), out2, torch.ones(1, device=d), 1e-7)
+    assert rel_err(dy, y_hat.grad) < TOL
+    out0 = ops.cross_entropy_fwd(y_hat.detach().to(d), torch.zeros(50, 2, device=d), 1e-7)
+    assert float(out0[1]) == 0.0                                               # no labelled rows -> loss 0
+
+
+def test_sgd_and_metrics(ops):
+    from oracle import wesup_oracle as orc
+    d = dev()
+    n = 100003
+    p = rnd(n + 1, seed=1)[:n]
+    g = rnd(n + 1, seed=2)[:n]
+    pd, gd = p.to(d).contiguous(), g.to(d).contiguous()
+    vd = torch.zeros(n, device=d)
+    params, bufs = {'w': p.clone()}, {}
+    for step in range(3):
+        params, bufs = orc.sgd_step(params, {'w': g * 0.5}, bufs, 5e-5, 0.9, 1e-3)
+        ops.sgd_step(pd, gd, vd, 5e-5, 0.9, 1e-3, 0.5, step == 0)
+    assert rel_err(pd, params['w']) < 1e-6 and rel_err(vd, bufs['w']) < 1e-6
+    from wesup_amd import synth
+    B, H, W = 2, 40, 36
+    pred = torch.rand(B, H, W)
+    pred[0, 0, :4] = torch.tensor([0.5, 1.5, 0.4999, 0.5001])                 # round half to even
+    mask = np.stack([synth.pixel_mask(b, H, W) for b in range(B)])
+    out = ops.seg_metrics(pred.to(d), torch.from_numpy(mask).to(d)).cpu()
+    P = pred.round().long()
+    G = torch.from_numpy(mask).long().argmax(dim=1)
+    for b in range(B):
+        acc = float(out[b, 0]) / (H * W)
+        dice = 2 * float(out[b, 1]) / (float(out[b, 3]) + float(out[b, 2]) + 1e-7)
+        assert abs(acc - orc.accuracy(P[b], G[b])) < 1e-6
+        assert abs(dice - orc.dice(P[b], G[b])) < 1e-6

@@ -1,0 +1,105 @@
+"""ctypes binding of libwesup_hip.so (C ABI in include/wesup_hip.h).
+
+The product path has NO CPU fallback: if the shared library is missing or a
+kernel entry fails, this module raises.  ``build()`` compiles it with hipcc for
+gfx950 (cross-compiles without a GPU).
+"""
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, 'csrc')
+LIB_PATH = os.path.join(CSRC, 'libwesup_hip.so')
+
+c_void_p = ctypes.c_void_p
+c_int = ctypes.c_int
+c_float = ctypes.c_float
+c_size_t = ctypes.c_size_t
+
+# name -> (restype, [argtypes]);  'p' pointer, 'i' int, 'f' float, 'z' size_t
+_SIGS = {
+    'wesup_abi_version': (c_int, ''),
+    'wesup_strerror': (ctypes.c_char_p, 'i'),
+    'wesup_pack_input': (c_int, 'ppiiip'),
+    'wesup_conv3x3_kpad': (c_int, 'i'),
+    'wesup_pack_conv3x3_weight': (c_int, 'pppiip'),
+    'wesup_transpose': (c_int, 'ppiip'),
+    'wesup_conv3x3_fwd': (c_int, 'ppppiiiiiip'),
+    'wesup_conv3x3_dgrad': (c_int, 'ppppiiiiiip'),
+    'wesup_conv3x3_wgrad_workspace_bytes': (c_size_t, 'iiiii'),
+    'wesup_conv3x3_wgrad': (c_int, 'ppppiiiiiipzp'),
+    'wesup_gemm_nt': (c_int, 'pipippipiiiiip'),
+    'wesup_gemm_tn_workspace_bytes': (c_size_t, 'iii'),
+    'wesup_gemm_tn': (c_int, 'pipipiiiiipzp'),
+    'wesup_colsum_workspace_bytes': (c_size_t, 'ii'),
+    'wesup_colsum': (c_int, 'pipiipzp'),
+    'wesup_maxpool2_fwd': (c_int, 'ppiiiip'),
+    'wesup_maxpool2_bwd': (c_int, 'pppiiiiip'),
+    'wesup_upsample_fwd': (c_int, 'ppiiiiiiiip'),
+    'wesup_upsample_bwd': (c_int, 'ppppiiiiiiiiip'),
+    'wesup_sp_preprocess_workspace_bytes': (c_size_t, 'iiii'),
+    'wesup_sp_preprocess': (c_int, 'ppiiii' + 'pppppppppp' + 'pzp'),
+    'wesup_spmaps_to_labels': (c_int, 'ppiip'),
+    'wesup_sp_pool_fwd': (c_int, 'ppppiiiiip'),
+    'wesup_sp_pool_bwd': (c_int, 'ppppiiiiip'),
+    'wesup_paint_fwd': (c_int, 'pppiiiiip'),
+    'wesup_classifier_fwd': (c_int, 'ppppiip'),
+    'wesup_classifier_bwd_workspace_bytes': (c_size_t, 'ii'),
+    'wesup_classifier_bwd': (c_int, 'ppppppppiipzp'),
+    'wesup_propagate': (c_int, 'ppppfipppiiiip'),
+    'wesup_loss_fwd': (c_int, 'ppppffppiiip'),
+    'wesup_loss_bwd': (c_int, 'ppppppffpiiip'),
+    'wesup_cross_entropy_fwd': (c_int, 'ppfpiip'),
+    'wesup_cross_entropy_bwd': (c_int, 'ppppfpiip'),
+    'wesup_sgd_step': (c_int, 'pppzffffip'),
+    'wesup_seg_metrics': (c_int, 'pppiiip'),
+}
+_T = {'p': c_void_p, 'i': c_int, 'f': c_float, 'z': c_size_t}
+
+EXPORTS = sorted(_SIGS)
+
+_lib = None
+
+
+class WesupHipError(RuntimeError):
+    pass
+
+
+def build(verbose=False):
+    """Compile libwesup_hip.so for gfx950 in-tree (wesup_amd/csrc)."""
+    cmd = ['make', '-C', CSRC, '-j4']
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if verbose or r.returncode != 0:
+        print(r.stdout)
+    if r.returncode != 0:
+        raise WesupHipError('building libwesup_hip.so failed')
+    return LIB_PATH
+
+
+def load():
+    """Load the library (no GPU needed to load; kernels need one to run)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise WesupHipError(f'{LIB_PATH} not found: run `python -c "import __graft_entry__ as g; g.build()"` '
+                            '(there is no CPU fallback for the HIP path)')
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGS.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is missing: fail loudly
+        fn.restype = res
+        fn.argtypes = [_T[a] for a in args]
+    _lib = lib
+    return lib
+
+
+def check(rc, what=''):
+    if rc != 0:
+        msg = load().wesup_strerror(rc).decode()
+        raise WesupHipError(f'{what} failed: {msg} (code {rc})')
+
+
+def call(name, *args):
+    """Call an int-returning entry and raise on a non-zero code."""
+    check(getattr(load(), name)(*args), name)

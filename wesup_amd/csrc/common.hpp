@@ -1,0 +1,48 @@
+// Shared helpers for the gfx950 kernels of libwesup_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include "../../include/wesup_hip.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define WESUP_CHECK_LAUNCH()                                   \
+    do {                                                       \
+        if (hipGetLastError() != hipSuccess) return WESUP_ERR_LAUNCH; \
+    } while (0)
+
+static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+static inline size_t align_up(size_t a, size_t b) { return (a + b - 1) / b * b; }
+
+// Exact n / d for n*d < 2^40 via one 64-bit multiply (n < 2^26 pixels, d < 2^12 here).
+struct FastDiv {
+    unsigned long long m;
+    int d;
+};
+static inline FastDiv make_fastdiv(int d) {
+    FastDiv f;
+    f.d = d;
+    f.m = ((1ull << 40) + (unsigned long long)d - 1) / (unsigned long long)d;
+    return f;
+}
+__device__ __forceinline__ int fast_div(int n, const FastDiv f) {
+    return (int)(((unsigned long long)(unsigned)n * f.m) >> 40);
+}
+
+// Bijective XCD-aware block remap (cdna_hip_programming.md 5, "XCD swizzle must be bijective"):
+// blocks b and b+8 share an XCD; give each XCD a contiguous range of logical tiles so that
+// neighbouring tiles (which share activation rows / halos) hit the same L2.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7;
+    const int xcd = bid & 7, idx = bid >> 3;
+    const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + idx;
+}
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ float4 relu4(float4 v) {
+    return make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+}

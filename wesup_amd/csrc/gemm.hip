@@ -1,0 +1,612 @@
+// fp32 MFMA GEMM family for gfx950: implicit-GEMM 3x3 convolution (fwd + dgrad), plain NT GEMM
+// (1x1 side convs, fc layers), TN GEMM with deterministic split-K (all weight gradients), column sums.
+//
+// Matrix core: v_mfma_f32_32x32x2_f32 (exact fp32, 64 FLOP/clk/SIMD = 157 TFLOP/s chip peak).  One
+// MFMA takes 64 cycles on its SIMD, so the kernel is paced by MFMA issue; everything else (global
+// loads into registers, LDS transposing stores, ds_read_b32 fragment reads) has to hide under it.
+//
+// LDS image of every operand tile is K-MAJOR:  T[k][m]  (m contiguous).  An MFMA fragment is then one
+// conflict-free ds_read_b32: lane l reads T[2*kp + (l>>5)][m0 + (l&31)].  Operands whose global layout
+// is k-contiguous (activations NHWC x weights [N][K]) are transposed while being stored to LDS, with the
+// row stride == 1 (mod 32) so that the 4 scalar stores of a float4 are conflict free; operands that are
+// m-contiguous in memory (wgrad: both operands are [pixel][channel]) are stored with ds_write_b128.
+#include "common.hpp"
+
+#define BK 32
+
+struct NtParams {
+    const float* A;
+    const float* Bw;
+    const float* bias;
+    float* C;
+    const float* mask;
+    int M, N, K;
+    int lda, ldb, ldc, ldmask;
+    int H, W, Cin, cin_shift;
+    int flags;
+    int tiles_m, tiles_n;
+};
+
+// ---------------------------------------------------------------------------------------------
+// NT kernel:  C[M][N] = A[M][K] * Bw[N][K]^T   with A either a plain row-major matrix or the implicit
+// im2col view of an NHWC tensor under a 3x3/pad-1 window (K order = (kh, kw, ci), ci fastest).
+// MODE 0: plain; 1: conv3x3 with Cin % 32 == 0; 2: conv3x3 with Cin == 4 (image layer, K padded to 64).
+// ---------------------------------------------------------------------------------------------
+template <int BM, int BN, int WM, int WN, int MODE>
+__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const NtParams p) {
+    constexpr int LDA_S = BM + 1, LDB_S = BN + 1;
+    constexpr int RA = BM / 32, RB = BN / 32;
+    constexpr int WAVES_N = BN / (32 * WN);
+    static_assert((BM / (32 * WM)) * WAVES_N == 4, "4 waves per block");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;                       // [2][BK][LDA_S]
+    float* Bs = smem + 2 * BK * LDA_S;      // [2][BK][LDB_S]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nwg = p.tiles_m * p.tiles_n;
+    const int lt = xcd_remap(blockIdx.x, nwg);
+    const int tile_n = lt % p.tiles_n, tile_m = lt / p.tiles_n;
+    const int m_blk = tile_m * BM, n_blk = tile_n * BN;
+    const int quad = tid & 7, lrow = tid >> 3;
+    const bool relu_in = p.flags & WESUP_RELU_IN;
+
+    // ---- per-thread A rows
+    long a_off[RA];
+    unsigned a_msk[RA];
+#pragma unroll
+    for (int i = 0; i < RA; ++i) {
+        const int m = m_blk + lrow + 32 * i;
+        if (MODE == 0) {
+            a_off[i] = (long)m * p.lda + 4 * quad;
+            a_msk[i] = (m < p.M) ? 1u : 0u;
+        } else {
+            const int hw = p.H * p.W;
+            const int b = m / hw;
+            const int rem = m - b * hw;
+            const int h = rem / p.W, w = rem - h * p.W;
+            unsigned msk = 0;
+            if (m < p.M) {
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    const int hh = h + t / 3 - 1, ww = w + t % 3 - 1;
+                    if (hh >= 0 && hh < p.H && ww >= 0 && ww < p.W) msk |= 1u << t;
+                }
+            }
+            a_msk[i] = msk;
+            a_off[i] = (long)m * p.Cin + (MODE == 1 ? 4 * quad : 0);
+        }
+    }
+    long b_off[RB];
+    bool b_ok[RB];
+#pragma unroll
+    for (int j = 0; j < RB; ++j) {
+        const int n = n_blk + lrow + 32 * j;
+        b_ok[j] = n < p.N;
+        b_off[j] = (long)n * p.ldb + 4 * quad;
+    }
+
+    float4 ra[RA], rb[RB];
+    auto load_global = [&](int kk) {
+        if (MODE == 0) {
+#pragma unroll
+            for (int i = 0; i < RA; ++i)
+                ra[i] = a_msk[i] ? ld4(p.A + a_off[i] + kk * BK) : make_float4(0.f, 0.f, 0.f, 0.f);
+        } else if (MODE == 1) {
+            const int k0 = kk * BK;
+            const int tap = k0 >> p.cin_shift;
+            const int ci0 = k0 & (p.Cin - 1);
+            const int toff = ((tap / 3 - 1) * p.W + (tap % 3 - 1)) * p.Cin + ci0;
+#pragma unroll
+            for (int i = 0; i < RA; ++i)
+                ra[i] = ((a_msk[i] >> tap) & 1u) ? ld4(p.A + a_off[i] + toff) : make_float4(0.f, 0.f, 0.f, 0.f);
+        } else {
+            const int tap = kk * 8 + quad;
+            const int toff = ((tap / 3 - 1) * p.W + (tap % 3 - 1)) * 4;
+#pragma unroll
+            for (int i = 0; i < RA; ++i)
+                ra[i] = (tap < 9 && ((a_msk[i] >> tap) & 1u)) ? ld4(p.A + a_off[i] + toff)
+                                                               : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        if (relu_in) {
+#pragma unroll
+            for (int i = 0; i < RA; ++i) ra[i] = relu4(ra[i]);
+        }
+#pragma unroll
+        for (int j = 0; j < RB; ++j)
+            rb[j] = b_ok[j] ? ld4(p.Bw + b_off[j] + kk * BK) : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    auto store_lds = [&](int buf) {
+        float* as = As + buf * BK * LDA_S + (4 * quad) * LDA_S + lrow;
+#pragma unroll
+        for (int i = 0; i < RA; ++i) {
+            as[32 * i] = ra[i].x;
+            as[32 * i + LDA_S] = ra[i].y;
+            as[32 * i + 2 * LDA_S] = ra[i].z;
+            as[32 * i + 3 * LDA_S] = ra[i].w;
+        }
+        float* bs = Bs + buf * BK * LDB_S + (4 * quad) * LDB_S + lrow;
+#pragma unroll
+        for (int j = 0; j < RB; ++j) {
+            bs[32 * j] = rb[j].x;
+            bs[32 * j + LDB_S] = rb[j].y;
+            bs[32 * j + 2 * LDB_S] = rb[j].z;
+            bs[32 * j + 3 * LDB_S] = rb[j].w;
+        }
+    };
+
+    f32x16 acc[WM][WN];
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int wm0 = (wave / WAVES_N) * 32 * WM, wn0 = (wave % WAVES_N) * 32 * WN;
+    const int l31 = lane & 31, lhi = lane >> 5;
+    const int nk = p.K / BK;
+
+    load_global(0);
+    store_lds(0);
+    __syncthreads();
+    int cur = 0;
+    for (int kk = 0; kk < nk; ++kk) {
+        const bool more = kk + 1 < nk;
+        if (more) load_global(kk + 1);
+        const float* as = As + cur * BK * LDA_S + lhi * LDA_S + wm0 + l31;
+        const float* bs = Bs + cur * BK * LDB_S + lhi * LDB_S + wn0 + l31;
+#pragma unroll
+        for (int kp = 0; kp < BK / 2; ++kp) {
+            float a[WM], b[WN];
+#pragma unroll
+            for (int i = 0; i < WM; ++i) a[i] = as[2 * kp * LDA_S + 32 * i];
+#pragma unroll
+            for (int j = 0; j < WN; ++j) b[j] = bs[2 * kp * LDB_S + 32 * j];
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int j = 0; j < WN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        if (more) store_lds(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    // ---- epilogue: lane holds D[row = (r&3) + 8*(r>>2) + 4*lhi][col = l31] of each 32x32 tile
+    const bool relu_out = p.flags & WESUP_RELU_OUT, accum = p.flags & WESUP_ACCUM, use_mask = p.flags & WESUP_MASK;
+#pragma unroll
+    for (int j = 0; j < WN; ++j) {
+        const int n = n_blk + wn0 + 32 * j + l31;
+        if (n >= p.N) continue;
+        const float bv = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < WM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m_blk + wm0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                if (m >= p.M) continue;
+                float v = acc[i][j][r] + bv;
+                if (relu_out) v = fmaxf(v, 0.f);
+                if (use_mask) v = (p.mask[(long)m * p.ldmask + n] > 0.f) ? v : 0.f;
+                float* c = p.C + (long)m * p.ldc + n;
+                if (accum) v += *c;
+                *c = v;
+            }
+        }
+    }
+}
+
+template <int BM, int BN, int WM, int WN, int MODE>
+static int launch_nt(NtParams p, hipStream_t st) {
+    p.tiles_m = ceil_div(p.M, BM);
+    p.tiles_n = ceil_div(p.N, BN);
+    const size_t lds = (size_t)2 * BK * ((BM + 1) + (BN + 1)) * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_kernel<BM, BN, WM, WN, MODE>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, WM, WN, MODE>), dim3(p.tiles_m * p.tiles_n), dim3(256), lds, st, p);
+    WESUP_CHECK_LAUNCH();
+    return WESUP_OK;
+}
+
+// Tile choice: 128x128 when the grid still fills 256 CUs twice over; 128x64 for N <= 64; 64x64 for small M.
+template <int MODE>
+static int dispatch_nt(NtParams p, hipStream_t st) {
+    const long t128 = (long)ceil_div(p.M, 128) * ceil_div(p.N, 128);
+    if (p.N > 64 && t128 >= 384) return launch_nt<128, 128, 2, 2, MODE>(p, st);
+    if (p.N <= 64 && (long)ceil_div(p.M, 128) >= 384) return launch_nt<128, 64, 2, 1, MODE>(p, st);
+    return launch_nt<64, 64, 1, 1, MODE>(p, st);
+}
+
+static int ilog2(int v) {
+    int s = 0;
+    while ((1 << s) < v) ++s;
+    return s;
+}
+
+extern "C" int wesup_gemm_nt(const float* A, int lda, const float* B, int ldb, const float* bias, float* C,
+                             int ldc, const float* mask, int ldmask, int M, int N, int K, int flags,
+                             void* stream) {
+    if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || (K % BK) || (lda % 4) || (ldb % 4)) return WESUP_ERR_INVALID;
+    if ((flags & WESUP_MASK) && !mask) return WESUP_ERR_INVALID;
+    NtParams p = {};
+    p.A = A; p.Bw = B; p.bias = bias; p.C = C; p.mask = mask;
+    p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldmask = ldmask;
+    p.flags = flags;
+    return dispatch_nt<0>(p, (hipStream_t)stream);
+}
+
+extern "C" int wesup_conv3x3_kpad(int Ci) {
+    const int cip = Ci < 4 ? 4 : Ci;
+    return (9 * cip + BK - 1) / BK * BK;
+}
+
+static int conv_common(const float* x, const float* w, const float* bias, float* y, const float* mask, int B,
+                       int H, int W, int Cin, int Cout, int flags, hipStream_t st) {
+    if (!x || !w || !y || B <= 0 || H <= 0 || W <= 0) return WESUP_ERR_INVALID;
+    const bool small = (Cin == 4);
+    if (!small && (Cin < 32 || (Cin & (Cin - 1)))) return WESUP_ERR_INVALID;
+    if ((long)B * H * W * (long)(Cin > Cout ? Cin : Cout) >= (1l << 31)) return WESUP_ERR_INVALID;
+    NtParams p = {};
+    p.A = x; p.Bw = w; p.bias = bias; p.C = y; p.mask = mask;
+    p.M = B * H * W; p.N = Cout; p.K = wesup_conv3x3_kpad(Cin);
+    p.lda = Cin; p.ldb = p.K; p.ldc = Cout; p.ldmask = Cout;
+    p.H = H; p.W = W; p.Cin = Cin; p.cin_shift = ilog2(Cin);
+    p.flags = flags;
+    return small ? dispatch_nt<2>(p, st) : dispatch_nt<1>(p, st);
+}
+
+extern "C" int wesup_conv3x3_fwd(const float* x, const float* w_fwd, const float* bias, float* y, int B, int H,
+                                 int W, int Cin, int Cout, int relu_in, void* stream) {
+    return conv_common(x, w_fwd, bias, y, nullptr, B, H, W, Cin, Cout, relu_in ? WESUP_RELU_IN : 0,
+                       (hipStream_t)stream);
+}
+
+extern "C" int wesup_conv3x3_dgrad(const float* dy, const float* w_dgrad, const float* mask_src, float* dx, int B,
+                                   int H, int W, int Cin, int Cout, int accumulate, void* stream) {
+    // the same implicit GEMM with the roles of the channel counts swapped: input dy has Cout channels
+    int flags = (mask_src ? WESUP_MASK : 0) | (accumulate ? WESUP_ACCUM : 0);
+    return conv_common(dy, w_dgrad, nullptr, dx, mask_src, B, H, W, Cout, Cin, flags, (hipStream_t)stream);
+}
+
+// ---------------------------------------------------------------------------------------------
+// TN kernel (weight gradients):  C[M][N] = sum_k A[k][M] * B[k][N], k = pixel / row index.
+// MODE 0: plain matrices.  MODE 1: conv3x3 wgrad, grid.x also enumerates the 9 taps; B row k is the
+// input pixel shifted by the tap.  MODE 2: conv3x3 wgrad for the 4-channel image: N = 9 taps x 4.
+// Split-K over grid.y; every split writes its own slab (deterministic), reduced by a second kernel.
+// ---------------------------------------------------------------------------------------------
+struct TnParams {
+    const float* A;
+    const float* Bx;
+    float* slab;     // [S][M][Nslab]
+    int M, N, K;     // N: columns per tap (MODE 1) or total
+    int lda, ldb;
+    int Nslab;       // slab row length
+    int H, W;
+    FastDiv dW, dH;
+    int relu_b;
+    int tiles_m, tiles_n, taps;
+    int k_per_split;  // multiple of BK
+};
+
+template <int BM, int BN, int WM, int WN, int MODE>
+__global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnParams p) {
+    constexpr int LDA_S = BM + 4, LDB_S = BN + 4;
+    constexpr int QA = BM / 4, RPA = 256 / QA, NA = BK / RPA;
+    constexpr int QB = BN / 4, RPB = 256 / QB, NB = BK / RPB;
+    constexpr int WAVES_N = BN / (32 * WN);
+    static_assert((BM / (32 * WM)) * WAVES_N == 4, "4 waves per block");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;                       // [2][BK][LDA_S]
+    float* Bs = smem + 2 * BK * LDA_S;      // [2][BK][LDB_S]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int lt = blockIdx.x;
+    const int tile_n = lt % p.tiles_n;
+    lt /= p.tiles_n;
+    const int tile_m = lt % p.tiles_m;
+    const int tap = lt / p.tiles_m;          // 0 for MODE 0/2
+    const int m_blk = tile_m * BM, n_blk = tile_n * BN;
+    const int k_begin = blockIdx.y * p.k_per_split;
+    const int k_end = min(p.K, k_begin + p.k_per_split);
+
+    const int qa = tid % QA, ra_row = tid / QA;
+    const int qb = tid % QB, rb_row = tid / QB;
+    const bool a_col_ok = (m_blk + 4 * qa) < p.M;      // M, N multiples of 4
+    const bool b_col_ok = (n_blk + 4 * qb) < p.N;
+    const int dh = (MODE == 1) ? tap / 3 - 1 : 0, dw = (MODE == 1) ? tap % 3 - 1 : 0;
+    // MODE 2: column quad qb is tap qb (4 channels each), only 9 of the 16 quads are real
+    const int dh2 = qb / 3 - 1, dw2 = qb % 3 - 1;
+
+    float4 ra[NA], rb[NB];
+    auto load_global = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int k = k0 + ra_row + RPA * i;
+            ra[i] = (a_col_ok && k < k_end) ? ld4(p.A + (long)k * p.lda + m_blk + 4 * qa)
+                                            : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int k = k0 + rb_row + RPB * i;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (MODE == 0) {
+                if (b_col_ok && k < k_end) v = ld4(p.Bx + (long)k * p.ldb + n_blk + 4 * qb);
+            } else {
+                const int t = fast_div(k, p.dW);       // b*H + h
+                const int w = k - t * p.W;
+                const int bb = fast_div(t, p.dH);
+                const int h = t - bb * p.H;
+                if (MODE == 1) {
+                    const int hh = h + dh, ww = w + dw;
+                    if (b_col_ok && k < k_end && hh >= 0 && hh < p.H && ww >= 0 && ww < p.W)
+                        v = ld4(p.Bx + (long)(k + dh * p.W + dw) * p.ldb + n_blk + 4 * qb);
+                } else {
+                    const int hh = h + dh2, ww = w + dw2;
+                    if (qb < 9 && k < k_end && hh >= 0 && hh < p.H && ww >= 0 && ww < p.W)
+                        v = ld4(p.Bx + (long)(k + dh2 * p.W + dw2) * 4);
+                }
+            }
+            rb[i] = p.relu_b ? relu4(v) : v;
+        }
+    };
+    auto store_lds = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) st4(As + buf * BK * LDA_S + (ra_row + RPA * i) * LDA_S + 4 * qa, ra[i]);
+#pragma unroll
+        for (int i = 0; i < NB; ++i) st4(Bs + buf * BK * LDB_S + (rb_row + RPB * i) * LDB_S + 4 * qb, rb[i]);
+    };
+
+    f32x16 acc[WM][WN];
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int wm0 = (wave / WAVES_N) * 32 * WM, wn0 = (wave % WAVES_N) * 32 * WN;
+    const int l31 = lane & 31, lhi = lane >> 5;
+    const int nk = (k_end - k_begin + BK - 1) / BK;
+
+    if (nk > 0) {
+        load_global(k_begin);
+        store_lds(0);
+    }
+    __syncthreads();
+    int cur = 0;
+    for (int kk = 0; kk < nk; ++kk) {
+        const bool more = kk + 1 < nk;
+        if (more) load_global(k_begin + (kk + 1) * BK);
+        const float* as = As + cur * BK * LDA_S + lhi * LDA_S + wm0 + l31;
+        const float* bs = Bs + cur * BK * LDB_S + lhi * LDB_S + wn0 + l31;
+#pragma unroll
+        for (int kp = 0; kp < BK / 2; ++kp) {
+            float a[WM], b[WN];
+#pragma unroll
+            for (int i = 0; i < WM; ++i) a[i] = as[2 * kp * LDA_S + 32 * i];
+#pragma unroll
+            for (int j = 0; j < WN; ++j) b[j] = bs[2 * kp * LDB_S + 32 * j];
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int j = 0; j < WN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        if (more) store_lds(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    float* slab = p.slab + (long)blockIdx.y * p.M * p.Nslab;
+    const int ncol0 = (MODE == 1) ? tap * p.N : 0;
+#pragma unroll
+    for (int j = 0; j < WN; ++j) {
+        const int n = n_blk + wn0 + 32 * j + l31;
+        if (n >= p.N) continue;
+#pragma unroll
+        for (int i = 0; i < WM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m_blk + wm0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                if (m < p.M) slab[(long)m * p.Nslab + ncol0 + n] = acc[i][j][r];
+            }
+        }
+    }
+}
+
+// C[m][n] = sum_s slab[s][m][n]     (plain)            -- or, for conv weights --
+// dW[co][ci][t] = sum_s slab[s][co][t*Cs + ci]          (torch (Co,Ci,3,3) layout; Cs = slab channels per tap)
+__global__ void tn_reduce_kernel(const float* slab, float* C, int ldc, int M, int N, int Nslab, int S) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)M * N) return;
+    const int m = idx / N, n = idx - (long)m * N;
+    float s = 0.f;
+    for (int k = 0; k < S; ++k) s += slab[((long)k * M + m) * Nslab + n];
+    C[(long)m * ldc + n] = s;
+}
+__global__ void wgrad_reduce_kernel(const float* slab, float* dw, int Co, int Ci, int Cs, int Nslab, int S) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)Co * Ci) return;
+    const int co = idx / Ci, ci = idx - (long)co * Ci;
+    float acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) acc[t] = 0.f;
+    for (int k = 0; k < S; ++k) {
+        const float* s = slab + ((long)k * Co + co) * Nslab + ci;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) acc[t] += s[t * Cs];
+    }
+    float* d = dw + ((long)co * Ci + ci) * 9;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) d[t] = acc[t];
+}
+
+struct TnPlan {
+    int bm, bn;       // 128x128 or 64x64
+    int tiles_m, tiles_n, taps, S, k_per_split, Nslab;
+};
+
+static TnPlan plan_tn(int M, int N, int K, int taps) {
+    TnPlan pl;
+    const bool big = (M >= 128 && N >= 128);
+    pl.bm = big ? 128 : 64;
+    pl.bn = big ? 128 : 64;
+    pl.tiles_m = ceil_div(M, pl.bm);
+    pl.tiles_n = ceil_div(N, pl.bn);
+    pl.taps = taps;
+    const int tiles = pl.tiles_m * pl.tiles_n * taps;
+    const int ksteps = ceil_div(K, BK);
+    int S = ceil_div(768, tiles);
+    const int maxS = ksteps / 8 > 0 ? ksteps / 8 : 1;
+    if (S > maxS) S = maxS;
+    if (S < 1) S = 1;
+    const int steps_per = ceil_div(ksteps, S);
+    pl.k_per_split = steps_per * BK;
+    pl.S = ceil_div(K, pl.k_per_split);
+    pl.Nslab = N * taps;
+    return pl;
+}
+
+template <int MODE>
+static int launch_tn(TnParams p, const TnPlan& pl, hipStream_t st) {
+    p.tiles_m = pl.tiles_m; p.tiles_n = pl.tiles_n; p.taps = pl.taps; p.k_per_split = pl.k_per_split;
+    p.Nslab = pl.Nslab;
+    dim3 grid(pl.tiles_m * pl.tiles_n * pl.taps, pl.S);
+    if (pl.bm == 128) {
+        const size_t lds = (size_t)2 * BK * (132 + 132) * sizeof(float);
+        static bool a = false;
+        if (!a) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_kernel<128, 128, 2, 2, MODE>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            a = true;
+        }
+        hipLaunchKernelGGL((gemm_tn_kernel<128, 128, 2, 2, MODE>), grid, dim3(256), lds, st, p);
+    } else {
+        const size_t lds = (size_t)2 * BK * (68 + 68) * sizeof(float);
+        hipLaunchKernelGGL((gemm_tn_kernel<64, 64, 1, 1, MODE>), grid, dim3(256), lds, st, p);
+    }
+    WESUP_CHECK_LAUNCH();
+    return WESUP_OK;
+}
+
+extern "C" size_t wesup_gemm_tn_workspace_bytes(int M, int N, int K) {
+    if (M <= 0 || N <= 0 || K <= 0) return 0;
+    const TnPlan pl = plan_tn(M, N, K, 1);
+    return (size_t)pl.S * M * pl.Nslab * sizeof(float);
+}
+
+extern "C" int wesup_gemm_tn(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N,
+                             int K, int relu_b, void* ws, size_t ws_bytes, void* stream) {
+    if (!A || !B || !C || !ws || M <= 0 || N <= 0 || K <= 0 || (M % 4) || (N % 4) || (lda % 4) || (ldb % 4))
+        return WESUP_ERR_INVALID;
+    if (ws_bytes < wesup_gemm_tn_workspace_bytes(M, N, K)) return WESUP_ERR_WORKSPACE;
+    const TnPlan pl = plan_tn(M, N, K, 1);
+    TnParams p = {};
+    p.A = A; p.Bx = B; p.slab = (float*)ws; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb;
+    p.relu_b = relu_b; p.H = 1; p.W = 1; p.dW = make_fastdiv(1); p.dH = make_fastdiv(1);
+    hipStream_t st = (hipStream_t)stream;
+    int rc = launch_tn<0>(p, pl, st);
+    if (rc) return rc;
+    const long tot = (long)M * N;
+    hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, (const float*)ws, C,
+                       ldc, M, N, pl.Nslab, pl.S);
+    WESUP_CHECK_LAUNCH();
+    return WESUP_OK;
+}
+
+// ---- column sums (bias gradients): two-stage, fixed order
+__global__ void colsum_stage1(const float* A, int lda, float* part, int M, int N, int rows_per) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const int m0 = blockIdx.y * rows_per;
+    const int m1 = min(M, m0 + rows_per);
+    float s = 0.f;
+    for (int m = m0; m < m1; ++m) s += A[(long)m * lda + n];
+    part[(long)blockIdx.y * N + n] = s;
+}
+__global__ void colsum_stage2(const float* part, float* out, int N, int chunks) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    float s = 0.f;
+    for (int c = 0; c < chunks; ++c) s += part[(long)c * N + n];
+    out[n] = s;
+}
+static int colsum_chunks(int M, int N) {
+    int chunks = ceil_div(M, 256);
+    const int cap = ceil_div(1 << 16, N > 0 ? N : 1);     // keep the partial buffer small
+    if (chunks > cap) chunks = cap;
+    if (chunks > 1024) chunks = 1024;
+    if (chunks < 1) chunks = 1;
+    return chunks;
+}
+extern "C" size_t wesup_colsum_workspace_bytes(int M, int N) {
+    if (M <= 0 || N <= 0) return 0;
+    return (size_t)colsum_chunks(M, N) * N * sizeof(float);
+}
+extern "C" int wesup_colsum(const float* A, int lda, float* out, int M, int N, void* ws, size_t ws_bytes,
+                            void* stream) {
+    if (!A || !out || !ws || M <= 0 || N <= 0) return WESUP_ERR_INVALID;
+    if (ws_bytes < wesup_colsum_workspace_bytes(M, N)) return WESUP_ERR_WORKSPACE;
+    const int chunks = colsum_chunks(M, N);
+    const int rows_per = ceil_div(M, chunks);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(colsum_stage1, dim3(ceil_div(N, 64), chunks), dim3(64), 0, st, A, lda, (float*)ws, M, N,
+                       rows_per);
+    hipLaunchKernelGGL(colsum_stage2, dim3(ceil_div(N, 64)), dim3(64), 0, st, (const float*)ws, out, N, chunks);
+    WESUP_CHECK_LAUNCH();
+    return WESUP_OK;
+}
+
+// ---- conv3x3 wgrad entry
+static TnPlan plan_wgrad(int B, int H, int W, int Ci, int Cout) {
+    const int K = B * H * W;
+    if (Ci < 32) {                     // image layer: tensor has 4 channels, N = 64 covers 9 taps x 4
+        TnPlan pl = plan_tn(Cout, 64, K, 1);
+        return pl;
+    }
+    return plan_tn(Cout, Ci, K, 9);
+}
+extern "C" size_t wesup_conv3x3_wgrad_workspace_bytes(int B, int H, int W, int Ci, int Cout) {
+    if (B <= 0 || H <= 0 || W <= 0 || Ci <= 0 || Cout <= 0) return 0;
+    const TnPlan pl = plan_wgrad(B, H, W, Ci, Cout);
+    const size_t slab = (size_t)pl.S * Cout * pl.Nslab * sizeof(float);
+    return align_up(slab, 256) + wesup_colsum_workspace_bytes(B * H * W, Cout);
+}
+extern "C" int wesup_conv3x3_wgrad(const float* x, const float* dy, float* dw_kcrs, float* db, int B, int H, int W,
+                                   int Ci, int Cout, int relu_in, void* ws, size_t ws_bytes, void* stream) {
+    if (!x || !dy || !dw_kcrs || !ws || B <= 0 || H <= 0 || W <= 0) return WESUP_ERR_INVALID;
+    const bool small = Ci < 32;
+    if (small && Ci != 3) return WESUP_ERR_INVALID;
+    if (!small && (Ci & (Ci - 1))) return WESUP_ERR_INVALID;
+    if (Cout % 32) return WESUP_ERR_INVALID;
+    if (ws_bytes < wesup_conv3x3_wgrad_workspace_bytes(B, H, W, Ci, Cout)) return WESUP_ERR_WORKSPACE;
+    const TnPlan pl = plan_wgrad(B, H, W, Ci, Cout);
+    hipStream_t st = (hipStream_t)stream;
+    TnParams p = {};
+    p.A = dy; p.Bx = x; p.slab = (float*)ws; p.M = Cout; p.K = B * H * W; p.lda = Cout;
+    p.relu_b = relu_in; p.H = H; p.W = W; p.dW = make_fastdiv(W); p.dH = make_fastdiv(H);
+    int rc;
+    if (small) {
+        p.N = 64; p.ldb = 4;
+        rc = launch_tn<2>(p, pl, st);
+    } else {
+        p.N = Ci; p.ldb = Ci;
+        rc = launch_tn<1>(p, pl, st);
+    }
+    if (rc) return rc;
+    const long tot = (long)Cout * Ci;
+    // slab rows: [co][tap*Cs + ci] with Cs = 4 for the image layer (Nslab = 64), Ci otherwise
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, (const float*)ws,
+                       dw_kcrs, Cout, Ci, small ? 4 : Ci, pl.Nslab, pl.S);
+    WESUP_CHECK_LAUNCH();
+    if (db) {
+        const size_t slab = align_up((size_t)pl.S * Cout * pl.Nslab * sizeof(float), 256);
+        return wesup_colsum(dy, Cout, db, B * H * W, Cout, (char*)ws + slab, ws_bytes - slab, stream);
+    }
+    return WESUP_OK;
+}

@@ -1,0 +1,465 @@
+// Head and loss kernels: classifier + softmax, label propagation over the superpixel affinity
+// exp(-|fi-fj|^2), semi-supervised cross entropy, fused SGD, segmentation metric sums.
+// All reductions are fixed-order (no float atomics): results are bitwise reproducible.
+#include "common.hpp"
+
+// block-wide sum of `v` over 256 threads, fixed tree order; result valid in all threads
+__device__ __forceinline__ float block_sum256(float v, float* sh) {
+    const int tid = threadIdx.x;
+    sh[tid] = v;
+    __syncthreads();
+#pragma unroll
+    for (int off = 128; off > 0; off >>= 1) {
+        if (tid < off) sh[tid] += sh[tid + off];
+        __syncthreads();
+    }
+    const float r = sh[0];
+    __syncthreads();
+    return r;
+}
+
+// ------------------------------------------------------------------ classifier Linear(D,2) + Softmax(dim=1)
+__global__ void classifier_fwd_kernel(const float* __restrict__ feat, const float* __restrict__ Wc,
+                                      const float* __restrict__ bc, float* __restrict__ pred, int R, int D) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R) return;
+    float z0 = bc[0], z1 = bc[1];
+    const float* f = feat + (long)r * D;
+    for (int k = 0; k < D; ++k) {
+        const float v = f[k];
+        z0 = fmaf(v, Wc[k], z0);
+        z1 = fmaf(v, Wc[D + k], z1);
+    }
+    const float m = fmaxf(z0, z1);
+    const float e0 = expf(z0 - m), e1 = expf(z1 - m);
+    const float inv = 1.f / (e0 + e1);
+    pred[2 * r] = e0 * inv;
+    pred[2 * r + 1] = e1 * inv;
+}
+extern "C" int wesup_classifier_fwd(const float* feat, const float* Wc, const float* bc, float* pred, int R, int D,
+                                    void* stream) {
+    if (!feat || !Wc || !bc || !pred || R <= 0 || D <= 0) return WESUP_ERR_INVALID;
+    hipLaunchKernelGGL(classifier_fwd_kernel, dim3(ceil_div(R, 256)), dim3(256), 0, (hipStream_t)stream, feat, Wc, bc, pred,
+                       R, D);
+    WESUP_CHECK_LAUNCH();
+    return WESUP_OK;
+}
+
+// backward: dz = p * (dp - sum_c dp_c p_c); dfeat = (dz . Wc + extra) masked by feat > 0; partial dWc/dbc per 64 rows
+#define CLS_ROWS 64
+__global__ void classifier_bwd_kernel(const float* __restrict__ feat, const float* __restrict__ Wc,
+                                      const float* __restrict__ pred, const float* __restrict__ dpred,
+                                      const float* __restrict__ extra, float* __restrict__ dfeat,
+                                      float* __restrict__ part, int R, int D) {
+    __shared__ float dz[CLS_ROWS][2];
+    const int r0 = blockIdx.x * CLS_ROWS;
+    const int tid = threadIdx.x;                      // 256 threads
+    if (tid < CLS_ROWS) {
+        const int r = r0 + tid;
+        float a = 0.f, b = 0.f;
+        if (r < R) {
+            const float p0 = pred[2 * r], p1 = pred[2 * r + 1];
+            const float d0 = dpred[2 * r], d1 = dpred[2 * r + 1];
+            const float s = d0 * p0 + d1 * p1;
+            a = p0 * (d0 - s);
+            b = p1 * (d1 - s);
+        }
+        dz[tid][0] = a;
+        dz[tid][1] = b;
+    }
+    __syncthreads();
+    // dfeat
+    for (int e = tid; e < CLS_ROWS * D; e += 256) {
+        const int rr = e / D, k = e - rr * D;
+        const int r = r0 + rr;
+        if (r < R) {
+            float g = dz[rr][0] * Wc[k] + dz[rr][1] * Wc[D + k];
+            if (extra) g += extra[(long)r * D + k];
+            dfeat[(long)r * D + k] = feat[(long)r * D + k] > 0.f ? g : 0.f;
+        }
+    }
+    // partial dWc[c][k] (2*D entries) and dbc[c] (2 entries) for this block of rows
+    float* pout = part + (long)blockIdx.x * (2 * D + 2);
+    for (int e = tid; e < 2 * D + 2; e += 256) {
+        float s = 0.f;
+        if (e < 2 * D) {
+            const int c = e / D, k = e - c * D;
+            for (int rr = 0; rr < CLS_ROWS; ++rr) {
+                const int r = r0 + rr;
+                if (r < R) s += dz[rr][c] * feat[(long)r * D + k];
+            }
+        } else {
+            const int c = e - 2 * D;
+            for (int rr = 0; rr < CLS_ROWS; ++rr) s += dz[rr][c];
+        }
+        pout[e] = s;
+    }
+}
+__global__ void classifier_bwd_reduce(const float* __restrict__ part, float* __restrict__ dWc, float* __restrict__ dbc,
+                                      int nblk, int D) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= 2 * D + 2) return;
+    float s = 0.f;
+    for (int b = 0; b < nblk; ++b) s += part[(long)b * (2 * D + 2) + e];
+    if (e < 2 * D) dWc[e] = s;
+    else dbc[e - 2 * D] = s;
+}
+extern "C" size_t wesup_classifier_bwd_workspace_bytes(int R, int D) {
+    if (R <= 0 || D <= 0) return 0;
+    return (size_t)ceil_div(R, CLS_ROWS) * (2 * D + 2) * sizeof(float);
+}
+extern "C" int wesup_classifier_bwd(const float* feat, const float* Wc, const float* pred, const float* dpred,
+                                    const float* dfeat_extra, float* dfeat, float* dWc, float* dbc, int R, int D,
+                                    void* ws, size_t ws_bytes, void* stream) {
+    if (!feat || !Wc || !pred || !dpred || !dfeat || !dWc || !dbc || !ws || R <= 0 || D <= 0) return WESUP_ERR_INVALID;
+    if (ws_bytes < wesup_classifier_bwd_workspace_bytes(R, D)) return WESUP_ERR_WORKSPACE;
+    const int nblk = ceil_div(R, CLS_ROWS);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(classifier_bwd_kernel, dim3(nblk), dim3(256), 0, st, feat, Wc, pred, dpred, dfeat_extra, dfeat,
+                       (float*)ws, R, D);
+    hipLaunchKernelGGL(classifier_bwd_reduce, dim3(ceil_div(2 * D + 2, 64)), dim3(64), 0, st, (const float*)ws, dWc, dbc,
+                       nblk, D);
+    WESUP_CHECK_LAUNCH();
+    return WESUP_OK;
+}
+
+// ------------------------------------------------------------------ label propagation (models/wesup.py:99-139)
+__global__ void prop_init_kernel(const float* __restrict__ sp_labels, const int32_t* __restrict__ n_l,
+                                 float* __restrict__ y_all, int32_t* __restrict__ src_idx, float* __restrict__ max_sim,
+                                 int Kmax, int C, long total) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const long br = idx / C;
+    const int b = br / Kmax, r = br - (long)b * Kmax;
+    y_all[idx] = (r < n_l[b]) ? sp_labels[idx] : 0.f;
+    if (idx % C == 0) {
+        src_idx[br] = -1;
+        max_sim[br] = 0.f;
+    }
+}
+// One wave per unlabelled row i; lanes stride over labelled rows j (staged in LDS 256 at a time, row stride
+// D+1 floats so that lanes hit distinct banks).  d_ij = sum_k (f_j,k - f_i,k)^2 as a direct difference in
+// ascending k (not |a|^2+|b|^2-2ab: near-ties must not flip); W = expf(-d); the row maximum takes the FIRST
+// (lowest) labelled index on ties, as torch.max(dim=1) does; propagate iff W > threshold (strict).
+#define PROP_TILE 256
+#define PROP_ROWS 16
+__global__ __launch_bounds__(256) void prop_kernel(const float* __restrict__ feat, const float* __restrict__ sp_labels,
+                                                   const int32_t* __restrict__ n_sp, const int32_t* __restrict__ n_l,
+                                                   float thr, float* __restrict__ y_all, int32_t* __restrict__ src_idx,
+                                                   float* __restrict__ max_sim, int Kmax, int D, int C) {
+    extern __shared__ float sh[];
+    float* fl = sh;                               // [PROP_TILE][D+1]
+    float* fi = sh + PROP_TILE * (D + 1);         // [PROP_ROWS][D]
+    const int b = blockIdx.y;
+    const int nl = n_l[b], ns = n_sp[b];
+    const int i_blk = nl + blockIdx.x * PROP_ROWS;
+    if (nl <= 0 || i_blk >= ns) return;           // uniform per block
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* fb = feat + (long)b * Kmax * D;
+    for (int e = tid; e < PROP_ROWS * D; e += 256) {
+        const int rr = e / D, k = e - rr * D;
+        fi[e] = (i_blk + rr < ns) ? fb[(long)(i_blk + rr) * D + k] : 0.f;
+    }
+    float best_w[PROP_ROWS / 4];
+    int best_j[PROP_ROWS / 4];
+#pragma unroll
+    for (int q = 0; q < PROP_ROWS / 4; ++q) {
+        best_w[q] = -1.f;
+        best_j[q] = 0x7fffffff;
+    }
+    for (int j0 = 0; j0 < nl; j0 += PROP_TILE) {
+        const int nj = min(PROP_TILE, nl - j0);
+        __syncthreads();
+        for (int e = tid; e < nj * D; e += 256) {
+            const int jj = e / D, k = e - jj * D;
+            fl[jj * (D + 1) + k] = fb[(long)(j0 + jj) * D + k];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < PROP_ROWS / 4; ++q) {
+            const float* f_i = fi + (wave * (PROP_ROWS / 4) + q) * D;
+            for (int jj = lane; jj < nj; jj += 64) {
+                const float* f_j = fl + jj * (D + 1);
+                float d = 0.f;
+                for (int k = 0; k < D; ++k) {
+                    const float t = f_j[k] - f_i[k];
+                    d = fmaf(t, t, d);
+                }
+                const float w = expf(-d);
+                if (w > best_w[q]) {              // strict: earlier j wins ties inside a lane
+                    best_w[q] = w;
+                    best_j[q] = j0 + jj;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < PROP_ROWS / 4; ++q) {
+        float w = best_w[q];
+        int j = best_j[q];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const float ow = __shfl_xor(w, off);
+            const int oj = __shfl_xor(j, off);
+            if (ow > w || (ow == w && oj < j)) {
+                w = ow;
+                j = oj;
+            }
+        }
+        const int i = i_blk + wave * (PROP_ROWS / 4) + q;
+        if (lane == 0 && i < ns) {
+            max_sim[(long)b * Kmax + i] = w;
+            src_idx[(long)b * Kmax + i] = j;
+            if (w > thr)
+                for (int c = 0; c < C; ++c)
+                    y_all[((long)b * Kmax + i) * C + c] = sp_labels[((long)b * Kmax + j) * C + c];
+        }
+    }
+}
+extern "C" int wesup_propagate(const float* feat, const float* sp_labels, const int32_t* n_sp, const int32_t* n_l,
+                               float threshold, int enable, float* y_all, int32_t* src_idx, float* max_sim, int B,
+                               int Kmax, int D, int C, void* stream) {
+    if (!feat || !sp_labels || !n_sp || !n_l || !y_all || !src_idx || !max_sim || B <= 0 || Kmax <= 0 || D <= 0 ||
+        D > 256 || C <= 0)
+        return WESUP_ERR_INVALID;
+    hipStream_t st = (hipStream_t)stream;
+    const long total = (long)B * Kmax * C;
+    hipLaunchKernelGGL(prop_init_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, sp_labels, n_l, y_all,
+                       src_idx, max_sim, Kmax, C, total);
+    if (enable) {
+        const size_t lds = ((size_t)PROP_TILE * (D + 1) + (size_t)PROP_ROWS * D) * sizeof(float);
+        hipLaunchKernelGGL(prop_kernel, dim3(ceil_div(Kmax, PROP_ROWS), B), dim3(256), lds, st, feat, sp_labels, n_sp, n_l,
+                           threshold, y_all, src_idx, max_sim, Kmax, D, C);
+    }
+    WESUP_CHECK_LAUNCH();
+    return WESUP_OK;
+}
+
+// ------------------------------------------------------------------ loss (models/wesup.py:66-96, 492-531)
+__device__ __forceinline__ float ce_row(const float* p, const float* y, int C, float eps, float* ysum) {
+    float s = 0.f, ys = 0.f;
+    for (int c = 0; c < C; ++c) {
+        const float yc = y[c];
+        ys += yc;
+        const float pc = fminf(fmaxf(p[c], eps), 1.f - eps);
+        s += -yc * logf(pc);
+    }
+    *ysum = ys;
+    return s;
+}
+__global__ __launch_bounds__(256) void loss_fwd_kernel(const float* __restrict__ pred, const float* __restrict__ y_all,
+                                                       const int32_t* __restrict__ n_sp, const int32_t* __restrict__ n_l,
+                                                       float eps, float prop_weight, float* __restrict__ terms, int Kmax,
+                                                       int C) {
+    __shared__ float sh[256];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int ns = n_sp[b], nl = n_l[b];
+    float sup = 0.f, supc = 0.f, pro = 0.f, proc = 0.f, plab = 0.f;
+    for (int r = tid; r < ns; r += 256) {
+        float ys;
+        const float ce = ce_row(pred + ((long)b * Kmax + r) * C, y_all + ((long)b * Kmax + r) * C, C, eps, &ys);
+        if (r < nl) {
+            sup += ce;
+            supc += (ys > 0.f) ? 1.f : 0.f;
+        } else {
+            pro += ce;
+            proc += (ys > 0.f) ? 1.f : 0.f;
+            plab += ys;
+        }
+    }
+    sup = block_sum256(sup, sh);
+    supc = block_sum256(supc, sh);
+    pro = block_sum256(pro, sh);
+    proc = block_sum256(proc, sh);
+    plab = block_sum256(plab, sh);
+    if (tid == 0) {
+        float l = (supc > 0.f) ? sup / supc : 0.f;
+        if (nl < ns && proc > 0.f) l += prop_weight * (pro / proc);
+        float* t = terms + (long)b * 8;
+        t[0] = sup; t[1] = supc; t[2] = pro; t[3] = proc; t[4] = plab; t[5] = l; t[6] = 0.f; t[7] = 0.f;
+    }
+}
+__global__ void loss_mean_kernel(const float* __restrict__ terms, float* __restrict__ loss, int B) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        float s = 0.f;
+        for (int b = 0; b < B; ++b) s += terms[(long)b * 8 + 5];
+        loss[0] = s / (float)B;
+    }
+}
+extern "C" int wesup_loss_fwd(const float* pred, const float* y_all, const int32_t* n_sp, const int32_t* n_l, float eps,
+                              float prop_weight, float* terms, float* loss, int B, int Kmax, int C, void* stream) {
+    if (!pred || !y_all || !n_sp || !n_l || !terms || !loss || B <= 0 || Kmax <= 0 || C <= 0) return WESUP_ERR_INVALID;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(loss_fwd_kernel, dim3(B), dim3(256), 0, st, pred, y_all, n_sp, n_l, eps, prop_weight, terms, Kmax, C);
+    hipLaunchKernelGGL(loss_mean_kernel, dim3(1), dim3(64), 0, st, (const float*)terms, loss, B);
+    WESUP_CHECK_LAUNCH();
+    return WESUP_OK;
+}
+// d loss / d pred: -y/p where eps <= p <= 1-eps (torch.clamp passes the gradient on the closed interval)
+__global__ void loss_bwd_kernel(const float* __restrict__ pred, const float* __restrict__ y_all,
+                                const int32_t* __restrict__ n_sp, const int32_t* __restrict__ n_l,
+                                const float* __restrict__ terms, const float* __restrict__ dloss, float eps,
+                                float prop_weight, float* __restrict__ dpred, int B, int Kmax, int C, long total) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const long br = idx / C;
+    const int b = br / Kmax, r = br - (long)b * Kmax;
+    const int ns = n_sp[b], nl = n_l[b];
+    float g = 0.f;
+    if (r < ns) {
+        const float* t = terms + (long)b * 8;
+        float coef;
+        if (r < nl) coef = (t[1] > 0.f) ? 1.f / t[1] : 0.f;
+        else coef = (nl < ns && t[3] > 0.f) ? prop_weight / t[3] : 0.f;
+        const float p = pred[idx];
+        if (p >= eps && p <= 1.f - eps) g = dloss[0] * (1.f / (float)B) * coef * (-y_all[idx] / p);
+    }
+    dpred[idx] = g;
+}
+extern "C" int wesup_loss_bwd(const float* pred, const float* y_all, const int32_t* n_sp, const int32_t* n_l,
+                              const float* terms, const float* dloss, float eps, float prop_weight, float* dpred, int B,
+                              int Kmax, int C, void* stream) {
+    if (!pred || !y_all || !n_sp || !n_l || !terms || !dloss || !dpred || B <= 0 || Kmax <= 0 || C <= 0)
+        return WESUP_ERR_INVALID;
+    const long total = (long)B * Kmax * C;
+    hipLaunchKernelGGL(loss_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, pred,
+                       y_all, n_sp, n_l, terms, dloss, eps, prop_weight, dpred, B, Kmax, C, total);
+    WESUP_CHECK_LAUNCH();
+    return WESUP_OK;
+}
+
+// generic _cross_entropy on (n, C)
+__global__ __launch_bounds__(256) void ce_fwd_kernel(const float* __restrict__ y_hat, const float* __restrict__ y_true,
+                                                     float eps, float* __restrict__ out2, int n, int C) {
+    __shared__ float sh[256];
+    float s = 0.f, cnt = 0.f;
+    for (int r = threadIdx.x; r < n; r += 256) {
+        float ys;
+        s += ce_row(y_hat + (long)r * C, y_true + (long)r * C, C, eps, &ys);
+        cnt += (ys > 0.f) ? 1.f : 0.f;
+    }
+    s = block_sum256(s, sh);
+    cnt = block_sum256(cnt, sh);
+    if (threadIdx.x == 0) {
+        out2[0] = s;
+        out2[1] = cnt;
+    }
+}
+__global__ void ce_bwd_kernel(const float* __restrict__ y_hat, const float* __restrict__ y_true,
+                              const float* __restrict__ out2, const float* __restrict__ dloss, float eps,
+                              float* __restrict__ dy, long total) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const float cnt = out2[1];
+    const float p = y_hat[idx];
+    float g = 0.f;
+    if (cnt > 0.f && p >= eps && p <= 1.f - eps) g = dloss[0] * (-y_true[idx] / p) / cnt;
+    dy[idx] = g;
+}
+extern "C" int wesup_cross_entropy_fwd(const float* y_hat, const float* y_true, float eps, float* out2, int n, int C,
+                                       void* stream) {
+    if (!y_hat || !y_true || !out2 || n < 0 || C <= 0) return WESUP_ERR_INVALID;
+    hipLaunchKernelGGL(ce_fwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, y_hat, y_true, eps, out2, n, C);
+    WESUP_CHECK_LAUNCH();
+    return WESUP_OK;
+}
+extern "C" int wesup_cross_entropy_bwd(const float* y_hat, const float* y_true, const float* out2, const float* dloss,
+                                       float eps, float* dy_hat, int n, int C, void* stream) {
+    if (!y_hat || !y_true || !out2 || !dloss || !dy_hat || n <= 0 || C <= 0) return WESUP_ERR_INVALID;
+    const long total = (long)n * C;
+    hipLaunchKernelGGL(ce_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, y_hat,
+                       y_true, out2, dloss, eps, dy_hat, total);
+    WESUP_CHECK_LAUNCH();
+    return WESUP_OK;
+}
+
+// ------------------------------------------------------------------ SGD with momentum + weight decay
+__global__ void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ v, size_t n, float lr,
+                           float mu, float wd, float gs, int first) {
+    const size_t n4 = n / 4;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        float4 pp = ld4(p + 4 * i);
+        const float4 gg = ld4(g + 4 * i);
+        float4 vv = first ? make_float4(0.f, 0.f, 0.f, 0.f) : ld4(v + 4 * i);
+        const float gx = gg.x * gs + wd * pp.x, gy = gg.y * gs + wd * pp.y;
+        const float gz = gg.z * gs + wd * pp.z, gw = gg.w * gs + wd * pp.w;
+        vv.x = first ? gx : mu * vv.x + gx;
+        vv.y = first ? gy : mu * vv.y + gy;
+        vv.z = first ? gz : mu * vv.z + gz;
+        vv.w = first ? gw : mu * vv.w + gw;
+        pp.x -= lr * vv.x;
+        pp.y -= lr * vv.y;
+        pp.z -= lr * vv.z;
+        pp.w -= lr * vv.w;
+        st4(v + 4 * i, vv);
+        st4(p + 4 * i, pp);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        const size_t i = n4 * 4 + threadIdx.x;
+        const float gi = g[i] * gs + wd * p[i];
+        const float vi = first ? gi : mu * v[i] + gi;
+        v[i] = vi;
+        p[i] -= lr * vi;
+    }
+}
+extern "C" int wesup_sgd_step(float* p, const float* g, float* v, size_t n, float lr, float momentum, float weight_decay,
+                              float grad_scale, int first_step, void* stream) {
+    if (!p || !g || !v || n == 0) return WESUP_ERR_INVALID;
+    if (((uintptr_t)p | (uintptr_t)g | (uintptr_t)v) & 15) return WESUP_ERR_INVALID;
+    const size_t n4 = n / 4;
+    size_t blocks = (n4 + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(sgd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, v, n, lr, momentum,
+                       weight_decay, grad_scale, first_step);
+    WESUP_CHECK_LAUNCH();
+    return WESUP_OK;
+}
+
+// ------------------------------------------------------------------ accuracy / dice sums
+__global__ __launch_bounds__(256) void seg_metrics_kernel(const float* __restrict__ pred, const uint8_t* __restrict__ mask,
+                                                          float* __restrict__ out4, int HW, int C) {
+    __shared__ float sh[256];
+    const int b = blockIdx.x;
+    float eq = 0.f, pg = 0.f, sp = 0.f, sg = 0.f;
+    for (int p = threadIdx.x; p < HW; p += 256) {
+        const float P = rintf(pred[(long)b * HW + p]);        // round half to even, as torch.round
+        int gi = 0;
+        uint8_t best = mask[((long)b * C) * HW + p];
+        for (int c = 1; c < C; ++c) {
+            const uint8_t v = mask[((long)b * C + c) * HW + p];
+            if (v > best) { best = v; gi = c; }
+        }
+        const float G = (float)gi;
+        eq += (P == G) ? 1.f : 0.f;
+        pg += P * G;
+        sp += P;
+        sg += G;
+    }
+    eq = block_sum256(eq, sh);
+    pg = block_sum256(pg, sh);
+    sp = block_sum256(sp, sh);
+    sg = block_sum256(sg, sh);
+    if (threadIdx.x == 0) {
+        out4[4 * b] = eq; out4[4 * b + 1] = pg; out4[4 * b + 2] = sp; out4[4 * b + 3] = sg;
+    }
+}
+extern "C" int wesup_seg_metrics(const float* pred, const uint8_t* mask, float* out4, int B, int HW, int C, void* stream) {
+    if (!pred || !mask || !out4 || B <= 0 || HW <= 0 || C <= 0) return WESUP_ERR_INVALID;
+    hipLaunchKernelGGL(seg_metrics_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, pred, mask, out4, HW, C);
+    WESUP_CHECK_LAUNCH();
+    return WESUP_OK;
+}
+
+// ------------------------------------------------------------------ misc
+extern "C" int wesup_abi_version(void) { return 1; }
+extern "C" const char* wesup_strerror(int code) {
+    switch (code) {
+        case WESUP_OK: return "ok";
+        case WESUP_ERR_INVALID: return "invalid argument (shape, alignment or null pointer)";
+        case WESUP_ERR_LAUNCH: return "HIP kernel launch failed";
+        case WESUP_ERR_WORKSPACE: return "workspace too small";
+        default: return "unknown error";
+    }
+}

@@ -1,0 +1,287 @@
+// Memory-bound NHWC helpers: input / weight packing, 2x2 max-pool fwd/bwd, bilinear (align_corners)
+// upsample fwd and its gather-form backward (optionally fused with the superpixel-pooling backward).
+// All of them move 16 B per lane along the channel axis (coalesced), no atomics, deterministic.
+#include "common.hpp"
+
+// ------------------------------------------------------------------ input packing
+__global__ void pack_input_kernel(const float* __restrict__ img, float* __restrict__ out, int B, long HW) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= B * HW) return;
+    const long b = idx / HW, p = idx - b * HW;
+    const float* s = img + b * 3 * HW + p;
+    st4(out + idx * 4, make_float4(s[0], s[HW], s[2 * HW], 0.f));
+}
+extern "C" int wesup_pack_input(const float* img, float* out, int B, int H, int W, void* stream) {
+    if (!img || !out || B <= 0 || H <= 0 || W <= 0) return WESUP_ERR_INVALID;
+    const long tot = (long)B * H * W;
+    hipLaunchKernelGGL(pack_input_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, img,
+                       out, B, (long)H * W);
+    WESUP_CHECK_LAUNCH();
+    return WESUP_OK;
+}
+
+// ------------------------------------------------------------------ conv weight packing
+// w_fwd[co][t*Cip + ci]  (lanes along ci)
+__global__ void pack_w_fwd_kernel(const float* __restrict__ w, float* __restrict__ wf, int Co, int Ci, int Cip, int Kf) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)Co * Cip) return;
+    const int co = idx / Cip, ci = idx - (long)co * Cip;
+    float* d = wf + (long)co * Kf + ci;
+    if (ci < Ci) {
+        const float* s = w + ((long)co * Ci + ci) * 9;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) d[t * Cip] = s[t];
+    } else {
+#pragma unroll
+        for (int t = 0; t < 9; ++t) d[t * Cip] = 0.f;
+    }
+    // zero the K padding (only exists when 9*Cip is not a multiple of 32, i.e. the image layer)
+    if (ci == 0)
+        for (int k = 9 * Cip; k < Kf; ++k) wf[(long)co * Kf + k] = 0.f;
+}
+// w_dgrad[ci][(8-t)*Co + co]  (lanes along co)
+__global__ void pack_w_dgrad_kernel(const float* __restrict__ w, float* __restrict__ wd, int Co, int Ci) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)Co * Ci) return;
+    const int ci = idx / Co, co = idx - (long)ci * Co;
+    const float* s = w + ((long)co * Ci + ci) * 9;
+    float* d = wd + (long)ci * 9 * Co + co;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) d[(8 - t) * Co] = s[t];
+}
+extern "C" int wesup_pack_conv3x3_weight(const float* w, float* w_fwd, float* w_dgrad, int Co, int Ci, void* stream) {
+    if (!w || !w_fwd || Co <= 0 || Ci <= 0) return WESUP_ERR_INVALID;
+    const int Cip = Ci < 4 ? 4 : Ci;
+    const int Kf = wesup_conv3x3_kpad(Ci);
+    hipStream_t st = (hipStream_t)stream;
+    long tot = (long)Co * Cip;
+    hipLaunchKernelGGL(pack_w_fwd_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, w, w_fwd, Co, Ci, Cip, Kf);
+    if (w_dgrad) {
+        tot = (long)Co * Ci;
+        hipLaunchKernelGGL(pack_w_dgrad_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, w, w_dgrad, Co, Ci);
+    }
+    WESUP_CHECK_LAUNCH();
+    return WESUP_OK;
+}
+
+// ------------------------------------------------------------------ transpose (weights for dgrad GEMMs)
+__global__ void transpose_kernel(const float* __restrict__ in, float* __restrict__ out, int rows, int cols) {
+    __shared__ float t[32][33];
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;     // 256 threads: ty 0..7
+    for (int k = ty; k < 32; k += 8) {
+        const int r = r0 + k, c = c0 + tx;
+        t[k][tx] = (r < rows && c < cols) ? in[(long)r * cols + c] : 0.f;
+    }
+    __syncthreads();
+    for (int k = ty; k < 32; k += 8) {
+        const int c = c0 + k, r = r0 + tx;
+        if (r < rows && c < cols) out[(long)c * rows + r] = t[tx][k];
+    }
+}
+extern "C" int wesup_transpose(const float* in, float* out, int rows, int cols, void* stream) {
+    if (!in || !out || rows <= 0 || cols <= 0) return WESUP_ERR_INVALID;
+    hipLaunchKernelGGL(transpose_kernel, dim3(ceil_div(cols, 32), ceil_div(rows, 32)), dim3(256), 0,
+                       (hipStream_t)stream, in, out, rows, cols);
+    WESUP_CHECK_LAUNCH();
+    return WESUP_OK;
+}
+
+// ------------------------------------------------------------------ 2x2 max pool on pre-ReLU values
+__device__ __forceinline__ float4 max4(float4 a, float4 b) {
+    return make_float4(fmaxf(a.x, b.x), fmaxf(a.y, b.y), fmaxf(a.z, b.z), fmaxf(a.w, b.w));
+}
+__global__ void maxpool_fwd_kernel(const float* __restrict__ y, float* __restrict__ yp, int B, int H, int W, int C4) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int Ho = H >> 1, Wo = W >> 1;
+    if (idx >= (long)B * Ho * Wo * C4) return;
+    const int c = idx % C4;
+    long t = idx / C4;
+    const int xo = t % Wo;
+    t /= Wo;
+    const int yo = t % Ho;
+    const int b = t / Ho;
+    const float* s = y + (((long)b * H + 2 * yo) * W + 2 * xo) * C4 * 4 + 4 * c;
+    const long rs = (long)W * C4 * 4;
+    const float4 v = max4(max4(ld4(s), ld4(s + C4 * 4)), max4(ld4(s + rs), ld4(s + rs + C4 * 4)));
+    st4(yp + idx * 4, v);
+}
+extern "C" int wesup_maxpool2_fwd(const float* y, float* yp, int B, int H, int W, int C, void* stream) {
+    if (!y || !yp || B <= 0 || H < 2 || W < 2 || (C % 4)) return WESUP_ERR_INVALID;
+    const long tot = (long)B * (H / 2) * (W / 2) * (C / 4);
+    hipLaunchKernelGGL(maxpool_fwd_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, y, yp,
+                       B, H, W, C / 4);
+    WESUP_CHECK_LAUNCH();
+    return WESUP_OK;
+}
+
+// backward through ReLU -> MaxPool(2,2): the gradient goes to the FIRST maximum of the window (torch scan
+// order: (0,0),(0,1),(1,0),(1,1)) and only if that maximum is positive (ReLU).  Pixels of an odd trailing
+// row/column belong to no window and get 0.
+__global__ void maxpool_bwd_kernel(const float* __restrict__ y, const float* __restrict__ dyp, float* __restrict__ dy,
+                                   int B, int H, int W, int C4, int accumulate) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)B * H * W * C4) return;
+    const int c = idx % C4;
+    long t = idx / C4;
+    const int x = t % W;
+    t /= W;
+    const int yy = t % H;
+    const int b = t / H;
+    const int Ho = H >> 1, Wo = W >> 1;
+    const int yo = yy >> 1, xo = x >> 1;
+    float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (yo < Ho && xo < Wo) {
+        const float* s = y + (((long)b * H + 2 * yo) * W + 2 * xo) * C4 * 4 + 4 * c;
+        const long rs = (long)W * C4 * 4;
+        const float4 v0 = ld4(s), v1 = ld4(s + C4 * 4), v2 = ld4(s + rs), v3 = ld4(s + rs + C4 * 4);
+        const float4 d = ld4(dyp + ((((long)b * Ho + yo) * Wo + xo) * C4 + c) * 4);
+        const int me = (yy & 1) * 2 + (x & 1);
+        const float a0[4] = {v0.x, v1.x, v2.x, v3.x}, a1[4] = {v0.y, v1.y, v2.y, v3.y};
+        const float a2[4] = {v0.z, v1.z, v2.z, v3.z}, a3[4] = {v0.w, v1.w, v2.w, v3.w};
+        auto pick = [&](const float* a, float dv) {
+            int best = 0;
+            float m = a[0];
+#pragma unroll
+            for (int k = 1; k < 4; ++k)
+                if (a[k] > m) { m = a[k]; best = k; }
+            return (best == me && m > 0.f) ? dv : 0.f;
+        };
+        g = make_float4(pick(a0, d.x), pick(a1, d.y), pick(a2, d.z), pick(a3, d.w));
+    }
+    float* o = dy + idx * 4;
+    if (accumulate) {
+        const float4 old = ld4(o);
+        g = make_float4(g.x + old.x, g.y + old.y, g.z + old.z, g.w + old.w);
+    }
+    st4(o, g);
+}
+extern "C" int wesup_maxpool2_bwd(const float* y, const float* dyp, float* dy, int B, int H, int W, int C,
+                                  int accumulate, void* stream) {
+    if (!y || !dyp || !dy || B <= 0 || H < 2 || W < 2 || (C % 4)) return WESUP_ERR_INVALID;
+    const long tot = (long)B * H * W * (C / 4);
+    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, y, dyp,
+                       dy, B, H, W, C / 4, accumulate);
+    WESUP_CHECK_LAUNCH();
+    return WESUP_OK;
+}
+
+// ------------------------------------------------------------------ bilinear, align_corners=True
+// torch: scale = (in-1)/(out-1) (float); src = scale*dst; i0 = min(int(src), in-1); i1 = i0 + (i0 < in-1);
+// l1 = clamp(src - i0, 0, 1); l0 = 1 - l1.
+struct Lerp {
+    int i0, i1;
+    float l0, l1;
+};
+__device__ __forceinline__ Lerp lerp_of(int dst, float scale, int in) {
+    Lerp r;
+    const float src = scale * (float)dst;
+    r.i0 = min((int)src, in - 1);
+    r.i1 = r.i0 + ((r.i0 < in - 1) ? 1 : 0);
+    r.l1 = fminf(fmaxf(src - (float)r.i0, 0.f), 1.f);
+    r.l0 = 1.f - r.l1;
+    return r;
+}
+static inline float ac_scale(int in, int out) { return out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f; }
+
+__global__ void upsample_fwd_kernel(const float* __restrict__ s, float* __restrict__ fm, int B, int h, int w, int H,
+                                    int W, int C4, int ldf, int coff, float sh, float sw) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)B * H * W * C4) return;
+    const int c = idx % C4;
+    long t = idx / C4;
+    const int X = t % W;
+    t /= W;
+    const int Y = t % H;
+    const int b = t / H;
+    const Lerp ly = lerp_of(Y, sh, h), lx = lerp_of(X, sw, w);
+    const float* base = s + (long)b * h * w * C4 * 4 + 4 * c;
+    const float4 v00 = ld4(base + ((long)ly.i0 * w + lx.i0) * C4 * 4);
+    const float4 v01 = ld4(base + ((long)ly.i0 * w + lx.i1) * C4 * 4);
+    const float4 v10 = ld4(base + ((long)ly.i1 * w + lx.i0) * C4 * 4);
+    const float4 v11 = ld4(base + ((long)ly.i1 * w + lx.i1) * C4 * 4);
+    float4 o;
+    o.x = ly.l0 * (lx.l0 * v00.x + lx.l1 * v01.x) + ly.l1 * (lx.l0 * v10.x + lx.l1 * v11.x);
+    o.y = ly.l0 * (lx.l0 * v00.y + lx.l1 * v01.y) + ly.l1 * (lx.l0 * v10.y + lx.l1 * v11.y);
+    o.z = ly.l0 * (lx.l0 * v00.z + lx.l1 * v01.z) + ly.l1 * (lx.l0 * v10.z + lx.l1 * v11.z);
+    o.w = ly.l0 * (lx.l0 * v00.w + lx.l1 * v01.w) + ly.l1 * (lx.l0 * v10.w + lx.l1 * v11.w);
+    st4(fm + (((long)b * H + Y) * W + X) * ldf + coff + 4 * c, o);
+}
+extern "C" int wesup_upsample_fwd(const float* s, float* fm, int B, int h, int w, int H, int W, int C, int ldf,
+                                  int coff, void* stream) {
+    if (!s || !fm || B <= 0 || h <= 0 || w <= 0 || H <= 0 || W <= 0 || (C % 4) || (ldf % 4) || (coff % 4))
+        return WESUP_ERR_INVALID;
+    const long tot = (long)B * H * W * (C / 4);
+    hipLaunchKernelGGL(upsample_fwd_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, s, fm,
+                       B, h, w, H, W, C / 4, ldf, coff, ac_scale(h, H), ac_scale(w, W));
+    WESUP_CHECK_LAUNCH();
+    return WESUP_OK;
+}
+
+// Gather-form backward: one thread per (low-res pixel q, channel quad) sums over the full-res pixels whose
+// interpolation touches q, in raster order (deterministic).  The candidate window is a safe superset; the
+// weight is recomputed with the exact forward formula, so a candidate that does not touch q contributes 0.
+template <bool FUSED>
+__global__ void upsample_bwd_kernel(const float* __restrict__ src, const int32_t* __restrict__ new_row,
+                                    const int32_t* __restrict__ area, float* __restrict__ ds, int B, int h, int w,
+                                    int H, int W, int C4, int ldf, int coff, int Kmax, float sh, float sw) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)B * h * w * C4) return;
+    const int c = idx % C4;
+    long t = idx / C4;
+    const int qx = t % w;
+    t /= w;
+    const int qy = t % h;
+    const int b = t / h;
+    int Ylo = 0, Yhi = H - 1, Xlo = 0, Xhi = W - 1;
+    if (sh > 0.f) {
+        Ylo = max(0, (int)floorf((float)(qy - 1) / sh) - 1);
+        Yhi = min(H - 1, (int)ceilf((float)(qy + 1) / sh) + 1);
+    }
+    if (sw > 0.f) {
+        Xlo = max(0, (int)floorf((float)(qx - 1) / sw) - 1);
+        Xhi = min(W - 1, (int)ceilf((float)(qx + 1) / sw) + 1);
+    }
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int Y = Ylo; Y <= Yhi; ++Y) {
+        const Lerp ly = lerp_of(Y, sh, h);
+        const float wy = (ly.i0 == qy ? ly.l0 : 0.f) + (ly.i1 == qy ? ly.l1 : 0.f);
+        if (wy == 0.f) continue;
+        for (int X = Xlo; X <= Xhi; ++X) {
+            const Lerp lx = lerp_of(X, sw, w);
+            const float wx = (lx.i0 == qx ? lx.l0 : 0.f) + (lx.i1 == qx ? lx.l1 : 0.f);
+            if (wx == 0.f) continue;
+            const long p = (long)Y * W + X;
+            float wgt = wy * wx;
+            float4 v;
+            if (FUSED) {
+                const int r = new_row[(long)b * H * W + p];
+                wgt *= 1.f / (float)area[(long)b * Kmax + r];
+                v = ld4(src + ((long)b * Kmax + r) * ldf + coff + 4 * c);
+            } else {
+                v = ld4(src + ((long)b * H * W + p) * ldf + coff + 4 * c);
+            }
+            acc.x += wgt * v.x;
+            acc.y += wgt * v.y;
+            acc.z += wgt * v.z;
+            acc.w += wgt * v.w;
+        }
+    }
+    st4(ds + idx * 4, acc);
+}
+extern "C" int wesup_upsample_bwd(const float* dfm_or_g, const int32_t* new_row, const int32_t* area_new, float* ds,
+                                  int B, int h, int w, int H, int W, int C, int ldf, int coff, int Kmax, void* stream) {
+    if (!dfm_or_g || !ds || B <= 0 || h <= 0 || w <= 0 || H <= 0 || W <= 0 || (C % 4) || (ldf % 4) || (coff % 4))
+        return WESUP_ERR_INVALID;
+    if (new_row && (!area_new || Kmax <= 0)) return WESUP_ERR_INVALID;
+    const long tot = (long)B * h * w * (C / 4);
+    const dim3 grid((unsigned)((tot + 255) / 256));
+    if (new_row)
+        hipLaunchKernelGGL(upsample_bwd_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, dfm_or_g, new_row, area_new,
+                           ds, B, h, w, H, W, C / 4, ldf, coff, Kmax, ac_scale(h, H), ac_scale(w, W));
+    else
+        hipLaunchKernelGGL(upsample_bwd_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, dfm_or_g, new_row, area_new,
+                           ds, B, h, w, H, W, C / 4, ldf, coff, Kmax, ac_scale(h, H), ac_scale(w, W));
+    WESUP_CHECK_LAUNCH();
+    return WESUP_OK;
+}

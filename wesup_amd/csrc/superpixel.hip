@@ -1,0 +1,357 @@
+// Superpixel kernels: preprocessing from the label map (histograms, reference ordering, a stable counting
+// sort of the pixels by superpixel), the scatter-mean pooling forward (row gather, HBM-bound) and backward,
+// paint-back, and the dense-sp_maps compatibility argmax.
+//
+// Feature maps are PIXEL-major ([B][HW][ldf], 2112 fp32 channels contiguous per pixel), so the scatter-mean
+// of models/wesup.py:283-285 becomes a gather of whole 8448-byte rows through the sorted pixel list: every
+// load instruction of a wave is 1 KiB contiguous, there are no atomics, and the summation order is fixed
+// (ascending pixel index), so results are bitwise reproducible.
+#include "common.hpp"
+
+#define SP_CHUNK 2048            // pixels per counting-sort chunk
+#define SP_MAX_K 16384           // LDS histogram capacity (ids per image)
+
+// ------------------------------------------------------------------ 1. per-chunk histograms (+ class counts)
+__global__ void sp_hist_kernel(const int32_t* __restrict__ labels, const uint8_t* __restrict__ mask, int HW, int C,
+                               int Kmax, int nchunk, int32_t* __restrict__ chunk_hist, int32_t* __restrict__ cnt,
+                               int32_t* __restrict__ nmax, int32_t* __restrict__ status) {
+    extern __shared__ int32_t hist[];
+    const int b = blockIdx.y, g = blockIdx.x;
+    for (int i = threadIdx.x; i < Kmax; i += blockDim.x) hist[i] = 0;
+    __syncthreads();
+    const int p0 = g * SP_CHUNK, p1 = min(HW, p0 + SP_CHUNK);
+    int lmax = 0;
+    for (int p = p0 + threadIdx.x; p < p1; p += blockDim.x) {
+        const int l = labels[(long)b * HW + p];
+        if (l < 0 || l >= Kmax) {
+            atomicOr(&status[b], 1);
+            continue;
+        }
+        atomicAdd(&hist[l], 1);
+        lmax = max(lmax, l + 1);
+        if (mask) {
+            for (int c = 0; c < C; ++c)
+                if (mask[((long)b * C + c) * HW + p]) atomicAdd(&cnt[((long)b * Kmax + l) * C + c], 1);
+        }
+    }
+    if (lmax) atomicMax(&nmax[b], lmax);
+    __syncthreads();
+    int32_t* out = chunk_hist + ((long)b * nchunk + g) * Kmax;
+    for (int i = threadIdx.x; i < Kmax; i += blockDim.x) out[i] = hist[i];
+}
+
+// block-wide exclusive scan of one int per thread (1024 threads); returns the exclusive prefix, total in *total
+__device__ int block_excl_scan(int v, int* total, int* sh /*[1024]*/) {
+    const int tid = threadIdx.x;
+    sh[tid] = v;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        const int t = (tid >= off) ? sh[tid - off] : 0;
+        __syncthreads();
+        sh[tid] += t;
+        __syncthreads();
+    }
+    const int incl = sh[tid];
+    *total = sh[1023];
+    __syncthreads();
+    return incl - v;
+}
+
+// ------------------------------------------------------------------ 2. ordering (one block per image)
+// rows: labelled ids ascending, then unlabelled ids ascending (models/wesup.py:45-47); label = multi-hot
+// of the classes whose pixel count equals the row maximum (models/wesup.py:50-52, integer form).
+__global__ __launch_bounds__(1024) void sp_order_kernel(const int32_t* __restrict__ chunk_hist,
+                                                        const int32_t* __restrict__ cnt, const int32_t* __restrict__ nmax,
+                                                        int nchunk, int C, int Kmax, int HW, int has_mask,
+                                                        int32_t* __restrict__ n_sp, int32_t* __restrict__ n_l,
+                                                        int32_t* __restrict__ perm, int32_t* __restrict__ inv_perm,
+                                                        int32_t* __restrict__ area_new, float* __restrict__ sp_labels,
+                                                        int32_t* __restrict__ row_start, int32_t* __restrict__ area_old,
+                                                        int32_t* __restrict__ status) {
+    __shared__ int sh[1024];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int n = min(nmax[b], Kmax);
+    const int per = (Kmax + 1023) / 1024;
+    const int i0 = tid * per, i1 = min(Kmax, i0 + per);
+    // areas by old id (sum of chunk histograms)
+    int nlab = 0;
+    bool empty = false;
+    for (int i = i0; i < i1; ++i) {
+        int a = 0;
+        for (int g = 0; g < nchunk; ++g) a += chunk_hist[((long)b * nchunk + g) * Kmax + i];
+        area_old[(long)b * Kmax + i] = a;
+        if (i < n) {
+            if (a == 0) empty = true;
+            int s = 0;
+            if (has_mask)
+                for (int c = 0; c < C; ++c) s += cnt[((long)b * Kmax + i) * C + c];
+            if (s > 0) ++nlab;
+        }
+    }
+    if (empty) atomicOr(&status[b], 2);
+    int total_l;
+    const int pre_l = block_excl_scan(nlab, &total_l, sh);
+    // second pass: assign rows
+    int rl = pre_l, ru = total_l + (min(i0, n) - pre_l);
+    for (int i = i0; i < i1; ++i) {
+        int row;
+        if (i < n) {
+            int s = 0, mx = 0;
+            if (has_mask)
+                for (int c = 0; c < C; ++c) {
+                    const int v = cnt[((long)b * Kmax + i) * C + c];
+                    s += v;
+                    mx = max(mx, v);
+                }
+            if (s > 0) {
+                row = rl++;
+                for (int c = 0; c < C; ++c)
+                    sp_labels[((long)b * Kmax + row) * C + c] = (cnt[((long)b * Kmax + i) * C + c] == mx) ? 1.f : 0.f;
+            } else {
+                row = ru++;
+                for (int c = 0; c < C; ++c) sp_labels[((long)b * Kmax + row) * C + c] = 0.f;
+            }
+        } else {
+            row = i;      // padding rows keep their place, area 0
+            for (int c = 0; c < C; ++c) sp_labels[((long)b * Kmax + row) * C + c] = 0.f;
+        }
+        perm[(long)b * Kmax + row] = i;
+        inv_perm[(long)b * Kmax + i] = row;
+        area_new[(long)b * Kmax + row] = area_old[(long)b * Kmax + i];
+    }
+    if (tid == 0) {
+        n_sp[b] = n;
+        n_l[b] = total_l;
+    }
+    __syncthreads();
+    // row_start = exclusive scan of area_new over rows
+    int asum = 0;
+    for (int r = i0; r < i1; ++r) asum += area_new[(long)b * Kmax + r];
+    int tot;
+    int pre = block_excl_scan(asum, &tot, sh);
+    for (int r = i0; r < i1; ++r) {
+        row_start[(long)b * (Kmax + 1) + r] = pre;
+        pre += area_new[(long)b * Kmax + r];
+    }
+    if (tid == 1023) row_start[(long)b * (Kmax + 1) + Kmax] = tot;
+}
+
+// ------------------------------------------------------------------ 3. chunk bases: where chunk g starts inside each row
+__global__ void sp_chunk_base_kernel(int32_t* __restrict__ chunk_hist, const int32_t* __restrict__ inv_perm,
+                                     const int32_t* __restrict__ row_start, int nchunk, int Kmax) {
+    const int b = blockIdx.y;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= Kmax) return;
+    int run = row_start[(long)b * (Kmax + 1) + inv_perm[(long)b * Kmax + i]];
+    for (int g = 0; g < nchunk; ++g) {
+        int32_t* h = chunk_hist + ((long)b * nchunk + g) * Kmax + i;
+        const int v = *h;
+        *h = run;
+        run += v;
+    }
+}
+
+// ------------------------------------------------------------------ 4. stable placement: one wave per chunk
+__global__ __launch_bounds__(64) void sp_place_kernel(const int32_t* __restrict__ labels,
+                                                      const int32_t* __restrict__ chunk_base,
+                                                      const int32_t* __restrict__ inv_perm, int HW, int Kmax, int nchunk,
+                                                      int32_t* __restrict__ pix_sorted, int32_t* __restrict__ new_row) {
+    extern __shared__ int32_t cntl[];
+    const int b = blockIdx.y, g = blockIdx.x, lane = threadIdx.x;
+    for (int i = lane; i < Kmax; i += 64) cntl[i] = 0;
+    __syncthreads();
+    const int32_t* base = chunk_base + ((long)b * nchunk + g) * Kmax;
+    const int p0 = g * SP_CHUNK, p1 = min(HW, p0 + SP_CHUNK);
+    for (int s = p0; s < p1; s += 64) {
+        const int p = s + lane;
+        int l = (p < p1) ? labels[(long)b * HW + p] : -1;
+        if (l >= Kmax) l = -1;
+        unsigned long long rem = __ballot(l >= 0);
+        int pos = -1;
+        while (rem) {
+            const int leader = __ffsll((long long)rem) - 1;
+            const int ll = __shfl(l, leader);
+            const unsigned long long m = __ballot(l == ll);
+            if (l == ll) pos = base[ll] + cntl[ll] + __popcll(m & ((1ull << lane) - 1ull));
+            __syncthreads();
+            if (lane == leader) cntl[ll] += __popcll(m);
+            __syncthreads();
+            rem &= ~m;
+        }
+        if (l >= 0) {
+            pix_sorted[(long)b * HW + pos] = p;
+            new_row[(long)b * HW + p] = inv_perm[(long)b * Kmax + l];
+        } else if (p < p1) {
+            new_row[(long)b * HW + p] = 0;
+        }
+    }
+}
+
+extern "C" size_t wesup_sp_preprocess_workspace_bytes(int B, int HW, int C, int Kmax) {
+    if (B <= 0 || HW <= 0 || Kmax <= 0) return 0;
+    const size_t nchunk = (HW + SP_CHUNK - 1) / SP_CHUNK;
+    size_t bytes = align_up((size_t)B * nchunk * Kmax * 4, 256);     // chunk_hist / chunk_base
+    bytes += align_up((size_t)B * Kmax * (C > 0 ? C : 1) * 4, 256);  // cnt
+    bytes += align_up((size_t)B * Kmax * 4, 256);                     // area by old id
+    bytes += align_up((size_t)B * 4, 256);                            // nmax
+    return bytes;
+}
+
+extern "C" int wesup_sp_preprocess(const int32_t* labels, const uint8_t* mask, int B, int HW, int C, int Kmax,
+                                   int32_t* n_sp, int32_t* n_l, int32_t* perm, int32_t* inv_perm, int32_t* area_new,
+                                   float* sp_labels, int32_t* new_row, int32_t* row_start, int32_t* pix_sorted,
+                                   int32_t* status, void* ws, size_t ws_bytes, void* stream) {
+    if (!labels || !n_sp || !n_l || !perm || !inv_perm || !area_new || !sp_labels || !new_row || !row_start ||
+        !pix_sorted || !status || !ws)
+        return WESUP_ERR_INVALID;
+    if (B <= 0 || HW <= 0 || C <= 0 || Kmax <= 0 || Kmax > SP_MAX_K) return WESUP_ERR_INVALID;
+    if (ws_bytes < wesup_sp_preprocess_workspace_bytes(B, HW, C, Kmax)) return WESUP_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    const int nchunk = (HW + SP_CHUNK - 1) / SP_CHUNK;
+    char* w = (char*)ws;
+    int32_t* chunk_hist = (int32_t*)w;
+    w += align_up((size_t)B * nchunk * Kmax * 4, 256);
+    int32_t* cnt = (int32_t*)w;
+    const size_t cnt_bytes = align_up((size_t)B * Kmax * C * 4, 256);
+    w += cnt_bytes;
+    int32_t* area_old = (int32_t*)w;
+    w += align_up((size_t)B * Kmax * 4, 256);
+    int32_t* nmax = (int32_t*)w;
+    if (hipMemsetAsync(cnt, 0, cnt_bytes, st) != hipSuccess) return WESUP_ERR_LAUNCH;
+    if (hipMemsetAsync(nmax, 0, align_up((size_t)B * 4, 256), st) != hipSuccess) return WESUP_ERR_LAUNCH;
+    if (hipMemsetAsync(status, 0, (size_t)B * 4, st) != hipSuccess) return WESUP_ERR_LAUNCH;
+    hipLaunchKernelGGL(sp_hist_kernel, dim3(nchunk, B), dim3(256), (size_t)Kmax * 4, st, labels, mask, HW, C, Kmax, nchunk,
+                       chunk_hist, cnt, nmax, status);
+    hipLaunchKernelGGL(sp_order_kernel, dim3(B), dim3(1024), 0, st, chunk_hist, cnt, nmax, nchunk, C, Kmax, HW,
+                       mask ? 1 : 0, n_sp, n_l, perm, inv_perm, area_new, sp_labels, row_start, area_old, status);
+    hipLaunchKernelGGL(sp_chunk_base_kernel, dim3(ceil_div(Kmax, 256), B), dim3(256), 0, st, chunk_hist, inv_perm,
+                       row_start, nchunk, Kmax);
+    hipLaunchKernelGGL(sp_place_kernel, dim3(nchunk, B), dim3(64), (size_t)Kmax * 4, st, labels, chunk_hist, inv_perm, HW,
+                       Kmax, nchunk, pix_sorted, new_row);
+    WESUP_CHECK_LAUNCH();
+    return WESUP_OK;
+}
+
+// ------------------------------------------------------------------ dense compat: labels from (N,H,W) maps
+__global__ void spmaps_argmax_kernel(const float* __restrict__ maps, int32_t* __restrict__ labels, int N, long HW) {
+    const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= HW) return;
+    float best = maps[p];
+    int bi = 0;
+    for (int n = 1; n < N; ++n) {
+        const float v = maps[(long)n * HW + p];
+        if (v > best) { best = v; bi = n; }
+    }
+    labels[p] = bi;
+}
+extern "C" int wesup_spmaps_to_labels(const float* sp_maps, int32_t* labels, int N, int HW, void* stream) {
+    if (!sp_maps || !labels || N <= 0 || HW <= 0) return WESUP_ERR_INVALID;
+    hipLaunchKernelGGL(spmaps_argmax_kernel, dim3((HW + 255) / 256), dim3(256), 0, (hipStream_t)stream, sp_maps, labels, N,
+                       (long)HW);
+    WESUP_CHECK_LAUNCH();
+    return WESUP_OK;
+}
+
+// ------------------------------------------------------------------ scatter-mean forward
+// One wave per (row, 256-channel slab): lane owns 4 channels, walks the row's pixel list 8 pixels per
+// iteration (8 x 1 KiB loads in flight per wave), acc = fma(v, 1/area, acc) as the reference's pre-normalised
+// GEMM does.  Algorithmic bytes per image: C*HW*4 (features) + HW*4 (pixel list) + N*C*4 (output).
+#define POOL_UNROLL 8
+__global__ __launch_bounds__(256) void sp_pool_fwd_kernel(const float* __restrict__ fm,
+                                                          const int32_t* __restrict__ pix_sorted,
+                                                          const int32_t* __restrict__ row_start,
+                                                          float* __restrict__ sp_feat, int HW, int ldf, int C, int Kmax,
+                                                          int nslab, int units_per_img) {
+    const int b = blockIdx.y;
+    // wave-uniform unit id -> row bounds and pixel indices live in SGPRs (scalar loads)
+    const int unit = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (unit >= units_per_img) return;
+    const int lane = threadIdx.x & 63;
+    const int r = unit / nslab, slab = unit - r * nslab;
+    const int c = slab * 256 + 4 * lane;
+    if (c >= C) return;
+    const int j0 = row_start[(long)b * (Kmax + 1) + r], j1 = row_start[(long)b * (Kmax + 1) + r + 1];
+    const float inv = (j1 > j0) ? 1.f / (float)(j1 - j0) : 0.f;
+    const int32_t* list = pix_sorted + (long)b * HW;
+    const float* base = fm + (long)b * HW * ldf + c;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    int j = j0;
+    for (; j + POOL_UNROLL <= j1; j += POOL_UNROLL) {
+        int pix[POOL_UNROLL];
+#pragma unroll
+        for (int u = 0; u < POOL_UNROLL; ++u) pix[u] = list[j + u];
+        float4 v[POOL_UNROLL];
+#pragma unroll
+        for (int u = 0; u < POOL_UNROLL; ++u) v[u] = ld4(base + (long)pix[u] * ldf);
+#pragma unroll
+        for (int u = 0; u < POOL_UNROLL; ++u) {
+            acc.x = fmaf(v[u].x, inv, acc.x);
+            acc.y = fmaf(v[u].y, inv, acc.y);
+            acc.z = fmaf(v[u].z, inv, acc.z);
+            acc.w = fmaf(v[u].w, inv, acc.w);
+        }
+    }
+    for (; j < j1; ++j) {
+        const float4 v = ld4(base + (long)list[j] * ldf);
+        acc.x = fmaf(v.x, inv, acc.x);
+        acc.y = fmaf(v.y, inv, acc.y);
+        acc.z = fmaf(v.z, inv, acc.z);
+        acc.w = fmaf(v.w, inv, acc.w);
+    }
+    st4(sp_feat + ((long)b * Kmax + r) * C + c, acc);
+}
+extern "C" int wesup_sp_pool_fwd(const float* fm, const int32_t* pix_sorted, const int32_t* row_start, float* sp_feat,
+                                 int B, int HW, int ldf, int C, int Kmax, void* stream) {
+    if (!fm || !pix_sorted || !row_start || !sp_feat || B <= 0 || HW <= 0 || Kmax <= 0 || (C % 4) || (ldf % 4) || C > ldf)
+        return WESUP_ERR_INVALID;
+    const int nslab = ceil_div(C, 256);
+    const int units = Kmax * nslab;
+    hipLaunchKernelGGL(sp_pool_fwd_kernel, dim3(ceil_div(units, 4), B), dim3(256), 0, (hipStream_t)stream, fm, pix_sorted,
+                       row_start, sp_feat, HW, ldf, C, Kmax, nslab, units);
+    WESUP_CHECK_LAUNCH();
+    return WESUP_OK;
+}
+
+// ------------------------------------------------------------------ scatter-mean backward (row broadcast)
+__global__ void sp_pool_bwd_kernel(const float* __restrict__ g, const int32_t* __restrict__ new_row,
+                                   const int32_t* __restrict__ area, float* __restrict__ dfm, long HW, int ldf, int C4,
+                                   int Kmax, long total) {
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int c = idx % C4;
+        const long bp = idx / C4;              // b*HW + p
+        const long b = bp / HW;
+        const int r = new_row[bp];
+        const float inv = 1.f / (float)area[b * Kmax + r];
+        const float4 v = ld4(g + (b * Kmax + r) * (long)(C4 * 4) + 4 * c);
+        st4(dfm + bp * ldf + 4 * c, make_float4(v.x * inv, v.y * inv, v.z * inv, v.w * inv));
+    }
+}
+extern "C" int wesup_sp_pool_bwd(const float* g, const int32_t* new_row, const int32_t* area_new, float* dfm, int B,
+                                 int HW, int ldf, int C, int Kmax, void* stream) {
+    if (!g || !new_row || !area_new || !dfm || B <= 0 || HW <= 0 || Kmax <= 0 || (C % 4) || (ldf % 4) || C > ldf)
+        return WESUP_ERR_INVALID;
+    const long total = (long)B * HW * (C / 4);
+    const long blocks = (total + 255) / 256;
+    hipLaunchKernelGGL(sp_pool_bwd_kernel, dim3((unsigned)(blocks < 16384 ? blocks : 16384)), dim3(256), 0,
+                       (hipStream_t)stream, g, new_row, area_new, dfm, (long)HW, ldf, C / 4, Kmax, total);
+    WESUP_CHECK_LAUNCH();
+    return WESUP_OK;
+}
+
+// ------------------------------------------------------------------ paint-back
+__global__ void paint_kernel(const float* __restrict__ sp_pred, const int32_t* __restrict__ new_row,
+                             float* __restrict__ pred, long HW, int Kmax, int C, int cls, long total) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const long b = idx / HW;
+    pred[idx] = sp_pred[(b * Kmax + new_row[idx]) * C + cls];
+}
+extern "C" int wesup_paint_fwd(const float* sp_pred, const int32_t* new_row, float* pred, int B, int HW, int Kmax, int C,
+                               int cls, void* stream) {
+    if (!sp_pred || !new_row || !pred || B <= 0 || HW <= 0 || Kmax <= 0 || cls < 0 || cls >= C) return WESUP_ERR_INVALID;
+    const long total = (long)B * HW;
+    hipLaunchKernelGGL(paint_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, sp_pred,
+                       new_row, pred, (long)HW, Kmax, C, cls, total);
+    WESUP_CHECK_LAUNCH();
+    return WESUP_OK;
+}

@@ -1,0 +1,420 @@
+"""Tensor-level wrappers over the C ABI (include/wesup_hip.h).
+
+Each wrapper checks on the HOST that operand shapes/dtypes/devices match what
+the kernel and its grid assume (a faulting kernel can reset the GPU), then calls
+the entry on torch's current stream.  torch is only used for device memory and
+streams here.  No CPU fallback: a CPU tensor raises.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+
+RELU_IN, RELU_OUT, ACCUM, MASK = 1, 2, 4, 8
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _chk(t, dtype=torch.float32, name='tensor'):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise _lib.WesupHipError(f'{name}: expected a CUDA/HIP tensor (the HIP path has no CPU fallback)')
+    if t.dtype != dtype:
+        raise _lib.WesupHipError(f'{name}: expected {dtype}, got {t.dtype}')
+    if not t.is_contiguous():
+        raise _lib.WesupHipError(f'{name}: expected a contiguous tensor')
+    return t
+
+
+def _p(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+_ws_cache = {}
+
+
+def workspace(nbytes, device, tag='default'):
+    """Grow-only byte workspace per (device, tag)."""
+    key = (str(device), tag)
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+        _ws_cache[key] = buf
+    return buf
+
+
+# ---------------------------------------------------------------- packing
+def pack_input(img, out=None):
+    _chk(img, name='img')
+    B, C, H, W = img.shape
+    assert C == 3
+    if out is None:
+        out = torch.empty(B, H, W, 4, dtype=torch.float32, device=img.device)
+    _lib.call('wesup_pack_input', _p(img), _p(out), B, H, W, _stream())
+    return out
+
+
+def conv3x3_kpad(Ci):
+    return _lib.load().wesup_conv3x3_kpad(int(Ci))
+
+
+def pack_conv3x3_weight(w, w_fwd=None, w_dgrad=None, need_dgrad=True):
+    _chk(w, name='w')
+    Co, Ci, kh, kw = w.shape
+    assert kh == 3 and kw == 3
+    if w_fwd is None:
+        w_fwd = torch.empty(Co, conv3x3_kpad(Ci), dtype=torch.float32, device=w.device)
+    if need_dgrad and w_dgrad is None:
+        w_dgrad = torch.empty(Ci, 9 * Co, dtype=torch.float32, device=w.device)
+    _lib.call('wesup_pack_conv3x3_weight', _p(w), _p(w_fwd), _p(w_dgrad) if need_dgrad else None, Co, Ci, _stream())
+    return w_fwd, w_dgrad
+
+
+def transpose(a, out=None):
+    _chk(a, name='a')
+    r, c = a.shape
+    if out is None:
+        out = torch.empty(c, r, dtype=torch.float32, device=a.device)
+    _lib.call('wesup_transpose', _p(a), _p(out), r, c, _stream())
+    return out
+
+
+# ---------------------------------------------------------------- conv 3x3
+def conv3x3_fwd(x, w_fwd, bias, Cout, relu_in, out=None):
+    _chk(x, name='x'); _chk(w_fwd, name='w_fwd')
+    B, H, W, Cin = x.shape
+    assert w_fwd.shape == (Cout, conv3x3_kpad(Cin)), (w_fwd.shape, Cout, Cin)
+    if bias is not None:
+        _chk(bias, name='bias'); assert bias.numel() == Cout
+    if out is None:
+        out = torch.empty(B, H, W, Cout, dtype=torch.float32, device=x.device)
+    assert out.shape == (B, H, W, Cout) and out.is_contiguous()
+    _lib.call('wesup_conv3x3_fwd', _p(x), _p(w_fwd), _p(bias), _p(out), B, H, W, Cin, Cout, int(relu_in), _stream())
+    return out
+
+
+def conv3x3_dgrad(dy, w_dgrad, Cin, mask_src=None, out=None, accumulate=False):
+    _chk(dy, name='dy'); _chk(w_dgrad, name='w_dgrad')
+    B, H, W, Cout = dy.shape
+    assert w_dgrad.shape == (Cin, 9 * Cout)
+    if mask_src is not None:
+        _chk(mask_src, name='mask_src'); assert mask_src.shape == (B, H, W, Cin)
+    if out is None:
+        assert not accumulate
+        out = torch.empty(B, H, W, Cin, dtype=torch.float32, device=dy.device)
+    assert out.shape == (B, H, W, Cin) and out.is_contiguous()
+    _lib.call('wesup_conv3x3_dgrad', _p(dy), _p(w_dgrad), _p(mask_src), _p(out), B, H, W, Cin, Cout, int(accumulate),
+              _stream())
+    return out
+
+
+def conv3x3_wgrad(x, dy, Ci, relu_in, dw=None, db=None):
+    _chk(x, name='x'); _chk(dy, name='dy')
+    B, H, W, Cx = x.shape
+    Cout = dy.shape[3]
+    assert dy.shape[:3] == (B, H, W) and Cx == (4 if Ci == 3 else Ci)
+    if dw is None:
+        dw = torch.empty(Cout, Ci, 3, 3, dtype=torch.float32, device=x.device)
+    if db is None:
+        db = torch.empty(Cout, dtype=torch.float32, device=x.device)
+    assert dw.is_contiguous() and dw.numel() == Cout * Ci * 9 and db.numel() == Cout
+    nb = _lib.load().wesup_conv3x3_wgrad_workspace_bytes(B, H, W, Ci, Cout)
+    ws = workspace(nb, x.device)
+    _lib.call('wesup_conv3x3_wgrad', _p(x), _p(dy), _p(dw), _p(db), B, H, W, Ci, Cout, int(relu_in), _p(ws), nb, _stream())
+    return dw, db
+
+
+# ---------------------------------------------------------------- GEMMs
+def _ld(t):
+    assert t.dim() == 2 and t.stride(1) == 1
+    return t.stride(0)
+
+
+def gemm_nt(A, Bw, bias=None, out=None, mask=None, flags=0):
+    """out[M][N] = epi(A[M][K] @ Bw[N][K]^T + bias).  A/out/mask may be row-strided 2-D views."""
+    for t, n in ((A, 'A'), (Bw, 'B')):
+        if not t.is_cuda or t.dtype != torch.float32:
+            raise _lib.WesupHipError(f'{n}: expected float32 CUDA/HIP tensor')
+    M, K = A.shape
+    N, K2 = Bw.shape
+    assert K == K2 and K % 32 == 0, (A.shape, Bw.shape)
+    if out is None:
+        out = torch.empty(M, N, dtype=torch.float32, device=A.device)
+    assert out.shape == (M, N) and out.is_cuda
+    ldmask = 0
+    if mask is not None:
+        assert mask.shape == (M, N) and mask.is_cuda
+        ldmask = _ld(mask)
+        flags |= MASK
+    if bias is not None:
+        _chk(bias, name='bias'); assert bias.numel() == N
+    _lib.call('wesup_gemm_nt', _p(A), _ld(A), _p(Bw), _ld(Bw), _p(bias), _p(out), _ld(out), _p(mask), ldmask, M, N, K,
+              flags, _stream())
+    return out
+
+
+def gemm_tn(A, Bm, out=None, relu_b=False):
+    """out[M][N] = A[K][M]^T @ Bm[K][N]  (deterministic split-K)."""
+    K, M = A.shape
+    K2, N = Bm.shape
+    assert K == K2 and A.is_cuda and Bm.is_cuda
+    if out is None:
+        out = torch.empty(M, N, dtype=torch.float32, device=A.device)
+    assert out.shape == (M, N)
+    nb = _lib.load().wesup_gemm_tn_workspace_bytes(M, N, K)
+    ws = workspace(nb, A.device)
+    _lib.call('wesup_gemm_tn', _p(A), _ld(A), _p(Bm), _ld(Bm), _p(out), _ld(out), M, N, K, int(relu_b), _p(ws), nb,
+              _stream())
+    return out
+
+
+def colsum(A, out=None):
+    M, N = A.shape
+    assert A.is_cuda
+    if out is None:
+        out = torch.empty(N, dtype=torch.float32, device=A.device)
+    nb = _lib.load().wesup_colsum_workspace_bytes(M, N)
+    ws = workspace(nb, A.device, 'colsum')
+    _lib.call('wesup_colsum', _p(A), _ld(A), _p(out), M, N, _p(ws), nb, _stream())
+    return out
+
+
+# ---------------------------------------------------------------- pooling / upsampling
+def maxpool2_fwd(y, out=None):
+    _chk(y, name='y')
+    B, H, W, C = y.shape
+    if out is None:
+        out = torch.empty(B, H // 2, W // 2, C, dtype=torch.float32, device=y.device)
+    assert out.shape == (B, H // 2, W // 2, C)
+    _lib.call('wesup_maxpool2_fwd', _p(y), _p(out), B, H, W, C, _stream())
+    return out
+
+
+def maxpool2_bwd(y, dyp, dy=None, accumulate=False):
+    _chk(y, name='y'); _chk(dyp, name='dyp')
+    B, H, W, C = y.shape
+    assert dyp.shape == (B, H // 2, W // 2, C)
+    if dy is None:
+        assert not accumulate
+        dy = torch.empty_like(y)
+    assert dy.shape == y.shape and dy.is_contiguous()
+    _lib.call('wesup_maxpool2_bwd', _p(y), _p(dyp), _p(dy), B, H, W, C, int(accumulate), _stream())
+    return dy
+
+
+def upsample_fwd(s, fm, coff):
+    _chk(s, name='s'); _chk(fm, name='fm')
+    B, h, w, C = s.shape
+    B2, H, W, ldf = fm.shape
+    assert B == B2 and coff + C <= ldf
+    _lib.call('wesup_upsample_fwd', _p(s), _p(fm), B, h, w, H, W, C, ldf, coff, _stream())
+    return fm
+
+
+def upsample_bwd(dfm, coff, h, w, C, out=None):
+    _chk(dfm, name='dfm')
+    B, H, W, ldf = dfm.shape
+    assert coff + C <= ldf
+    if out is None:
+        out = torch.empty(B, h, w, C, dtype=torch.float32, device=dfm.device)
+    assert out.shape == (B, h, w, C)
+    _lib.call('wesup_upsample_bwd', _p(dfm), None, None, _p(out), B, h, w, H, W, C, ldf, coff, 0, _stream())
+    return out
+
+
+def upsample_bwd_fused(g, new_row, area_new, H, W, coff, h, w, C, out=None):
+    """pool-backward fused in: reads g[B][Kmax][ldf] through new_row instead of a materialised dfm."""
+    _chk(g, name='g'); _chk(new_row, torch.int32, 'new_row'); _chk(area_new, torch.int32, 'area_new')
+    B, Kmax, ldf = g.shape
+    assert new_row.shape == (B, H * W) and area_new.shape == (B, Kmax) and coff + C <= ldf
+    if out is None:
+        out = torch.empty(B, h, w, C, dtype=torch.float32, device=g.device)
+    assert out.shape == (B, h, w, C)
+    _lib.call('wesup_upsample_bwd', _p(g), _p(new_row), _p(area_new), _p(out), B, h, w, H, W, C, ldf, coff, Kmax, _stream())
+    return out
+
+
+# ---------------------------------------------------------------- superpixels
+class SuperpixelMeta:
+    """Device-side result of wesup_sp_preprocess for a batch of label maps (padded to Kmax rows per image)."""
+    __slots__ = ('B', 'H', 'W', 'C', 'Kmax', 'labels', 'mask', 'n_sp', 'n_l', 'perm', 'inv_perm', 'area_new',
+                 'sp_labels', 'new_row', 'row_start', 'pix_sorted', 'status', 'n_sp_host')
+
+    def check(self):
+        """Host sync: raise on label-map errors the reference would turn into NaNs (models/wesup.py:57-61)."""
+        st = self.status.cpu()
+        if int(st.max()) != 0:
+            bad = [(b, int(v)) for b, v in enumerate(st.tolist()) if v]
+            raise ValueError(f'invalid label map (image, code): {bad}; 1 = id >= Kmax, 2 = empty id below the '
+                             'maximum id (ids must be contiguous 0..K-1)')
+
+
+def sp_preprocess(labels, mask, Kmax, n_classes=2, n_sp_host=None):
+    """labels (B,H,W) int32; mask (B,C,H,W) uint8 or None."""
+    _chk(labels, torch.int32, 'labels')
+    B, H, W = labels.shape
+    HW = H * W
+    dev = labels.device
+    C = n_classes
+    if mask is not None:
+        _chk(mask, torch.uint8, 'mask')
+        assert mask.shape == (B, C, H, W)
+    m = SuperpixelMeta()
+    m.B, m.H, m.W, m.C, m.Kmax = B, H, W, C, int(Kmax)
+    m.labels, m.mask, m.n_sp_host = labels, mask, n_sp_host
+    i32 = dict(dtype=torch.int32, device=dev)
+    m.n_sp = torch.empty(B, **i32); m.n_l = torch.empty(B, **i32)
+    m.perm = torch.empty(B, Kmax, **i32); m.inv_perm = torch.empty(B, Kmax, **i32)
+    m.area_new = torch.empty(B, Kmax, **i32)
+    m.sp_labels = torch.empty(B, Kmax, C, dtype=torch.float32, device=dev)
+    m.new_row = torch.empty(B, HW, **i32); m.row_start = torch.empty(B, Kmax + 1, **i32)
+    m.pix_sorted = torch.empty(B, HW, **i32); m.status = torch.empty(B, **i32)
+    nb = _lib.load().wesup_sp_preprocess_workspace_bytes(B, HW, C, Kmax)
+    ws = workspace(nb, dev, 'sp')
+    _lib.call('wesup_sp_preprocess', _p(labels), _p(mask), B, HW, C, Kmax, _p(m.n_sp), _p(m.n_l), _p(m.perm),
+              _p(m.inv_perm), _p(m.area_new), _p(m.sp_labels), _p(m.new_row), _p(m.row_start), _p(m.pix_sorted),
+              _p(m.status), _p(ws), nb, _stream())
+    return m
+
+
+def spmaps_to_labels(sp_maps):
+    _chk(sp_maps, name='sp_maps')
+    N, H, W = sp_maps.shape
+    labels = torch.empty(1, H, W, dtype=torch.int32, device=sp_maps.device)
+    _lib.call('wesup_spmaps_to_labels', _p(sp_maps), _p(labels), N, H * W, _stream())
+    return labels
+
+
+def sp_pool_fwd(fm, meta, C=None, out=None):
+    _chk(fm, name='fm')
+    B, H, W, ldf = fm.shape
+    C = ldf if C is None else C
+    assert (B, H, W) == (meta.B, meta.H, meta.W)
+    if out is None:
+        out = torch.empty(B, meta.Kmax, C, dtype=torch.float32, device=fm.device)
+    assert out.shape == (B, meta.Kmax, C) and out.is_contiguous()
+    _lib.call('wesup_sp_pool_fwd', _p(fm), _p(meta.pix_sorted), _p(meta.row_start), _p(out), B, H * W, ldf, C, meta.Kmax,
+              _stream())
+    return out
+
+
+def sp_pool_bwd(g, meta, out=None):
+    _chk(g, name='g')
+    B, Kmax, C = g.shape
+    assert B == meta.B and Kmax == meta.Kmax
+    if out is None:
+        out = torch.empty(B, meta.H, meta.W, C, dtype=torch.float32, device=g.device)
+    assert out.shape == (B, meta.H, meta.W, C) and out.is_contiguous()
+    _lib.call('wesup_sp_pool_bwd', _p(g), _p(meta.new_row), _p(meta.area_new), _p(out), B, meta.H * meta.W, C, C, Kmax,
+              _stream())
+    return out
+
+
+def paint_fwd(sp_pred, meta, cls=1, out=None):
+    _chk(sp_pred, name='sp_pred')
+    B, Kmax, C = sp_pred.shape
+    assert B == meta.B and Kmax == meta.Kmax
+    if out is None:
+        out = torch.empty(B, meta.H, meta.W, dtype=torch.float32, device=sp_pred.device)
+    _lib.call('wesup_paint_fwd', _p(sp_pred), _p(meta.new_row), _p(out), B, meta.H * meta.W, Kmax, C, cls, _stream())
+    return out
+
+
+# ---------------------------------------------------------------- head / loss / optimiser
+def classifier_fwd(feat, Wc, bc, out=None):
+    _chk(feat, name='feat'); _chk(Wc, name='Wc'); _chk(bc, name='bc')
+    R, D = feat.shape
+    assert Wc.shape == (2, D) and bc.numel() == 2
+    if out is None:
+        out = torch.empty(R, 2, dtype=torch.float32, device=feat.device)
+    _lib.call('wesup_classifier_fwd', _p(feat), _p(Wc), _p(bc), _p(out), R, D, _stream())
+    return out
+
+
+def classifier_bwd(feat, Wc, pred, dpred, dfeat_extra=None, dfeat=None, dWc=None, dbc=None):
+    _chk(feat, name='feat'); _chk(pred, name='pred'); _chk(dpred, name='dpred')
+    R, D = feat.shape
+    assert pred.shape == (R, 2) and dpred.shape == (R, 2)
+    if dfeat_extra is not None:
+        _chk(dfeat_extra, name='dfeat_extra'); assert dfeat_extra.shape == (R, D)
+    dev = feat.device
+    dfeat = torch.empty(R, D, dtype=torch.float32, device=dev) if dfeat is None else dfeat
+    dWc = torch.empty(2, D, dtype=torch.float32, device=dev) if dWc is None else dWc
+    dbc = torch.empty(2, dtype=torch.float32, device=dev) if dbc is None else dbc
+    nb = _lib.load().wesup_classifier_bwd_workspace_bytes(R, D)
+    ws = workspace(nb, dev, 'cls')
+    _lib.call('wesup_classifier_bwd', _p(feat), _p(Wc), _p(pred), _p(dpred), _p(dfeat_extra), _p(dfeat), _p(dWc), _p(dbc),
+              R, D, _p(ws), nb, _stream())
+    return dfeat, dWc, dbc
+
+
+def propagate(feat, meta, threshold, enable=True):
+    """feat (B,Kmax,D).  Returns y_all (B,Kmax,C), src_idx (B,Kmax) int32, max_sim (B,Kmax)."""
+    _chk(feat, name='feat')
+    B, Kmax, D = feat.shape
+    assert B == meta.B and Kmax == meta.Kmax
+    dev = feat.device
+    y_all = torch.empty(B, Kmax, meta.C, dtype=torch.float32, device=dev)
+    src = torch.empty(B, Kmax, dtype=torch.int32, device=dev)
+    sim = torch.empty(B, Kmax, dtype=torch.float32, device=dev)
+    _lib.call('wesup_propagate', _p(feat), _p(meta.sp_labels), _p(meta.n_sp), _p(meta.n_l), float(threshold), int(enable),
+              _p(y_all), _p(src), _p(sim), B, Kmax, D, meta.C, _stream())
+    return y_all, src, sim
+
+
+def loss_fwd(pred, y_all, meta, eps, prop_weight):
+    _chk(pred, name='pred'); _chk(y_all, name='y_all')
+    B, Kmax, C = pred.shape
+    assert y_all.shape == (B, Kmax, C) and B == meta.B and Kmax == meta.Kmax
+    terms = torch.empty(B, 8, dtype=torch.float32, device=pred.device)
+    loss = torch.empty(1, dtype=torch.float32, device=pred.device)
+    _lib.call('wesup_loss_fwd', _p(pred), _p(y_all), _p(meta.n_sp), _p(meta.n_l), float(eps), float(prop_weight),
+              _p(terms), _p(loss), B, Kmax, C, _stream())
+    return loss, terms
+
+
+def loss_bwd(pred, y_all, meta, terms, dloss, eps, prop_weight, out=None):
+    _chk(dloss, name='dloss')
+    B, Kmax, C = pred.shape
+    if out is None:
+        out = torch.empty_like(pred)
+    _lib.call('wesup_loss_bwd', _p(pred), _p(y_all), _p(meta.n_sp), _p(meta.n_l), _p(terms), _p(dloss), float(eps),
+              float(prop_weight), _p(out), B, Kmax, C, _stream())
+    return out
+
+
+def cross_entropy_fwd(y_hat, y_true, eps):
+    _chk(y_hat, name='y_hat'); _chk(y_true, name='y_true')
+    n, C = y_hat.shape
+    assert y_true.shape == (n, C)
+    out2 = torch.empty(2, dtype=torch.float32, device=y_hat.device)
+    _lib.call('wesup_cross_entropy_fwd', _p(y_hat), _p(y_true), float(eps), _p(out2), n, C, _stream())
+    return out2
+
+
+def cross_entropy_bwd(y_hat, y_true, out2, dloss, eps):
+    n, C = y_hat.shape
+    dy = torch.empty_like(y_hat)
+    if n > 0:
+        _lib.call('wesup_cross_entropy_bwd', _p(y_hat), _p(y_true), _p(out2), _p(dloss), float(eps), _p(dy), n, C, _stream())
+    return dy
+
+
+def sgd_step(p, g, v, lr, momentum, weight_decay, grad_scale, first_step):
+    for t, n in ((p, 'p'), (g, 'g'), (v, 'v')):
+        _chk(t, name=n)
+    assert p.numel() == g.numel() == v.numel()
+    _lib.call('wesup_sgd_step', _p(p), _p(g), _p(v), p.numel(), float(lr), float(momentum), float(weight_decay),
+              float(grad_scale), int(first_step), _stream())
+
+
+def seg_metrics(pred, mask):
+    """pred (B,H,W) f32, mask (B,C,H,W) uint8 -> (B,4) sums {#(P==G), sum(P*G), sum(P), sum(G)}."""
+    _chk(pred, name='pred'); _chk(mask, torch.uint8, 'mask')
+    B, H, W = pred.shape
+    C = mask.shape[1]
+    out = torch.empty(B, 4, dtype=torch.float32, device=pred.device)
+    _lib.call('wesup_seg_metrics', _p(pred), _p(mask), _p(out), B, H * W, C, _stream())
+    return out
