@@ -1,0 +1,163 @@
+"""Headline benchmark: training images/sec of the WESUP step on GlaS-shaped synthetic patches.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+         bench.py --gpus N --steps K --warmup W
+
+A step is one full training iteration (BASELINE.json metric): superpixel
+preprocessing from the label map -> forward -> loss (label propagation + CE) -> backward ->
+gradient all-reduce (N > 1) -> SGD, on a batch of 4 images per GPU, 480x480, 576 superpixels each,
+fp32, with inputs already resident in HBM.  SLIC is excluded (label maps are inputs).
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_MFMA_F32_TFLOPS = 157.3      # MI355X_MICROARCH.md, Peak FP32 (matrix), dense
+PEAK_HBM_GBS = 8000.0             # HBM3E spec; 6290 GB/s measured streaming copy
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--batch', type=int, default=4, help='images per GPU (BASELINE configs[1]: 4)')
+    ap.add_argument('--size', type=int, default=480)
+    ap.add_argument('--grid', type=int, default=24, help='superpixel grid side: g*g superpixels per image')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-kernel-timing', action='store_true')
+    ap.add_argument('--unfused-pool-bwd', action='store_true')
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run'
+    dev = torch.device('cuda', local_rank)
+    torch.cuda.set_device(dev)
+
+    from oracle import wesup_oracle as orc          # only for the seeded weights + the cpu_baseline leg
+    from wesup_amd import synth
+    from wesup_amd.models import initialize_trainer
+    from wesup_amd.utils.metrics import accuracy, dice
+
+    B, H, W, g = args.batch, args.size, args.size, args.grid
+    weights = orc.make_weights(0, feat_scale=0.05)
+    trainer = initialize_trainer('wesup', device=str(dev), max_superpixels=g * g)
+    trainer.model.load_state_dict({k: torch.from_numpy(v) for k, v in weights.items()})
+    trainer.optimizer, trainer.scheduler = trainer.get_default_optimizer()
+    trainer.metric_funcs = [accuracy, dice]
+    trainer.model.train()
+    trainer.tracker.train()
+    trainer.model.engine.fuse_pool_bwd = not args.unfused_pool_bwd
+    if world > 1:
+        trainer.enable_data_parallel()
+
+    # two different synthetic batches per rank, resident in HBM before the timed region
+    pool = []
+    for i in range(2):
+        imgs, labs, pts, pix = synth.make_batch(1000 * rank + i + 1, B, H, W, g)
+        pool.append((torch.from_numpy(imgs).to(dev), torch.from_numpy(pix).to(dev), torch.from_numpy(pts).to(dev),
+                     torch.from_numpy(labs).to(dev)))
+
+    def step(i):
+        trainer.train_one_iteration('train', *pool[i % len(pool)])
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    timer = trainer.model.engine.timer
+    timer.reset()
+    timer.enabled = not args.no_kernel_timing
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    timer.enabled = False
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    loss_last = trainer.tracker.history['loss'][-1]
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = world * B * args.steps / elapsed
+        out = {
+            'metric': 'training images/sec, GlaS 480x480 VGG16 ~600 SP/img', 'value': round(value, 3), 'unit': 'images/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 3),
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': f'BASELINE configs[1]: GlaS-shaped synthetic {H}x{W} patches, VGG16 side-output '
+                                   f'extractor, batch={B}/GPU, {g * g} superpixels/img (jittered Voronoi), 20% point-labelled, '
+                                   'full train step (preprocess+fwd+loss+bwd+allreduce+SGD), SLIC excluded',
+                       'global_batch': world * B, 'image': [H, W], 'superpixels': g * g,
+                       'parallelism': f'dp{world}', 'last_loss': loss_last},
+        }
+        if timer.totals or timer.pending:
+            tot = timer.collect()
+            kern = {}
+            for tag, (ms, n, work) in sorted(tot.items()):
+                kern[tag] = {'ms_per_step': round(ms / args.steps, 4), 'launches_per_step': n / args.steps,
+                             'avg_us': round(ms / n * 1e3, 2)}
+                if tag.startswith('conv3x3') or tag in ('side_fwd', 'side_bwd', 'mlp_fwd', 'mlp_bwd'):
+                    kern[tag]['tflops'] = round(work / (ms * 1e-3) / 1e12, 2)
+                else:
+                    kern[tag]['gbs'] = round(work / (ms * 1e-3) / 1e9, 1)
+            # dominant kernel: the implicit-GEMM 3x3 convolution (forward + dgrad share gemm_nt_kernel<..,1>)
+            ms = sum(tot[t][0] for t in ('conv3x3_fwd', 'conv3x3_dgrad') if t in tot)
+            fl = sum(tot[t][2] for t in ('conv3x3_fwd', 'conv3x3_dgrad') if t in tot)
+            nl = sum(tot[t][1] for t in ('conv3x3_fwd', 'conv3x3_dgrad') if t in tot)
+            ach = fl / (ms * 1e-3) / 1e12
+            out['roofline'] = {'bound': 'mfma', 'kernel': 'gemm_nt_kernel (conv3x3 implicit GEMM fwd+dgrad, fp32 MFMA 32x32x2)',
+                               'achieved': round(ach, 2), 'peak': PEAK_MFMA_F32_TFLOPS, 'unit': 'TFLOP/s',
+                               'frac': round(ach / PEAK_MFMA_F32_TFLOPS, 4), 'traffic': None,
+                               'avg_launch_us': round(ms / nl * 1e3, 2), 'launches_per_step': nl / args.steps,
+                               'flop_per_step': fl / args.steps}
+            if 'conv3x3_wgrad' in tot:
+                ms, n, fl = tot['conv3x3_wgrad']
+                a = fl / (ms * 1e-3) / 1e12
+                out['roofline_wgrad'] = {'bound': 'mfma', 'kernel': 'gemm_tn_kernel + reduce (conv3x3 wgrad)',
+                                         'achieved': round(a, 2), 'peak': PEAK_MFMA_F32_TFLOPS, 'unit': 'TFLOP/s',
+                                         'frac': round(a / PEAK_MFMA_F32_TFLOPS, 4)}
+            if 'sp_pool_fwd' in tot:
+                ms, n, by = tot['sp_pool_fwd']
+                a = by / (ms * 1e-3) / 1e9
+                out['roofline_scatter_mean'] = {'bound': 'hbm', 'kernel': 'sp_pool_fwd_kernel (superpixel scatter-mean)',
+                                                'achieved': round(a, 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
+                                                'frac': round(a / PEAK_HBM_GBS, 4), 'traffic': None,
+                                                'avg_launch_us': round(ms / n * 1e3, 2)}
+            out['kernels'] = kern
+        if world == 1 and not args.no_cpu_baseline:
+            v, cores, sample = orc.time_cpu_baseline(iters=2, warmup=1)
+            out['cpu_baseline'] = {'value': round(v, 4), 'unit': 'images/s', 'cores': cores, 'kind': 'port', 'sample': sample}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

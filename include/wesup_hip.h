@@ -142,7 +142,8 @@ int wesup_loss_fwd(const float* pred, const float* y_all, const int32_t* n_sp, c
 int wesup_loss_bwd(const float* pred, const float* y_all, const int32_t* n_sp, const int32_t* n_l,
                    const float* terms, const float* dloss, float eps, float prop_weight, float* dpred,
                    int B, int Kmax, int C, void* stream);
-/* generic _cross_entropy (models/wesup.py:66-96) on (n, C): out = {sum(-y log clamp(yhat)), #rows with sum(y) > 0} */
+/* generic _cross_entropy (models/wesup.py:66-96) on (n, C): out2[4] = {sum(-y log clamp(yhat)), #rows with sum(y) > 0,
+ * loss = sum/#rows (0 if no row is labelled), 0} */
 int wesup_cross_entropy_fwd(const float* y_hat, const float* y_true, float eps, float* out2, int n, int C, void* stream);
 int wesup_cross_entropy_bwd(const float* y_hat, const float* y_true, const float* out2, const float* dloss,
                             float eps, float* dy_hat, int n, int C, void* stream);
@@ -151,7 +152,9 @@ int wesup_sgd_step(float* p, const float* g, float* v, size_t n, float lr, float
                    float grad_scale, int first_step, void* stream);
 /* accuracy / dice inputs (utils/metrics.py:31-45,112-135): out[b] = {#(P==G), sum(P*G), sum(P), sum(G)} with
  * P = round(pred) (half to even, models/wesup.py:534), G = argmax_c mask (first max) */
-int wesup_seg_metrics(const float* pred, const uint8_t* mask, float* out4, int B, int HW, int C, void* stream);
+size_t wesup_seg_metrics_workspace_bytes(int B);
+int wesup_seg_metrics(const float* pred, const uint8_t* mask, float* out4, int B, int HW, int C,
+                      void* ws, size_t ws_bytes, void* stream);
 
 #ifdef __cplusplus
 }

@@ -353,13 +353,14 @@ def dice(S, G, epsilon=EPS):
     return d.mean().item()
 
 
-def time_cpu_baseline(H=480, W=480, g=14, iters=3, warmup=1, seed=0, threads=None):
+def time_cpu_baseline(H=480, W=480, g=14, iters=2, warmup=1, seed=0, threads=None):
     """Timed CPU leg for bench.py: config c1 (1 image 480x480, ~200 SP),
     forward + loss + backward with this oracle.  Returns (img/s, cores, sample)."""
     import os
     from wesup_amd import synth
     if threads is None:
-        threads = os.cpu_count() or 1
+        # torch CPU collapses when oversubscribed (256 threads on the GPU box: 63 s/step); 16 is near its best
+        threads = min(os.cpu_count() or 1, 16)
     torch.set_num_threads(threads)
     weights = make_weights(seed, feat_scale=0.05)
     imgs, labs, pts, _ = synth.make_batch(seed, 1, H, W, g)

@@ -1,0 +1,278 @@
+"""End-to-end parity of the HIP training step (forward + loss + backward + SGD) on a real MI355X.
+
+Checked against (a) the golden vectors produced by the real reference (tests/golden) and (b) the
+CPU oracle on the same seeded inputs.  Bar: integer outputs (row order, propagated labels, argmax
+source indices, rounded prediction) bit-exact; fp32 tensors within 1e-4 relative."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4
+CASES = ['c32_point', 'c32_point_far', 'c64_point_tie', 'c64_full', 'c96x80_point', 'c64_identical']
+
+
+def rel_err(a, b):
+    a = torch.as_tensor(a).detach().double().cpu()
+    b = torch.as_tensor(b).detach().double().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+def load_case(golden_dir, name):
+    fx = dict(np.load(os.path.join(golden_dir, name + '.npz')))
+    shape = tuple(int(v) for v in fx['mask_shape'])
+    fx['mask'] = np.unpackbits(fx['mask'])[:int(np.prod(shape))].reshape(shape)
+    return fx
+
+
+def make_trainer(weights, **kw):
+    from wesup_amd.models import initialize_trainer
+    from wesup_amd.utils.metrics import accuracy, dice
+    trainer = initialize_trainer('wesup', device='cuda:0', **kw)
+    trainer.model.load_state_dict({k: torch.from_numpy(v) for k, v in weights.items()})
+    trainer.optimizer, trainer.scheduler = trainer.get_default_optimizer()
+    trainer.metric_funcs = [accuracy, dice]
+    return trainer
+
+
+@pytest.mark.parametrize('name', CASES)
+@pytest.mark.parametrize('fused', [True, False])
+def test_step_matches_reference_golden(golden_dir, name, fused):
+    from oracle import wesup_oracle as orc
+    from wesup_amd.models.wesup import preprocess_label_maps, SuperpixelMaps
+    fx = load_case(golden_dir, name)
+    d = torch.device('cuda:0')
+    weights = orc.make_weights(int(fx['seed']), feat_scale=float(fx['feat_scale']))
+    trainer = make_trainer(weights)
+    model = trainer.model
+    model._ensure_engine()
+    model.engine.fuse_pool_bwd = fused
+    img = torch.from_numpy(fx['img'])[None].to(d)
+    seg = torch.from_numpy(fx['seg'].astype(np.int32))[None].to(d)
+    mask = torch.from_numpy(fx['mask'].astype(np.uint8))[None].to(d)
+    K = int(fx['seg'].max()) + 1
+    meta = preprocess_label_maps(seg, mask, Kmax=K + 3, n_sp_host=[K])
+    meta.check()
+    n_l = int(meta.n_l[0])
+    assert n_l == fx['sp_labels'].shape[0]
+    assert np.array_equal(meta.sp_labels[0, :n_l].cpu().numpy(), fx['sp_labels'])
+    assert np.array_equal(meta.new_row[0].cpu().numpy().reshape(fx['new_row'].shape), fx['new_row'])
+
+    sp_maps = SuperpixelMaps(meta)
+    pred = model((img, sp_maps))
+    assert rel_err(model.sp_features, fx['sp_features']) < TOL
+    assert rel_err(model.sp_pred, fx['sp_pred']) < TOL
+    assert rel_err(pred, fx['pred']) < TOL
+    assert np.array_equal(trainer.postprocess(pred).cpu().numpy().astype(np.int8), fx['post_pred'])
+    fm = model.feature_maps
+    assert tuple(fm.shape) == (2112, int(fx['H']), int(fx['W']))
+    assert rel_err(fm.mean(dim=(1, 2)), fx['fm_chan_mean']) < TOL
+    assert rel_err(fm[::37, ::5, ::7], fx['fm_sample']) < TOL
+    assert rel_err(sp_maps.dense().sum(dim=(1, 2)), fx['sp_maps_rowsum']) < 1e-5
+
+    metrics = {}
+    feats_padded = model._padded[0].detach().clone()
+    loss = trainer.compute_loss(pred, (mask, sp_maps), metrics=metrics)
+    host = trainer._read_back(loss, metrics, None)
+    assert abs(host['loss'] - float(fx['loss'])) <= TOL * abs(float(fx['loss']))
+    if n_l < K:
+        assert metrics['propagated_labels'] == float(fx['propagated_labels'])
+        assert abs(metrics['propagate_loss'] - float(fx['propagate_loss'])) < 1e-5
+        assert abs(metrics['labeled_sp_ratio'] - float(fx['labeled_sp_ratio'])) < 1e-7
+        from wesup_amd import ops
+        y_all, src, sim = ops.propagate(feats_padded, meta, 0.8)
+        assert np.array_equal(src[0, n_l:K].cpu().numpy(), fx['src'])          # argmax indices bit-exact
+        assert np.array_equal(y_all[0, n_l:K].cpu().numpy(), fx['y_u'])
+        assert rel_err(sim[0, n_l:K], fx['max_sim']) < TOL
+    loss.backward()
+    grads = {k: p.grad for k, p in model.named_parameters()}
+    for k in [k[6:] for k in fx if k.startswith('gnorm.')]:
+        g = grads[k]
+        ref_norm = float(fx['gnorm.' + k])
+        assert abs(g.double().norm().item() - ref_norm) <= 2e-4 * ref_norm + 1e-12, k
+        # element samples: the reference's own fp32 gradients carry summation-order noise of this size on
+        # cancellation-heavy sums (conv1_1 dW sums 4096 mixed-sign products); the accuracy of the HIP
+        # gradients against an fp64 evaluation is pinned in test_gradients_at_fp32_noise_level.
+        samp = g.flatten()[::max(1, g.numel() // 64)][:64].cpu().numpy()
+        assert np.abs(samp - fx['gsamp.' + k]).max() <= 1e-3 * (np.abs(fx['gsamp.' + k]).max() + 1e-12), k
+
+
+def test_reference_signature_dense_sp_maps(golden_dir):
+    """forward((img, dense sp_maps (N,H,W))) + compute_loss with a plain (N_l,C) sp_labels tensor, exactly
+    as the reference's train_one_iteration drives it (models/base.py:192-208)."""
+    from oracle import wesup_oracle as orc
+    fx = load_case(golden_dir, 'c64_point_tie')
+    d = torch.device('cuda:0')
+    weights = orc.make_weights(int(fx['seed']), feat_scale=float(fx['feat_scale']))
+    trainer = make_trainer(weights)
+    model = trainer.model
+    sp_maps, sp_labels = orc.preprocess_superpixels_dense(torch.from_numpy(fx['seg'].astype(np.int64)),
+                                                          torch.from_numpy(fx['mask'].astype(np.int64)))
+    img = torch.from_numpy(fx['img'])[None].to(d)
+    with pytest.raises(RuntimeError):
+        trainer.compute_loss(None, (None, sp_labels.to(d)))                      # loss before forward
+    pred = model((img, sp_maps.to(d)))
+    assert tuple(pred.shape) == (1, 64, 64)
+    assert rel_err(pred, fx['pred']) < TOL
+    assert rel_err(model.sp_pred, fx['sp_pred']) < TOL
+    metrics = {}
+    loss = trainer.compute_loss(pred, (None, sp_labels.to(d)), metrics=metrics)
+    assert model.sp_pred is None                                                 # cleared (models/wesup.py:529)
+    assert abs(float(loss) - float(fx['loss'])) <= TOL * abs(float(fx['loss']))
+    assert metrics['propagated_labels'] == float(fx['propagated_labels'])
+    loss.backward()
+    g = model.fc_layers[0].weight.grad
+    assert abs(g.double().norm().item() - float(fx['gnorm.fc_layers.0.weight'])) <= 2e-4 * float(fx['gnorm.fc_layers.0.weight'])
+    # the free functions keep the reference behaviour
+    from wesup_amd.models.wesup import _label_propagate, _cross_entropy, _preprocess_superpixels
+    yu = _label_propagate(torch.zeros(5, 32, device=d), torch.tensor([[1., 0.], [0., 1.]], device=d), 0.8)
+    assert torch.equal(yu.cpu(), torch.tensor([[1., 0.]] * 3))                  # ties -> first labelled index
+    assert float(_cross_entropy(torch.tensor([[0.3, 0.7]], device=d), torch.zeros(1, 2, device=d))) == 0.0
+    maps, labels = _preprocess_superpixels(torch.from_numpy(fx['seg'].astype(np.int64)).to(d),
+                                           torch.from_numpy(fx['mask'].astype(np.int64)).to(d))
+    assert np.array_equal(labels.cpu().numpy(), fx['sp_labels'])
+    assert rel_err(maps.dense(), sp_maps) < 1e-6
+    with pytest.raises(ValueError):
+        trainer.preprocess(img, img, img, img, img)                              # bad arity (models/wesup.py:469)
+
+
+def test_batched_step_matches_oracle():
+    """B = 3 ragged images: loss, every parameter gradient and the SGD update vs the CPU oracle."""
+    from oracle import wesup_oracle as orc
+    from wesup_amd import synth
+    d = torch.device('cuda:0')
+    B, H, W = 3, 64, 48
+    weights = orc.make_weights(11, feat_scale=0.03)
+    imgs = np.stack([synth.synth_image(100 + b, H, W) for b in range(B)])
+    gs = [5, 6, 4]
+    segs = np.stack([synth.voronoi_labels(200 + b, H, W, gs[b]) for b in range(B)])
+    pts = np.stack([synth.point_mask(300 + b, segs[b], 0.3, 2, tie_every=4) for b in range(B)])
+    pix = np.stack([synth.pixel_mask(400 + b, H, W) for b in range(B)])
+    ref_loss, ref_grads, ref_new, _, outs, mets = orc.train_step(weights, imgs, segs.astype(np.int64), pts.astype(np.int64))
+
+    results = []
+    for rep in range(2):
+        trainer = make_trainer(weights)
+        trainer.model.train()
+        trainer.tracker.train()
+        data = (torch.from_numpy(imgs).to(d), torch.from_numpy(pix).long().to(d), torch.from_numpy(pts).long().to(d),
+                torch.from_numpy(segs))
+        trainer.train_one_iteration('train', *data)
+        hist = trainer.tracker.history
+        assert abs(hist['loss'][0] - ref_loss) <= TOL * abs(ref_loss)
+        assert abs(hist['propagated_labels'][0] - np.mean([m['propagated_labels'] for m in mets])) < 1e-6
+        assert abs(hist['labeled_sp_ratio'][0] - np.mean([m['labeled_sp_ratio'] for m in mets])) < 1e-6
+        P = torch.stack([o['pred'].detach().round().long() for o in outs])
+        G = torch.from_numpy(pix).long().argmax(dim=1)
+        assert abs(hist['accuracy'][0] - np.mean([orc.accuracy(P[b], G[b]) for b in range(B)])) < 1e-6
+        assert abs(hist['dice'][0] - np.mean([orc.dice(P[b], G[b]) for b in range(B)])) < 1e-6
+        grads = {k: trainer.model._grad_views[k].clone() for k in ref_grads}
+        for k, g in ref_grads.items():
+            assert rel_err(grads[k], g) < 3e-4, k
+        new = {k: v.detach().cpu() for k, v in trainer.model.state_dict().items()}
+        for k, v in ref_new.items():
+            assert rel_err(new[k], v) < 1e-5, k
+        results.append((hist['loss'][0], {k: v.cpu() for k, v in grads.items()}))
+    # run-to-run determinism: bitwise identical loss and gradients
+    assert results[0][0] == results[1][0]
+    for k in results[0][1]:
+        assert torch.equal(results[0][1][k], results[1][1][k]), k
+
+
+def test_gradients_at_fp32_noise_level(golden_dir):
+    """Every parameter gradient of the HIP step vs an fp64 evaluation of the oracle: within 1e-4 of the
+    tensor's max magnitude, and no worse than a small multiple of the error torch's own fp32 CPU path makes."""
+    from oracle import wesup_oracle as orc
+    fx = load_case(golden_dir, 'c64_point_tie')
+    d = torch.device('cuda:0')
+    weights = orc.make_weights(int(fx['seed']), feat_scale=float(fx['feat_scale']))
+    imgs, segs, masks = fx['img'][None], fx['seg'][None].astype(np.int64), fx['mask'][None].astype(np.int64)
+    _, g32, _, _, _, _ = orc.train_step(weights, imgs, segs, masks)
+    w64 = {k: torch.from_numpy(v).double().requires_grad_(True) for k, v in weights.items()}
+    loss64, _, _ = orc.batch_loss(w64, torch.from_numpy(imgs).double(), torch.from_numpy(segs), torch.from_numpy(masks))
+    loss64.backward()
+    trainer = make_trainer(weights)
+    trainer.tracker.train()
+    trainer.train_one_iteration('train', torch.from_numpy(imgs), torch.from_numpy(masks), torch.from_numpy(masks),
+                                torch.from_numpy(segs.astype(np.int32)))
+    assert abs(trainer.tracker.history['loss'][0] - float(loss64)) < 1e-5
+    for k, v in w64.items():
+        ref = v.grad
+        scale = float(ref.abs().max()) + 1e-30
+        e_gpu = float((trainer.model._grad_views[k].double().cpu() - ref).abs().max()) / scale
+        e_cpu = float((g32[k].double() - ref).abs().max()) / scale
+        # 1e-4 of the tensor's magnitude, unless the reference's own fp32 path is noisier than that on this
+        # tensor (conv1_1 dW: measured 3.1e-4 for torch CPU fp32 vs 1.4e-4 for the HIP path)
+        assert e_gpu < max(1e-4, 2 * e_cpu), (k, e_gpu, e_cpu)
+
+
+def test_val_phase_and_checkpoint_roundtrip(tmp_path):
+    from oracle import wesup_oracle as orc
+    from wesup_amd import synth
+    d = torch.device('cuda:0')
+    weights = orc.make_weights(5, feat_scale=0.05)
+    trainer = make_trainer(weights)
+    imgs, labs, pts, pix = synth.make_batch(3, 2, 32, 32, 4)
+    data = (torch.from_numpy(imgs), torch.from_numpy(pix).long(), torch.from_numpy(pts).long(), torch.from_numpy(labs))
+    trainer.tracker.train()
+    trainer.train_one_iteration('train', *data)
+    trainer.train_one_iteration('train', *data)
+    trainer.tracker.eval()
+    trainer.train_one_iteration('val', *data[:2], torch.tensor(0), data[3])
+    assert 'val_accuracy' in trainer.tracker.history and 'val_loss' not in trainer.tracker.history
+    ck = tmp_path / 'checkpoints' / 'ckpt.0001.pth'
+    trainer.save_checkpoint(ck, epoch=1)
+    saved = torch.load(ck, map_location='cpu')
+    assert set(saved) >= {'model_state_dict', 'optimizer_state_dict', 'epoch'}
+    assert list(saved['model_state_dict'].keys()) == orc.param_names()
+    t2 = make_trainer(orc.make_weights(6))
+    t2.load_checkpoint(ck)
+    assert t2.initial_epoch == 2
+    for (k, a), (_, b) in zip(trainer.model.state_dict().items(), t2.model.state_dict().items()):
+        assert torch.equal(a, b), k
+    # the resumed optimiser continues with the saved momentum: one more identical step on both
+    trainer.train_one_iteration('train', *data)
+    t2.tracker.train()
+    t2.train_one_iteration('train', *data)
+    for (k, a), (_, b) in zip(trainer.model.state_dict().items(), t2.model.state_dict().items()):
+        assert torch.equal(a, b), k
+
+
+def test_full_size_properties():
+    """BASELINE config c2 shape (480x480, ~576 superpixels, B = 2 here): size-independent properties."""
+    from oracle import wesup_oracle as orc
+    from wesup_amd import synth, ops
+    d = torch.device('cuda:0')
+    trainer = make_trainer(orc.make_weights(0, feat_scale=0.05))
+    model = trainer.model
+    B, H, W, g = 2, 480, 480, 24
+    imgs, labs, pts, pix = synth.make_batch(1, B, H, W, g)
+    (img, sp_maps), target = trainer.preprocess(torch.from_numpy(imgs).to(d), torch.from_numpy(pix).long().to(d),
+                                                 torch.from_numpy(pts).long().to(d), torch.from_numpy(labs))
+    meta = sp_maps.meta
+    meta.check()
+    pred = model((img, sp_maps))
+    # pooling a constant map gives the constant; rows sum to area; painting is piecewise constant per superpixel
+    ones = torch.ones(B, H, W, 64, device=d)
+    pooled = ops.sp_pool_fwd(ones, meta)
+    n = int(meta.n_sp[0])
+    assert torch.allclose(pooled[:, :n], torch.ones_like(pooled[:, :n]), atol=1e-5)
+    assert int(meta.area_new.sum()) == B * H * W
+    assert torch.equal(meta.pix_sorted.sort(dim=1).values, torch.arange(H * W, device=d, dtype=torch.int32).expand(B, -1))
+    sp_pred = model.sp_pred
+    assert torch.allclose(sp_pred[:, :n].sum(dim=2), torch.ones(B, n, device=d), atol=1e-5)
+    assert torch.equal(pred.reshape(B, -1), torch.gather(sp_pred[..., 1], 1, meta.new_row.long()))
+    loss = trainer.compute_loss(pred, target, metrics={})
+    assert torch.isfinite(loss)
+    loss.backward()
+    gsum = sum(float(p.grad.abs().sum()) for p in model.parameters())
+    assert np.isfinite(gsum) and gsum > 0
+    # linearity of the backward pass: doubling the upstream gradient doubles every parameter gradient
+    g1 = model._flat_grad.clone()
+    pred = model((img, sp_maps))
+    loss = trainer.compute_loss(pred, target, metrics={})
+    (2.0 * loss).backward()
+    assert rel_err(model._flat_grad, 2.0 * g1) < 1e-5

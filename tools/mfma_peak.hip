@@ -1,0 +1,45 @@
+// Calibration: back-to-back v_mfma_f32_32x32x2_f32 on every SIMD (operands in registers), reports TFLOP/s
+// and the in-kernel clock (s_memtime / s_memrealtime).  Not part of the product; used to read the real
+// fp32-MFMA ceiling of the device the bench runs on (DVFS: MI355X_MICROARCH.md "DVFS give-back").
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+__global__ __launch_bounds__(256) void mfma_loop(float* out, int iters, unsigned long long* clk) {
+    f32x16 acc[4];
+    for (int i = 0; i < 4; ++i) for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    float a = 1.0f + threadIdx.x * 1e-3f, b = 0.5f + blockIdx.x * 1e-4f;
+    unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(b, a, acc[1], 0, 0, 0);
+            acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, a, acc[2], 0, 0, 0);
+            acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(b, b, acc[3], 0, 0, 0);
+        }
+    }
+    unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    float s = 0.f;
+    for (int i = 0; i < 4; ++i) for (int r = 0; r < 16; ++r) s += acc[i][r];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+    if (threadIdx.x == 0) { clk[2 * blockIdx.x] = t1 - t0; clk[2 * blockIdx.x + 1] = r1 - r0; }
+}
+int main() {
+    const int blocks = 256 * 2, iters = 20000;
+    float* out; unsigned long long* clk;
+    hipMalloc(&out, blocks * 256 * 4); hipMalloc(&clk, blocks * 16);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int rep = 0; rep < 4; ++rep) {
+        hipEventRecord(e0);
+        hipLaunchKernelGGL(mfma_loop, dim3(blocks), dim3(256), 0, 0, out, iters, clk);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        double flop = (double)blocks * 4 * iters * 16 * 4096.0;
+        std::vector<unsigned long long> h(blocks * 2);
+        hipMemcpy(h.data(), clk, blocks * 16, hipMemcpyDeviceToHost);
+        double ghz = (double)h[0] / (double)h[1] * 0.1;
+        printf("rep %d: %.2f ms  %.1f TFLOP/s  in-kernel clock %.2f GHz\n", rep, ms, flop / ms / 1e9, ghz);
+    }
+    return 0;
+}

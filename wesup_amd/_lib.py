@@ -53,7 +53,8 @@ _SIGS = {
     'wesup_cross_entropy_fwd': (c_int, 'ppfpiip'),
     'wesup_cross_entropy_bwd': (c_int, 'ppppfpiip'),
     'wesup_sgd_step': (c_int, 'pppzffffip'),
-    'wesup_seg_metrics': (c_int, 'pppiiip'),
+    'wesup_seg_metrics_workspace_bytes': (c_size_t, 'i'),
+    'wesup_seg_metrics': (c_int, 'pppiiipzp'),
 }
 _T = {'p': c_void_p, 'i': c_int, 'f': c_float, 'z': c_size_t}
 

@@ -11,6 +11,7 @@
 // row stride == 1 (mod 32) so that the 4 scalar stores of a float4 are conflict free; operands that are
 // m-contiguous in memory (wgrad: both operands are [pixel][channel]) are stored with ds_write_b128.
 #include "common.hpp"
+#include <cstdlib>
 
 #define BK 32
 
@@ -32,22 +33,33 @@ struct NtParams {
 // im2col view of an NHWC tensor under a 3x3/pad-1 window (K order = (kh, kw, ci), ci fastest).
 // MODE 0: plain; 1: conv3x3 with Cin % 32 == 0; 2: conv3x3 with Cin == 4 (image layer, K padded to 64).
 // ---------------------------------------------------------------------------------------------
-template <int BM, int BN, int WM, int WN, int MODE>
-__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const NtParams p) {
-    constexpr int LDA_S = BM + 1, LDB_S = BN + 1;
-    constexpr int RA = BM / 32, RB = BN / 32;
+template <int BM, int BN, int WM, int WN, int MODE, int KB, int MINB>
+__global__ __launch_bounds__(256, MINB) void gemm_nt_kernel(const NtParams p) {
+    // LDS image of both operands is [row][k] with a row stride of BK+4 floats (144 B = 9 x 16 B): a lane's
+    // MFMA fragments for 4 consecutive k-steps are ONE ds_read_b128, conflict free (9*m mod 16 is a bijection
+    // over the 16 rows of a b128 lane group), and the staging store is one ds_write_b128 per float4 loaded.
+    // MFMA t of a group uses element t of the A and the B fragment: lanes 0-31 then carry k = 8g+t, lanes
+    // 32-63 k = 8g+4+t -- any consistent k permutation is fine for a dot product.
+    constexpr int LDK = KB + 4;
+    constexpr int RA = BM * KB / 1024, RB = BN * KB / 1024;
     constexpr int WAVES_N = BN / (32 * WN);
+    constexpr int LDC = BN + 4;
     static_assert((BM / (32 * WM)) * WAVES_N == 4, "4 waves per block");
+    constexpr int LDS_FLOATS = 2 * (BM + BN) * LDK;
+    constexpr int EP = (BM * LDC + LDS_FLOATS - 1) / LDS_FLOATS;     // epilogue passes (C tile staged in row slabs)
+    constexpr int HR = BM / EP;
+    static_assert(HR % (32 * WM) == 0 && HR * LDC <= LDS_FLOATS, "epilogue slab fits in the staging buffers");
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* As = smem;                       // [2][BK][LDA_S]
-    float* Bs = smem + 2 * BK * LDA_S;      // [2][BK][LDB_S]
+    float* As = smem;                       // [2][BM][LDK]
+    float* Bs = smem + 2 * BM * LDK;        // [2][BN][LDK]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nwg = p.tiles_m * p.tiles_n;
     const int lt = xcd_remap(blockIdx.x, nwg);
     const int tile_n = lt % p.tiles_n, tile_m = lt / p.tiles_n;
     const int m_blk = tile_m * BM, n_blk = tile_n * BN;
-    const int quad = tid & 7, lrow = tid >> 3;
+    constexpr int QK = KB / 4, RPP = 256 / QK;      // float4 per row, rows per pass
+    const int quad = tid % QK, lrow = tid / QK;
     const bool relu_in = p.flags & WESUP_RELU_IN;
 
     // ---- per-thread A rows
@@ -55,7 +67,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const NtParams p) {
     unsigned a_msk[RA];
 #pragma unroll
     for (int i = 0; i < RA; ++i) {
-        const int m = m_blk + lrow + 32 * i;
+        const int m = m_blk + lrow + RPP * i;
         if (MODE == 0) {
             a_off[i] = (long)m * p.lda + 4 * quad;
             a_msk[i] = (m < p.M) ? 1u : 0u;
@@ -80,58 +92,59 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const NtParams p) {
     bool b_ok[RB];
 #pragma unroll
     for (int j = 0; j < RB; ++j) {
-        const int n = n_blk + lrow + 32 * j;
+        const int n = n_blk + lrow + RPP * j;
         b_ok[j] = n < p.N;
-        b_off[j] = (long)n * p.ldb + 4 * quad;
+        b_off[j] = b_ok[j] ? (long)n * p.ldb + 4 * quad : 0;
     }
 
+    // Predicated loads are branch free: an invalid lane loads the (always mapped) first 16 bytes of the
+    // operand and the value is replaced by zero with a select.
     float4 ra[RA], rb[RB];
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
     auto load_global = [&](int kk) {
         if (MODE == 0) {
 #pragma unroll
-            for (int i = 0; i < RA; ++i)
-                ra[i] = a_msk[i] ? ld4(p.A + a_off[i] + kk * BK) : make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int i = 0; i < RA; ++i) {
+                const bool ok = a_msk[i] != 0;
+                const float4 v = ld4(p.A + (ok ? a_off[i] + kk * KB : 0));
+                ra[i] = ok ? v : zero4;
+            }
         } else if (MODE == 1) {
-            const int k0 = kk * BK;
+            const int k0 = kk * KB;
             const int tap = k0 >> p.cin_shift;
             const int ci0 = k0 & (p.Cin - 1);
             const int toff = ((tap / 3 - 1) * p.W + (tap % 3 - 1)) * p.Cin + ci0;
 #pragma unroll
-            for (int i = 0; i < RA; ++i)
-                ra[i] = ((a_msk[i] >> tap) & 1u) ? ld4(p.A + a_off[i] + toff) : make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int i = 0; i < RA; ++i) {
+                const bool ok = (a_msk[i] >> tap) & 1u;
+                const float4 v = ld4(p.A + (ok ? a_off[i] + toff : 0));
+                ra[i] = ok ? v : zero4;
+            }
         } else {
-            const int tap = kk * 8 + quad;
+            const int tap = kk * QK + quad;
             const int toff = ((tap / 3 - 1) * p.W + (tap % 3 - 1)) * 4;
 #pragma unroll
-            for (int i = 0; i < RA; ++i)
-                ra[i] = (tap < 9 && ((a_msk[i] >> tap) & 1u)) ? ld4(p.A + a_off[i] + toff)
-                                                               : make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int i = 0; i < RA; ++i) {
+                const bool ok = tap < 9 && ((a_msk[i] >> tap) & 1u);
+                const float4 v = ld4(p.A + (ok ? a_off[i] + toff : 0));
+                ra[i] = ok ? v : zero4;
+            }
         }
-        if (relu_in) {
-#pragma unroll
-            for (int i = 0; i < RA; ++i) ra[i] = relu4(ra[i]);
-        }
-#pragma unroll
-        for (int j = 0; j < RB; ++j)
-            rb[j] = b_ok[j] ? ld4(p.Bw + b_off[j] + kk * BK) : make_float4(0.f, 0.f, 0.f, 0.f);
-    };
-    auto store_lds = [&](int buf) {
-        float* as = As + buf * BK * LDA_S + (4 * quad) * LDA_S + lrow;
-#pragma unroll
-        for (int i = 0; i < RA; ++i) {
-            as[32 * i] = ra[i].x;
-            as[32 * i + LDA_S] = ra[i].y;
-            as[32 * i + 2 * LDA_S] = ra[i].z;
-            as[32 * i + 3 * LDA_S] = ra[i].w;
-        }
-        float* bs = Bs + buf * BK * LDB_S + (4 * quad) * LDB_S + lrow;
 #pragma unroll
         for (int j = 0; j < RB; ++j) {
-            bs[32 * j] = rb[j].x;
-            bs[32 * j + LDB_S] = rb[j].y;
-            bs[32 * j + 2 * LDB_S] = rb[j].z;
-            bs[32 * j + 3 * LDB_S] = rb[j].w;
+            const float4 v = ld4(p.Bw + b_off[j] + (b_ok[j] ? kk * KB : 0));
+            rb[j] = b_ok[j] ? v : zero4;
         }
+    };
+    auto store_lds = [&](int buf) {
+        // ReLU of the previous layer is applied here, AFTER the MFMA phase: applying it at load time
+        // would put the vmcnt wait in front of the MFMAs and expose the global-load latency every K-step.
+        float* as = As + buf * BM * LDK + lrow * LDK + 4 * quad;
+#pragma unroll
+        for (int i = 0; i < RA; ++i) st4(as + RPP * i * LDK, relu_in ? relu4(ra[i]) : ra[i]);
+        float* bs = Bs + buf * BN * LDK + lrow * LDK + 4 * quad;
+#pragma unroll
+        for (int j = 0; j < RB; ++j) st4(bs + RPP * j * LDK, rb[j]);
     };
 
     f32x16 acc[WM][WN];
@@ -144,7 +157,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const NtParams p) {
 
     const int wm0 = (wave / WAVES_N) * 32 * WM, wn0 = (wave % WAVES_N) * 32 * WN;
     const int l31 = lane & 31, lhi = lane >> 5;
-    const int nk = p.K / BK;
+    const int nk = p.K / KB;
 
     load_global(0);
     store_lds(0);
@@ -153,73 +166,118 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const NtParams p) {
     for (int kk = 0; kk < nk; ++kk) {
         const bool more = kk + 1 < nk;
         if (more) load_global(kk + 1);
-        const float* as = As + cur * BK * LDA_S + lhi * LDA_S + wm0 + l31;
-        const float* bs = Bs + cur * BK * LDB_S + lhi * LDB_S + wn0 + l31;
+        const float* as = As + cur * BM * LDK + (wm0 + l31) * LDK + 4 * lhi;
+        const float* bs = Bs + cur * BN * LDK + (wn0 + l31) * LDK + 4 * lhi;
 #pragma unroll
-        for (int kp = 0; kp < BK / 2; ++kp) {
-            float a[WM], b[WN];
+        for (int g = 0; g < KB / 8; ++g) {
+            float4 a[WM], b[WN];
 #pragma unroll
-            for (int i = 0; i < WM; ++i) a[i] = as[2 * kp * LDA_S + 32 * i];
+            for (int i = 0; i < WM; ++i) a[i] = ld4(as + 32 * i * LDK + 8 * g);
 #pragma unroll
-            for (int j = 0; j < WN; ++j) b[j] = bs[2 * kp * LDB_S + 32 * j];
+            for (int j = 0; j < WN; ++j) b[j] = ld4(bs + 32 * j * LDK + 8 * g);
 #pragma unroll
             for (int i = 0; i < WM; ++i)
 #pragma unroll
-                for (int j = 0; j < WN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < WN; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b[j].y, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[j].z, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
+                }
         }
         if (more) store_lds(cur ^ 1);
         __syncthreads();
         cur ^= 1;
     }
 
-    // ---- epilogue: lane holds D[row = (r&3) + 8*(r>>2) + 4*lhi][col = l31] of each 32x32 tile
+    // ---- epilogue through LDS: the accumulator tile (lane holds D[(r&3)+8*(r>>2)+4*lhi][l31] of each 32x32
+    // sub-tile) is written to a [BM][BN+4] image, then every thread handles 16-byte pieces of full rows so that
+    // bias / ReLU mask / accumulate / store all move 16 B per lane on contiguous row segments.
+    float* Cs = smem;
     const bool relu_out = p.flags & WESUP_RELU_OUT, accum = p.flags & WESUP_ACCUM, use_mask = p.flags & WESUP_MASK;
+    constexpr int QN = BN / 4;                 // float4 pieces per row
+    constexpr int ROWS_PER_PASS = 256 / QN;
+    const int cq = tid % QN, r0 = tid / QN;
+    const int n = n_blk + 4 * cq;
+    float4 bv = zero4;
+    if (p.bias && n < p.N) bv = ld4(p.bias + n);
 #pragma unroll
-    for (int j = 0; j < WN; ++j) {
-        const int n = n_blk + wn0 + 32 * j + l31;
-        if (n >= p.N) continue;
-        const float bv = p.bias ? p.bias[n] : 0.f;
+    for (int e = 0; e < EP; ++e) {
+        if (e > 0) __syncthreads();
+        if (wm0 >= e * HR && wm0 < (e + 1) * HR) {
 #pragma unroll
-        for (int i = 0; i < WM; ++i) {
+            for (int i = 0; i < WM; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m_blk + wm0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-                if (m >= p.M) continue;
-                float v = acc[i][j][r] + bv;
-                if (relu_out) v = fmaxf(v, 0.f);
-                if (use_mask) v = (p.mask[(long)m * p.ldmask + n] > 0.f) ? v : 0.f;
+                for (int j = 0; j < WN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        Cs[(wm0 - e * HR + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lhi) * LDC + wn0 + 32 * j + l31] = acc[i][j][r];
+        }
+        __syncthreads();
+        if (n < p.N) {                              // N % 4 == 0
+#pragma unroll 4
+            for (int rr = r0; rr < HR; rr += ROWS_PER_PASS) {
+                const int m = m_blk + e * HR + rr;
+                if (m >= p.M) break;
+                float4 v = ld4(Cs + rr * LDC + 4 * cq);
+                v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+                if (relu_out) v = relu4(v);
+                if (use_mask) {
+                    const float4 mk = ld4(p.mask + (long)m * p.ldmask + n);
+                    v.x = mk.x > 0.f ? v.x : 0.f;
+                    v.y = mk.y > 0.f ? v.y : 0.f;
+                    v.z = mk.z > 0.f ? v.z : 0.f;
+                    v.w = mk.w > 0.f ? v.w : 0.f;
+                }
                 float* c = p.C + (long)m * p.ldc + n;
-                if (accum) v += *c;
-                *c = v;
+                if (accum) {
+                    const float4 o = ld4(c);
+                    v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+                }
+                st4(c, v);
             }
         }
     }
 }
 
-template <int BM, int BN, int WM, int WN, int MODE>
+template <int BM, int BN, int WM, int WN, int MODE, int KB, int MINB>
 static int launch_nt(NtParams p, hipStream_t st) {
     p.tiles_m = ceil_div(p.M, BM);
     p.tiles_n = ceil_div(p.N, BN);
-    const size_t lds = (size_t)2 * BK * ((BM + 1) + (BN + 1)) * sizeof(float);
+    const size_t lds = (size_t)2 * (BM + BN) * (KB + 4) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_kernel<BM, BN, WM, WN, MODE>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_kernel<BM, BN, WM, WN, MODE, KB, MINB>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, WM, WN, MODE>), dim3(p.tiles_m * p.tiles_n), dim3(256), lds, st, p);
+    hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, WM, WN, MODE, KB, MINB>), dim3(p.tiles_m * p.tiles_n), dim3(256), lds, st, p);
     WESUP_CHECK_LAUNCH();
     return WESUP_OK;
+}
+
+static int nt_variant() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("WESUP_NT_VARIANT");
+        v = e ? atoi(e) : 0;
+    }
+    return v;
 }
 
 // Tile choice: 128x128 when the grid still fills 256 CUs twice over; 128x64 for N <= 64; 64x64 for small M.
 template <int MODE>
 static int dispatch_nt(NtParams p, hipStream_t st) {
     const long t128 = (long)ceil_div(p.M, 128) * ceil_div(p.N, 128);
-    if (p.N > 64 && t128 >= 384) return launch_nt<128, 128, 2, 2, MODE>(p, st);
-    if (p.N <= 64 && (long)ceil_div(p.M, 128) >= 384) return launch_nt<128, 64, 2, 1, MODE>(p, st);
-    return launch_nt<64, 64, 1, 1, MODE>(p, st);
+    if (p.N > 64 && t128 >= 384) {
+        if constexpr (MODE != 2) { if (nt_variant() == 1) return launch_nt<128, 128, 2, 2, MODE, 16, 3>(p, st); }
+        return launch_nt<128, 128, 2, 2, MODE, 32, 2>(p, st);
+    }
+    if (p.N <= 64 && (long)ceil_div(p.M, 128) >= 384) {
+        if constexpr (MODE != 2) { if (nt_variant() == 1) return launch_nt<128, 64, 2, 1, MODE, 16, 3>(p, st); }
+        return launch_nt<128, 64, 2, 1, MODE, 32, 2>(p, st);
+    }
+    return launch_nt<64, 64, 1, 1, MODE, 32, 2>(p, st);
 }
 
 static int ilog2(int v) {
@@ -231,7 +289,9 @@ static int ilog2(int v) {
 extern "C" int wesup_gemm_nt(const float* A, int lda, const float* B, int ldb, const float* bias, float* C,
                              int ldc, const float* mask, int ldmask, int M, int N, int K, int flags,
                              void* stream) {
-    if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || (K % BK) || (lda % 4) || (ldb % 4)) return WESUP_ERR_INVALID;
+    if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || (K % BK) || (lda % 4) || (ldb % 4) || (N % 4) || (ldc % 4) ||
+        (ldmask % 4) || (((uintptr_t)A | (uintptr_t)B | (uintptr_t)C | (uintptr_t)mask | (uintptr_t)bias) & 15))
+        return WESUP_ERR_INVALID;
     if ((flags & WESUP_MASK) && !mask) return WESUP_ERR_INVALID;
     NtParams p = {};
     p.A = A; p.Bw = B; p.bias = bias; p.C = C; p.mask = mask;
@@ -351,14 +411,15 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnParams p) {
                         v = ld4(p.Bx + (long)(k + dh2 * p.W + dw2) * 4);
                 }
             }
-            rb[i] = p.relu_b ? relu4(v) : v;
+            rb[i] = v;
         }
     };
     auto store_lds = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < NA; ++i) st4(As + buf * BK * LDA_S + (ra_row + RPA * i) * LDA_S + 4 * qa, ra[i]);
 #pragma unroll
-        for (int i = 0; i < NB; ++i) st4(Bs + buf * BK * LDB_S + (rb_row + RPB * i) * LDB_S + 4 * qb, rb[i]);
+        for (int i = 0; i < NB; ++i)      // ReLU applied after the MFMA phase (see the NT kernel)
+            st4(Bs + buf * BK * LDB_S + (rb_row + RPB * i) * LDB_S + 4 * qb, p.relu_b ? relu4(rb[i]) : rb[i]);
     };
 
     f32x16 acc[WM][WN];
@@ -519,28 +580,38 @@ extern "C" int wesup_gemm_tn(const float* A, int lda, const float* B, int ldb, f
     return WESUP_OK;
 }
 
-// ---- column sums (bias gradients): two-stage, fixed order
-__global__ void colsum_stage1(const float* A, int lda, float* part, int M, int N, int rows_per) {
-    const int n = blockIdx.x * blockDim.x + threadIdx.x;
-    if (n >= N) return;
+// ---- column sums (bias gradients): two-stage, fixed order, 16 B per lane
+// stage 1: block = 16 row-groups x 16 column quads (64 columns); each thread sums its rows of the chunk,
+// the 16 row-groups are combined through LDS in a fixed order.  stage 2 adds the chunk partials in order.
+__global__ __launch_bounds__(256) void colsum_stage1(const float* __restrict__ A, int lda, float* __restrict__ part,
+                                                     int M, int N, int rows_per) {
+    __shared__ float4 sh[16][16];
+    const int q = threadIdx.x & 15, rg = threadIdx.x >> 4;
+    const int n = blockIdx.x * 64 + 4 * q;
     const int m0 = blockIdx.y * rows_per;
     const int m1 = min(M, m0 + rows_per);
-    float s = 0.f;
-    for (int m = m0; m < m1; ++m) s += A[(long)m * lda + n];
-    part[(long)blockIdx.y * N + n] = s;
-}
-__global__ void colsum_stage2(const float* part, float* out, int N, int chunks) {
-    const int n = blockIdx.x * blockDim.x + threadIdx.x;
-    if (n >= N) return;
-    float s = 0.f;
-    for (int c = 0; c < chunks; ++c) s += part[(long)c * N + n];
-    out[n] = s;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (n < N) {
+        for (int m = m0 + rg; m < m1; m += 16) {
+            const float4 v = ld4(A + (long)m * lda + n);
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+    }
+    sh[rg][q] = s;
+    __syncthreads();
+    if (rg == 0 && n < N) {
+#pragma unroll
+        for (int r = 1; r < 16; ++r) {
+            const float4 v = sh[r][q];
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        st4(part + (long)blockIdx.y * N + n, s);
+    }
 }
 static int colsum_chunks(int M, int N) {
-    int chunks = ceil_div(M, 256);
-    const int cap = ceil_div(1 << 16, N > 0 ? N : 1);     // keep the partial buffer small
-    if (chunks > cap) chunks = cap;
-    if (chunks > 1024) chunks = 1024;
+    int chunks = 2048 / ceil_div(N, 64);
+    const int maxc = ceil_div(M, 64);
+    if (chunks > maxc) chunks = maxc;
     if (chunks < 1) chunks = 1;
     return chunks;
 }
@@ -548,16 +619,18 @@ extern "C" size_t wesup_colsum_workspace_bytes(int M, int N) {
     if (M <= 0 || N <= 0) return 0;
     return (size_t)colsum_chunks(M, N) * N * sizeof(float);
 }
+// stage 2 = the same kernel over the [chunks][N] partial matrix with a single chunk (fixed order again)
 extern "C" int wesup_colsum(const float* A, int lda, float* out, int M, int N, void* ws, size_t ws_bytes,
                             void* stream) {
-    if (!A || !out || !ws || M <= 0 || N <= 0) return WESUP_ERR_INVALID;
+    if (!A || !out || !ws || M <= 0 || N <= 0 || (N % 4) || (lda % 4) || ((uintptr_t)A & 15)) return WESUP_ERR_INVALID;
     if (ws_bytes < wesup_colsum_workspace_bytes(M, N)) return WESUP_ERR_WORKSPACE;
     const int chunks = colsum_chunks(M, N);
     const int rows_per = ceil_div(M, chunks);
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(colsum_stage1, dim3(ceil_div(N, 64), chunks), dim3(64), 0, st, A, lda, (float*)ws, M, N,
+    hipLaunchKernelGGL(colsum_stage1, dim3(ceil_div(N, 64), chunks), dim3(256), 0, st, A, lda, (float*)ws, M, N,
                        rows_per);
-    hipLaunchKernelGGL(colsum_stage2, dim3(ceil_div(N, 64)), dim3(64), 0, st, (const float*)ws, out, N, chunks);
+    hipLaunchKernelGGL(colsum_stage1, dim3(ceil_div(N, 64), 1), dim3(256), 0, st, (const float*)ws, N, out, chunks, N,
+                       chunks);
     WESUP_CHECK_LAUNCH();
     return WESUP_OK;
 }

@@ -343,6 +343,8 @@ __global__ __launch_bounds__(256) void ce_fwd_kernel(const float* __restrict__ y
     if (threadIdx.x == 0) {
         out2[0] = s;
         out2[1] = cnt;
+        out2[2] = (cnt > 0.f) ? s / cnt : 0.f;      // models/wesup.py:88-96
+        out2[3] = 0.f;
     }
 }
 __global__ void ce_bwd_kernel(const float* __restrict__ y_hat, const float* __restrict__ y_true,
@@ -418,12 +420,14 @@ extern "C" int wesup_sgd_step(float* p, const float* g, float* v, size_t n, floa
 }
 
 // ------------------------------------------------------------------ accuracy / dice sums
+// SEG_BLOCKS blocks per image write partial sums; a second tiny kernel adds them in a fixed order.
+#define SEG_BLOCKS 64
 __global__ __launch_bounds__(256) void seg_metrics_kernel(const float* __restrict__ pred, const uint8_t* __restrict__ mask,
-                                                          float* __restrict__ out4, int HW, int C) {
+                                                          float* __restrict__ part, int HW, int C) {
     __shared__ float sh[256];
-    const int b = blockIdx.x;
+    const int b = blockIdx.y;
     float eq = 0.f, pg = 0.f, sp = 0.f, sg = 0.f;
-    for (int p = threadIdx.x; p < HW; p += 256) {
+    for (int p = blockIdx.x * 256 + threadIdx.x; p < HW; p += SEG_BLOCKS * 256) {
         const float P = rintf(pred[(long)b * HW + p]);        // round half to even, as torch.round
         int gi = 0;
         uint8_t best = mask[((long)b * C) * HW + p];
@@ -442,12 +446,26 @@ __global__ __launch_bounds__(256) void seg_metrics_kernel(const float* __restric
     sp = block_sum256(sp, sh);
     sg = block_sum256(sg, sh);
     if (threadIdx.x == 0) {
-        out4[4 * b] = eq; out4[4 * b + 1] = pg; out4[4 * b + 2] = sp; out4[4 * b + 3] = sg;
+        float* o = part + ((long)b * SEG_BLOCKS + blockIdx.x) * 4;
+        o[0] = eq; o[1] = pg; o[2] = sp; o[3] = sg;
     }
 }
-extern "C" int wesup_seg_metrics(const float* pred, const uint8_t* mask, float* out4, int B, int HW, int C, void* stream) {
-    if (!pred || !mask || !out4 || B <= 0 || HW <= 0 || C <= 0) return WESUP_ERR_INVALID;
-    hipLaunchKernelGGL(seg_metrics_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, pred, mask, out4, HW, C);
+__global__ void seg_metrics_reduce(const float* __restrict__ part, float* __restrict__ out4, int B) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= B * 4) return;
+    const int b = idx >> 2, k = idx & 3;
+    float s = 0.f;
+    for (int i = 0; i < SEG_BLOCKS; ++i) s += part[((long)b * SEG_BLOCKS + i) * 4 + k];
+    out4[idx] = s;
+}
+extern "C" size_t wesup_seg_metrics_workspace_bytes(int B) { return B > 0 ? (size_t)B * SEG_BLOCKS * 4 * sizeof(float) : 0; }
+extern "C" int wesup_seg_metrics(const float* pred, const uint8_t* mask, float* out4, int B, int HW, int C, void* ws,
+                                 size_t ws_bytes, void* stream) {
+    if (!pred || !mask || !out4 || !ws || B <= 0 || HW <= 0 || C <= 0) return WESUP_ERR_INVALID;
+    if (ws_bytes < (size_t)B * SEG_BLOCKS * 4 * sizeof(float)) return WESUP_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(seg_metrics_kernel, dim3(SEG_BLOCKS, B), dim3(256), 0, st, pred, mask, (float*)ws, HW, C);
+    hipLaunchKernelGGL(seg_metrics_reduce, dim3(ceil_div(B * 4, 64)), dim3(64), 0, st, (const float*)ws, out4, B);
     WESUP_CHECK_LAUNCH();
     return WESUP_OK;
 }

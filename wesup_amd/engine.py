@@ -1,0 +1,296 @@
+"""Hand-scheduled forward/backward of the WESUP training step on the HIP kernels.
+
+This is the MI355X replacement of the ATen op sequence the reference runs per
+iteration:
+
+  forward   pack image -> 13 x [conv3x3 (pre-ReLU tap) -> side 1x1 GEMM -> bilinear upsample into the
+            pixel-major feature map] (+ 2x2 maxpool on 4 of them) -> superpixel scatter-mean ->
+            fc_layers (3 GEMMs, fused bias+ReLU) -> classifier+softmax -> paint-back
+            (models/wesup.py:263-304)
+  backward  classifier -> fc_layers (TN GEMMs for dW, NT GEMMs with fused ReLU mask for dx) ->
+            scatter-mean backward -> per layer: upsample backward, side-conv wgrad/dgrad -> main path
+            from conv5_3 down: conv3x3 wgrad, conv3x3 dgrad with fused ReLU mask + accumulate into the
+            side-branch gradient (maxpool backward where the layer was pooled)   (autograd in the reference,
+            models/base.py:207)
+
+Activations are NHWC fp32.  Parameter gradients are written straight into one flat buffer (the model's
+parameters are views of a flat buffer too) so that SGD is one kernel and the data-parallel all-reduce is a
+few large RCCL calls launched while the rest of backward still runs.
+"""
+import torch
+
+from . import ops
+
+CONV_IDX = [0, 2, 5, 7, 10, 12, 14, 17, 19, 21, 24, 26, 28]
+CONV_CH = [(3, 64), (64, 64), (64, 128), (128, 128), (128, 256), (256, 256), (256, 256),
+           (256, 512), (512, 512), (512, 512), (512, 512), (512, 512), (512, 512)]
+POOL_AFTER = [False, True, False, True, False, False, True, False, False, True, False, False, False]
+SIDE_OFF = [0, 32, 64, 128, 192, 320, 448, 576, 832, 1088, 1344, 1600, 1856]
+FM_CHANNELS = 2112
+# (the 13th conv is followed by a MaxPool in VGG16 whose output the reference discards, models/wesup.py:279)
+
+
+class KernelTimer:
+    """Optional HIP-event timing of kernel classes on the launch stream (bench.py's roofline leg)."""
+
+    def __init__(self):
+        self.enabled = False
+        self.pending = []          # (tag, start_event, end_event, work)
+        self.totals = {}
+
+    def begin(self, tag):
+        if not self.enabled:
+            return None
+        s = torch.cuda.Event(enable_timing=True)
+        s.record()
+        return (tag, s)
+
+    def end(self, tok, work=0.0):
+        if tok is None:
+            return
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        self.pending.append((tok[0], tok[1], e, work))
+
+    def collect(self):
+        """Call after a device sync.  Returns {tag: (ms_total, launches, work_total)}."""
+        for tag, s, e, work in self.pending:
+            ms, n, wk = self.totals.get(tag, (0.0, 0, 0.0))
+            self.totals[tag] = (ms + s.elapsed_time(e), n + 1, wk + work)
+        self.pending = []
+        return self.totals
+
+    def reset(self):
+        self.pending, self.totals = [], {}
+
+
+class _Bufs:
+    pass
+
+
+class WesupEngine:
+    def __init__(self, params, grads, D=32):
+        """params/grads: dict name -> tensor (views of the flat parameter / gradient buffers)."""
+        self.p = params
+        self.g = grads
+        self.D = D
+        self.device = next(iter(params.values())).device
+        self._bufs = {}
+        self._packed = None
+        self.ctx = None
+        self.fuse_pool_bwd = True        # skip the (B,HW,2112) gradient tensor: pool-bwd fused into upsample-bwd
+        self.timer = KernelTimer()
+        self.on_grads_ready = None       # callback(names) for the data-parallel layer
+
+    # ------------------------------------------------------------------ buffers
+    def _get_bufs(self, B, H, W, Kmax, train):
+        key = (B, H, W, Kmax)
+        b = self._bufs.get(key)
+        dev = self.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        if b is None:
+            b = _Bufs()
+            b.x0 = torch.empty(B, H, W, 4, **f32)
+            b.y, b.yp, b.s, b.dims = [], [], [], []
+            h, w = H, W
+            for l, (ci, co) in enumerate(CONV_CH):
+                b.dims.append((h, w))
+                b.y.append(torch.empty(B, h, w, co, **f32))
+                b.s.append(None if (h, w) == (H, W) else torch.empty(B, h, w, co // 2, **f32))
+                if POOL_AFTER[l]:
+                    h, w = h // 2, w // 2
+                    b.yp.append(torch.empty(B, h, w, co, **f32))
+                else:
+                    b.yp.append(None)
+            b.fm = torch.empty(B, H, W, FM_CHANNELS, **f32)
+            R = B * Kmax
+            b.sp_in = torch.empty(B, Kmax, FM_CHANNELS, **f32)
+            b.h1 = torch.empty(R, 1024, **f32)
+            b.h2 = torch.empty(R, 1024, **f32)
+            b.feats = torch.empty(R, self.D, **f32)
+            b.sp_pred = torch.empty(R, 2, **f32)
+            b.pred = torch.empty(B, H, W, **f32)
+            b.train = False
+            self._bufs[key] = b
+        if train and not b.train:
+            R = B * Kmax
+            b.G = [torch.empty_like(y) for y in b.y]
+            b.ds = [None if s is None and not self.fuse_pool_bwd else torch.empty(B, hh, ww, co // 2, **f32)
+                    for s, (hh, ww), (ci, co) in zip(b.s, b.dims, CONV_CH)]
+            b.dxp = [None if yp is None else torch.empty(yp.shape[0], yp.shape[1], yp.shape[2], CONV_CH[l + 1][0], **f32)
+                     for l, yp in enumerate(b.yp)]
+            b.dfm = None if self.fuse_pool_bwd else torch.empty(B, H, W, FM_CHANNELS, **f32)
+            b.dfeat = torch.empty(R, self.D, **f32)
+            b.dh2 = torch.empty(R, 1024, **f32)
+            b.dh1 = torch.empty(R, 1024, **f32)
+            b.gsp = torch.empty(B, Kmax, FM_CHANNELS, **f32)
+            b.train = True
+        return b
+
+    def release_buffers(self):
+        self._bufs = {}
+        self.ctx = None
+
+    # ------------------------------------------------------------------ weights
+    def _pack_weights(self, train):
+        pk = self._packed
+        if pk is None:
+            pk = _Bufs()
+            pk.wf, pk.wd = [], []
+            for l, (ci, co) in enumerate(CONV_CH):
+                pk.wf.append(torch.empty(co, ops.conv3x3_kpad(ci), dtype=torch.float32, device=self.device))
+                pk.wd.append(None if l == 0 else torch.empty(ci, 9 * co, dtype=torch.float32, device=self.device))
+            pk.sideT = [torch.empty(co, co // 2, dtype=torch.float32, device=self.device) for ci, co in CONV_CH]
+            pk.fcT = [torch.empty(FM_CHANNELS, 1024, dtype=torch.float32, device=self.device),
+                      torch.empty(1024, 1024, dtype=torch.float32, device=self.device),
+                      torch.empty(1024, self.D, dtype=torch.float32, device=self.device)]
+            self._packed = pk
+        for l, idx in enumerate(CONV_IDX):
+            ops.pack_conv3x3_weight(self.p[f'backbone.{idx}.weight'], pk.wf[l], pk.wd[l], need_dgrad=(train and l > 0))
+        if train:
+            for l, off in enumerate(SIDE_OFF):
+                co = CONV_CH[l][1]
+                ops.transpose(self.p[f'side_conv{off}.weight'].view(co // 2, co), pk.sideT[l])
+            for i, k in enumerate((0, 2, 4)):
+                ops.transpose(self.p[f'fc_layers.{k}.weight'], pk.fcT[i])
+        return pk
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, img, meta, train=True, need_paint=True):
+        """img (B,3,H,W) fp32 on the GPU, meta = ops.sp_preprocess(...).  Returns (feats, sp_pred, pred)
+        shaped (B,Kmax,D), (B,Kmax,2), (B,H,W); buffers are reused by the next call of the same shape."""
+        B, _, H, W = img.shape
+        Kmax = meta.Kmax
+        assert (meta.B, meta.H, meta.W) == (B, H, W)
+        b = self._get_bufs(B, H, W, Kmax, train)
+        pk = self._pack_weights(train)
+        p = self.p
+        T = self.timer
+        ops.pack_input(img, b.x0)
+        cur = b.x0
+        fm2d = b.fm.view(B * H * W, FM_CHANNELS)
+        for l, (ci, co) in enumerate(CONV_CH):
+            h, w = b.dims[l]
+            idx, off = CONV_IDX[l], SIDE_OFF[l]
+            tok = T.begin('conv3x3_fwd')
+            ops.conv3x3_fwd(cur, pk.wf[l], p[f'backbone.{idx}.bias'], co, relu_in=(l > 0), out=b.y[l])
+            T.end(tok, 2.0 * B * h * w * (3 if l == 0 else ci) * co * 9)
+            y2d = b.y[l].view(B * h * w, co)
+            ws = p[f'side_conv{off}.weight'].view(co // 2, co)
+            tok = T.begin('side_fwd')
+            if b.s[l] is None:       # full resolution: the side conv writes its channel slice of fm directly
+                ops.gemm_nt(y2d, ws, p[f'side_conv{off}.bias'], out=fm2d[:, off:off + co // 2])
+            else:
+                ops.gemm_nt(y2d, ws, p[f'side_conv{off}.bias'], out=b.s[l].view(B * h * w, co // 2))
+            T.end(tok, 2.0 * B * h * w * co * (co // 2))
+            if b.s[l] is not None:
+                tok = T.begin('upsample_fwd')
+                ops.upsample_fwd(b.s[l], b.fm, off)
+                T.end(tok, 4.0 * B * H * W * (co // 2))
+            if POOL_AFTER[l]:
+                ops.maxpool2_fwd(b.y[l], b.yp[l])
+                cur = b.yp[l]
+            else:
+                cur = b.y[l]
+        tok = T.begin('sp_pool_fwd')
+        ops.sp_pool_fwd(b.fm, meta, out=b.sp_in)
+        T.end(tok, 4.0 * B * (FM_CHANNELS * H * W + H * W + Kmax * FM_CHANNELS))
+        R = B * Kmax
+        tok = T.begin('mlp_fwd')
+        ops.gemm_nt(b.sp_in.view(R, FM_CHANNELS), p['fc_layers.0.weight'], p['fc_layers.0.bias'], out=b.h1, flags=ops.RELU_OUT)
+        ops.gemm_nt(b.h1, p['fc_layers.2.weight'], p['fc_layers.2.bias'], out=b.h2, flags=ops.RELU_OUT)
+        ops.gemm_nt(b.h2, p['fc_layers.4.weight'], p['fc_layers.4.bias'], out=b.feats, flags=ops.RELU_OUT)
+        T.end(tok, 2.0 * R * (FM_CHANNELS * 1024 + 1024 * 1024 + 1024 * self.D))
+        ops.classifier_fwd(b.feats, p['classifier.0.weight'], p['classifier.0.bias'], b.sp_pred)
+        sp_pred3 = b.sp_pred.view(B, Kmax, 2)
+        if need_paint:
+            ops.paint_fwd(sp_pred3, meta, 1, out=b.pred)
+        self.ctx = (b, pk, meta, B, H, W, Kmax) if train else None
+        return b.feats.view(B, Kmax, self.D), sp_pred3, b.pred
+
+    def feature_maps(self):
+        """(B,H,W,2112) pixel-major feature maps of the last forward (models/wesup.py:280)."""
+        for b in self._bufs.values():
+            pass
+        return b.fm
+
+    # ------------------------------------------------------------------ backward
+    def backward(self, dfeat_extra, dpred):
+        """dpred (B,Kmax,2) [and optional dfeat_extra (B,Kmax,D)]: gradients of the loss w.r.t. sp_pred /
+        sp_features.  Writes every parameter gradient into self.g (overwrites)."""
+        assert self.ctx is not None, 'backward without a training-mode forward'
+        b, pk, meta, B, H, W, Kmax = self.ctx
+        p, g, T = self.p, self.g, self.timer
+        R = B * Kmax
+        D = self.D
+        ready = self.on_grads_ready or (lambda names: None)
+        # ---- classifier + fc_layers
+        tok = T.begin('mlp_bwd')
+        ops.classifier_bwd(b.feats, p['classifier.0.weight'], b.sp_pred, dpred.reshape(R, 2),
+                           None if dfeat_extra is None else dfeat_extra.reshape(R, D),
+                           b.dfeat, g['classifier.0.weight'], g['classifier.0.bias'])
+        ops.gemm_tn(b.dfeat, b.h2, out=g['fc_layers.4.weight'])
+        ops.colsum(b.dfeat, g['fc_layers.4.bias'])
+        ops.gemm_nt(b.dfeat, pk.fcT[2], None, out=b.dh2, mask=b.h2)
+        ops.gemm_tn(b.dh2, b.h1, out=g['fc_layers.2.weight'])
+        ops.colsum(b.dh2, g['fc_layers.2.bias'])
+        ops.gemm_nt(b.dh2, pk.fcT[1], None, out=b.dh1, mask=b.h1)
+        ops.gemm_tn(b.dh1, b.sp_in.view(R, FM_CHANNELS), out=g['fc_layers.0.weight'])
+        ops.colsum(b.dh1, g['fc_layers.0.bias'])
+        gsp2d = b.gsp.view(R, FM_CHANNELS)
+        ops.gemm_nt(b.dh1, pk.fcT[0], None, out=gsp2d)
+        T.end(tok, 4.0 * R * (FM_CHANNELS * 1024 + 1024 * 1024 + 1024 * D))
+        ready(['classifier.0.weight', 'classifier.0.bias'] + [f'fc_layers.{k}.{t}' for k in (0, 2, 4) for t in ('weight', 'bias')])
+        # ---- scatter-mean backward (materialised) or fused into the upsample backward
+        if not self.fuse_pool_bwd:
+            tok = T.begin('sp_pool_bwd')
+            ops.sp_pool_bwd(b.gsp, meta, out=b.dfm)
+            T.end(tok, 4.0 * B * (FM_CHANNELS * H * W + H * W + Kmax * FM_CHANNELS))
+            dfm2d = b.dfm.view(B * H * W, FM_CHANNELS)
+        # ---- side branches: ds_l, side-conv wgrad, side-conv dgrad -> G_l
+        names = []
+        for l, (ci, co) in enumerate(CONV_CH):
+            h, w = b.dims[l]
+            off = SIDE_OFF[l]
+            P = B * h * w
+            tok = T.begin('upsample_bwd')
+            if self.fuse_pool_bwd:
+                ops.upsample_bwd_fused(b.gsp, meta.new_row, meta.area_new, H, W, off, h, w, co // 2, out=b.ds[l])
+                ds2d = b.ds[l].view(P, co // 2)
+            elif b.s[l] is None:
+                ds2d = dfm2d[:, off:off + co // 2]
+            else:
+                ops.upsample_bwd(b.dfm, off, h, w, co // 2, out=b.ds[l])
+                ds2d = b.ds[l].view(P, co // 2)
+            T.end(tok, 4.0 * B * H * W * (co // 2))
+            tok = T.begin('side_bwd')
+            y2d = b.y[l].view(P, co)
+            ops.gemm_tn(ds2d, y2d, out=g[f'side_conv{off}.weight'].view(co // 2, co))
+            ops.colsum(ds2d, g[f'side_conv{off}.bias'])
+            ops.gemm_nt(ds2d, pk.sideT[l], None, out=b.G[l].view(P, co))
+            T.end(tok, 4.0 * P * co * (co // 2))
+            names += [f'side_conv{off}.weight', f'side_conv{off}.bias']
+        ready(names)
+        # ---- main path, conv5_3 down to conv1_1
+        for l in range(12, -1, -1):
+            ci, co = CONV_CH[l]
+            h, w = b.dims[l]
+            idx = CONV_IDX[l]
+            if l == 0:
+                x_in = b.x0
+            else:
+                x_in = b.yp[l - 1] if POOL_AFTER[l - 1] else b.y[l - 1]
+            tok = T.begin('conv3x3_wgrad')
+            ops.conv3x3_wgrad(x_in, b.G[l], ci, relu_in=(l > 0), dw=g[f'backbone.{idx}.weight'], db=g[f'backbone.{idx}.bias'])
+            T.end(tok, 2.0 * B * h * w * ci * co * 9)
+            if l > 0:
+                tok = T.begin('conv3x3_dgrad')
+                if POOL_AFTER[l - 1]:
+                    ops.conv3x3_dgrad(b.G[l], pk.wd[l], ci, out=b.dxp[l - 1])
+                else:
+                    ops.conv3x3_dgrad(b.G[l], pk.wd[l], ci, mask_src=b.y[l - 1], out=b.G[l - 1], accumulate=True)
+                T.end(tok, 2.0 * B * h * w * ci * co * 9)
+                if POOL_AFTER[l - 1]:
+                    ops.maxpool2_bwd(b.y[l - 1], b.dxp[l - 1], b.G[l - 1], accumulate=True)
+            ready([f'backbone.{idx}.weight', f'backbone.{idx}.bias'])
+        self.ctx = None

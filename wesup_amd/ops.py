@@ -389,7 +389,7 @@ def cross_entropy_fwd(y_hat, y_true, eps):
     _chk(y_hat, name='y_hat'); _chk(y_true, name='y_true')
     n, C = y_hat.shape
     assert y_true.shape == (n, C)
-    out2 = torch.empty(2, dtype=torch.float32, device=y_hat.device)
+    out2 = torch.empty(4, dtype=torch.float32, device=y_hat.device)
     _lib.call('wesup_cross_entropy_fwd', _p(y_hat), _p(y_true), float(eps), _p(out2), n, C, _stream())
     return out2
 
@@ -416,5 +416,7 @@ def seg_metrics(pred, mask):
     B, H, W = pred.shape
     C = mask.shape[1]
     out = torch.empty(B, 4, dtype=torch.float32, device=pred.device)
-    _lib.call('wesup_seg_metrics', _p(pred), _p(mask), _p(out), B, H * W, C, _stream())
+    nb = _lib.load().wesup_seg_metrics_workspace_bytes(B)
+    ws = workspace(nb, pred.device, 'seg')
+    _lib.call('wesup_seg_metrics', _p(pred), _p(mask), _p(out), B, H * W, C, _p(ws), nb, _stream())
     return out
