@@ -1,19 +1,32 @@
 // fp32 MFMA GEMM family for gfx950: implicit-GEMM 3x3 convolution (fwd + dgrad), plain NT GEMM
 // (1x1 side convs, fc layers), TN GEMM with deterministic split-K (all weight gradients), column sums.
 //
-// Matrix core: v_mfma_f32_32x32x2_f32 (exact fp32, 64 FLOP/clk/SIMD = 157 TFLOP/s chip peak).  One
-// MFMA takes 64 cycles on its SIMD, so the kernel is paced by MFMA issue; everything else (global
-// loads into registers, LDS transposing stores, ds_read_b32 fragment reads) has to hide under it.
+// Matrix core: v_mfma_f32_32x32x2_f32 (exact fp32, 64 FLOP/clk/SIMD = 157 TFLOP/s chip peak; 155.8 measured
+// with operands in registers, tools/mfma_peak.hip).  One MFMA takes 64 cycles on its SIMD, so the kernels are
+// paced by MFMA issue and everything else has to hide under it.
 //
-// LDS image of every operand tile is K-MAJOR:  T[k][m]  (m contiguous).  An MFMA fragment is then one
-// conflict-free ds_read_b32: lane l reads T[2*kp + (l>>5)][m0 + (l&31)].  Operands whose global layout
-// is k-contiguous (activations NHWC x weights [N][K]) are transposed while being stored to LDS, with the
-// row stride == 1 (mod 32) so that the 4 scalar stores of a float4 are conflict free; operands that are
-// m-contiguous in memory (wgrad: both operands are [pixel][channel]) are stored with ds_write_b128.
+// Operand staging is LDS-DMA (global_load_lds_dwordx4): a wave-instruction copies 64 x 16 B from per-lane
+// global addresses straight into 1 KiB of LDS, no staging registers and no ds_write.  tools/mfma_ingredients.hip
+// measured why: with register staging hipcc either waits for the loads in front of the MFMA phase or sinks them
+// behind it (100-124 TFLOP/s for the bare loop); with LDS-DMA the only wait is the vmcnt(0) that __syncthreads()
+// emits, exactly at the end of the K-step (128-137 TFLOP/s).
+//   * the LDS destination of a wave-instruction is linear (base + lane*16), so tiles are unpadded; bank conflicts
+//     of the NT kernel's ds_read_b128 fragment reads are removed by XOR-swizzling the 16-B chunk index with
+//     (row>>1)&7 -- on the per-lane SOURCE address when staging and on the read address (same involution);
+//   * a lane whose element is outside the image / matrix reads from a zeroed page instead (implicit zero padding);
+//   * ReLU of the previous layer is applied to the fragments after the ds_read.
 #include "common.hpp"
 #include <cstdlib>
 
 #define BK 32
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+__device__ float4 g_zero_page[16];      // 256 B of zeros, source of masked lanes
+
+__device__ __forceinline__ void glds16(const float* src, float* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)lds_wave_base, 16, 0, 0);
+}
 
 struct NtParams {
     const float* A;
@@ -32,44 +45,43 @@ struct NtParams {
 // NT kernel:  C[M][N] = A[M][K] * Bw[N][K]^T   with A either a plain row-major matrix or the implicit
 // im2col view of an NHWC tensor under a 3x3/pad-1 window (K order = (kh, kw, ci), ci fastest).
 // MODE 0: plain; 1: conv3x3 with Cin % 32 == 0; 2: conv3x3 with Cin == 4 (image layer, K padded to 64).
+// LDS image of both operands: [row][32 floats], chunk c of row r stored at chunk position c ^ ((r>>1)&7).
+// A lane's fragments for 4 consecutive MFMA k-steps are ONE ds_read_b128; MFMA t of a group uses element t of the
+// A and the B fragment: lanes 0-31 then carry k = 8g+t, lanes 32-63 k = 8g+4+t (any consistent k order is fine).
 // ---------------------------------------------------------------------------------------------
-template <int BM, int BN, int WM, int WN, int MODE, int KB, int MINB>
+template <int BM, int BN, int WM, int WN, int MODE, int MINB>
 __global__ __launch_bounds__(256, MINB) void gemm_nt_kernel(const NtParams p) {
-    // LDS image of both operands is [row][k] with a row stride of BK+4 floats (144 B = 9 x 16 B): a lane's
-    // MFMA fragments for 4 consecutive k-steps are ONE ds_read_b128, conflict free (9*m mod 16 is a bijection
-    // over the 16 rows of a b128 lane group), and the staging store is one ds_write_b128 per float4 loaded.
-    // MFMA t of a group uses element t of the A and the B fragment: lanes 0-31 then carry k = 8g+t, lanes
-    // 32-63 k = 8g+4+t -- any consistent k permutation is fine for a dot product.
-    constexpr int LDK = KB + 4;
-    constexpr int RA = BM * KB / 1024, RB = BN * KB / 1024;
+    constexpr int RA = BM / 32, RB = BN / 32;          // staging passes (32 rows x 8 chunks per pass)
     constexpr int WAVES_N = BN / (32 * WN);
     constexpr int LDC = BN + 4;
     static_assert((BM / (32 * WM)) * WAVES_N == 4, "4 waves per block");
-    constexpr int LDS_FLOATS = 2 * (BM + BN) * LDK;
+    constexpr int LDS_FLOATS = 2 * (BM + BN) * BK;
     constexpr int EP = (BM * LDC + LDS_FLOATS - 1) / LDS_FLOATS;     // epilogue passes (C tile staged in row slabs)
     constexpr int HR = BM / EP;
     static_assert(HR % (32 * WM) == 0 && HR * LDC <= LDS_FLOATS, "epilogue slab fits in the staging buffers");
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* As = smem;                       // [2][BM][LDK]
-    float* Bs = smem + 2 * BM * LDK;        // [2][BN][LDK]
+    float* As = smem;                       // [2][BM][BK]
+    float* Bs = smem + 2 * BM * BK;         // [2][BN][BK]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nwg = p.tiles_m * p.tiles_n;
     const int lt = xcd_remap(blockIdx.x, nwg);
     const int tile_n = lt % p.tiles_n, tile_m = lt / p.tiles_n;
     const int m_blk = tile_m * BM, n_blk = tile_n * BN;
-    constexpr int QK = KB / 4, RPP = 256 / QK;      // float4 per row, rows per pass
-    const int quad = tid % QK, lrow = tid / QK;
     const bool relu_in = p.flags & WESUP_RELU_IN;
+    const float* zero = reinterpret_cast<const float*>(g_zero_page);
 
-    // ---- per-thread A rows
+    // ---- staging role of this lane: row (tid>>3) of each 32-row pass, chunk position tid&7; the logical chunk it
+    // fetches is position ^ swizzle(row) (the swizzle does not depend on the pass: 32*i >> 1 == 0 mod 8)
+    const int srow = tid >> 3;
+    const int schunk = (tid & 7) ^ ((srow >> 1) & 7);
     long a_off[RA];
     unsigned a_msk[RA];
 #pragma unroll
     for (int i = 0; i < RA; ++i) {
-        const int m = m_blk + lrow + RPP * i;
+        const int m = m_blk + srow + 32 * i;
         if (MODE == 0) {
-            a_off[i] = (long)m * p.lda + 4 * quad;
+            a_off[i] = (long)m * p.lda + 4 * schunk;
             a_msk[i] = (m < p.M) ? 1u : 0u;
         } else {
             const int hw = p.H * p.W;
@@ -85,66 +97,42 @@ __global__ __launch_bounds__(256, MINB) void gemm_nt_kernel(const NtParams p) {
                 }
             }
             a_msk[i] = msk;
-            a_off[i] = (long)m * p.Cin + (MODE == 1 ? 4 * quad : 0);
+            a_off[i] = (long)m * p.Cin + (MODE == 1 ? 4 * schunk : 0);
         }
     }
     long b_off[RB];
     bool b_ok[RB];
 #pragma unroll
     for (int j = 0; j < RB; ++j) {
-        const int n = n_blk + lrow + RPP * j;
+        const int n = n_blk + srow + 32 * j;
         b_ok[j] = n < p.N;
-        b_off[j] = b_ok[j] ? (long)n * p.ldb + 4 * quad : 0;
+        b_off[j] = (long)n * p.ldb + 4 * schunk;
     }
 
-    // Predicated loads are branch free: an invalid lane loads the (always mapped) first 16 bytes of the
-    // operand and the value is replaced by zero with a select.
-    float4 ra[RA], rb[RB];
-    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    auto load_global = [&](int kk) {
+    auto stage = [&](int kk, int buf) {
+        float* adst = As + buf * BM * BK + wave * 256;           // wave-uniform: rows 8*wave.. of pass 0
+        float* bdst = Bs + buf * BN * BK + wave * 256;
         if (MODE == 0) {
 #pragma unroll
-            for (int i = 0; i < RA; ++i) {
-                const bool ok = a_msk[i] != 0;
-                const float4 v = ld4(p.A + (ok ? a_off[i] + kk * KB : 0));
-                ra[i] = ok ? v : zero4;
-            }
+            for (int i = 0; i < RA; ++i)
+                glds16(a_msk[i] ? p.A + a_off[i] + kk * BK : zero, adst + i * 32 * BK);
         } else if (MODE == 1) {
-            const int k0 = kk * KB;
+            const int k0 = kk * BK;
             const int tap = k0 >> p.cin_shift;
             const int ci0 = k0 & (p.Cin - 1);
             const int toff = ((tap / 3 - 1) * p.W + (tap % 3 - 1)) * p.Cin + ci0;
 #pragma unroll
-            for (int i = 0; i < RA; ++i) {
-                const bool ok = (a_msk[i] >> tap) & 1u;
-                const float4 v = ld4(p.A + (ok ? a_off[i] + toff : 0));
-                ra[i] = ok ? v : zero4;
-            }
+            for (int i = 0; i < RA; ++i)
+                glds16(((a_msk[i] >> tap) & 1u) ? p.A + a_off[i] + toff : zero, adst + i * 32 * BK);
         } else {
-            const int tap = kk * QK + quad;
+            const int tap = kk * 8 + schunk;                     // logical chunk = tap (4 channels each)
             const int toff = ((tap / 3 - 1) * p.W + (tap % 3 - 1)) * 4;
 #pragma unroll
-            for (int i = 0; i < RA; ++i) {
-                const bool ok = tap < 9 && ((a_msk[i] >> tap) & 1u);
-                const float4 v = ld4(p.A + (ok ? a_off[i] + toff : 0));
-                ra[i] = ok ? v : zero4;
-            }
+            for (int i = 0; i < RA; ++i)
+                glds16((tap < 9 && ((a_msk[i] >> tap) & 1u)) ? p.A + a_off[i] + toff : zero, adst + i * 32 * BK);
         }
 #pragma unroll
-        for (int j = 0; j < RB; ++j) {
-            const float4 v = ld4(p.Bw + b_off[j] + (b_ok[j] ? kk * KB : 0));
-            rb[j] = b_ok[j] ? v : zero4;
-        }
-    };
-    auto store_lds = [&](int buf) {
-        // ReLU of the previous layer is applied here, AFTER the MFMA phase: applying it at load time
-        // would put the vmcnt wait in front of the MFMAs and expose the global-load latency every K-step.
-        float* as = As + buf * BM * LDK + lrow * LDK + 4 * quad;
-#pragma unroll
-        for (int i = 0; i < RA; ++i) st4(as + RPP * i * LDK, relu_in ? relu4(ra[i]) : ra[i]);
-        float* bs = Bs + buf * BN * LDK + lrow * LDK + 4 * quad;
-#pragma unroll
-        for (int j = 0; j < RB; ++j) st4(bs + RPP * j * LDK, rb[j]);
+        for (int j = 0; j < RB; ++j) glds16(b_ok[j] ? p.Bw + b_off[j] + kk * BK : zero, bdst + j * 32 * BK);
     };
 
     f32x16 acc[WM][WN];
@@ -157,24 +145,27 @@ __global__ __launch_bounds__(256, MINB) void gemm_nt_kernel(const NtParams p) {
 
     const int wm0 = (wave / WAVES_N) * 32 * WM, wn0 = (wave % WAVES_N) * 32 * WN;
     const int l31 = lane & 31, lhi = lane >> 5;
-    const int nk = p.K / KB;
+    const int swa = ((wm0 + l31) >> 1) & 7, swb = ((wn0 + l31) >> 1) & 7;   // read-side swizzle (same for every i / j)
+    const int nk = p.K / BK;
 
-    load_global(0);
-    store_lds(0);
-    __syncthreads();
+    stage(0, 0);
+    __syncthreads();                // vmcnt(0) for the LDS-DMA + barrier
     int cur = 0;
     for (int kk = 0; kk < nk; ++kk) {
-        const bool more = kk + 1 < nk;
-        if (more) load_global(kk + 1);
-        const float* as = As + cur * BM * LDK + (wm0 + l31) * LDK + 4 * lhi;
-        const float* bs = Bs + cur * BN * LDK + (wn0 + l31) * LDK + 4 * lhi;
+        if (kk + 1 < nk) stage(kk + 1, cur ^ 1);
+        const float* as = As + cur * BM * BK + (wm0 + l31) * BK;
+        const float* bs = Bs + cur * BN * BK + (wn0 + l31) * BK;
 #pragma unroll
-        for (int g = 0; g < KB / 8; ++g) {
+        for (int g = 0; g < BK / 8; ++g) {
             float4 a[WM], b[WN];
+            const int ca = ((2 * g + lhi) ^ swa) << 2, cb = ((2 * g + lhi) ^ swb) << 2;
 #pragma unroll
-            for (int i = 0; i < WM; ++i) a[i] = ld4(as + 32 * i * LDK + 8 * g);
+            for (int i = 0; i < WM; ++i) {
+                a[i] = ld4(as + 32 * i * BK + ca);
+                if (relu_in) a[i] = relu4(a[i]);
+            }
 #pragma unroll
-            for (int j = 0; j < WN; ++j) b[j] = ld4(bs + 32 * j * LDK + 8 * g);
+            for (int j = 0; j < WN; ++j) b[j] = ld4(bs + 32 * j * BK + cb);
 #pragma unroll
             for (int i = 0; i < WM; ++i)
 #pragma unroll
@@ -185,13 +176,12 @@ __global__ __launch_bounds__(256, MINB) void gemm_nt_kernel(const NtParams p) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
                 }
         }
-        if (more) store_lds(cur ^ 1);
-        __syncthreads();
+        __syncthreads();            // every wave done reading buf[cur]; next tile landed in buf[cur^1]
         cur ^= 1;
     }
 
     // ---- epilogue through LDS: the accumulator tile (lane holds D[(r&3)+8*(r>>2)+4*lhi][l31] of each 32x32
-    // sub-tile) is written to a [BM][BN+4] image, then every thread handles 16-byte pieces of full rows so that
+    // sub-tile) is written to a [rows][BN+4] image, then every thread handles 16-byte pieces of full rows so that
     // bias / ReLU mask / accumulate / store all move 16 B per lane on contiguous row segments.
     float* Cs = smem;
     const bool relu_out = p.flags & WESUP_RELU_OUT, accum = p.flags & WESUP_ACCUM, use_mask = p.flags & WESUP_MASK;
@@ -199,6 +189,7 @@ __global__ __launch_bounds__(256, MINB) void gemm_nt_kernel(const NtParams p) {
     constexpr int ROWS_PER_PASS = 256 / QN;
     const int cq = tid % QN, r0 = tid / QN;
     const int n = n_blk + 4 * cq;
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
     float4 bv = zero4;
     if (p.bias && n < p.N) bv = ld4(p.bias + n);
 #pragma unroll
@@ -240,44 +231,23 @@ __global__ __launch_bounds__(256, MINB) void gemm_nt_kernel(const NtParams p) {
     }
 }
 
-template <int BM, int BN, int WM, int WN, int MODE, int KB, int MINB>
+template <int BM, int BN, int WM, int WN, int MODE, int MINB>
 static int launch_nt(NtParams p, hipStream_t st) {
     p.tiles_m = ceil_div(p.M, BM);
     p.tiles_n = ceil_div(p.N, BN);
-    const size_t lds = (size_t)2 * (BM + BN) * (KB + 4) * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_kernel<BM, BN, WM, WN, MODE, KB, MINB>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
-    hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, WM, WN, MODE, KB, MINB>), dim3(p.tiles_m * p.tiles_n), dim3(256), lds, st, p);
+    const size_t lds = (size_t)2 * (BM + BN) * BK * sizeof(float);
+    hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, WM, WN, MODE, MINB>), dim3(p.tiles_m * p.tiles_n), dim3(256), lds, st, p);
     WESUP_CHECK_LAUNCH();
     return WESUP_OK;
-}
-
-static int nt_variant() {
-    static int v = -1;
-    if (v < 0) {
-        const char* e = getenv("WESUP_NT_VARIANT");
-        v = e ? atoi(e) : 0;
-    }
-    return v;
 }
 
 // Tile choice: 128x128 when the grid still fills 256 CUs twice over; 128x64 for N <= 64; 64x64 for small M.
 template <int MODE>
 static int dispatch_nt(NtParams p, hipStream_t st) {
     const long t128 = (long)ceil_div(p.M, 128) * ceil_div(p.N, 128);
-    if (p.N > 64 && t128 >= 384) {
-        if constexpr (MODE != 2) { if (nt_variant() == 1) return launch_nt<128, 128, 2, 2, MODE, 16, 3>(p, st); }
-        return launch_nt<128, 128, 2, 2, MODE, 32, 2>(p, st);
-    }
-    if (p.N <= 64 && (long)ceil_div(p.M, 128) >= 384) {
-        if constexpr (MODE != 2) { if (nt_variant() == 1) return launch_nt<128, 64, 2, 1, MODE, 16, 3>(p, st); }
-        return launch_nt<128, 64, 2, 1, MODE, 32, 2>(p, st);
-    }
-    return launch_nt<64, 64, 1, 1, MODE, 32, 2>(p, st);
+    if (p.N > 64 && t128 >= 384) return launch_nt<128, 128, 2, 2, MODE, 2>(p, st);
+    if (p.N <= 64 && (long)ceil_div(p.M, 128) >= 384) return launch_nt<128, 64, 2, 1, MODE, 2>(p, st);
+    return launch_nt<64, 64, 1, 1, MODE, 2>(p, st);
 }
 
 static int ilog2(int v) {
@@ -337,6 +307,9 @@ extern "C" int wesup_conv3x3_dgrad(const float* dy, const float* w_dgrad, const 
 // TN kernel (weight gradients):  C[M][N] = sum_k A[k][M] * B[k][N], k = pixel / row index.
 // MODE 0: plain matrices.  MODE 1: conv3x3 wgrad, grid.x also enumerates the 9 taps; B row k is the
 // input pixel shifted by the tap.  MODE 2: conv3x3 wgrad for the 4-channel image: N = 9 taps x 4.
+// Both operands are m-contiguous in memory ([pixel][channel]), so the LDS image is k-major [32 k][BM] and an MFMA
+// fragment is one conflict-free ds_read_b32 (lane l reads T[2*kp + (l>>5)][m0 + (l&31)]).  Rows are unpadded:
+// a wave-instruction of the LDS-DMA fills 1 KiB = 256 consecutive floats of the image.
 // Split-K over grid.y; every split writes its own slab (deterministic), reduced by a second kernel.
 // ---------------------------------------------------------------------------------------------
 struct TnParams {
@@ -355,14 +328,13 @@ struct TnParams {
 
 template <int BM, int BN, int WM, int WN, int MODE>
 __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnParams p) {
-    constexpr int LDA_S = BM + 4, LDB_S = BN + 4;
     constexpr int QA = BM / 4, RPA = 256 / QA, NA = BK / RPA;
     constexpr int QB = BN / 4, RPB = 256 / QB, NB = BK / RPB;
     constexpr int WAVES_N = BN / (32 * WN);
     static_assert((BM / (32 * WM)) * WAVES_N == 4, "4 waves per block");
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* As = smem;                       // [2][BK][LDA_S]
-    float* Bs = smem + 2 * BK * LDA_S;      // [2][BK][LDB_S]
+    float* As = smem;                       // [2][BK][BM]
+    float* Bs = smem + 2 * BK * BM;         // [2][BK][BN]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int lt = blockIdx.x;
@@ -373,6 +345,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnParams p) {
     const int m_blk = tile_m * BM, n_blk = tile_n * BN;
     const int k_begin = blockIdx.y * p.k_per_split;
     const int k_end = min(p.K, k_begin + p.k_per_split);
+    const float* zero = reinterpret_cast<const float*>(g_zero_page);
 
     const int qa = tid % QA, ra_row = tid / QA;
     const int qb = tid % QB, rb_row = tid / QB;
@@ -382,20 +355,20 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnParams p) {
     // MODE 2: column quad qb is tap qb (4 channels each), only 9 of the 16 quads are real
     const int dh2 = qb / 3 - 1, dw2 = qb % 3 - 1;
 
-    float4 ra[NA], rb[NB];
-    auto load_global = [&](int k0) {
+    auto stage = [&](int k0, int buf) {
+        float* adst = As + buf * BK * BM + wave * 256;       // the image is linear in tid: 4*tid floats per pass
+        float* bdst = Bs + buf * BK * BN + wave * 256;
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             const int k = k0 + ra_row + RPA * i;
-            ra[i] = (a_col_ok && k < k_end) ? ld4(p.A + (long)k * p.lda + m_blk + 4 * qa)
-                                            : make_float4(0.f, 0.f, 0.f, 0.f);
+            glds16((a_col_ok && k < k_end) ? p.A + (long)k * p.lda + m_blk + 4 * qa : zero, adst + i * 1024);
         }
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
             const int k = k0 + rb_row + RPB * i;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            const float* src = zero;
             if (MODE == 0) {
-                if (b_col_ok && k < k_end) v = ld4(p.Bx + (long)k * p.ldb + n_blk + 4 * qb);
+                if (b_col_ok && k < k_end) src = p.Bx + (long)k * p.ldb + n_blk + 4 * qb;
             } else {
                 const int t = fast_div(k, p.dW);       // b*H + h
                 const int w = k - t * p.W;
@@ -404,22 +377,15 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnParams p) {
                 if (MODE == 1) {
                     const int hh = h + dh, ww = w + dw;
                     if (b_col_ok && k < k_end && hh >= 0 && hh < p.H && ww >= 0 && ww < p.W)
-                        v = ld4(p.Bx + (long)(k + dh * p.W + dw) * p.ldb + n_blk + 4 * qb);
+                        src = p.Bx + (long)(k + dh * p.W + dw) * p.ldb + n_blk + 4 * qb;
                 } else {
                     const int hh = h + dh2, ww = w + dw2;
                     if (qb < 9 && k < k_end && hh >= 0 && hh < p.H && ww >= 0 && ww < p.W)
-                        v = ld4(p.Bx + (long)(k + dh2 * p.W + dw2) * 4);
+                        src = p.Bx + (long)(k + dh2 * p.W + dw2) * 4;
                 }
             }
-            rb[i] = v;
+            glds16(src, bdst + i * 1024);
         }
-    };
-    auto store_lds = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < NA; ++i) st4(As + buf * BK * LDA_S + (ra_row + RPA * i) * LDA_S + 4 * qa, ra[i]);
-#pragma unroll
-        for (int i = 0; i < NB; ++i)      // ReLU applied after the MFMA phase (see the NT kernel)
-            st4(Bs + buf * BK * LDB_S + (rb_row + RPB * i) * LDB_S + 4 * qb, p.relu_b ? relu4(rb[i]) : rb[i]);
     };
 
     f32x16 acc[WM][WN];
@@ -433,32 +399,31 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnParams p) {
     const int wm0 = (wave / WAVES_N) * 32 * WM, wn0 = (wave % WAVES_N) * 32 * WN;
     const int l31 = lane & 31, lhi = lane >> 5;
     const int nk = (k_end - k_begin + BK - 1) / BK;
+    const bool relu_b = p.relu_b;
 
-    if (nk > 0) {
-        load_global(k_begin);
-        store_lds(0);
-    }
+    if (nk > 0) stage(k_begin, 0);
     __syncthreads();
     int cur = 0;
     for (int kk = 0; kk < nk; ++kk) {
-        const bool more = kk + 1 < nk;
-        if (more) load_global(k_begin + (kk + 1) * BK);
-        const float* as = As + cur * BK * LDA_S + lhi * LDA_S + wm0 + l31;
-        const float* bs = Bs + cur * BK * LDB_S + lhi * LDB_S + wn0 + l31;
+        if (kk + 1 < nk) stage(k_begin + (kk + 1) * BK, cur ^ 1);
+        const float* as = As + cur * BK * BM + lhi * BM + wm0 + l31;
+        const float* bs = Bs + cur * BK * BN + lhi * BN + wn0 + l31;
 #pragma unroll
         for (int kp = 0; kp < BK / 2; ++kp) {
             float a[WM], b[WN];
 #pragma unroll
-            for (int i = 0; i < WM; ++i) a[i] = as[2 * kp * LDA_S + 32 * i];
+            for (int i = 0; i < WM; ++i) a[i] = as[2 * kp * BM + 32 * i];
 #pragma unroll
-            for (int j = 0; j < WN; ++j) b[j] = bs[2 * kp * LDB_S + 32 * j];
+            for (int j = 0; j < WN; ++j) {
+                b[j] = bs[2 * kp * BN + 32 * j];
+                if (relu_b) b[j] = fmaxf(b[j], 0.f);
+            }
 #pragma unroll
             for (int i = 0; i < WM; ++i)
 #pragma unroll
                 for (int j = 0; j < WN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
         }
-        if (more) store_lds(cur ^ 1);
         __syncthreads();
         cur ^= 1;
     }
@@ -539,16 +504,10 @@ static int launch_tn(TnParams p, const TnPlan& pl, hipStream_t st) {
     p.Nslab = pl.Nslab;
     dim3 grid(pl.tiles_m * pl.tiles_n * pl.taps, pl.S);
     if (pl.bm == 128) {
-        const size_t lds = (size_t)2 * BK * (132 + 132) * sizeof(float);
-        static bool a = false;
-        if (!a) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_kernel<128, 128, 2, 2, MODE>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            a = true;
-        }
+        const size_t lds = (size_t)2 * BK * (128 + 128) * sizeof(float);
         hipLaunchKernelGGL((gemm_tn_kernel<128, 128, 2, 2, MODE>), grid, dim3(256), lds, st, p);
     } else {
-        const size_t lds = (size_t)2 * BK * (68 + 68) * sizeof(float);
+        const size_t lds = (size_t)2 * BK * (64 + 64) * sizeof(float);
         hipLaunchKernelGGL((gemm_tn_kernel<64, 64, 1, 1, MODE>), grid, dim3(256), lds, st, p);
     }
     WESUP_CHECK_LAUNCH();
@@ -563,7 +522,8 @@ extern "C" size_t wesup_gemm_tn_workspace_bytes(int M, int N, int K) {
 
 extern "C" int wesup_gemm_tn(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N,
                              int K, int relu_b, void* ws, size_t ws_bytes, void* stream) {
-    if (!A || !B || !C || !ws || M <= 0 || N <= 0 || K <= 0 || (M % 4) || (N % 4) || (lda % 4) || (ldb % 4))
+    if (!A || !B || !C || !ws || M <= 0 || N <= 0 || K <= 0 || (M % 4) || (N % 4) || (lda % 4) || (ldb % 4) ||
+        (((uintptr_t)A | (uintptr_t)B) & 15))
         return WESUP_ERR_INVALID;
     if (ws_bytes < wesup_gemm_tn_workspace_bytes(M, N, K)) return WESUP_ERR_WORKSPACE;
     const TnPlan pl = plan_tn(M, N, K, 1);
@@ -580,9 +540,9 @@ extern "C" int wesup_gemm_tn(const float* A, int lda, const float* B, int ldb, f
     return WESUP_OK;
 }
 
-// ---- column sums (bias gradients): two-stage, fixed order, 16 B per lane
-// stage 1: block = 16 row-groups x 16 column quads (64 columns); each thread sums its rows of the chunk,
-// the 16 row-groups are combined through LDS in a fixed order.  stage 2 adds the chunk partials in order.
+// ---- column sums (bias gradients): two passes of one kernel, fixed order, 16 B per lane
+// block = 16 row-groups x 16 column quads (64 columns); each thread sums its rows of the chunk, the 16 row-groups
+// are combined through LDS in a fixed order.  Pass 2 runs the same kernel over the [chunks][N] partial matrix.
 __global__ __launch_bounds__(256) void colsum_stage1(const float* __restrict__ A, int lda, float* __restrict__ part,
                                                      int M, int N, int rows_per) {
     __shared__ float4 sh[16][16];
@@ -619,7 +579,6 @@ extern "C" size_t wesup_colsum_workspace_bytes(int M, int N) {
     if (M <= 0 || N <= 0) return 0;
     return (size_t)colsum_chunks(M, N) * N * sizeof(float);
 }
-// stage 2 = the same kernel over the [chunks][N] partial matrix with a single chunk (fixed order again)
 extern "C" int wesup_colsum(const float* A, int lda, float* out, int M, int N, void* ws, size_t ws_bytes,
                             void* stream) {
     if (!A || !out || !ws || M <= 0 || N <= 0 || (N % 4) || (lda % 4) || ((uintptr_t)A & 15)) return WESUP_ERR_INVALID;

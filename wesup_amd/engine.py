@@ -13,6 +13,10 @@ iteration:
             side-branch gradient (maxpool backward where the layer was pooled)   (autograd in the reference,
             models/base.py:207)
 
+Two HIP streams: the MFMA-bound convolution chain runs on the caller's stream, the HBM-bound side branch
+(1x1 side GEMMs, upsampling, bias sums) on a second stream, joined by events; the memory-bound kernels
+then fill the tails and stalls of the matrix kernels instead of extending the critical path.
+
 Activations are NHWC fp32.  Parameter gradients are written straight into one flat buffer (the model's
 parameters are views of a flat buffer too) so that SGD is one kernel and the data-parallel all-reduce is a
 few large RCCL calls launched while the rest of backward still runs.
@@ -42,7 +46,7 @@ class KernelTimer:
         if not self.enabled:
             return None
         s = torch.cuda.Event(enable_timing=True)
-        s.record()
+        s.record()                 # on the current stream = the stream the kernel is launched on
         return (tag, s)
 
     def end(self, tok, work=0.0):
@@ -79,8 +83,47 @@ class WesupEngine:
         self._packed = None
         self.ctx = None
         self.fuse_pool_bwd = True        # skip the (B,HW,2112) gradient tensor: pool-bwd fused into upsample-bwd
+        self.two_streams = True          # side branch on its own HIP stream
+        self._side_stream = None
+        self._wgrad_stream = None
         self.timer = KernelTimer()
         self.on_grads_ready = None       # callback(names) for the data-parallel layer
+
+    # ------------------------------------------------------------------ streams
+    def _side(self):
+        if self._side_stream is None:
+            self._side_stream = torch.cuda.Stream(device=self.device)
+        return self._side_stream
+
+    def _wg(self):
+        if self._wgrad_stream is None:
+            self._wgrad_stream = torch.cuda.Stream(device=self.device)
+        return self._wgrad_stream
+
+    class _OnSide:
+        """Run the body on the side stream after everything queued so far on the main stream."""
+
+        def __init__(self, eng, wait_main=True):
+            self.eng, self.wait_main = eng, wait_main
+
+        def __enter__(self):
+            e = self.eng
+            if not e.two_streams:
+                return None
+            if self.wait_main:
+                e._side().wait_stream(torch.cuda.current_stream())
+            self.cm = torch.cuda.stream(e._side())
+            self.cm.__enter__()
+            return None
+
+        def __exit__(self, *a):
+            if self.eng.two_streams:
+                self.cm.__exit__(*a)
+            return False
+
+    def _join_side(self):
+        if self.two_streams:
+            torch.cuda.current_stream().wait_stream(self._side())
 
     # ------------------------------------------------------------------ buffers
     def _get_bufs(self, B, H, W, Kmax, train):
@@ -175,23 +218,26 @@ class WesupEngine:
             tok = T.begin('conv3x3_fwd')
             ops.conv3x3_fwd(cur, pk.wf[l], p[f'backbone.{idx}.bias'], co, relu_in=(l > 0), out=b.y[l])
             T.end(tok, 2.0 * B * h * w * (3 if l == 0 else ci) * co * 9)
-            y2d = b.y[l].view(B * h * w, co)
-            ws = p[f'side_conv{off}.weight'].view(co // 2, co)
-            tok = T.begin('side_fwd')
-            if b.s[l] is None:       # full resolution: the side conv writes its channel slice of fm directly
-                ops.gemm_nt(y2d, ws, p[f'side_conv{off}.bias'], out=fm2d[:, off:off + co // 2])
-            else:
-                ops.gemm_nt(y2d, ws, p[f'side_conv{off}.bias'], out=b.s[l].view(B * h * w, co // 2))
-            T.end(tok, 2.0 * B * h * w * co * (co // 2))
-            if b.s[l] is not None:
-                tok = T.begin('upsample_fwd')
-                ops.upsample_fwd(b.s[l], b.fm, off)
-                T.end(tok, 4.0 * B * H * W * (co // 2))
+            # side branch of this layer: 1x1 conv on the pre-ReLU tap + upsample into fm's channel slice
+            with self._OnSide(self):
+                y2d = b.y[l].view(B * h * w, co)
+                ws = p[f'side_conv{off}.weight'].view(co // 2, co)
+                tok = T.begin('side_fwd')
+                if b.s[l] is None:       # full resolution: the side conv writes its channel slice of fm directly
+                    ops.gemm_nt(y2d, ws, p[f'side_conv{off}.bias'], out=fm2d[:, off:off + co // 2])
+                else:
+                    ops.gemm_nt(y2d, ws, p[f'side_conv{off}.bias'], out=b.s[l].view(B * h * w, co // 2))
+                T.end(tok, 2.0 * B * h * w * co * (co // 2))
+                if b.s[l] is not None:
+                    tok = T.begin('upsample_fwd')
+                    ops.upsample_fwd(b.s[l], b.fm, off)
+                    T.end(tok, 4.0 * B * H * W * (co // 2))
             if POOL_AFTER[l]:
                 ops.maxpool2_fwd(b.y[l], b.yp[l])
                 cur = b.yp[l]
             else:
                 cur = b.y[l]
+        self._join_side()
         tok = T.begin('sp_pool_fwd')
         ops.sp_pool_fwd(b.fm, meta, out=b.sp_in)
         T.end(tok, 4.0 * B * (FM_CHANNELS * H * W + H * W + Kmax * FM_CHANNELS))
@@ -247,43 +293,67 @@ class WesupEngine:
             ops.sp_pool_bwd(b.gsp, meta, out=b.dfm)
             T.end(tok, 4.0 * B * (FM_CHANNELS * H * W + H * W + Kmax * FM_CHANNELS))
             dfm2d = b.dfm.view(B * H * W, FM_CHANNELS)
-        # ---- side branches: ds_l, side-conv wgrad, side-conv dgrad -> G_l
-        names = []
-        for l, (ci, co) in enumerate(CONV_CH):
-            h, w = b.dims[l]
-            off = SIDE_OFF[l]
-            P = B * h * w
-            tok = T.begin('upsample_bwd')
-            if self.fuse_pool_bwd:
-                ops.upsample_bwd_fused(b.gsp, meta.new_row, meta.area_new, H, W, off, h, w, co // 2, out=b.ds[l])
-                ds2d = b.ds[l].view(P, co // 2)
-            elif b.s[l] is None:
-                ds2d = dfm2d[:, off:off + co // 2]
-            else:
-                ops.upsample_bwd(b.dfm, off, h, w, co // 2, out=b.ds[l])
-                ds2d = b.ds[l].view(P, co // 2)
-            T.end(tok, 4.0 * B * H * W * (co // 2))
-            tok = T.begin('side_bwd')
-            y2d = b.y[l].view(P, co)
-            ops.gemm_tn(ds2d, y2d, out=g[f'side_conv{off}.weight'].view(co // 2, co))
-            ops.colsum(ds2d, g[f'side_conv{off}.bias'])
-            ops.gemm_nt(ds2d, pk.sideT[l], None, out=b.G[l].view(P, co))
-            T.end(tok, 4.0 * P * co * (co // 2))
-            names += [f'side_conv{off}.weight', f'side_conv{off}.bias']
-        ready(names)
-        # ---- main path, conv5_3 down to conv1_1
+        # ---- side branches (side stream), deepest layer first: ds_l, side-conv wgrad, side-conv dgrad -> G_l.
+        # g_ready[l] marks "G_l holds the side-branch gradient"; the main chain accumulates into it afterwards.
+        g_ready = [None] * 13
+        side_names = []
+        with self._OnSide(self):
+            for l in range(12, -1, -1):
+                ci, co = CONV_CH[l]
+                h, w = b.dims[l]
+                off = SIDE_OFF[l]
+                P = B * h * w
+                tok = T.begin('upsample_bwd')
+                if self.fuse_pool_bwd:
+                    ops.upsample_bwd_fused(b.gsp, meta.new_row, meta.area_new, H, W, off, h, w, co // 2, out=b.ds[l])
+                    ds2d = b.ds[l].view(P, co // 2)
+                elif b.s[l] is None:
+                    ds2d = dfm2d[:, off:off + co // 2]
+                else:
+                    ops.upsample_bwd(b.dfm, off, h, w, co // 2, out=b.ds[l])
+                    ds2d = b.ds[l].view(P, co // 2)
+                T.end(tok, 4.0 * B * H * W * (co // 2))
+                tok = T.begin('side_bwd')
+                y2d = b.y[l].view(P, co)
+                ops.gemm_nt(ds2d, pk.sideT[l], None, out=b.G[l].view(P, co))
+                if self.two_streams:
+                    g_ready[l] = torch.cuda.Event()
+                    g_ready[l].record()
+                ops.gemm_tn(ds2d, y2d, out=g[f'side_conv{off}.weight'].view(co // 2, co), ws_tag='side')
+                ops.colsum(ds2d, g[f'side_conv{off}.bias'], ws_tag='side_colsum')
+                T.end(tok, 4.0 * P * co * (co // 2))
+                side_names += [f'side_conv{off}.weight', f'side_conv{off}.bias']
+        # ---- main path, conv5_3 down to conv1_1.  The dgrad chain stays on the caller's stream; each layer's wgrad
+        # (which only produces parameter gradients) goes to a third stream so that it fills the tails of the dgrad
+        # kernels instead of sitting on the critical path.
+        main = torch.cuda.current_stream()
+        wg = self._wg() if self.two_streams else None
         for l in range(12, -1, -1):
             ci, co = CONV_CH[l]
             h, w = b.dims[l]
             idx = CONV_IDX[l]
+            if g_ready[l] is not None:
+                main.wait_event(g_ready[l])
             if l == 0:
                 x_in = b.x0
             else:
                 x_in = b.yp[l - 1] if POOL_AFTER[l - 1] else b.y[l - 1]
-            tok = T.begin('conv3x3_wgrad')
-            ops.conv3x3_wgrad(x_in, b.G[l], ci, relu_in=(l > 0), dw=g[f'backbone.{idx}.weight'], db=g[f'backbone.{idx}.bias'])
-            T.end(tok, 2.0 * B * h * w * ci * co * 9)
+            if wg is not None:
+                wg.wait_stream(main)                       # G_l is final here
+                with torch.cuda.stream(wg):
+                    tok = T.begin('conv3x3_wgrad')
+                    ops.conv3x3_wgrad(x_in, b.G[l], ci, relu_in=(l > 0), dw=g[f'backbone.{idx}.weight'],
+                                      db=g[f'backbone.{idx}.bias'], ws_tag='wgrad')
+                    T.end(tok, 2.0 * B * h * w * ci * co * 9)
+                    ready([f'backbone.{idx}.weight', f'backbone.{idx}.bias'])
+            else:
+                tok = T.begin('conv3x3_wgrad')
+                ops.conv3x3_wgrad(x_in, b.G[l], ci, relu_in=(l > 0), dw=g[f'backbone.{idx}.weight'], db=g[f'backbone.{idx}.bias'])
+                T.end(tok, 2.0 * B * h * w * ci * co * 9)
+                ready([f'backbone.{idx}.weight', f'backbone.{idx}.bias'])
             if l > 0:
+                if g_ready[l - 1] is not None:
+                    main.wait_event(g_ready[l - 1])
                 tok = T.begin('conv3x3_dgrad')
                 if POOL_AFTER[l - 1]:
                     ops.conv3x3_dgrad(b.G[l], pk.wd[l], ci, out=b.dxp[l - 1])
@@ -292,5 +362,8 @@ class WesupEngine:
                 T.end(tok, 2.0 * B * h * w * ci * co * 9)
                 if POOL_AFTER[l - 1]:
                     ops.maxpool2_bwd(b.y[l - 1], b.dxp[l - 1], b.G[l - 1], accumulate=True)
-            ready([f'backbone.{idx}.weight', f'backbone.{idx}.bias'])
+        if wg is not None:
+            main.wait_stream(wg)
+        self._join_side()
+        ready(side_names)
         self.ctx = None

@@ -110,7 +110,7 @@ def conv3x3_dgrad(dy, w_dgrad, Cin, mask_src=None, out=None, accumulate=False):
     return out
 
 
-def conv3x3_wgrad(x, dy, Ci, relu_in, dw=None, db=None):
+def conv3x3_wgrad(x, dy, Ci, relu_in, dw=None, db=None, ws_tag='default'):
     _chk(x, name='x'); _chk(dy, name='dy')
     B, H, W, Cx = x.shape
     Cout = dy.shape[3]
@@ -121,7 +121,7 @@ def conv3x3_wgrad(x, dy, Ci, relu_in, dw=None, db=None):
         db = torch.empty(Cout, dtype=torch.float32, device=x.device)
     assert dw.is_contiguous() and dw.numel() == Cout * Ci * 9 and db.numel() == Cout
     nb = _lib.load().wesup_conv3x3_wgrad_workspace_bytes(B, H, W, Ci, Cout)
-    ws = workspace(nb, x.device)
+    ws = workspace(nb, x.device, ws_tag)
     _lib.call('wesup_conv3x3_wgrad', _p(x), _p(dy), _p(dw), _p(db), B, H, W, Ci, Cout, int(relu_in), _p(ws), nb, _stream())
     return dw, db
 
@@ -155,7 +155,7 @@ def gemm_nt(A, Bw, bias=None, out=None, mask=None, flags=0):
     return out
 
 
-def gemm_tn(A, Bm, out=None, relu_b=False):
+def gemm_tn(A, Bm, out=None, relu_b=False, ws_tag='default'):
     """out[M][N] = A[K][M]^T @ Bm[K][N]  (deterministic split-K)."""
     K, M = A.shape
     K2, N = Bm.shape
@@ -164,19 +164,19 @@ def gemm_tn(A, Bm, out=None, relu_b=False):
         out = torch.empty(M, N, dtype=torch.float32, device=A.device)
     assert out.shape == (M, N)
     nb = _lib.load().wesup_gemm_tn_workspace_bytes(M, N, K)
-    ws = workspace(nb, A.device)
+    ws = workspace(nb, A.device, ws_tag)      # one workspace per stream that may run concurrently
     _lib.call('wesup_gemm_tn', _p(A), _ld(A), _p(Bm), _ld(Bm), _p(out), _ld(out), M, N, K, int(relu_b), _p(ws), nb,
               _stream())
     return out
 
 
-def colsum(A, out=None):
+def colsum(A, out=None, ws_tag='colsum'):
     M, N = A.shape
     assert A.is_cuda
     if out is None:
         out = torch.empty(N, dtype=torch.float32, device=A.device)
     nb = _lib.load().wesup_colsum_workspace_bytes(M, N)
-    ws = workspace(nb, A.device, 'colsum')
+    ws = workspace(nb, A.device, ws_tag)
     _lib.call('wesup_colsum', _p(A), _ld(A), _p(out), M, N, _p(ws), nb, _stream())
     return out
 
