@@ -1,0 +1,99 @@
+"""Host-side mirror of the reference interface, checked without a GPU: config defaults, factory errors,
+state_dict key names / parameter count, metric formulas, history bookkeeping, synthetic data contract, and the
+"no CPU fallback" rule (the product path raises instead of silently running eager PyTorch)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import wesup_oracle as orc
+from wesup_amd import synth
+from wesup_amd.models import initialize_trainer, WESUP, WESUPConfig
+from wesup_amd.models.base import BaseConfig
+from wesup_amd.utils import empty_tensor, is_empty_tensor, underline
+from wesup_amd.utils.history import HistoryTracker
+from wesup_amd.utils import metrics as M
+
+
+def test_config_defaults_match_reference():
+    c = WESUPConfig().to_dict()                      # models/wesup.py:142-179, models/base.py:16-36
+    assert c['rescale_factor'] == 0.5 and c['multiscale_range'] == (0.3, 0.4) and c['n_classes'] == 2
+    assert c['class_weights'] == (3, 1) and c['sp_area'] == 200 and c['sp_compactness'] == 40
+    assert c['enable_propagation'] is True and c['propagate_threshold'] == 0.8 and c['propagate_weight'] == 0.5
+    assert c['momentum'] == 0.9 and c['weight_decay'] == 0.001 and c['freeze_backbone'] is False
+    assert c['batch_size'] == 1 and c['epochs'] == 300 and c['epsilon'] == 1e-7
+    assert BaseConfig().to_dict() == {'batch_size': 1, 'epochs': 10, 'epsilon': 1e-7}
+
+
+def test_factory_and_module_names():
+    with pytest.raises(ValueError):
+        initialize_trainer('unet', device='cpu')          # models/__init__.py:17
+    model = WESUP()
+    keys = list(model.state_dict().keys())
+    assert keys == orc.param_names()                       # SURVEY.md 8(b) state_dict keys
+    assert sum(p.numel() for p in model.parameters()) == 18868194
+    assert model.fm_channels_sum == 2112
+    assert model.side_conv1856.weight.shape == (256, 512, 1, 1)
+    assert model.classifier[0].weight.shape == (2, 32)     # always 2-way (models/wesup.py:230)
+
+
+def test_no_cpu_fallback():
+    model = WESUP()
+    img = torch.zeros(1, 3, 16, 16)
+    with pytest.raises(RuntimeError, match='HIP'):
+        model((img, torch.ones(1, 16, 16)))                # CPU model: the HIP path refuses, no eager fallback
+    trainer = initialize_trainer('wesup', device='cpu')
+    with pytest.raises(RuntimeError):
+        trainer.compute_loss(None, (None, torch.zeros(1, 2)))      # loss before forward (models/wesup.py:498-500)
+
+
+def test_metric_formulas_and_sentinel():
+    P = torch.randint(0, 2, (3, 20, 24))
+    G = torch.randint(0, 2, (3, 20, 24))
+    sums = np.stack([[float((P[b] == G[b]).sum()), float((P[b] * G[b]).sum()), float(P[b].sum()), float(G[b].sum())]
+                     for b in range(3)])
+    assert abs(M.accuracy_from_sums(sums, 20 * 24) - np.mean([orc.accuracy(P[b], G[b]) for b in range(3)])) < 1e-7
+    assert abs(M.dice_from_sums(sums) - np.mean([orc.dice(P[b], G[b]) for b in range(3)])) < 1e-6
+    assert abs(M.accuracy(P[0], G[0]) - orc.accuracy(P[0], G[0])) < 1e-7
+    assert abs(M.dice(P, G) - orc.dice(P, G)) < 1e-6
+    assert is_empty_tensor(empty_tensor()) and not is_empty_tensor(torch.zeros(1))
+    assert underline('ab') == 'ab\n--'
+
+
+def test_history_tracker(tmp_path):
+    t = HistoryTracker(tmp_path / 'history.csv')
+    t.start_new_epoch(5e-5)
+    t.train()
+    t.step({'loss': 1.0, 'accuracy': 0.5})
+    t.step({'loss': 3.0, 'accuracy': 0.7})
+    t.eval()
+    t.step({'accuracy': 0.9})
+    assert t.history['val_accuracy'] == [0.9]
+    t.train()
+    assert 'loss = 2.0000' in t.log().lower()
+    t.save()
+    t.start_new_epoch(5e-5)
+    t.step({'loss': 2.0, 'accuracy': 0.6})
+    t.eval(); t.step({'accuracy': 0.8}); t.train()
+    t.save()
+    assert 'accuracy' in t.report()
+    with pytest.raises(RuntimeError):
+        HistoryTracker().save()
+
+
+def test_synthetic_inputs_are_reproducible_and_well_formed():
+    lab = synth.voronoi_labels(3, 96, 80, 7)
+    assert lab.dtype == np.int32 and lab.min() == 0 and lab.max() == 48 and len(np.unique(lab)) == 49
+    assert np.array_equal(lab, synth.voronoi_labels(3, 96, 80, 7))
+    pts = synth.point_mask(3, lab, 0.25, 2, tie_every=2)
+    assert pts.shape == (2, 96, 80) and pts.max() == 1 and pts.sum() >= 12
+    sk = synth.skewed_labels(3, 128, 128, 16)
+    areas = np.bincount(sk.ravel())
+    assert areas.min() > 0 and areas.max() > 20 * np.median(areas)
+    from wesup_amd.utils.data import get_dataset
+    ds = get_dataset('synthetic:32:32:4:3/train')
+    img, pix, p, seg = ds[0]
+    assert img.shape == (3, 32, 32) and pix.shape == (2, 32, 32) and seg.shape == (32, 32) and len(ds) == 3
+    with pytest.raises(NotImplementedError):
+        get_dataset('/data/glas/train')
