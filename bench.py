@@ -37,14 +37,19 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true')
     ap.add_argument('--unfused-pool-bwd', action='store_true')
+    ap.add_argument('--force-ddp', action='store_true', help='run the RCCL gradient all-reduce path even with one rank')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if world > 1:
+    use_dist = world > 1 or args.force_ddp
+    if use_dist:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29511')
+        os.environ.setdefault('RANK', '0')
+        os.environ.setdefault('WORLD_SIZE', '1')
         torch.cuda.set_device(local_rank)
         dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
     assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run'
@@ -58,14 +63,14 @@ def main():
 
     B, H, W, g = args.batch, args.size, args.size, args.grid
     weights = orc.make_weights(0, feat_scale=0.05)
-    trainer = initialize_trainer('wesup', device=str(dev), max_superpixels=g * g)
+    trainer = initialize_trainer('wesup', device=str(dev), max_superpixels=g * g, force_allreduce=args.force_ddp)
     trainer.model.load_state_dict({k: torch.from_numpy(v) for k, v in weights.items()})
     trainer.optimizer, trainer.scheduler = trainer.get_default_optimizer()
     trainer.metric_funcs = [accuracy, dice]
     trainer.model.train()
     trainer.tracker.train()
     trainer.model.engine.fuse_pool_bwd = not args.unfused_pool_bwd
-    if world > 1:
+    if use_dist:
         trainer.enable_data_parallel()
 
     # two different synthetic batches per rank, resident in HBM before the timed region
@@ -79,7 +84,7 @@ def main():
         trainer.train_one_iteration('train', *pool[i % len(pool)])
 
     def barrier():
-        if world > 1:
+        if use_dist:
             import torch.distributed as dist
             dist.barrier()
         torch.cuda.synchronize()
@@ -96,7 +101,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     timer.enabled = False
-    if world > 1:
+    if use_dist:
         import torch.distributed as dist
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -154,7 +159,7 @@ def main():
             v, cores, sample = orc.time_cpu_baseline(iters=2, warmup=1)
             out['cpu_baseline'] = {'value': round(v, 4), 'unit': 'images/s', 'cores': cores, 'kind': 'port', 'sample': sample}
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         import torch.distributed as dist
         dist.destroy_process_group()
 

@@ -22,12 +22,13 @@ class GradAllReducer:
         self.works = []
         self.lo = self.hi = None
         self.launched = []           # (lo, hi) ranges, for tests
+        self.force = False           # also all-reduce with a single rank (exercises the RCCL path)
 
     def _flush(self):
         if self.lo is None:
             return
         seg = self.flat[self.lo:self.hi]
-        if dist.is_initialized() and dist.get_world_size(self.group) > 1:
+        if dist.is_initialized() and (dist.get_world_size(self.group) > 1 or self.force):
             self.works.append(dist.all_reduce(seg, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
         self.launched.append((self.lo, self.hi))
         self.lo = self.hi = None

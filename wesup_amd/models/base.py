@@ -119,6 +119,7 @@ class BaseTrainer(ABC):
         self.rank = dist.get_rank(group)
         ddp.broadcast_parameters(self.model, 0, group)
         self.reducer = ddp.attach(self.model, group, bucket_bytes)
+        self.reducer.force = bool(self.kwargs.get('force_allreduce', False))
         if self.optimizer is not None and hasattr(self.optimizer, 'grad_scale'):
             self.optimizer.grad_scale = 1.0 / self.world_size
 
