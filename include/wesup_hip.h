@@ -113,6 +113,12 @@ int wesup_spmaps_to_labels(const float* sp_maps, int32_t* labels, int N, int HW,
 /* scatter-mean: sp_feat[b][r][c] = (1/area_r) sum_{p in row r} fm[b][p][c]   (torch.mm, models/wesup.py:283-285) */
 int wesup_sp_pool_fwd(const float* fm, const int32_t* pix_sorted, const int32_t* row_start,
                       float* sp_feat, int B, int HW, int ldf, int C, int Kmax, void* stream);
+/* fused upsample + scatter-mean: sp_feat[b][r][coff+c] = (1/area_r) sum_{p in row r} bilinear_ac(s[b], p)[c], s = side
+ * output [B][h][w][C] (C in {32,64,128,256}); equals wesup_upsample_fwd followed by wesup_sp_pool_fwd on that slice
+ * without materialising the (HW x 2112) feature map (models/wesup.py:254-261 + :283-285) */
+int wesup_sp_pool_upsample_fwd(const float* s, const int32_t* pix_sorted, const int32_t* row_start,
+                               float* sp_feat, int B, int h, int w, int H, int W, int C, int ldo, int coff,
+                               int Kmax, void* stream);
 /* dfm[b][p][c] = g[b][new_row[p]][c] / area[new_row[p]] */
 int wesup_sp_pool_bwd(const float* g, const int32_t* new_row, const int32_t* area_new, float* dfm,
                       int B, int HW, int ldf, int C, int Kmax, void* stream);

@@ -267,6 +267,21 @@ def test_sp_pool(ops, B, H, W, g, C):
         ref.backward(gup[b, :K])
         assert rel_err(dfm[b].reshape(H * W, C), fmc.grad.t()) < TOL
     assert torch.equal(out, ops.sp_pool_fwd(fm.to(d), m))          # bitwise reproducible
+    # fused upsample + scatter-mean forward == upsample_fwd followed by sp_pool_fwd
+    for (h, w, Cs, coff) in [(H, W, 32, 0), (H // 2, W // 2, 64, 64), (H // 4, W // 4, 128, 128), (max(1, H // 16), max(1, W // 16), 256, 512)]:
+        if coff + Cs > C:
+            continue
+        sl = rnd(B, h, w, Cs, seed=9).to(d)
+        fm2 = torch.zeros(B, H, W, C, device=d)
+        ops.upsample_fwd(sl, fm2, coff)
+        ref2 = ops.sp_pool_fwd(fm2, m)
+        got = torch.zeros(B, Kmax, C, device=d)
+        ops.sp_pool_upsample_fwd(sl, m, got, coff)
+        assert rel_err(got[..., coff:coff + Cs], ref2[..., coff:coff + Cs]) < 1e-5
+        assert float(got[..., :coff].abs().max() if coff else 0.0) == 0.0
+        got2 = torch.zeros(B, Kmax, C, device=d)
+        ops.sp_pool_upsample_fwd(sl, m, got2, coff)
+        assert torch.equal(got, got2)
     # fused pool-backward + upsample-backward == unfused
     for (h, w, Cs, coff) in [(H, W, 32, 0), (H // 2, W // 2, 64, 64), (max(1, H // 16), max(1, W // 16), 64, 128)]:
         if coff + Cs > C:

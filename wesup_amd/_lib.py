@@ -43,6 +43,7 @@ _SIGS = {
     'wesup_spmaps_to_labels': (c_int, 'ppiip'),
     'wesup_sp_pool_fwd': (c_int, 'ppppiiiiip'),
     'wesup_sp_pool_bwd': (c_int, 'ppppiiiiip'),
+    'wesup_sp_pool_upsample_fwd': (c_int, 'ppppiiiiiiiiip'),
     'wesup_paint_fwd': (c_int, 'pppiiiiip'),
     'wesup_classifier_fwd': (c_int, 'ppppiip'),
     'wesup_classifier_bwd_workspace_bytes': (c_size_t, 'ii'),

@@ -24,8 +24,21 @@ typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 __device__ float4 g_zero_page[16];      // 256 B of zeros, source of masked lanes
 
-__device__ __forceinline__ void glds16(const float* src, float* lds_wave_base) {
-    __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)lds_wave_base, 16, 0, 0);
+// LDS-DMA through inline asm: hipcc cannot prove that the ds_reads of the current tile do not alias the DMA
+// destination (same __shared__ array, runtime buffer index) and, for the builtin form, parks an s_waitcnt vmcnt(0)
+// right behind the DMA issue -- the whole DMA latency in front of the MFMA phase, every K-step.  An asm statement
+// is outside its wait bookkeeping (cdna_hip_programming.md 5.7): the only wait is glds_wait() placed by hand in front
+// of the barrier that ends the K-step.  M0 carries the wave-uniform LDS byte address and is restored.
+__device__ __forceinline__ void glds16(const float* src, unsigned lds_byte_addr_uniform) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(src), "s"(lds_byte_addr_uniform)
+                 : "memory");
+}
+__device__ __forceinline__ void glds_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ unsigned lds_addr(const float* p) {
+    return (unsigned)(unsigned long)(lptr_t)p;      // LDS byte offset of a pointer into __shared__ memory
 }
 
 struct NtParams {
@@ -39,6 +52,8 @@ struct NtParams {
     int H, W, Cin, cin_shift;
     int flags;
     int tiles_m, tiles_n;
+    int m_fastest;   // tile order inside an XCD's contiguous range
+    int stagger;     // s_sleep units (64 clk) for every second wave of blocks
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -66,7 +81,10 @@ __global__ __launch_bounds__(256, MINB) void gemm_nt_kernel(const NtParams p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nwg = p.tiles_m * p.tiles_n;
     const int lt = xcd_remap(blockIdx.x, nwg);
-    const int tile_n = lt % p.tiles_n, tile_m = lt / p.tiles_n;
+    // n fastest: the N-tiles of one pixel tile run together (activation rows shared through L2); m fastest: blocks of
+    // one weight slab run together (weights stay in L2) -- chosen per launch by which operand is the larger stream.
+    const int tile_n = p.m_fastest ? lt / p.tiles_m : lt % p.tiles_n;
+    const int tile_m = p.m_fastest ? lt % p.tiles_m : lt / p.tiles_n;
     const int m_blk = tile_m * BM, n_blk = tile_n * BN;
     const bool relu_in = p.flags & WESUP_RELU_IN;
     const float* zero = reinterpret_cast<const float*>(g_zero_page);
@@ -110,12 +128,13 @@ __global__ __launch_bounds__(256, MINB) void gemm_nt_kernel(const NtParams p) {
     }
 
     auto stage = [&](int kk, int buf) {
-        float* adst = As + buf * BM * BK + wave * 256;           // wave-uniform: rows 8*wave.. of pass 0
-        float* bdst = Bs + buf * BN * BK + wave * 256;
+        // wave-uniform LDS byte addresses: rows 8*wave.. of pass 0
+        const unsigned adst = __builtin_amdgcn_readfirstlane(lds_addr(As + buf * BM * BK + wave * 256));
+        const unsigned bdst = __builtin_amdgcn_readfirstlane(lds_addr(Bs + buf * BN * BK + wave * 256));
         if (MODE == 0) {
 #pragma unroll
             for (int i = 0; i < RA; ++i)
-                glds16(a_msk[i] ? p.A + a_off[i] + kk * BK : zero, adst + i * 32 * BK);
+                glds16(a_msk[i] ? p.A + a_off[i] + kk * BK : zero, adst + i * 32 * BK * 4);
         } else if (MODE == 1) {
             const int k0 = kk * BK;
             const int tap = k0 >> p.cin_shift;
@@ -123,16 +142,16 @@ __global__ __launch_bounds__(256, MINB) void gemm_nt_kernel(const NtParams p) {
             const int toff = ((tap / 3 - 1) * p.W + (tap % 3 - 1)) * p.Cin + ci0;
 #pragma unroll
             for (int i = 0; i < RA; ++i)
-                glds16(((a_msk[i] >> tap) & 1u) ? p.A + a_off[i] + toff : zero, adst + i * 32 * BK);
+                glds16(((a_msk[i] >> tap) & 1u) ? p.A + a_off[i] + toff : zero, adst + i * 32 * BK * 4);
         } else {
             const int tap = kk * 8 + schunk;                     // logical chunk = tap (4 channels each)
             const int toff = ((tap / 3 - 1) * p.W + (tap % 3 - 1)) * 4;
 #pragma unroll
             for (int i = 0; i < RA; ++i)
-                glds16((tap < 9 && ((a_msk[i] >> tap) & 1u)) ? p.A + a_off[i] + toff : zero, adst + i * 32 * BK);
+                glds16((tap < 9 && ((a_msk[i] >> tap) & 1u)) ? p.A + a_off[i] + toff : zero, adst + i * 32 * BK * 4);
         }
 #pragma unroll
-        for (int j = 0; j < RB; ++j) glds16(b_ok[j] ? p.Bw + b_off[j] + kk * BK : zero, bdst + j * 32 * BK);
+        for (int j = 0; j < RB; ++j) glds16(b_ok[j] ? p.Bw + b_off[j] + kk * BK : zero, bdst + j * 32 * BK * 4);
     };
 
     f32x16 acc[WM][WN];
@@ -149,7 +168,14 @@ __global__ __launch_bounds__(256, MINB) void gemm_nt_kernel(const NtParams p) {
     const int nk = p.K / BK;
 
     stage(0, 0);
-    __syncthreads();                // vmcnt(0) for the LDS-DMA + barrier
+    glds_wait();
+    __syncthreads();
+    // Two blocks share a CU and run the same program: started together they stay in lockstep and their non-MFMA
+    // phases (DMA issue, barrier) coincide.  Delaying every second resident block by about half a K-step lets one
+    // block's MFMA phase cover the other's staging phase (MI355X_MICROARCH.md, 'Two waves per SIMD', item 9).
+    if (p.stagger > 0 && ((blockIdx.x >> 8) & 1)) {
+        for (int z = 0; z < p.stagger; ++z) __builtin_amdgcn_s_sleep(16);
+    }
     int cur = 0;
     for (int kk = 0; kk < nk; ++kk) {
         if (kk + 1 < nk) stage(kk + 1, cur ^ 1);
@@ -176,7 +202,8 @@ __global__ __launch_bounds__(256, MINB) void gemm_nt_kernel(const NtParams p) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
                 }
         }
-        __syncthreads();            // every wave done reading buf[cur]; next tile landed in buf[cur^1]
+        glds_wait();                // this wave's DMA for the next tile has landed ...
+        __syncthreads();            // ... and so has everybody's; every wave is done reading buf[cur]
         cur ^= 1;
     }
 
@@ -235,6 +262,14 @@ template <int BM, int BN, int WM, int WN, int MODE, int MINB>
 static int launch_nt(NtParams p, hipStream_t st) {
     p.tiles_m = ceil_div(p.M, BM);
     p.tiles_n = ceil_div(p.N, BN);
+    {
+        static int ord = -1;
+        if (ord < 0) { const char* e = getenv("WESUP_TILE_ORDER"); ord = e ? atoi(e) : 0; }
+        p.m_fastest = ord;
+        static int stg = -1;
+        if (stg < 0) { const char* e = getenv("WESUP_STAGGER"); stg = e ? atoi(e) : 0; }
+        p.stagger = stg;
+    }
     const size_t lds = (size_t)2 * (BM + BN) * BK * sizeof(float);
     hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, WM, WN, MODE, MINB>), dim3(p.tiles_m * p.tiles_n), dim3(256), lds, st, p);
     WESUP_CHECK_LAUNCH();
@@ -356,12 +391,13 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnParams p) {
     const int dh2 = qb / 3 - 1, dw2 = qb % 3 - 1;
 
     auto stage = [&](int k0, int buf) {
-        float* adst = As + buf * BK * BM + wave * 256;       // the image is linear in tid: 4*tid floats per pass
-        float* bdst = Bs + buf * BK * BN + wave * 256;
+        // the image is linear in tid (4*tid floats per pass): wave-uniform LDS byte addresses
+        const unsigned adst = __builtin_amdgcn_readfirstlane(lds_addr(As + buf * BK * BM + wave * 256));
+        const unsigned bdst = __builtin_amdgcn_readfirstlane(lds_addr(Bs + buf * BK * BN + wave * 256));
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             const int k = k0 + ra_row + RPA * i;
-            glds16((a_col_ok && k < k_end) ? p.A + (long)k * p.lda + m_blk + 4 * qa : zero, adst + i * 1024);
+            glds16((a_col_ok && k < k_end) ? p.A + (long)k * p.lda + m_blk + 4 * qa : zero, adst + i * 4096);
         }
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
@@ -384,7 +420,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnParams p) {
                         src = p.Bx + (long)(k + dh2 * p.W + dw2) * 4;
                 }
             }
-            glds16(src, bdst + i * 1024);
+            glds16(src, bdst + i * 4096);
         }
     };
 
@@ -402,6 +438,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnParams p) {
     const bool relu_b = p.relu_b;
 
     if (nk > 0) stage(k_begin, 0);
+    glds_wait();
     __syncthreads();
     int cur = 0;
     for (int kk = 0; kk < nk; ++kk) {
@@ -424,6 +461,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnParams p) {
                 for (int j = 0; j < WN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
         }
+        glds_wait();
         __syncthreads();
         cur ^= 1;
     }
@@ -487,10 +525,23 @@ static TnPlan plan_tn(int M, int N, int K, int taps) {
     pl.taps = taps;
     const int tiles = pl.tiles_m * pl.tiles_n * taps;
     const int ksteps = ceil_div(K, BK);
-    int S = ceil_div(768, tiles);
+    // Split-K factor: the grid (tiles x S blocks, all of equal cost) should fill the resident block slots of the chip
+    // a whole number of times -- 2 blocks/CU for the 128x128 tile (64 KiB LDS each), 4 for 64x64 -- so that no
+    // partial round is left at the end.  Among 1..3 rounds pick the fullest; every split keeps >= 8 K-steps.
+    const int slots = 256 * (big ? 2 : 4);
     const int maxS = ksteps / 8 > 0 ? ksteps / 8 : 1;
-    if (S > maxS) S = maxS;
-    if (S < 1) S = 1;
+    int S = 1;
+    double best = -1.0;
+    for (int rounds = 1; rounds <= 3; ++rounds) {
+        int cand = (slots * rounds) / tiles;
+        if (cand < 1) cand = 1;
+        if (cand > maxS) cand = maxS;
+        const int blocks = tiles * cand;
+        const int r = ceil_div(blocks, slots);
+        const double fill = (double)blocks / ((double)r * slots);
+        // prefer fuller rounds; among equal fills prefer fewer splits (less slab traffic)
+        if (fill > best + 0.02) { best = fill; S = cand; }
+    }
     const int steps_per = ceil_div(ksteps, S);
     pl.k_per_split = steps_per * BK;
     pl.S = ceil_div(K, pl.k_per_split);

@@ -312,6 +312,100 @@ extern "C" int wesup_sp_pool_fwd(const float* fm, const int32_t* pix_sorted, con
     return WESUP_OK;
 }
 
+// ------------------------------------------------------------------ scatter-mean of the UPSAMPLED side output, fused
+// sp_feat[b][r][coff+c] = (1/area_r) * sum_{p in row r} bilinear(s[b], p)[c]  -- the same value wesup_upsample_fwd +
+// wesup_sp_pool_fwd produce, without ever writing the (HW x 2112) feature map: s (the side conv output at its
+// native h x w resolution, a few MB, L2/MALL resident) is sampled on the fly.  One wave per row; LPP = C/4 lanes
+// cover the channels of one pixel, so a wave walks 64/LPP pixels at a time; lane groups are combined by a fixed
+// xor-shuffle tree (deterministic).  Pixel order inside a group is ascending list order.
+struct Lerp2 {
+    int i0, i1;
+    float l0, l1;
+};
+__device__ __forceinline__ Lerp2 lerp2_of(int dst, float scale, int in) {
+    Lerp2 r;
+    const float src = scale * (float)dst;
+    r.i0 = min((int)src, in - 1);
+    r.i1 = r.i0 + ((r.i0 < in - 1) ? 1 : 0);
+    r.l1 = fminf(fmaxf(src - (float)r.i0, 0.f), 1.f);
+    r.l0 = 1.f - r.l1;
+    return r;
+}
+template <int LPP>
+__global__ __launch_bounds__(256) void sp_pool_up_fwd_kernel(const float* __restrict__ s, const int32_t* __restrict__ pix_sorted,
+                                                             const int32_t* __restrict__ row_start, float* __restrict__ sp_feat,
+                                                             int h, int w, int H, int W, FastDiv dW, int ldo, int coff, int Kmax,
+                                                             float sh, float sw) {
+    constexpr int PPW = 64 / LPP;
+    constexpr int C = LPP * 4;
+    const int b = blockIdx.y;
+    const int r = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (r >= Kmax) return;
+    const int lane = threadIdx.x & 63;
+    const int grp = lane / LPP, cl = lane % LPP;
+    const int HW = H * W;
+    const int j0 = row_start[(long)b * (Kmax + 1) + r], j1 = row_start[(long)b * (Kmax + 1) + r + 1];
+    const float inv = (j1 > j0) ? 1.f / (float)(j1 - j0) : 0.f;
+    const int32_t* list = pix_sorted + (long)b * HW;
+    const float* base = s + (long)b * h * w * C + 4 * cl;
+    const bool ident = (h == H && w == W);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int j = j0 + grp; j < j1; j += PPW) {
+        const int p = list[j];
+        float4 v;
+        if (ident) {
+            v = ld4(base + (long)p * C);
+        } else {
+            const int Y = fast_div(p, dW), X = p - Y * W;
+            const Lerp2 ly = lerp2_of(Y, sh, h), lx = lerp2_of(X, sw, w);
+            const float4 v00 = ld4(base + ((long)ly.i0 * w + lx.i0) * C);
+            const float4 v01 = ld4(base + ((long)ly.i0 * w + lx.i1) * C);
+            const float4 v10 = ld4(base + ((long)ly.i1 * w + lx.i0) * C);
+            const float4 v11 = ld4(base + ((long)ly.i1 * w + lx.i1) * C);
+            v.x = ly.l0 * (lx.l0 * v00.x + lx.l1 * v01.x) + ly.l1 * (lx.l0 * v10.x + lx.l1 * v11.x);
+            v.y = ly.l0 * (lx.l0 * v00.y + lx.l1 * v01.y) + ly.l1 * (lx.l0 * v10.y + lx.l1 * v11.y);
+            v.z = ly.l0 * (lx.l0 * v00.z + lx.l1 * v01.z) + ly.l1 * (lx.l0 * v10.z + lx.l1 * v11.z);
+            v.w = ly.l0 * (lx.l0 * v00.w + lx.l1 * v01.w) + ly.l1 * (lx.l0 * v10.w + lx.l1 * v11.w);
+        }
+        acc.x = fmaf(v.x, inv, acc.x);
+        acc.y = fmaf(v.y, inv, acc.y);
+        acc.z = fmaf(v.z, inv, acc.z);
+        acc.w = fmaf(v.w, inv, acc.w);
+    }
+#pragma unroll
+    for (int off = LPP; off < 64; off <<= 1) {
+        acc.x += __shfl_xor(acc.x, off);
+        acc.y += __shfl_xor(acc.y, off);
+        acc.z += __shfl_xor(acc.z, off);
+        acc.w += __shfl_xor(acc.w, off);
+    }
+    if (grp == 0) st4(sp_feat + ((long)b * Kmax + r) * ldo + coff + 4 * cl, acc);
+}
+extern "C" int wesup_sp_pool_upsample_fwd(const float* s, const int32_t* pix_sorted, const int32_t* row_start,
+                                          float* sp_feat, int B, int h, int w, int H, int W, int C, int ldo, int coff,
+                                          int Kmax, void* stream) {
+    if (!s || !pix_sorted || !row_start || !sp_feat || B <= 0 || h <= 0 || w <= 0 || H <= 0 || W <= 0 || Kmax <= 0 ||
+        (ldo % 4) || (coff % 4) || coff + C > ldo)
+        return WESUP_ERR_INVALID;
+    const dim3 grid(ceil_div(Kmax, 4), B);
+    const float sh = H > 1 ? (float)(h - 1) / (float)(H - 1) : 0.f, sw = W > 1 ? (float)(w - 1) / (float)(W - 1) : 0.f;
+    const FastDiv dW = make_fastdiv(W);
+    hipStream_t st = (hipStream_t)stream;
+#define WESUP_LAUNCH_PU(L)                                                                                              \
+    hipLaunchKernelGGL(sp_pool_up_fwd_kernel<L>, grid, dim3(256), 0, st, s, pix_sorted, row_start, sp_feat, h, w, H, W, \
+                       dW, ldo, coff, Kmax, sh, sw)
+    switch (C) {
+        case 32: WESUP_LAUNCH_PU(8); break;
+        case 64: WESUP_LAUNCH_PU(16); break;
+        case 128: WESUP_LAUNCH_PU(32); break;
+        case 256: WESUP_LAUNCH_PU(64); break;
+        default: return WESUP_ERR_INVALID;
+    }
+#undef WESUP_LAUNCH_PU
+    WESUP_CHECK_LAUNCH();
+    return WESUP_OK;
+}
+
 // ------------------------------------------------------------------ scatter-mean backward (row broadcast)
 __global__ void sp_pool_bwd_kernel(const float* __restrict__ g, const int32_t* __restrict__ new_row,
                                    const int32_t* __restrict__ area, float* __restrict__ dfm, long HW, int ldf, int C4,

@@ -83,6 +83,7 @@ class WesupEngine:
         self._packed = None
         self.ctx = None
         self.fuse_pool_bwd = True        # skip the (B,HW,2112) gradient tensor: pool-bwd fused into upsample-bwd
+        self.fuse_pool_fwd = True        # skip the (B,HW,2112) feature map: scatter-mean fused with the upsample
         self.two_streams = True          # side branch on its own HIP stream
         self._side_stream = None
         self._wgrad_stream = None
@@ -139,13 +140,17 @@ class WesupEngine:
             for l, (ci, co) in enumerate(CONV_CH):
                 b.dims.append((h, w))
                 b.y.append(torch.empty(B, h, w, co, **f32))
-                b.s.append(None if (h, w) == (H, W) else torch.empty(B, h, w, co // 2, **f32))
+                full = (h, w) == (H, W)
+                b.s.append(None if (full and not self.fuse_pool_fwd) else torch.empty(B, h, w, co // 2, **f32))
                 if POOL_AFTER[l]:
                     h, w = h // 2, w // 2
                     b.yp.append(torch.empty(B, h, w, co, **f32))
                 else:
                     b.yp.append(None)
-            b.fm = torch.empty(B, H, W, FM_CHANNELS, **f32)
+            # the (B,HW,2112) feature map only exists on the unfused path (or when somebody asks for it)
+            b.fm = None if self.fuse_pool_fwd else torch.empty(B, H, W, FM_CHANNELS, **f32)
+            b.fm_valid = False
+            b.shape = (B, H, W)
             R = B * Kmax
             b.sp_in = torch.empty(B, Kmax, FM_CHANNELS, **f32)
             b.h1 = torch.empty(R, 1024, **f32)
@@ -158,8 +163,8 @@ class WesupEngine:
         if train and not b.train:
             R = B * Kmax
             b.G = [torch.empty_like(y) for y in b.y]
-            b.ds = [None if s is None and not self.fuse_pool_bwd else torch.empty(B, hh, ww, co // 2, **f32)
-                    for s, (hh, ww), (ci, co) in zip(b.s, b.dims, CONV_CH)]
+            b.ds = [None if ((hh, ww) == (H, W) and not self.fuse_pool_bwd) else torch.empty(B, hh, ww, co // 2, **f32)
+                    for (hh, ww), (ci, co) in zip(b.dims, CONV_CH)]
             b.dxp = [None if yp is None else torch.empty(yp.shape[0], yp.shape[1], yp.shape[2], CONV_CH[l + 1][0], **f32)
                      for l, yp in enumerate(b.yp)]
             b.dfm = None if self.fuse_pool_bwd else torch.empty(B, H, W, FM_CHANNELS, **f32)
@@ -211,24 +216,31 @@ class WesupEngine:
         T = self.timer
         ops.pack_input(img, b.x0)
         cur = b.x0
-        fm2d = b.fm.view(B * H * W, FM_CHANNELS)
+        fused = self.fuse_pool_fwd
+        b.fm_valid = not fused
+        fm2d = None if fused else b.fm.view(B * H * W, FM_CHANNELS)
         for l, (ci, co) in enumerate(CONV_CH):
             h, w = b.dims[l]
             idx, off = CONV_IDX[l], SIDE_OFF[l]
             tok = T.begin('conv3x3_fwd')
             ops.conv3x3_fwd(cur, pk.wf[l], p[f'backbone.{idx}.bias'], co, relu_in=(l > 0), out=b.y[l])
             T.end(tok, 2.0 * B * h * w * (3 if l == 0 else ci) * co * 9)
-            # side branch of this layer: 1x1 conv on the pre-ReLU tap + upsample into fm's channel slice
+            # side branch of this layer: 1x1 conv on the pre-ReLU tap, then either the fused upsample+scatter-mean
+            # straight into the superpixel feature slice, or upsample into fm's channel slice
             with self._OnSide(self):
                 y2d = b.y[l].view(B * h * w, co)
                 ws = p[f'side_conv{off}.weight'].view(co // 2, co)
                 tok = T.begin('side_fwd')
-                if b.s[l] is None:       # full resolution: the side conv writes its channel slice of fm directly
+                if b.s[l] is None:       # unfused, full resolution: the side conv writes its slice of fm directly
                     ops.gemm_nt(y2d, ws, p[f'side_conv{off}.bias'], out=fm2d[:, off:off + co // 2])
                 else:
                     ops.gemm_nt(y2d, ws, p[f'side_conv{off}.bias'], out=b.s[l].view(B * h * w, co // 2))
                 T.end(tok, 2.0 * B * h * w * co * (co // 2))
-                if b.s[l] is not None:
+                if fused:
+                    tok = T.begin('sp_pool_up_fwd')
+                    ops.sp_pool_upsample_fwd(b.s[l], meta, b.sp_in, off)
+                    T.end(tok, 4.0 * B * (h * w * (co // 2) + H * W + Kmax * (co // 2)))
+                elif b.s[l] is not None:
                     tok = T.begin('upsample_fwd')
                     ops.upsample_fwd(b.s[l], b.fm, off)
                     T.end(tok, 4.0 * B * H * W * (co // 2))
@@ -238,9 +250,10 @@ class WesupEngine:
             else:
                 cur = b.y[l]
         self._join_side()
-        tok = T.begin('sp_pool_fwd')
-        ops.sp_pool_fwd(b.fm, meta, out=b.sp_in)
-        T.end(tok, 4.0 * B * (FM_CHANNELS * H * W + H * W + Kmax * FM_CHANNELS))
+        if not fused:
+            tok = T.begin('sp_pool_fwd')
+            ops.sp_pool_fwd(b.fm, meta, out=b.sp_in)
+            T.end(tok, 4.0 * B * (FM_CHANNELS * H * W + H * W + Kmax * FM_CHANNELS))
         R = B * Kmax
         tok = T.begin('mlp_fwd')
         ops.gemm_nt(b.sp_in.view(R, FM_CHANNELS), p['fc_layers.0.weight'], p['fc_layers.0.bias'], out=b.h1, flags=ops.RELU_OUT)
@@ -255,9 +268,20 @@ class WesupEngine:
         return b.feats.view(B, Kmax, self.D), sp_pred3, b.pred
 
     def feature_maps(self):
-        """(B,H,W,2112) pixel-major feature maps of the last forward (models/wesup.py:280)."""
+        """(B,H,W,2112) pixel-major feature maps of the last forward (models/wesup.py:280).  On the fused path they
+        are never needed by the step itself; they are materialised here on demand from the saved side outputs."""
+        b = None
         for b in self._bufs.values():
             pass
+        if b is None:
+            return None
+        if not b.fm_valid:
+            B, H, W = b.shape
+            if b.fm is None:
+                b.fm = torch.empty(B, H, W, FM_CHANNELS, dtype=torch.float32, device=self.device)
+            for l, off in enumerate(SIDE_OFF):
+                ops.upsample_fwd(b.s[l], b.fm, off)
+            b.fm_valid = True
         return b.fm
 
     # ------------------------------------------------------------------ backward

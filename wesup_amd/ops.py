@@ -300,6 +300,16 @@ def sp_pool_fwd(fm, meta, C=None, out=None):
     return out
 
 
+def sp_pool_upsample_fwd(s, meta, out, coff):
+    """Fused upsample + scatter-mean of one side output s (B,h,w,C) into out[..., coff:coff+C] (out: (B,Kmax,ldo))."""
+    _chk(s, name='s'); _chk(out, name='out')
+    B, h, w, C = s.shape
+    assert out.shape[:2] == (B, meta.Kmax) and B == meta.B and coff + C <= out.shape[2]
+    _lib.call('wesup_sp_pool_upsample_fwd', _p(s), _p(meta.pix_sorted), _p(meta.row_start), _p(out), B, h, w, meta.H, meta.W,
+              C, out.shape[2], coff, meta.Kmax, _stream())
+    return out
+
+
 def sp_pool_bwd(g, meta, out=None):
     _chk(g, name='g')
     B, Kmax, C = g.shape
