@@ -108,6 +108,37 @@ def main():
         elapsed = float(t.item())
     loss_last = trainer.tracker.history['loss'][-1]
 
+    # ---- untimed extras for the roofline report (every rank runs them so that collectives stay matched)
+    iso, pool_ms = None, None
+    if not args.no_kernel_timing:
+        eng = trainer.model.engine
+        timed = timer.collect()                       # keep the timed-region numbers
+        timed = {k: v for k, v in timed.items()}
+        timer.reset()
+        eng.two_streams = False                       # kernels alone on the GPU: isolated per-launch durations
+        timer.enabled = True
+        for i in range(2):
+            step(i)
+        torch.cuda.synchronize()
+        iso = dict(timer.collect())
+        timer.enabled = False
+        eng.two_streams = True
+        timer.reset()
+        timer.totals = timed
+        if rank == 0:
+            from wesup_amd import ops
+            fm = eng.feature_maps()                   # materialise the (B,H,W,2112) map of the last step
+            meta = trainer.model._last_meta
+            outp = torch.empty(B, meta.Kmax, fm.shape[-1], device=dev)
+            ops.sp_pool_fwd(fm, meta, out=outp)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(5):
+                ops.sp_pool_fwd(fm, meta, out=outp)
+            e1.record()
+            torch.cuda.synchronize()
+            pool_ms = e0.elapsed_time(e1) / 5
+
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = world * B * args.steps / elapsed
@@ -147,14 +178,34 @@ def main():
                 out['roofline_wgrad'] = {'bound': 'mfma', 'kernel': 'gemm_tn_kernel + reduce (conv3x3 wgrad)',
                                          'achieved': round(a, 2), 'peak': PEAK_MFMA_F32_TFLOPS, 'unit': 'TFLOP/s',
                                          'frac': round(a / PEAK_MFMA_F32_TFLOPS, 4)}
-            if 'sp_pool_fwd' in tot:
-                ms, n, by = tot['sp_pool_fwd']
-                a = by / (ms * 1e-3) / 1e9
-                out['roofline_scatter_mean'] = {'bound': 'hbm', 'kernel': 'sp_pool_fwd_kernel (superpixel scatter-mean)',
-                                                'achieved': round(a, 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
-                                                'frac': round(a / PEAK_HBM_GBS, 4), 'traffic': None,
-                                                'avg_launch_us': round(ms / n * 1e3, 2)}
+            out['roofline']['note'] = ('HIP-event time of the launches inside the timed region, where the side-branch and '
+                                       'wgrad streams run concurrently; roofline_isolated has the same kernels alone')
             out['kernels'] = kern
+            if iso is not None:
+                def tf(tags):
+                    ms = sum(iso[t][0] for t in tags if t in iso)
+                    fl = sum(iso[t][2] for t in tags if t in iso)
+                    return round(fl / (ms * 1e-3) / 1e12, 2) if ms > 0 else None
+                a, wgr = tf(('conv3x3_fwd', 'conv3x3_dgrad')), tf(('conv3x3_wgrad',))
+                out['roofline_isolated'] = {
+                    'how': '2 extra untimed steps with single-stream scheduling, HIP events per launch',
+                    'conv3x3_fwd_dgrad': {'bound': 'mfma', 'achieved': a, 'peak': PEAK_MFMA_F32_TFLOPS, 'unit': 'TFLOP/s',
+                                          'frac': round(a / PEAK_MFMA_F32_TFLOPS, 4)},
+                    'conv3x3_wgrad': {'bound': 'mfma', 'achieved': wgr, 'peak': PEAK_MFMA_F32_TFLOPS, 'unit': 'TFLOP/s',
+                                      'frac': round(wgr / PEAK_MFMA_F32_TFLOPS, 4)},
+                }
+            if pool_ms is not None:
+                by = 4.0 * B * (2112 * H * W + H * W + g * g * 2112)
+                a = by / (pool_ms * 1e-3) / 1e9
+                # traffic: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, KiB units, gfx950 FETCH x2
+                # correction) on tools/pool_micro.py at this shape: profiles/r01_pmc_summary.csv
+                out['roofline_scatter_mean'] = {
+                    'bound': 'hbm', 'kernel': 'sp_pool_fwd_kernel (superpixel scatter-mean over the materialised '
+                                              '(HW x 2112) feature map; the step itself uses the fused upsample+scatter-mean)',
+                    'achieved': round(a, 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': round(a / PEAK_HBM_GBS, 4),
+                    'frac_of_measured_copy_6290': round(a / 6290.0, 4),
+                    'traffic': (3813303.7 * 2 + 19008.0) * 1024 if (B, H, g) == (4, 480, 24) else None,
+                    'avg_launch_us': round(pool_ms * 1e3, 2), 'algorithmic_bytes': by}
         if world == 1 and not args.no_cpu_baseline:
             v, cores, sample = orc.time_cpu_baseline(iters=2, warmup=1)
             out['cpu_baseline'] = {'value': round(v, 4), 'unit': 'images/s', 'cores': cores, 'kind': 'port', 'sample': sample}

@@ -277,3 +277,36 @@ def test_full_size_properties():
     loss = trainer.compute_loss(pred, target, metrics={})
     (2.0 * loss).backward()
     assert rel_err(model._flat_grad, 2.0 * g1) < 1e-5
+
+
+@pytest.mark.parametrize('H,W,g,B', [(800, 800, 39, 2), (1024, 1024, 55, 2)])
+def test_large_configs_properties(H, W, g, B):
+    """BASELINE configs[3] (CRAG 800x800, ~1500 SP) and configs[4] (1024x1024, 3025 SP) shapes, reduced batch:
+    size-independent properties of one full training iteration (the oracle needs minutes per image here)."""
+    from oracle import wesup_oracle as orc
+    from wesup_amd import synth
+    d = torch.device('cuda:0')
+    trainer = make_trainer(orc.make_weights(0, feat_scale=0.05), max_superpixels=g * g)
+    trainer.tracker.train()
+    imgs, labs, pts, pix = synth.make_batch(2, B, H, W, g)
+    data = (torch.from_numpy(imgs).to(d), torch.from_numpy(pix).to(d), torch.from_numpy(pts).to(d), torch.from_numpy(labs).to(d))
+    before = trainer.model._flat.clone() if trainer.model._flat is not None else None
+    trainer.train_one_iteration('train', *data)
+    h = trainer.tracker.history
+    assert np.isfinite(h['loss'][0]) and 0.0 < h['loss'][0] < 10.0
+    assert 0.15 < h['labeled_sp_ratio'][0] < 0.25            # 20 % point-labelled superpixels
+    assert 0.0 <= h['accuracy'][0] <= 1.0 and 0.0 <= h['dice'][0] <= 1.0
+    meta = trainer.model._last_meta
+    meta.check()
+    assert int(meta.n_sp.min()) == g * g and int(meta.area_new.sum()) == B * H * W
+    gflat = trainer.model._flat_grad
+    assert bool(torch.isfinite(gflat).all()) and float(gflat.abs().sum()) > 0
+    assert not torch.equal(before, trainer.model._flat)     # SGD moved the weights
+    # determinism at full size: same batch, fresh trainer -> identical loss bits
+    t2 = make_trainer(orc.make_weights(0, feat_scale=0.05), max_superpixels=g * g)
+    t2.tracker.train()
+    t2.train_one_iteration('train', *data)
+    assert t2.tracker.history['loss'][0] == h['loss'][0]
+    assert torch.equal(t2.model._flat_grad, gflat)
+    trainer.model.engine.release_buffers(); t2.model.engine.release_buffers()
+    torch.cuda.empty_cache()
