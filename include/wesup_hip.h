@@ -36,6 +36,11 @@ extern "C" {
 #define WESUP_MASK 8       /* result := mask > 0 ? result : 0 (ReLU backward) */
 
 int wesup_abi_version(void);
+/* debug, host-synchronous: shader clock (MHz) held during the main loop of the last wesup_gemm_nt / conv3x3 fwd /
+ * dgrad launch (s_memtime / s_memrealtime of block 0) */
+int wesup_debug_clock(double* mhz_out /* host */);
+/* debug, host-synchronous: per-block {start, loop start, loop end, end} timestamps (100 MHz ticks) of NT launches */
+int wesup_debug_set_trace(void* device_buf);
 const char* wesup_strerror(int code);
 
 /* ------------------------------------------------------------------ layout packing

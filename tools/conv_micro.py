@@ -30,3 +30,10 @@ ev[1].record()
 torch.cuda.synchronize()
 ms = ev[0].elapsed_time(ev[1]) / reps
 print(f'{which} B{B} {H}x{W} {Ci}->{Co}: {ms*1e3:.1f} us  {2.0*B*H*W*Ci*Co*9/ms/1e9:.1f} TFLOP/s')
+
+import ctypes
+from wesup_amd import _lib
+mhz = ctypes.c_double(0.0)
+_lib.load().wesup_debug_clock(ctypes.byref(mhz))
+if which != 'wgrad':
+    print(f'  in-kernel clock of the last launch: {mhz.value:.0f} MHz -> fp32 MFMA peak at that clock {157.3 * mhz.value / 2400:.1f} TFLOP/s')

@@ -1,0 +1,30 @@
+"""Per-block timeline of one NT GEMM / conv launch (debug trace in gemm.hip): where does a tile spend its time?"""
+import sys, os, ctypes
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from wesup_amd import ops, _lib
+d = torch.device('cuda:0')
+lib = _lib.load()
+def run(name, fn, nblocks):
+    buf = torch.zeros(nblocks * 4, dtype=torch.int64, device=d)
+    fn(); torch.cuda.synchronize()
+    lib.wesup_debug_set_trace(ctypes.c_void_p(buf.data_ptr()))
+    fn(); torch.cuda.synchronize()
+    lib.wesup_debug_set_trace(None)
+    t = buf.cpu().numpy().reshape(nblocks, 4).astype(np.float64) * 0.01    # us
+    t0 = t[:, 0].min()
+    st, ls, le, en = (t[:, i] - t0 for i in range(4))
+    print(f'{name}: blocks {nblocks}  kernel span {en.max():.1f} us')
+    print(f'   block start     : p0 {st.min():.1f} p50 {np.median(st):.1f} p90 {np.percentile(st, 90):.1f} max {st.max():.1f}')
+    print(f'   prologue (start->loop) p50 {np.median(ls - st):.2f} max {(ls - st).max():.2f}')
+    print(f'   main loop       : p10 {np.percentile(le - ls, 10):.1f} p50 {np.median(le - ls):.1f} p90 {np.percentile(le - ls, 90):.1f} max {(le - ls).max():.1f}')
+    print(f'   epilogue        : p50 {np.median(en - le):.2f} max {(en - le).max():.2f}')
+    print(f'   block end       : p10 {np.percentile(en, 10):.1f} p50 {np.median(en):.1f} p90 {np.percentile(en, 90):.1f} max {en.max():.1f}')
+    first = st < 1.0
+    print(f'   first-wave blocks: {first.sum()}  their loop p50 {np.median((le - ls)[first]):.1f}; later blocks loop p50 {np.median((le - ls)[~first]) if (~first).any() else 0:.1f}')
+M, N, K = 32768, 256, 2304
+A = torch.randn(M, K, device=d); B = torch.randn(N, K, device=d); C = torch.empty(M, N, device=d)
+run('gemm 512 tiles K=2304', lambda: ops.gemm_nt(A, B, None, out=C), 512)
+x = torch.randn(4, 120, 120, 256, device=d); w = torch.randn(256, 256, 3, 3, device=d) * 0.02
+wf, _ = ops.pack_conv3x3_weight(w, need_dgrad=False); y = torch.empty(4, 120, 120, 256, device=d); bias = torch.zeros(256, device=d)
+run('conv fwd L6 (900 tiles)', lambda: ops.conv3x3_fwd(x, wf, bias, 256, True, out=y), 900)

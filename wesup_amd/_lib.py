@@ -20,6 +20,8 @@ c_size_t = ctypes.c_size_t
 # name -> (restype, [argtypes]);  'p' pointer, 'i' int, 'f' float, 'z' size_t
 _SIGS = {
     'wesup_abi_version': (c_int, ''),
+    'wesup_debug_clock': (c_int, 'p'),
+    'wesup_debug_set_trace': (c_int, 'p'),
     'wesup_strerror': (ctypes.c_char_p, 'i'),
     'wesup_pack_input': (c_int, 'ppiiip'),
     'wesup_conv3x3_kpad': (c_int, 'i'),

@@ -23,6 +23,11 @@
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 __device__ float4 g_zero_page[16];      // 256 B of zeros, source of masked lanes
+// clock probe: block 0 of the last NT launch leaves {shader cycles, 100 MHz ticks} of its main loop here; read by
+// wesup_debug_clock().  Two scalar clock reads per block, outside the K-loop; nothing is computed from them.
+__device__ unsigned long long g_clock_probe[2];
+// optional per-block trace (debug): when set, every NT block stores {start, loop start, loop end, end} in 100 MHz ticks
+__device__ unsigned long long* g_trace = nullptr;
 
 // LDS-DMA through inline asm: hipcc cannot prove that the ds_reads of the current tile do not alias the DMA
 // destination (same __shared__ array, runtime buffer index) and, for the builtin form, parks an s_waitcnt vmcnt(0)
@@ -54,6 +59,7 @@ struct NtParams {
     int tiles_m, tiles_n;
     int m_fastest;   // tile order inside an XCD's contiguous range
     int stagger;     // s_sleep units (64 clk) for every second wave of blocks
+    int prio;        // experiment: 1 = raise priority outside the MFMA phase, 2 = inside it
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -79,6 +85,7 @@ __global__ __launch_bounds__(256, MINB) void gemm_nt_kernel(const NtParams p) {
     float* Bs = smem + 2 * BM * BK;         // [2][BN][BK]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const unsigned long long tr0 = __builtin_amdgcn_s_memrealtime();
     const int nwg = p.tiles_m * p.tiles_n;
     const int lt = xcd_remap(blockIdx.x, nwg);
     // n fastest: the N-tiles of one pixel tile run together (activation rows shared through L2); m fastest: blocks of
@@ -132,6 +139,13 @@ __global__ __launch_bounds__(256, MINB) void gemm_nt_kernel(const NtParams p) {
         const unsigned adst = __builtin_amdgcn_readfirstlane(lds_addr(As + buf * BM * BK + wave * 256));
         const unsigned bdst = __builtin_amdgcn_readfirstlane(lds_addr(Bs + buf * BN * BK + wave * 256));
         if (MODE == 0) {
+            if (p.stagger == 99) {      // diagnostic: no predication at all (valid only for full tiles)
+#pragma unroll
+                for (int i = 0; i < RA; ++i) glds16(p.A + a_off[i] + kk * BK, adst + i * 32 * BK * 4);
+#pragma unroll
+                for (int j = 0; j < RB; ++j) glds16(p.Bw + b_off[j] + kk * BK, bdst + j * 32 * BK * 4);
+                return;
+            }
 #pragma unroll
             for (int i = 0; i < RA; ++i)
                 glds16(a_msk[i] ? p.A + a_off[i] + kk * BK : zero, adst + i * 32 * BK * 4);
@@ -170,6 +184,7 @@ __global__ __launch_bounds__(256, MINB) void gemm_nt_kernel(const NtParams p) {
     stage(0, 0);
     glds_wait();
     __syncthreads();
+    const unsigned long long clk0 = __builtin_amdgcn_s_memtime(), rt0 = __builtin_amdgcn_s_memrealtime();
     // Two blocks share a CU and run the same program: started together they stay in lockstep and their non-MFMA
     // phases (DMA issue, barrier) coincide.  Delaying every second resident block by about half a K-step lets one
     // block's MFMA phase cover the other's staging phase (MI355X_MICROARCH.md, 'Two waves per SIMD', item 9).
@@ -177,8 +192,12 @@ __global__ __launch_bounds__(256, MINB) void gemm_nt_kernel(const NtParams p) {
         for (int z = 0; z < p.stagger; ++z) __builtin_amdgcn_s_sleep(16);
     }
     int cur = 0;
+    const int prio = p.prio;
     for (int kk = 0; kk < nk; ++kk) {
+        if (prio == 1) __builtin_amdgcn_s_setprio(3);
         if (kk + 1 < nk) stage(kk + 1, cur ^ 1);
+        if (prio == 1) __builtin_amdgcn_s_setprio(0);
+        if (prio == 2) __builtin_amdgcn_s_setprio(1);
         const float* as = As + cur * BM * BK + (wm0 + l31) * BK;
         const float* bs = Bs + cur * BN * BK + (wn0 + l31) * BK;
 #pragma unroll
@@ -202,11 +221,18 @@ __global__ __launch_bounds__(256, MINB) void gemm_nt_kernel(const NtParams p) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
                 }
         }
+        if (prio == 2) __builtin_amdgcn_s_setprio(0);
+        if (prio == 1) __builtin_amdgcn_s_setprio(3);
         glds_wait();                // this wave's DMA for the next tile has landed ...
         __syncthreads();            // ... and so has everybody's; every wave is done reading buf[cur]
         cur ^= 1;
     }
 
+    const unsigned long long tr2 = __builtin_amdgcn_s_memrealtime();
+    if (blockIdx.x == 0 && tid == 0) {
+        g_clock_probe[0] = __builtin_amdgcn_s_memtime() - clk0;
+        g_clock_probe[1] = tr2 - rt0;
+    }
     // ---- epilogue through LDS: the accumulator tile (lane holds D[(r&3)+8*(r>>2)+4*lhi][l31] of each 32x32
     // sub-tile) is written to a [rows][BN+4] image, then every thread handles 16-byte pieces of full rows so that
     // bias / ReLU mask / accumulate / store all move 16 B per lane on contiguous row segments.
@@ -256,6 +282,10 @@ __global__ __launch_bounds__(256, MINB) void gemm_nt_kernel(const NtParams p) {
             }
         }
     }
+    if (g_trace && tid == 0) {
+        unsigned long long* t = g_trace + 4 * (long)blockIdx.x;
+        t[0] = tr0; t[1] = rt0; t[2] = tr2; t[3] = __builtin_amdgcn_s_memrealtime();
+    }
 }
 
 template <int BM, int BN, int WM, int WN, int MODE, int MINB>
@@ -269,6 +299,9 @@ static int launch_nt(NtParams p, hipStream_t st) {
         static int stg = -1;
         if (stg < 0) { const char* e = getenv("WESUP_STAGGER"); stg = e ? atoi(e) : 0; }
         p.stagger = stg;
+        static int pr = -1;
+        if (pr < 0) { const char* e = getenv("WESUP_PRIO"); pr = e ? atoi(e) : 0; }
+        p.prio = pr;
     }
     const size_t lds = (size_t)2 * (BM + BN) * BK * sizeof(float);
     hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, WM, WN, MODE, MINB>), dim3(p.tiles_m * p.tiles_n), dim3(256), lds, st, p);
@@ -303,6 +336,20 @@ extern "C" int wesup_gemm_nt(const float* A, int lda, const float* B, int ldb, c
     p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldmask = ldmask;
     p.flags = flags;
     return dispatch_nt<0>(p, (hipStream_t)stream);
+}
+
+// host-synchronous debug helper (NOT part of the hot path): in-kernel clock of the last NT GEMM launch in MHz
+extern "C" int wesup_debug_clock(double* mhz_out) {
+    unsigned long long h[2] = {0, 0};
+    if (!mhz_out) return WESUP_ERR_INVALID;
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_clock_probe), sizeof(h)) != hipSuccess) return WESUP_ERR_LAUNCH;
+    *mhz_out = h[1] ? (double)h[0] / (double)h[1] * 100.0 : 0.0;
+    return WESUP_OK;
+}
+
+extern "C" int wesup_debug_set_trace(void* device_buf /* >= 32 B per block of the next launches, or NULL */) {
+    unsigned long long* ptr = (unsigned long long*)device_buf;
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_trace), &ptr, sizeof(ptr)) == hipSuccess ? WESUP_OK : WESUP_ERR_LAUNCH;
 }
 
 extern "C" int wesup_conv3x3_kpad(int Ci) {
