@@ -116,14 +116,22 @@ int wesup_sp_preprocess(const int32_t* labels, const uint8_t* mask, int B, int H
 /* dense compat: labels[p] = argmax_n sp_maps[n][p] (first max), as models/wesup.py:295 does */
 int wesup_spmaps_to_labels(const float* sp_maps, int32_t* labels, int N, int HW, void* stream);
 /* scatter-mean: sp_feat[b][r][c] = (1/area_r) sum_{p in row r} fm[b][p][c]   (torch.mm, models/wesup.py:283-285) */
+int wesup_sp_max_units(int HW, int Kmax);      /* upper bound of segments per image: Kmax + HW / 512 */
+/* segment table for load-balanced pooling: a superpixel row is cut into segments of <= 512 pixels;
+ * seg_start[B][Kmax+1] (exclusive scan of segments per row), unit_row[B][Umax] (segment -> row) */
+int wesup_sp_segments(const int32_t* row_start, int B, int Kmax, int Umax, int32_t* seg_start, int32_t* unit_row,
+                      void* stream);
+size_t wesup_sp_pool_workspace_bytes(int B, int Umax, int C);   /* partial sums of multi-segment rows */
 int wesup_sp_pool_fwd(const float* fm, const int32_t* pix_sorted, const int32_t* row_start,
-                      float* sp_feat, int B, int HW, int ldf, int C, int Kmax, void* stream);
+                      const int32_t* seg_start, const int32_t* unit_row, float* sp_feat,
+                      int B, int HW, int ldf, int C, int Kmax, int Umax, void* ws, size_t ws_bytes, void* stream);
 /* fused upsample + scatter-mean: sp_feat[b][r][coff+c] = (1/area_r) sum_{p in row r} bilinear_ac(s[b], p)[c], s = side
  * output [B][h][w][C] (C in {32,64,128,256}); equals wesup_upsample_fwd followed by wesup_sp_pool_fwd on that slice
  * without materialising the (HW x 2112) feature map (models/wesup.py:254-261 + :283-285) */
 int wesup_sp_pool_upsample_fwd(const float* s, const int32_t* pix_sorted, const int32_t* row_start,
-                               float* sp_feat, int B, int h, int w, int H, int W, int C, int ldo, int coff,
-                               int Kmax, void* stream);
+                               const int32_t* seg_start, const int32_t* unit_row, float* sp_feat,
+                               int B, int h, int w, int H, int W, int C, int ldo, int coff, int Kmax, int Umax,
+                               void* ws, size_t ws_bytes, void* stream);
 /* dfm[b][p][c] = g[b][new_row[p]][c] / area[new_row[p]] */
 int wesup_sp_pool_bwd(const float* g, const int32_t* new_row, const int32_t* area_new, float* dfm,
                       int B, int HW, int ldf, int C, int Kmax, void* stream);

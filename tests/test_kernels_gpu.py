@@ -412,3 +412,43 @@ def test_sgd_and_metrics(ops):
         dice = 2 * float(out[b, 1]) / (float(out[b, 3]) + float(out[b, 2]) + 1e-7)
         assert abs(acc - orc.accuracy(P[b], G[b])) < 1e-6
         assert abs(dice - orc.dice(P[b], G[b])) < 1e-6
+
+
+@pytest.mark.parametrize('H,W,g', [(128, 128, 16), (240, 200, 20)])
+def test_sp_pool_skewed_maps_multi_segment_rows(ops, H, W, g):
+    """Adversarial label maps (a few superpixels ~50x the median): rows longer than one 512-pixel
+    segment go through the partial-sum + ordered combine path of both pooling kernels."""
+    from oracle import wesup_oracle as orc
+    from wesup_amd import synth
+    d = dev()
+    B, C = 2, 2112
+    labs = np.stack([synth.skewed_labels(31 + b, H, W, g) for b in range(B)])
+    Kmax = int(labs.max()) + 3
+    m = ops.sp_preprocess(torch.from_numpy(labs).to(d), None, Kmax)
+    m.check()
+    areas = m.area_new.cpu()
+    assert int(areas.max()) > 4 * 512                      # really multi-segment
+    seg = m.seg_start.cpu()
+    for b in range(B):
+        nseg = torch.clamp((areas[b] + 511) // 512, min=1)
+        assert torch.equal(seg[b, 1:] - seg[b, :-1], nseg.int())
+        ur = m.unit_row[b, :int(seg[b, -1])].cpu()
+        assert torch.equal(ur, torch.repeat_interleave(torch.arange(Kmax, dtype=torch.int32), nseg))
+    fm = rnd(B, H, W, C, seed=3)
+    out = ops.sp_pool_fwd(fm.to(d), m)
+    for b in range(B):
+        pp = orc.preprocess_superpixels(torch.from_numpy(labs[b]).long(), None)
+        K = pp['K']
+        seg_new = pp['inv_perm'][torch.from_numpy(labs[b]).long().reshape(-1)]
+        ref = orc.pool_labelmap(fm[b].reshape(H * W, C).t().contiguous(), seg_new, pp['area'][pp['perm']], K)
+        assert rel_err(out[b, :K], ref) < TOL
+        assert float(out[b, K:].abs().max()) == 0.0
+    assert torch.equal(out, ops.sp_pool_fwd(fm.to(d), m))
+    for (h, w, Cs, coff) in [(H, W, 32, 0), (H // 2, W // 2, 64, 64), (H // 8, W // 8, 256, 512)]:
+        sl = rnd(B, h, w, Cs, seed=9).to(d)
+        fm2 = torch.zeros(B, H, W, C, device=d)
+        ops.upsample_fwd(sl, fm2, coff)
+        ref2 = ops.sp_pool_fwd(fm2, m)
+        got = torch.zeros(B, Kmax, C, device=d)
+        ops.sp_pool_upsample_fwd(sl, m, got, coff)
+        assert rel_err(got[..., coff:coff + Cs], ref2[..., coff:coff + Cs]) < 1e-5

@@ -6,12 +6,15 @@ from wesup_amd import ops, _lib
 d = torch.device('cuda:0')
 lib = _lib.load()
 def run(name, fn, nblocks):
-    buf = torch.zeros(nblocks * 4, dtype=torch.int64, device=d)
+    buf = torch.zeros(nblocks * 6, dtype=torch.int64, device=d)
     fn(); torch.cuda.synchronize()
     lib.wesup_debug_set_trace(ctypes.c_void_p(buf.data_ptr()))
     fn(); torch.cuda.synchronize()
     lib.wesup_debug_set_trace(None)
-    t = buf.cpu().numpy().reshape(nblocks, 4).astype(np.float64) * 0.01    # us
+    raw = buf.cpu().numpy().reshape(nblocks, 6)
+    t = raw[:, :4].astype(np.float64) * 0.01    # us
+    xcc = raw[:, 4] & 0xf; hw = raw[:, 5]
+    cu = (hw >> 8) & 0xf; sh = (hw >> 12) & 0x1; se = (hw >> 13) & 0x7; simd = (hw >> 4) & 0x3
     t0 = t[:, 0].min()
     st, ls, le, en = (t[:, i] - t0 for i in range(4))
     print(f'{name}: blocks {nblocks}  kernel span {en.max():.1f} us')
@@ -20,6 +23,17 @@ def run(name, fn, nblocks):
     print(f'   main loop       : p10 {np.percentile(le - ls, 10):.1f} p50 {np.median(le - ls):.1f} p90 {np.percentile(le - ls, 90):.1f} max {(le - ls).max():.1f}')
     print(f'   epilogue        : p50 {np.median(en - le):.2f} max {(en - le).max():.2f}')
     print(f'   block end       : p10 {np.percentile(en, 10):.1f} p50 {np.median(en):.1f} p90 {np.percentile(en, 90):.1f} max {en.max():.1f}')
+    loop = le - ls
+    print('   loop p50 by XCC:', {int(x): round(float(np.median(loop[(xcc == x) & (st < 5)])), 1) for x in sorted(set(xcc.tolist()))})
+    key = xcc * 1000 + se * 100 + sh * 16 + cu
+    firstw = st < 5
+    groups = {}
+    for k_, l_ in zip(key[firstw].tolist(), loop[firstw].tolist()): groups.setdefault(k_, []).append(l_)
+    sizes = [len(v) for v in groups.values()]
+    pair_diff = [abs(v[0] - v[1]) for v in groups.values() if len(v) == 2]
+    print(f'   distinct CUs {len(groups)}, blocks/CU histogram {np.bincount(sizes).tolist()}, same-CU pair |dt| p50 {np.median(pair_diff) if pair_diff else -1:.1f} us')
+    cu_mean = np.array([np.mean(v) for v in groups.values()])
+    print(f'   per-CU mean loop: p10 {np.percentile(cu_mean,10):.1f} p50 {np.median(cu_mean):.1f} p90 {np.percentile(cu_mean,90):.1f}; by blocks/CU:', {n: round(float(np.mean([np.mean(v) for v in groups.values() if len(v) == n])), 1) for n in sorted(set(sizes))})
     first = st < 1.0
     print(f'   first-wave blocks: {first.sum()}  their loop p50 {np.median((le - ls)[first]):.1f}; later blocks loop p50 {np.median((le - ls)[~first]) if (~first).any() else 0:.1f}')
 M, N, K = 32768, 256, 2304

@@ -43,9 +43,12 @@ _SIGS = {
     'wesup_sp_preprocess_workspace_bytes': (c_size_t, 'iiii'),
     'wesup_sp_preprocess': (c_int, 'ppiiii' + 'pppppppppp' + 'pzp'),
     'wesup_spmaps_to_labels': (c_int, 'ppiip'),
-    'wesup_sp_pool_fwd': (c_int, 'ppppiiiiip'),
+    'wesup_sp_max_units': (c_int, 'ii'),
+    'wesup_sp_segments': (c_int, 'piiippp'),
+    'wesup_sp_pool_workspace_bytes': (c_size_t, 'iii'),
+    'wesup_sp_pool_fwd': (c_int, 'ppppppiiiiiipzp'),
     'wesup_sp_pool_bwd': (c_int, 'ppppiiiiip'),
-    'wesup_sp_pool_upsample_fwd': (c_int, 'ppppiiiiiiiiip'),
+    'wesup_sp_pool_upsample_fwd': (c_int, 'ppppppiiiiiiiiiipzp'),
     'wesup_paint_fwd': (c_int, 'pppiiiiip'),
     'wesup_classifier_fwd': (c_int, 'ppppiip'),
     'wesup_classifier_bwd_workspace_bytes': (c_size_t, 'ii'),

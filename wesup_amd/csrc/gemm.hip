@@ -194,35 +194,40 @@ __global__ __launch_bounds__(256, MINB) void gemm_nt_kernel(const NtParams p) {
     int cur = 0;
     const int prio = p.prio;
     for (int kk = 0; kk < nk; ++kk) {
-        if (prio == 1) __builtin_amdgcn_s_setprio(3);
-        if (kk + 1 < nk) stage(kk + 1, cur ^ 1);
-        if (prio == 1) __builtin_amdgcn_s_setprio(0);
-        if (prio == 2) __builtin_amdgcn_s_setprio(1);
+        (void)prio;
         const float* as = As + cur * BM * BK + (wm0 + l31) * BK;
         const float* bs = Bs + cur * BN * BK + (wn0 + l31) * BK;
-#pragma unroll
-        for (int g = 0; g < BK / 8; ++g) {
-            float4 a[WM], b[WN];
+        // Fragment double buffering: the ds_reads of group g+1 are issued BEFORE the 16 MFMAs of group g, so their
+        // LDS latency hides under ~1000 MFMA cycles; only the first group of a K-step waits right after its reads.
+        // The DMA for the next tile is issued after the first group's reads so that those are not queued behind it.
+        float4 fa[2][WM], fb[2][WN];
+        auto load_frag = [&](int g, int slot) {
             const int ca = ((2 * g + lhi) ^ swa) << 2, cb = ((2 * g + lhi) ^ swb) << 2;
 #pragma unroll
-            for (int i = 0; i < WM; ++i) {
-                a[i] = ld4(as + 32 * i * BK + ca);
-                if (relu_in) a[i] = relu4(a[i]);
-            }
+            for (int i = 0; i < WM; ++i) fa[slot][i] = ld4(as + 32 * i * BK + ca);
 #pragma unroll
-            for (int j = 0; j < WN; ++j) b[j] = ld4(bs + 32 * j * BK + cb);
+            for (int j = 0; j < WN; ++j) fb[slot][j] = ld4(bs + 32 * j * BK + cb);
+        };
+        load_frag(0, 0);
+        if (kk + 1 < nk) stage(kk + 1, cur ^ 1);
+#pragma unroll
+        for (int g = 0; g < BK / 8; ++g) {
+            const int sl = g & 1;
+            if (g + 1 < BK / 8) load_frag(g + 1, sl ^ 1);
+            if (relu_in) {
+#pragma unroll
+                for (int i = 0; i < WM; ++i) fa[sl][i] = relu4(fa[sl][i]);
+            }
 #pragma unroll
             for (int i = 0; i < WM; ++i)
 #pragma unroll
                 for (int j = 0; j < WN; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b[j].y, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[j].z, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[sl][i].x, fb[sl][j].x, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[sl][i].y, fb[sl][j].y, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[sl][i].z, fb[sl][j].z, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[sl][i].w, fb[sl][j].w, acc[i][j], 0, 0, 0);
                 }
         }
-        if (prio == 2) __builtin_amdgcn_s_setprio(0);
-        if (prio == 1) __builtin_amdgcn_s_setprio(3);
         glds_wait();                // this wave's DMA for the next tile has landed ...
         __syncthreads();            // ... and so has everybody's; every wave is done reading buf[cur]
         cur ^= 1;
@@ -283,8 +288,10 @@ __global__ __launch_bounds__(256, MINB) void gemm_nt_kernel(const NtParams p) {
         }
     }
     if (g_trace && tid == 0) {
-        unsigned long long* t = g_trace + 4 * (long)blockIdx.x;
+        unsigned long long* t = g_trace + 6 * (long)blockIdx.x;
         t[0] = tr0; t[1] = rt0; t[2] = tr2; t[3] = __builtin_amdgcn_s_memrealtime();
+        t[4] = __builtin_amdgcn_s_getreg((20 /*HW_REG_XCC_ID*/) | (0 << 6) | (31 << 11));
+        t[5] = __builtin_amdgcn_s_getreg((4 /*HW_REG_HW_ID*/) | (0 << 6) | (31 << 11));
     }
 }
 
@@ -313,6 +320,9 @@ static int launch_nt(NtParams p, hipStream_t st) {
 template <int MODE>
 static int dispatch_nt(NtParams p, hipStream_t st) {
     const long t128 = (long)ceil_div(p.M, 128) * ceil_div(p.N, 128);
+    static int force = -1;
+    if (force < 0) { const char* e = getenv("WESUP_NT_TILE"); force = e ? atoi(e) : 0; }
+    if (force == 1 && p.M >= 128) return launch_nt<128, 64, 2, 1, MODE, 3>(p, st);   // experiment: 3 blocks/CU
     if (p.N > 64 && t128 >= 384) return launch_nt<128, 128, 2, 2, MODE, 2>(p, st);
     if (p.N <= 64 && (long)ceil_div(p.M, 128) >= 384) return launch_nt<128, 64, 2, 1, MODE, 2>(p, st);
     return launch_nt<64, 64, 1, 1, MODE, 2>(p, st);

@@ -256,22 +256,102 @@ extern "C" int wesup_spmaps_to_labels(const float* sp_maps, int32_t* labels, int
 // One wave per (row, 256-channel slab): lane owns 4 channels, walks the row's pixel list 8 pixels per
 // iteration (8 x 1 KiB loads in flight per wave), acc = fma(v, 1/area, acc) as the reference's pre-normalised
 // GEMM does.  Algorithmic bytes per image: C*HW*4 (features) + HW*4 (pixel list) + N*C*4 (output).
+//
+// Skewed maps: a superpixel is cut into segments of at most SP_SEG pixels (wesup_sp_segments builds, per image,
+// seg_start[row] and the inverse unit_row[segment]); the work unit of a wave is one SEGMENT.  Rows of one segment
+// (the normal case) are written directly; longer rows leave one partial sum per segment in the workspace and
+// sp_pool_combine_kernel adds them in segment order -- still a fixed summation order, and a superpixel 50x the
+// median no longer serialises on one wave.
 #define POOL_UNROLL 8
+#define SP_SEG 512
+struct SegInfo {
+    int r, j0, j1, nseg, u;
+    float inv;
+};
+// wave-uniform: everything comes from scalar loads
+__device__ __forceinline__ bool seg_lookup(const int32_t* __restrict__ row_start, const int32_t* __restrict__ seg_start,
+                                           const int32_t* __restrict__ unit_row, int b, int u, int Kmax, int Umax,
+                                           SegInfo& s) {
+    const int32_t* ss = seg_start + (long)b * (Kmax + 1);
+    if (u >= ss[Kmax]) return false;
+    const int r = unit_row[(long)b * Umax + u];
+    const int s0 = ss[r];
+    const int a0 = row_start[(long)b * (Kmax + 1) + r], a1 = row_start[(long)b * (Kmax + 1) + r + 1];
+    s.r = r;
+    s.u = u;
+    s.nseg = ss[r + 1] - s0;
+    s.j0 = a0 + (u - s0) * SP_SEG;
+    s.j1 = min(a1, s.j0 + SP_SEG);
+    s.inv = (a1 > a0) ? 1.f / (float)(a1 - a0) : 0.f;
+    return true;
+}
+__global__ __launch_bounds__(1024) void sp_segments_kernel(const int32_t* __restrict__ row_start, int Kmax, int Umax,
+                                                           int32_t* __restrict__ seg_start, int32_t* __restrict__ unit_row) {
+    __shared__ int sh[1024];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int per = (Kmax + 1023) / 1024;
+    const int i0 = min(Kmax, tid * per), i1 = min(Kmax, i0 + per);
+    const int32_t* rs = row_start + (long)b * (Kmax + 1);
+    int cnt = 0;
+    for (int r = i0; r < i1; ++r) cnt += max(1, (rs[r + 1] - rs[r] + SP_SEG - 1) / SP_SEG);
+    int total;
+    int pre = block_excl_scan(cnt, &total, sh);
+    for (int r = i0; r < i1; ++r) {
+        const int n = max(1, (rs[r + 1] - rs[r] + SP_SEG - 1) / SP_SEG);
+        seg_start[(long)b * (Kmax + 1) + r] = pre;
+        for (int k = 0; k < n && pre + k < Umax; ++k) unit_row[(long)b * Umax + pre + k] = r;
+        pre += n;
+    }
+    if (tid == 1023) seg_start[(long)b * (Kmax + 1) + Kmax] = min(total, Umax);
+}
+extern "C" int wesup_sp_max_units(int HW, int Kmax) { return (HW > 0 && Kmax > 0) ? Kmax + HW / SP_SEG : 0; }
+extern "C" int wesup_sp_segments(const int32_t* row_start, int B, int Kmax, int Umax, int32_t* seg_start,
+                                 int32_t* unit_row, void* stream) {
+    if (!row_start || !seg_start || !unit_row || B <= 0 || Kmax <= 0 || Umax < Kmax) return WESUP_ERR_INVALID;
+    hipLaunchKernelGGL(sp_segments_kernel, dim3(B), dim3(1024), 0, (hipStream_t)stream, row_start, Kmax, Umax, seg_start,
+                       unit_row);
+    WESUP_CHECK_LAUNCH();
+    return WESUP_OK;
+}
+// out[b][r][c] = sum over the row's segments (in order) of part[b][seg][c]; rows with one segment were written directly
+__global__ void sp_pool_combine_kernel(const float* __restrict__ part, const int32_t* __restrict__ seg_start,
+                                       float* __restrict__ out, int Kmax, int Umax, int C4, int ldo, int coff) {
+    const int b = blockIdx.y;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)Kmax * C4) return;
+    const int r = idx / C4, q = idx - (long)r * C4;
+    const int s0 = seg_start[(long)b * (Kmax + 1) + r], s1 = seg_start[(long)b * (Kmax + 1) + r + 1];
+    if (s1 - s0 <= 1) return;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int u = s0; u < s1; ++u) {
+        const float4 v = ld4(part + (((long)b * Umax + u) * C4 + q) * 4);
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    st4(out + ((long)b * Kmax + r) * ldo + coff + 4 * q, acc);
+}
+extern "C" size_t wesup_sp_pool_workspace_bytes(int B, int Umax, int C) {
+    return (B > 0 && Umax > 0 && C > 0) ? (size_t)B * Umax * C * sizeof(float) : 0;
+}
+
 __global__ __launch_bounds__(256) void sp_pool_fwd_kernel(const float* __restrict__ fm,
                                                           const int32_t* __restrict__ pix_sorted,
                                                           const int32_t* __restrict__ row_start,
+                                                          const int32_t* __restrict__ seg_start,
+                                                          const int32_t* __restrict__ unit_row, float* __restrict__ part,
                                                           float* __restrict__ sp_feat, int HW, int ldf, int C, int Kmax,
-                                                          int nslab, int units_per_img) {
+                                                          int Umax, int nslab, int units_per_img) {
     const int b = blockIdx.y;
     // wave-uniform unit id -> row bounds and pixel indices live in SGPRs (scalar loads)
     const int unit = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (unit >= units_per_img) return;
     const int lane = threadIdx.x & 63;
-    const int r = unit / nslab, slab = unit - r * nslab;
+    const int u = unit / nslab, slab = unit - u * nslab;
     const int c = slab * 256 + 4 * lane;
+    SegInfo sg;
+    if (!seg_lookup(row_start, seg_start, unit_row, b, u, Kmax, Umax, sg)) return;
     if (c >= C) return;
-    const int j0 = row_start[(long)b * (Kmax + 1) + r], j1 = row_start[(long)b * (Kmax + 1) + r + 1];
-    const float inv = (j1 > j0) ? 1.f / (float)(j1 - j0) : 0.f;
+    const int r = sg.r, j0 = sg.j0, j1 = sg.j1;
+    const float inv = sg.inv;
     const int32_t* list = pix_sorted + (long)b * HW;
     const float* base = fm + (long)b * HW * ldf + c;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -298,16 +378,24 @@ __global__ __launch_bounds__(256) void sp_pool_fwd_kernel(const float* __restric
         acc.z = fmaf(v.z, inv, acc.z);
         acc.w = fmaf(v.w, inv, acc.w);
     }
-    st4(sp_feat + ((long)b * Kmax + r) * C + c, acc);
+    if (sg.nseg == 1) st4(sp_feat + ((long)b * Kmax + r) * C + c, acc);
+    else st4(part + ((long)b * Umax + sg.u) * C + c, acc);
 }
-extern "C" int wesup_sp_pool_fwd(const float* fm, const int32_t* pix_sorted, const int32_t* row_start, float* sp_feat,
-                                 int B, int HW, int ldf, int C, int Kmax, void* stream) {
-    if (!fm || !pix_sorted || !row_start || !sp_feat || B <= 0 || HW <= 0 || Kmax <= 0 || (C % 4) || (ldf % 4) || C > ldf)
+extern "C" int wesup_sp_pool_fwd(const float* fm, const int32_t* pix_sorted, const int32_t* row_start,
+                                 const int32_t* seg_start, const int32_t* unit_row, float* sp_feat, int B, int HW, int ldf,
+                                 int C, int Kmax, int Umax, void* ws, size_t ws_bytes, void* stream) {
+    if (!fm || !pix_sorted || !row_start || !seg_start || !unit_row || !sp_feat || !ws || B <= 0 || HW <= 0 || Kmax <= 0 ||
+        Umax < Kmax || (C % 4) || (ldf % 4) || C > ldf)
         return WESUP_ERR_INVALID;
+    if (ws_bytes < wesup_sp_pool_workspace_bytes(B, Umax, C)) return WESUP_ERR_WORKSPACE;
     const int nslab = ceil_div(C, 256);
-    const int units = Kmax * nslab;
-    hipLaunchKernelGGL(sp_pool_fwd_kernel, dim3(ceil_div(units, 4), B), dim3(256), 0, (hipStream_t)stream, fm, pix_sorted,
-                       row_start, sp_feat, HW, ldf, C, Kmax, nslab, units);
+    const int units = Umax * nslab;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(sp_pool_fwd_kernel, dim3(ceil_div(units, 4), B), dim3(256), 0, st, fm, pix_sorted, row_start,
+                       seg_start, unit_row, (float*)ws, sp_feat, HW, ldf, C, Kmax, Umax, nslab, units);
+    const long tot = (long)Kmax * (C / 4);
+    hipLaunchKernelGGL(sp_pool_combine_kernel, dim3((unsigned)((tot + 255) / 256), B), dim3(256), 0, st, (const float*)ws,
+                       seg_start, sp_feat, Kmax, Umax, C / 4, C, 0);
     WESUP_CHECK_LAUNCH();
     return WESUP_OK;
 }
@@ -333,19 +421,23 @@ __device__ __forceinline__ Lerp2 lerp2_of(int dst, float scale, int in) {
 }
 template <int LPP>
 __global__ __launch_bounds__(256) void sp_pool_up_fwd_kernel(const float* __restrict__ s, const int32_t* __restrict__ pix_sorted,
-                                                             const int32_t* __restrict__ row_start, float* __restrict__ sp_feat,
-                                                             int h, int w, int H, int W, FastDiv dW, int ldo, int coff, int Kmax,
-                                                             float sh, float sw) {
+                                                             const int32_t* __restrict__ row_start,
+                                                             const int32_t* __restrict__ seg_start,
+                                                             const int32_t* __restrict__ unit_row, float* __restrict__ part,
+                                                             float* __restrict__ sp_feat, int h, int w, int H, int W,
+                                                             FastDiv dW, int ldo, int coff, int Kmax, int Umax, float sh,
+                                                             float sw) {
     constexpr int PPW = 64 / LPP;
     constexpr int C = LPP * 4;
     const int b = blockIdx.y;
-    const int r = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    if (r >= Kmax) return;
+    const int u = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    SegInfo sg;
+    if (u >= Umax || !seg_lookup(row_start, seg_start, unit_row, b, u, Kmax, Umax, sg)) return;
     const int lane = threadIdx.x & 63;
     const int grp = lane / LPP, cl = lane % LPP;
     const int HW = H * W;
-    const int j0 = row_start[(long)b * (Kmax + 1) + r], j1 = row_start[(long)b * (Kmax + 1) + r + 1];
-    const float inv = (j1 > j0) ? 1.f / (float)(j1 - j0) : 0.f;
+    const int r = sg.r, j0 = sg.j0, j1 = sg.j1;
+    const float inv = sg.inv;
     const int32_t* list = pix_sorted + (long)b * HW;
     const float* base = s + (long)b * h * w * C + 4 * cl;
     const bool ident = (h == H && w == W);
@@ -379,21 +471,27 @@ __global__ __launch_bounds__(256) void sp_pool_up_fwd_kernel(const float* __rest
         acc.z += __shfl_xor(acc.z, off);
         acc.w += __shfl_xor(acc.w, off);
     }
-    if (grp == 0) st4(sp_feat + ((long)b * Kmax + r) * ldo + coff + 4 * cl, acc);
+    if (grp == 0) {
+        if (sg.nseg == 1) st4(sp_feat + ((long)b * Kmax + r) * ldo + coff + 4 * cl, acc);
+        else st4(part + ((long)b * Umax + sg.u) * C + 4 * cl, acc);
+    }
 }
 extern "C" int wesup_sp_pool_upsample_fwd(const float* s, const int32_t* pix_sorted, const int32_t* row_start,
-                                          float* sp_feat, int B, int h, int w, int H, int W, int C, int ldo, int coff,
-                                          int Kmax, void* stream) {
-    if (!s || !pix_sorted || !row_start || !sp_feat || B <= 0 || h <= 0 || w <= 0 || H <= 0 || W <= 0 || Kmax <= 0 ||
-        (ldo % 4) || (coff % 4) || coff + C > ldo)
+                                          const int32_t* seg_start, const int32_t* unit_row, float* sp_feat, int B, int h,
+                                          int w, int H, int W, int C, int ldo, int coff, int Kmax, int Umax, void* ws,
+                                          size_t ws_bytes, void* stream) {
+    if (!s || !pix_sorted || !row_start || !seg_start || !unit_row || !sp_feat || !ws || B <= 0 || h <= 0 || w <= 0 ||
+        H <= 0 || W <= 0 || Kmax <= 0 || Umax < Kmax || (ldo % 4) || (coff % 4) || coff + C > ldo)
         return WESUP_ERR_INVALID;
-    const dim3 grid(ceil_div(Kmax, 4), B);
+    if (ws_bytes < wesup_sp_pool_workspace_bytes(B, Umax, C)) return WESUP_ERR_WORKSPACE;
+    const dim3 grid(ceil_div(Umax, 4), B);
     const float sh = H > 1 ? (float)(h - 1) / (float)(H - 1) : 0.f, sw = W > 1 ? (float)(w - 1) / (float)(W - 1) : 0.f;
     const FastDiv dW = make_fastdiv(W);
     hipStream_t st = (hipStream_t)stream;
+    float* part = (float*)ws;
 #define WESUP_LAUNCH_PU(L)                                                                                              \
-    hipLaunchKernelGGL(sp_pool_up_fwd_kernel<L>, grid, dim3(256), 0, st, s, pix_sorted, row_start, sp_feat, h, w, H, W, \
-                       dW, ldo, coff, Kmax, sh, sw)
+    hipLaunchKernelGGL(sp_pool_up_fwd_kernel<L>, grid, dim3(256), 0, st, s, pix_sorted, row_start, seg_start, unit_row, \
+                       part, sp_feat, h, w, H, W, dW, ldo, coff, Kmax, Umax, sh, sw)
     switch (C) {
         case 32: WESUP_LAUNCH_PU(8); break;
         case 64: WESUP_LAUNCH_PU(16); break;
@@ -402,6 +500,9 @@ extern "C" int wesup_sp_pool_upsample_fwd(const float* s, const int32_t* pix_sor
         default: return WESUP_ERR_INVALID;
     }
 #undef WESUP_LAUNCH_PU
+    const long tot = (long)Kmax * (C / 4);
+    hipLaunchKernelGGL(sp_pool_combine_kernel, dim3((unsigned)((tot + 255) / 256), B), dim3(256), 0, st, (const float*)ws,
+                       seg_start, sp_feat, Kmax, Umax, C / 4, ldo, coff);
     WESUP_CHECK_LAUNCH();
     return WESUP_OK;
 }

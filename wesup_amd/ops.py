@@ -240,7 +240,8 @@ def upsample_bwd_fused(g, new_row, area_new, H, W, coff, h, w, C, out=None):
 class SuperpixelMeta:
     """Device-side result of wesup_sp_preprocess for a batch of label maps (padded to Kmax rows per image)."""
     __slots__ = ('B', 'H', 'W', 'C', 'Kmax', 'labels', 'mask', 'n_sp', 'n_l', 'perm', 'inv_perm', 'area_new',
-                 'sp_labels', 'new_row', 'row_start', 'pix_sorted', 'status', 'n_sp_host')
+                 'sp_labels', 'new_row', 'row_start', 'pix_sorted', 'status', 'n_sp_host', 'seg_start', 'unit_row',
+                 'Umax')
 
     def check(self):
         """Host sync: raise on label-map errors the reference would turn into NaNs (models/wesup.py:57-61)."""
@@ -276,6 +277,11 @@ def sp_preprocess(labels, mask, Kmax, n_classes=2, n_sp_host=None):
     _lib.call('wesup_sp_preprocess', _p(labels), _p(mask), B, HW, C, Kmax, _p(m.n_sp), _p(m.n_l), _p(m.perm),
               _p(m.inv_perm), _p(m.area_new), _p(m.sp_labels), _p(m.new_row), _p(m.row_start), _p(m.pix_sorted),
               _p(m.status), _p(ws), nb, _stream())
+    # segment table (rows cut into <= 512-pixel segments) for the load-balanced pooling kernels
+    m.Umax = _lib.load().wesup_sp_max_units(HW, int(Kmax))
+    m.seg_start = torch.empty(B, Kmax + 1, **i32)
+    m.unit_row = torch.empty(B, m.Umax, **i32)
+    _lib.call('wesup_sp_segments', _p(m.row_start), B, int(Kmax), m.Umax, _p(m.seg_start), _p(m.unit_row), _stream())
     return m
 
 
@@ -295,8 +301,10 @@ def sp_pool_fwd(fm, meta, C=None, out=None):
     if out is None:
         out = torch.empty(B, meta.Kmax, C, dtype=torch.float32, device=fm.device)
     assert out.shape == (B, meta.Kmax, C) and out.is_contiguous()
-    _lib.call('wesup_sp_pool_fwd', _p(fm), _p(meta.pix_sorted), _p(meta.row_start), _p(out), B, H * W, ldf, C, meta.Kmax,
-              _stream())
+    nb = _lib.load().wesup_sp_pool_workspace_bytes(B, meta.Umax, C)
+    ws = workspace(nb, fm.device, 'pool')
+    _lib.call('wesup_sp_pool_fwd', _p(fm), _p(meta.pix_sorted), _p(meta.row_start), _p(meta.seg_start), _p(meta.unit_row),
+              _p(out), B, H * W, ldf, C, meta.Kmax, meta.Umax, _p(ws), nb, _stream())
     return out
 
 
@@ -305,8 +313,11 @@ def sp_pool_upsample_fwd(s, meta, out, coff):
     _chk(s, name='s'); _chk(out, name='out')
     B, h, w, C = s.shape
     assert out.shape[:2] == (B, meta.Kmax) and B == meta.B and coff + C <= out.shape[2]
-    _lib.call('wesup_sp_pool_upsample_fwd', _p(s), _p(meta.pix_sorted), _p(meta.row_start), _p(out), B, h, w, meta.H, meta.W,
-              C, out.shape[2], coff, meta.Kmax, _stream())
+    nb = _lib.load().wesup_sp_pool_workspace_bytes(B, meta.Umax, C)
+    ws = workspace(nb, s.device, 'pool_up')
+    _lib.call('wesup_sp_pool_upsample_fwd', _p(s), _p(meta.pix_sorted), _p(meta.row_start), _p(meta.seg_start),
+              _p(meta.unit_row), _p(out), B, h, w, meta.H, meta.W, C, out.shape[2], coff, meta.Kmax, meta.Umax, _p(ws), nb,
+              _stream())
     return out
 
 
