@@ -139,6 +139,16 @@ int wesup_sp_pool_bwd(const float* g, const int32_t* new_row, const int32_t* are
 int wesup_paint_fwd(const float* sp_pred, const int32_t* new_row, float* pred, int B, int HW, int Kmax,
                     int C, int cls, void* stream);
 
+/* ------------------------------------------------------------------ SLIC superpixels
+ * replaces the CPU skimage.segmentation.slic call of WESUPTrainer.preprocess (models/wesup.py:471-476).
+ * img [B][3][H][W] RGB in [0,1]; labels [B][HW] get contiguous ids 0..n_labels[b]-1 (4-connected superpixels,
+ * numbered in raster order of their first pixel).  Third-party algorithm, parity unpinned (see csrc/slic.hip). */
+int wesup_slic_num_centers(int H, int W, int n_segments);
+size_t wesup_slic_workspace_bytes(int B, int H, int W, int n_segments);
+int wesup_slic(const float* img_nchw, int32_t* labels, int32_t* n_labels, int B, int H, int W, int n_segments,
+               float compactness, int max_iter, int enforce_connectivity, float min_size_factor,
+               void* ws, size_t ws_bytes, void* stream);
+
 /* ------------------------------------------------------------------ head, loss, optimiser (K7/K10/K11/K13)
  * classifier Linear(D,2)+Softmax(dim=1) (models/wesup.py:229-232,292) */
 int wesup_classifier_fwd(const float* feat, const float* Wc, const float* bc, float* pred, int R, int D, void* stream);

@@ -50,6 +50,9 @@ _SIGS = {
     'wesup_sp_pool_bwd': (c_int, 'ppppiiiiip'),
     'wesup_sp_pool_upsample_fwd': (c_int, 'ppppppiiiiiiiiiipzp'),
     'wesup_paint_fwd': (c_int, 'pppiiiiip'),
+    'wesup_slic_num_centers': (c_int, 'iii'),
+    'wesup_slic_workspace_bytes': (c_size_t, 'iiii'),
+    'wesup_slic': (c_int, 'pppiiiifiifpzp'),
     'wesup_classifier_fwd': (c_int, 'ppppiip'),
     'wesup_classifier_bwd_workspace_bytes': (c_size_t, 'ii'),
     'wesup_classifier_bwd': (c_int, 'ppppppppiipzp'),

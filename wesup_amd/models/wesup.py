@@ -352,17 +352,27 @@ class WESUPTrainer(BaseTrainer):
         return optimizer, None
 
     def slic(self, img):
-        """Superpixel segmentation of one (3,H,W) image -> (H,W) integer label map.  The reference calls
-        skimage.segmentation.slic on the CPU (models/wesup.py:471-476); it is outside the hot path
-         and not shipped here: pass ``segments`` with the data or set ``slic_fn``."""
+        """Superpixel segmentation of a batch (B,3,H,W) -> (labels (B,H,W) int32 on the device, upper bound on ids).
+
+        The reference calls skimage.segmentation.slic on the CPU for every iteration (models/wesup.py:471-476, with
+        a device->host->device round trip).  Here the default is the GPU SLIC of libwesup_hip.so (``wesup_slic``,
+        same n_segments / compactness, 10 iterations, connectivity enforced, contiguous 0-based ids); a CPU
+        implementation can still be plugged in with ``slic_fn=callable(img_hwc_numpy, n_segments, compactness)``."""
+        H, W = img.size(-2), img.size(-1)
+        n_segments = int(H * W / self.kwargs.get('sp_area'))                    # models/wesup.py:473-474
         fn = self.kwargs.get('slic_fn')
-        if fn is None:
-            raise RuntimeError('no superpixel segmentation available: provide label maps with the batch '
-                               '(4th datum) or pass slic_fn=callable(img_hwc_numpy, n_segments, compactness)')
-        seg = fn(img.cpu().numpy().transpose(1, 2, 0),
-                 int(img.size(-2) * img.size(-1) / self.kwargs.get('sp_area')), self.kwargs.get('sp_compactness'))
-        seg = np.asarray(seg)
-        return torch.as_tensor(seg - seg.min(), dtype=torch.int32)
+        if fn is not None:
+            segs = []
+            for b in range(img.size(0)):
+                seg = np.asarray(fn(img[b].cpu().numpy().transpose(1, 2, 0), n_segments, self.kwargs.get('sp_compactness')))
+                segs.append(torch.as_tensor(seg - seg.min(), dtype=torch.int32))
+            return torch.stack(segs).to(self.device), max(int(s.max()) + 1 for s in segs)
+        labels, _ = ops.slic(img.contiguous().float(), n_segments, float(self.kwargs.get('sp_compactness')), 10)
+        # every connected superpixel holds its first pixel alone -> at most one id per grid centre plus split-offs;
+        # the number of initial centres bounds the count after small components were absorbed only loosely, so use
+        # the safe bound HW / min_size (no host sync)
+        kmax = int(2 * n_segments) + 8
+        return labels, kmax
 
     def preprocess(self, *data):
         """(img, pixel_mask[, point_mask[, segments]]) -> ((img, sp_maps), (pixel_mask, sp_labels))
@@ -385,10 +395,9 @@ class WESUPTrainer(BaseTrainer):
 
         B = img.size(0)
         n_sp_host = None
+        kmax_bound = None
         if segments is None:
-            segs = [self.slic(img[b]) for b in range(B)]
-            n_sp_host = [int(s.max()) + 1 for s in segs]
-            segments = torch.stack(segs)
+            segments, kmax_bound = self.slic(img)
         elif not segments.is_cuda:
             n_sp_host = [int(segments[b].max()) + 1 for b in range(B)]
         segments = segments.to(self.device)
@@ -401,7 +410,7 @@ class WESUPTrainer(BaseTrainer):
             mask = None
 
         # label maps already on the GPU: an upper bound on the ids avoids a host sync (padded rows are inert)
-        Kmax = max(n_sp_host) if n_sp_host is not None else self.kwargs.get('max_superpixels')
+        Kmax = max(n_sp_host) if n_sp_host is not None else (kmax_bound or self.kwargs.get('max_superpixels'))
         meta = preprocess_label_maps(segments, mask, Kmax=Kmax, n_sp_host=n_sp_host)
         if self.kwargs.get('check_label_maps', False):
             meta.check()

@@ -343,6 +343,21 @@ def paint_fwd(sp_pred, meta, cls=1, out=None):
     return out
 
 
+# ---------------------------------------------------------------- SLIC
+def slic(img, n_segments, compactness=40.0, max_iter=10, enforce_connectivity=True, min_size_factor=0.5):
+    """GPU SLIC: img (B,3,H,W) RGB in [0,1] -> (labels (B,H,W) int32 with contiguous ids, n_labels (B,) int32)."""
+    _chk(img, name='img')
+    B, C, H, W = img.shape
+    assert C == 3
+    labels = torch.empty(B, H, W, dtype=torch.int32, device=img.device)
+    n_labels = torch.empty(B, dtype=torch.int32, device=img.device)
+    nb = _lib.load().wesup_slic_workspace_bytes(B, H, W, int(n_segments))
+    ws = workspace(nb, img.device, 'slic')
+    _lib.call('wesup_slic', _p(img), _p(labels), _p(n_labels), B, H, W, int(n_segments), float(compactness), int(max_iter),
+              int(enforce_connectivity), float(min_size_factor), _p(ws), nb, _stream())
+    return labels, n_labels
+
+
 # ---------------------------------------------------------------- head / loss / optimiser
 def classifier_fwd(feat, Wc, bc, out=None):
     _chk(feat, name='feat'); _chk(Wc, name='Wc'); _chk(bc, name='bc')
