@@ -162,6 +162,18 @@ def main():
         print(f'{name}: N={n} n_l={n_l} loss={loss.item():.6f} propagated={metrics.get("propagated_labels")}'
               f' ploss={metrics.get("propagate_loss")}')
 
+    # pixel-wise inference (models/wesup.py:307-400), SURVEY.md 8(f) row 3
+    weights = orc.make_weights(4, feat_scale=0.3)
+    pmodel = ref.WESUPPixelInference()
+    pmodel.load_state_dict({k: torch.from_numpy(v) for k, v in weights.items()})
+    pmodel.eval()
+    img = synth.synth_image(8, 48, 80)
+    with torch.no_grad():
+        pout = pmodel(torch.from_numpy(img).unsqueeze(0))
+    np.savez_compressed(os.path.join(out_dir, 'pixel_infer.npz'), img=img, seed=4, feat_scale=0.3,
+                        out=pout.numpy().astype(np.float32))
+    print('pixel_infer:', tuple(pout.shape), float(pout[..., 1].mean()))
+
     # reference behaviours the tests pin (SURVEY.md 8(c) last row)
     f = torch.zeros(5, 32)
     y_l = torch.tensor([[1., 0.], [0., 1.]])

@@ -377,3 +377,15 @@ def time_cpu_baseline(H=480, W=480, g=14, iters=2, warmup=1, seed=0, threads=Non
     med = sorted(ts)[len(ts) // 2]
     sample = f'{iters} timed fwd+loss+bwd steps of 1 image {H}x{W}, {g*g} superpixels (config c1), median'
     return 1.0 / med, threads, sample
+
+
+# ----------------------------------------------------------------------------
+# WESUPPixelInference.forward  (models/wesup.py:382-400) -- SURVEY.md 8(f) row 3
+# ----------------------------------------------------------------------------
+def pixel_inference(w, img):
+    """img (1,3,H,W) -> (H,W,C): fc_layers + classifier applied to every pixel's 2112-vector."""
+    H, W = img.shape[-2:]
+    fm = feature_maps(w, img)[0]                        # (2112,H,W)
+    x = fm.reshape(fm.shape[0], -1)                     # :397
+    _, pred = mlp_head(w, x.t())                        # :398
+    return pred.view(H, W, -1)                          # :400

@@ -89,3 +89,12 @@ def test_empty_id_rejected():
     seg = torch.tensor([[1, 1], [2, 2]])      # 1-based ids: id 0 empty -> NaN row in the reference
     with pytest.raises(ValueError):
         orc.preprocess_superpixels(seg, None)
+
+
+def test_pixel_inference_oracle_matches_reference(golden_dir):
+    """oracle.pixel_inference vs the reference's WESUPPixelInference.forward (models/wesup.py:382-400)."""
+    fx = np.load(os.path.join(golden_dir, 'pixel_infer.npz'))
+    w = orc.to_torch(orc.make_weights(int(fx['seed']), feat_scale=float(fx['feat_scale'])))
+    out = orc.pixel_inference(w, torch.from_numpy(fx['img'])[None])
+    assert tuple(out.shape) == fx['out'].shape
+    assert rel_err(out.numpy(), fx['out']) < 1e-5

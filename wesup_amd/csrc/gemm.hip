@@ -134,38 +134,39 @@ __global__ __launch_bounds__(256, MINB) void gemm_nt_kernel(const NtParams p) {
         b_off[j] = (long)n * p.ldb + 4 * schunk;
     }
 
-    auto stage = [&](int kk, int buf) {
-        // wave-uniform LDS byte addresses: rows 8*wave.. of pass 0
-        const unsigned adst = __builtin_amdgcn_readfirstlane(lds_addr(As + buf * BM * BK + wave * 256));
-        const unsigned bdst = __builtin_amdgcn_readfirstlane(lds_addr(Bs + buf * BN * BK + wave * 256));
-        if (MODE == 0) {
-            if (p.stagger == 99) {      // diagnostic: no predication at all (valid only for full tiles)
+    // Staging of tile kk into buffer buf; part q issues the q-th 32-row pass of A and of B (kept separable so that
+    // the issue can be spread over the MFMA groups -- tried, no gain, see the main loop).
+    constexpr int NPART = (RA > RB) ? RA : RB;
+    auto stage_part = [&](int kk, int buf, int q) {
+        // wave-uniform LDS byte addresses: rows 8*wave.. of pass q
+        const unsigned adst = __builtin_amdgcn_readfirstlane(lds_addr(As + buf * BM * BK + wave * 256)) + q * 32 * BK * 4;
+        const unsigned bdst = __builtin_amdgcn_readfirstlane(lds_addr(Bs + buf * BN * BK + wave * 256)) + q * 32 * BK * 4;
 #pragma unroll
-                for (int i = 0; i < RA; ++i) glds16(p.A + a_off[i] + kk * BK, adst + i * 32 * BK * 4);
-#pragma unroll
-                for (int j = 0; j < RB; ++j) glds16(p.Bw + b_off[j] + kk * BK, bdst + j * 32 * BK * 4);
-                return;
+        for (int i = 0; i < RA; ++i) {
+            if (i != q) continue;
+            if (MODE == 0) {
+                glds16(a_msk[i] ? p.A + a_off[i] + kk * BK : zero, adst);
+            } else if (MODE == 1) {
+                const int k0 = kk * BK;
+                const int tap = k0 >> p.cin_shift;
+                const int ci0 = k0 & (p.Cin - 1);
+                const int toff = ((tap / 3 - 1) * p.W + (tap % 3 - 1)) * p.Cin + ci0;
+                glds16(((a_msk[i] >> tap) & 1u) ? p.A + a_off[i] + toff : zero, adst);
+            } else {
+                const int tap = kk * 8 + schunk;                     // logical chunk = tap (4 channels each)
+                const int toff = ((tap / 3 - 1) * p.W + (tap % 3 - 1)) * 4;
+                glds16((tap < 9 && ((a_msk[i] >> tap) & 1u)) ? p.A + a_off[i] + toff : zero, adst);
             }
-#pragma unroll
-            for (int i = 0; i < RA; ++i)
-                glds16(a_msk[i] ? p.A + a_off[i] + kk * BK : zero, adst + i * 32 * BK * 4);
-        } else if (MODE == 1) {
-            const int k0 = kk * BK;
-            const int tap = k0 >> p.cin_shift;
-            const int ci0 = k0 & (p.Cin - 1);
-            const int toff = ((tap / 3 - 1) * p.W + (tap % 3 - 1)) * p.Cin + ci0;
-#pragma unroll
-            for (int i = 0; i < RA; ++i)
-                glds16(((a_msk[i] >> tap) & 1u) ? p.A + a_off[i] + toff : zero, adst + i * 32 * BK * 4);
-        } else {
-            const int tap = kk * 8 + schunk;                     // logical chunk = tap (4 channels each)
-            const int toff = ((tap / 3 - 1) * p.W + (tap % 3 - 1)) * 4;
-#pragma unroll
-            for (int i = 0; i < RA; ++i)
-                glds16((tap < 9 && ((a_msk[i] >> tap) & 1u)) ? p.A + a_off[i] + toff : zero, adst + i * 32 * BK * 4);
         }
 #pragma unroll
-        for (int j = 0; j < RB; ++j) glds16(b_ok[j] ? p.Bw + b_off[j] + kk * BK : zero, bdst + j * 32 * BK * 4);
+        for (int j = 0; j < RB; ++j) {
+            if (j != q) continue;
+            glds16(b_ok[j] ? p.Bw + b_off[j] + kk * BK : zero, bdst);
+        }
+    };
+    auto stage = [&](int kk, int buf) {
+#pragma unroll
+        for (int q = 0; q < NPART; ++q) stage_part(kk, buf, q);
     };
 
     f32x16 acc[WM][WN];
@@ -209,6 +210,7 @@ __global__ __launch_bounds__(256, MINB) void gemm_nt_kernel(const NtParams p) {
             for (int j = 0; j < WN; ++j) fb[slot][j] = ld4(bs + 32 * j * BK + cb);
         };
         load_frag(0, 0);
+        // (issuing one staging part per MFMA group instead was measured 3-4 % slower: tools/gemm_trace.py)
         if (kk + 1 < nk) stage(kk + 1, cur ^ 1);
 #pragma unroll
         for (int g = 0; g < BK / 8; ++g) {
@@ -230,6 +232,7 @@ __global__ __launch_bounds__(256, MINB) void gemm_nt_kernel(const NtParams p) {
         }
         glds_wait();                // this wave's DMA for the next tile has landed ...
         __syncthreads();            // ... and so has everybody's; every wave is done reading buf[cur]
+        // (timing-only diagnostic without this barrier: main loop only 5 % shorter -- barrier coupling is not the limiter)
         cur ^= 1;
     }
 

@@ -305,6 +305,32 @@ class WESUP(nn.Module):
         return pred
 
 
+class WESUPPixelInference(WESUP):
+    """Pixel-wise inference (mirror of models/wesup.py:307-400): the MLP head runs on every
+    pixel's 2112-vector instead of on superpixel means.  Reuses the training kernels: backbone + side outputs
+    (engine), bilinear upsample into the pixel-major feature map, three fused GEMMs, classifier + softmax."""
+
+    @torch.no_grad()
+    def forward(self, x):
+        """x (1,3,H,W) -> (H,W,C) class probabilities (models/wesup.py:382-400)."""
+        self._ensure_engine()
+        if x.size(0) != 1:
+            raise ValueError('pixel inference takes one image (models/wesup.py:386)')
+        x = x.contiguous().float()
+        H, W = x.size(2), x.size(3)
+        labels = torch.zeros(1, H, W, dtype=torch.int32, device=x.device)        # one dummy superpixel
+        meta = ops.sp_preprocess(labels, None, 1, n_sp_host=[1])
+        self.engine.forward(x, meta, train=False, need_paint=False)
+        fm = self.engine.feature_maps().view(H * W, FM_CHANNELS)                  # (HW, 2112), pixel-major
+        self.fm_size = (H, W)
+        p = self.engine.p
+        h1 = ops.gemm_nt(fm, p['fc_layers.0.weight'], p['fc_layers.0.bias'], flags=ops.RELU_OUT)
+        h2 = ops.gemm_nt(h1, p['fc_layers.2.weight'], p['fc_layers.2.bias'], flags=ops.RELU_OUT)
+        feats = ops.gemm_nt(h2, p['fc_layers.4.weight'], p['fc_layers.4.bias'], flags=ops.RELU_OUT)
+        pred = ops.classifier_fwd(feats, p['classifier.0.weight'], p['classifier.0.bias'])
+        return pred.view(H, W, -1)
+
+
 class _WesupLossFn(torch.autograd.Function):
     """compute_loss of models/wesup.py:492-531 for a padded batch, all on the device."""
 
