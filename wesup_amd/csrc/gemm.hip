@@ -57,9 +57,6 @@ struct NtParams {
     int H, W, Cin, cin_shift;
     int flags;
     int tiles_m, tiles_n;
-    int m_fastest;   // tile order inside an XCD's contiguous range
-    int stagger;     // s_sleep units (64 clk) for every second wave of blocks
-    int prio;        // experiment: 1 = raise priority outside the MFMA phase, 2 = inside it
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -88,10 +85,9 @@ __global__ __launch_bounds__(256, MINB) void gemm_nt_kernel(const NtParams p) {
     const unsigned long long tr0 = __builtin_amdgcn_s_memrealtime();
     const int nwg = p.tiles_m * p.tiles_n;
     const int lt = xcd_remap(blockIdx.x, nwg);
-    // n fastest: the N-tiles of one pixel tile run together (activation rows shared through L2); m fastest: blocks of
-    // one weight slab run together (weights stay in L2) -- chosen per launch by which operand is the larger stream.
-    const int tile_n = p.m_fastest ? lt / p.tiles_m : lt % p.tiles_n;
-    const int tile_m = p.m_fastest ? lt % p.tiles_m : lt / p.tiles_n;
+    // n fastest: the N-tiles of one pixel tile run together and share the activation rows through their XCD's L2
+    // (the m-fastest order, which keeps a weight slab in L2 instead, measured within 1 %)
+    const int tile_n = lt % p.tiles_n, tile_m = lt / p.tiles_n;
     const int m_blk = tile_m * BM, n_blk = tile_n * BN;
     const bool relu_in = p.flags & WESUP_RELU_IN;
     const float* zero = reinterpret_cast<const float*>(g_zero_page);
@@ -186,16 +182,9 @@ __global__ __launch_bounds__(256, MINB) void gemm_nt_kernel(const NtParams p) {
     glds_wait();
     __syncthreads();
     const unsigned long long clk0 = __builtin_amdgcn_s_memtime(), rt0 = __builtin_amdgcn_s_memrealtime();
-    // Two blocks share a CU and run the same program: started together they stay in lockstep and their non-MFMA
-    // phases (DMA issue, barrier) coincide.  Delaying every second resident block by about half a K-step lets one
-    // block's MFMA phase cover the other's staging phase (MI355X_MICROARCH.md, 'Two waves per SIMD', item 9).
-    if (p.stagger > 0 && ((blockIdx.x >> 8) & 1)) {
-        for (int z = 0; z < p.stagger; ++z) __builtin_amdgcn_s_sleep(16);
-    }
+    // (staggering every second resident block by 0.5-4 K-steps, s_setprio around either phase: no effect)
     int cur = 0;
-    const int prio = p.prio;
     for (int kk = 0; kk < nk; ++kk) {
-        (void)prio;
         const float* as = As + cur * BM * BK + (wm0 + l31) * BK;
         const float* bs = Bs + cur * BN * BK + (wn0 + l31) * BK;
         // Fragment double buffering: the ds_reads of group g+1 are issued BEFORE the 16 MFMAs of group g, so their
@@ -302,17 +291,6 @@ template <int BM, int BN, int WM, int WN, int MODE, int MINB>
 static int launch_nt(NtParams p, hipStream_t st) {
     p.tiles_m = ceil_div(p.M, BM);
     p.tiles_n = ceil_div(p.N, BN);
-    {
-        static int ord = -1;
-        if (ord < 0) { const char* e = getenv("WESUP_TILE_ORDER"); ord = e ? atoi(e) : 0; }
-        p.m_fastest = ord;
-        static int stg = -1;
-        if (stg < 0) { const char* e = getenv("WESUP_STAGGER"); stg = e ? atoi(e) : 0; }
-        p.stagger = stg;
-        static int pr = -1;
-        if (pr < 0) { const char* e = getenv("WESUP_PRIO"); pr = e ? atoi(e) : 0; }
-        p.prio = pr;
-    }
     const size_t lds = (size_t)2 * (BM + BN) * BK * sizeof(float);
     hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, WM, WN, MODE, MINB>), dim3(p.tiles_m * p.tiles_n), dim3(256), lds, st, p);
     WESUP_CHECK_LAUNCH();
@@ -323,9 +301,6 @@ static int launch_nt(NtParams p, hipStream_t st) {
 template <int MODE>
 static int dispatch_nt(NtParams p, hipStream_t st) {
     const long t128 = (long)ceil_div(p.M, 128) * ceil_div(p.N, 128);
-    static int force = -1;
-    if (force < 0) { const char* e = getenv("WESUP_NT_TILE"); force = e ? atoi(e) : 0; }
-    if (force == 1 && p.M >= 128) return launch_nt<128, 64, 2, 1, MODE, 3>(p, st);   // experiment: 3 blocks/CU
     if (p.N > 64 && t128 >= 384) return launch_nt<128, 128, 2, 2, MODE, 2>(p, st);
     if (p.N <= 64 && (long)ceil_div(p.M, 128) >= 384) return launch_nt<128, 64, 2, 1, MODE, 2>(p, st);
     return launch_nt<64, 64, 1, 1, MODE, 2>(p, st);
