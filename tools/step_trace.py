@@ -1,0 +1,48 @@
+"""Kernel-by-kernel durations of ONE training step (single-stream schedule) from a rocprofv3 kernel trace.
+
+  rocprofv3 --kernel-trace --output-format csv -d gpurun_out/trace -- python3 tools/step_trace.py run
+  python3 tools/step_trace.py report gpurun_out/trace > gpurun_out/step_trace.txt
+"""
+import sys, os, glob, csv, re
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+if sys.argv[1] == 'run':
+    import torch
+    from oracle import wesup_oracle as orc
+    from wesup_amd import synth
+    from wesup_amd.models import initialize_trainer
+    from wesup_amd.utils.metrics import accuracy, dice
+    dev = torch.device('cuda:0')
+    B, H, W, g = 4, 480, 480, 24
+    trainer = initialize_trainer('wesup', device='cuda:0', max_superpixels=g * g)
+    trainer.model.load_state_dict({k: torch.from_numpy(v) for k, v in orc.make_weights(0, feat_scale=0.05).items()})
+    trainer.optimizer, _ = trainer.get_default_optimizer()
+    trainer.metric_funcs = [accuracy, dice]
+    trainer.tracker.train()
+    trainer.model.engine.two_streams = len(sys.argv) > 2 and sys.argv[2] == 'multi'
+    imgs, labs, pts, pix = synth.make_batch(1, B, H, W, g)
+    data = (torch.from_numpy(imgs).to(dev), torch.from_numpy(pix).to(dev), torch.from_numpy(pts).to(dev), torch.from_numpy(labs).to(dev))
+    for _ in range(4):
+        trainer.train_one_iteration('train', *data)
+    torch.cuda.synchronize()
+else:
+    f = glob.glob(os.path.join(sys.argv[2], '**', '*kernel_trace.csv'), recursive=True)[0]
+    rows = list(csv.DictReader(open(f)))
+    rows.sort(key=lambda r: int(r['Start_Timestamp']))
+    # last step = kernels after the last-but-one sgd_kernel
+    sgd = [i for i, r in enumerate(rows) if 'sgd_kernel' in r['Kernel_Name']]
+    lo = sgd[-2] + 1
+    step = rows[lo:sgd[-1] + 1]
+    t0 = int(step[0]['Start_Timestamp'])
+    agg = {}
+    for r in step:
+        n = r['Kernel_Name']
+        n = re.sub(r'\(.*', '', n).replace('void ', '')
+        d = (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3
+        print(f"{(int(r['Start_Timestamp']) - t0) / 1e3:10.1f} {d:9.1f} us  grid {r.get('Grid_Size_X', r.get('Grid_Size', '?')):>9} wg {r.get('Workgroup_Size_X', r.get('Workgroup_Size', '?')):>4}  {n}")
+        a = agg.setdefault(n, [0, 0.0])
+        a[0] += 1; a[1] += d
+    print('--- totals')
+    for n, (c, d) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+        print(f'{d:10.1f} us {c:4d}  {n}')
+    print('sum of kernel durations %.1f us, span %.1f us' % (sum(v[1] for v in agg.values()), (int(step[-1]['End_Timestamp']) - t0) / 1e3))

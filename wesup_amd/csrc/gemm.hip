@@ -545,6 +545,26 @@ __global__ void wgrad_reduce_kernel(const float* slab, float* dw, int Co, int Ci
     for (int t = 0; t < 9; ++t) d[t] = acc[t];
 }
 
+// Many slabs (tiny outputs under a long K, e.g. the 32x64 side-conv gradients over 921600 pixels: S > 1000): a
+// thread per output element walking all S slabs serially took 100-500 us.  The slab stack is a [S][M*Nslab] matrix
+// and its reduction a column sum, so a first pass of colsum_stage1 folds groups of slabs into <= 16 partial slabs
+// (same layout) and the final kernel only walks those.  Fixed order, deterministic.
+__global__ void colsum_stage1(const float* __restrict__ A, int lda, float* __restrict__ part, int M, int N, int rows_per);
+static int slab_fold_chunks(int S) { return S > 32 ? 16 : 0; }          // 0: reduce the slabs directly
+static size_t slab_fold_bytes(int S, size_t slab_elems) {
+    return slab_fold_chunks(S) ? (size_t)slab_fold_chunks(S) * slab_elems * sizeof(float) : 0;
+}
+// returns the slab stack the final reduce kernel should read, and its depth
+static const float* slab_fold(const float* slab, int& S, long slab_elems, float* part, hipStream_t st) {
+    const int chunks = slab_fold_chunks(S);
+    if (!chunks) return slab;
+    const int rows_per = ceil_div(S, chunks);
+    hipLaunchKernelGGL(colsum_stage1, dim3((unsigned)ceil_div(slab_elems, 64l), chunks), dim3(256), 0, st, slab,
+                       (int)slab_elems, part, S, (int)slab_elems, rows_per);
+    S = ceil_div(S, rows_per);
+    return part;
+}
+
 struct TnPlan {
     int bm, bn;       // 128x128 or 64x64
     int tiles_m, tiles_n, taps, S, k_per_split, Nslab;
@@ -603,7 +623,8 @@ static int launch_tn(TnParams p, const TnPlan& pl, hipStream_t st) {
 extern "C" size_t wesup_gemm_tn_workspace_bytes(int M, int N, int K) {
     if (M <= 0 || N <= 0 || K <= 0) return 0;
     const TnPlan pl = plan_tn(M, N, K, 1);
-    return (size_t)pl.S * M * pl.Nslab * sizeof(float);
+    const size_t elems = (size_t)M * pl.Nslab;
+    return align_up((size_t)pl.S * elems * sizeof(float), 256) + slab_fold_bytes(pl.S, elems);
 }
 
 extern "C" int wesup_gemm_tn(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N,
@@ -620,8 +641,11 @@ extern "C" int wesup_gemm_tn(const float* A, int lda, const float* B, int ldb, f
     int rc = launch_tn<0>(p, pl, st);
     if (rc) return rc;
     const long tot = (long)M * N;
-    hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, (const float*)ws, C,
-                       ldc, M, N, pl.Nslab, pl.S);
+    int S = pl.S;
+    float* part = (float*)((char*)ws + align_up((size_t)pl.S * tot * sizeof(float), 256));
+    const float* src = slab_fold((const float*)ws, S, tot, part, st);
+    hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, src, C, ldc, M, N,
+                       pl.Nslab, S);
     WESUP_CHECK_LAUNCH();
     return WESUP_OK;
 }
@@ -629,8 +653,8 @@ extern "C" int wesup_gemm_tn(const float* A, int lda, const float* B, int ldb, f
 // ---- column sums (bias gradients): two passes of one kernel, fixed order, 16 B per lane
 // block = 16 row-groups x 16 column quads (64 columns); each thread sums its rows of the chunk, the 16 row-groups
 // are combined through LDS in a fixed order.  Pass 2 runs the same kernel over the [chunks][N] partial matrix.
-__global__ __launch_bounds__(256) void colsum_stage1(const float* __restrict__ A, int lda, float* __restrict__ part,
-                                                     int M, int N, int rows_per) {
+__global__ void colsum_stage1(const float* __restrict__ A, int lda, float* __restrict__ part, int M, int N,
+                              int rows_per) {
     __shared__ float4 sh[16][16];
     const int q = threadIdx.x & 15, rg = threadIdx.x >> 4;
     const int n = blockIdx.x * 64 + 4 * q;
@@ -692,8 +716,9 @@ static TnPlan plan_wgrad(int B, int H, int W, int Ci, int Cout) {
 extern "C" size_t wesup_conv3x3_wgrad_workspace_bytes(int B, int H, int W, int Ci, int Cout) {
     if (B <= 0 || H <= 0 || W <= 0 || Ci <= 0 || Cout <= 0) return 0;
     const TnPlan pl = plan_wgrad(B, H, W, Ci, Cout);
-    const size_t slab = (size_t)pl.S * Cout * pl.Nslab * sizeof(float);
-    return align_up(slab, 256) + wesup_colsum_workspace_bytes(B * H * W, Cout);
+    const size_t elems = (size_t)Cout * pl.Nslab;
+    return align_up((size_t)pl.S * elems * sizeof(float), 256) + align_up(slab_fold_bytes(pl.S, elems), 256) +
+           wesup_colsum_workspace_bytes(B * H * W, Cout);
 }
 extern "C" int wesup_conv3x3_wgrad(const float* x, const float* dy, float* dw_kcrs, float* db, int B, int H, int W,
                                    int Ci, int Cout, int relu_in, void* ws, size_t ws_bytes, void* stream) {
@@ -719,12 +744,15 @@ extern "C" int wesup_conv3x3_wgrad(const float* x, const float* dy, float* dw_kc
     if (rc) return rc;
     const long tot = (long)Cout * Ci;
     // slab rows: [co][tap*Cs + ci] with Cs = 4 for the image layer (Nslab = 64), Ci otherwise
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, (const float*)ws,
-                       dw_kcrs, Cout, Ci, small ? 4 : Ci, pl.Nslab, pl.S);
+    const size_t elems = (size_t)Cout * pl.Nslab;
+    const size_t slab_b = align_up((size_t)pl.S * elems * sizeof(float), 256);
+    const size_t fold_b = align_up(slab_fold_bytes(pl.S, elems), 256);
+    int S = pl.S;
+    const float* src = slab_fold((const float*)ws, S, (long)elems, (float*)((char*)ws + slab_b), st);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, src, dw_kcrs, Cout,
+                       Ci, small ? 4 : Ci, pl.Nslab, S);
     WESUP_CHECK_LAUNCH();
-    if (db) {
-        const size_t slab = align_up((size_t)pl.S * Cout * pl.Nslab * sizeof(float), 256);
-        return wesup_colsum(dy, Cout, db, B * H * W, Cout, (char*)ws + slab, ws_bytes - slab, stream);
-    }
+    if (db)
+        return wesup_colsum(dy, Cout, db, B * H * W, Cout, (char*)ws + slab_b + fold_b, ws_bytes - slab_b - fold_b, stream);
     return WESUP_OK;
 }

@@ -39,20 +39,25 @@ class KernelTimer:
 
     def __init__(self):
         self.enabled = False
+        self.only = None           # optional set of tags: every other class runs without events
         self.pending = []          # (tag, start_event, end_event, work)
         self.totals = {}
+        self._free = []            # recycled events (an event record is not free: it fences the queue it is put on)
+
+    def _event(self):
+        return self._free.pop() if self._free else torch.cuda.Event(enable_timing=True)
 
     def begin(self, tag):
-        if not self.enabled:
+        if not self.enabled or (self.only is not None and tag not in self.only):
             return None
-        s = torch.cuda.Event(enable_timing=True)
+        s = self._event()
         s.record()                 # on the current stream = the stream the kernel is launched on
         return (tag, s)
 
     def end(self, tok, work=0.0):
         if tok is None:
             return
-        e = torch.cuda.Event(enable_timing=True)
+        e = self._event()
         e.record()
         self.pending.append((tok[0], tok[1], e, work))
 
@@ -61,6 +66,7 @@ class KernelTimer:
         for tag, s, e, work in self.pending:
             ms, n, wk = self.totals.get(tag, (0.0, 0, 0.0))
             self.totals[tag] = (ms + s.elapsed_time(e), n + 1, wk + work)
+            self._free += [s, e]
         self.pending = []
         return self.totals
 
