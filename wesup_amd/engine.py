@@ -87,6 +87,7 @@ class WesupEngine:
         self.device = next(iter(params.values())).device
         self._bufs = {}
         self._packed = None
+        self._prefetched = None
         self.ctx = None
         self.fuse_pool_bwd = True        # skip the (B,HW,2112) gradient tensor: pool-bwd fused into upsample-bwd
         self.fuse_pool_fwd = True        # skip the (B,HW,2112) feature map: scatter-mean fused with the upsample
@@ -199,15 +200,33 @@ class WesupEngine:
                       torch.empty(1024, 1024, dtype=torch.float32, device=self.device),
                       torch.empty(1024, self.D, dtype=torch.float32, device=self.device)]
             self._packed = pk
-        for l, idx in enumerate(CONV_IDX):
-            ops.pack_conv3x3_weight(self.p[f'backbone.{idx}.weight'], pk.wf[l], pk.wd[l], need_dgrad=(train and l > 0))
-        if train:
-            for l, off in enumerate(SIDE_OFF):
-                co = CONV_CH[l][1]
-                ops.transpose(self.p[f'side_conv{off}.weight'].view(co // 2, co), pk.sideT[l])
-            for i, k in enumerate((0, 2, 4)):
-                ops.transpose(self.p[f'fc_layers.{k}.weight'], pk.fcT[i])
+        if self._prefetched == train:          # prefetch_weights() already queued exactly this for the current step
+            self._prefetched = None
+            return pk
+        self._prefetched = None
+        # ~40 launch-latency-bound repack kernels go to the side stream (idle at this point) and are joined in front of
+        # the first convolution; the trainer queues them before the superpixel preprocessing (prefetch_weights)
+        with self._OnSide(self):
+            for l, idx in enumerate(CONV_IDX):
+                ops.pack_conv3x3_weight(self.p[f'backbone.{idx}.weight'], pk.wf[l], pk.wd[l], need_dgrad=(train and l > 0))
+            pk.ready = None
+            if self.two_streams:
+                pk.ready = torch.cuda.Event()
+                pk.ready.record()
+            if train:
+                for l, off in enumerate(SIDE_OFF):
+                    co = CONV_CH[l][1]
+                    ops.transpose(self.p[f'side_conv{off}.weight'].view(co // 2, co), pk.sideT[l])
+                for i, k in enumerate((0, 2, 4)):
+                    ops.transpose(self.p[f'fc_layers.{k}.weight'], pk.fcT[i])
         return pk
+
+    def prefetch_weights(self, train=True):
+        """Queue the weight repacking of the coming forward now (side stream, behind everything queued so far, i.e.
+        behind the optimiser step).  The parameters must not change between this call and the forward."""
+        self._prefetched = None
+        self._pack_weights(train)
+        self._prefetched = train
 
     # ------------------------------------------------------------------ forward
     def forward(self, img, meta, train=True, need_paint=True):
@@ -228,6 +247,8 @@ class WesupEngine:
         for l, (ci, co) in enumerate(CONV_CH):
             h, w = b.dims[l]
             idx, off = CONV_IDX[l], SIDE_OFF[l]
+            if l == 0 and pk.ready is not None:
+                torch.cuda.current_stream().wait_event(pk.ready)
             tok = T.begin('conv3x3_fwd')
             ops.conv3x3_fwd(cur, pk.wf[l], p[f'backbone.{idx}.bias'], co, relu_in=(l > 0), out=b.y[l])
             T.end(tok, 2.0 * B * h * w * (3 if l == 0 else ci) * co * 9)

@@ -56,6 +56,7 @@ class BaseTrainer(ABC):
         self.optimizer, self.scheduler = None, None
         self.metric_funcs = []
         self.reducer = None
+        self._host_buf = None            # pinned staging buffer of the per-step read-back
         self.world_size = 1
         self.rank = 0
 
@@ -130,6 +131,8 @@ class BaseTrainer(ABC):
 
     def train_one_iteration(self, phase, *data):
         from .. import ops
+        if hasattr(self.model, 'prefetch_weights'):      # weight repacking runs beside the superpixel preprocessing
+            self.model.prefetch_weights(train=(phase == 'train'))
         input_, target = self.preprocess(*data)
 
         self.optimizer.zero_grad()
@@ -145,13 +148,19 @@ class BaseTrainer(ABC):
                 seg = ops.seg_metrics(pred.detach().contiguous(), pixel_mask.to(torch.uint8).contiguous())
             if phase == 'train':
                 loss = self.compute_loss(pred, target, metrics=metrics)
-                host = self._read_back(loss, metrics, seg)           # the ONE host sync of the step
-                if math.isnan(host['loss']):
-                    raise ValueError('Loss is nan!')
-                metrics['loss'] = host['loss']
+                # The ONE host sync of the step.  The copy to pinned memory is queued behind the loss kernels, the
+                # backward pass is queued behind it, and only then does the host wait -- for the copy, i.e. for the
+                # forward pass -- so the GPU does not idle while the host wakes up and walks the backward schedule.
+                # A NaN loss still raises before the weights are touched (models/base.py:202-203): only the gradient
+                # buffers have been written by then.
+                pending = self._stage_read_back(loss, metrics, seg)
                 loss.backward()
                 if self.reducer is not None:
                     self.reducer.finish()
+                host = self._finish_read_back(pending, metrics)
+                if math.isnan(host['loss']):
+                    raise ValueError('Loss is nan!')
+                metrics['loss'] = host['loss']
                 self.optimizer.step()
             else:
                 host = self._read_back(None, metrics, seg)
@@ -172,6 +181,10 @@ class BaseTrainer(ABC):
 
     def _read_back(self, loss, metrics, seg):
         """Bring loss, the per-image loss terms and the segmentation sums to the host in one copy."""
+        return self._finish_read_back(self._stage_read_back(loss, metrics, seg), metrics)
+
+    def _stage_read_back(self, loss, metrics, seg):
+        """Queue the one device-to-host copy of the step (pinned buffer + event); no host wait here."""
         parts, layout = [], []
         if loss is not None:
             parts.append(loss.detach().reshape(1)); layout.append(('loss', 1))
@@ -182,10 +195,24 @@ class BaseTrainer(ABC):
             layout += [('terms', terms.numel()), ('n_sp', meta.B), ('n_l', meta.B)]
         if seg is not None:
             parts.append(seg.reshape(-1)); layout.append(('seg', seg.numel()))
-        out = {}
         if not parts:
+            return None
+        flat = torch.cat(parts)
+        n = flat.numel()
+        if self._host_buf is None or self._host_buf.numel() < n:
+            self._host_buf = torch.empty(max(4096, n), dtype=torch.float32).pin_memory()
+        self._host_buf[:n].copy_(flat, non_blocking=True)
+        done = torch.cuda.Event()
+        done.record()
+        return (layout, n, done)
+
+    def _finish_read_back(self, pending, metrics):
+        out = {}
+        if pending is None:
             return out
-        flat = torch.cat(parts).cpu().numpy().astype(np.float64)     # <- host sync
+        layout, n, done = pending
+        done.synchronize()                                           # <- host sync
+        flat = self._host_buf[:n].numpy().astype(np.float64)
         o = 0
         for name, n in layout:
             out[name] = flat[o:o + n]

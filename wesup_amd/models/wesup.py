@@ -279,6 +279,11 @@ class WESUP(nn.Module):
         fm = self.engine.feature_maps()
         return fm[0].permute(2, 0, 1) if fm.shape[0] == 1 else fm.permute(0, 3, 1, 2)
 
+    def prefetch_weights(self, train=True):
+        """Queue the repacking of the weights for the coming forward (see WesupEngine.prefetch_weights)."""
+        self._ensure_engine()
+        self.engine.prefetch_weights(train and self._anchor.requires_grad)
+
     def forward(self, x):
         """x = (img (B,3,H,W), sp_maps) with sp_maps a dense (N,H,W) tensor as in the reference (B = 1)
         or a SuperpixelMaps.  Returns the painted class-1 probability, (B,H,W)  (models/wesup.py:263-304)."""
