@@ -178,9 +178,9 @@ def main():
             for tag, (ms, n, work) in sorted(allk.items()):
                 kern[tag] = {'ms_per_step': round(ms / n_extra, 4), 'launches_per_step': n / n_extra,
                              'avg_us': round(ms / n * 1e3, 2)}
-                if tag.startswith('conv3x3') or tag in ('side_fwd', 'side_bwd', 'mlp_fwd', 'mlp_bwd'):
+                if tag.startswith('conv3x3') or tag in ('side_fwd', 'side_bwd', 'mlp_fwd', 'mlp_bwd', 'sp_pool_mat_fwd', 'upsample_mat_bwd'):
                     kern[tag]['tflops'] = round(work / (ms * 1e-3) / 1e12, 2)
-                else:
+                elif work > 0:
                     kern[tag]['gbs'] = round(work / (ms * 1e-3) / 1e9, 1)
             # dominant kernel: the implicit-GEMM 3x3 convolution (forward + dgrad share gemm_nt_kernel<..,1>)
             ms = sum(tot[t][0] for t in ('conv3x3_fwd', 'conv3x3_dgrad') if t in tot)

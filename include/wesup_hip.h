@@ -58,11 +58,17 @@ int wesup_transpose(const float* in, float* out, int rows, int cols, void* strea
  * replaces torchvision VGG16 Conv2d(k=3,pad=1)+ReLU (models/wesup.py:199,279) and its autograd.
  * y is the PRE-ReLU output (the hook taps it, models/wesup.py:246-253); the next
  * layer applies ReLU while loading (relu_in).  x has Cin channels (4 for the image). */
+/* ws (optional, may be NULL): room for the partial accumulator tiles of the stream-K blocks that balance a short last
+ * round of tiles over all block slots; without it the plain tiling is used.  Size for (Cin -> Cout); for dgrad ask
+ * with the channel counts swapped.  One workspace per stream that may run concurrently. */
+size_t wesup_conv3x3_workspace_bytes(int B, int H, int W, int Cin, int Cout);
 int wesup_conv3x3_fwd(const float* x, const float* w_fwd, const float* bias, float* y,
-                      int B, int H, int W, int Cin, int Cout, int relu_in, void* stream);
+                      int B, int H, int W, int Cin, int Cout, int relu_in,
+                      void* ws, size_t ws_bytes, void* stream);
 /* dx = conv_transpose(dy) ; if mask_src: dx = mask_src > 0 ? dx : 0 ; if accumulate: dx += old dx */
 int wesup_conv3x3_dgrad(const float* dy, const float* w_dgrad, const float* mask_src, float* dx,
-                        int B, int H, int W, int Cin, int Cout, int accumulate, void* stream);
+                        int B, int H, int W, int Cin, int Cout, int accumulate,
+                        void* ws, size_t ws_bytes, void* stream);
 /* dw in torch layout (Co,Ci,3,3); db (Co).  Ci is the TRUE channel count (3 for the image,
  * whose tensor has 4); relu_in applies ReLU to x while loading. */
 size_t wesup_conv3x3_wgrad_workspace_bytes(int B, int H, int W, int Ci, int Cout);
@@ -75,9 +81,10 @@ int wesup_conv3x3_wgrad(const float* x, const float* dy, float* dw_kcrs, float* 
  * nt:  C[M][N] = epilogue( A[M][K] . B[N][K]^T + bias[N] )      (K % 32 == 0, rows 16B aligned)
  * tn:  C[M][N] = A[K][M]^T . B[K][N]      (weight gradients; deterministic split-K)
  * colsum: out[N] = sum_m A[m][n]          (bias gradients) */
+size_t wesup_gemm_nt_workspace_bytes(int M, int N, int K);      /* stream-K partial tiles; ws may be NULL */
 int wesup_gemm_nt(const float* A, int lda, const float* B, int ldb, const float* bias,
                   float* C, int ldc, const float* mask, int ldmask,
-                  int M, int N, int K, int flags, void* stream);
+                  int M, int N, int K, int flags, void* ws, size_t ws_bytes, void* stream);
 size_t wesup_gemm_tn_workspace_bytes(int M, int N, int K);
 int wesup_gemm_tn(const float* A, int lda, const float* B, int ldb, float* C, int ldc,
                   int M, int N, int K, int relu_b, void* ws, size_t ws_bytes, void* stream);
@@ -132,6 +139,12 @@ int wesup_sp_pool_upsample_fwd(const float* s, const int32_t* pix_sorted, const 
                                const int32_t* seg_start, const int32_t* unit_row, float* sp_feat,
                                int B, int h, int w, int H, int W, int C, int ldo, int coff, int Kmax, int Umax,
                                void* ws, size_t ws_bytes, void* stream);
+/* the same linear map as a matrix over the h*w cells of a coarse side output:
+ * Wm[b][r][q] = (1/area_r) sum_{p in row r} bilinear_ac weight of cell q at pixel p     ([B][Kmax][h*w], h*w <= 8192).
+ * Then  sp_feat[b][:, slice] = Wm[b] . s[b]  and  ds[b] = Wm[b]^T . g[b][:, slice]  are wesup_gemm_tn calls
+ * (on Wm^T resp. Wm); used for the deep layers, where Wm is small (models/wesup.py:254-261 + :283-285 and autograd) */
+int wesup_sp_interp_matrix(const int32_t* pix_sorted, const int32_t* row_start, float* Wm,
+                           int B, int H, int W, int h, int w, int Kmax, void* stream);
 /* dfm[b][p][c] = g[b][new_row[p]][c] / area[new_row[p]] */
 int wesup_sp_pool_bwd(const float* g, const int32_t* new_row, const int32_t* area_new, float* dfm,
                       int B, int HW, int ldf, int C, int Kmax, void* stream);

@@ -39,6 +39,12 @@ def ops():
     return o
 
 
+@pytest.fixture(scope='module')
+def lib():
+    from wesup_amd import _lib as l
+    return l
+
+
 def rnd(*shape, seed=0, scale=1.0):
     g = torch.Generator().manual_seed(seed)
     return (torch.randn(*shape, generator=g) * scale).float()
@@ -452,3 +458,78 @@ def test_sp_pool_skewed_maps_multi_segment_rows(ops, H, W, g):
         got = torch.zeros(B, Kmax, C, device=d)
         ops.sp_pool_upsample_fwd(sl, m, got, coff)
         assert rel_err(got[..., coff:coff + Cs], ref2[..., coff:coff + Cs]) < 1e-5
+
+
+# ---------------------------------------------------------------- interpolation-pooling matrix (deep layers)
+@pytest.mark.parametrize('B,H,W,g,h,w', [(2, 64, 64, 6, 8, 8), (1, 96, 80, 7, 12, 10), (1, 120, 120, 12, 30, 30),
+                                         (1, 96, 96, 5, 96, 96 // 2)])
+def test_sp_interp_matrix_equals_fused_upsample_pool(ops, B, H, W, g, h, w):
+    """Wm . s == fused upsample + scatter-mean, Wm^T . g == fused pool-backward + upsample-backward, rows sum to 1."""
+    d = dev()
+    labs, masks = _sp_case(13, B, H, W, g)
+    Kmax = (g * g + 7) // 4 * 4
+    m = ops.sp_preprocess(torch.from_numpy(labs).to(d), torch.from_numpy(masks).to(d), Kmax)
+    Wm = ops.sp_interp_matrix(m, h, w)
+    assert torch.equal(Wm, ops.sp_interp_matrix(m, h, w))                   # order-independent accumulation
+    n_sp = m.n_sp.cpu().tolist()
+    C = 64
+    s = rnd(B, h, w, C, seed=5).to(d)
+    want = torch.zeros(B, Kmax, C, device=d)
+    ops.sp_pool_upsample_fwd(s, m, want, 0)
+    gup = rnd(B, Kmax, C, seed=6).to(d)
+    for b in range(B):
+        rows = Wm[b].sum(1).cpu()
+        assert float((rows[:n_sp[b]] - 1).abs().max()) < 1e-5 and float(rows[n_sp[b]:].abs().max()) == 0.0
+        got = ops.gemm_tn(ops.transpose(Wm[b]), s[b].view(h * w, C))         # (Kmax, C)
+        assert rel_err(got, want[b]) < 1e-5
+    want_ds = ops.upsample_bwd_fused(gup, m.new_row, m.area_new, H, W, 0, h, w, C)
+    for b in range(B):
+        gb = gup[b].clone()
+        gb[n_sp[b]:] = 0                                                       # padded rows carry no gradient
+        ds = ops.gemm_tn(Wm[b], gb)                                            # (hw, C)
+        want_b = ops.upsample_bwd_fused(gb.unsqueeze(0).expand(B, -1, -1).contiguous(), m.new_row, m.area_new, H, W, 0, h, w, C)[b]
+        assert rel_err(ds, want_b.view(h * w, C)) < 1e-5
+    del want_ds
+
+
+# ---------------------------------------------------------------- stream-K shapes of the NT family
+@pytest.mark.parametrize('M,N,K', [(2336, 1024, 2112), (3600, 512, 4608), (14400, 512, 2304), (57600, 256, 1152),
+                                   (130, 128, 512), (66000, 128, 512)])
+def test_gemm_nt_streamk(ops, lib, M, N, K):
+    """Shapes whose last round of 128x128 tiles is partial go through the stream-K blocks + fix-up kernel."""
+    d = dev()
+    assert lib.load().wesup_gemm_nt_workspace_bytes(M, N, K) > 0
+    A = rnd(M, K, seed=1)
+    Bw = rnd(N, K, seed=2, scale=K ** -0.5)
+    bias = rnd(N, seed=3)
+    ref = (A.double() @ Bw.double().t() + bias.double()).float()
+    out = ops.gemm_nt(A.to(d), Bw.to(d), bias.to(d))
+    assert rel_err(out, ref) < TOL
+    assert torch.equal(out, ops.gemm_nt(A.to(d), Bw.to(d), bias.to(d)))        # fixed summation order
+    big = rnd(M, N + 64, seed=4).to(d)
+    base = big.clone()
+    mask = rnd(M, N, seed=5)
+    ops.gemm_nt(A.to(d), Bw.to(d), None, out=big[:, 32:32 + N], mask=mask.to(d), flags=ops.ACCUM | ops.RELU_IN)
+    ref2 = base.cpu()
+    ref2[:, 32:32 + N] += torch.where(mask > 0, (F.relu(A).double() @ Bw.double().t()).float(), torch.zeros(()))
+    assert rel_err(big, ref2) < TOL
+
+
+@pytest.mark.parametrize('B,H,W,Cin,Cout', [(4, 30, 30, 512, 512), (2, 60, 60, 256, 512), (1, 120, 120, 128, 256)])
+def test_conv3x3_streamk(ops, lib, B, H, W, Cin, Cout):
+    d = dev()
+    assert lib.load().wesup_conv3x3_workspace_bytes(B, H, W, Cin, Cout) > 0
+    x = rnd(B, Cin, H, W, seed=1)
+    w = rnd(Cout, Cin, 3, 3, seed=2, scale=(9 * Cin) ** -0.5)
+    bias = rnd(Cout, seed=3)
+    ref = F.conv2d(F.relu(x).double(), w.double(), bias.double(), padding=1).float()
+    wf, wd = ops.pack_conv3x3_weight(w.to(d))
+    y = ops.conv3x3_fwd(nhwc(x).to(d), wf, bias.to(d), Cout, True)
+    assert rel_err(y, nhwc(ref)) < TOL
+    dy = rnd(B, Cout, H, W, seed=4)
+    refdx = F.conv_transpose2d(dy.double(), w.double(), padding=1).float()
+    msk = rnd(B, Cin, H, W, seed=5)
+    acc0 = rnd(B, H, W, Cin, seed=6)
+    dx = acc0.clone().to(d)
+    ops.conv3x3_dgrad(nhwc(dy).to(d), wd, Cin, mask_src=nhwc(msk).to(d), out=dx, accumulate=True)
+    assert rel_err(dx, acc0 + nhwc(torch.where(msk > 0, refdx, torch.zeros(())))) < TOL

@@ -46,3 +46,24 @@ else:
     for n, (c, d) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
         print(f'{d:10.1f} us {c:4d}  {n}')
     print('sum of kernel durations %.1f us, span %.1f us' % (sum(v[1] for v in agg.values()), (int(step[-1]['End_Timestamp']) - t0) / 1e3))
+    # ---- concurrency view: how long is any / an MFMA kernel in flight, how much do kernels overlap
+    ev = []
+    for r in step:
+        n = r['Kernel_Name']
+        mf = ('gemm_nt_kernel' in n) or ('gemm_tn_kernel' in n)
+        ev.append((int(r['Start_Timestamp']), 1, mf))
+        ev.append((int(r['End_Timestamp']), -1, mf))
+    ev.sort()
+    any_n = mf_n = 0
+    last = ev[0][0]
+    t_any = t_mf = t_mf2 = t_idle = 0
+    for t, d, mf in ev:
+        dt = t - last
+        if any_n > 0: t_any += dt
+        else: t_idle += dt
+        if mf_n > 0: t_mf += dt
+        if mf_n > 1: t_mf2 += dt
+        last = t
+        any_n += d
+        if mf: mf_n += d
+    print('in flight: any kernel %.1f us, idle %.1f us, >=1 MFMA GEMM %.1f us, >=2 MFMA GEMMs %.1f us' % (t_any / 1e3, t_idle / 1e3, t_mf / 1e3, t_mf2 / 1e3))

@@ -27,11 +27,13 @@ _SIGS = {
     'wesup_conv3x3_kpad': (c_int, 'i'),
     'wesup_pack_conv3x3_weight': (c_int, 'pppiip'),
     'wesup_transpose': (c_int, 'ppiip'),
-    'wesup_conv3x3_fwd': (c_int, 'ppppiiiiiip'),
-    'wesup_conv3x3_dgrad': (c_int, 'ppppiiiiiip'),
+    'wesup_conv3x3_workspace_bytes': (c_size_t, 'iiiii'),
+    'wesup_conv3x3_fwd': (c_int, 'ppppiiiiiipzp'),
+    'wesup_conv3x3_dgrad': (c_int, 'ppppiiiiiipzp'),
     'wesup_conv3x3_wgrad_workspace_bytes': (c_size_t, 'iiiii'),
     'wesup_conv3x3_wgrad': (c_int, 'ppppiiiiiipzp'),
-    'wesup_gemm_nt': (c_int, 'pipippipiiiiip'),
+    'wesup_gemm_nt_workspace_bytes': (c_size_t, 'iii'),
+    'wesup_gemm_nt': (c_int, 'pipippipiiiiipzp'),
     'wesup_gemm_tn_workspace_bytes': (c_size_t, 'iii'),
     'wesup_gemm_tn': (c_int, 'pipipiiiiipzp'),
     'wesup_colsum_workspace_bytes': (c_size_t, 'ii'),
@@ -49,6 +51,7 @@ _SIGS = {
     'wesup_sp_pool_fwd': (c_int, 'ppppppiiiiiipzp'),
     'wesup_sp_pool_bwd': (c_int, 'ppppiiiiip'),
     'wesup_sp_pool_upsample_fwd': (c_int, 'ppppppiiiiiiiiiipzp'),
+    'wesup_sp_interp_matrix': (c_int, 'pppiiiiiip'),
     'wesup_paint_fwd': (c_int, 'pppiiiiip'),
     'wesup_slic_num_centers': (c_int, 'iii'),
     'wesup_slic_workspace_bytes': (c_size_t, 'iiii'),

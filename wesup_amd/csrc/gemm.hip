@@ -57,6 +57,10 @@ struct NtParams {
     int H, W, Cin, cin_shift;
     int flags;
     int tiles_m, tiles_n;
+    int full_tiles;      // blocks [0, full_tiles) own one tile each
+    int sk_parts;        // stream-K blocks behind them (0: none) ...
+    int sk_steps;        // ... sharing this many K-steps of the remaining tiles
+    float* sk_ws;        // [sk_parts][2][BM*BN] partial tiles
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -83,19 +87,46 @@ __global__ __launch_bounds__(256, MINB) void gemm_nt_kernel(const NtParams p) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const unsigned long long tr0 = __builtin_amdgcn_s_memrealtime();
-    const int nwg = p.tiles_m * p.tiles_n;
-    const int lt = xcd_remap(blockIdx.x, nwg);
-    // n fastest: the N-tiles of one pixel tile run together and share the activation rows through their XCD's L2
-    // (the m-fastest order, which keeps a weight slab in L2 instead, measured within 1 %)
-    const int tile_n = lt % p.tiles_n, tile_m = lt / p.tiles_n;
-    const int m_blk = tile_m * BM, n_blk = tile_n * BN;
     const bool relu_in = p.flags & WESUP_RELU_IN;
     const float* zero = reinterpret_cast<const float*>(g_zero_page);
-
     // ---- staging role of this lane: row (tid>>3) of each 32-row pass, chunk position tid&7; the logical chunk it
     // fetches is position ^ swizzle(row) (the swizzle does not depend on the pass: 32*i >> 1 == 0 mod 8)
     const int srow = tid >> 3;
     const int schunk = (tid & 7) ^ ((srow >> 1) & 7);
+    const int wm0 = (wave / WAVES_N) * 32 * WM, wn0 = (wave % WAVES_N) * 32 * WN;
+    const int l31 = lane & 31, lhi = lane >> 5;
+    const int swa = ((wm0 + l31) >> 1) & 7, swb = ((wn0 + l31) >> 1) & 7;   // read-side swizzle (same for every i / j)
+    const int nk = p.K / BK;
+    unsigned long long clk0 = 0, rt0 = 0, tr2 = 0;
+
+    // ---- work of this block.  Blocks [0, full_tiles) compute one whole tile each.  The tiles that would form a partial
+    // last round (tile count not a multiple of the resident block slots) are cut stream-K style instead: their K-steps,
+    // laid end to end, are divided evenly over sk_parts blocks, so a block works on the tail of one tile and the head of
+    // the next, leaves both partial accumulator tiles in the workspace, and nt_fixup_kernel adds the pieces of each
+    // tile in K order and applies the epilogue.  Every slot of the chip then finishes together.
+    const bool sk = (int)blockIdx.x >= p.full_tiles;
+    int seg_g = 0, seg_end = nk, lt_full = 0, part = 0, slot = 0;
+    if (!sk) {
+        lt_full = xcd_remap(blockIdx.x, p.full_tiles);
+    } else {
+        part = xcd_remap(blockIdx.x - p.full_tiles, p.sk_parts);       // full_tiles % 8 == 0
+        seg_g = (int)((long)part * p.sk_steps / p.sk_parts);
+        seg_end = (int)((long)(part + 1) * p.sk_steps / p.sk_parts);
+    }
+
+    while (seg_g < seg_end) {
+    int lt = lt_full, ks = 0, ke = nk;
+    if (sk) {
+        const int t = seg_g / nk;
+        lt = p.full_tiles + t;
+        ks = seg_g - t * nk;
+        ke = min(nk, ks + seg_end - seg_g);
+    }
+    // n fastest: the N-tiles of one pixel tile run together and share the activation rows through their XCD's L2
+    // (the m-fastest order, which keeps a weight slab in L2 instead, measured within 1 %)
+    const int tile_n = lt % p.tiles_n, tile_m = lt / p.tiles_n;
+    const int m_blk = tile_m * BM, n_blk = tile_n * BN;
+
     long a_off[RA];
     unsigned a_msk[RA];
 #pragma unroll
@@ -173,34 +204,29 @@ __global__ __launch_bounds__(256, MINB) void gemm_nt_kernel(const NtParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int wm0 = (wave / WAVES_N) * 32 * WM, wn0 = (wave % WAVES_N) * 32 * WN;
-    const int l31 = lane & 31, lhi = lane >> 5;
-    const int swa = ((wm0 + l31) >> 1) & 7, swb = ((wn0 + l31) >> 1) & 7;   // read-side swizzle (same for every i / j)
-    const int nk = p.K / BK;
-
-    stage(0, 0);
+    stage(ks, 0);
     glds_wait();
     __syncthreads();
-    const unsigned long long clk0 = __builtin_amdgcn_s_memtime(), rt0 = __builtin_amdgcn_s_memrealtime();
+    if (slot == 0) { clk0 = __builtin_amdgcn_s_memtime(); rt0 = __builtin_amdgcn_s_memrealtime(); }
     // (staggering every second resident block by 0.5-4 K-steps, s_setprio around either phase: no effect)
     int cur = 0;
-    for (int kk = 0; kk < nk; ++kk) {
+    for (int kk = ks; kk < ke; ++kk) {
         const float* as = As + cur * BM * BK + (wm0 + l31) * BK;
         const float* bs = Bs + cur * BN * BK + (wn0 + l31) * BK;
         // Fragment double buffering: the ds_reads of group g+1 are issued BEFORE the 16 MFMAs of group g, so their
         // LDS latency hides under ~1000 MFMA cycles; only the first group of a K-step waits right after its reads.
         // The DMA for the next tile is issued after the first group's reads so that those are not queued behind it.
         float4 fa[2][WM], fb[2][WN];
-        auto load_frag = [&](int g, int slot) {
+        auto load_frag = [&](int g, int sl) {
             const int ca = ((2 * g + lhi) ^ swa) << 2, cb = ((2 * g + lhi) ^ swb) << 2;
 #pragma unroll
-            for (int i = 0; i < WM; ++i) fa[slot][i] = ld4(as + 32 * i * BK + ca);
+            for (int i = 0; i < WM; ++i) fa[sl][i] = ld4(as + 32 * i * BK + ca);
 #pragma unroll
-            for (int j = 0; j < WN; ++j) fb[slot][j] = ld4(bs + 32 * j * BK + cb);
+            for (int j = 0; j < WN; ++j) fb[sl][j] = ld4(bs + 32 * j * BK + cb);
         };
         load_frag(0, 0);
         // (issuing one staging part per MFMA group instead was measured 3-4 % slower: tools/gemm_trace.py)
-        if (kk + 1 < nk) stage(kk + 1, cur ^ 1);
+        if (kk + 1 < ke) stage(kk + 1, cur ^ 1);
 #pragma unroll
         for (int g = 0; g < BK / 8; ++g) {
             const int sl = g & 1;
@@ -225,14 +251,17 @@ __global__ __launch_bounds__(256, MINB) void gemm_nt_kernel(const NtParams p) {
         cur ^= 1;
     }
 
-    const unsigned long long tr2 = __builtin_amdgcn_s_memrealtime();
-    if (blockIdx.x == 0 && tid == 0) {
-        g_clock_probe[0] = __builtin_amdgcn_s_memtime() - clk0;
-        g_clock_probe[1] = tr2 - rt0;
+    if (slot == 0) {
+        tr2 = __builtin_amdgcn_s_memrealtime();
+        if (blockIdx.x == 0 && tid == 0) {
+            g_clock_probe[0] = __builtin_amdgcn_s_memtime() - clk0;
+            g_clock_probe[1] = tr2 - rt0;
+        }
     }
     // ---- epilogue through LDS: the accumulator tile (lane holds D[(r&3)+8*(r>>2)+4*lhi][l31] of each 32x32
     // sub-tile) is written to a [rows][BN+4] image, then every thread handles 16-byte pieces of full rows so that
-    // bias / ReLU mask / accumulate / store all move 16 B per lane on contiguous row segments.
+    // bias / ReLU mask / accumulate / store all move 16 B per lane on contiguous row segments.  A stream-K block
+    // stores the raw tile to its workspace slot instead.
     float* Cs = smem;
     const bool relu_out = p.flags & WESUP_RELU_OUT, accum = p.flags & WESUP_ACCUM, use_mask = p.flags & WESUP_MASK;
     constexpr int QN = BN / 4;                 // float4 pieces per row
@@ -241,7 +270,8 @@ __global__ __launch_bounds__(256, MINB) void gemm_nt_kernel(const NtParams p) {
     const int n = n_blk + 4 * cq;
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
     float4 bv = zero4;
-    if (p.bias && n < p.N) bv = ld4(p.bias + n);
+    if (!sk && p.bias && n < p.N) bv = ld4(p.bias + n);
+    float* raw = sk ? p.sk_ws + ((long)part * 2 + slot) * (BM * BN) : nullptr;
 #pragma unroll
     for (int e = 0; e < EP; ++e) {
         if (e > 0) __syncthreads();
@@ -255,7 +285,11 @@ __global__ __launch_bounds__(256, MINB) void gemm_nt_kernel(const NtParams p) {
                         Cs[(wm0 - e * HR + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lhi) * LDC + wn0 + 32 * j + l31] = acc[i][j][r];
         }
         __syncthreads();
-        if (n < p.N) {                              // N % 4 == 0
+        if (sk) {
+#pragma unroll 4
+            for (int rr = r0; rr < HR; rr += ROWS_PER_PASS)
+                st4(raw + (long)(e * HR + rr) * BN + 4 * cq, ld4(Cs + rr * LDC + 4 * cq));
+        } else if (n < p.N) {                       // N % 4 == 0
 #pragma unroll 4
             for (int rr = r0; rr < HR; rr += ROWS_PER_PASS) {
                 const int m = m_blk + e * HR + rr;
@@ -279,6 +313,11 @@ __global__ __launch_bounds__(256, MINB) void gemm_nt_kernel(const NtParams p) {
             }
         }
     }
+    seg_g += ke - ks;
+    ++slot;
+    if (seg_g < seg_end) __syncthreads();          // the staging buffers double as the epilogue image
+    }   // segments
+
     if (g_trace && tid == 0) {
         unsigned long long* t = g_trace + 6 * (long)blockIdx.x;
         t[0] = tr0; t[1] = rt0; t[2] = tr2; t[3] = __builtin_amdgcn_s_memrealtime();
@@ -287,20 +326,110 @@ __global__ __launch_bounds__(256, MINB) void gemm_nt_kernel(const NtParams p) {
     }
 }
 
+// Stream-K fix-up: C tile = epilogue(sum of the partial tiles of the parts that covered it, in K order).
+// One float4 per thread; the part boundaries are the same integer formula the GEMM blocks used.
+template <int BM, int BN>
+__global__ __launch_bounds__(256) void nt_fixup_kernel(const NtParams p) {
+    constexpr int PER_TILE = BM * BN / 4 / 256;
+    const int t = blockIdx.x / PER_TILE;
+    const int piece = (blockIdx.x % PER_TILE) * 256 + threadIdx.x;
+    const int rr = piece / (BN / 4), cq = piece % (BN / 4);
+    const int nk = p.K / BK;
+    const long W = p.sk_steps;
+    const int P = p.sk_parts;
+    auto first_step = [&](int q) { return (long)q * W / P; };
+    auto part_of = [&](long s) {
+        int q = (int)(s * P / W);
+        while (q + 1 < P && first_step(q + 1) <= s) ++q;
+        return q;
+    };
+    const int q0 = part_of((long)t * nk), q1 = part_of((long)t * nk + nk - 1);
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int q = q0; q <= q1; ++q) {
+        const int slot = ((int)(first_step(q) / nk) == t) ? 0 : 1;
+        const float4 w = ld4(p.sk_ws + ((long)q * 2 + slot) * (BM * BN) + rr * BN + 4 * cq);
+        v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
+    }
+    const int lt = p.full_tiles + t;
+    const int tile_n = lt % p.tiles_n, tile_m = lt / p.tiles_n;
+    const int m = tile_m * BM + rr, n = tile_n * BN + 4 * cq;
+    if (m >= p.M || n >= p.N) return;
+    if (p.bias) {
+        const float4 bv = ld4(p.bias + n);
+        v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+    }
+    if (p.flags & WESUP_RELU_OUT) v = relu4(v);
+    if (p.flags & WESUP_MASK) {
+        const float4 mk = ld4(p.mask + (long)m * p.ldmask + n);
+        v.x = mk.x > 0.f ? v.x : 0.f;
+        v.y = mk.y > 0.f ? v.y : 0.f;
+        v.z = mk.z > 0.f ? v.z : 0.f;
+        v.w = mk.w > 0.f ? v.w : 0.f;
+    }
+    float* c = p.C + (long)m * p.ldc + n;
+    if (p.flags & WESUP_ACCUM) {
+        const float4 o = ld4(c);
+        v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+    }
+    st4(c, v);
+}
+
+// Stream-K plan of an (M, N, K) problem under 128x128 tiles and 2 resident blocks per CU: how many tiles run whole,
+// how many blocks share the K-steps of the rest.  parts == 0: plain tiling.
+struct SkPlan {
+    int full, parts, steps;
+    size_t ws_bytes;
+};
+static SkPlan plan_streamk(int M, int N, int K) {
+    SkPlan pl = {0, 0, 0, 0};
+    const int slots = 512;
+    const long tiles = (long)ceil_div(M, 128) * ceil_div(N, 128);
+    const int nk = K / BK;
+    pl.full = (int)tiles;
+    const int R = (int)(tiles % slots);
+    // worth it when the last round is visibly short of full and a part still gets >= 8 K-steps; a part must be shorter
+    // than a tile (so that it touches at most two tiles: two workspace slots per part)
+    if (N <= 64 || nk < 16 || R == 0 || R * 10 > slots * 9) return pl;
+    const long W = (long)R * nk;
+    const int P = (int)(W / 8 < slots ? W / 8 : slots);
+    if (P <= R) return pl;
+    pl.full = (int)tiles - R;
+    pl.parts = P;
+    pl.steps = (int)W;
+    pl.ws_bytes = (size_t)P * 2 * 128 * 128 * sizeof(float);
+    return pl;
+}
+
 template <int BM, int BN, int WM, int WN, int MODE, int MINB>
-static int launch_nt(NtParams p, hipStream_t st) {
+static int launch_nt(NtParams p, hipStream_t st, const SkPlan* sk = nullptr, void* ws = nullptr) {
     p.tiles_m = ceil_div(p.M, BM);
     p.tiles_n = ceil_div(p.N, BN);
+    p.full_tiles = p.tiles_m * p.tiles_n;
+    p.sk_parts = 0; p.sk_steps = 0; p.sk_ws = nullptr;
+    if (sk && sk->parts > 0) {
+        p.full_tiles = sk->full; p.sk_parts = sk->parts; p.sk_steps = sk->steps; p.sk_ws = (float*)ws;
+    }
     const size_t lds = (size_t)2 * (BM + BN) * BK * sizeof(float);
-    hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, WM, WN, MODE, MINB>), dim3(p.tiles_m * p.tiles_n), dim3(256), lds, st, p);
+    hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, WM, WN, MODE, MINB>), dim3(p.full_tiles + p.sk_parts), dim3(256), lds, st, p);
     WESUP_CHECK_LAUNCH();
+    if (p.sk_parts > 0) {
+        const int rem_tiles = p.tiles_m * p.tiles_n - p.full_tiles;
+        hipLaunchKernelGGL((nt_fixup_kernel<BM, BN>), dim3(rem_tiles * (BM * BN / 1024)), dim3(256), 0, st, p);
+        WESUP_CHECK_LAUNCH();
+    }
     return WESUP_OK;
 }
 
-// Tile choice: 128x128 when the grid still fills 256 CUs twice over; 128x64 for N <= 64; 64x64 for small M.
+// Tile choice: 128x128 when the grid fills 256 CUs twice over, or -- given a workspace -- whenever stream-K can spread
+// the tiles of a short last round over all block slots; 128x64 for N <= 64; 64x64 for small problems.
 template <int MODE>
-static int dispatch_nt(NtParams p, hipStream_t st) {
+static int dispatch_nt(NtParams p, hipStream_t st, void* ws, size_t ws_bytes) {
     const long t128 = (long)ceil_div(p.M, 128) * ceil_div(p.N, 128);
+    if (ws && p.N > 64) {
+        const SkPlan sk = plan_streamk(p.M, p.N, p.K);
+        if (sk.parts > 0 && ws_bytes >= sk.ws_bytes && !((uintptr_t)ws & 15))
+            return launch_nt<128, 128, 2, 2, MODE, 2>(p, st, &sk, ws);
+    }
     if (p.N > 64 && t128 >= 384) return launch_nt<128, 128, 2, 2, MODE, 2>(p, st);
     if (p.N <= 64 && (long)ceil_div(p.M, 128) >= 384) return launch_nt<128, 64, 2, 1, MODE, 2>(p, st);
     return launch_nt<64, 64, 1, 1, MODE, 2>(p, st);
@@ -312,9 +441,14 @@ static int ilog2(int v) {
     return s;
 }
 
+extern "C" size_t wesup_gemm_nt_workspace_bytes(int M, int N, int K) {
+    if (M <= 0 || N <= 0 || K <= 0 || (K % BK)) return 0;
+    return plan_streamk(M, N, K).ws_bytes;
+}
+
 extern "C" int wesup_gemm_nt(const float* A, int lda, const float* B, int ldb, const float* bias, float* C,
                              int ldc, const float* mask, int ldmask, int M, int N, int K, int flags,
-                             void* stream) {
+                             void* ws, size_t ws_bytes, void* stream) {
     if (!A || !B || !C || M <= 0 || N <= 0 || K <= 0 || (K % BK) || (lda % 4) || (ldb % 4) || (N % 4) || (ldc % 4) ||
         (ldmask % 4) || (((uintptr_t)A | (uintptr_t)B | (uintptr_t)C | (uintptr_t)mask | (uintptr_t)bias) & 15))
         return WESUP_ERR_INVALID;
@@ -323,7 +457,7 @@ extern "C" int wesup_gemm_nt(const float* A, int lda, const float* B, int ldb, c
     p.A = A; p.Bw = B; p.bias = bias; p.C = C; p.mask = mask;
     p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldmask = ldmask;
     p.flags = flags;
-    return dispatch_nt<0>(p, (hipStream_t)stream);
+    return dispatch_nt<0>(p, (hipStream_t)stream, ws, ws_bytes);
 }
 
 // host-synchronous debug helper (NOT part of the hot path): in-kernel clock of the last NT GEMM launch in MHz
@@ -346,7 +480,7 @@ extern "C" int wesup_conv3x3_kpad(int Ci) {
 }
 
 static int conv_common(const float* x, const float* w, const float* bias, float* y, const float* mask, int B,
-                       int H, int W, int Cin, int Cout, int flags, hipStream_t st) {
+                       int H, int W, int Cin, int Cout, int flags, void* ws, size_t ws_bytes, hipStream_t st) {
     if (!x || !w || !y || B <= 0 || H <= 0 || W <= 0) return WESUP_ERR_INVALID;
     const bool small = (Cin == 4);
     if (!small && (Cin < 32 || (Cin & (Cin - 1)))) return WESUP_ERR_INVALID;
@@ -357,20 +491,28 @@ static int conv_common(const float* x, const float* w, const float* bias, float*
     p.lda = Cin; p.ldb = p.K; p.ldc = Cout; p.ldmask = Cout;
     p.H = H; p.W = W; p.Cin = Cin; p.cin_shift = ilog2(Cin);
     p.flags = flags;
-    return small ? dispatch_nt<2>(p, st) : dispatch_nt<1>(p, st);
+    return small ? dispatch_nt<2>(p, st, nullptr, 0) : dispatch_nt<1>(p, st, ws, ws_bytes);
+}
+
+// workspace of the forward implicit GEMM (stream-K partial tiles) for (Cin -> Cout); for dgrad call it with the
+// channel counts swapped (the input of that GEMM is dy)
+extern "C" size_t wesup_conv3x3_workspace_bytes(int B, int H, int W, int Cin, int Cout) {
+    if (B <= 0 || H <= 0 || W <= 0 || Cin < 32 || Cout <= 0) return 0;
+    return plan_streamk(B * H * W, Cout, 9 * Cin).ws_bytes;
 }
 
 extern "C" int wesup_conv3x3_fwd(const float* x, const float* w_fwd, const float* bias, float* y, int B, int H,
-                                 int W, int Cin, int Cout, int relu_in, void* stream) {
-    return conv_common(x, w_fwd, bias, y, nullptr, B, H, W, Cin, Cout, relu_in ? WESUP_RELU_IN : 0,
+                                 int W, int Cin, int Cout, int relu_in, void* ws, size_t ws_bytes, void* stream) {
+    return conv_common(x, w_fwd, bias, y, nullptr, B, H, W, Cin, Cout, relu_in ? WESUP_RELU_IN : 0, ws, ws_bytes,
                        (hipStream_t)stream);
 }
 
 extern "C" int wesup_conv3x3_dgrad(const float* dy, const float* w_dgrad, const float* mask_src, float* dx, int B,
-                                   int H, int W, int Cin, int Cout, int accumulate, void* stream) {
+                                   int H, int W, int Cin, int Cout, int accumulate, void* ws, size_t ws_bytes,
+                                   void* stream) {
     // the same implicit GEMM with the roles of the channel counts swapped: input dy has Cout channels
     int flags = (mask_src ? WESUP_MASK : 0) | (accumulate ? WESUP_ACCUM : 0);
-    return conv_common(dy, w_dgrad, nullptr, dx, mask_src, B, H, W, Cout, Cin, flags, (hipStream_t)stream);
+    return conv_common(dy, w_dgrad, nullptr, dx, mask_src, B, H, W, Cout, Cin, flags, ws, ws_bytes, (hipStream_t)stream);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -507,6 +507,54 @@ extern "C" int wesup_sp_pool_upsample_fwd(const float* s, const int32_t* pix_sor
     return WESUP_OK;
 }
 
+// ------------------------------------------------------------------ interpolation-pooling matrix of a coarse grid
+// For a side output at a coarse h x w grid, "bilinear upsample to H x W, then average over superpixel r" is one
+// linear map of the h*w coarse cells:   Wm[b][r][q] = (1/area_r) * sum_{p in row r} bw(p, q),  bw = the (<= 4) bilinear
+// weights of full-resolution pixel p (torch align_corners=True formula, as in wesup_upsample_fwd).  With it the
+// fused forward is  sp_feat[b][:, slice] = Wm[b] . s[b]  and the fused backward  ds[b] = Wm[b]^T . g[b][:, slice]:
+// two small MFMA GEMMs per image (wesup_gemm_tn on Wm^T / Wm) instead of H*W*C gathers per layer.  It pays for the
+// deep layers (60x60 / 30x30 at 480x480: 1536 of the 2112 channels), where Wm is a few MB per image.
+// One block per row r; the weights are accumulated in LDS as 2^-40 fixed point with 64-bit integer atomics, so the
+// result does not depend on the order in which the pixels arrive (deterministic).
+__global__ __launch_bounds__(256) void sp_interp_matrix_kernel(const int32_t* __restrict__ pix_sorted,
+                                                               const int32_t* __restrict__ row_start,
+                                                               float* __restrict__ Wm, int H, int W, int h, int w,
+                                                               int Kmax, FastDiv dW, float sh, float sw) {
+    extern __shared__ unsigned long long cell[];
+    const int r = blockIdx.x, b = blockIdx.y;
+    const int hw = h * w;
+    const int j0 = row_start[b * (Kmax + 1) + r], j1 = row_start[b * (Kmax + 1) + r + 1];
+    for (int q = threadIdx.x; q < hw; q += 256) cell[q] = 0ull;
+    __syncthreads();
+    const int32_t* list = pix_sorted + (long)b * H * W;
+    const float FX = 1099511627776.f;      // 2^40
+    for (int j = j0 + threadIdx.x; j < j1; j += 256) {
+        const int p = list[j];
+        const int Y = fast_div(p, dW), X = p - Y * W;
+        const Lerp2 ly = lerp2_of(Y, sh, h), lx = lerp2_of(X, sw, w);
+        // (a tap with zero weight adds nothing; i0 == i1 at the last row / column just adds twice into one cell)
+        atomicAdd(&cell[ly.i0 * w + lx.i0], (unsigned long long)(ly.l0 * lx.l0 * FX + 0.5f));
+        atomicAdd(&cell[ly.i0 * w + lx.i1], (unsigned long long)(ly.l0 * lx.l1 * FX + 0.5f));
+        atomicAdd(&cell[ly.i1 * w + lx.i0], (unsigned long long)(ly.l1 * lx.l0 * FX + 0.5f));
+        atomicAdd(&cell[ly.i1 * w + lx.i1], (unsigned long long)(ly.l1 * lx.l1 * FX + 0.5f));
+    }
+    __syncthreads();
+    const float scale = (j1 > j0) ? 1.f / ((float)(j1 - j0) * FX) : 0.f;
+    float* out = Wm + ((long)b * Kmax + r) * hw;
+    for (int q = threadIdx.x; q < hw; q += 256) out[q] = (float)cell[q] * scale;
+}
+extern "C" int wesup_sp_interp_matrix(const int32_t* pix_sorted, const int32_t* row_start, float* Wm, int B, int H,
+                                      int W, int h, int w, int Kmax, void* stream) {
+    if (!pix_sorted || !row_start || !Wm || B <= 0 || H <= 0 || W <= 0 || h <= 0 || w <= 0 || h > H || w > W ||
+        Kmax <= 0 || (long)h * w > 8192)
+        return WESUP_ERR_INVALID;
+    const float sh = H > 1 ? (float)(h - 1) / (float)(H - 1) : 0.f, sw = W > 1 ? (float)(w - 1) / (float)(W - 1) : 0.f;
+    hipLaunchKernelGGL(sp_interp_matrix_kernel, dim3(Kmax, B), dim3(256), (size_t)h * w * sizeof(unsigned long long),
+                       (hipStream_t)stream, pix_sorted, row_start, Wm, H, W, h, w, Kmax, make_fastdiv(W), sh, sw);
+    WESUP_CHECK_LAUNCH();
+    return WESUP_OK;
+}
+
 // ------------------------------------------------------------------ scatter-mean backward (row broadcast)
 __global__ void sp_pool_bwd_kernel(const float* __restrict__ g, const int32_t* __restrict__ new_row,
                                    const int32_t* __restrict__ area, float* __restrict__ dfm, long HW, int ldf, int C4,

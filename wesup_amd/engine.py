@@ -91,6 +91,7 @@ class WesupEngine:
         self.ctx = None
         self.fuse_pool_bwd = True        # skip the (B,HW,2112) gradient tensor: pool-bwd fused into upsample-bwd
         self.fuse_pool_fwd = True        # skip the (B,HW,2112) feature map: scatter-mean fused with the upsample
+        self.matrix_pool = True          # coarse layers: upsample+scatter-mean (and backward) as GEMMs with Wm
         self.two_streams = True          # side branch on its own HIP stream
         self._side_stream = None
         self._wgrad_stream = None
@@ -154,6 +155,31 @@ class WesupEngine:
                     b.yp.append(torch.empty(B, h, w, co, **f32))
                 else:
                     b.yp.append(None)
+            # Coarse resolutions (deep layers): upsample + scatter-mean and its backward run as GEMMs with the
+            # interpolation-pooling matrix Wm of the resolution; the side outputs of the layers that share a
+            # resolution sit side by side in one buffer so that one GEMM per image serves all of them.
+            b.groups, b.group_of = [], [None] * 13
+            if self.fuse_pool_fwd and self.fuse_pool_bwd and self.matrix_pool and Kmax % 4 == 0:
+                l = 0
+                while l < 13:
+                    e = l
+                    while e + 1 < 13 and b.dims[e + 1] == b.dims[l]:
+                        e += 1
+                    gh, gw = b.dims[l]
+                    if (gh, gw) != (H, W) and gh * gw <= 4096 and (gh * gw) % 4 == 0:
+                        g = _Bufs()
+                        g.layers, g.h, g.w = list(range(l, e + 1)), gh, gw
+                        g.off = SIDE_OFF[l]
+                        g.C = sum(CONV_CH[i][1] // 2 for i in g.layers)
+                        g.s = torch.empty(B, gh, gw, g.C, **f32)
+                        g.Wm = torch.empty(B, Kmax, gh * gw, **f32)
+                        g.WmT = torch.empty(B, gh * gw, Kmax, **f32)
+                        for i in g.layers:
+                            c0 = SIDE_OFF[i] - g.off
+                            b.s[i] = g.s[..., c0:c0 + CONV_CH[i][1] // 2]
+                            b.group_of[i] = len(b.groups)
+                        b.groups.append(g)
+                    l = e + 1
             # the (B,HW,2112) feature map only exists on the unfused path (or when somebody asks for it)
             b.fm = None if self.fuse_pool_fwd else torch.empty(B, H, W, FM_CHANNELS, **f32)
             b.fm_valid = False
@@ -172,6 +198,11 @@ class WesupEngine:
             b.G = [torch.empty_like(y) for y in b.y]
             b.ds = [None if ((hh, ww) == (H, W) and not self.fuse_pool_bwd) else torch.empty(B, hh, ww, co // 2, **f32)
                     for (hh, ww), (ci, co) in zip(b.dims, CONV_CH)]
+            for g in b.groups:
+                g.ds = torch.empty(B, g.h, g.w, g.C, **f32)
+                for i in g.layers:
+                    c0 = SIDE_OFF[i] - g.off
+                    b.ds[i] = g.ds[..., c0:c0 + CONV_CH[i][1] // 2]
             b.dxp = [None if yp is None else torch.empty(yp.shape[0], yp.shape[1], yp.shape[2], CONV_CH[l + 1][0], **f32)
                      for l, yp in enumerate(b.yp)]
             b.dfm = None if self.fuse_pool_bwd else torch.empty(B, H, W, FM_CHANNELS, **f32)
@@ -240,6 +271,14 @@ class WesupEngine:
         p = self.p
         T = self.timer
         ops.pack_input(img, b.x0)
+        if b.groups:
+            with self._OnSide(self):     # the side stream is idle until conv1_1 is done
+                tok = T.begin('interp_matrix')
+                for g in b.groups:
+                    ops.sp_interp_matrix(meta, g.h, g.w, out=g.Wm)
+                    for i in range(B):
+                        ops.transpose(g.Wm[i], g.WmT[i])
+                T.end(tok, 0.0)
         cur = b.x0
         fused = self.fuse_pool_fwd
         b.fm_valid = not fused
@@ -263,7 +302,15 @@ class WesupEngine:
                 else:
                     ops.gemm_nt(y2d, ws, p[f'side_conv{off}.bias'], out=b.s[l].view(B * h * w, co // 2))
                 T.end(tok, 2.0 * B * h * w * co * (co // 2))
-                if fused:
+                if b.group_of[l] is not None:
+                    g = b.groups[b.group_of[l]]
+                    if l == g.layers[-1]:        # all side outputs of this resolution are in: sp_in slice = Wm . s
+                        tok = T.begin('sp_pool_mat_fwd')
+                        for i in range(B):
+                            ops.gemm_tn(g.WmT[i], g.s[i].view(g.h * g.w, g.C), out=b.sp_in[i][:, g.off:g.off + g.C],
+                                        ws_tag='side')
+                        T.end(tok, 2.0 * B * Kmax * g.h * g.w * g.C)
+                elif fused:
                     tok = T.begin('sp_pool_up_fwd')
                     ops.sp_pool_upsample_fwd(b.s[l], meta, b.sp_in, off)
                     T.end(tok, 4.0 * B * (h * w * (co // 2) + H * W + Kmax * (co // 2)))
@@ -307,7 +354,7 @@ class WesupEngine:
             if b.fm is None:
                 b.fm = torch.empty(B, H, W, FM_CHANNELS, dtype=torch.float32, device=self.device)
             for l, off in enumerate(SIDE_OFF):
-                ops.upsample_fwd(b.s[l], b.fm, off)
+                ops.upsample_fwd(b.s[l].contiguous(), b.fm, off)
             b.fm_valid = True
         return b.fm
 
@@ -354,8 +401,18 @@ class WesupEngine:
                 h, w = b.dims[l]
                 off = SIDE_OFF[l]
                 P = B * h * w
-                tok = T.begin('upsample_bwd')
-                if self.fuse_pool_bwd:
+                if b.group_of[l] is not None:
+                    grp = b.groups[b.group_of[l]]
+                    if l == grp.layers[-1]:      # ds of every layer of this resolution at once: ds = Wm^T . gsp slice
+                        tok = T.begin('upsample_mat_bwd')
+                        for i in range(B):
+                            ops.gemm_tn(grp.Wm[i], b.gsp[i][:, grp.off:grp.off + grp.C],
+                                        out=grp.ds[i].view(grp.h * grp.w, grp.C), ws_tag='side')
+                        T.end(tok, 2.0 * B * Kmax * grp.h * grp.w * grp.C)
+                    tok = None
+                    ds2d = b.ds[l].view(P, co // 2)
+                elif self.fuse_pool_bwd:
+                    tok = T.begin('upsample_bwd')
                     ops.upsample_bwd_fused(b.gsp, meta.new_row, meta.area_new, H, W, off, h, w, co // 2, out=b.ds[l])
                     ds2d = b.ds[l].view(P, co // 2)
                 elif b.s[l] is None:

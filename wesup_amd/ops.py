@@ -45,6 +45,13 @@ def workspace(nbytes, device, tag='default'):
     return buf
 
 
+def _nt_workspace(nbytes, device):
+    """Stream-K workspace of the NT GEMM family: one per stream, because launches on different streams overlap."""
+    if not nbytes:
+        return None
+    return workspace(nbytes, device, 'nt%x' % torch.cuda.current_stream().cuda_stream)
+
+
 # ---------------------------------------------------------------- packing
 def pack_input(img, out=None):
     _chk(img, name='img')
@@ -91,7 +98,9 @@ def conv3x3_fwd(x, w_fwd, bias, Cout, relu_in, out=None):
     if out is None:
         out = torch.empty(B, H, W, Cout, dtype=torch.float32, device=x.device)
     assert out.shape == (B, H, W, Cout) and out.is_contiguous()
-    _lib.call('wesup_conv3x3_fwd', _p(x), _p(w_fwd), _p(bias), _p(out), B, H, W, Cin, Cout, int(relu_in), _stream())
+    nb = _lib.load().wesup_conv3x3_workspace_bytes(B, H, W, Cin, Cout)
+    _lib.call('wesup_conv3x3_fwd', _p(x), _p(w_fwd), _p(bias), _p(out), B, H, W, Cin, Cout, int(relu_in),
+              _p(_nt_workspace(nb, x.device)), nb, _stream())
     return out
 
 
@@ -105,8 +114,9 @@ def conv3x3_dgrad(dy, w_dgrad, Cin, mask_src=None, out=None, accumulate=False):
         assert not accumulate
         out = torch.empty(B, H, W, Cin, dtype=torch.float32, device=dy.device)
     assert out.shape == (B, H, W, Cin) and out.is_contiguous()
+    nb = _lib.load().wesup_conv3x3_workspace_bytes(B, H, W, Cout, Cin)
     _lib.call('wesup_conv3x3_dgrad', _p(dy), _p(w_dgrad), _p(mask_src), _p(out), B, H, W, Cin, Cout, int(accumulate),
-              _stream())
+              _p(_nt_workspace(nb, dy.device)), nb, _stream())
     return out
 
 
@@ -150,8 +160,9 @@ def gemm_nt(A, Bw, bias=None, out=None, mask=None, flags=0):
         flags |= MASK
     if bias is not None:
         _chk(bias, name='bias'); assert bias.numel() == N
+    nb = _lib.load().wesup_gemm_nt_workspace_bytes(M, N, K)
     _lib.call('wesup_gemm_nt', _p(A), _ld(A), _p(Bw), _ld(Bw), _p(bias), _p(out), _ld(out), _p(mask), ldmask, M, N, K,
-              flags, _stream())
+              flags, _p(_nt_workspace(nb, A.device)), nb, _stream())
     return out
 
 
@@ -317,6 +328,19 @@ def sp_pool_upsample_fwd(s, meta, out, coff):
     ws = workspace(nb, s.device, 'pool_up')
     _lib.call('wesup_sp_pool_upsample_fwd', _p(s), _p(meta.pix_sorted), _p(meta.row_start), _p(meta.seg_start),
               _p(meta.unit_row), _p(out), B, h, w, meta.H, meta.W, C, out.shape[2], coff, meta.Kmax, meta.Umax, _p(ws), nb,
+              _stream())
+    return out
+
+
+def sp_interp_matrix(meta, h, w, out=None):
+    """Wm (B,Kmax,h*w): upsample-to-(H,W)-then-average-over-superpixel as a matrix over the coarse cells."""
+    B, Kmax = meta.B, meta.Kmax
+    assert 0 < h <= meta.H and 0 < w <= meta.W and h * w <= 8192
+    if out is None:
+        out = torch.empty(B, Kmax, h * w, dtype=torch.float32, device=meta.pix_sorted.device)
+    _chk(out, name='out')
+    assert out.shape == (B, Kmax, h * w)
+    _lib.call('wesup_sp_interp_matrix', _p(meta.pix_sorted), _p(meta.row_start), _p(out), B, meta.H, meta.W, h, w, Kmax,
               _stream())
     return out
 
