@@ -36,6 +36,7 @@ def main():
     ap.add_argument('--grid', type=int, default=24, help='superpixel grid side: g*g superpixels per image')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true')
+    ap.add_argument('--no-streamk', action='store_true', help='A/B: plain tiling in the NT GEMM family')
     ap.add_argument('--event-every', type=int, default=4, help='steps of the timed region that carry HIP events: every n-th')
     ap.add_argument('--timed-classes', default='conv3x3_fwd,conv3x3_dgrad',
                     help="kernel classes that get HIP events inside the timed region ('all', 'none' or a comma list); an "
@@ -67,6 +68,9 @@ def main():
     from wesup_amd.utils.metrics import accuracy, dice
 
     B, H, W, g = args.batch, args.size, args.size, args.grid
+    if args.no_streamk:
+        from wesup_amd import ops as _ops
+        _ops.STREAMK = False
     weights = orc.make_weights(0, feat_scale=0.05)
     trainer = initialize_trainer('wesup', device=str(dev), max_superpixels=g * g, force_allreduce=args.force_ddp)
     trainer.model.load_state_dict({k: torch.from_numpy(v) for k, v in weights.items()})
@@ -115,7 +119,10 @@ def main():
     if use_dist:
         import torch.distributed as dist
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        tmin = t.clone()
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tmin, op=dist.ReduceOp.MIN)
+        rank_time = {'min_s': round(float(tmin.item()), 4), 'max_s': round(float(t.item()), 4)}
         elapsed = float(t.item())
     loss_last = trainer.tracker.history['loss'][-1]
 
@@ -231,9 +238,18 @@ def main():
                     'frac_of_measured_copy_6290': round(a / 6290.0, 4),
                     'traffic': (3813303.7 * 2 + 19008.0) * 1024 if (B, H, g) == (4, 480, 24) else None,
                     'avg_launch_us': round(pool_ms * 1e3, 2), 'algorithmic_bytes': by}
+        if use_dist:
+            out['rank_time'] = rank_time              # spread of the per-rank wall time of the timed region
         if world == 1 and not args.no_cpu_baseline:
             v, cores, sample = orc.time_cpu_baseline(iters=2, warmup=1)
-            out['cpu_baseline'] = {'value': round(v, 4), 'unit': 'images/s', 'cores': cores, 'kind': 'port', 'sample': sample}
+            cpu = 'unknown CPU'
+            try:
+                with open('/proc/cpuinfo') as f:
+                    cpu = next(l.split(':', 1)[1].strip() for l in f if l.startswith('model name'))
+            except Exception:
+                pass
+            out['cpu_baseline'] = {'value': round(v, 4), 'unit': 'images/s', 'cores': cores, 'kind': 'port',
+                                   'sample': sample, 'host': f'{cpu}, {os.cpu_count()} logical cores'}
         print(json.dumps(out), flush=True)
     if use_dist:
         import torch.distributed as dist

@@ -567,38 +567,49 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnParams p) {
     // MODE 2: column quad qb is tap qb (4 channels each), only 9 of the 16 quads are real
     const int dh2 = qb / 3 - 1, dw2 = qb % 3 - 1;
 
-    auto stage = [&](int k0, int buf) {
+    // Staging is split in two: src_of() turns a K-step into the per-lane source pointers (integer VALU work only:
+    // pixel -> (b, h, w), border tests, address), issue() fires the LDS-DMA with pointers computed one K-step earlier.
+    // The pointer arithmetic for step kk+2 sits in the same basic block as the MFMAs of step kk, branch-free, so the
+    // scheduler can sink it into the MFMA shadow instead of leaving ~250 VALU instructions in front of every K-step
+    // during which this wave issues no matrix instruction.
+    auto src_a = [&](int k0, int i) -> const float* {
+        const int k = k0 + ra_row + RPA * i;
+        const bool ok = a_col_ok & (k < k_end);
+        return ok ? p.A + (long)k * p.lda + m_blk + 4 * qa : zero;
+    };
+    auto src_b = [&](int k0, int i) -> const float* {
+        const int k = k0 + rb_row + RPB * i;
+        if (MODE == 0) {
+            const bool ok = b_col_ok & (k < k_end);
+            return ok ? p.Bx + (long)k * p.ldb + n_blk + 4 * qb : zero;
+        }
+        const int t = fast_div(k, p.dW);       // b*H + h
+        const int w = k - t * p.W;
+        const int bb = fast_div(t, p.dH);
+        const int h = t - bb * p.H;
+        if (MODE == 1) {
+            const int hh = h + dh, ww = w + dw;
+            const bool ok = b_col_ok & (k < k_end) & (hh >= 0) & (hh < p.H) & (ww >= 0) & (ww < p.W);
+            return ok ? p.Bx + (long)(k + dh * p.W + dw) * p.ldb + n_blk + 4 * qb : zero;
+        }
+        const int hh = h + dh2, ww = w + dw2;
+        const bool ok = (qb < 9) & (k < k_end) & (hh >= 0) & (hh < p.H) & (ww >= 0) & (ww < p.W);
+        return ok ? p.Bx + (long)(k + dh2 * p.W + dw2) * 4 : zero;
+    };
+    auto src_of = [&](int k0, const float* (&pa)[NA], const float* (&pb)[NB]) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) pa[i] = src_a(k0, i);
+#pragma unroll
+        for (int i = 0; i < NB; ++i) pb[i] = src_b(k0, i);
+    };
+    auto issue = [&](const float* (&pa)[NA], const float* (&pb)[NB], int buf) {
         // the image is linear in tid (4*tid floats per pass): wave-uniform LDS byte addresses
         const unsigned adst = __builtin_amdgcn_readfirstlane(lds_addr(As + buf * BK * BM + wave * 256));
         const unsigned bdst = __builtin_amdgcn_readfirstlane(lds_addr(Bs + buf * BK * BN + wave * 256));
 #pragma unroll
-        for (int i = 0; i < NA; ++i) {
-            const int k = k0 + ra_row + RPA * i;
-            glds16((a_col_ok && k < k_end) ? p.A + (long)k * p.lda + m_blk + 4 * qa : zero, adst + i * 4096);
-        }
+        for (int i = 0; i < NA; ++i) glds16(pa[i], adst + i * 4096);
 #pragma unroll
-        for (int i = 0; i < NB; ++i) {
-            const int k = k0 + rb_row + RPB * i;
-            const float* src = zero;
-            if (MODE == 0) {
-                if (b_col_ok && k < k_end) src = p.Bx + (long)k * p.ldb + n_blk + 4 * qb;
-            } else {
-                const int t = fast_div(k, p.dW);       // b*H + h
-                const int w = k - t * p.W;
-                const int bb = fast_div(t, p.dH);
-                const int h = t - bb * p.H;
-                if (MODE == 1) {
-                    const int hh = h + dh, ww = w + dw;
-                    if (b_col_ok && k < k_end && hh >= 0 && hh < p.H && ww >= 0 && ww < p.W)
-                        src = p.Bx + (long)(k + dh * p.W + dw) * p.ldb + n_blk + 4 * qb;
-                } else {
-                    const int hh = h + dh2, ww = w + dw2;
-                    if (qb < 9 && k < k_end && hh >= 0 && hh < p.H && ww >= 0 && ww < p.W)
-                        src = p.Bx + (long)(k + dh2 * p.W + dw2) * 4;
-                }
-            }
-            glds16(src, bdst + i * 4096);
-        }
+        for (int i = 0; i < NB; ++i) glds16(pb[i], bdst + i * 4096);
     };
 
     f32x16 acc[WM][WN];
@@ -614,29 +625,45 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnParams p) {
     const int nk = (k_end - k_begin + BK - 1) / BK;
     const bool relu_b = p.relu_b;
 
-    if (nk > 0) stage(k_begin, 0);
+    const float* pa[NA];
+    const float* pb[NB];
+    src_of(k_begin, pa, pb);
+    if (nk > 0) issue(pa, pb, 0);
+    src_of(k_begin + BK, pa, pb);                  // pointers of K-step 1 (all-zero-page beyond k_end)
     glds_wait();
     __syncthreads();
     int cur = 0;
     for (int kk = 0; kk < nk; ++kk) {
-        if (kk + 1 < nk) stage(k_begin + (kk + 1) * BK, cur ^ 1);
+        issue(pa, pb, cur ^ 1);                    // unconditional (past k_end every lane reads the zero page)
+        const int k2 = k_begin + (kk + 2) * BK;    // its pointers are consumed by the next iteration's issue()
         const float* as = As + cur * BK * BM + lhi * BM + wm0 + l31;
         const float* bs = Bs + cur * BK * BN + lhi * BN + wn0 + l31;
+        // fragment double buffering: the reads of k-pair kp+1 are in flight while the MFMAs of kp issue
+        float a[2][WM], b[2][WN];
+        auto load_frag = [&](int kp, int sl) {
+#pragma unroll
+            for (int i = 0; i < WM; ++i) a[sl][i] = as[2 * kp * BM + 32 * i];
+#pragma unroll
+            for (int j = 0; j < WN; ++j) b[sl][j] = bs[2 * kp * BN + 32 * j];
+        };
+        load_frag(0, 0);
 #pragma unroll
         for (int kp = 0; kp < BK / 2; ++kp) {
-            float a[WM], b[WN];
+            const int sl = kp & 1;
+            if (kp + 1 < BK / 2) load_frag(kp + 1, sl ^ 1);
+            if (relu_b) {
 #pragma unroll
-            for (int i = 0; i < WM; ++i) a[i] = as[2 * kp * BM + 32 * i];
-#pragma unroll
-            for (int j = 0; j < WN; ++j) {
-                b[j] = bs[2 * kp * BN + 32 * j];
-                if (relu_b) b[j] = fmaxf(b[j], 0.f);
+                for (int j = 0; j < WN; ++j) b[sl][j] = fmaxf(b[sl][j], 0.f);
             }
 #pragma unroll
             for (int i = 0; i < WM; ++i)
 #pragma unroll
                 for (int j = 0; j < WN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[sl][i], b[sl][j], acc[i][j], 0, 0, 0);
+            // one slice of the pointer arithmetic per MFMA group, fenced so that it stays in this group's shadow
+            if (kp < NB) pb[kp] = src_b(k2, kp);
+            else if (kp < NB + NA) pa[kp - NB] = src_a(k2, kp - NB);
+            __builtin_amdgcn_sched_barrier(0);
         }
         glds_wait();
         __syncthreads();
@@ -724,7 +751,8 @@ static TnPlan plan_tn(int M, int N, int K, int taps) {
     const int ksteps = ceil_div(K, BK);
     // Split-K factor: the grid (tiles x S blocks, all of equal cost) should fill the resident block slots of the chip
     // a whole number of times -- 2 blocks/CU for the 128x128 tile (64 KiB LDS each), 4 for 64x64 -- so that no
-    // partial round is left at the end.  Among 1..3 rounds pick the fullest; every split keeps >= 8 K-steps.
+    // partial round is left at the end.  Among 1..3 rounds pick the fullest (starting from 2-4 rounds instead measured
+    // 0-4 % slower); every split keeps >= 8 K-steps.
     const int slots = 256 * (big ? 2 : 4);
     const int maxS = ksteps / 8 > 0 ? ksteps / 8 : 1;
     int S = 1;

@@ -12,6 +12,7 @@ import torch
 from . import _lib
 
 RELU_IN, RELU_OUT, ACCUM, MASK = 1, 2, 4, 8
+STREAMK = True        # hand the NT GEMM family its stream-K workspace (False: plain tiling, for A/B measurements)
 
 
 def _stream():
@@ -47,7 +48,7 @@ def workspace(nbytes, device, tag='default'):
 
 def _nt_workspace(nbytes, device):
     """Stream-K workspace of the NT GEMM family: one per stream, because launches on different streams overlap."""
-    if not nbytes:
+    if not nbytes or not STREAMK:
         return None
     return workspace(nbytes, device, 'nt%x' % torch.cuda.current_stream().cuda_stream)
 
