@@ -235,15 +235,17 @@ __global__ __launch_bounds__(256, MINB) void gemm_nt_kernel(const NtParams p) {
 #pragma unroll
                 for (int i = 0; i < WM; ++i) fa[sl][i] = relu4(fa[sl][i]);
             }
+            // element t of the fragments = k-step t of the group; consecutive MFMAs go to different accumulators
 #pragma unroll
-            for (int i = 0; i < WM; ++i)
+            for (int t = 0; t < 4; ++t)
 #pragma unroll
-                for (int j = 0; j < WN; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[sl][i].x, fb[sl][j].x, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[sl][i].y, fb[sl][j].y, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[sl][i].z, fb[sl][j].z, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[sl][i].w, fb[sl][j].w, acc[i][j], 0, 0, 0);
-                }
+                for (int i = 0; i < WM; ++i)
+#pragma unroll
+                    for (int j = 0; j < WN; ++j) {
+                        const float av = t == 0 ? fa[sl][i].x : t == 1 ? fa[sl][i].y : t == 2 ? fa[sl][i].z : fa[sl][i].w;
+                        const float bv = t == 0 ? fb[sl][j].x : t == 1 ? fb[sl][j].y : t == 2 ? fb[sl][j].z : fb[sl][j].w;
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][j], 0, 0, 0);
+                    }
         }
         glds_wait();                // this wave's DMA for the next tile has landed ...
         __syncthreads();            // ... and so has everybody's; every wave is done reading buf[cur]
