@@ -210,6 +210,15 @@ def main():
                                        f'{args.steps} timed steps; the side-branch and wgrad streams run concurrently '
                                        '(roofline_isolated has the same kernels alone on the GPU)')
             out['kernels'] = kern
+            # whole-step view of the matrix cores: every GEMM-shaped FLOP of the step (conv fwd/dgrad/wgrad, side convs,
+            # MLP, matrix pooling of the deep layers) over the wall time of the step, all streams together
+            gemm_tags = ('conv3x3_fwd', 'conv3x3_dgrad', 'conv3x3_wgrad', 'side_fwd', 'side_bwd', 'mlp_fwd', 'mlp_bwd',
+                         'sp_pool_mat_fwd', 'upsample_mat_bwd')
+            fl_step = sum(allk[t][2] for t in gemm_tags if t in allk) / n_extra
+            a = fl_step / (ms_per_step * 1e-3) / 1e12
+            out['roofline_step'] = {'bound': 'mfma', 'what': 'all GEMM FLOPs of one step / wall time of the step (3 streams)',
+                                    'achieved': round(a, 2), 'peak': PEAK_MFMA_F32_TFLOPS, 'unit': 'TFLOP/s',
+                                    'frac': round(a / PEAK_MFMA_F32_TFLOPS, 4), 'flop_per_step': fl_step}
             out['kernels_how'] = (f'{n_extra} extra untimed steps with events on every kernel class (same 3-stream '
                                   'schedule); events on every class inside the timed region cost 16 % of the step')
             if iso is not None:

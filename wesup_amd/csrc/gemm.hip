@@ -208,7 +208,8 @@ __global__ __launch_bounds__(256, MINB) void gemm_nt_kernel(const NtParams p) {
     glds_wait();
     __syncthreads();
     if (slot == 0) { clk0 = __builtin_amdgcn_s_memtime(); rt0 = __builtin_amdgcn_s_memrealtime(); }
-    // (staggering every second resident block by 0.5-4 K-steps, s_setprio around either phase: no effect)
+    // (staggering every second resident block by 0.5-4 K-steps; s_setprio around either phase, alternating between the two
+    // co-resident blocks per K-step, or fixed per block: no effect on throughput)
     int cur = 0;
     for (int kk = ks; kk < ke; ++kk) {
         const float* as = As + cur * BM * BK + (wm0 + l31) * BK;
