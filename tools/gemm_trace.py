@@ -34,6 +34,10 @@ def run(name, fn, nblocks):
     print(f'   distinct CUs {len(groups)}, blocks/CU histogram {np.bincount(sizes).tolist()}, same-CU pair |dt| p50 {np.median(pair_diff) if pair_diff else -1:.1f} us')
     cu_mean = np.array([np.mean(v) for v in groups.values()])
     print(f'   per-CU mean loop: p10 {np.percentile(cu_mean,10):.1f} p50 {np.median(cu_mean):.1f} p90 {np.percentile(cu_mean,90):.1f}; by blocks/CU:', {n: round(float(np.mean([np.mean(v) for v in groups.values() if len(v) == n])), 1) for n in sorted(set(sizes))})
+    if nblocks > 512:      # blocks behind the whole tiles are stream-K parts
+        pt = np.arange(nblocks) >= 512
+        print(f'   whole tiles: start p50 {np.median(st[~pt]):.1f}, end p10 {np.percentile(en[~pt],10):.1f} p50 {np.median(en[~pt]):.1f} p90 {np.percentile(en[~pt],90):.1f} max {en[~pt].max():.1f}')
+        print(f'   parts      : start p10 {np.percentile(st[pt],10):.1f} p50 {np.median(st[pt]):.1f} p90 {np.percentile(st[pt],90):.1f}, end p10 {np.percentile(en[pt],10):.1f} p50 {np.median(en[pt]):.1f} p90 {np.percentile(en[pt],90):.1f} max {en[pt].max():.1f}; duration p10 {np.percentile((en-st)[pt],10):.1f} p50 {np.median((en-st)[pt]):.1f} p90 {np.percentile((en-st)[pt],90):.1f}')
     first = st < 1.0
     print(f'   first-wave blocks: {first.sum()}  their loop p50 {np.median((le - ls)[first]):.1f}; later blocks loop p50 {np.median((le - ls)[~first]) if (~first).any() else 0:.1f}')
 M, N, K = 32768, 256, 2304
@@ -41,4 +45,4 @@ A = torch.randn(M, K, device=d); B = torch.randn(N, K, device=d); C = torch.empt
 run('gemm 512 tiles K=2304', lambda: ops.gemm_nt(A, B, None, out=C), 512)
 x = torch.randn(4, 120, 120, 256, device=d); w = torch.randn(256, 256, 3, 3, device=d) * 0.02
 wf, _ = ops.pack_conv3x3_weight(w, need_dgrad=False); y = torch.empty(4, 120, 120, 256, device=d); bias = torch.zeros(256, device=d)
-run('conv fwd L6 (900 tiles)', lambda: ops.conv3x3_fwd(x, wf, bias, 256, True, out=y), 900)
+run('conv fwd L6 (900 tiles: 512 whole + 512 stream-K parts)', lambda: ops.conv3x3_fwd(x, wf, bias, 256, True, out=y), 1024)
