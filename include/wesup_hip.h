@@ -80,13 +80,15 @@ int wesup_conv3x3_wgrad(const float* x, const float* dy, float* dw_kcrs, float* 
  * side 1x1 convs (models/wesup.py:208-209,253), fc_layers (models/wesup.py:213-220,288) and their grads.
  * nt:  C[M][N] = epilogue( A[M][K] . B[N][K]^T + bias[N] )      (K % 32 == 0, rows 16B aligned)
  * tn:  C[M][N] = A[K][M]^T . B[K][N]      (weight gradients; deterministic split-K)
- * colsum: out[N] = sum_m A[m][n]          (bias gradients) */
+ * colsum: out[N] = sum_m A[m][n]          (bias gradients without a weight gradient next to them) */
 size_t wesup_gemm_nt_workspace_bytes(int M, int N, int K);      /* stream-K partial tiles; ws may be NULL */
 int wesup_gemm_nt(const float* A, int lda, const float* B, int ldb, const float* bias,
                   float* C, int ldc, const float* mask, int ldmask,
                   int M, int N, int K, int flags, void* ws, size_t ws_bytes, void* stream);
 size_t wesup_gemm_tn_workspace_bytes(int M, int N, int K);
-int wesup_gemm_tn(const float* A, int lda, const float* B, int ldb, float* C, int ldc,
+/* colsum_a (optional, [M]): also out[m] = sum_k A[k][m] -- the bias gradient that goes with a weight gradient --
+ * accumulated from the staged A tiles, so A is not read a second time */
+int wesup_gemm_tn(const float* A, int lda, const float* B, int ldb, float* C, int ldc, float* colsum_a,
                   int M, int N, int K, int relu_b, void* ws, size_t ws_bytes, void* stream);
 size_t wesup_colsum_workspace_bytes(int M, int N);
 int wesup_colsum(const float* A, int lda, float* out, int M, int N, void* ws, size_t ws_bytes, void* stream);

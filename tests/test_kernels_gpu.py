@@ -155,6 +155,12 @@ def test_gemm_tn_colsum(ops, M, N, K):
     assert torch.equal(out, ops.gemm_tn(A.to(d), Bm.to(d)))
     cs = ops.colsum(A.to(d))
     assert rel_err(cs, A.double().sum(0).float()) < TOL
+    cs2 = torch.empty(M, device=d)                                     # the same sums as a by-product of the GEMM
+    out2 = ops.gemm_tn(A.to(d), Bm.to(d), colsum=cs2)
+    assert torch.equal(out2, out) and rel_err(cs2, A.double().sum(0).float()) < TOL
+    cs3 = torch.empty(M, device=d)
+    ops.gemm_tn(A.to(d), Bm.to(d), colsum=cs3)
+    assert torch.equal(cs2, cs3)
     assert rel_err(ops.transpose(Bm.to(d)), Bm.t()) == 0.0
 
 

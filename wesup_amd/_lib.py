@@ -35,7 +35,7 @@ _SIGS = {
     'wesup_gemm_nt_workspace_bytes': (c_size_t, 'iii'),
     'wesup_gemm_nt': (c_int, 'pipippipiiiiipzp'),
     'wesup_gemm_tn_workspace_bytes': (c_size_t, 'iii'),
-    'wesup_gemm_tn': (c_int, 'pipipiiiiipzp'),
+    'wesup_gemm_tn': (c_int, 'pipipipiiiipzp'),
     'wesup_colsum_workspace_bytes': (c_size_t, 'ii'),
     'wesup_colsum': (c_int, 'pipiipzp'),
     'wesup_maxpool2_fwd': (c_int, 'ppiiiip'),

@@ -526,11 +526,15 @@ extern "C" int wesup_conv3x3_dgrad(const float* dy, const float* w_dgrad, const 
 // fragment is one conflict-free ds_read_b32 (lane l reads T[2*kp + (l>>5)][m0 + (l&31)]).  Rows are unpadded:
 // a wave-instruction of the LDS-DMA fills 1 KiB = 256 consecutive floats of the image.
 // Split-K over grid.y; every split writes its own slab (deterministic), reduced by a second kernel.
+// Bias gradients ride along: out[m] = sum_k A[k][m] is accumulated from the staged A tile by the blocks of the first
+// N-tile (and first tap) and stored behind the slab, so the activations' gradient is not read a second time.
 // ---------------------------------------------------------------------------------------------
 struct TnParams {
     const float* A;
     const float* Bx;
-    float* slab;     // [S][M][Nslab]
+    float* slab;     // [S][slab_stride]: M x Nslab partial products, then M column sums of A (bias gradient)
+    long slab_stride;
+    int want_colsum;
     int M, N, K;     // N: columns per tap (MODE 1) or total
     int lda, ldb;
     int Nslab;       // slab row length
@@ -628,6 +632,8 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnParams p) {
     const int nk = (k_end - k_begin + BK - 1) / BK;
     const bool relu_b = p.relu_b;
 
+    const bool do_cs = p.want_colsum && tile_n == 0 && tap == 0 && tid < BM;     // wave-uniform (BM % 64 == 0)
+    float csum = 0.f;
     const float* pa[NA];
     const float* pb[NB];
     src_of(k_begin, pa, pb);
@@ -639,6 +645,11 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnParams p) {
     for (int kk = 0; kk < nk; ++kk) {
         issue(pa, pb, cur ^ 1);                    // unconditional (past k_end every lane reads the zero page)
         const int k2 = k_begin + (kk + 2) * BK;    // its pointers are consumed by the next iteration's issue()
+        if (do_cs) {
+            const float* col = As + cur * BK * BM + tid;
+#pragma unroll
+            for (int kr = 0; kr < BK; ++kr) csum += col[kr * BM];
+        }
         const float* as = As + cur * BK * BM + lhi * BM + wm0 + l31;
         const float* bs = Bs + cur * BK * BN + lhi * BN + wn0 + l31;
         // fragment double buffering: the reads of k-pair kp+1 are in flight while the MFMAs of kp issue
@@ -673,7 +684,8 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnParams p) {
         cur ^= 1;
     }
 
-    float* slab = p.slab + (long)blockIdx.y * p.M * p.Nslab;
+    float* slab = p.slab + (long)blockIdx.y * p.slab_stride;
+    if (do_cs && m_blk + tid < p.M) slab[(long)p.M * p.Nslab + m_blk + tid] = csum;
     const int ncol0 = (MODE == 1) ? tap * p.N : 0;
 #pragma unroll
     for (int j = 0; j < WN; ++j) {
@@ -692,23 +704,41 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnParams p) {
 
 // C[m][n] = sum_s slab[s][m][n]     (plain)            -- or, for conv weights --
 // dW[co][ci][t] = sum_s slab[s][co][t*Cs + ci]          (torch (Co,Ci,3,3) layout; Cs = slab channels per tap)
-__global__ void tn_reduce_kernel(const float* slab, float* C, int ldc, int M, int N, int Nslab, int S) {
+__global__ void tn_reduce_kernel(const float* slab, long stride, float* C, int ldc, int M, int N, int Nslab, int S,
+                                 float* colsum_out) {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (long)M * N) return;
+    if (idx >= (long)M * N) {
+        const long m = idx - (long)M * N;              // the column sums of A sit behind each slab
+        if (colsum_out && m < M) {
+            float s = 0.f;
+            for (int k = 0; k < S; ++k) s += slab[(long)k * stride + (long)M * Nslab + m];
+            colsum_out[m] = s;
+        }
+        return;
+    }
     const int m = idx / N, n = idx - (long)m * N;
     float s = 0.f;
-    for (int k = 0; k < S; ++k) s += slab[((long)k * M + m) * Nslab + n];
+    for (int k = 0; k < S; ++k) s += slab[(long)k * stride + (long)m * Nslab + n];
     C[(long)m * ldc + n] = s;
 }
-__global__ void wgrad_reduce_kernel(const float* slab, float* dw, int Co, int Ci, int Cs, int Nslab, int S) {
+__global__ void wgrad_reduce_kernel(const float* slab, long stride, float* dw, int Co, int Ci, int Cs, int Nslab, int S,
+                                    float* db) {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (long)Co * Ci) return;
+    if (idx >= (long)Co * Ci) {
+        const long m = idx - (long)Co * Ci;
+        if (db && m < Co) {
+            float s = 0.f;
+            for (int k = 0; k < S; ++k) s += slab[(long)k * stride + (long)Co * Nslab + m];
+            db[m] = s;
+        }
+        return;
+    }
     const int co = idx / Ci, ci = idx - (long)co * Ci;
     float acc[9];
 #pragma unroll
     for (int t = 0; t < 9; ++t) acc[t] = 0.f;
     for (int k = 0; k < S; ++k) {
-        const float* s = slab + ((long)k * Co + co) * Nslab + ci;
+        const float* s = slab + (long)k * stride + (long)co * Nslab + ci;
 #pragma unroll
         for (int t = 0; t < 9; ++t) acc[t] += s[t * Cs];
     }
@@ -793,15 +823,17 @@ static int launch_tn(TnParams p, const TnPlan& pl, hipStream_t st) {
     return WESUP_OK;
 }
 
+static size_t tn_slab_stride(int M, int Nslab) { return (size_t)M * Nslab + M; }    // products + column sums of A
+
 extern "C" size_t wesup_gemm_tn_workspace_bytes(int M, int N, int K) {
     if (M <= 0 || N <= 0 || K <= 0) return 0;
     const TnPlan pl = plan_tn(M, N, K, 1);
-    const size_t elems = (size_t)M * pl.Nslab;
+    const size_t elems = tn_slab_stride(M, pl.Nslab);
     return align_up((size_t)pl.S * elems * sizeof(float), 256) + slab_fold_bytes(pl.S, elems);
 }
 
-extern "C" int wesup_gemm_tn(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N,
-                             int K, int relu_b, void* ws, size_t ws_bytes, void* stream) {
+extern "C" int wesup_gemm_tn(const float* A, int lda, const float* B, int ldb, float* C, int ldc, float* colsum_a,
+                             int M, int N, int K, int relu_b, void* ws, size_t ws_bytes, void* stream) {
     if (!A || !B || !C || !ws || M <= 0 || N <= 0 || K <= 0 || (M % 4) || (N % 4) || (lda % 4) || (ldb % 4) ||
         (((uintptr_t)A | (uintptr_t)B) & 15))
         return WESUP_ERR_INVALID;
@@ -810,15 +842,16 @@ extern "C" int wesup_gemm_tn(const float* A, int lda, const float* B, int ldb, f
     TnParams p = {};
     p.A = A; p.Bx = B; p.slab = (float*)ws; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb;
     p.relu_b = relu_b; p.H = 1; p.W = 1; p.dW = make_fastdiv(1); p.dH = make_fastdiv(1);
+    p.slab_stride = (long)tn_slab_stride(M, pl.Nslab); p.want_colsum = colsum_a != nullptr;
     hipStream_t st = (hipStream_t)stream;
     int rc = launch_tn<0>(p, pl, st);
     if (rc) return rc;
     const long tot = (long)M * N;
     int S = pl.S;
-    float* part = (float*)((char*)ws + align_up((size_t)pl.S * tot * sizeof(float), 256));
-    const float* src = slab_fold((const float*)ws, S, tot, part, st);
-    hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, src, C, ldc, M, N,
-                       pl.Nslab, S);
+    float* part = (float*)((char*)ws + align_up((size_t)pl.S * p.slab_stride * sizeof(float), 256));
+    const float* src = slab_fold((const float*)ws, S, p.slab_stride, part, st);
+    hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)((tot + M + 255) / 256)), dim3(256), 0, st, src, p.slab_stride, C,
+                       ldc, M, N, pl.Nslab, S, colsum_a);
     WESUP_CHECK_LAUNCH();
     return WESUP_OK;
 }
@@ -889,9 +922,8 @@ static TnPlan plan_wgrad(int B, int H, int W, int Ci, int Cout) {
 extern "C" size_t wesup_conv3x3_wgrad_workspace_bytes(int B, int H, int W, int Ci, int Cout) {
     if (B <= 0 || H <= 0 || W <= 0 || Ci <= 0 || Cout <= 0) return 0;
     const TnPlan pl = plan_wgrad(B, H, W, Ci, Cout);
-    const size_t elems = (size_t)Cout * pl.Nslab;
-    return align_up((size_t)pl.S * elems * sizeof(float), 256) + align_up(slab_fold_bytes(pl.S, elems), 256) +
-           wesup_colsum_workspace_bytes(B * H * W, Cout);
+    const size_t elems = tn_slab_stride(Cout, pl.Nslab);
+    return align_up((size_t)pl.S * elems * sizeof(float), 256) + align_up(slab_fold_bytes(pl.S, elems), 256);
 }
 extern "C" int wesup_conv3x3_wgrad(const float* x, const float* dy, float* dw_kcrs, float* db, int B, int H, int W,
                                    int Ci, int Cout, int relu_in, void* ws, size_t ws_bytes, void* stream) {
@@ -906,6 +938,7 @@ extern "C" int wesup_conv3x3_wgrad(const float* x, const float* dy, float* dw_kc
     TnParams p = {};
     p.A = dy; p.Bx = x; p.slab = (float*)ws; p.M = Cout; p.K = B * H * W; p.lda = Cout;
     p.relu_b = relu_in; p.H = H; p.W = W; p.dW = make_fastdiv(W); p.dH = make_fastdiv(H);
+    p.slab_stride = (long)tn_slab_stride(Cout, pl.Nslab); p.want_colsum = db != nullptr;
     int rc;
     if (small) {
         p.N = 64; p.ldb = 4;
@@ -916,16 +949,12 @@ extern "C" int wesup_conv3x3_wgrad(const float* x, const float* dy, float* dw_kc
     }
     if (rc) return rc;
     const long tot = (long)Cout * Ci;
-    // slab rows: [co][tap*Cs + ci] with Cs = 4 for the image layer (Nslab = 64), Ci otherwise
-    const size_t elems = (size_t)Cout * pl.Nslab;
-    const size_t slab_b = align_up((size_t)pl.S * elems * sizeof(float), 256);
-    const size_t fold_b = align_up(slab_fold_bytes(pl.S, elems), 256);
+    // slab rows: [co][tap*Cs + ci] with Cs = 4 for the image layer (Nslab = 64), Ci otherwise; db rides behind them
+    const size_t slab_b = align_up((size_t)pl.S * p.slab_stride * sizeof(float), 256);
     int S = pl.S;
-    const float* src = slab_fold((const float*)ws, S, (long)elems, (float*)((char*)ws + slab_b), st);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, src, dw_kcrs, Cout,
-                       Ci, small ? 4 : Ci, pl.Nslab, S);
+    const float* src = slab_fold((const float*)ws, S, p.slab_stride, (float*)((char*)ws + slab_b), st);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((tot + Cout + 255) / 256)), dim3(256), 0, st, src,
+                       p.slab_stride, dw_kcrs, Cout, Ci, small ? 4 : Ci, pl.Nslab, S, db);
     WESUP_CHECK_LAUNCH();
-    if (db)
-        return wesup_colsum(dy, Cout, db, B * H * W, Cout, (char*)ws + slab_b + fold_b, ws_bytes - slab_b - fold_b, stream);
     return WESUP_OK;
 }

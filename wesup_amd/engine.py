@@ -373,14 +373,11 @@ class WesupEngine:
         ops.classifier_bwd(b.feats, p['classifier.0.weight'], b.sp_pred, dpred.reshape(R, 2),
                            None if dfeat_extra is None else dfeat_extra.reshape(R, D),
                            b.dfeat, g['classifier.0.weight'], g['classifier.0.bias'])
-        ops.gemm_tn(b.dfeat, b.h2, out=g['fc_layers.4.weight'])
-        ops.colsum(b.dfeat, g['fc_layers.4.bias'])
+        ops.gemm_tn(b.dfeat, b.h2, out=g['fc_layers.4.weight'], colsum=g['fc_layers.4.bias'])
         ops.gemm_nt(b.dfeat, pk.fcT[2], None, out=b.dh2, mask=b.h2)
-        ops.gemm_tn(b.dh2, b.h1, out=g['fc_layers.2.weight'])
-        ops.colsum(b.dh2, g['fc_layers.2.bias'])
+        ops.gemm_tn(b.dh2, b.h1, out=g['fc_layers.2.weight'], colsum=g['fc_layers.2.bias'])
         ops.gemm_nt(b.dh2, pk.fcT[1], None, out=b.dh1, mask=b.h1)
-        ops.gemm_tn(b.dh1, b.sp_in.view(R, FM_CHANNELS), out=g['fc_layers.0.weight'])
-        ops.colsum(b.dh1, g['fc_layers.0.bias'])
+        ops.gemm_tn(b.dh1, b.sp_in.view(R, FM_CHANNELS), out=g['fc_layers.0.weight'], colsum=g['fc_layers.0.bias'])
         gsp2d = b.gsp.view(R, FM_CHANNELS)
         ops.gemm_nt(b.dh1, pk.fcT[0], None, out=gsp2d)
         T.end(tok, 4.0 * R * (FM_CHANNELS * 1024 + 1024 * 1024 + 1024 * D))
@@ -427,8 +424,8 @@ class WesupEngine:
                 if self.two_streams:
                     g_ready[l] = torch.cuda.Event()
                     g_ready[l].record()
-                ops.gemm_tn(ds2d, y2d, out=g[f'side_conv{off}.weight'].view(co // 2, co), ws_tag='side')
-                ops.colsum(ds2d, g[f'side_conv{off}.bias'], ws_tag='side_colsum')
+                ops.gemm_tn(ds2d, y2d, out=g[f'side_conv{off}.weight'].view(co // 2, co), ws_tag='side',
+                            colsum=g[f'side_conv{off}.bias'])
                 T.end(tok, 4.0 * P * co * (co // 2))
                 side_names += [f'side_conv{off}.weight', f'side_conv{off}.bias']
         # ---- main path, conv5_3 down to conv1_1.  The dgrad chain stays on the caller's stream; each layer's wgrad

@@ -167,8 +167,8 @@ def gemm_nt(A, Bw, bias=None, out=None, mask=None, flags=0):
     return out
 
 
-def gemm_tn(A, Bm, out=None, relu_b=False, ws_tag='default'):
-    """out[M][N] = A[K][M]^T @ Bm[K][N]  (deterministic split-K)."""
+def gemm_tn(A, Bm, out=None, relu_b=False, ws_tag='default', colsum=None):
+    """out[M][N] = A[K][M]^T @ Bm[K][N]  (deterministic split-K); colsum (M,), optional: also sum_k A[k][m]."""
     K, M = A.shape
     K2, N = Bm.shape
     assert K == K2 and A.is_cuda and Bm.is_cuda
@@ -177,8 +177,10 @@ def gemm_tn(A, Bm, out=None, relu_b=False, ws_tag='default'):
     assert out.shape == (M, N)
     nb = _lib.load().wesup_gemm_tn_workspace_bytes(M, N, K)
     ws = workspace(nb, A.device, ws_tag)      # one workspace per stream that may run concurrently
-    _lib.call('wesup_gemm_tn', _p(A), _ld(A), _p(Bm), _ld(Bm), _p(out), _ld(out), M, N, K, int(relu_b), _p(ws), nb,
-              _stream())
+    if colsum is not None:
+        _chk(colsum, name='colsum'); assert colsum.numel() == M
+    _lib.call('wesup_gemm_tn', _p(A), _ld(A), _p(Bm), _ld(Bm), _p(out), _ld(out), _p(colsum), M, N, K, int(relu_b),
+              _p(ws), nb, _stream())
     return out
 
 
