@@ -67,3 +67,28 @@ else:
         any_n += d
         if mf: mf_n += d
     print('in flight: any kernel %.1f us, idle %.1f us, >=1 MFMA GEMM %.1f us, >=2 MFMA GEMMs %.1f us' % (t_any / 1e3, t_idle / 1e3, t_mf / 1e3, t_mf2 / 1e3))
+    # ---- intervals without any MFMA GEMM in flight: what runs there
+    gaps = []
+    mf_n = 0
+    last = None
+    for t, d, mf in ev:
+        if mf:
+            if mf_n == 0 and d == 1 and last is not None and t - last > 3000:
+                gaps.append((last, t))
+            mf_n += d
+            if mf_n == 0:
+                last = t
+        elif last is None and mf_n == 0:
+            last = ev[0][0]
+    gaps.sort(key=lambda g: g[0] - g[1])
+    print('--- longest intervals with no MFMA GEMM in flight (us from step start, length, kernels running inside)')
+    for a, b in sorted(gaps[:14]):
+        inside = {}
+        for r in step:
+            s_, e_ = int(r['Start_Timestamp']), int(r['End_Timestamp'])
+            if e_ > a and s_ < b:
+                n = re.sub(r'\(.*', '', r['Kernel_Name']).replace('void ', '')[:40]
+                inside[n] = inside.get(n, 0) + (min(e_, b) - max(s_, a)) / 1e3
+        top = sorted(inside.items(), key=lambda kv: -kv[1])[:4]
+        print(f'{(a - t0) / 1e3:9.1f} {(b - a) / 1e3:7.1f} us  ' + ', '.join(f'{k} {v:.0f}' for k, v in top))
+    print('total no-GEMM time in intervals > 3 us: %.1f us' % (sum(b - a for a, b in gaps) / 1e3))

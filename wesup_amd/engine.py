@@ -95,6 +95,7 @@ class WesupEngine:
         self.two_streams = True          # side branch on its own HIP stream
         self._side_stream = None
         self._wgrad_stream = None
+        self._aux_stream = None
         self.timer = KernelTimer()
         self.on_grads_ready = None       # callback(names) for the data-parallel layer
 
@@ -108,6 +109,11 @@ class WesupEngine:
         if self._wgrad_stream is None:
             self._wgrad_stream = torch.cuda.Stream(device=self.device)
         return self._wgrad_stream
+
+    def _aux(self):
+        if self._aux_stream is None:
+            self._aux_stream = torch.cuda.Stream(device=self.device)
+        return self._aux_stream
 
     class _OnSide:
         """Run the body on the side stream after everything queued so far on the main stream."""
@@ -392,6 +398,23 @@ class WesupEngine:
         # g_ready[l] marks "G_l holds the side-branch gradient"; the main chain accumulates into it afterwards.
         g_ready = [None] * 13
         side_names = []
+        # The gather-style upsample backward of the shallow layers only needs gsp.  Queued in layer order on the side
+        # stream it sat between the side GEMMs of layers 7..1 and the dgrad chain waited for it (~0.75 ms with no MFMA
+        # kernel in flight); on a stream of its own it runs under the deep layers' GEMMs.
+        ds_ready = [None] * 13
+        if self.two_streams and self.fuse_pool_bwd:
+            aux = self._aux()
+            aux.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(aux):
+                for l in range(12, -1, -1):
+                    if b.group_of[l] is None:
+                        h, w = b.dims[l]
+                        tok = T.begin('upsample_bwd')
+                        ops.upsample_bwd_fused(b.gsp, meta.new_row, meta.area_new, H, W, SIDE_OFF[l], h, w,
+                                               CONV_CH[l][1] // 2, out=b.ds[l])
+                        T.end(tok, 4.0 * B * H * W * (CONV_CH[l][1] // 2))
+                        ds_ready[l] = torch.cuda.Event()
+                        ds_ready[l].record()
         with self._OnSide(self):
             for l in range(12, -1, -1):
                 ci, co = CONV_CH[l]
@@ -406,6 +429,10 @@ class WesupEngine:
                             ops.gemm_tn(grp.Wm[i], b.gsp[i][:, grp.off:grp.off + grp.C],
                                         out=grp.ds[i].view(grp.h * grp.w, grp.C), ws_tag='side')
                         T.end(tok, 2.0 * B * Kmax * grp.h * grp.w * grp.C)
+                    tok = None
+                    ds2d = b.ds[l].view(P, co // 2)
+                elif ds_ready[l] is not None:
+                    torch.cuda.current_stream().wait_event(ds_ready[l])
                     tok = None
                     ds2d = b.ds[l].view(P, co // 2)
                 elif self.fuse_pool_bwd:
