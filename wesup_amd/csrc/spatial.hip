@@ -50,12 +50,13 @@ __global__ void pack_w_dgrad_kernel(const float* __restrict__ w, float* __restri
     for (int t = 0; t < 9; ++t) d[(8 - t) * Co] = s[t];
 }
 extern "C" int wesup_pack_conv3x3_weight(const float* w, float* w_fwd, float* w_dgrad, int Co, int Ci, void* stream) {
-    if (!w || !w_fwd || Co <= 0 || Ci <= 0) return WESUP_ERR_INVALID;
+    if (!w || (!w_fwd && !w_dgrad) || Co <= 0 || Ci <= 0) return WESUP_ERR_INVALID;     // either panel may be skipped
     const int Cip = Ci < 4 ? 4 : Ci;
     const int Kf = wesup_conv3x3_kpad(Ci);
     hipStream_t st = (hipStream_t)stream;
     long tot = (long)Co * Cip;
-    hipLaunchKernelGGL(pack_w_fwd_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, w, w_fwd, Co, Ci, Cip, Kf);
+    if (w_fwd)
+        hipLaunchKernelGGL(pack_w_fwd_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, w, w_fwd, Co, Ci, Cip, Kf);
     if (w_dgrad) {
         tot = (long)Co * Ci;
         hipLaunchKernelGGL(pack_w_dgrad_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, w, w_dgrad, Co, Ci);

@@ -244,13 +244,19 @@ class WesupEngine:
         # ~40 launch-latency-bound repack kernels go to the side stream (idle at this point) and are joined in front of
         # the first convolution; the trainer queues them before the superpixel preprocessing (prefetch_weights)
         with self._OnSide(self):
-            for l, idx in enumerate(CONV_IDX):
-                ops.pack_conv3x3_weight(self.p[f'backbone.{idx}.weight'], pk.wf[l], pk.wd[l], need_dgrad=(train and l > 0))
-            pk.ready = None
+            pk.ready0 = pk.ready = None
+            for l, idx in enumerate(CONV_IDX):     # forward panels first: conv1_1 only waits for its own
+                ops.pack_conv3x3_weight(self.p[f'backbone.{idx}.weight'], pk.wf[l], None, need_dgrad=False)
+                if l == 0 and self.two_streams:
+                    pk.ready0 = torch.cuda.Event()
+                    pk.ready0.record()
             if self.two_streams:
                 pk.ready = torch.cuda.Event()
                 pk.ready.record()
             if train:
+                for l, idx in enumerate(CONV_IDX):
+                    if l > 0:
+                        ops.pack_conv3x3_weight(self.p[f'backbone.{idx}.weight'], None, pk.wd[l], need_fwd=False)
                 for l, off in enumerate(SIDE_OFF):
                     co = CONV_CH[l][1]
                     ops.transpose(self.p[f'side_conv{off}.weight'].view(co // 2, co), pk.sideT[l])
@@ -264,6 +270,12 @@ class WesupEngine:
         self._prefetched = None
         self._pack_weights(train)
         self._prefetched = train
+
+    def side_stream(self):
+        """Context: run the body on the side stream behind everything queued so far on the current stream.  The trainer
+        puts the superpixel preprocessing there: the conv chain does not need it, only the pooling (side stream) and
+        the kernels behind the forward join do."""
+        return self._OnSide(self)
 
     # ------------------------------------------------------------------ forward
     def forward(self, img, meta, train=True, need_paint=True):
@@ -292,7 +304,9 @@ class WesupEngine:
         for l, (ci, co) in enumerate(CONV_CH):
             h, w = b.dims[l]
             idx, off = CONV_IDX[l], SIDE_OFF[l]
-            if l == 0 and pk.ready is not None:
+            if l == 0 and pk.ready0 is not None:
+                torch.cuda.current_stream().wait_event(pk.ready0)
+            if l == 1 and pk.ready is not None:
                 torch.cuda.current_stream().wait_event(pk.ready)
             tok = T.begin('conv3x3_fwd')
             ops.conv3x3_fwd(cur, pk.wf[l], p[f'backbone.{idx}.bias'], co, relu_in=(l > 0), out=b.y[l])

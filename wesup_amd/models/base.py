@@ -131,9 +131,12 @@ class BaseTrainer(ABC):
 
     def train_one_iteration(self, phase, *data):
         from .. import ops
-        if hasattr(self.model, 'prefetch_weights'):      # weight repacking runs beside the superpixel preprocessing
-            self.model.prefetch_weights(train=(phase == 'train'))
-        input_, target = self.preprocess(*data)
+        if hasattr(self.model, 'prefetch_weights'):      # weight repacking and superpixel preprocessing go to the side
+            self.model.prefetch_weights(train=(phase == 'train'))      # stream: conv1_1 only waits for its own panel
+            with self.model.engine.side_stream():
+                input_, target = self.preprocess(*data)
+        else:
+            input_, target = self.preprocess(*data)
 
         self.optimizer.zero_grad()
         metrics = dict()

@@ -68,15 +68,16 @@ def conv3x3_kpad(Ci):
     return _lib.load().wesup_conv3x3_kpad(int(Ci))
 
 
-def pack_conv3x3_weight(w, w_fwd=None, w_dgrad=None, need_dgrad=True):
+def pack_conv3x3_weight(w, w_fwd=None, w_dgrad=None, need_dgrad=True, need_fwd=True):
     _chk(w, name='w')
     Co, Ci, kh, kw = w.shape
-    assert kh == 3 and kw == 3
-    if w_fwd is None:
+    assert kh == 3 and kw == 3 and (need_fwd or need_dgrad)
+    if need_fwd and w_fwd is None:
         w_fwd = torch.empty(Co, conv3x3_kpad(Ci), dtype=torch.float32, device=w.device)
     if need_dgrad and w_dgrad is None:
         w_dgrad = torch.empty(Ci, 9 * Co, dtype=torch.float32, device=w.device)
-    _lib.call('wesup_pack_conv3x3_weight', _p(w), _p(w_fwd), _p(w_dgrad) if need_dgrad else None, Co, Ci, _stream())
+    _lib.call('wesup_pack_conv3x3_weight', _p(w), _p(w_fwd) if need_fwd else None, _p(w_dgrad) if need_dgrad else None,
+              Co, Ci, _stream())
     return w_fwd, w_dgrad
 
 
