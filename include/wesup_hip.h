@@ -90,6 +90,11 @@ size_t wesup_gemm_tn_workspace_bytes(int M, int N, int K);
  * accumulated from the staged A tiles, so A is not read a second time */
 int wesup_gemm_tn(const float* A, int lda, const float* B, int ldb, float* C, int ldc, float* colsum_a,
                   int M, int N, int K, int relu_b, void* ws, size_t ws_bytes, void* stream);
+/* nbatch products of one shape in one launch: C_b = A_b^T . B_b, element strides between batch entries */
+size_t wesup_gemm_tn_batched_workspace_bytes(int nbatch, int M, int N, int K);
+int wesup_gemm_tn_batched(const float* A, int lda, long strideA, const float* B, int ldb, long strideB,
+                          float* C, int ldc, long strideC, int nbatch, int M, int N, int K, int relu_b,
+                          void* ws, size_t ws_bytes, void* stream);
 size_t wesup_colsum_workspace_bytes(int M, int N);
 int wesup_colsum(const float* A, int lda, float* out, int M, int N, void* ws, size_t ws_bytes, void* stream);
 

@@ -38,7 +38,8 @@ def test_ctypes_signatures_match_header(lib):
         for a in [a.strip() for a in args.replace('\n', ' ').split(',')]:
             if a in ('void', ''):
                 continue
-            sig += 'p' if '*' in a else 'z' if a.startswith('size_t') else 'f' if a.startswith('float') else 'i'
+            sig += ('p' if '*' in a else 'z' if a.startswith('size_t') else 'f' if a.startswith('float')
+                    else 'l' if a.startswith('long') else 'i')
         assert lib._SIGS[name][1] == sig, name
 
 

@@ -164,6 +164,22 @@ def test_gemm_tn_colsum(ops, M, N, K):
     assert rel_err(ops.transpose(Bm.to(d)), Bm.t()) == 0.0
 
 
+def test_gemm_tn_batched(ops):
+    d = dev()
+    nb, K, M, N = 3, 900, 584, 768
+    A = rnd(nb, K, M, seed=1).to(d)
+    big = rnd(nb, K, N + 128, seed=2).to(d)
+    Bm = big[:, :, 64:64 + N]                                              # row-strided operand
+    outbig = torch.zeros(nb, M, N + 32, device=d)
+    out = outbig[:, :, 32:]
+    ops.gemm_tn_batched(A, Bm, out)
+    ref = torch.einsum('bkm,bkn->bmn', A.double().cpu(), Bm.double().cpu()).float()
+    assert rel_err(out, ref) < TOL
+    assert float(outbig[:, :, :32].abs().max()) == 0.0
+    for i in range(nb):                                                    # same numbers as the single-product entry?
+        assert rel_err(ops.gemm_tn(A[i], Bm[i]), ref[i]) < TOL
+
+
 # ---------------------------------------------------------------- maxpool / upsample
 @pytest.mark.parametrize('B,H,W,C', [(2, 8, 6, 64), (1, 30, 30, 512), (1, 10, 14, 128)])
 def test_maxpool(ops, B, H, W, C):

@@ -17,7 +17,7 @@ c_int = ctypes.c_int
 c_float = ctypes.c_float
 c_size_t = ctypes.c_size_t
 
-# name -> (restype, [argtypes]);  'p' pointer, 'i' int, 'f' float, 'z' size_t
+# name -> (restype, [argtypes]);  'p' pointer, 'i' int, 'f' float, 'z' size_t, 'l' long
 _SIGS = {
     'wesup_abi_version': (c_int, ''),
     'wesup_debug_clock': (c_int, 'p'),
@@ -36,6 +36,8 @@ _SIGS = {
     'wesup_gemm_nt': (c_int, 'pipippipiiiiipzp'),
     'wesup_gemm_tn_workspace_bytes': (c_size_t, 'iii'),
     'wesup_gemm_tn': (c_int, 'pipipipiiiipzp'),
+    'wesup_gemm_tn_batched_workspace_bytes': (c_size_t, 'iiii'),
+    'wesup_gemm_tn_batched': (c_int, 'pilpilpiliiiiipzp'),
     'wesup_colsum_workspace_bytes': (c_size_t, 'ii'),
     'wesup_colsum': (c_int, 'pipiipzp'),
     'wesup_maxpool2_fwd': (c_int, 'ppiiiip'),
@@ -68,7 +70,7 @@ _SIGS = {
     'wesup_seg_metrics_workspace_bytes': (c_size_t, 'i'),
     'wesup_seg_metrics': (c_int, 'pppiiipzp'),
 }
-_T = {'p': c_void_p, 'i': c_int, 'f': c_float, 'z': c_size_t}
+_T = {'p': c_void_p, 'i': c_int, 'f': c_float, 'z': c_size_t, 'l': ctypes.c_long}
 
 EXPORTS = sorted(_SIGS)
 

@@ -535,6 +535,7 @@ struct TnParams {
     float* slab;     // [S][slab_stride]: M x Nslab partial products, then M column sums of A (bias gradient)
     long slab_stride;
     int want_colsum;
+    long batchA, batchB, batch_slab;   // grid.z = batch index: element strides of A, B and the slab stack per batch entry
     int M, N, K;     // N: columns per tap (MODE 1) or total
     int lda, ldb;
     int Nslab;       // slab row length
@@ -563,6 +564,8 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnParams p) {
     const int tap = lt / p.tiles_m;          // 0 for MODE 0/2
     const int m_blk = tile_m * BM, n_blk = tile_n * BN;
     const int k_begin = blockIdx.y * p.k_per_split;
+    const float* Ab = p.A + (long)blockIdx.z * p.batchA;
+    const float* Bb = p.Bx + (long)blockIdx.z * p.batchB;
     const int k_end = min(p.K, k_begin + p.k_per_split);
     const float* zero = reinterpret_cast<const float*>(g_zero_page);
 
@@ -582,13 +585,13 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnParams p) {
     auto src_a = [&](int k0, int i) -> const float* {
         const int k = k0 + ra_row + RPA * i;
         const bool ok = a_col_ok & (k < k_end);
-        return ok ? p.A + (long)k * p.lda + m_blk + 4 * qa : zero;
+        return ok ? Ab + (long)k * p.lda + m_blk + 4 * qa : zero;
     };
     auto src_b = [&](int k0, int i) -> const float* {
         const int k = k0 + rb_row + RPB * i;
         if (MODE == 0) {
             const bool ok = b_col_ok & (k < k_end);
-            return ok ? p.Bx + (long)k * p.ldb + n_blk + 4 * qb : zero;
+            return ok ? Bb + (long)k * p.ldb + n_blk + 4 * qb : zero;
         }
         const int t = fast_div(k, p.dW);       // b*H + h
         const int w = k - t * p.W;
@@ -597,11 +600,11 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnParams p) {
         if (MODE == 1) {
             const int hh = h + dh, ww = w + dw;
             const bool ok = b_col_ok & (k < k_end) & (hh >= 0) & (hh < p.H) & (ww >= 0) & (ww < p.W);
-            return ok ? p.Bx + (long)(k + dh * p.W + dw) * p.ldb + n_blk + 4 * qb : zero;
+            return ok ? Bb + (long)(k + dh * p.W + dw) * p.ldb + n_blk + 4 * qb : zero;
         }
         const int hh = h + dh2, ww = w + dw2;
         const bool ok = (qb < 9) & (k < k_end) & (hh >= 0) & (hh < p.H) & (ww >= 0) & (ww < p.W);
-        return ok ? p.Bx + (long)(k + dh2 * p.W + dw2) * 4 : zero;
+        return ok ? Bb + (long)(k + dh2 * p.W + dw2) * 4 : zero;
     };
     auto src_of = [&](int k0, const float* (&pa)[NA], const float* (&pb)[NB]) {
 #pragma unroll
@@ -684,7 +687,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnParams p) {
         cur ^= 1;
     }
 
-    float* slab = p.slab + (long)blockIdx.y * p.slab_stride;
+    float* slab = p.slab + (long)blockIdx.z * p.batch_slab + (long)blockIdx.y * p.slab_stride;
     if (do_cs && m_blk + tid < p.M) slab[(long)p.M * p.Nslab + m_blk + tid] = csum;
     const int ncol0 = (MODE == 1) ? tap * p.N : 0;
 #pragma unroll
@@ -705,8 +708,10 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnParams p) {
 // C[m][n] = sum_s slab[s][m][n]     (plain)            -- or, for conv weights --
 // dW[co][ci][t] = sum_s slab[s][co][t*Cs + ci]          (torch (Co,Ci,3,3) layout; Cs = slab channels per tap)
 __global__ void tn_reduce_kernel(const float* slab, long stride, float* C, int ldc, int M, int N, int Nslab, int S,
-                                 float* colsum_out) {
+                                 float* colsum_out, long batch_slab, long batchC) {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    slab += (long)blockIdx.y * batch_slab;             // grid.y = batch index
+    C += (long)blockIdx.y * batchC;
     if (idx >= (long)M * N) {
         const long m = idx - (long)M * N;              // the column sums of A sit behind each slab
         if (colsum_out && m < M) {
@@ -772,7 +777,7 @@ struct TnPlan {
     int tiles_m, tiles_n, taps, S, k_per_split, Nslab;
 };
 
-static TnPlan plan_tn(int M, int N, int K, int taps) {
+static TnPlan plan_tn(int M, int N, int K, int taps, int nbatch = 1) {
     TnPlan pl;
     const bool big = (M >= 128 && N >= 128);
     pl.bm = big ? 128 : 64;
@@ -780,7 +785,7 @@ static TnPlan plan_tn(int M, int N, int K, int taps) {
     pl.tiles_m = ceil_div(M, pl.bm);
     pl.tiles_n = ceil_div(N, pl.bn);
     pl.taps = taps;
-    const int tiles = pl.tiles_m * pl.tiles_n * taps;
+    const int tiles = pl.tiles_m * pl.tiles_n * taps * nbatch;
     const int ksteps = ceil_div(K, BK);
     // Split-K factor: the grid (tiles x S blocks, all of equal cost) should fill the resident block slots of the chip
     // a whole number of times -- 2 blocks/CU for the 128x128 tile (64 KiB LDS each), 4 for 64x64 -- so that no
@@ -808,10 +813,10 @@ static TnPlan plan_tn(int M, int N, int K, int taps) {
 }
 
 template <int MODE>
-static int launch_tn(TnParams p, const TnPlan& pl, hipStream_t st) {
+static int launch_tn(TnParams p, const TnPlan& pl, hipStream_t st, int nbatch = 1) {
     p.tiles_m = pl.tiles_m; p.tiles_n = pl.tiles_n; p.taps = pl.taps; p.k_per_split = pl.k_per_split;
     p.Nslab = pl.Nslab;
-    dim3 grid(pl.tiles_m * pl.tiles_n * pl.taps, pl.S);
+    dim3 grid(pl.tiles_m * pl.tiles_n * pl.taps, pl.S, nbatch);
     if (pl.bm == 128) {
         const size_t lds = (size_t)2 * BK * (128 + 128) * sizeof(float);
         hipLaunchKernelGGL((gemm_tn_kernel<128, 128, 2, 2, MODE>), grid, dim3(256), lds, st, p);
@@ -851,7 +856,37 @@ extern "C" int wesup_gemm_tn(const float* A, int lda, const float* B, int ldb, f
     float* part = (float*)((char*)ws + align_up((size_t)pl.S * p.slab_stride * sizeof(float), 256));
     const float* src = slab_fold((const float*)ws, S, p.slab_stride, part, st);
     hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)((tot + M + 255) / 256)), dim3(256), 0, st, src, p.slab_stride, C,
-                       ldc, M, N, pl.Nslab, S, colsum_a);
+                       ldc, M, N, pl.Nslab, S, colsum_a, 0l, 0l);
+    WESUP_CHECK_LAUNCH();
+    return WESUP_OK;
+}
+
+// nbatch independent products of one shape in one launch (grid.z) + one reduce: C_b = A_b^T . B_b with element strides
+// between the batch entries.  Used for the per-image interpolation-pooling GEMMs (4 small products per resolution).
+extern "C" size_t wesup_gemm_tn_batched_workspace_bytes(int nbatch, int M, int N, int K) {
+    if (nbatch <= 0 || M <= 0 || N <= 0 || K <= 0) return 0;
+    const TnPlan pl = plan_tn(M, N, K, 1, nbatch);
+    return (size_t)nbatch * pl.S * tn_slab_stride(M, pl.Nslab) * sizeof(float);
+}
+extern "C" int wesup_gemm_tn_batched(const float* A, int lda, long strideA, const float* B, int ldb, long strideB, float* C,
+                                     int ldc, long strideC, int nbatch, int M, int N, int K, int relu_b, void* ws,
+                                     size_t ws_bytes, void* stream) {
+    if (!A || !B || !C || !ws || nbatch <= 0 || nbatch > 65535 || M <= 0 || N <= 0 || K <= 0 || (M % 4) || (N % 4) ||
+        (lda % 4) || (ldb % 4) || (strideA % 4) || (strideB % 4) || (((uintptr_t)A | (uintptr_t)B) & 15))
+        return WESUP_ERR_INVALID;
+    if (ws_bytes < wesup_gemm_tn_batched_workspace_bytes(nbatch, M, N, K)) return WESUP_ERR_WORKSPACE;
+    const TnPlan pl = plan_tn(M, N, K, 1, nbatch);
+    TnParams p = {};
+    p.A = A; p.Bx = B; p.slab = (float*)ws; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb;
+    p.relu_b = relu_b; p.H = 1; p.W = 1; p.dW = make_fastdiv(1); p.dH = make_fastdiv(1);
+    p.slab_stride = (long)tn_slab_stride(M, pl.Nslab); p.want_colsum = 0;
+    p.batchA = strideA; p.batchB = strideB; p.batch_slab = (long)pl.S * p.slab_stride;
+    hipStream_t st = (hipStream_t)stream;
+    int rc = launch_tn<0>(p, pl, st, nbatch);
+    if (rc) return rc;
+    const long tot = (long)M * N;
+    hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)((tot + 255) / 256), nbatch), dim3(256), 0, st, (const float*)ws,
+                       p.slab_stride, C, ldc, M, N, pl.Nslab, pl.S, (float*)nullptr, p.batch_slab, strideC);
     WESUP_CHECK_LAUNCH();
     return WESUP_OK;
 }

@@ -326,9 +326,8 @@ class WesupEngine:
                     g = b.groups[b.group_of[l]]
                     if l == g.layers[-1]:        # all side outputs of this resolution are in: sp_in slice = Wm . s
                         tok = T.begin('sp_pool_mat_fwd')
-                        for i in range(B):
-                            ops.gemm_tn(g.WmT[i], g.s[i].view(g.h * g.w, g.C), out=b.sp_in[i][:, g.off:g.off + g.C],
-                                        ws_tag='side')
+                        ops.gemm_tn_batched(g.WmT, g.s.view(B, g.h * g.w, g.C), b.sp_in[:, :, g.off:g.off + g.C],
+                                            ws_tag='side')
                         T.end(tok, 2.0 * B * Kmax * g.h * g.w * g.C)
                 elif fused:
                     tok = T.begin('sp_pool_up_fwd')
@@ -439,9 +438,8 @@ class WesupEngine:
                     grp = b.groups[b.group_of[l]]
                     if l == grp.layers[-1]:      # ds of every layer of this resolution at once: ds = Wm^T . gsp slice
                         tok = T.begin('upsample_mat_bwd')
-                        for i in range(B):
-                            ops.gemm_tn(grp.Wm[i], b.gsp[i][:, grp.off:grp.off + grp.C],
-                                        out=grp.ds[i].view(grp.h * grp.w, grp.C), ws_tag='side')
+                        ops.gemm_tn_batched(grp.Wm, b.gsp[:, :, grp.off:grp.off + grp.C],
+                                            grp.ds.view(B, grp.h * grp.w, grp.C), ws_tag='side')
                         T.end(tok, 2.0 * B * Kmax * grp.h * grp.w * grp.C)
                     tok = None
                     ds2d = b.ds[l].view(P, co // 2)

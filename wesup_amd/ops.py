@@ -185,6 +185,21 @@ def gemm_tn(A, Bm, out=None, relu_b=False, ws_tag='default', colsum=None):
     return out
 
 
+def gemm_tn_batched(A, Bm, out, ws_tag='default'):
+    """out[b] = A[b]^T @ Bm[b] for 3-D operands (nb,K,M), (nb,K,N) -> (nb,M,N); the last two dims may be row-strided
+    views (unit stride along the last), the batch stride is free.  One launch + one reduce for all nb products."""
+    nb, K, M = A.shape
+    nb2, K2, N = Bm.shape
+    assert nb == nb2 and K == K2 and out.shape == (nb, M, N)
+    for t in (A, Bm, out):
+        assert t.is_cuda and t.dtype == torch.float32 and t.stride(2) == 1
+    nbytes = _lib.load().wesup_gemm_tn_batched_workspace_bytes(nb, M, N, K)
+    ws = workspace(nbytes, A.device, ws_tag)
+    _lib.call('wesup_gemm_tn_batched', _p(A), A.stride(1), A.stride(0), _p(Bm), Bm.stride(1), Bm.stride(0), _p(out),
+              out.stride(1), out.stride(0), nb, M, N, K, 0, _p(ws), nbytes, _stream())
+    return out
+
+
 def colsum(A, out=None, ws_tag='colsum'):
     M, N = A.shape
     assert A.is_cuda
