@@ -245,7 +245,7 @@ def main():
                                               '(HW x 2112) feature map; the step itself uses the fused upsample+scatter-mean)',
                     'achieved': round(a, 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': round(a / PEAK_HBM_GBS, 4),
                     'frac_of_measured_copy_6290': round(a / 6290.0, 4),
-                    'traffic': (3813303.7 * 2 + 19008.0) * 1024 if (B, H, g) == (4, 480, 24) else None,
+                    'traffic': (3813814.1 * 2 + 19701.0) * 1024 if (B, H, g) == (4, 480, 24) else None,
                     'avg_launch_us': round(pool_ms * 1e3, 2), 'algorithmic_bytes': by}
         if use_dist:
             out['rank_time'] = rank_time              # spread of the per-rank wall time of the timed region
