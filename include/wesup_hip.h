@@ -48,8 +48,9 @@ const char* wesup_strerror(int code);
  * 3 image channels padded to 4.  Conv weights stay in torch's (Co,Ci,3,3) layout
  * in the state_dict; they are re-packed per step. */
 int wesup_pack_input(const float* img_nchw, float* out_nhwc4, int B, int H, int W, void* stream);
-/* w_fwd  [Co][Kf], Kf = wesup_conv3x3_kpad(Ci): k = (kh*3+kw)*Cip + ci, Cip = max(Ci,4), zero padded
- * w_dgrad[Ci][9*Co]: k = ((2-kh)*3+(2-kw))*Co + co          (either panel may be NULL) */
+/* w_fwd  [Co][Kf], Kf = wesup_conv3x3_kpad(Ci): k = ((ci/32)*9 + kh*3+kw)*32 + ci%32 for Ci >= 32 (32-channel chunk,
+ *         tap, channel: the taps of a chunk are consecutive K-steps); image layer: k = (kh*3+kw)*4 + ci, zero padded
+ * w_dgrad[Ci][9*Co]: k = ((co/32)*9 + (2-kh)*3+(2-kw))*32 + co%32          (either panel may be NULL) */
 int wesup_conv3x3_kpad(int Ci);
 int wesup_pack_conv3x3_weight(const float* w_kcrs, float* w_fwd, float* w_dgrad, int Co, int Ci, void* stream);
 int wesup_transpose(const float* in, float* out, int rows, int cols, void* stream);

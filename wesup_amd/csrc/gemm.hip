@@ -174,9 +174,12 @@ __global__ __launch_bounds__(256, MINB) void gemm_nt_kernel(const NtParams p) {
             if (MODE == 0) {
                 glds16(a_msk[i] ? p.A + a_off[i] + kk * BK : zero, adst);
             } else if (MODE == 1) {
-                const int k0 = kk * BK;
-                const int tap = k0 >> p.cin_shift;
-                const int ci0 = k0 & (p.Cin - 1);
+                // K order = (32-channel chunk, tap, channel in chunk): the 9 taps of one chunk are consecutive K-steps,
+                // so the shifted re-reads of the same 128 B per pixel hit L2 (with the tap outermost every tap streamed
+                // the whole activation tensor again: FETCH_SIZE 9x the tensor)
+                const int chunk = kk / 9;
+                const int tap = kk - 9 * chunk;
+                const int ci0 = chunk * BK;
                 const int toff = ((tap / 3 - 1) * p.W + (tap % 3 - 1)) * p.Cin + ci0;
                 glds16(((a_msk[i] >> tap) & 1u) ? p.A + a_off[i] + toff : zero, adst);
             } else {

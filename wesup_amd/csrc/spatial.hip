@@ -21,33 +21,36 @@ extern "C" int wesup_pack_input(const float* img, float* out, int B, int H, int 
 }
 
 // ------------------------------------------------------------------ conv weight packing
-// w_fwd[co][t*Cip + ci]  (lanes along ci)
+// w_fwd[co][k], k = ((ci/32)*9 + t)*32 + ci%32 for Ci >= 32 (the NT kernel's K order: chunk, tap, channel);
+// image layer (Cip = 4): k = t*4 + ci  (lanes along ci)
 __global__ void pack_w_fwd_kernel(const float* __restrict__ w, float* __restrict__ wf, int Co, int Ci, int Cip, int Kf) {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (long)Co * Cip) return;
     const int co = idx / Cip, ci = idx - (long)co * Cip;
-    float* d = wf + (long)co * Kf + ci;
+    const bool chunked = Cip >= 32;
+    float* d = wf + (long)co * Kf + (chunked ? (ci >> 5) * 288 + (ci & 31) : ci);
+    const int ts = chunked ? 32 : Cip;               // K distance between taps
     if (ci < Ci) {
         const float* s = w + ((long)co * Ci + ci) * 9;
 #pragma unroll
-        for (int t = 0; t < 9; ++t) d[t * Cip] = s[t];
+        for (int t = 0; t < 9; ++t) d[t * ts] = s[t];
     } else {
 #pragma unroll
-        for (int t = 0; t < 9; ++t) d[t * Cip] = 0.f;
+        for (int t = 0; t < 9; ++t) d[t * ts] = 0.f;
     }
     // zero the K padding (only exists when 9*Cip is not a multiple of 32, i.e. the image layer)
     if (ci == 0)
         for (int k = 9 * Cip; k < Kf; ++k) wf[(long)co * Kf + k] = 0.f;
 }
-// w_dgrad[ci][(8-t)*Co + co]  (lanes along co)
+// w_dgrad[ci][k], k = ((co/32)*9 + (8-t))*32 + co%32  (same K order with the roles of the channels swapped; lanes along co)
 __global__ void pack_w_dgrad_kernel(const float* __restrict__ w, float* __restrict__ wd, int Co, int Ci) {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (long)Co * Ci) return;
     const int ci = idx / Co, co = idx - (long)ci * Co;
     const float* s = w + ((long)co * Ci + ci) * 9;
-    float* d = wd + (long)ci * 9 * Co + co;
+    float* d = wd + (long)ci * 9 * Co + (co >> 5) * 288 + (co & 31);
 #pragma unroll
-    for (int t = 0; t < 9; ++t) d[(8 - t) * Co] = s[t];
+    for (int t = 0; t < 9; ++t) d[(8 - t) * 32] = s[t];
 }
 extern "C" int wesup_pack_conv3x3_weight(const float* w, float* w_fwd, float* w_dgrad, int Co, int Ci, void* stream) {
     if (!w || (!w_fwd && !w_dgrad) || Co <= 0 || Ci <= 0) return WESUP_ERR_INVALID;     // either panel may be skipped
