@@ -55,6 +55,15 @@ int wesup_conv3x3_kpad(int Ci);
 int wesup_pack_conv3x3_weight(const float* w_kcrs, float* w_fwd, float* w_dgrad, int Co, int Ci, void* stream);
 int wesup_transpose(const float* in, float* out, int rows, int cols, void* stream);
 
+/* ------------------------------------------------------------------ input pipeline
+ * replaces the per-item CPU augmentation (albumentations) of utils/data.py:116-133,302-327 for a batch of decoded,
+ * resized uint8 images: flips + shift/scale/rotate as ONE inverse affine map per image (bilinear image, nearest mask,
+ * reflect-101 borders), HueSaturationValue, RandomBrightnessContrast, ToTensor.  params: 12 floats per image
+ * {a00,a01,a02,a10,a11,a12 (output pixel -> source), alpha, beta, hue, sat, val, 0}.  mask_hw / out_mask may be NULL.
+ * out_img fp32 [B][3][H][W] in [0,1]; out_mask uint8 one-hot [B][C][H][W] (class index 255 = no class). */
+int wesup_augment(const uint8_t* img_hwc, const uint8_t* mask_hw, const float* params, float* out_img_nchw,
+                  uint8_t* out_mask_chw, int B, int H, int W, int C, void* stream);
+
 /* ------------------------------------------------------------------ VGG16 3x3 convs (K1/K2/K12)
  * replaces torchvision VGG16 Conv2d(k=3,pad=1)+ReLU (models/wesup.py:199,279) and its autograd.
  * y is the PRE-ReLU output (the hook taps it, models/wesup.py:246-253); the next

@@ -1,0 +1,121 @@
+"""CPU restatement (numpy) of the GPU input-pipeline kernel ``wesup_augment`` -- test infrastructure only.
+
+PARITY UNPINNED.  The reference augments on the CPU with albumentations / OpenCV (utils/data.py:116-133,302-327);
+neither library exists in the build image and the reference holds no test or golden vector for it, so there is
+nothing to pin against.  This file restates, in numpy, the published definitions the kernel follows:
+
+  * HorizontalFlip / VerticalFlip / ShiftScaleRotate(shift_limit=0.0625, scale_limit=0.1, rotate_limit=45,
+    interpolation=linear, border=reflect_101) as ONE affine map about the image centre (albumentations
+    ``functional.shift_scale_rotate``: cv2.getRotationMatrix2D(center, angle, scale) then translation dx*W, dy*H,
+    applied with cv2.warpAffine, i.e. the kernel receives the INVERSE map output->source);
+  * HueSaturationValue on OpenCV's 8-bit HSV (H in [0,180) wrapping, S and V saturating);
+  * RandomBrightnessContrast: img*alpha + beta*255, clipped (brightness_by_max=True);
+  * ToTensor: /255, HWC -> CHW; masks: nearest, one-hot (utils/data.py:136-142).
+Only tests/ may import it."""
+import numpy as np
+
+
+def sample_params(rng, H, W, p_flip=0.5, shift=0.0625, scale=0.1, rotate=45.0, hue=20.0, sat=30.0, val=20.0,
+                  brightness=0.3, contrast=0.3, appearance=True, geometry=True):
+    """One parameter row (12 floats) + the forward 2x3 matrix (for keypoints).  albumentations defaults of the
+    reference's PointSupervisionDataset pipeline (utils/data.py:302-327)."""
+    M = np.eye(3)
+    if geometry:
+        if rng.random_sample() < p_flip:                      # HorizontalFlip
+            M = np.array([[-1, 0, W - 1], [0, 1, 0], [0, 0, 1.0]]) @ M
+        if rng.random_sample() < p_flip:                      # VerticalFlip
+            M = np.array([[1, 0, 0], [0, -1, H - 1], [0, 0, 1.0]]) @ M
+        ang = rng.uniform(-rotate, rotate)
+        sc = 1.0 + rng.uniform(-scale, scale)
+        dx, dy = rng.uniform(-shift, shift), rng.uniform(-shift, shift)
+        cx, cy = (W - 1) * 0.5, (H - 1) * 0.5                  # albumentations >= 1.0 uses the pixel-centre convention
+        a, b = sc * np.cos(np.deg2rad(ang)), sc * np.sin(np.deg2rad(ang))
+        R = np.array([[a, b, (1 - a) * cx - b * cy + dx * W], [-b, a, b * cx + (1 - a) * cy + dy * H], [0, 0, 1.0]])
+        M = R @ M
+    Minv = np.linalg.inv(M)
+    row = np.zeros(12, dtype=np.float32)
+    row[0:3], row[3:6] = Minv[0], Minv[1]
+    row[6], row[7] = 1.0, 0.0
+    if appearance:
+        row[6] = 1.0 + rng.uniform(-contrast, contrast)
+        row[7] = rng.uniform(-brightness, brightness)
+        row[8], row[9], row[10] = rng.uniform(-hue, hue), rng.uniform(-sat, sat), rng.uniform(-val, val)
+    return row, M[:2].astype(np.float64)
+
+
+def reflect101(i, n):
+    if n == 1:
+        return np.zeros_like(i)
+    period = 2 * n - 2
+    i = np.mod(i, period)
+    return np.where(i < n, i, period - i)
+
+
+def rgb_to_hsv8(c):
+    r, g, b = c[..., 0], c[..., 1], c[..., 2]
+    mx, mn = np.maximum(r, np.maximum(g, b)), np.minimum(r, np.minimum(g, b))
+    d = mx - mn
+    with np.errstate(divide='ignore', invalid='ignore'):
+        s = np.where(mx > 0, np.float32(255.0) * d / mx, np.float32(0))
+        hr = np.float32(60.0) * (g - b) / d
+        hg = np.float32(120.0) + np.float32(60.0) * (b - r) / d
+        hb = np.float32(240.0) + np.float32(60.0) * (r - g) / d
+    hh = np.where(mx == r, hr, np.where(mx == g, hg, hb))
+    hh = np.where(d > 0, hh, np.float32(0))
+    hh = np.where(hh < 0, hh + np.float32(360.0), hh)
+    return (np.float32(0.5) * hh).astype(np.float32), s.astype(np.float32), mx.astype(np.float32)
+
+
+def hsv8_to_rgb(h, s, v):
+    hh = h * np.float32(2.0) / np.float32(60.0)
+    sf = s / np.float32(255.0)
+    sec = np.floor(hh).astype(np.int64) % 6
+    f = hh - np.floor(hh)
+    p, q, t = v * (1 - sf), v * (1 - sf * f), v * (1 - sf * (1 - f))
+    r = np.choose(sec, [v, q, p, p, t, v])
+    g = np.choose(sec, [t, v, v, q, p, p])
+    b = np.choose(sec, [p, p, t, v, v, q])
+    return np.stack([r, g, b], -1).astype(np.float32)
+
+
+def augment(img_u8, mask_u8, row, C=2):
+    """img (H,W,3) uint8, mask (H,W) uint8 class index (or None), row: 12 floats -> (img f32 (3,H,W), mask u8 (C,H,W))."""
+    H, W = img_u8.shape[:2]
+    a = row.astype(np.float32)
+    y, x = np.meshgrid(np.arange(H, dtype=np.float32), np.arange(W, dtype=np.float32), indexing='ij')
+    sx = a[0] * x + a[1] * y + a[2]
+    sy = a[3] * x + a[4] * y + a[5]
+    fx, fy = np.floor(sx), np.floor(sy)
+    wx, wy = (sx - fx)[..., None], (sy - fy)[..., None]
+    x0, x1 = reflect101(fx.astype(np.int64), W), reflect101(fx.astype(np.int64) + 1, W)
+    y0, y1 = reflect101(fy.astype(np.int64), H), reflect101(fy.astype(np.int64) + 1, H)
+    src = img_u8.astype(np.float32)
+    c = (1 - wy) * ((1 - wx) * src[y0, x0] + wx * src[y0, x1]) + wy * ((1 - wx) * src[y1, x0] + wx * src[y1, x1])
+    c = c.astype(np.float32)
+    if a[8] != 0 or a[9] != 0 or a[10] != 0:
+        h, s, v = rgb_to_hsv8(c)
+        h = np.fmod(h + a[8] + np.float32(360.0), np.float32(180.0))
+        s = np.clip(s + a[9], 0, 255)
+        v = np.clip(v + a[10], 0, 255)
+        c = hsv8_to_rgb(h.astype(np.float32), s.astype(np.float32), v.astype(np.float32))
+    out = np.clip(c * a[6] + a[7] * np.float32(255.0), 0, 255) * np.float32(1.0 / 255.0)
+    out_img = np.ascontiguousarray(out.transpose(2, 0, 1)).astype(np.float32)
+    out_mask = None
+    if mask_u8 is not None:
+        mx = reflect101(np.floor(sx + np.float32(0.5)).astype(np.int64), W)
+        my = reflect101(np.floor(sy + np.float32(0.5)).astype(np.int64), H)
+        cls = mask_u8[my, mx]
+        out_mask = np.stack([(cls == k) for k in range(C)]).astype(np.uint8)
+    return out_img, out_mask
+
+
+def transform_points(points_xyc, M, H, W):
+    """Keypoints (x, y, class) through the forward map; points that leave the image are dropped, the rest floored
+    (albumentations keypoint handling + the reference's integer rasterisation, utils/data.py:352-362)."""
+    if len(points_xyc) == 0:
+        return np.zeros((0, 3), dtype=np.int64)
+    p = np.asarray(points_xyc, dtype=np.float64)
+    xy = p[:, :2] @ M[:, :2].T + M[:, 2]
+    keep = (xy[:, 0] >= 0) & (xy[:, 0] < W) & (xy[:, 1] >= 0) & (xy[:, 1] < H)
+    out = np.concatenate([np.floor(xy[keep]), p[keep, 2:3]], 1)
+    return out.astype(np.int64)

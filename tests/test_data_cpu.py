@@ -1,0 +1,117 @@
+"""Host side of the input pipeline: on-disk format, resize / point rescaling, keypoint
+transforms, augmentation oracle invariants, per-rank sharding.  No GPU."""
+import csv
+import os
+
+import numpy as np
+import pytest
+import torch
+
+
+def _make_dataset(root, n=3, H=40, W=56, with_masks=True, with_points=True):
+    from PIL import Image
+    rs = np.random.RandomState(0)
+    for sub in ['images'] + (['masks'] if with_masks else []) + (['points'] if with_points else []):
+        os.makedirs(os.path.join(root, sub), exist_ok=True)
+    truth = []
+    for i in range(n):
+        img = rs.randint(0, 256, (H, W, 3)).astype(np.uint8)
+        Image.fromarray(img).save(os.path.join(root, 'images', f'im{i:02d}.png'))
+        mask = (rs.random_sample((H, W)) > 0.5).astype(np.uint8)
+        if with_masks:
+            Image.fromarray(mask).save(os.path.join(root, 'masks', f'im{i:02d}.png'))
+        pts = np.stack([rs.randint(0, W, 7), rs.randint(0, H, 7), rs.randint(0, 2, 7)], 1)
+        if with_points:
+            with open(os.path.join(root, 'points', f'im{i:02d}.csv'), 'w', newline='') as fp:
+                csv.writer(fp).writerows(pts.tolist())
+        truth.append((img, mask, pts))
+    return truth
+
+
+def test_point_dataset_reads_the_reference_layout(tmp_path):
+    from wesup_amd.utils.data import get_dataset, PointSupervisionDataset, NO_CLASS
+    truth = _make_dataset(str(tmp_path))
+    ds = get_dataset(tmp_path, train=True)
+    assert isinstance(ds, PointSupervisionDataset) and len(ds) == 3
+    img, mask, pts = ds[1]
+    assert img.dtype == torch.uint8 and img.shape == (40, 56, 3) and mask.shape == (40, 56)
+    assert np.array_equal(img.numpy(), truth[1][0]) and np.array_equal(mask.numpy(), truth[1][1])
+    got = pts.numpy()
+    assert np.array_equal(got[:7], truth[1][2]) and (got[7:] == -1).all()
+    ref_img, ref_mask = ds.to_reference_item((img, mask, pts))            # utils/data.py:135-152
+    assert ref_img.shape == (3, 40, 56) and ref_img.dtype == torch.float32 and float(ref_img.max()) <= 1.0
+    assert ref_mask.shape == (2, 40, 56) and ref_mask.dtype == torch.int64
+    assert torch.equal(ref_mask.sum(0), torch.ones(40, 56, dtype=torch.int64))
+    # no masks: the class-index map is the "no class" value and the reference item carries the empty sentinel
+    _make_dataset(str(tmp_path / 'nomask'), with_masks=False)
+    ds2 = get_dataset(tmp_path / 'nomask')
+    img2, mask2, _ = ds2[0]
+    assert int(mask2.min()) == NO_CLASS
+    assert len(ds2.to_reference_item((img2, mask2, None))[1].size()) == 0
+
+
+def test_resize_rescales_points_like_the_reference(tmp_path):
+    from wesup_amd.utils.data import PointSupervisionDataset, SegmentationDataset
+    truth = _make_dataset(str(tmp_path))
+    ds = PointSupervisionDataset(tmp_path, target_size=(80, 84))
+    img, mask, pts = ds[0]
+    assert img.shape == (80, 84, 3) and mask.shape == (80, 84)
+    want = np.floor(truth[0][2] * np.array([[84 / 56, 80 / 40, 1]])).astype(np.int32)      # utils/data.py:340-353
+    assert np.array_equal(pts.numpy()[:7], want)
+    ds = PointSupervisionDataset(tmp_path, rescale_factor=0.5)
+    img, mask, pts = ds[0]
+    assert img.shape == (20, 28, 3)
+    assert np.array_equal(pts.numpy()[:7], np.floor(truth[0][2] * np.array([[0.5, 0.5, 1]])).astype(np.int32))
+    assert set(np.unique(mask.numpy())) <= {0, 1}                                            # order-0 resize keeps labels
+    ds = SegmentationDataset(tmp_path, proportion=0.67, seed=3)
+    assert len(ds) == 2 and list(ds.picked) == sorted(ds.picked)
+
+
+def test_augment_oracle_identity_flip_and_keypoints():
+    from oracle import augment_oracle as ao
+    from wesup_amd.utils import data as D
+    rs = np.random.RandomState(1)
+    H, W = 24, 30
+    img = rs.randint(0, 256, (H, W, 3)).astype(np.uint8)
+    mask = rs.randint(0, 2, (H, W)).astype(np.uint8)
+    row, M = D.sample_params(rs, H, W, train=False)
+    out, om = ao.augment(img, mask, row)
+    assert np.allclose(out, img.transpose(2, 0, 1) / 255.0, atol=1e-6)                       # identity = ToTensor
+    assert np.array_equal(om[1], mask) and np.array_equal(om[0], 1 - mask)
+    # horizontal flip as an affine map: exact mirror, keypoints land on the mirrored pixel
+    Mf = np.array([[-1, 0, W - 1], [0, 1, 0.0]])
+    row = np.zeros(12, dtype=np.float32); row[0:3] = [-1, 0, W - 1]; row[3:6] = [0, 1, 0]; row[6] = 1
+    out, om = ao.augment(img, mask, row)
+    assert np.allclose(out, img[:, ::-1].transpose(2, 0, 1) / 255.0, atol=1e-6) and np.array_equal(om[1], mask[:, ::-1])
+    pts = np.array([[3, 5, 1], [29, 0, 0], [0, 23, 1]])
+    q = D.transform_points(pts, Mf, H, W)
+    assert np.array_equal(q, np.array([[26, 5, 1], [0, 0, 0], [29, 23, 1]]))
+    assert np.array_equal(q, ao.transform_points(pts, Mf, H, W))
+    # a point pushed outside the image is dropped; padded rows (-1) are ignored
+    Ms = np.array([[1, 0, 10.0], [0, 1, 0.0]])
+    assert len(D.transform_points(np.array([[25, 2, 0], [-1, -1, -1]]), Ms, H, W)) == 0
+    # random training parameters: inverse and forward maps agree, gains inside the albumentations limits
+    for _ in range(20):
+        row, M = D.sample_params(rs, H, W, train=True)
+        Minv = np.array([row[0:3], row[3:6]], dtype=np.float64)
+        full = np.vstack([M, [0, 0, 1]]) @ np.vstack([Minv, [0, 0, 1]])
+        assert np.allclose(full, np.eye(3), atol=1e-4)
+        assert 0.7 <= row[6] <= 1.3 and abs(row[7]) <= 0.3 and abs(row[8]) <= 20 and abs(row[9]) <= 30
+    # brightness/contrast only: img*alpha + beta*255 clipped
+    row = np.zeros(12, dtype=np.float32); row[0:3] = [1, 0, 0]; row[3:6] = [0, 1, 0]; row[6] = 1.2; row[7] = -0.1
+    out, _ = ao.augment(img, None, row)
+    assert np.allclose(out, np.clip(img.transpose(2, 0, 1) * 1.2 - 25.5, 0, 255) / 255.0, atol=1e-5)
+    # HSV round trip with zero shifts is skipped; a pure value shift moves max(r,g,b) by that amount
+    row[6], row[7], row[10] = 1.0, 0.0, 10.0
+    out, _ = ao.augment(img, None, row)
+    v0 = img.max(-1).astype(np.float32)
+    assert np.allclose(out.max(0) * 255.0, np.clip(v0 + 10, 0, 255), atol=1e-2)
+
+
+def test_rank_sharding_partitions_an_epoch():
+    from wesup_amd.ddp import shard_indices
+    n, world = 37, 4
+    shards = [shard_indices(n, r, world, seed=5, epoch=2) for r in range(world)]
+    assert len({len(s) for s in shards}) == 1
+    assert set(sum(shards, [])) == set(range(n))
+    assert shards != [shard_indices(n, r, world, seed=5, epoch=3) for r in range(world)]

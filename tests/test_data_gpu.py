@@ -1,0 +1,80 @@
+"""GPU side of the input pipeline: wesup_augment against its numpy restatement, and the DevicePrefetcher feeding
+the trainer from an on-disk dataset in the reference's layout."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_augment_kernel_matches_the_numpy_restatement():
+    from oracle import augment_oracle as ao
+    from wesup_amd import ops
+    from wesup_amd.utils import data as D
+    d = torch.device('cuda:0')
+    rs = np.random.RandomState(3)
+    B, H, W = 5, 61, 83
+    img = rs.randint(0, 256, (B, H, W, 3)).astype(np.uint8)
+    # smooth images as well: random noise hides interpolation mistakes behind large local contrast
+    yy, xx = np.mgrid[0:H, 0:W]
+    img[1] = np.stack([(xx * 3) % 256, (yy * 4) % 256, (xx + yy) % 256], -1).astype(np.uint8)
+    mask = rs.randint(0, 2, (B, H, W)).astype(np.uint8)
+    mask[2] = 255                                                     # an image without a mask: no class anywhere
+    rows = []
+    for b in range(B):
+        row, _ = D.sample_params(rs, H, W, train=(b > 0))
+        if b == 3:
+            row[8:11] = 0                                             # geometry + brightness/contrast only
+        rows.append(row)
+    params = np.stack(rows)
+    out, om = ops.augment(torch.from_numpy(img).to(d), torch.from_numpy(mask).to(d), torch.from_numpy(params).to(d))
+    out, om = out.cpu().numpy(), om.cpu().numpy()
+    for b in range(B):
+        want, wm = ao.augment(img[b], mask[b], params[b])
+        assert np.array_equal(om[b], wm), b                           # nearest-neighbour labels: exact
+        diff = np.abs(out[b] - want)
+        if params[b, 8] == 0 and params[b, 9] == 0 and params[b, 10] == 0:
+            assert diff.max() < 2e-5, (b, diff.max())                 # no HSV: affine + gain only (fma contraction of the coordinates)
+        else:
+            # the HSV round trip is piecewise: a pixel exactly on a hue-sector boundary may take the other branch
+            # under different fp32 contraction; everything else agrees to rounding
+            assert np.mean(diff > 1e-4) < 1e-3 and np.median(diff) < 1e-6, (b, np.mean(diff > 1e-4))
+    assert om[2].sum() == 0
+    # identity parameters are exactly ToTensor
+    assert np.array_equal(out[0], (img[0].transpose(2, 0, 1).astype(np.float32) * np.float32(1 / 255.0)))
+
+
+def test_prefetcher_feeds_the_trainer_from_disk(tmp_path):
+    from tests.test_data_cpu import _make_dataset
+    from wesup_amd.utils import data as D
+    from wesup_amd.models import initialize_trainer
+    from wesup_amd.utils.metrics import accuracy, dice
+    _make_dataset(str(tmp_path), n=5, H=64, W=64)
+    ds = D.get_dataset(tmp_path, train=True)
+    loader = torch.utils.data.DataLoader(ds, batch_size=2, shuffle=False, num_workers=0)
+    pf = D.DevicePrefetcher(loader, 'cuda:0', train=True, with_points=True, has_masks=True, seed=0)
+    batches = list(pf)
+    assert [b[0].shape[0] for b in batches] == [2, 2, 1]
+    img, pixel_mask, point_mask = batches[0]
+    assert img.shape == (2, 3, 64, 64) and img.dtype == torch.float32 and 0.0 <= float(img.min()) and float(img.max()) <= 1.0
+    assert pixel_mask.shape == (2, 2, 64, 64) and int(pixel_mask.sum(1).max()) == 1
+    assert point_mask.shape == (2, 2, 64, 64) and 0 < int(point_mask.sum()) <= 14
+    # validation mode: no augmentation -> the reference's CPU item, and points exactly where the CSV puts them
+    pv = D.DevicePrefetcher(torch.utils.data.DataLoader(ds, batch_size=1), 'cuda:0', train=False, seed=0)
+    vimg, vmask, vpts = next(iter(pv))
+    raw = ds[0]
+    ref_img, ref_mask = ds.to_reference_item(raw)
+    assert torch.allclose(vimg[0].cpu(), ref_img, atol=1e-7, rtol=0) and torch.equal(vmask[0].cpu().long(), ref_mask)
+    want = torch.zeros(2, 64, 64, dtype=torch.uint8)
+    for x, y, c in raw[2][raw[2][:, 2] >= 0].tolist():
+        want[c, y, x] = 1
+    assert torch.equal(vpts[0].cpu(), want)
+    # and a training iteration straight from the prefetcher (GPU SLIC inside preprocess)
+    trainer = initialize_trainer('wesup', device='cuda:0', sp_area=64)
+    trainer.optimizer, _ = trainer.get_default_optimizer()
+    trainer.metric_funcs = [accuracy, dice]
+    trainer.tracker.train()
+    for data in pf:
+        trainer.train_one_iteration('train', *data)
+    hist = trainer.tracker.history
+    assert len(hist['loss']) == 3 and all(np.isfinite(hist['loss']))

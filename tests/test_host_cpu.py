@@ -95,5 +95,5 @@ def test_synthetic_inputs_are_reproducible_and_well_formed():
     ds = get_dataset('synthetic:32:32:4:3/train')
     img, pix, p, seg = ds[0]
     assert img.shape == (3, 32, 32) and pix.shape == (2, 32, 32) and seg.shape == (32, 32) and len(ds) == 3
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(FileNotFoundError):                      # a real path is read from disk (tests/test_data_cpu.py)
         get_dataset('/data/glas/train')

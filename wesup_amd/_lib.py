@@ -23,6 +23,7 @@ _SIGS = {
     'wesup_debug_clock': (c_int, 'p'),
     'wesup_debug_set_trace': (c_int, 'p'),
     'wesup_strerror': (ctypes.c_char_p, 'i'),
+    'wesup_augment': (c_int, 'pppppiiiip'),
     'wesup_pack_input': (c_int, 'ppiiip'),
     'wesup_conv3x3_kpad': (c_int, 'i'),
     'wesup_pack_conv3x3_weight': (c_int, 'pppiip'),

@@ -65,7 +65,7 @@ struct NtParams {
 
 // ---------------------------------------------------------------------------------------------
 // NT kernel:  C[M][N] = A[M][K] * Bw[N][K]^T   with A either a plain row-major matrix or the implicit
-// im2col view of an NHWC tensor under a 3x3/pad-1 window (K order = (kh, kw, ci), ci fastest).
+// im2col view of an NHWC tensor under a 3x3/pad-1 window (K order = (32-channel chunk, tap, channel in chunk)).
 // MODE 0: plain; 1: conv3x3 with Cin % 32 == 0; 2: conv3x3 with Cin == 4 (image layer, K padded to 64).
 // LDS image of both operands: [row][32 floats], chunk c of row r stored at chunk position c ^ ((r>>1)&7).
 // A lane's fragments for 4 consecutive MFMA k-steps are ONE ds_read_b128; MFMA t of a group uses element t of the

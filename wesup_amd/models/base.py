@@ -289,6 +289,15 @@ class BaseTrainer(ABC):
             self.dataloaders['val'] = torch.utils.data.DataLoader(val_dataset, batch_size=1, num_workers=workers)
         else:
             has_val = False
+        # datasets read from disk hand out raw uint8 items: H2D through pinned memory one batch ahead, augmentation /
+        # ToTensor / one-hot on the GPU (utils/data.py: DevicePrefetcher)
+        from ..utils import data as D
+        for phase, ds in (('train', train_dataset), ('val', val_dataset if has_val else None)):
+            if isinstance(ds, D.SegmentationDataset):
+                self.dataloaders[phase] = D.DevicePrefetcher(
+                    self.dataloaders[phase], self.device, train=(phase == 'train'),
+                    with_points=isinstance(ds, D.PointSupervisionDataset), has_masks=ds.mask_paths is not None,
+                    n_classes=ds.n_classes, seed=self.rank)
 
         self.logger.info(underline('\nTraining Stage', '='))
         self.metric_funcs = self.kwargs.get('metrics')

@@ -53,6 +53,22 @@ def _nt_workspace(nbytes, device):
     return workspace(nbytes, device, 'nt%x' % torch.cuda.current_stream().cuda_stream)
 
 
+# ---------------------------------------------------------------- input pipeline
+def augment(img_u8, mask_u8, params, n_classes=2):
+    """img (B,H,W,3) uint8, mask (B,H,W) uint8 class index or None, params (B,12) fp32 -> img f32 (B,3,H,W) in [0,1],
+    one-hot mask uint8 (B,C,H,W) or None."""
+    _chk(img_u8, torch.uint8, 'img'); _chk(params, name='params')
+    B, H, W, three = img_u8.shape
+    assert three == 3 and params.shape == (B, 12)
+    out = torch.empty(B, 3, H, W, dtype=torch.float32, device=img_u8.device)
+    om = None
+    if mask_u8 is not None:
+        _chk(mask_u8, torch.uint8, 'mask'); assert mask_u8.shape == (B, H, W)
+        om = torch.empty(B, n_classes, H, W, dtype=torch.uint8, device=img_u8.device)
+    _lib.call('wesup_augment', _p(img_u8), _p(mask_u8), _p(params), _p(out), _p(om), B, H, W, n_classes, _stream())
+    return out, om
+
+
 # ---------------------------------------------------------------- packing
 def pack_input(img, out=None):
     _chk(img, name='img')

@@ -1,13 +1,27 @@
-"""Data contract of the training step (reference: utils/data.py:135-152,459-512).
+"""Input pipeline of the training step (reference utils/data.py:33-165,279-375).
 
-Real dataset readers / augmentation are host-side I/O outside the hot path
-(8(f) rank 2).  What the trainer needs is the tensor contract:
-an item is (img f32 (3,H,W) in [0,1], pixel_mask (C,H,W) one-hot, point_mask (C,H,W)
-radius-0 dots, segments (H,W) int32 label map).  ``SyntheticGlasDataset`` produces
-GlaS-shaped items of that contract; ``get_dataset`` accepts 'synthetic:H:W:g:n'."""
+On-disk contract (reference README.md:17-59): ``root/images/*`` (PNG/BMP), optional ``root/masks/*`` (class index per
+pixel), optional ``root/points/*.csv`` (rows ``x,y,class``).  The reference decodes, resizes AND augments every item
+on the CPU in DataLoader workers (skimage + albumentations).  Here the host only decodes and resizes (PIL, in
+DataLoader workers); ``DevicePrefetcher`` moves a collated uint8 batch to the GPU through pinned memory one batch
+ahead and runs the augmentation there (``wesup_augment``: flips + shift/scale/rotate as one affine map, HSV shift,
+brightness/contrast, ToTensor, one-hot masks); keypoints follow the same affine map on the host and are rasterised
+as radius-0 dots (utils/data.py:352-362).  What comes out is the reference's item contract, batched:
+``img f32 (B,3,H,W) in [0,1]``, ``pixel_mask (B,C,H,W)`` one-hot or the empty tensor, ``point_mask (B,C,H,W)``.
+
+Not reproduced: CLAHE, Blur, ElasticTransform of the reference's pipelines; exact skimage / OpenCV / albumentations
+numerics (all absent from the build image: parity unpinned).  ``SyntheticGlasDataset`` keeps producing
+GlaS-shaped items of the same contract for benchmarks ('synthetic:H:W:g:n')."""
+import csv
+from pathlib import Path
+
+import numpy as np
 import torch
 
 from .. import synth
+from . import empty_tensor
+
+NO_CLASS = 255
 
 
 class SyntheticGlasDataset(torch.utils.data.Dataset):
@@ -33,11 +47,222 @@ class SyntheticGlasDataset(torch.utils.data.Dataset):
         return img, pix, pts, seg
 
 
-def get_dataset(root_dir, train=True, proportion=1.0, multiscale_range=None, rescale_factor=None):
+def _imread(path):
+    from PIL import Image
+    with Image.open(path) as im:
+        return im.copy()
+
+
+class SegmentationDataset(torch.utils.data.Dataset):
+    """Decode + resize on the host (utils/data.py:33-165).  Items are RAW: ``img uint8 (H,W,3)``, ``mask uint8 (H,W)``
+    class index (255 everywhere when the dataset has no masks), ``points int32 (P_MAX,3)`` rows (x,y,class) padded
+    with -1 (only PointSupervisionDataset fills them).  Augmentation, ToTensor and one-hot happen on the GPU in
+    ``DevicePrefetcher``; ``to_reference_item`` gives the reference's un-augmented CPU item for a raw item."""
+    P_MAX = 4096
+
+    def __init__(self, root_dir, mode=None, target_size=None, rescale_factor=None, multiscale_range=None, train=True,
+                 proportion=1, n_classes=2, seed=0):
+        self.root_dir = Path(root_dir).expanduser()
+        self.img_paths = sorted((self.root_dir / 'images').iterdir())
+        self.mask_paths = None
+        if (self.root_dir / 'masks').exists():
+            self.mask_paths = sorted((self.root_dir / 'masks').iterdir())
+        self.mode = mode or 'mask' if self.mask_paths is not None else None           # utils/data.py:68
+        self.target_size, self.rescale_factor, self.multiscale_range = target_size, rescale_factor, multiscale_range
+        self.train, self.proportion, self.n_classes = train, proportion, n_classes
+        self.picked = np.arange(len(self.img_paths))
+        if self.proportion < 1:                                                        # utils/data.py:84-88
+            rs = np.random.RandomState(seed)
+            rs.shuffle(self.picked)
+            self.picked = np.sort(self.picked[:len(self)])
+
+    def __len__(self):
+        return int(self.proportion * len(self.img_paths))
+
+    def summary(self, logger=None):
+        msg = (f'{type(self).__name__} at {self.root_dir}: {len(self)} of {len(self.img_paths)} images, '
+               f'masks: {self.mask_paths is not None}, mode: {self.mode}, train: {self.train}')
+        (logger.info if logger else print)(msg)
+
+    def _target_hw(self, height, width):
+        if self.target_size is not None:
+            return tuple(self.target_size), None
+        f = self.rescale_factor
+        if self.multiscale_range is not None:
+            f = float(np.random.uniform(*self.multiscale_range))
+        if f is not None:
+            return (int(np.ceil(f * height)), int(np.ceil(f * width))), f               # utils/data.py:99-106
+        return (height, width), None
+
+    def _load(self, idx):
+        from PIL import Image
+        img = _imread(self.img_paths[idx]).convert('RGB')
+        width, height = img.size
+        (th, tw), factor = self._target_hw(height, width)
+        if (th, tw) != (height, width):
+            img = img.resize((tw, th), Image.BILINEAR)                                 # order 1, no anti-aliasing
+        mask = None
+        if self.mask_paths is not None:
+            mask = _imread(self.mask_paths[idx])
+            if (th, tw) != (height, width):
+                mask = mask.resize((tw, th), Image.NEAREST)                            # order 0
+            mask = np.asarray(mask)
+            if mask.ndim == 3:
+                mask = mask[..., 0]
+            mask = mask.astype(np.uint8)
+        return np.array(img, dtype=np.uint8), mask, (height, width), factor
+
+    def __getitem__(self, i):
+        idx = int(self.picked[i])
+        img, mask, _, _ = self._load(idx)
+        if mask is None:
+            mask = np.full(img.shape[:2], NO_CLASS, dtype=np.uint8)
+        pts = np.full((self.P_MAX, 3), -1, dtype=np.int32)
+        return torch.from_numpy(img), torch.from_numpy(mask), torch.from_numpy(pts)
+
+    def to_reference_item(self, raw):
+        """The reference's CPU item for a raw item without augmentation (utils/data.py:135-152)."""
+        img, mask, pts = raw
+        out = [img.permute(2, 0, 1).float() / 255.0]
+        if self.mask_paths is not None:
+            out.append(torch.stack([(mask == k) for k in range(self.n_classes)]).long())
+        else:
+            out.append(empty_tensor())
+        return tuple(out)
+
+
+class PointSupervisionDataset(SegmentationDataset):
+    """images + points/*.csv (+ masks) -> raw item with the rescaled keypoints (utils/data.py:279-375)."""
+
+    def __init__(self, root_dir, target_size=None, rescale_factor=None, multiscale_range=None, radius=0, train=True,
+                 proportion=1):
+        super().__init__(root_dir, mode='point', target_size=target_size, rescale_factor=rescale_factor, train=train,
+                         proportion=proportion, multiscale_range=multiscale_range)
+        self.point_paths = sorted((self.root_dir / 'points').glob('*.csv'))
+        if radius != 0:
+            raise NotImplementedError('only radius-0 point labels (the reference default) are rasterised on the GPU')
+        self.radius = radius
+
+    def __getitem__(self, i):
+        idx = int(self.picked[i])
+        img, mask, (oh, ow), factor = self._load(idx)
+        h, w = img.shape[:2]
+        if factor is None:                                                              # utils/data.py:340-347
+            rescaler = np.array([[w / ow, h / oh, 1]])
+        else:
+            rescaler = np.array([[factor, factor, 1]])
+        with open(str(self.point_paths[idx])) as fp:
+            rows = [[int(d) for d in r] for r in csv.reader(fp) if r]
+        pts = np.full((self.P_MAX, 3), -1, dtype=np.int32)
+        if rows:
+            p = np.floor(np.array(rows) * rescaler).astype(np.int32)[:self.P_MAX]         # utils/data.py:350-353
+            pts[:len(p)] = p
+        if mask is None:
+            mask = np.full((h, w), NO_CLASS, dtype=np.uint8)
+        return torch.from_numpy(img), torch.from_numpy(mask), torch.from_numpy(pts)
+
+
+def sample_params(rs, H, W, train, point_pipeline=True):
+    """12 floats for wesup_augment + the forward 2x3 matrix for keypoints.  Parameter ranges are the albumentations
+    defaults the reference's pipelines rely on (utils/data.py:116-133 for masks, :302-327 for points)."""
+    M = np.eye(3)
+    row = np.zeros(12, dtype=np.float32)
+    row[6] = 1.0
+    if train:
+        if rs.random_sample() < 0.5:
+            M = np.array([[-1, 0, W - 1], [0, 1, 0], [0, 0, 1.0]]) @ M
+        if rs.random_sample() < 0.5:
+            M = np.array([[1, 0, 0], [0, -1, H - 1], [0, 0, 1.0]]) @ M
+        if point_pipeline or rs.random_sample() < 0.8:            # ShiftScaleRotate p=1 (points) / p=0.8 (masks)
+            ang = np.deg2rad(rs.uniform(-45, 45))
+            sc = 1.0 + rs.uniform(-0.1, 0.1)
+            dx, dy = rs.uniform(-0.0625, 0.0625), rs.uniform(-0.0625, 0.0625)
+            cx, cy = (W - 1) * 0.5, (H - 1) * 0.5
+            a, b = sc * np.cos(ang), sc * np.sin(ang)
+            M = np.array([[a, b, (1 - a) * cx - b * cy + dx * W], [-b, a, b * cx + (1 - a) * cy + dy * H], [0, 0, 1.0]]) @ M
+        lim_bc, lim_h, lim_s, lim_v = (0.3, 20.0, 30.0, 20.0) if point_pipeline else (0.1, 10.0, 10.0, 10.0)
+        row[6] = 1.0 + rs.uniform(-lim_bc, lim_bc)
+        row[7] = rs.uniform(-lim_bc, lim_bc)
+        row[8], row[9], row[10] = rs.uniform(-lim_h, lim_h), rs.uniform(-lim_s, lim_s), rs.uniform(-lim_v, lim_v)
+    Minv = np.linalg.inv(M)
+    row[0:3], row[3:6] = Minv[0], Minv[1]
+    return row, M[:2]
+
+
+def transform_points(pts_xyc, M, H, W):
+    """Keypoints (x,y,class) through the forward map; points leaving the image are dropped, the rest floored."""
+    p = np.asarray(pts_xyc, dtype=np.float64).reshape(-1, 3)
+    p = p[p[:, 2] >= 0]
+    if len(p) == 0:
+        return np.zeros((0, 3), dtype=np.int64)
+    xy = p[:, :2] @ M[:, :2].T + M[:, 2]
+    keep = (xy[:, 0] >= 0) & (xy[:, 0] < W) & (xy[:, 1] >= 0) & (xy[:, 1] < H)
+    return np.concatenate([np.floor(xy[keep]), p[keep, 2:3]], 1).astype(np.int64)
+
+
+class DevicePrefetcher:
+    """Wraps a DataLoader over raw items: pinned staging + asynchronous H2D on a copy stream one batch ahead,
+    augmentation / ToTensor / one-hot / point rasterisation on the GPU.  Yields the trainer's data tuple
+    ``(img, pixel_mask, point_mask)`` (or ``(img, pixel_mask)`` for mask datasets)."""
+
+    def __init__(self, loader, device, train=True, with_points=True, has_masks=True, n_classes=2, seed=0):
+        self.loader, self.device, self.train = loader, torch.device(device), train
+        self.with_points, self.has_masks, self.n_classes = with_points, has_masks, n_classes
+        self.rs = np.random.RandomState(seed)
+        self.copy_stream = torch.cuda.Stream(device=self.device)
+
+    def __len__(self):
+        return len(self.loader)
+
+    def _stage(self, raw):
+        from .. import ops
+        img, mask, pts = raw
+        B, H, W, _ = img.shape
+        rows, mats = zip(*[sample_params(self.rs, H, W, self.train, self.with_points) for _ in range(B)])
+        params = torch.from_numpy(np.stack(rows))
+        bi, ci, yi, xi = [], [], [], []
+        if self.with_points:                     # keypoints follow the forward map on the host (a few hundred per image)
+            for b in range(B):
+                q = transform_points(pts[b].numpy(), mats[b], H, W)
+                bi += [b] * len(q); xi += q[:, 0].tolist(); yi += q[:, 1].tolist(); ci += q[:, 2].tolist()
+        idx = torch.tensor([bi, ci, yi, xi], dtype=torch.int64).reshape(4, -1)
+        with torch.cuda.stream(self.copy_stream):
+            d_img = img.pin_memory().to(self.device, non_blocking=True)
+            d_mask = mask.pin_memory().to(self.device, non_blocking=True) if self.has_masks else None
+            d_par = params.pin_memory().to(self.device, non_blocking=True)
+            out_img, out_mask = ops.augment(d_img, d_mask, d_par, self.n_classes)
+            point_mask = None
+            if self.with_points:
+                point_mask = torch.zeros(B, self.n_classes, H, W, dtype=torch.uint8, device=self.device)
+                if idx.shape[1]:
+                    d_idx = idx.pin_memory().to(self.device, non_blocking=True)
+                    point_mask[d_idx[0], d_idx[1], d_idx[2], d_idx[3]] = 1
+            done = torch.cuda.Event()
+            done.record()
+        pixel_mask = out_mask if self.has_masks else empty_tensor()
+        return ((out_img, pixel_mask, point_mask) if self.with_points else (out_img, pixel_mask)), done
+
+    def __iter__(self):
+        nxt = None
+        for raw in self.loader:
+            cur, nxt = nxt, self._stage(raw)
+            if cur is not None:
+                torch.cuda.current_stream().wait_event(cur[1])
+                yield cur[0]
+        if nxt is not None:
+            torch.cuda.current_stream().wait_event(nxt[1])
+            yield nxt[0]
+
+
+def get_dataset(root_dir, train=True, proportion=1.0, multiscale_range=None, rescale_factor=None, target_size=None):
     root = str(root_dir)
     if 'synthetic:' in root:
         spec = root[root.index('synthetic:'):].split('/')[0].split(':')[1:]
         H, W, g, n = (int(v) for v in (spec + ['480', '480', '24', '16'][len(spec):])[:4])
         return SyntheticGlasDataset(H, W, g, max(1, int(n * proportion)), seed=0 if train else 1)
-    raise NotImplementedError('dataset readers/augmentation are outside the MI355X hot path (SURVEY.md 8(f) rank 2); '
-                              "use 'synthetic:H:W:g:n' or feed tensors to trainer.train_one_iteration directly")
+    root_dir = Path(root_dir)
+    if (root_dir / 'points').exists():                                                 # models/wesup.py:436-443
+        return PointSupervisionDataset(root_dir, target_size=target_size, rescale_factor=rescale_factor,
+                                       multiscale_range=multiscale_range, train=train, proportion=proportion)
+    return SegmentationDataset(root_dir, target_size=target_size, rescale_factor=rescale_factor, train=train,
+                               proportion=proportion, multiscale_range=multiscale_range)
