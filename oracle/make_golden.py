@@ -186,3 +186,49 @@ def main():
 
 if __name__ == '__main__':
     main()
+
+
+def metrics_golden():
+    """GlaS challenge metrics of the reference (utils/metrics.py:48-281) on small blob masks -> tests/golden/metrics.npz.
+    The reference labels connected components with skimage.measure.label (absent here): the stand-in supplies
+    scipy.ndimage.label with 8-connectivity, which is skimage's documented default for 2-D input; everything else
+    (object matching, weights, Dice / F1 / Hausdorff formulas) is the reference's own code."""
+    from scipy import ndimage
+    _install_standins()
+    sk = _Anything('skimage.measure')
+    sk.label = lambda a: ndimage.label(np.asarray(a) != 0, structure=np.ones((3, 3), dtype=np.int32))[0]
+    sys.modules['skimage.measure'] = sk
+    sys.modules['skimage'].measure = sk
+    sys.path.insert(0, REF)
+    import importlib
+    refm = importlib.import_module('utils.metrics')
+
+    def blobs(seed, H=64, W=72, n=6):
+        rs = np.random.RandomState(seed)
+        yy, xx = np.mgrid[0:H, 0:W]
+        m = np.zeros((H, W), dtype=np.uint8)
+        for _ in range(n):
+            cy, cx, r = rs.randint(0, H), rs.randint(0, W), rs.randint(3, 10)
+            m |= ((yy - cy) ** 2 + (xx - cx) ** 2 <= r * r).astype(np.uint8)
+        return m
+
+    cases = [(blobs(1), blobs(2)), (blobs(3), blobs(3)), (blobs(4, n=2), blobs(5, n=9)),
+             (np.zeros((64, 72), np.uint8), blobs(6)), (blobs(7), np.zeros((64, 72), np.uint8)),
+             (np.zeros((64, 72), np.uint8), np.zeros((64, 72), np.uint8))]
+    # one pair shifted by a few pixels: partial overlaps around the 50 % threshold
+    b = blobs(8)
+    cases.append((np.roll(b, 4, axis=1), b))
+    out = dict(n=len(cases))
+    for i, (S, G) in enumerate(cases):
+        out[f'S{i}'], out[f'G{i}'] = S, G
+        vals = [refm.detection_f1(S, G), refm.object_dice(S, G)]
+        # object_hausdorff of an empty against a non-empty map is ill-defined in the reference (division by zero): skip
+        vals.append(refm.object_hausdorff(S, G) if S.any() and G.any() else np.nan)
+        vals.append(refm.hausdorff(S, G))
+        out[f'v{i}'] = np.array(vals, dtype=np.float64)
+        print('metrics case', i, out[f'v{i}'])
+    np.savez_compressed(os.path.join(ROOT, 'tests', 'golden', 'metrics.npz'), **out)
+
+
+if __name__ == '__main__' and 'metrics' in sys.argv[1:]:
+    metrics_golden()

@@ -98,3 +98,20 @@ def test_pixel_inference_oracle_matches_reference(golden_dir):
     out = orc.pixel_inference(w, torch.from_numpy(fx['img'])[None])
     assert tuple(out.shape) == fx['out'].shape
     assert rel_err(out.numpy(), fx['out']) < 1e-5
+
+
+def test_challenge_metrics_match_the_reference(golden_dir):
+    """detection_f1 / object_dice / object_hausdorff / hausdorff (utils/metrics.py:48-281) against values produced by
+    the reference's own functions (oracle/make_golden.py metrics_golden)."""
+    from wesup_amd.utils import metrics as M
+    fx = np.load(os.path.join(golden_dir, 'metrics.npz'))
+    for i in range(int(fx['n'])):
+        S, G, want = fx[f'S{i}'], fx[f'G{i}'], fx[f'v{i}']
+        got = [M.detection_f1(S, G), M.object_dice(S, G), M.object_hausdorff(S, G) if S.any() and G.any() else np.nan,
+               M.hausdorff(S, G)]
+        for g, w in zip(got, want):
+            if np.isnan(w):
+                continue
+            assert (np.isinf(w) and np.isinf(g)) or abs(g - w) <= 1e-9 * max(1.0, abs(w)), (i, got, want)
+        # torch inputs are accepted like numpy ones
+        assert M.object_dice(torch.from_numpy(S), torch.from_numpy(G)) == got[1]
