@@ -71,12 +71,15 @@ struct NtParams {
 // A lane's fragments for 4 consecutive MFMA k-steps are ONE ds_read_b128; MFMA t of a group uses element t of the
 // A and the B fragment: lanes 0-31 then carry k = 8g+t, lanes 32-63 k = 8g+4+t (any consistent k order is fine).
 // ---------------------------------------------------------------------------------------------
-template <int BM, int BN, int WM, int WN, int MODE, int MINB>
-__global__ __launch_bounds__(256, MINB) void gemm_nt_kernel(const NtParams p) {
-    constexpr int RA = BM / 32, RB = BN / 32;          // staging passes (32 rows x 8 chunks per pass)
+template <int NW, int BM, int BN, int WM, int WN, int MODE, int MINB>
+__global__ __launch_bounds__(NW * 64, MINB) void gemm_nt_kernel(const NtParams p) {
+    constexpr int NT = NW * 64;                        // threads per block
+    constexpr int PR = NW * 8;                         // rows per staging pass (8 threads fetch one 128-B row)
+    constexpr int RA = BM / PR, RB = BN / PR;          // staging passes
     constexpr int WAVES_N = BN / (32 * WN);
     constexpr int LDC = BN + 4;
-    static_assert((BM / (32 * WM)) * WAVES_N == 4, "4 waves per block");
+    static_assert((BM / (32 * WM)) * WAVES_N == NW, "wave grid covers the tile");
+    static_assert(BM % PR == 0 && BN % PR == 0, "whole staging passes");
     constexpr int LDS_FLOATS = 2 * (BM + BN) * BK;
     constexpr int EP = (BM * LDC + LDS_FLOATS - 1) / LDS_FLOATS;     // epilogue passes (C tile staged in row slabs)
     constexpr int HR = BM / EP;
@@ -89,8 +92,8 @@ __global__ __launch_bounds__(256, MINB) void gemm_nt_kernel(const NtParams p) {
     const unsigned long long tr0 = __builtin_amdgcn_s_memrealtime();
     const bool relu_in = p.flags & WESUP_RELU_IN;
     const float* zero = reinterpret_cast<const float*>(g_zero_page);
-    // ---- staging role of this lane: row (tid>>3) of each 32-row pass, chunk position tid&7; the logical chunk it
-    // fetches is position ^ swizzle(row) (the swizzle does not depend on the pass: 32*i >> 1 == 0 mod 8)
+    // ---- staging role of this lane: row (tid>>3) of each PR-row pass, chunk position tid&7; the logical chunk it
+    // fetches is position ^ swizzle(row) (the swizzle does not depend on the pass: PR*i >> 1 == 0 mod 8)
     const int srow = tid >> 3;
     const int schunk = (tid & 7) ^ ((srow >> 1) & 7);
     const int wm0 = (wave / WAVES_N) * 32 * WM, wn0 = (wave % WAVES_N) * 32 * WN;
@@ -131,7 +134,7 @@ __global__ __launch_bounds__(256, MINB) void gemm_nt_kernel(const NtParams p) {
     unsigned a_msk[RA];
 #pragma unroll
     for (int i = 0; i < RA; ++i) {
-        const int m = m_blk + srow + 32 * i;
+        const int m = m_blk + srow + PR * i;
         if (MODE == 0) {
             a_off[i] = (long)m * p.lda + 4 * schunk;
             a_msk[i] = (m < p.M) ? 1u : 0u;
@@ -156,18 +159,18 @@ __global__ __launch_bounds__(256, MINB) void gemm_nt_kernel(const NtParams p) {
     bool b_ok[RB];
 #pragma unroll
     for (int j = 0; j < RB; ++j) {
-        const int n = n_blk + srow + 32 * j;
+        const int n = n_blk + srow + PR * j;
         b_ok[j] = n < p.N;
         b_off[j] = (long)n * p.ldb + 4 * schunk;
     }
 
-    // Staging of tile kk into buffer buf; part q issues the q-th 32-row pass of A and of B (kept separable so that
+    // Staging of tile kk into buffer buf; part q issues the q-th PR-row pass of A and of B (kept separable so that
     // the issue can be spread over the MFMA groups -- tried, no gain, see the main loop).
     constexpr int NPART = (RA > RB) ? RA : RB;
     auto stage_part = [&](int kk, int buf, int q) {
         // wave-uniform LDS byte addresses: rows 8*wave.. of pass q
-        const unsigned adst = __builtin_amdgcn_readfirstlane(lds_addr(As + buf * BM * BK + wave * 256)) + q * 32 * BK * 4;
-        const unsigned bdst = __builtin_amdgcn_readfirstlane(lds_addr(Bs + buf * BN * BK + wave * 256)) + q * 32 * BK * 4;
+        const unsigned adst = __builtin_amdgcn_readfirstlane(lds_addr(As + buf * BM * BK + wave * 256)) + q * PR * BK * 4;
+        const unsigned bdst = __builtin_amdgcn_readfirstlane(lds_addr(Bs + buf * BN * BK + wave * 256)) + q * PR * BK * 4;
 #pragma unroll
         for (int i = 0; i < RA; ++i) {
             if (i != q) continue;
@@ -271,7 +274,7 @@ __global__ __launch_bounds__(256, MINB) void gemm_nt_kernel(const NtParams p) {
     float* Cs = smem;
     const bool relu_out = p.flags & WESUP_RELU_OUT, accum = p.flags & WESUP_ACCUM, use_mask = p.flags & WESUP_MASK;
     constexpr int QN = BN / 4;                 // float4 pieces per row
-    constexpr int ROWS_PER_PASS = 256 / QN;
+    constexpr int ROWS_PER_PASS = NT / QN;
     const int cq = tid % QN, r0 = tid / QN;
     const int n = n_blk + 4 * cq;
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -380,16 +383,23 @@ __global__ __launch_bounds__(256) void nt_fixup_kernel(const NtParams p) {
     st4(c, v);
 }
 
-// Stream-K plan of an (M, N, K) problem under 128x128 tiles and 2 resident blocks per CU: how many tiles run whole,
+// Block shapes of the NT family.  BIG: 256x128, 8 waves (the same 64x64 wave tile), ONE block per CU: the eight waves
+// run in lock step behind one barrier, so every tile of a round ends at the same time and the stream-K tail starts
+// level on all CUs (with two independent 128x128 blocks per CU the older block of a pair wins the MFMA arbitration and
+// finishes a 72-step tile ~100 us before its partner, which leaves the end of the launch ragged); a quarter less
+// operand traffic per FLOP comes with it.  tools/gemm_lab.hip: +2-4 % over the 2-blocks-per-CU form on whole rounds.
+// STD: 128x128, 4 waves, two blocks per CU.
+enum NtShape { NT_BIG = 0, NT_STD = 1, NT_N64 = 2, NT_SMALL = 3 };
+
+// Stream-K plan of an (M, N, K) problem under bm x bn tiles and `slots` resident blocks: how many tiles run whole,
 // how many blocks share the K-steps of the rest.  parts == 0: plain tiling.
 struct SkPlan {
     int full, parts, steps;
     size_t ws_bytes;
 };
-static SkPlan plan_streamk(int M, int N, int K) {
+static SkPlan plan_streamk(int M, int N, int K, int bm, int bn, int slots) {
     SkPlan pl = {0, 0, 0, 0};
-    const int slots = 512;
-    const long tiles = (long)ceil_div(M, 128) * ceil_div(N, 128);
+    const long tiles = (long)ceil_div(M, bm) * ceil_div(N, bn);
     const int nk = K / BK;
     pl.full = (int)tiles;
     const int R = (int)(tiles % slots);
@@ -402,11 +412,47 @@ static SkPlan plan_streamk(int M, int N, int K) {
     pl.full = (int)tiles - R;
     pl.parts = P;
     pl.steps = (int)W;
-    pl.ws_bytes = (size_t)P * 2 * 128 * 128 * sizeof(float);
+    pl.ws_bytes = (size_t)P * 2 * bm * bn * sizeof(float);
     return pl;
 }
 
-template <int BM, int BN, int WM, int WN, int MODE, int MINB>
+// Shape choice (shared by the workspace queries and the dispatch).  The step uses STD: alone BIG is 1-3 % faster on the
+// 120x120 / 60x60 layers (conv forward 5.27 -> 5.25, dgrad 5.12 -> 5.03 ms per step), but a block that takes 96 KiB of
+// LDS and all wave slots of its CU leaves no room for the kernels of the other two streams, and the 3-stream step
+// goes from 20.0 to 20.8 ms.  WESUP_NT_SHAPE=big selects it for measurements.
+struct NtChoice {
+    NtShape shape;
+    SkPlan sk;       // with_ws: the stream-K plan the dispatch will use if the caller passes the workspace
+};
+static bool nt_force_std() {
+    static const int v = [] { const char* e = getenv("WESUP_NT_SHAPE"); return (e && e[0] == 'b') ? 0 : 1; }();
+    return v != 0;
+}
+static NtChoice choose_nt(int M, int N, int K, bool with_ws) {
+    NtChoice c;
+    c.sk = SkPlan{0, 0, 0, 0};
+    const long t128 = (long)ceil_div(M, 128) * ceil_div(N, 128);
+    const long t256 = (long)ceil_div(M, 256) * ceil_div(N, 128);
+    if (N > 64 && !nt_force_std() && M >= 2048) {
+        if (with_ws) {
+            const SkPlan sk = plan_streamk(M, N, K, 256, 128, 256);
+            if (sk.parts > 0) { c.shape = NT_BIG; c.sk = sk; return c; }
+        }
+        if (t256 >= 192) { c.shape = NT_BIG; return c; }
+    }
+    if (N > 64) {
+        if (with_ws) {
+            const SkPlan sk = plan_streamk(M, N, K, 128, 128, 512);
+            if (sk.parts > 0) { c.shape = NT_STD; c.sk = sk; return c; }
+        }
+        if (t128 >= 384) { c.shape = NT_STD; return c; }
+    }
+    if (N <= 64 && (long)ceil_div(M, 128) >= 384) { c.shape = NT_N64; return c; }
+    c.shape = NT_SMALL;
+    return c;
+}
+
+template <int NW, int BM, int BN, int WM, int WN, int MODE, int MINB>
 static int launch_nt(NtParams p, hipStream_t st, const SkPlan* sk = nullptr, void* ws = nullptr) {
     p.tiles_m = ceil_div(p.M, BM);
     p.tiles_n = ceil_div(p.N, BN);
@@ -416,7 +462,13 @@ static int launch_nt(NtParams p, hipStream_t st, const SkPlan* sk = nullptr, voi
         p.full_tiles = sk->full; p.sk_parts = sk->parts; p.sk_steps = sk->steps; p.sk_ws = (float*)ws;
     }
     const size_t lds = (size_t)2 * (BM + BN) * BK * sizeof(float);
-    hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, WM, WN, MODE, MINB>), dim3(p.full_tiles + p.sk_parts), dim3(256), lds, st, p);
+    auto kern = gemm_nt_kernel<NW, BM, BN, WM, WN, MODE, MINB>;
+    if (lds > 64 * 1024) {           // more than the default dynamic LDS limit: raise it once per instantiation
+        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (attr != hipSuccess) return WESUP_ERR_LAUNCH;
+    }
+    hipLaunchKernelGGL(kern, dim3(p.full_tiles + p.sk_parts), dim3(NW * 64), lds, st, p);
     WESUP_CHECK_LAUNCH();
     if (p.sk_parts > 0) {
         const int rem_tiles = p.tiles_m * p.tiles_n - p.full_tiles;
@@ -426,19 +478,18 @@ static int launch_nt(NtParams p, hipStream_t st, const SkPlan* sk = nullptr, voi
     return WESUP_OK;
 }
 
-// Tile choice: 128x128 when the grid fills 256 CUs twice over, or -- given a workspace -- whenever stream-K can spread
-// the tiles of a short last round over all block slots; 128x64 for N <= 64; 64x64 for small problems.
 template <int MODE>
 static int dispatch_nt(NtParams p, hipStream_t st, void* ws, size_t ws_bytes) {
-    const long t128 = (long)ceil_div(p.M, 128) * ceil_div(p.N, 128);
-    if (ws && p.N > 64) {
-        const SkPlan sk = plan_streamk(p.M, p.N, p.K);
-        if (sk.parts > 0 && ws_bytes >= sk.ws_bytes && !((uintptr_t)ws & 15))
-            return launch_nt<128, 128, 2, 2, MODE, 2>(p, st, &sk, ws);
+    const bool ws_ok = ws && !((uintptr_t)ws & 15);
+    NtChoice c = choose_nt(p.M, p.N, p.K, ws_ok);
+    if (c.sk.parts > 0 && ws_bytes < c.sk.ws_bytes) c = choose_nt(p.M, p.N, p.K, false);   // workspace too small: plain tiling
+    const SkPlan* sk = c.sk.parts > 0 ? &c.sk : nullptr;
+    switch (c.shape) {
+        case NT_BIG: return launch_nt<8, 256, 128, 2, 2, MODE, 1>(p, st, sk, ws);
+        case NT_STD: return launch_nt<4, 128, 128, 2, 2, MODE, 2>(p, st, sk, ws);
+        case NT_N64: return launch_nt<4, 128, 64, 2, 1, MODE, 2>(p, st);
+        default: return launch_nt<4, 64, 64, 1, 1, MODE, 2>(p, st);
     }
-    if (p.N > 64 && t128 >= 384) return launch_nt<128, 128, 2, 2, MODE, 2>(p, st);
-    if (p.N <= 64 && (long)ceil_div(p.M, 128) >= 384) return launch_nt<128, 64, 2, 1, MODE, 2>(p, st);
-    return launch_nt<64, 64, 1, 1, MODE, 2>(p, st);
 }
 
 static int ilog2(int v) {
@@ -449,7 +500,7 @@ static int ilog2(int v) {
 
 extern "C" size_t wesup_gemm_nt_workspace_bytes(int M, int N, int K) {
     if (M <= 0 || N <= 0 || K <= 0 || (K % BK)) return 0;
-    return plan_streamk(M, N, K).ws_bytes;
+    return choose_nt(M, N, K, true).sk.ws_bytes;
 }
 
 extern "C" int wesup_gemm_nt(const float* A, int lda, const float* B, int ldb, const float* bias, float* C,
@@ -504,7 +555,7 @@ static int conv_common(const float* x, const float* w, const float* bias, float*
 // channel counts swapped (the input of that GEMM is dy)
 extern "C" size_t wesup_conv3x3_workspace_bytes(int B, int H, int W, int Cin, int Cout) {
     if (B <= 0 || H <= 0 || W <= 0 || Cin < 32 || Cout <= 0) return 0;
-    return plan_streamk(B * H * W, Cout, 9 * Cin).ws_bytes;
+    return choose_nt(B * H * W, Cout, 9 * Cin, true).sk.ws_bytes;
 }
 
 extern "C" int wesup_conv3x3_fwd(const float* x, const float* w_fwd, const float* bias, float* y, int B, int H,
@@ -525,8 +576,9 @@ extern "C" int wesup_conv3x3_dgrad(const float* dy, const float* w_dgrad, const 
 // TN kernel (weight gradients):  C[M][N] = sum_k A[k][M] * B[k][N], k = pixel / row index.
 // MODE 0: plain matrices.  MODE 1: conv3x3 wgrad, grid.x also enumerates the 9 taps; B row k is the
 // input pixel shifted by the tap.  MODE 2: conv3x3 wgrad for the 4-channel image: N = 9 taps x 4.
-// Both operands are m-contiguous in memory ([pixel][channel]), so the LDS image is k-major [32 k][BM] and an MFMA
-// fragment is one conflict-free ds_read_b32 (lane l reads T[2*kp + (l>>5)][m0 + (l&31)]).  Rows are unpadded:
+// Both operands are m-contiguous in memory ([pixel][channel]), so the LDS image is k-major [32 k][BM] and the MFMA
+// fragments of a lane for the WM sub-tiles of its wave are one conflict-free ds_read of 4*WM bytes (lane l reads
+// T[2*kp + (l>>5)][m0 + WM*(l&31) ...]: the sub-tiles interleave the rows of the wave tile).  Rows are unpadded:
 // a wave-instruction of the LDS-DMA fills 1 KiB = 256 consecutive floats of the image.
 // Split-K over grid.y; every split writes its own slab (deterministic), reduced by a second kernel.
 // Bias gradients ride along: out[m] = sum_k A[k][m] is accumulated from the staged A tile by the blocks of the first
@@ -656,33 +708,46 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnParams p) {
 #pragma unroll
             for (int kr = 0; kr < BK; ++kr) csum += col[kr * BM];
         }
-        const float* as = As + cur * BK * BM + lhi * BM + wm0 + l31;
-        const float* bs = Bs + cur * BK * BN + lhi * BN + wn0 + l31;
-        // fragment double buffering: the reads of k-pair kp+1 are in flight while the MFMAs of kp issue
-        float a[2][WM], b[2][WN];
-        auto load_frag = [&](int kp, int sl) {
+        // Fragment mapping: MFMA sub-tile i of the wave takes rows wm0 + WM*a + i (a = A-lane), so the WM operands of a
+        // lane are adjacent in the k-major image and come with ONE ds_read of 4*WM bytes (ds_read_b64 for the 64x64
+        // wave tile: twice the LDS rate of ds_read_b32 and half the instructions); same for the columns.
+        const float* as = As + cur * BK * BM + lhi * BM + wm0 + WM * l31;
+        const float* bs = Bs + cur * BK * BN + lhi * BN + wn0 + WN * l31;
+        // fragment double buffering in groups of two k-pairs: the reads of group g+1 are in flight while the 2*WM*WN
+        // MFMAs of group g issue
+        constexpr int GK = 2, NG = BK / 2 / GK;
+        typedef float fragA __attribute__((ext_vector_type(WM)));
+        typedef float fragB __attribute__((ext_vector_type(WN)));
+        fragA a[2][GK];
+        fragB b[2][GK];
+        auto load_group = [&](int g, int sl) {
 #pragma unroll
-            for (int i = 0; i < WM; ++i) a[sl][i] = as[2 * kp * BM + 32 * i];
-#pragma unroll
-            for (int j = 0; j < WN; ++j) b[sl][j] = bs[2 * kp * BN + 32 * j];
-        };
-        load_frag(0, 0);
-#pragma unroll
-        for (int kp = 0; kp < BK / 2; ++kp) {
-            const int sl = kp & 1;
-            if (kp + 1 < BK / 2) load_frag(kp + 1, sl ^ 1);
-            if (relu_b) {
-#pragma unroll
-                for (int j = 0; j < WN; ++j) b[sl][j] = fmaxf(b[sl][j], 0.f);
+            for (int u = 0; u < GK; ++u) {
+                a[sl][u] = *reinterpret_cast<const fragA*>(as + 2 * (GK * g + u) * BM);
+                b[sl][u] = *reinterpret_cast<const fragB*>(bs + 2 * (GK * g + u) * BN);
             }
+        };
+        load_group(0, 0);
 #pragma unroll
-            for (int i = 0; i < WM; ++i)
+        for (int g = 0; g < NG; ++g) {
+            const int sl = g & 1;
+            if (g + 1 < NG) load_group(g + 1, sl ^ 1);
 #pragma unroll
-                for (int j = 0; j < WN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[sl][i], b[sl][j], acc[i][j], 0, 0, 0);
-            // one slice of the pointer arithmetic per MFMA group, fenced so that it stays in this group's shadow
-            if (kp < NB) pb[kp] = src_b(k2, kp);
-            else if (kp < NB + NA) pa[kp - NB] = src_a(k2, kp - NB);
+            for (int u = 0; u < GK; ++u) {
+#pragma unroll
+                for (int i = 0; i < WM; ++i)
+#pragma unroll
+                    for (int j = 0; j < WN; ++j) {
+                        const float av = a[sl][u][i];
+                        float bv = b[sl][u][j];
+                        if (relu_b) bv = fmaxf(bv, 0.f);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][j], 0, 0, 0);
+                    }
+                // one slice of the pointer arithmetic per k-pair, fenced so that it stays in this group's shadow
+                const int kp = GK * g + u;
+                if (kp < NB) pb[kp] = src_b(k2, kp);
+                else if (kp < NB + NA) pa[kp - NB] = src_a(k2, kp - NB);
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
         glds_wait();
@@ -693,16 +758,23 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnParams p) {
     float* slab = p.slab + (long)blockIdx.z * p.batch_slab + (long)blockIdx.y * p.slab_stride;
     if (do_cs && m_blk + tid < p.M) slab[(long)p.M * p.Nslab + m_blk + tid] = csum;
     const int ncol0 = (MODE == 1) ? tap * p.N : 0;
-#pragma unroll
-    for (int j = 0; j < WN; ++j) {
-        const int n = n_blk + wn0 + 32 * j + l31;
-        if (n >= p.N) continue;
+    // accumulator register r of sub-tile (i, j): row wm0 + WM*q + i with q = (r&3) + 8*(r>>2) + 4*lhi, column
+    // wn0 + WN*l31 + j -- the WN columns of a lane are adjacent: one 4*WN-byte store
+    const int n0 = n_blk + wn0 + WN * l31;
+    if (n0 < p.N) {                      // N % 4 == 0 and WN | 4: n0 < N implies the whole piece is inside
 #pragma unroll
         for (int i = 0; i < WM; ++i) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int m = m_blk + wm0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-                if (m < p.M) slab[(long)m * p.Nslab + ncol0 + n] = acc[i][j][r];
+                const int m = m_blk + wm0 + WM * ((r & 3) + 8 * (r >> 2) + 4 * lhi) + i;
+                if (m >= p.M) continue;
+                float* d = slab + (long)m * p.Nslab + ncol0 + n0;
+                if constexpr (WN == 2) {
+                    *reinterpret_cast<float2*>(d) = make_float2(acc[i][0][r], acc[i][1][r]);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < WN; ++j) d[j] = acc[i][j][r];
+                }
             }
         }
     }
