@@ -21,6 +21,22 @@ __device__ __forceinline__ void glds16(const float* src, unsigned lds_byte_addr_
                  : "v"(src), "s"(lds_byte_addr_uniform)
                  : "memory");
 }
+// buffer form of the LDS-DMA (VAR bit 11): SRD in SGPRs, one 32-bit offset VGPR per lane, the K-step offset in an SGPR:
+// no vector address arithmetic per instruction
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void bglds16(unsigned voff, i32x4 srd, unsigned soff, unsigned lds_byte_addr_uniform) {
+    asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds"
+                 ::"v"(voff), "s"(srd), "s"(soff), "s"(lds_byte_addr_uniform) : "memory");
+}
+__device__ __forceinline__ i32x4 make_srd(const void* base, unsigned bytes) {
+    const unsigned long a = (unsigned long)base;
+    i32x4 r;
+    r[0] = __builtin_amdgcn_readfirstlane((int)(a & 0xffffffffu));
+    r[1] = __builtin_amdgcn_readfirstlane((int)((a >> 32) & 0xffffu));
+    r[2] = __builtin_amdgcn_readfirstlane((int)bytes);
+    r[3] = 0x00020000;
+    return r;
+}
 // timing experiments on the M0 handling (results wrong): no M0 write at all / write without save+restore
 __device__ __forceinline__ void glds16_nom0(const float* src) {
     asm volatile("global_load_lds_dwordx4 %0, off" ::"v"(src) : "memory");
@@ -86,7 +102,25 @@ __global__ __launch_bounds__(NW * 64, MINB) void lab_kernel(const float* __restr
 
     // DMAs [lo, hi) of the staging of K-step kk (A passes first, then B passes)
     f32x4 stg[(VAR & 512) ? NDMA : 1];
+    unsigned a_voff[RA], b_voff[RB];
+#pragma unroll
+    for (int i = 0; i < RA; ++i) a_voff[i] = (unsigned)(((long)(m_blk + srow + PR * i) * K + 4 * schunk) * 4);
+#pragma unroll
+    for (int j = 0; j < RB; ++j) b_voff[j] = (unsigned)(((long)(n_blk + srow + PR * j) * K + 4 * schunk) * 4);
+    const i32x4 srdA = make_srd(A, 0xffffffffu), srdB = make_srd(B, 0xffffffffu);
     auto stage_range = [&](int kk, int buf, int lo, int hi) {
+        if (VAR & 2048) {
+            const unsigned adst = __builtin_amdgcn_readfirstlane(lds_addr(smem + buf * STAGE_FLOATS + wave * 256));
+            const unsigned bdst = __builtin_amdgcn_readfirstlane(lds_addr(smem + buf * STAGE_FLOATS + BM * BK + wave * 256));
+            const unsigned soff = (unsigned)kk * BK * 4;
+#pragma unroll
+            for (int i = 0; i < RA; ++i)
+                if (i >= lo && i < hi) bglds16(a_voff[i], srdA, soff, adst + i * PR * BK * 4);
+#pragma unroll
+            for (int j = 0; j < RB; ++j)
+                if (RA + j >= lo && RA + j < hi) bglds16(b_voff[j], srdB, soff, bdst + j * PR * BK * 4);
+            return;
+        }
         if (VAR & 512) {
 #pragma unroll
             for (int i = 0; i < RA; ++i)
@@ -115,7 +149,7 @@ __global__ __launch_bounds__(NW * 64, MINB) void lab_kernel(const float* __restr
     };
 
     auto stage = [&](int kk, int buf) {
-        if (VAR & (128 | 256 | 512)) { stage_range(kk, buf, 0, NDMA); return; }
+        if (VAR & (128 | 256 | 512 | 2048)) { stage_range(kk, buf, 0, NDMA); return; }
         const unsigned adst = __builtin_amdgcn_readfirstlane(lds_addr(smem + buf * STAGE_FLOATS + wave * 256));
         const unsigned bdst = __builtin_amdgcn_readfirstlane(lds_addr(smem + buf * STAGE_FLOATS + BM * BK + wave * 256));
 #pragma unroll
@@ -325,13 +359,16 @@ int main(int argc, char** argv) {
     (void)hipMemcpy(dA, hA.data(), hA.size() * 4, hipMemcpyHostToDevice);
     (void)hipMemcpy(dB, hB.data(), hB.size() * 4, hipMemcpyHostToDevice);
     const int N = 256;
-    for (int M : {57600, 131072}) {
+    for (int M : {131072}) {
         //   NW WAVES_M WM WN STAGES MINB VAR
         run<4, 2, 2, 2, 2, 2, 0>("base 4w 2blk/CU", M, N, K);
-        run<8, 4, 2, 2, 2, 1, 0>("8w 256x128 1blk/CU", M, N, K);
-        run<8, 2, 2, 4, 2, 1, 0>("8w 128x256 (64x128/wave)", M, N, K);
+        run<4, 2, 2, 2, 2, 2, 2048>("base, buffer DMA", M, N, K);
         run<8, 2, 4, 2, 2, 1, 0>("8w 256x256 (128x64/wave)", M, N, K);
+        run<8, 2, 4, 2, 2, 1, 2048>("8w 256x256, buffer DMA", M, N, K);
+        run<4, 2, 4, 4, 2, 1, 0>("4w 256x256 (128x128/wave)", M, N, K);
+        run<4, 2, 4, 4, 2, 1, 2048>("4w 256x256, buffer DMA", M, N, K);
         run<4, 2, 4, 4, 2, 1, 64>("4w 256x256 spread", M, N, K);
+        run<4, 2, 4, 4, 2, 1, 2048 + 64>("4w 256x256 spread, buffer DMA", M, N, K);
         printf("\n");
     }
     return 0;

@@ -13,7 +13,9 @@
 //   * the LDS destination of a wave-instruction is linear (base + lane*16), so tiles are unpadded; bank conflicts
 //     of the NT kernel's ds_read_b128 fragment reads are removed by XOR-swizzling the 16-B chunk index with
 //     (row>>1)&7 -- on the per-lane SOURCE address when staging and on the read address (same involution);
-//   * a lane whose element is outside the image / matrix reads from a zeroed page instead (implicit zero padding);
+//   * a lane whose element is outside the image / matrix is given an out-of-range buffer offset and the DMA writes
+//     zeros for it (implicit zero padding; the 64-bit global form of the image layer and of the TN kernel reads a
+//     zeroed page instead);
 //   * ReLU of the previous layer is applied to the fragments after the ds_read.
 #include "common.hpp"
 #include <cstdlib>
@@ -39,6 +41,30 @@ __device__ __forceinline__ void glds16(const float* src, unsigned lds_byte_addr_
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep)
                  : "v"(src), "s"(lds_byte_addr_uniform)
+                 : "memory");
+}
+// Buffer form of the same DMA (buffer_load_dwordx4 ... lds): the base lives in a scalar resource descriptor, the lane
+// supplies one 32-bit byte offset and the K-step adds a scalar offset, so a staging instruction needs no vector
+// address arithmetic at all (the 64-bit global form needed an add-with-carry and two selects per instruction), and
+// a lane whose offset is >= num_records gets ZEROS written to LDS -- implicit zero padding without a zero page
+// (tools/bufdma_probe.hip: out-of-range lanes store 0, the scalar offset takes part in the range check).
+// tools/gemm_lab.hip: +2.4 % on the 128x128 two-blocks-per-CU loop.
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+#define WESUP_OOB 0x80000000u            // per-lane offset of a masked lane; every descriptor has num_records <= 2 GiB
+__device__ __forceinline__ i32x4 make_srd(const float* base, unsigned num_records = WESUP_OOB) {
+    const unsigned long a = (unsigned long)base;
+    i32x4 r;
+    r[0] = __builtin_amdgcn_readfirstlane((int)(a & 0xffffffffu));
+    r[1] = __builtin_amdgcn_readfirstlane((int)((a >> 32) & 0xffffu));      // stride 0: raw buffer
+    r[2] = __builtin_amdgcn_readfirstlane((int)num_records);
+    r[3] = 0x00020000;
+    return r;
+}
+__device__ __forceinline__ void bglds16(unsigned voff, i32x4 srd, unsigned soff_uniform, unsigned lds_byte_addr_uniform) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(srd), "s"(soff_uniform), "s"(lds_byte_addr_uniform)
                  : "memory");
 }
 __device__ __forceinline__ void glds_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
@@ -130,14 +156,20 @@ __global__ __launch_bounds__(NW * 64, MINB) void gemm_nt_kernel(const NtParams p
     const int tile_n = lt % p.tiles_n, tile_m = lt / p.tiles_n;
     const int m_blk = tile_m * BM, n_blk = tile_n * BN;
 
+    // Staging addresses.  MODE 0/1 use the buffer form: descriptor base = first row of the tile (MODE 1: moved down by
+    // one image row + one pixel so that the shifted taps have non-negative scalar offsets), per-lane byte offset inside
+    // the tile, masked lanes at WESUP_OOB.  MODE 2 (image layer, per-lane taps) keeps the 64-bit global form.
     long a_off[RA];
-    unsigned a_msk[RA];
+    unsigned a_msk[RA], a_vo[RA], b_vo[RB];
+    const int margin = (MODE == 1) ? (p.W + 1) * p.Cin : 0;
+    const float* a_base = (MODE == 0) ? p.A + (long)m_blk * p.lda : p.A + ((long)m_blk * p.Cin - margin);
+    const i32x4 srdA = make_srd(a_base), srdB = make_srd(p.Bw + (long)n_blk * p.ldb);
 #pragma unroll
     for (int i = 0; i < RA; ++i) {
         const int m = m_blk + srow + PR * i;
         if (MODE == 0) {
-            a_off[i] = (long)m * p.lda + 4 * schunk;
-            a_msk[i] = (m < p.M) ? 1u : 0u;
+            a_vo[i] = (m < p.M) ? (unsigned)(((srow + PR * i) * p.lda + 4 * schunk) * 4) : WESUP_OOB;
+            a_msk[i] = 0; a_off[i] = 0;
         } else {
             const int hw = p.H * p.W;
             const int b = m / hw;
@@ -152,16 +184,14 @@ __global__ __launch_bounds__(NW * 64, MINB) void gemm_nt_kernel(const NtParams p
                 }
             }
             a_msk[i] = msk;
-            a_off[i] = (long)m * p.Cin + (MODE == 1 ? 4 * schunk : 0);
+            a_off[i] = (long)m * p.Cin;
+            a_vo[i] = (unsigned)(((srow + PR * i) * p.Cin + 4 * schunk) * 4);
         }
     }
-    long b_off[RB];
-    bool b_ok[RB];
 #pragma unroll
     for (int j = 0; j < RB; ++j) {
         const int n = n_blk + srow + PR * j;
-        b_ok[j] = n < p.N;
-        b_off[j] = (long)n * p.ldb + 4 * schunk;
+        b_vo[j] = (n < p.N) ? (unsigned)(((srow + PR * j) * p.ldb + 4 * schunk) * 4) : WESUP_OOB;
     }
 
     // Staging of tile kk into buffer buf; part q issues the q-th PR-row pass of A and of B (kept separable so that
@@ -175,16 +205,15 @@ __global__ __launch_bounds__(NW * 64, MINB) void gemm_nt_kernel(const NtParams p
         for (int i = 0; i < RA; ++i) {
             if (i != q) continue;
             if (MODE == 0) {
-                glds16(a_msk[i] ? p.A + a_off[i] + kk * BK : zero, adst);
+                bglds16(a_vo[i], srdA, (unsigned)(kk * BK * 4), adst);
             } else if (MODE == 1) {
                 // K order = (32-channel chunk, tap, channel in chunk): the 9 taps of one chunk are consecutive K-steps,
                 // so the shifted re-reads of the same 128 B per pixel hit L2 (with the tap outermost every tap streamed
                 // the whole activation tensor again: FETCH_SIZE 9x the tensor)
                 const int chunk = kk / 9;
                 const int tap = kk - 9 * chunk;
-                const int ci0 = chunk * BK;
-                const int toff = ((tap / 3 - 1) * p.W + (tap % 3 - 1)) * p.Cin + ci0;
-                glds16(((a_msk[i] >> tap) & 1u) ? p.A + a_off[i] + toff : zero, adst);
+                const int toff = ((tap / 3 - 1) * p.W + (tap % 3 - 1)) * p.Cin + chunk * BK + margin;   // >= 0
+                bglds16(((a_msk[i] >> tap) & 1u) ? a_vo[i] : WESUP_OOB, srdA, (unsigned)(toff * 4), adst);
             } else {
                 const int tap = kk * 8 + schunk;                     // logical chunk = tap (4 channels each)
                 const int toff = ((tap / 3 - 1) * p.W + (tap % 3 - 1)) * 4;
@@ -194,7 +223,7 @@ __global__ __launch_bounds__(NW * 64, MINB) void gemm_nt_kernel(const NtParams p
 #pragma unroll
         for (int j = 0; j < RB; ++j) {
             if (j != q) continue;
-            glds16(b_ok[j] ? p.Bw + b_off[j] + kk * BK : zero, bdst);
+            bglds16(b_vo[j], srdB, (unsigned)(kk * BK * 4), bdst);
         }
     };
     auto stage = [&](int kk, int buf) {
@@ -622,7 +651,6 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnParams p) {
     const float* Ab = p.A + (long)blockIdx.z * p.batchA;
     const float* Bb = p.Bx + (long)blockIdx.z * p.batchB;
     const int k_end = min(p.K, k_begin + p.k_per_split);
-    const float* zero = reinterpret_cast<const float*>(g_zero_page);
 
     const int qa = tid % QA, ra_row = tid / QA;
     const int qb = tid % QB, rb_row = tid / QB;
@@ -632,49 +660,54 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnParams p) {
     // MODE 2: column quad qb is tap qb (4 channels each), only 9 of the 16 quads are real
     const int dh2 = qb / 3 - 1, dw2 = qb % 3 - 1;
 
-    // Staging is split in two: src_of() turns a K-step into the per-lane source pointers (integer VALU work only:
-    // pixel -> (b, h, w), border tests, address), issue() fires the LDS-DMA with pointers computed one K-step earlier.
-    // The pointer arithmetic for step kk+2 sits in the same basic block as the MFMAs of step kk, branch-free, so the
-    // scheduler can sink it into the MFMA shadow instead of leaving ~250 VALU instructions in front of every K-step
-    // during which this wave issues no matrix instruction.
-    auto src_a = [&](int k0, int i) -> const float* {
-        const int k = k0 + ra_row + RPA * i;
-        const bool ok = a_col_ok & (k < k_end);
-        return ok ? Ab + (long)k * p.lda + m_blk + 4 * qa : zero;
-    };
-    auto src_b = [&](int k0, int i) -> const float* {
+    // Staging by the buffer form of the LDS-DMA.  Descriptor bases are the first row of this block's K range (B: shifted
+    // by the tap), the per-lane offsets inside that range never change, a K-step adds a scalar offset.  The A operand
+    // and the plain B operand need no per-step vector work at all: rows >= k_end fall behind num_records and columns
+    // outside the matrix carry WESUP_OOB, and the DMA writes zeros for both.  The shifted B rows of the convolution
+    // modes need the border test of their pixel: mask_b() turns a K-step into the per-lane offset-or-OOB (integer VALU
+    // work only: pixel -> (b, h, w), border tests), computed one K-step ahead in slices between the MFMA groups so that
+    // it stays in their shadow; issue() fires the DMA.
+    const int rows = k_end - k_begin;
+    unsigned a_vo[NA], b_vo[NB];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) a_vo[i] = a_col_ok ? (unsigned)(((ra_row + RPA * i) * p.lda + 4 * qa) * 4) : WESUP_OOB;
+    const i32x4 srdA = make_srd(Ab + (long)k_begin * p.lda + m_blk, (unsigned)rows * (unsigned)p.lda * 4u);
+    const float* b_base;
+    unsigned b_nr = WESUP_OOB;
+    if (MODE == 0) {
+        b_base = Bb + (long)k_begin * p.ldb + n_blk;
+        b_nr = (unsigned)rows * (unsigned)p.ldb * 4u;
+    } else if (MODE == 1) {
+        b_base = Bb + ((long)k_begin + dh * p.W + dw) * p.ldb + n_blk;
+    } else {
+        b_base = Bb + ((long)k_begin - (p.W + 1)) * 4;          // per-lane tap shifts are >= -(W+1) pixels
+    }
+    const i32x4 srdB = make_srd(b_base, b_nr);
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        if (MODE == 2) b_vo[i] = (unsigned)((rb_row + RPB * i + dh2 * p.W + dw2 + p.W + 1) * 16);
+        else b_vo[i] = b_col_ok ? (unsigned)(((rb_row + RPB * i) * p.ldb + 4 * qb) * 4) : WESUP_OOB;
+    }
+    auto mask_b = [&](int k0, int i) -> unsigned {
+        if (MODE == 0) return b_vo[i];
         const int k = k0 + rb_row + RPB * i;
-        if (MODE == 0) {
-            const bool ok = b_col_ok & (k < k_end);
-            return ok ? Bb + (long)k * p.ldb + n_blk + 4 * qb : zero;
-        }
         const int t = fast_div(k, p.dW);       // b*H + h
         const int w = k - t * p.W;
         const int bb = fast_div(t, p.dH);
         const int h = t - bb * p.H;
-        if (MODE == 1) {
-            const int hh = h + dh, ww = w + dw;
-            const bool ok = b_col_ok & (k < k_end) & (hh >= 0) & (hh < p.H) & (ww >= 0) & (ww < p.W);
-            return ok ? Bb + (long)(k + dh * p.W + dw) * p.ldb + n_blk + 4 * qb : zero;
-        }
-        const int hh = h + dh2, ww = w + dw2;
-        const bool ok = (qb < 9) & (k < k_end) & (hh >= 0) & (hh < p.H) & (ww >= 0) & (ww < p.W);
-        return ok ? Bb + (long)(k + dh2 * p.W + dw2) * 4 : zero;
+        const int hh = h + (MODE == 1 ? dh : dh2), ww = w + (MODE == 1 ? dw : dw2);
+        const bool ok = (MODE == 1 ? b_col_ok : (qb < 9)) & (k < k_end) & (hh >= 0) & (hh < p.H) & (ww >= 0) & (ww < p.W);
+        return ok ? b_vo[i] : WESUP_OOB;
     };
-    auto src_of = [&](int k0, const float* (&pa)[NA], const float* (&pb)[NB]) {
-#pragma unroll
-        for (int i = 0; i < NA; ++i) pa[i] = src_a(k0, i);
-#pragma unroll
-        for (int i = 0; i < NB; ++i) pb[i] = src_b(k0, i);
-    };
-    auto issue = [&](const float* (&pa)[NA], const float* (&pb)[NB], int buf) {
+    const unsigned step_a = (unsigned)(BK * p.lda * 4), step_b = (unsigned)(BK * (MODE == 2 ? 4 : p.ldb) * 4);
+    auto issue = [&](int step, const unsigned (&vb)[NB], int buf) {
         // the image is linear in tid (4*tid floats per pass): wave-uniform LDS byte addresses
         const unsigned adst = __builtin_amdgcn_readfirstlane(lds_addr(As + buf * BK * BM + wave * 256));
         const unsigned bdst = __builtin_amdgcn_readfirstlane(lds_addr(Bs + buf * BK * BN + wave * 256));
 #pragma unroll
-        for (int i = 0; i < NA; ++i) glds16(pa[i], adst + i * 4096);
+        for (int i = 0; i < NA; ++i) bglds16(a_vo[i], srdA, (unsigned)step * step_a, adst + i * 4096);
 #pragma unroll
-        for (int i = 0; i < NB; ++i) glds16(pb[i], bdst + i * 4096);
+        for (int i = 0; i < NB; ++i) bglds16(vb[i], srdB, (unsigned)step * step_b, bdst + i * 4096);
     };
 
     f32x16 acc[WM][WN];
@@ -692,17 +725,18 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnParams p) {
 
     const bool do_cs = p.want_colsum && tile_n == 0 && tap == 0 && tid < BM;     // wave-uniform (BM % 64 == 0)
     float csum = 0.f;
-    const float* pa[NA];
-    const float* pb[NB];
-    src_of(k_begin, pa, pb);
-    if (nk > 0) issue(pa, pb, 0);
-    src_of(k_begin + BK, pa, pb);                  // pointers of K-step 1 (all-zero-page beyond k_end)
+    unsigned vb[NB];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) vb[i] = mask_b(k_begin, i);
+    if (nk > 0) issue(0, vb, 0);
+#pragma unroll
+    for (int i = 0; i < NB; ++i) vb[i] = mask_b(k_begin + BK, i);      // offsets of K-step 1 (all out of range beyond k_end)
     glds_wait();
     __syncthreads();
     int cur = 0;
     for (int kk = 0; kk < nk; ++kk) {
-        issue(pa, pb, cur ^ 1);                    // unconditional (past k_end every lane reads the zero page)
-        const int k2 = k_begin + (kk + 2) * BK;    // its pointers are consumed by the next iteration's issue()
+        issue(kk + 1, vb, cur ^ 1);                // unconditional (past k_end every lane is out of range: zeros)
+        const int k2 = k_begin + (kk + 2) * BK;    // its offsets are consumed by the next iteration's issue()
         if (do_cs) {
             const float* col = As + cur * BK * BM + tid;
 #pragma unroll
@@ -743,10 +777,9 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnParams p) {
                         if (relu_b) bv = fmaxf(bv, 0.f);
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][j], 0, 0, 0);
                     }
-                // one slice of the pointer arithmetic per k-pair, fenced so that it stays in this group's shadow
+                // one slice of the border arithmetic per k-pair, fenced so that it stays in this group's shadow
                 const int kp = GK * g + u;
-                if (kp < NB) pb[kp] = src_b(k2, kp);
-                else if (kp < NB + NA) pa[kp - NB] = src_a(k2, kp - NB);
+                if (MODE != 0 && kp < NB) vb[kp] = mask_b(k2, kp);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -891,6 +924,9 @@ template <int MODE>
 static int launch_tn(TnParams p, const TnPlan& pl, hipStream_t st, int nbatch = 1) {
     p.tiles_m = pl.tiles_m; p.tiles_n = pl.tiles_n; p.taps = pl.taps; p.k_per_split = pl.k_per_split;
     p.Nslab = pl.Nslab;
+    // buffer-form staging: the byte offsets inside one split's K range must stay below the 2 GiB out-of-range marker
+    const long ldmax = p.lda > p.ldb ? p.lda : p.ldb;
+    if (((long)pl.k_per_split + 2 * BK) * ldmax * 4 + (1l << 22) >= (1l << 31)) return WESUP_ERR_INVALID;
     dim3 grid(pl.tiles_m * pl.tiles_n * pl.taps, pl.S, nbatch);
     if (pl.bm == 128) {
         const size_t lds = (size_t)2 * BK * (128 + 128) * sizeof(float);
