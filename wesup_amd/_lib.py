@@ -10,7 +10,8 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, 'csrc')
-LIB_PATH = os.path.join(CSRC, 'libwesup_hip.so')
+# WESUP_HIP_LIB: another build of the same library (A/B measurements of kernel variants in one GPU session)
+LIB_PATH = os.environ.get('WESUP_HIP_LIB') or os.path.join(CSRC, 'libwesup_hip.so')
 
 c_void_p = ctypes.c_void_p
 c_int = ctypes.c_int

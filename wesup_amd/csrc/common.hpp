@@ -43,6 +43,10 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+// max(x, lo) as ONE v_med3_f32 (fmaxf() goes through llvm.maxnum, which first canonicalises a possibly-signalling
+// input with a second v_max; an asm v_max would be outside the compiler's s_waitcnt bookkeeping and read a fragment
+// before its ds_read has landed): ReLU-on-load in the GEMM loops, lo = 0 or -inf
+__device__ __forceinline__ float vmax1(float x, float lo) { return __builtin_amdgcn_fmed3f(x, lo, __builtin_inff()); }
 __device__ __forceinline__ float4 relu4(float4 v) {
     return make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
 }

@@ -97,7 +97,7 @@ struct NtParams {
 // A lane's fragments for 4 consecutive MFMA k-steps are ONE ds_read_b128; MFMA t of a group uses element t of the
 // A and the B fragment: lanes 0-31 then carry k = 8g+t, lanes 32-63 k = 8g+4+t (any consistent k order is fine).
 // ---------------------------------------------------------------------------------------------
-template <int NW, int BM, int BN, int WM, int WN, int MODE, int MINB>
+template <int NW, int BM, int BN, int WM, int WN, int MODE, int MINB, bool RELU>
 __global__ __launch_bounds__(NW * 64, MINB) void gemm_nt_kernel(const NtParams p) {
     constexpr int NT = NW * 64;                        // threads per block
     constexpr int PR = NW * 8;                         // rows per staging pass (8 threads fetch one 128-B row)
@@ -116,7 +116,6 @@ __global__ __launch_bounds__(NW * 64, MINB) void gemm_nt_kernel(const NtParams p
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const unsigned long long tr0 = __builtin_amdgcn_s_memrealtime();
-    const bool relu_in = p.flags & WESUP_RELU_IN;
     const float* zero = reinterpret_cast<const float*>(g_zero_page);
     // ---- staging role of this lane: row (tid>>3) of each PR-row pass, chunk position tid&7; the logical chunk it
     // fetches is position ^ swizzle(row) (the swizzle does not depend on the pass: PR*i >> 1 == 0 mod 8)
@@ -267,9 +266,18 @@ __global__ __launch_bounds__(NW * 64, MINB) void gemm_nt_kernel(const NtParams p
         for (int g = 0; g < BK / 8; ++g) {
             const int sl = g & 1;
             if (g + 1 < BK / 8) load_frag(g + 1, sl ^ 1);
-            if (relu_in) {
+            // ReLU-on-load, a compile-time variant of the kernel (applied unconditionally as max(x, -inf) it cost the
+            // layers that do not need it 5 %)
+            if constexpr (RELU) {
+                // kept together in front of the group's MFMAs (fenced): spread between the MFMAs by the scheduler the
+                // same 8 instructions cost 1 % of the kernel
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int i = 0; i < WM; ++i) fa[sl][i] = relu4(fa[sl][i]);
+                for (int i = 0; i < WM; ++i) {
+                    fa[sl][i].x = vmax1(fa[sl][i].x, 0.f); fa[sl][i].y = vmax1(fa[sl][i].y, 0.f);
+                    fa[sl][i].z = vmax1(fa[sl][i].z, 0.f); fa[sl][i].w = vmax1(fa[sl][i].w, 0.f);
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
             // element t of the fragments = k-step t of the group; consecutive MFMAs go to different accumulators
 #pragma unroll
@@ -481,7 +489,7 @@ static NtChoice choose_nt(int M, int N, int K, bool with_ws) {
     return c;
 }
 
-template <int NW, int BM, int BN, int WM, int WN, int MODE, int MINB>
+template <int NW, int BM, int BN, int WM, int WN, int MODE, int MINB, bool RELU>
 static int launch_nt(NtParams p, hipStream_t st, const SkPlan* sk = nullptr, void* ws = nullptr) {
     p.tiles_m = ceil_div(p.M, BM);
     p.tiles_n = ceil_div(p.N, BN);
@@ -491,7 +499,7 @@ static int launch_nt(NtParams p, hipStream_t st, const SkPlan* sk = nullptr, voi
         p.full_tiles = sk->full; p.sk_parts = sk->parts; p.sk_steps = sk->steps; p.sk_ws = (float*)ws;
     }
     const size_t lds = (size_t)2 * (BM + BN) * BK * sizeof(float);
-    auto kern = gemm_nt_kernel<NW, BM, BN, WM, WN, MODE, MINB>;
+    auto kern = gemm_nt_kernel<NW, BM, BN, WM, WN, MODE, MINB, RELU>;
     if (lds > 64 * 1024) {           // more than the default dynamic LDS limit: raise it once per instantiation
         static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -507,18 +515,23 @@ static int launch_nt(NtParams p, hipStream_t st, const SkPlan* sk = nullptr, voi
     return WESUP_OK;
 }
 
-template <int MODE>
-static int dispatch_nt(NtParams p, hipStream_t st, void* ws, size_t ws_bytes) {
+template <int MODE, bool RELU>
+static int dispatch_nt_r(NtParams p, hipStream_t st, void* ws, size_t ws_bytes) {
     const bool ws_ok = ws && !((uintptr_t)ws & 15);
     NtChoice c = choose_nt(p.M, p.N, p.K, ws_ok);
     if (c.sk.parts > 0 && ws_bytes < c.sk.ws_bytes) c = choose_nt(p.M, p.N, p.K, false);   // workspace too small: plain tiling
     const SkPlan* sk = c.sk.parts > 0 ? &c.sk : nullptr;
     switch (c.shape) {
-        case NT_BIG: return launch_nt<8, 256, 128, 2, 2, MODE, 1>(p, st, sk, ws);
-        case NT_STD: return launch_nt<4, 128, 128, 2, 2, MODE, 2>(p, st, sk, ws);
-        case NT_N64: return launch_nt<4, 128, 64, 2, 1, MODE, 2>(p, st);
-        default: return launch_nt<4, 64, 64, 1, 1, MODE, 2>(p, st);
+        case NT_BIG: return launch_nt<8, 256, 128, 2, 2, MODE, 1, RELU>(p, st, sk, ws);
+        case NT_STD: return launch_nt<4, 128, 128, 2, 2, MODE, 2, RELU>(p, st, sk, ws);
+        case NT_N64: return launch_nt<4, 128, 64, 2, 1, MODE, 2, RELU>(p, st);
+        default: return launch_nt<4, 64, 64, 1, 1, MODE, 2, RELU>(p, st);
     }
+}
+template <int MODE>
+static int dispatch_nt(NtParams p, hipStream_t st, void* ws, size_t ws_bytes) {
+    return (p.flags & WESUP_RELU_IN) ? dispatch_nt_r<MODE, true>(p, st, ws, ws_bytes)
+                                     : dispatch_nt_r<MODE, false>(p, st, ws, ws_bytes);
 }
 
 static int ilog2(int v) {
@@ -630,7 +643,7 @@ struct TnParams {
     int k_per_split;  // multiple of BK
 };
 
-template <int BM, int BN, int WM, int WN, int MODE>
+template <int BM, int BN, int WM, int WN, int MODE, bool RELU>
 __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnParams p) {
     constexpr int QA = BM / 4, RPA = 256 / QA, NA = BK / RPA;
     constexpr int QB = BN / 4, RPB = 256 / QB, NB = BK / RPB;
@@ -688,15 +701,35 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnParams p) {
         if (MODE == 2) b_vo[i] = (unsigned)((rb_row + RPB * i + dh2 * p.W + dw2 + p.W + 1) * 16);
         else b_vo[i] = b_col_ok ? (unsigned)(((rb_row + RPB * i) * p.ldb + 4 * qb) * 4) : WESUP_OOB;
     }
+    // The 32 pixels of a K-step are consecutive, so their image coordinates follow from those of the first one by a
+    // carry or two: the two divisions of "pixel -> (b, h, w)" are done ONCE per K-step on the scalar unit (k0 is
+    // wave-uniform) and each lane only adds its row, wraps w (twice when an image row is shorter than the 32-pixel
+    // step) and h, and compares -- ~10 vector instructions per staged row instead of ~25.
     auto mask_b = [&](int k0, int i) -> unsigned {
         if (MODE == 0) return b_vo[i];
-        const int k = k0 + rb_row + RPB * i;
-        const int t = fast_div(k, p.dW);       // b*H + h
-        const int w = k - t * p.W;
-        const int bb = fast_div(t, p.dH);
-        const int h = t - bb * p.H;
+        if (p.W < 16 || p.H < 2) {             // tiny images: more carries than the fast path handles; divide per lane
+            const int k = k0 + rb_row + RPB * i;
+            const int t = fast_div(k, p.dW);
+            const int w = k - t * p.W;
+            const int h = t - fast_div(t, p.dH) * p.H;
+            const int hh = h + (MODE == 1 ? dh : dh2), ww = w + (MODE == 1 ? dw : dw2);
+            const bool ok = (MODE == 1 ? b_col_ok : (qb < 9)) & (k < k_end) & (hh >= 0) & (hh < p.H) & (ww >= 0) & (ww < p.W);
+            return ok ? b_vo[i] : WESUP_OOB;
+        }
+        const int k0u = __builtin_amdgcn_readfirstlane(k0);
+        const int t0 = fast_div(k0u, p.dW);    // b*H + h of the first pixel of the step (scalar)
+        const int w0 = k0u - t0 * p.W;
+        const int h0 = t0 - fast_div(t0, p.dH) * p.H;
+        const int r = rb_row + RPB * i;        // this lane's pixel inside the step, < 32
+        int w = w0 + r, h = h0;
+        const bool c1 = w >= p.W;
+        w = c1 ? w - p.W : w; h = c1 ? h + 1 : h;
+        const bool c2 = w >= p.W;              // only possible when W < 32 (W >= 16 here: two carries suffice)
+        w = c2 ? w - p.W : w; h = c2 ? h + 1 : h;
+        h = h >= p.H ? h - p.H : h;            // next image (two carries cannot pass a whole image: H >= 2)
         const int hh = h + (MODE == 1 ? dh : dh2), ww = w + (MODE == 1 ? dw : dw2);
-        const bool ok = (MODE == 1 ? b_col_ok : (qb < 9)) & (k < k_end) & (hh >= 0) & (hh < p.H) & (ww >= 0) & (ww < p.W);
+        const bool ok = (MODE == 1 ? b_col_ok : (qb < 9)) & (k0 + r < k_end) & ((unsigned)hh < (unsigned)p.H) &
+                        ((unsigned)ww < (unsigned)p.W);
         return ok ? b_vo[i] : WESUP_OOB;
     };
     const unsigned step_a = (unsigned)(BK * p.lda * 4), step_b = (unsigned)(BK * (MODE == 2 ? 4 : p.ldb) * 4);
@@ -721,7 +754,6 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnParams p) {
     const int wm0 = (wave / WAVES_N) * 32 * WM, wn0 = (wave % WAVES_N) * 32 * WN;
     const int l31 = lane & 31, lhi = lane >> 5;
     const int nk = (k_end - k_begin + BK - 1) / BK;
-    const bool relu_b = p.relu_b;
 
     const bool do_cs = p.want_colsum && tile_n == 0 && tap == 0 && tid < BM;     // wave-uniform (BM % 64 == 0)
     float csum = 0.f;
@@ -768,15 +800,15 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnParams p) {
             if (g + 1 < NG) load_group(g + 1, sl ^ 1);
 #pragma unroll
             for (int u = 0; u < GK; ++u) {
+                if constexpr (RELU) {          // ReLU of the layer input
+#pragma unroll
+                    for (int j = 0; j < WN; ++j) b[sl][u][j] = vmax1(b[sl][u][j], 0.f);
+                }
 #pragma unroll
                 for (int i = 0; i < WM; ++i)
 #pragma unroll
-                    for (int j = 0; j < WN; ++j) {
-                        const float av = a[sl][u][i];
-                        float bv = b[sl][u][j];
-                        if (relu_b) bv = fmaxf(bv, 0.f);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][j], 0, 0, 0);
-                    }
+                    for (int j = 0; j < WN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[sl][u][i], b[sl][u][j], acc[i][j], 0, 0, 0);
                 // one slice of the border arithmetic per k-pair, fenced so that it stays in this group's shadow
                 const int kp = GK * g + u;
                 if (MODE != 0 && kp < NB) vb[kp] = mask_b(k2, kp);
@@ -930,10 +962,12 @@ static int launch_tn(TnParams p, const TnPlan& pl, hipStream_t st, int nbatch = 
     dim3 grid(pl.tiles_m * pl.tiles_n * pl.taps, pl.S, nbatch);
     if (pl.bm == 128) {
         const size_t lds = (size_t)2 * BK * (128 + 128) * sizeof(float);
-        hipLaunchKernelGGL((gemm_tn_kernel<128, 128, 2, 2, MODE>), grid, dim3(256), lds, st, p);
+        if (p.relu_b) hipLaunchKernelGGL((gemm_tn_kernel<128, 128, 2, 2, MODE, true>), grid, dim3(256), lds, st, p);
+        else hipLaunchKernelGGL((gemm_tn_kernel<128, 128, 2, 2, MODE, false>), grid, dim3(256), lds, st, p);
     } else {
         const size_t lds = (size_t)2 * BK * (64 + 64) * sizeof(float);
-        hipLaunchKernelGGL((gemm_tn_kernel<64, 64, 1, 1, MODE>), grid, dim3(256), lds, st, p);
+        if (p.relu_b) hipLaunchKernelGGL((gemm_tn_kernel<64, 64, 1, 1, MODE, true>), grid, dim3(256), lds, st, p);
+        else hipLaunchKernelGGL((gemm_tn_kernel<64, 64, 1, 1, MODE, false>), grid, dim3(256), lds, st, p);
     }
     WESUP_CHECK_LAUNCH();
     return WESUP_OK;
