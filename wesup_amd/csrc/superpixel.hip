@@ -419,6 +419,7 @@ __device__ __forceinline__ Lerp2 lerp2_of(int dst, float scale, int in) {
     r.l0 = 1.f - r.l1;
     return r;
 }
+#define SP_CELL_CAP 1024          // cells of a segment's box of the coarse grid kept in LDS (8 KiB per wave)
 template <int LPP>
 __global__ __launch_bounds__(256) void sp_pool_up_fwd_kernel(const float* __restrict__ s, const int32_t* __restrict__ pix_sorted,
                                                              const int32_t* __restrict__ row_start,
@@ -442,6 +443,62 @@ __global__ __launch_bounds__(256) void sp_pool_up_fwd_kernel(const float* __rest
     const float* base = s + (long)b * h * w * C + 4 * cl;
     const bool ident = (h == H && w == W);
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    // Coarse maps: "sample 4 cells per pixel, then average" is regrouped by CELL.  The segment's pixels touch only the
+    // cells of a small box of the coarse grid (a 400-pixel superpixel under a 120x120 map: ~8x8 cells), so the wave
+    // first sums the bilinear weights per cell of that box in LDS (2^-40 fixed point, 64-bit integer atomics: the sums
+    // do not depend on arrival order) and then fetches every touched cell ONCE: ~25x fewer cache reads than 4 loads per
+    // pixel.  A segment whose box does not fit (long thin diagonal shapes) takes the per-pixel loop below.
+    __shared__ unsigned long long cellbuf[4][SP_CELL_CAP];
+    bool by_cell = false;
+    if (!ident) {
+        unsigned long long* cell = cellbuf[threadIdx.x >> 6];
+        int y0 = 1 << 30, y1 = -1, x0 = 1 << 30, x1 = -1;
+        for (int j = j0 + lane; j < j1; j += 64) {
+            const int p = list[j];
+            const int Y = fast_div(p, dW), X = p - Y * W;
+            const Lerp2 ly = lerp2_of(Y, sh, h), lx = lerp2_of(X, sw, w);
+            y0 = min(y0, ly.i0); y1 = max(y1, ly.i1);
+            x0 = min(x0, lx.i0); x1 = max(x1, lx.i1);
+        }
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            y0 = min(y0, __shfl_xor(y0, off)); y1 = max(y1, __shfl_xor(y1, off));
+            x0 = min(x0, __shfl_xor(x0, off)); x1 = max(x1, __shfl_xor(x1, off));
+        }
+        const int bw = (y1 >= 0) ? x1 - x0 + 1 : 0, ncell = (y1 >= 0) ? bw * (y1 - y0 + 1) : 0;
+        by_cell = y1 >= 0 && ncell <= SP_CELL_CAP;          // wave-uniform
+        if (by_cell) {
+            for (int q = lane; q < ncell; q += 64) cell[q] = 0ull;
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            const float FX = 1099511627776.f;      // 2^40
+            for (int j = j0 + lane; j < j1; j += 64) {
+                const int p = list[j];
+                const int Y = fast_div(p, dW), X = p - Y * W;
+                const Lerp2 ly = lerp2_of(Y, sh, h), lx = lerp2_of(X, sw, w);
+                const int a0 = (ly.i0 - y0) * bw - x0, a1 = (ly.i1 - y0) * bw - x0;
+                atomicAdd(&cell[a0 + lx.i0], (unsigned long long)(ly.l0 * lx.l0 * FX + 0.5f));
+                atomicAdd(&cell[a0 + lx.i1], (unsigned long long)(ly.l0 * lx.l1 * FX + 0.5f));
+                atomicAdd(&cell[a1 + lx.i0], (unsigned long long)(ly.l1 * lx.l0 * FX + 0.5f));
+                atomicAdd(&cell[a1 + lx.i1], (unsigned long long)(ly.l1 * lx.l1 * FX + 0.5f));
+            }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            const float scale = inv * (1.f / FX);
+            for (int q = grp; q < ncell; q += PPW) {
+                const unsigned long long wq = cell[q];
+                if (wq == 0ull) continue;
+                const int cy = q / bw, cx = q - cy * bw;
+                const float wgt = (float)wq * scale;
+                const float4 v = ld4(base + ((long)(y0 + cy) * w + x0 + cx) * C);
+                acc.x = fmaf(v.x, wgt, acc.x);
+                acc.y = fmaf(v.y, wgt, acc.y);
+                acc.z = fmaf(v.z, wgt, acc.z);
+                acc.w = fmaf(v.w, wgt, acc.w);
+            }
+        }
+    }
+    if (!by_cell)
     for (int j = j0 + grp; j < j1; j += PPW) {
         const int p = list[j];
         float4 v;
