@@ -291,6 +291,69 @@ __global__ void upsample_bwd_kernel(const float* __restrict__ src, const int32_t
     if (FUSED) flush();
     st4(ds + idx * 4, acc);
 }
+// Fused backward on a coarse map, one WAVE per coarse cell.  Phase 1: the lanes share out the candidate window (one
+// full-resolution pixel each), compute its bilinear weight on this cell and look up its superpixel row.  The distinct
+// rows among them (2-4 under a 120x120 map) are then peeled off one at a time -- first pending lane's row, ballot of
+// the lanes that share it, fixed butterfly sum of their weights -- and phase 2 fetches that row of g ONCE with the lanes
+// as channel quads.  The thread-per-(cell, quad) form above repeats the window scan in every channel thread and fetches
+// a row per run of pixels (~10 per cell).  Order: rows by first occurrence in raster order, fixed reduction tree.
+__global__ __launch_bounds__(256) void upsample_bwd_cell_kernel(const float* __restrict__ g, const int32_t* __restrict__ new_row,
+                                                                const int32_t* __restrict__ area, float* __restrict__ ds,
+                                                                int B, int h, int w, int H, int W, int C4, int ldf, int coff,
+                                                                int Kmax, float sh, float sw) {
+    const long cellid = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (cellid >= (long)B * h * w) return;          // wave-uniform
+    const int lane = threadIdx.x & 63;
+    long t = cellid;
+    const int qx = t % w;
+    t /= w;
+    const int qy = t % h;
+    const int b = t / h;
+    int Ylo = 0, Yhi = H - 1, Xlo = 0, Xhi = W - 1;
+    if (sh > 0.f) {
+        Ylo = max(0, (int)floorf((float)(qy - 1) / sh) - 1);
+        Yhi = min(H - 1, (int)ceilf((float)(qy + 1) / sh) + 1);
+    }
+    if (sw > 0.f) {
+        Xlo = max(0, (int)floorf((float)(qx - 1) / sw) - 1);
+        Xhi = min(W - 1, (int)ceilf((float)(qx + 1) / sw) + 1);
+    }
+    const int nwx = Xhi - Xlo + 1, ncand = nwx * (Yhi - Ylo + 1);
+    const int32_t* rows = new_row + (long)b * H * W;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int base = 0; base < ncand; base += 64) {
+        const int i = base + lane;
+        float wgt = 0.f;
+        int r = -1;
+        if (i < ncand) {
+            const int dy = i / nwx, Y = Ylo + dy, X = Xlo + i - dy * nwx;
+            const Lerp ly = lerp_of(Y, sh, h), lx = lerp_of(X, sw, w);
+            const float wy = (ly.i0 == qy ? ly.l0 : 0.f) + (ly.i1 == qy ? ly.l1 : 0.f);
+            const float wx = (lx.i0 == qx ? lx.l0 : 0.f) + (lx.i1 == qx ? lx.l1 : 0.f);
+            wgt = wy * wx;
+            if (wgt != 0.f) r = rows[(long)Y * W + X];
+        }
+        unsigned long long todo = __ballot(r >= 0);
+        while (todo) {
+            const int first = __builtin_ctzll(todo);
+            const int rr = __builtin_amdgcn_readlane(r, first);
+            const bool mine = (r == rr);
+            float wsum = mine ? wgt : 0.f;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) wsum += __shfl_xor(wsum, off);
+            todo &= ~__ballot(mine);
+            if (lane < C4) {
+                const float coef = wsum * (1.f / (float)area[(long)b * Kmax + rr]);
+                const float4 v = ld4(g + ((long)b * Kmax + rr) * ldf + coff + 4 * lane);
+                acc.x += coef * v.x;
+                acc.y += coef * v.y;
+                acc.z += coef * v.z;
+                acc.w += coef * v.w;
+            }
+        }
+    }
+    if (lane < C4) st4(ds + (cellid * C4 + lane) * 4, acc);
+}
 extern "C" int wesup_upsample_bwd(const float* dfm_or_g, const int32_t* new_row, const int32_t* area_new, float* ds,
                                   int B, int h, int w, int H, int W, int C, int ldf, int coff, int Kmax, void* stream) {
     if (!dfm_or_g || !ds || B <= 0 || h <= 0 || w <= 0 || H <= 0 || W <= 0 || (C % 4) || (ldf % 4) || (coff % 4))
@@ -298,7 +361,11 @@ extern "C" int wesup_upsample_bwd(const float* dfm_or_g, const int32_t* new_row,
     if (new_row && (!area_new || Kmax <= 0)) return WESUP_ERR_INVALID;
     const long tot = (long)B * h * w * (C / 4);
     const dim3 grid((unsigned)((tot + 255) / 256));
-    if (new_row)
+    if (new_row && !(h == H && w == W) && C / 4 <= 64)
+        hipLaunchKernelGGL(upsample_bwd_cell_kernel, dim3((unsigned)(((long)B * h * w + 3) / 4)), dim3(256), 0,
+                           (hipStream_t)stream, dfm_or_g, new_row, area_new, ds, B, h, w, H, W, C / 4, ldf, coff, Kmax,
+                           ac_scale(h, H), ac_scale(w, W));
+    else if (new_row)
         hipLaunchKernelGGL(upsample_bwd_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, dfm_or_g, new_row, area_new,
                            ds, B, h, w, H, W, C / 4, ldf, coff, Kmax, ac_scale(h, H), ac_scale(w, W));
     else
