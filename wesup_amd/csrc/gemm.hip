@@ -61,11 +61,12 @@ __device__ __forceinline__ i32x4 make_srd(const float* base, unsigned num_record
     return r;
 }
 __device__ __forceinline__ void bglds16(unsigned voff, i32x4 srd, unsigned soff_uniform, unsigned lds_byte_addr_uniform) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
+    // M0 is written and left: nothing else in these kernels reads it (gfx9 LDS instructions do not, and the GEMM
+    // loops have no indirect register indexing); saving and restoring it around every DMA cost 0.7 %
+    asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds"
+                 :
                  : "v"(voff), "s"(srd), "s"(soff_uniform), "s"(lds_byte_addr_uniform)
-                 : "memory");
+                 : "memory", "m0");
 }
 __device__ __forceinline__ void glds_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 __device__ __forceinline__ unsigned lds_addr(const float* p) {
