@@ -184,7 +184,7 @@ def main():
     print('behaviours: identical_yu', yu.tolist(), 'ce_zero', ce0.item())
 
 
-if __name__ == '__main__':
+if __name__ == '__main__' and len(sys.argv) == 1:
     main()
 
 
@@ -232,3 +232,42 @@ def metrics_golden():
 
 if __name__ == '__main__' and 'metrics' in sys.argv[1:]:
     metrics_golden()
+
+
+def tiles_golden():
+    """Window strategy of the reference (infer_tile.py:23-91): top-left coordinates, division into patches and the
+    running-average recombination, on seeded images whose sizes are not multiples of the patch size
+    -> tests/golden/tiles.npz.  The three functions are numpy only; the module's third-party imports are stand-ins."""
+    _install_standins()
+    for name in ['tqdm', 'PIL', 'PIL.Image']:
+        try:
+            __import__(name)
+        except ImportError:
+            sys.modules[name] = _Anything(name)
+    sys.path.insert(0, REF)
+    import importlib
+    reft = importlib.import_module('infer_tile')
+    out = {}
+    cases = [(50, 70, 32), (64, 64, 32), (33, 97, 16), (40, 40, 40), (45, 31, 24)]
+    for i, (H, W, ps) in enumerate(cases):
+        rs = np.random.RandomState(100 + i)
+        img = rs.randint(0, 256, size=(H, W, 3)).astype(np.uint8)
+        coords = np.array(list(reft._get_top_left_coordinates(H, W, ps)), dtype=np.int64)
+        patches = reft.divide_image_to_patches(img, ps)
+        preds = rs.rand(patches.shape[0], ps, ps).astype(np.float64)
+        combined = reft.combine_patches_to_image(preds, H, W)
+        combined_c = reft.combine_patches_to_image(patches.astype(np.float64), H, W)      # with a channel axis
+        # inputs are regenerated in the test from RandomState(100 + i): only the reference's outputs are stored
+        out[f'shape{i}'] = np.array([H, W, ps])
+        out[f'coords{i}'] = coords
+        out[f'patch_sums{i}'] = patches.reshape(patches.shape[0], -1).sum(1).astype(np.int64)
+        out[f'combined{i}'] = combined.astype(np.float32)
+        if i in (0, 4):
+            out[f'patches{i}'] = patches
+            out[f'combined_c{i}'] = combined_c.astype(np.float32)
+        print('tiles case', i, (H, W, ps), 'patches', patches.shape, 'combined', combined.shape)
+    np.savez_compressed(os.path.join(ROOT, 'tests', 'golden', 'tiles.npz'), **out)
+
+
+if __name__ == '__main__' and 'tiles' in sys.argv[1:]:
+    tiles_golden()

@@ -101,3 +101,37 @@ def test_superpixel_inference_on_a_directory(tmp_path):
     # same images, same weights, same scale -> same prediction (deterministic GPU SLIC + forward)
     again = I.predict(trainer, ds, scales=(0.5, 1.0), device='cuda:0')
     assert all(np.array_equal(a, b) for a, b in zip(multi, again))
+
+
+def test_window_inference_matches_per_window_forward(tmp_path):
+    """infer_tile.py mirror: every window goes through preprocess -> forward -> postprocess on its own and the merge is
+    the reference's running average; the pixel-wise variant merges class-1 probabilities."""
+    from PIL import Image
+    from wesup_amd import infer_tile as T
+    from wesup_amd.models import initialize_trainer
+    from wesup_amd.models.wesup import WESUPPixelInference
+    from wesup_amd import synth
+    H, W, ps = 80, 112, 64
+    img = (synth.synth_image(5, H, W).transpose(1, 2, 0) * 255).astype(np.uint8)
+    (tmp_path / 'd' / 'images').mkdir(parents=True)
+    Image.fromarray(img).save(tmp_path / 'd' / 'images' / 'a.png')
+    trainer = initialize_trainer('wesup', device='cuda:0', sp_area=64)
+    preds = T.infer(trainer, tmp_path / 'd', ps, output_dir=tmp_path / 'out', device='cuda:0')
+    assert len(preds) == 1 and preds[0].shape == (H, W) and preds[0].min() >= 0.0 and preds[0].max() <= 1.0
+    # by hand: windows one by one, merged with the pinned function
+    singles = []
+    with torch.no_grad():
+        for patch in T.divide_image_to_patches(img, ps):
+            inp, _ = trainer.preprocess(T._to_tensor(patch, 'cuda:0'))
+            singles.append(trainer.postprocess(trainer.model(inp)).cpu().numpy()[..., None])
+    want = T.combine_patches_to_image(np.concatenate(singles), H, W)
+    assert np.array_equal(preds[0], want)
+    assert (tmp_path / 'out' / 'a.png').exists()
+    # pixel-wise variant
+    pm = WESUPPixelInference().to('cuda:0')
+    pm.load_state_dict(trainer.model.state_dict())
+    prob = T.pixel_predict_array(pm, img, ps, device='cuda:0')
+    assert prob.shape == (H, W) and prob.min() >= 0.0 and prob.max() <= 1.0
+    one = pm(T._to_tensor(img[:ps, :ps], 'cuda:0')).cpu().numpy()[..., 1]
+    # top-left corner pixels are covered by the first window only
+    assert np.allclose(prob[:8, :8], one[:8, :8], atol=1e-6)

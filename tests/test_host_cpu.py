@@ -97,3 +97,33 @@ def test_synthetic_inputs_are_reproducible_and_well_formed():
     assert img.shape == (3, 32, 32) and pix.shape == (2, 32, 32) and seg.shape == (32, 32) and len(ds) == 3
     with pytest.raises(FileNotFoundError):                      # a real path is read from disk (tests/test_data_cpu.py)
         get_dataset('/data/glas/train')
+
+
+def test_window_functions_match_reference():
+    """infer_tile.py:23-91 (window corners, division, running-average merge) against outputs of the reference's own
+    functions (tests/golden/tiles.npz, oracle/make_golden.py tiles)."""
+    import os
+    from wesup_amd import infer_tile as T
+    g = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'tiles.npz'))
+    for i in range(5):
+        H, W, ps = (int(v) for v in g[f'shape{i}'])
+        rs = np.random.RandomState(100 + i)
+        img = rs.randint(0, 256, size=(H, W, 3)).astype(np.uint8)
+        coords = np.array(list(T._get_top_left_coordinates(H, W, ps)), dtype=np.int64)
+        assert np.array_equal(coords, g[f'coords{i}'])
+        patches = T.divide_image_to_patches(img, ps)
+        assert patches.dtype == np.uint8 and patches.shape == (len(coords), ps, ps, 3)
+        assert np.array_equal(patches.reshape(len(coords), -1).sum(1).astype(np.int64), g[f'patch_sums{i}'])
+        preds = rs.rand(patches.shape[0], ps, ps).astype(np.float64)
+        combined = T.combine_patches_to_image(preds, H, W)
+        assert combined.shape == (H, W) and np.array_equal(combined.astype(np.float32), g[f'combined{i}'])
+        if f'patches{i}' in g.files:
+            assert np.array_equal(patches, g[f'patches{i}'])
+            cc = T.combine_patches_to_image(patches.astype(np.float64), H, W)
+            assert np.array_equal(cc.astype(np.float32), g[f'combined_c{i}'])
+    # the merge of the windows of an image is the image again (every pixel is an average of equal values)
+    img = np.random.RandomState(0).randint(0, 256, size=(70, 53, 3)).astype(np.uint8)
+    back = T.combine_patches_to_image(T.divide_image_to_patches(img, 32).astype(np.float64), 70, 53)
+    assert np.allclose(back, img, atol=1e-9)
+    with pytest.raises(ValueError):
+        T.divide_image_to_patches(img, 64)
