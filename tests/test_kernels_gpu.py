@@ -516,7 +516,7 @@ def test_sp_interp_matrix_equals_fused_upsample_pool(ops, B, H, W, g, h, w):
 
 # ---------------------------------------------------------------- stream-K shapes of the NT family
 @pytest.mark.parametrize('M,N,K', [(2336, 1024, 2112), (3600, 512, 4608), (14400, 512, 2304), (57600, 256, 1152),
-                                   (130, 128, 512), (66000, 128, 512)])
+                                   (130, 128, 1024), (66000, 128, 512)])
 def test_gemm_nt_streamk(ops, lib, M, N, K):
     """Shapes whose last round of 128x128 tiles is partial go through the stream-K blocks + fix-up kernel."""
     d = dev()
@@ -535,6 +535,21 @@ def test_gemm_nt_streamk(ops, lib, M, N, K):
     ref2 = base.cpu()
     ref2[:, 32:32 + N] += torch.where(mask > 0, (F.relu(A).double() @ Bw.double().t()).float(), torch.zeros(()))
     assert rel_err(big, ref2) < TOL
+
+
+@pytest.mark.parametrize('M,N,K', [(130, 128, 512), (14400, 256, 512), (3600, 256, 512)])
+def test_gemm_nt_short_k_under_one_round_is_plain(ops, lib, M, N, K):
+    """Short-K problems with fewer tiles than block slots (side convs of the deep layers) take plain smaller tiles: no
+    workspace, same result."""
+    d = dev()
+    assert lib.load().wesup_gemm_nt_workspace_bytes(M, N, K) == 0
+    A = rnd(M, K, seed=1)
+    Bw = rnd(N, K, seed=2, scale=K ** -0.5)
+    bias = rnd(N, seed=3)
+    ref = (A.double() @ Bw.double().t() + bias.double()).float()
+    out = ops.gemm_nt(A.to(d), Bw.to(d), bias.to(d))
+    assert rel_err(out, ref) < TOL
+    assert torch.equal(out, ops.gemm_nt(A.to(d), Bw.to(d), bias.to(d)))
 
 
 @pytest.mark.parametrize('B,H,W,Cin,Cout', [(4, 30, 30, 512, 512), (2, 60, 60, 256, 512), (1, 120, 120, 128, 256)])
