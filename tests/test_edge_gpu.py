@@ -191,3 +191,47 @@ def test_gapped_label_ids_are_rejected():
     seg[8:] = 2                                                     # id 1 missing: NaN row in the reference (:57-61)
     with pytest.raises(ValueError):
         _preprocess_superpixels(seg.to(d), None)
+
+
+def test_long_thin_diagonal_superpixel():
+    """A superpixel that is a 3-pixel diagonal band: its box of the coarse grids (80x80: 6400 cells, 40x40: 1600) does
+    not fit the per-segment LDS cell table of the fused upsample+scatter-mean, so that segment takes the per-pixel loop
+    while every other superpixel of the image is pooled cell by cell; both against the oracle."""
+    from wesup_amd import synth
+    H = W = 160
+    imgs = synth.synth_image(81, H, W)[None]
+    seg = synth.voronoi_labels(82, H, W, 8).astype(np.int32)
+    yy, xx = np.mgrid[0:H, 0:W]
+    band = np.abs(yy - xx) <= 1
+    seg[band] = seg.max() + 1
+    ids, seg = np.unique(seg, return_inverse=True)                 # contiguous ids again should a cell have vanished
+    segs = seg.reshape(1, H, W).astype(np.int32)
+    assert int((segs == segs.max()).sum()) == int(band.sum()) <= 512           # one segment
+    masks = synth.point_mask(83, segs[0], 0.3, 2)[None]
+    pix = synth.pixel_mask(84, H, W)[None]
+    run_both(imgs, segs, masks, pix)
+
+
+def test_one_block_per_cu_shape_of_the_nt_gemm():
+    """WESUP_NT_SHAPE=big (256x128 tiles, 8 waves, one block per CU; measurement knob) computes the same
+    convolution: run in a child process because the choice is read once per process."""
+    import subprocess, sys, os
+    code = (
+        "import torch, torch.nn.functional as F\n"
+        "from wesup_amd import ops\n"
+        "torch.manual_seed(0)\n"
+        "B,H,W,Ci,Co = 2,60,60,128,256\n"
+        "x = torch.randn(B,Ci,H,W); w = torch.randn(Co,Ci,3,3)*(9*Ci)**-0.5; b = torch.randn(Co)\n"
+        "ref = F.conv2d(F.relu(x).double(), w.double(), b.double(), padding=1).float().permute(0,2,3,1)\n"
+        "wf, wd = ops.pack_conv3x3_weight(w.cuda())\n"
+        "y = ops.conv3x3_fwd(x.permute(0,2,3,1).contiguous().cuda(), wf, b.cuda(), Co, True)\n"
+        "e = float((y.cpu().double()-ref.double()).abs().max()/ref.abs().max())\n"
+        "A = torch.randn(5000, 512); Bw = torch.randn(384, 512)*512**-0.5\n"
+        "o = ops.gemm_nt(A.cuda(), Bw.cuda(), None)\n"
+        "e2 = float((o.cpu().double()-(A.double()@Bw.double().t())).abs().max()/ (A.double()@Bw.double().t()).abs().max())\n"
+        "assert e < 1e-4 and e2 < 1e-4, (e, e2)\n"
+        "print('ok', e, e2)\n")
+    env = dict(os.environ, WESUP_NT_SHAPE='big')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, '-c', code], cwd=root, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and 'ok' in r.stdout, r.stdout + r.stderr
