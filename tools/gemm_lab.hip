@@ -12,7 +12,6 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void* lptr_t;
-#define BK 32
 
 __device__ __forceinline__ void glds16(const float* src, unsigned lds_byte_addr_uniform) {
     unsigned keep;
@@ -70,24 +69,26 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 // VAR bit 10: after every barrier wave w sleeps ~64*w cycles.
 // VAR bit 6: the DMA instructions of a K-step are spread over its MFMAs (16 slots) instead of issued in one burst.
 __device__ unsigned long long g_clk[2 * 8192];   // per block: shader cycles and 100 MHz ticks of the main loop
-template <int NW, int WAVES_M, int WM, int WN, int STAGES, int MINB, int VAR>
+template <int NW, int WAVES_M, int WM, int WN, int STAGES, int MINB, int VAR, int BK = 32>
 __global__ __launch_bounds__(NW * 64, MINB) void lab_kernel(const float* __restrict__ A, const float* __restrict__ B,
                                                             float* __restrict__ C, int M, int N, int K, int tiles_n,
                                                             int ntiles) {
     constexpr int WAVES_N = NW / WAVES_M;
     constexpr int BM = 32 * WM * WAVES_M, BN = 32 * WN * WAVES_N;
-    constexpr int PR = NW * 8;                      // rows per staging pass
+    constexpr int CPR = BK / 4;                     // 16-byte chunks per row (8 at BK = 32, 4 at BK = 16)
+    constexpr int PR = NW * 64 / CPR;               // rows per staging pass
+    constexpr int SWS = (CPR == 8) ? 1 : 2;         // swizzle: chunk ^= (row >> SWS) & (CPR - 1)
     constexpr int RA = BM / PR, RB = BN / PR;
     constexpr int NDMA = RA + RB;
     static_assert(BM % PR == 0 && BN % PR == 0, "staging passes");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int STAGE_FLOATS = (BM + BN) * BK;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int srow = tid >> 3;
-    const int schunk = (tid & 7) ^ ((srow >> 1) & 7);
+    const int srow = tid / CPR;
+    const int schunk = (tid % CPR) ^ ((srow >> SWS) & (CPR - 1));
     const int wm0 = (wave / WAVES_N) * 32 * WM, wn0 = (wave % WAVES_N) * 32 * WN;
     const int l31 = lane & 31, lhi = lane >> 5;
-    const int swa = ((wm0 + l31) >> 1) & 7, swb = ((wn0 + l31) >> 1) & 7;
+    const int swa = ((wm0 + l31) >> SWS) & (CPR - 1), swb = ((wn0 + l31) >> SWS) & (CPR - 1);
     const int nk = K / BK;
     const int lt = xcd_remap(blockIdx.x, ntiles);
     const int tile_n = lt % tiles_n, tile_m = lt / tiles_n;
@@ -197,8 +198,9 @@ __global__ __launch_bounds__(NW * 64, MINB) void lab_kernel(const float* __restr
         for (int t = 0; t < 4; ++t) {
             if ((VAR & 64) && kn >= 0) {
                 // spread staging: slot 4g+t of 16 carries its share of the NDMA instructions, pinned between the MFMAs
+                constexpr int NSLOT = BK / 2;
                 const int slot = 4 * g + t;
-                stage_range(kn, nbuf, (slot * NDMA + 15) / 16, ((slot + 1) * NDMA + 15) / 16);
+                stage_range(kn, nbuf, (slot * NDMA + NSLOT - 1) / NSLOT, ((slot + 1) * NDMA + NSLOT - 1) / NSLOT);
                 __builtin_amdgcn_sched_barrier(0);
             }
 #pragma unroll
@@ -303,14 +305,14 @@ __global__ __launch_bounds__(NW * 64, MINB) void lab_kernel(const float* __restr
 static std::vector<float> hA, hB;
 static float *dA, *dB, *dC;
 
-template <int NW, int WAVES_M, int WM, int WN, int STAGES, int MINB, int VAR>
+template <int NW, int WAVES_M, int WM, int WN, int STAGES, int MINB, int VAR, int BK = 32>
 static void run(const char* name, int M, int N, int K) {
     constexpr int WAVES_N = NW / WAVES_M;
     constexpr int BM = 32 * WM * WAVES_M, BN = 32 * WN * WAVES_N;
     if (M % BM || N % BN) { printf("%-34s M=%d N=%d: shape not a multiple of %dx%d\n", name, M, N, BM, BN); return; }
     const int tiles_n = N / BN, ntiles = (M / BM) * tiles_n;
     const size_t lds = (size_t)STAGES * (BM + BN) * BK * sizeof(float);
-    auto kern = lab_kernel<NW, WAVES_M, WM, WN, STAGES, MINB, VAR>;
+    auto kern = lab_kernel<NW, WAVES_M, WM, WN, STAGES, MINB, VAR, BK>;
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
         printf("%-34s: cannot get %zu B of LDS\n", name, lds); return;
     }
@@ -341,7 +343,7 @@ static void run(const char* name, int M, int N, int K) {
     for (int b = 0; b < ntiles; ++b) { cyc += (double)hc[2 * b]; ticks += (double)hc[2 * b + 1]; }
     const double mhz = cyc / ticks * 100.0;
     // MFMA cycles a SIMD needs for one block-tile (x2 when two blocks share the CU)
-    const double ideal = (double)(K / BK) * (WM * WN * 16) * 64.0 * (NW * MINB / 4);
+    const double ideal = (double)(K / BK) * (WM * WN * (BK / 2)) * 64.0 * (NW * MINB / 4);
     const double pipe = ideal / (cyc / ntiles);
     printf("%-34s %dx%d tile, M=%6d N=%4d K=%5d tiles=%5d: %8.1f us %6.1f TFLOP/s  %4.0f MHz (peak %5.1f) loop-pipe %4.1f%%  err %.1e%s\n", name, BM, BN, M, N, K, ntiles,
            ms * 1e3, 2.0 * M * N * K / ms / 1e9, mhz, 157.3 * mhz / 2400.0, 100.0 * pipe, worst, worst > 1e-4 ? "  WRONG" : "");
@@ -359,16 +361,14 @@ int main(int argc, char** argv) {
     (void)hipMemcpy(dA, hA.data(), hA.size() * 4, hipMemcpyHostToDevice);
     (void)hipMemcpy(dB, hB.data(), hB.size() * 4, hipMemcpyHostToDevice);
     const int N = 256;
-    for (int M : {131072}) {
-        //   NW WAVES_M WM WN STAGES MINB VAR
-        run<4, 2, 2, 2, 2, 2, 0>("base 4w 2blk/CU", M, N, K);
-        run<4, 2, 2, 2, 2, 2, 2048>("base, buffer DMA", M, N, K);
-        run<8, 2, 4, 2, 2, 1, 0>("8w 256x256 (128x64/wave)", M, N, K);
-        run<8, 2, 4, 2, 2, 1, 2048>("8w 256x256, buffer DMA", M, N, K);
-        run<4, 2, 4, 4, 2, 1, 0>("4w 256x256 (128x128/wave)", M, N, K);
-        run<4, 2, 4, 4, 2, 1, 2048>("4w 256x256, buffer DMA", M, N, K);
-        run<4, 2, 4, 4, 2, 1, 64>("4w 256x256 spread", M, N, K);
-        run<4, 2, 4, 4, 2, 1, 2048 + 64>("4w 256x256 spread, buffer DMA", M, N, K);
+    for (int M : {57600, 131072}) {
+        //   NW WAVES_M WM WN STAGES MINB VAR [BK]
+        run<4, 2, 2, 2, 2, 2, 2048>("base 4w 2blk/CU (buffer DMA)", M, N, K);
+        run<4, 2, 2, 2, 2, 3, 2048, 16>("128x128 BK16 3blk/CU", M, N, K);
+        run<4, 2, 4, 2, 2, 2, 2048, 16>("4w 256x128 BK16 2blk/CU", M, N, K);
+        run<4, 2, 2, 4, 2, 2, 2048, 16>("4w 128x256 BK16 2blk/CU", M, N, K);
+        run<4, 2, 4, 2, 3, 2, 2048, 16>("4w 256x128 BK16 ring3 2blk/CU", M, N, K);
+        run<8, 2, 4, 2, 2, 1, 2048>("8w 256x256 (128x64/wave) 1blk", M, N, K);
         printf("\n");
     }
     return 0;
