@@ -78,6 +78,29 @@ def test_prefetcher_feeds_the_trainer_from_disk(tmp_path):
         trainer.train_one_iteration('train', *data)
     hist = trainer.tracker.history
     assert len(hist['loss']) == 3 and all(np.isfinite(hist['loss']))
+    # SLIC one batch ahead on the copy stream: label maps + exact counts arrive with the batch and the step is the same
+    # step (same augmentation stream, same deterministic SLIC) as with the segmentation inside preprocess
+    t2 = initialize_trainer('wesup', device='cuda:0', sp_area=64)
+    t2.model.load_state_dict(initialize_trainer('wesup', device='cuda:0', sp_area=64).model.state_dict())
+    ta = initialize_trainer('wesup', device='cuda:0', sp_area=64)
+    ta.model.load_state_dict(t2.model.state_dict())
+    for t in (t2, ta):
+        t.optimizer, _ = t.get_default_optimizer()
+        t.metric_funcs = [accuracy, dice]
+        t.tracker.train()
+    pf_in = D.DevicePrefetcher(loader, 'cuda:0', train=True, with_points=True, has_masks=True, seed=3)
+    pf_ahead = D.DevicePrefetcher(loader, 'cuda:0', train=True, with_points=True, has_masks=True, seed=3,
+                                  segment_fn=ta.prefetch_segment_fn())
+    for data in pf_in:
+        t2.train_one_iteration('train', *data)
+    n_batches = 0
+    for data in pf_ahead:
+        assert len(data) == 4 and isinstance(data[3], D.LabelMaps) and data[3].labels.shape == data[0].shape[:1] + (64, 64)
+        assert all(isinstance(c, int) and c == int(data[3].labels[b].max()) + 1 for b, c in enumerate(data[3].counts))
+        ta.train_one_iteration('train', *data)
+        n_batches += 1
+    assert n_batches == 3
+    assert np.allclose(t2.tracker.history['loss'], ta.tracker.history['loss'], rtol=1e-5)
 
 
 def test_superpixel_inference_on_a_directory(tmp_path):

@@ -36,3 +36,30 @@ def step():
     trainer.train_one_iteration('train', img, pm, pts)          # no label map given: GPU SLIC inside preprocess
 ms = t(step, 10)
 print('augment + GPU SLIC (sp_area 200) + training step: %.2f ms/step = %.1f img/s' % (ms, B / ms * 1e3))
+
+# SLIC-ahead (utils/data.py DevicePrefetcher with segment_fn): augmentation + SLIC of the NEXT batch on a second stream,
+# beside the training step of the current one; the superpixel counts reach the host through pinned memory in the
+# meantime, so the step pads to the exact row count instead of the worst-case bound
+side = torch.cuda.Stream(device=dev)
+seg_fn = trainer.prefetch_segment_fn()
+state = {}
+def stage():
+    with torch.cuda.stream(side):
+        img, pm = ops.augment(d_img, d_mask, params)
+        seg, n_dev = seg_fn(img)
+        counts = torch.empty(n_dev.shape, dtype=n_dev.dtype).pin_memory()
+        counts.copy_(n_dev, non_blocking=True)
+        ev = torch.cuda.Event(); ev.record()
+    return img, pm, seg, counts, ev
+state['nxt'] = stage()
+def step_ahead():
+    img, pm, seg, counts, ev = state['nxt']
+    state['nxt'] = stage()
+    torch.cuda.current_stream().wait_event(ev)
+    ev.synchronize()
+    for t_ in (img, pm, seg):
+        t_.record_stream(torch.cuda.current_stream())
+    trainer.train_one_iteration('train', img, pm, pts, D.LabelMaps(seg, [int(v) for v in counts]))
+ms = t(step_ahead, 10)
+print('the same with augmentation + SLIC one batch ahead on a second stream, exact counts: %.2f ms/step = %.1f img/s' % (ms, B / ms * 1e3))
+print('superpixels per image:', [int(v) for v in state['nxt'][3]])

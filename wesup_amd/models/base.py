@@ -129,6 +129,11 @@ class BaseTrainer(ABC):
         names = [f.__name__ for f in (self.metric_funcs or [])]
         return all(n in ('accuracy', 'dice') for n in names), names
 
+    def prefetch_segment_fn(self):
+        """Optional callable the input pipeline runs one batch ahead on its copy stream (utils/data.py
+        DevicePrefetcher); its result is appended to the data tuple.  None: nothing to precompute."""
+        return None
+
     def train_one_iteration(self, phase, *data):
         from .. import ops
         if hasattr(self.model, 'prefetch_weights'):      # weight repacking and superpixel preprocessing go to the side
@@ -297,7 +302,7 @@ class BaseTrainer(ABC):
                 self.dataloaders[phase] = D.DevicePrefetcher(
                     self.dataloaders[phase], self.device, train=(phase == 'train'),
                     with_points=isinstance(ds, D.PointSupervisionDataset), has_masks=ds.mask_paths is not None,
-                    n_classes=ds.n_classes, seed=self.rank)
+                    n_classes=ds.n_classes, seed=self.rank, segment_fn=self.prefetch_segment_fn())
 
         self.logger.info(underline('\nTraining Stage', '='))
         self.metric_funcs = self.kwargs.get('metrics')

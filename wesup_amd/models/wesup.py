@@ -399,11 +399,24 @@ class WESUPTrainer(BaseTrainer):
                 segs.append(torch.as_tensor(seg - seg.min(), dtype=torch.int32))
             return torch.stack(segs).to(self.device), max(int(s.max()) + 1 for s in segs)
         labels, _ = ops.slic(img.contiguous().float(), n_segments, float(self.kwargs.get('sp_compactness')), 10)
+        return labels, self._slic_bound(H, W)
+
+    def _slic_bound(self, H, W):
         # every connected superpixel holds its first pixel alone -> at most one id per grid centre plus split-offs;
         # the number of initial centres bounds the count after small components were absorbed only loosely, so use
-        # the safe bound HW / min_size (no host sync)
-        kmax = int(2 * n_segments) + 8
-        return labels, kmax
+        # the safe bound 2 * n_segments (no host sync)
+        return int(2 * int(H * W / self.kwargs.get('sp_area'))) + 8
+
+    def prefetch_segment_fn(self):
+        """GPU SLIC of the next batch on the input pipeline's copy stream, beside the current training step
+        (``slic_ahead``, default on; a CPU ``slic_fn`` stays inside preprocess)."""
+        if self.kwargs.get('slic_fn') is not None or not self.kwargs.get('slic_ahead', True):
+            return None
+        def segment(img):
+            H, W = img.size(-2), img.size(-1)
+            return ops.slic(img.contiguous().float(), int(H * W / self.kwargs.get('sp_area')),
+                            float(self.kwargs.get('sp_compactness')), 10)
+        return segment
 
     def preprocess(self, *data):
         """(img, pixel_mask[, point_mask[, segments]]) -> ((img, sp_maps), (pixel_mask, sp_labels))
@@ -427,6 +440,9 @@ class WESUPTrainer(BaseTrainer):
         B = img.size(0)
         n_sp_host = None
         kmax_bound = None
+        if hasattr(segments, 'labels') and hasattr(segments, 'counts'):       # utils/data.py LabelMaps (SLIC ahead)
+            n_sp_host = list(segments.counts)
+            segments = segments.labels
         if segments is None:
             segments, kmax_bound = self.slic(img)
         elif not segments.is_cuda:
@@ -441,7 +457,10 @@ class WESUPTrainer(BaseTrainer):
             mask = None
 
         # label maps already on the GPU: an upper bound on the ids avoids a host sync (padded rows are inert)
-        Kmax = max(n_sp_host) if n_sp_host is not None else (kmax_bound or self.kwargs.get('max_superpixels'))
+        # (label maps that arrive on the GPU without counts -- the pipeline's SLIC-ahead -- get the SLIC bound unless
+        #  max_superpixels says otherwise)
+        Kmax = max(n_sp_host) if n_sp_host is not None else (
+            kmax_bound or self.kwargs.get('max_superpixels') or self._slic_bound(img.size(-2), img.size(-1)))
         meta = preprocess_label_maps(segments, mask, Kmax=Kmax, n_sp_host=n_sp_host)
         if self.kwargs.get('check_label_maps', False):
             meta.check()

@@ -200,14 +200,29 @@ def transform_points(pts_xyc, M, H, W):
     return np.concatenate([np.floor(xy[keep]), p[keep, 2:3]], 1).astype(np.int64)
 
 
+class LabelMaps:
+    """Label maps that were computed ahead of the step on the device, with their superpixel counts already on the host
+    (no sync and no padding to a worst-case bound when the trainer preprocesses them)."""
+
+    def __init__(self, labels, counts):
+        self.labels, self.counts = labels, counts
+
+
 class DevicePrefetcher:
     """Wraps a DataLoader over raw items: pinned staging + asynchronous H2D on a copy stream one batch ahead,
     augmentation / ToTensor / one-hot / point rasterisation on the GPU.  Yields the trainer's data tuple
     ``(img, pixel_mask, point_mask)`` (or ``(img, pixel_mask)`` for mask datasets)."""
 
-    def __init__(self, loader, device, train=True, with_points=True, has_masks=True, n_classes=2, seed=0):
+    def __init__(self, loader, device, train=True, with_points=True, has_masks=True, n_classes=2, seed=0,
+                 segment_fn=None):
+        """``segment_fn(img (B,3,H,W) float on the device) -> ((B,H,W) int32 label maps, (B,) int32 counts)``: when
+        given, the superpixel segmentation of the NEXT batch also runs on the copy stream, beside the training step of
+        the current one; its counts are copied to pinned host memory behind it, so that when the batch is consumed they
+        are plain integers (exact row count, no host sync in the step) and the label maps travel as a ``LabelMaps``
+        fourth element of the data tuple (WESUPTrainer.preprocess takes it)."""
         self.loader, self.device, self.train = loader, torch.device(device), train
         self.with_points, self.has_masks, self.n_classes = with_points, has_masks, n_classes
+        self.segment_fn = segment_fn
         self.rs = np.random.RandomState(seed)
         self.copy_stream = torch.cuda.Stream(device=self.device)
 
@@ -237,21 +252,45 @@ class DevicePrefetcher:
                 if idx.shape[1]:
                     d_idx = idx.pin_memory().to(self.device, non_blocking=True)
                     point_mask[d_idx[0], d_idx[1], d_idx[2], d_idx[3]] = 1
+            segments = counts = None
+            if self.segment_fn is not None:
+                segments, n_dev = self.segment_fn(out_img)
+                counts = torch.empty(n_dev.shape, dtype=n_dev.dtype).pin_memory()
+                counts.copy_(n_dev, non_blocking=True)
             done = torch.cuda.Event()
             done.record()
         pixel_mask = out_mask if self.has_masks else empty_tensor()
+        if segments is not None:
+            return (out_img, pixel_mask, point_mask if self.with_points else empty_tensor(), LabelMaps(segments, counts)), done
         return ((out_img, pixel_mask, point_mask) if self.with_points else (out_img, pixel_mask)), done
+
+    @staticmethod
+    def _hand_over(item):
+        """The tensors were allocated on the copy stream and are consumed on the caller's: tell the caching allocator."""
+        cur = torch.cuda.current_stream()
+        for t in item:
+            if isinstance(t, LabelMaps):
+                t.labels.record_stream(cur)
+            elif torch.is_tensor(t) and t.is_cuda:
+                t.record_stream(cur)
+        return item
 
     def __iter__(self):
         nxt = None
         for raw in self.loader:
             cur, nxt = nxt, self._stage(raw)
             if cur is not None:
-                torch.cuda.current_stream().wait_event(cur[1])
-                yield cur[0]
+                yield self._consume(cur)
         if nxt is not None:
-            torch.cuda.current_stream().wait_event(nxt[1])
-            yield nxt[0]
+            yield self._consume(nxt)
+
+    def _consume(self, staged):
+        item, done = staged
+        torch.cuda.current_stream().wait_event(done)
+        if isinstance(item[-1], LabelMaps):
+            done.synchronize()                   # queued a whole step ago: the counts are on the host by now
+            item[-1].counts = [int(v) for v in item[-1].counts]
+        return self._hand_over(item)
 
 
 def get_dataset(root_dir, train=True, proportion=1.0, multiscale_range=None, rescale_factor=None, target_size=None):
