@@ -19,6 +19,7 @@
 //   * ReLU of the previous layer is applied to the fragments after the ds_read.
 #include "common.hpp"
 #include <cstdlib>
+#include <cstdio>
 
 #define BK 32
 
@@ -645,9 +646,10 @@ struct TnParams {
     int relu_b;
     int tiles_m, tiles_n, taps;
     int k_per_split;  // multiple of BK
+    int w_old, w_young;   // > 0: weighted split of a single-round grid (see the kernel); 0: equal splits
 };
 
-template <int BM, int BN, int WM, int WN, int MODE, bool RELU>
+template <int BM, int BN, int WM, int WN, int MODE, bool RELU, bool TINY>
 __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnParams p) {
     constexpr int QA = BM / 4, RPA = 256 / QA, NA = BK / RPA;
     constexpr int QB = BN / 4, RPB = 256 / QB, NB = BK / RPB;
@@ -658,16 +660,35 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnParams p) {
     float* Bs = smem + 2 * BK * BM;         // [2][BK][BN]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const unsigned long long tr0 = __builtin_amdgcn_s_memrealtime();
     int lt = blockIdx.x;
     const int tile_n = lt % p.tiles_n;
     lt /= p.tiles_n;
     const int tile_m = lt % p.tiles_m;
     const int tap = lt / p.tiles_m;          // 0 for MODE 0/2
     const int m_blk = tile_m * BM, n_blk = tile_n * BN;
-    const int k_begin = blockIdx.y * p.k_per_split;
+    // K range of this split.  A grid of at most 512 blocks is dispatched as "blocks 0..255 one per CU, blocks 256.. into
+    // the second slot of each CU", and of the two blocks that share a CU the one that arrived first wins the MFMA
+    // arbitration (tools/tn_trace.py: with equal ranges the first blocks end at 500 us, their partners at 657 us, the
+    // last quarter of the launch running one block per CU at two thirds of the pipe).  So the ranges are weighted:
+    // a block of the first 256 gets w_old K-steps for every w_young of a later one, every tile's splits still
+    // partition [0, K) exactly, and the pairs end together.  Static, so the summation order stays fixed.
+    int k_begin, k_end;
+    if (p.w_old > 0) {
+        const int gx = gridDim.x, S = gridDim.y, y = blockIdx.y;
+        const int T = (p.K + BK - 1) / BK;
+        const int n_o = ((int)blockIdx.x < 256) ? min(S, (255 - (int)blockIdx.x) / gx + 1) : 0;   // splits of this tile among the first 256 blocks
+        const long wtot = (long)p.w_old * n_o + (long)p.w_young * (S - n_o);
+        const long w0 = (long)p.w_old * min(y, n_o) + (long)p.w_young * max(0, y - n_o);
+        const long w1 = (long)p.w_old * min(y + 1, n_o) + (long)p.w_young * max(0, y + 1 - n_o);
+        k_begin = (int)(T * w0 / wtot) * BK;
+        k_end = min(p.K, (int)(T * w1 / wtot) * BK);
+    } else {
+        k_begin = blockIdx.y * p.k_per_split;
+        k_end = min(p.K, k_begin + p.k_per_split);
+    }
     const float* Ab = p.A + (long)blockIdx.z * p.batchA;
     const float* Bb = p.Bx + (long)blockIdx.z * p.batchB;
-    const int k_end = min(p.K, k_begin + p.k_per_split);
 
     const int qa = tid % QA, ra_row = tid / QA;
     const int qb = tid % QB, rb_row = tid / QB;
@@ -711,7 +732,9 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnParams p) {
     // step) and h, and compares -- ~10 vector instructions per staged row instead of ~25.
     auto mask_b = [&](int k0, int i) -> unsigned {
         if (MODE == 0) return b_vo[i];
-        if (p.W < 16 || p.H < 2) {             // tiny images: more carries than the fast path handles; divide per lane
+        if constexpr (TINY) {                  // images with W < 16 or H < 2 (a kernel variant of their own, so that the
+                                               // loop below stays free of branches and fully unrolled): more carries
+                                               // than the fast path handles; divide per lane
             const int k = k0 + rb_row + RPB * i;
             const int t = fast_div(k, p.dW);
             const int w = k - t * p.W;
@@ -769,6 +792,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnParams p) {
     for (int i = 0; i < NB; ++i) vb[i] = mask_b(k_begin + BK, i);      // offsets of K-step 1 (all out of range beyond k_end)
     glds_wait();
     __syncthreads();
+    const unsigned long long tr1 = __builtin_amdgcn_s_memrealtime();
     int cur = 0;
     for (int kk = 0; kk < nk; ++kk) {
         issue(kk + 1, vb, cur ^ 1);                // unconditional (past k_end every lane is out of range: zeros)
@@ -824,6 +848,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnParams p) {
         cur ^= 1;
     }
 
+    const unsigned long long tr2 = __builtin_amdgcn_s_memrealtime();
     float* slab = p.slab + (long)blockIdx.z * p.batch_slab + (long)blockIdx.y * p.slab_stride;
     if (do_cs && m_blk + tid < p.M) slab[(long)p.M * p.Nslab + m_blk + tid] = csum;
     const int ncol0 = (MODE == 1) ? tap * p.N : 0;
@@ -846,6 +871,13 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnParams p) {
                 }
             }
         }
+    }
+    if (g_trace && tid == 0) {         // debug: per-block timeline, as in the NT kernel
+        const long bid = blockIdx.x + (long)gridDim.x * (blockIdx.y + (long)gridDim.y * blockIdx.z);
+        unsigned long long* t = g_trace + 6 * bid;
+        t[0] = tr0; t[1] = tr1; t[2] = tr2; t[3] = __builtin_amdgcn_s_memrealtime();
+        t[4] = __builtin_amdgcn_s_getreg((20 /*HW_REG_XCC_ID*/) | (0 << 6) | (31 << 11));
+        t[5] = __builtin_amdgcn_s_getreg((4 /*HW_REG_HW_ID*/) | (0 << 6) | (31 << 11));
     }
 }
 
@@ -956,23 +988,41 @@ static TnPlan plan_tn(int M, int N, int K, int taps, int nbatch = 1) {
     return pl;
 }
 
+static long grid_blocks(const TnPlan& pl) { return (long)pl.tiles_m * pl.tiles_n * pl.taps * pl.S; }
 template <int MODE>
 static int launch_tn(TnParams p, const TnPlan& pl, hipStream_t st, int nbatch = 1) {
     p.tiles_m = pl.tiles_m; p.tiles_n = pl.tiles_n; p.taps = pl.taps; p.k_per_split = pl.k_per_split;
     p.Nslab = pl.Nslab;
     // buffer-form staging: the byte offsets inside one split's K range must stay below the 2 GiB out-of-range marker
     const long ldmax = p.lda > p.ldb ? p.lda : p.ldb;
-    if (((long)pl.k_per_split + 2 * BK) * ldmax * 4 + (1l << 22) >= (1l << 31)) return WESUP_ERR_INVALID;
-    dim3 grid(pl.tiles_m * pl.tiles_n * pl.taps, pl.S, nbatch);
-    if (pl.bm == 128) {
-        const size_t lds = (size_t)2 * BK * (128 + 128) * sizeof(float);
-        if (p.relu_b) hipLaunchKernelGGL((gemm_tn_kernel<128, 128, 2, 2, MODE, true>), grid, dim3(256), lds, st, p);
-        else hipLaunchKernelGGL((gemm_tn_kernel<128, 128, 2, 2, MODE, false>), grid, dim3(256), lds, st, p);
-    } else {
-        const size_t lds = (size_t)2 * BK * (64 + 64) * sizeof(float);
-        if (p.relu_b) hipLaunchKernelGGL((gemm_tn_kernel<64, 64, 1, 1, MODE, true>), grid, dim3(256), lds, st, p);
-        else hipLaunchKernelGGL((gemm_tn_kernel<64, 64, 1, 1, MODE, false>), grid, dim3(256), lds, st, p);
+    // weighted splits (single round of 128x128 blocks, one product): default 3 : 2, WESUP_TN_WEIGHTS="a:b" overrides
+    // (measured at the bench shape: 1:1 5.38, 5:4 5.33, 3:2 5.29, 25:16 5.30, 2:1 5.32 ms of wgrad per step)
+    p.w_old = p.w_young = 0;
+    if (pl.bm == 128 && nbatch == 1 && pl.S >= 2 && (long)grid_blocks(pl) <= 512) {
+        static const int wts = [] {
+            const char* e = getenv("WESUP_TN_WEIGHTS");
+            int a = 3, b = 2;
+            if (e && sscanf(e, "%d:%d", &a, &b) == 2 && a >= 0 && b > 0 && a < 1024 && b < 1024) return a * 1024 + b;
+            return 3 * 1024 + 2;
+        }();
+        p.w_old = wts / 1024; p.w_young = wts % 1024;
     }
+    const long kmax = p.w_old > 0 ? 2l * pl.k_per_split : pl.k_per_split;      // a weighted range stays below twice the mean
+    if ((kmax + 2 * BK) * ldmax * 4 + (1l << 22) >= (1l << 31)) return WESUP_ERR_INVALID;
+    dim3 grid(pl.tiles_m * pl.tiles_n * pl.taps, pl.S, nbatch);
+    const bool tiny = MODE != 0 && (p.W < 16 || p.H < 2);
+#define WESUP_TN_LAUNCH(BM_, WM_, RELU_, TINY_)                                                                        \
+    hipLaunchKernelGGL((gemm_tn_kernel<BM_, BM_, WM_, WM_, MODE, RELU_, TINY_>), grid, dim3(256),                     \
+                       (size_t)2 * BK * (BM_ + BM_) * sizeof(float), st, p)
+#define WESUP_TN_PICK(BM_, WM_)                                                                                        \
+    do {                                                                                                               \
+        if (tiny) { if (p.relu_b) WESUP_TN_LAUNCH(BM_, WM_, true, (MODE != 0)); else WESUP_TN_LAUNCH(BM_, WM_, false, (MODE != 0)); } \
+        else { if (p.relu_b) WESUP_TN_LAUNCH(BM_, WM_, true, false); else WESUP_TN_LAUNCH(BM_, WM_, false, false); }  \
+    } while (0)
+    if (pl.bm == 128) WESUP_TN_PICK(128, 2);
+    else WESUP_TN_PICK(64, 1);
+#undef WESUP_TN_PICK
+#undef WESUP_TN_LAUNCH
     WESUP_CHECK_LAUNCH();
     return WESUP_OK;
 }
