@@ -16,6 +16,12 @@ import os
 import sys
 import time
 
+# HIP maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4).  The step uses 3 streams; a torch.distributed
+# process group brings its own, and with 4 queues two of the step's streams then share one (false serialisation:
+# +1.2 ms per step with nothing but the process group alive).  6 keeps every stream on a queue of its own; set before
+# the HIP runtime starts.  
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '6')
+
 import numpy as np
 import torch
 
@@ -44,12 +50,14 @@ def main():
                          "other classes are timed in extra untimed steps")
     ap.add_argument('--unfused-pool-bwd', action='store_true')
     ap.add_argument('--force-ddp', action='store_true', help='run the RCCL gradient all-reduce path even with one rank')
+    ap.add_argument('--bucket-mb', type=int, default=16, help='gradient all-reduce bucket size')
+    ap.add_argument('--ddp-probe', default='', help="diagnostics with one rank: 'pg' = process group only, 'reducer' = reducer without the collective")
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    use_dist = world > 1 or args.force_ddp
+    use_dist = world > 1 or args.force_ddp or bool(args.ddp_probe)
     if use_dist:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
@@ -79,8 +87,8 @@ def main():
     trainer.model.train()
     trainer.tracker.train()
     trainer.model.engine.fuse_pool_bwd = not args.unfused_pool_bwd
-    if use_dist:
-        trainer.enable_data_parallel()
+    if use_dist and args.ddp_probe != 'pg':
+        trainer.enable_data_parallel(bucket_bytes=args.bucket_mb << 20)
 
     # two different synthetic batches per rank, resident in HBM before the timed region
     pool = []

@@ -95,7 +95,6 @@ class WesupEngine:
         self.two_streams = True          # side branch on its own HIP stream
         self._side_stream = None
         self._wgrad_stream = None
-        self._aux_stream = None
         self.timer = KernelTimer()
         self.on_grads_ready = None       # callback(names) for the data-parallel layer
 
@@ -109,11 +108,6 @@ class WesupEngine:
         if self._wgrad_stream is None:
             self._wgrad_stream = torch.cuda.Stream(device=self.device)
         return self._wgrad_stream
-
-    def _aux(self):
-        if self._aux_stream is None:
-            self._aux_stream = torch.cuda.Stream(device=self.device)
-        return self._aux_stream
 
     class _OnSide:
         """Run the body on the side stream after everything queued so far on the main stream."""
@@ -416,7 +410,11 @@ class WesupEngine:
         # kernel in flight); on a stream of its own it runs under the deep layers' GEMMs.
         ds_ready = [None] * 13
         if self.two_streams and self.fuse_pool_bwd:
-            aux = self._aux()
+            # ... at the head of the wgrad stream, which has nothing to do until the first weight gradient is queued.
+            # (A fourth stream of its own measured the same; with three engine streams + the RCCL stream the process
+            # stays within the 4 hardware queues HIP maps streams onto by default -- a fifth stream aliases two of
+            # them and costs 1.2 ms per step, which is what a live process group did to the 4-stream schedule.)
+            aux = self._wg()
             aux.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(aux):
                 for l in range(12, -1, -1):
