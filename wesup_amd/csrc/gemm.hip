@@ -5,8 +5,9 @@
 // with operands in registers, tools/mfma_peak.hip).  One MFMA takes 64 cycles on its SIMD, so the kernels are
 // paced by MFMA issue and everything else has to hide under it.
 //
-// Operand staging is LDS-DMA (global_load_lds_dwordx4): a wave-instruction copies 64 x 16 B from per-lane
-// global addresses straight into 1 KiB of LDS, no staging registers and no ds_write.  tools/mfma_ingredients.hip
+// Operand staging is LDS-DMA (buffer_load_dwordx4 ... lds; global_load_lds_dwordx4 for the image layer): a
+// wave-instruction copies 64 x 16 B from per-lane addresses straight into 1 KiB of LDS, no staging registers and
+// no ds_write.  tools/mfma_ingredients.hip
 // measured why: with register staging hipcc either waits for the loads in front of the MFMA phase or sinks them
 // behind it (100-124 TFLOP/s for the bare loop); with LDS-DMA the only wait is the vmcnt(0) that __syncthreads()
 // emits, exactly at the end of the K-step (128-137 TFLOP/s).
@@ -14,9 +15,9 @@
 //     of the NT kernel's ds_read_b128 fragment reads are removed by XOR-swizzling the 16-B chunk index with
 //     (row>>1)&7 -- on the per-lane SOURCE address when staging and on the read address (same involution);
 //   * a lane whose element is outside the image / matrix is given an out-of-range buffer offset and the DMA writes
-//     zeros for it (implicit zero padding; the 64-bit global form of the image layer and of the TN kernel reads a
-//     zeroed page instead);
-//   * ReLU of the previous layer is applied to the fragments after the ds_read.
+//     zeros for it (implicit zero padding; the 64-bit global form of the image layer reads a zeroed page instead);
+//   * ReLU of the previous layer is applied to the fragments after the ds_read (compile-time kernel variant).
+// What the loops cost and why they look the way they do: DESIGN.md 3.1 and 6 (tools/gemm_lab.hip).
 #include "common.hpp"
 #include <cstdlib>
 #include <cstdio>
