@@ -108,3 +108,20 @@ def test_shard_indices_partition_the_dataset():
         assert set(seen) == set(range(n))
         assert ddp.shard_indices(n, 0, world, seed=3, epoch=1) == ddp.shard_indices(n, 0, world, seed=3, epoch=1)
         assert ddp.shard_indices(max(n, 9), 0, world, seed=3, epoch=1) != ddp.shard_indices(max(n, 9), 0, world, seed=3, epoch=2)
+
+
+def test_weight_bias_pairs_merge_into_one_range():
+    """The engine reports (weight, bias) of a layer in one call while backward walks the flat buffer downwards: the
+    pair must extend the pending range, not flush it (28 flushes per step instead of 6 buckets)."""
+    names, offs, sizes, total = [], {}, {}, 0
+    for i in range(6):
+        for t, n in (('weight', 640), ('bias', 64)):
+            k = f'backbone.{i}.{t}'
+            names.append(k); offs[k] = total; sizes[k] = n; total += n
+    flat = torch.zeros(total)
+    red = ddp.GradAllReducer(flat, offs, sizes, bucket_bytes=1 << 30)
+    for i in range(5, -1, -1):
+        red.ready([f'backbone.{i}.weight', f'backbone.{i}.bias'])
+        assert red.launched == []                    # nothing flushed: one growing contiguous range
+    done = red.finish()
+    assert done == [(0, total)]
