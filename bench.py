@@ -51,6 +51,9 @@ def main():
     ap.add_argument('--unfused-pool-bwd', action='store_true')
     ap.add_argument('--force-ddp', action='store_true', help='run the RCCL gradient all-reduce path even with one rank')
     ap.add_argument('--bucket-mb', type=int, default=16, help='gradient all-reduce bucket size')
+    ap.add_argument('--rehearse-on-one-gpu', action='store_true',
+                    help='multi-rank rehearsal on a one-GPU box: every rank uses cuda:0 and gloo carries the exchange '
+                         '(RCCL refuses two ranks on one device); exercises the launch contract, not performance')
     ap.add_argument('--ddp-probe', default='', help="diagnostics with one rank: 'pg' = process group only, 'reducer' = reducer without the collective")
     args = ap.parse_args()
 
@@ -64,8 +67,13 @@ def main():
         os.environ.setdefault('MASTER_PORT', '29511')
         os.environ.setdefault('RANK', '0')
         os.environ.setdefault('WORLD_SIZE', '1')
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        if args.rehearse_on_one_gpu:
+            local_rank = 0
+            torch.cuda.set_device(0)
+            dist.init_process_group('gloo')
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
     assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run'
     dev = torch.device('cuda', local_rank)
     torch.cuda.set_device(dev)
