@@ -9,10 +9,18 @@ preprocessing from the label map -> forward -> loss (label propagation + CE) -> 
 gradient all-reduce (N > 1) -> SGD, on a batch of 4 images per GPU, 480x480, 576 superpixels each,
 fp32, with inputs already resident in HBM.  SLIC is excluded (label maps are inputs).
 Rank 0 prints ONE JSON line.
+
+``--gpus N`` with N > 1 and no WORLD_SIZE in the environment launches itself: the parent (which never touches the GPU)
+starts N fresh child processes of this script, one per GPU, with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR /
+MASTER_PORT set, waits for them and exits non-zero if any of them does.  Under ``torch.distributed.run`` the
+environment is already there and every process is a rank.
 """
 import argparse
+import glob
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -22,9 +30,6 @@ import time
 # the HIP runtime starts.  
 os.environ.setdefault('GPU_MAX_HW_QUEUES', '6')
 
-import numpy as np
-import torch
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
@@ -32,7 +37,7 @@ PEAK_MFMA_F32_TFLOPS = 157.3      # MI355X_MICROARCH.md, Peak FP32 (matrix), den
 PEAK_HBM_GBS = 8000.0             # HBM3E spec; 6290 GB/s measured streaming copy
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
@@ -55,12 +60,144 @@ def main():
                     help='multi-rank rehearsal on a one-GPU box: every rank uses cuda:0 and gloo carries the exchange '
                          '(RCCL refuses two ranks on one device); exercises the launch contract, not performance')
     ap.add_argument('--ddp-probe', default='', help="diagnostics with one rank: 'pg' = process group only, 'reducer' = reducer without the collective")
-    args = ap.parse_args()
+    ap.add_argument('--stub-trainer', action='store_true',
+                    help='launch-contract rehearsal WITHOUT a GPU: every rank runs a trivial CPU step under gloo; only '
+                         'the launcher, the rendezvous, the barrier/max-over-ranks timing and the one JSON line are real '
+                         '(tests/test_bench_launch_cpu.py); the value it prints measures nothing')
+    ap.add_argument('--stub-fail-rank', type=int, default=-1, help='with --stub-trainer: this rank exits with an error')
+    return ap.parse_args(argv)
 
+
+# --------------------------------------------------------------------------------------------- self-launch
+def _free_port():
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def self_launch(args, argv):
+    """Parent of ``python bench.py --gpus N`` (N > 1, no torch.distributed.run around it): N fresh child processes,
+    one rank each.  Nothing here initialises the GPU (no HIP call, no exec of a process that did)."""
+    port = _free_port()
+    children = []
+    for rank in range(args.gpus):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(args.gpus),
+                   LOCAL_WORLD_SIZE=str(args.gpus), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+        children.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env))
+    rc = 0
+    try:
+        pending = list(children)
+        while pending:
+            for ch in list(pending):
+                r = ch.poll()
+                if r is None:
+                    continue
+                pending.remove(ch)
+                if r != 0 and rc == 0:
+                    rc = r if r > 0 else 1
+                    for other in pending:          # a rank died: the others would wait in a collective forever
+                        other.terminate()
+            time.sleep(0.05)
+    finally:
+        for ch in children:
+            if ch.poll() is None:
+                ch.kill()
+    return rc
+
+
+# --------------------------------------------------------------------------------------------- helpers
+def workload_label(B, H, W, g):
+    """Names the BASELINE.json config the shape corresponds to, or says that it is none of them."""
+    n = g * g
+    known = {(480, 480, 4, 576): 'BASELINE configs[1] (per-GPU shard of configs[2]): GlaS-shaped',
+             (800, 800, 4, 1521): 'per-GPU shard of BASELINE configs[3]: CRAG-shaped',
+             (1024, 1024, 8, 3025): 'per-GPU shard of BASELINE configs[4]: H&E-shaped'}
+    head = known.get((H, W, B, n), 'custom shape (not a BASELINE config):')
+    return (f'{head} synthetic {H}x{W} patches, VGG16 side-output extractor, batch={B}/GPU, {n} superpixels/img '
+            '(jittered Voronoi), 20% point-labelled, full train step (preprocess+fwd+loss+bwd+allreduce+SGD), '
+            'SLIC excluded')
+
+
+def roofline_inputs(B, H, W, g):
+    """Counter-derived inputs of the roofline objects, read from the newest profiles/rNN_roofline_inputs.json
+    (written by tools/roofline_inputs.py from the rocprofv3 --pmc passes of tools/collect_profiles.sh).  Only used
+    when the file was collected at this very shape; no number is typed into this file."""
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_roofline_inputs.json')))
+    if not files:
+        return None
+    with open(files[-1]) as f:
+        d = json.load(f)
+    sh = d.get('shape', {})
+    if (sh.get('batch'), sh.get('H'), sh.get('W'), sh.get('superpixels')) != (B, H, W, g * g):
+        return None
+    d['file'] = os.path.relpath(files[-1], ROOT)
+    return d
+
+
+def host_cpu():
+    try:
+        with open('/proc/cpuinfo') as f:
+            cpu = next(l.split(':', 1)[1].strip() for l in f if l.startswith('model name'))
+    except Exception:
+        cpu = 'unknown CPU'
+    return f'{cpu}, {os.cpu_count()} logical cores'
+
+
+def stub_worker(args, rank, world):
+    """--stub-trainer: the launch contract on CPU ranks (gloo).  See the flag's help."""
+    import torch
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group('gloo')
+    if rank == args.stub_fail_rank:
+        raise SystemExit(3)
+    x = torch.ones(1024)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+    for _ in range(args.warmup):
+        time.sleep(0.002)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        time.sleep(0.002 * (1 + rank))         # ranks differ: the reported time must be the slowest rank's
+        if world > 1:
+            dist.all_reduce(x)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    tmax = tmin = elapsed
+    if world > 1:
+        t = torch.tensor([elapsed, -elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        tmax, tmin = float(t[0]), -float(t[1])
+    if rank == 0:
+        print(json.dumps({'metric': 'STUB (launch-contract rehearsal, measures nothing)', 'value': world * args.batch * args.steps / tmax,
+                          'unit': 'images/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+                          'ms_per_step': tmax / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
+                          'vs_baseline': None, 'dtype': 'f32', 'data': 'none (stub)',
+                          'config': {'workload': 'stub', 'parallelism': f'dp{world}'},
+                          'rank_time': {'min_s': tmin, 'max_s': tmax},
+                          'collective': {'backend': 'gloo', 'ranks': world, 'allreduce_sum': float(x[0])}}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+# --------------------------------------------------------------------------------------------- one rank
+def worker(args):
     rank = int(os.environ.get('RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: the launcher and the flag disagree')
+    if args.stub_trainer:
+        return stub_worker(args, rank, world)
+
+    import numpy as np  # noqa: F401
+    import torch
     use_dist = world > 1 or args.force_ddp or bool(args.ddp_probe)
+    backend = None
     if use_dist:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
@@ -74,7 +211,7 @@ def main():
         else:
             torch.cuda.set_device(local_rank)
             dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
-    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run'
+        backend = dist.get_backend()
     dev = torch.device('cuda', local_rank)
     torch.cuda.set_device(dev)
 
@@ -110,7 +247,6 @@ def main():
 
     def barrier():
         if use_dist:
-            import torch.distributed as dist
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -132,14 +268,12 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     timer.enabled = False
+    rank_time = None
     if use_dist:
-        import torch.distributed as dist
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        tmin = t.clone()
+        t = torch.tensor([elapsed, -elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dist.all_reduce(tmin, op=dist.ReduceOp.MIN)
-        rank_time = {'min_s': round(float(tmin.item()), 4), 'max_s': round(float(t.item()), 4)}
-        elapsed = float(t.item())
+        rank_time = {'min_s': round(-float(t[1].item()), 4), 'max_s': round(float(t[0].item()), 4)}
+        elapsed = float(t[0].item())                      # the slowest rank's wall time of the timed region
     loss_last = trainer.tracker.history['loss'][-1]
 
     # ---- untimed extras for the roofline report (every rank runs them so that collectives stay matched)
@@ -186,12 +320,11 @@ def main():
             'metric': 'training images/sec, GlaS 480x480 VGG16 ~600 SP/img', 'value': round(value, 3), 'unit': 'images/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 3),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': f'BASELINE configs[1]: GlaS-shaped synthetic {H}x{W} patches, VGG16 side-output '
-                                   f'extractor, batch={B}/GPU, {g * g} superpixels/img (jittered Voronoi), 20% point-labelled, '
-                                   'full train step (preprocess+fwd+loss+bwd+allreduce+SGD), SLIC excluded',
+            'config': {'workload': workload_label(B, H, W, g),
                        'global_batch': world * B, 'image': [H, W], 'superpixels': g * g,
                        'parallelism': f'dp{world}', 'last_loss': loss_last},
         }
+        rin = roofline_inputs(B, H, W, g)
         if not args.no_kernel_timing:
             tot = timer.collect()
             n_ev = n_sampled
@@ -210,11 +343,19 @@ def main():
             fl = sum(tot[t][2] for t in ('conv3x3_fwd', 'conv3x3_dgrad') if t in tot)
             nl = sum(tot[t][1] for t in ('conv3x3_fwd', 'conv3x3_dgrad') if t in tot)
             ach = fl / (ms * 1e-3) / 1e12
+            conv_in = (rin or {}).get('conv3x3_fwd_dgrad', {})
             out['roofline'] = {'bound': 'mfma', 'kernel': 'gemm_nt_kernel (conv3x3 implicit GEMM fwd+dgrad, fp32 MFMA 32x32x2)',
                                'achieved': round(ach, 2), 'peak': PEAK_MFMA_F32_TFLOPS, 'unit': 'TFLOP/s',
-                               'frac': round(ach / PEAK_MFMA_F32_TFLOPS, 4), 'traffic': None,
+                               'frac': round(ach / PEAK_MFMA_F32_TFLOPS, 4),
+                               'traffic': conv_in.get('hbm_bytes_per_launch'),
                                'avg_launch_us': round(ms / nl * 1e3, 2), 'launches_per_step': nl / n_ev,
                                'flop_per_step': fl / n_ev, 'event_timed_steps': n_ev}
+            if conv_in:
+                out['roofline']['traffic_how'] = (f"{rin['file']}: rocprofv3 --pmc over this command, FETCH_SIZE x2 (gfx950 "
+                                                  'correction) + WRITE_SIZE, separate passes, mean over the conv fwd+dgrad '
+                                                  'launches of a step')
+                out['roofline']['algorithmic_bytes_per_launch'] = conv_in.get('algorithmic_bytes_per_launch')
+                out['roofline']['mfma_pipe_busy_frac'] = conv_in.get('mfma_busy_frac')
             if 'conv3x3_wgrad' in allk:
                 ms, n, fl = allk['conv3x3_wgrad']
                 a = fl / (ms * 1e-3) / 1e12
@@ -222,6 +363,10 @@ def main():
                                          'achieved': round(a, 2), 'peak': PEAK_MFMA_F32_TFLOPS, 'unit': 'TFLOP/s',
                                          'frac': round(a / PEAK_MFMA_F32_TFLOPS, 4),
                                          'how': f'{n_extra} extra untimed steps, same 3-stream schedule'}
+                wg_in = (rin or {}).get('conv3x3_wgrad', {})
+                if wg_in:
+                    out['roofline_wgrad']['traffic'] = wg_in.get('hbm_bytes_per_launch')
+                    out['roofline_wgrad']['mfma_pipe_busy_frac'] = wg_in.get('mfma_busy_frac')
             out['roofline']['note'] = (f'HIP events on the launch stream around every conv3x3 fwd/dgrad launch of {n_ev} of the '
                                        f'{args.steps} timed steps; the side-branch and wgrad streams run concurrently '
                                        '(roofline_isolated has the same kernels alone on the GPU)')
@@ -254,31 +399,44 @@ def main():
             if pool_ms is not None:
                 by = 4.0 * B * (2112 * H * W + H * W + g * g * 2112)
                 a = by / (pool_ms * 1e-3) / 1e9
-                # traffic: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, KiB units, gfx950 FETCH x2
-                # correction) on tools/pool_micro.py at this shape: profiles/r01_pmc_summary.csv
+                sm_in = (rin or {}).get('scatter_mean', {})
                 out['roofline_scatter_mean'] = {
                     'bound': 'hbm', 'kernel': 'sp_pool_fwd_kernel (superpixel scatter-mean over the materialised '
                                               '(HW x 2112) feature map; the step itself uses the fused upsample+scatter-mean)',
                     'achieved': round(a, 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': round(a / PEAK_HBM_GBS, 4),
                     'frac_of_measured_copy_6290': round(a / 6290.0, 4),
-                    'traffic': (3813814.1 * 2 + 19701.0) * 1024 if (B, H, g) == (4, 480, 24) else None,
+                    'traffic': sm_in.get('hbm_bytes_per_launch'),
+                    'traffic_how': (f"{rin['file']}: FETCH_SIZE x2 + WRITE_SIZE of sp_pool_fwd_kernel in the PMC passes over "
+                                    'this command') if sm_in else None,
                     'avg_launch_us': round(pool_ms * 1e3, 2), 'algorithmic_bytes': by}
         if use_dist:
             out['rank_time'] = rank_time              # spread of the per-rank wall time of the timed region
+            out['collective'] = {'backend': backend, 'ranks': dist.get_world_size(),
+                                 'what': 'bucketed all-reduce(sum) of the flat fp32 gradient buffer, 1/world folded into SGD',
+                                 'bucket_mb': args.bucket_mb}
         if world == 1 and not args.no_cpu_baseline:
-            v, cores, sample = orc.time_cpu_baseline(iters=2, warmup=1)
-            cpu = 'unknown CPU'
-            try:
-                with open('/proc/cpuinfo') as f:
-                    cpu = next(l.split(':', 1)[1].strip() for l in f if l.startswith('model name'))
-            except Exception:
-                pass
-            out['cpu_baseline'] = {'value': round(v, 4), 'unit': 'images/s', 'cores': cores, 'kind': 'port',
-                                   'sample': sample, 'host': f'{cpu}, {os.cpu_count()} logical cores'}
+            variants = {}
+            for name in ('faithful', 'label_map'):
+                v, cores, sample = orc.time_cpu_baseline(iters=5, warmup=3, variant=name)
+                variants[name] = {'value': round(v, 4), 'unit': 'images/s', 'cores': cores, 'sample': sample}
+            f = variants['faithful']
+            out['cpu_baseline'] = {'value': f['value'], 'unit': 'images/s', 'cores': f['cores'], 'kind': 'port',
+                                   'sample': f['sample'], 'host': host_cpu(),
+                                   'what': "oracle/wesup_oracle.py, variant 'faithful' = the reference's own algorithm "
+                                           '(dense sp_maps, incremental cat, dense mm; models/wesup.py:18-63,246-304,492-531 '
+                                           "+ backward); 'label_map' = the scatter-mean restatement of the same step",
+                                   'variants': variants}
         print(json.dumps(out), flush=True)
     if use_dist:
-        import torch.distributed as dist
         dist.destroy_process_group()
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = parse_args(argv)
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(self_launch(args, argv))
+    worker(args)
 
 
 if __name__ == '__main__':

@@ -201,11 +201,12 @@ int wesup_loss_fwd(const float* pred, const float* y_all, const int32_t* n_sp, c
 int wesup_loss_bwd(const float* pred, const float* y_all, const int32_t* n_sp, const int32_t* n_l,
                    const float* terms, const float* dloss, float eps, float prop_weight, float* dpred,
                    int B, int Kmax, int C, void* stream);
-/* generic _cross_entropy (models/wesup.py:66-96) on (n, C): out2[4] = {sum(-y log clamp(yhat)), #rows with sum(y) > 0,
- * loss = sum/#rows (0 if no row is labelled), 0} */
-int wesup_cross_entropy_fwd(const float* y_hat, const float* y_true, float eps, float* out2, int n, int C, void* stream);
-int wesup_cross_entropy_bwd(const float* y_hat, const float* y_true, const float* out2, const float* dloss,
-                            float eps, float* dy_hat, int n, int C, void* stream);
+/* generic _cross_entropy (models/wesup.py:66-96) on (n, C): out2[4] = {sum(-y log clamp(yhat) [* class_weights[c]]),
+ * #rows with sum(y) > 0, loss = sum/#rows (0 if no row is labelled), 0}; class_weights (C,) or NULL (models/wesup.py:93-94) */
+int wesup_cross_entropy_fwd(const float* y_hat, const float* y_true, const float* class_weights, float eps, float* out2,
+                            int n, int C, void* stream);
+int wesup_cross_entropy_bwd(const float* y_hat, const float* y_true, const float* class_weights, const float* out2,
+                            const float* dloss, float eps, float* dy_hat, int n, int C, void* stream);
 /* torch.optim.SGD step (models/wesup.py:445-451): g' = g*grad_scale + wd*p; v = first ? g' : mu*v + g'; p -= lr*v */
 int wesup_sgd_step(float* p, const float* g, float* v, size_t n, float lr, float momentum, float weight_decay,
                    float grad_scale, int first_step, void* stream);

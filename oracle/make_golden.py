@@ -62,6 +62,106 @@ def _install_standins():
         sys.modules[name] = _Anything(name)
 
 
+def _reference_case(ref, orc, synth, out_dir, name, H, W, g, mode, fs, seed, compact=False):
+    """Run the real reference (models/wesup.py:18-139,263-304,492-531 + autograd backward) on one seeded synthetic
+    image and store its outputs.  compact=True (full-size cases): the inputs are NOT stored (the test regenerates
+    them from wesup_amd.synth with the same seeds; a checksum is kept) and the big dense outputs are reduced to
+    bit-packed / strided samples, so that a 480x480 fixture stays at a few hundred KB."""
+    weights = orc.make_weights(seed, feat_scale=fs)
+    model = ref.WESUP()
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in weights.items()})
+    model.train()
+    img = synth.synth_image(seed, H, W)
+    seg = synth.voronoi_labels(seed, H, W, g)
+    if mode == 'full':
+        mask = synth.pixel_mask(seed, H, W)
+    elif mode == 'point_tie':
+        mask = synth.point_mask(seed, seg, 0.3, 2, tie_every=2)
+    elif mode == 'point20':
+        mask = synth.point_mask(seed, seg, 0.2, 2)               # the benchmark's 20 % point-labelled superpixels
+    else:
+        mask = synth.point_mask(seed, seg, 0.25, 2)
+    t_img = torch.from_numpy(img).unsqueeze(0)
+    t_seg = torch.from_numpy(seg).long()
+    t_mask = torch.from_numpy(mask).long()
+
+    sp_maps, sp_labels = ref._preprocess_superpixels(t_seg, t_mask, epsilon=1e-7)
+    # ordering implied by the maps: argmax over N recovers new row per pixel
+    new_row = sp_maps.argmax(dim=0)
+    pred = model((t_img, sp_maps))
+    sp_features = model.sp_features
+    sp_pred = model.sp_pred
+    fm = model.feature_maps.detach()
+
+    trainer = ref.WESUPTrainer.__new__(ref.WESUPTrainer)      # compute_loss only needs these:
+    trainer.model = model
+    trainer.kwargs = {**ref.WESUPConfig().to_dict(), 'epsilon': 1e-7}
+    trainer.xentropy = ref._cross_entropy
+    metrics = {}
+    pixel_mask = t_mask.unsqueeze(0)
+    sp_feat_keep = sp_features.detach().clone()
+    sp_pred_keep = sp_pred.detach().clone()
+    loss = trainer.compute_loss(pred, (pixel_mask, sp_labels), metrics=metrics)
+    n_l = sp_labels.size(0)
+    n = sp_pred_keep.size(0)
+    if n_l < n:
+        y_u = ref._label_propagate(sp_feat_keep, sp_labels, threshold=0.8)
+        f = sp_feat_keep
+        Wfull = torch.exp(-torch.einsum('ijk,ijk->ij', f - f.unsqueeze(1), f - f.unsqueeze(1)))
+        W_ul = Wfull[n_l:, :n_l]
+        max_sim, src = W_ul.max(dim=1)
+    else:
+        y_u = torch.zeros(0, 2)
+        W_ul = torch.zeros(0, n_l)
+        max_sim = torch.zeros(0)
+        src = torch.zeros(0, dtype=torch.long)
+    model.zero_grad()
+    if loss.requires_grad:
+        loss.backward()
+    grads = {k: (p.grad.detach().clone() if p.grad is not None else torch.zeros_like(p))
+             for k, p in model.named_parameters()}
+    post_pred = trainer.postprocess(pred.detach(), None)
+
+    fx = dict(
+        H=H, W=W, g=g, seed=seed, feat_scale=fs, mode=mode,
+        sp_labels=sp_labels.numpy(), new_row=new_row.numpy().astype(np.int16),
+        sp_maps_rowsum=sp_maps.sum(dim=(1, 2)).numpy(),
+        sp_maps_max=sp_maps.amax(dim=(1, 2)).numpy(),
+        fm_chan_mean=fm.mean(dim=(1, 2)).numpy(),
+        sp_features=sp_feat_keep.numpy(), sp_pred=sp_pred_keep.numpy(),
+        max_sim=max_sim.numpy(), src=src.numpy().astype(np.int32),
+        y_u=y_u.numpy(), loss=np.float32(loss.item()),
+        labeled_sp_ratio=np.float64(metrics.get('labeled_sp_ratio', -1)),
+        propagated_labels=np.float64(metrics.get('propagated_labels', -1)),
+        propagate_loss=np.float64(metrics.get('propagate_loss', -1)),
+    )
+    if compact:
+        # inputs come from wesup_amd.synth (seeded numpy); the checksums make a drifted generator fail loudly
+        fx.update(img_sum=np.float64(img.astype(np.float64).sum()), seg_sum=np.int64(seg.astype(np.int64).sum()),
+                  mask_sum=np.int64(mask.sum()),
+                  fm_sample=fm[::97, ::23, ::29].numpy(), pred_sample=pred.detach()[0, ::7, ::11].numpy(),
+                  post_pred_bits=np.packbits(post_pred.numpy().astype(np.uint8), axis=None),
+                  W_ul_rowsum=W_ul.sum(dim=1).numpy())
+        all_keys = list(grads)
+    else:
+        fx.update(img=img, seg=seg.astype(np.int16), mask=np.packbits(mask, axis=None), mask_shape=np.array(mask.shape),
+                  fm_sample=fm[::37, ::5, ::7].numpy(), pred=pred.detach().numpy(),
+                  post_pred=post_pred.numpy().astype(np.int8), W_ul=W_ul.numpy())
+        all_keys = ['backbone.0.weight', 'backbone.0.bias', 'backbone.12.weight', 'backbone.28.weight',
+                    'backbone.28.bias', 'side_conv0.weight', 'side_conv0.bias', 'side_conv576.weight',
+                    'side_conv1856.weight', 'fc_layers.0.weight', 'fc_layers.2.bias', 'fc_layers.4.weight',
+                    'classifier.0.weight', 'classifier.0.bias']
+    for k in all_keys:
+        gk = grads[k]
+        fx['gnorm.' + k] = np.float64(gk.double().norm().item())
+        fx['gsamp.' + k] = gk.flatten()[::max(1, gk.numel() // 64)][:64].numpy()
+        if compact:
+            fx['gmax.' + k] = np.float64(gk.double().abs().max().item())
+    np.savez_compressed(os.path.join(out_dir, name + '.npz'), **fx)
+    print(f'{name}: N={n} n_l={n_l} loss={loss.item():.6f} propagated={metrics.get("propagated_labels")}'
+          f' ploss={metrics.get("propagate_loss")}')
+
+
 def main():
     _install_standins()
     sys.path.insert(0, REF)
@@ -82,85 +182,8 @@ def main():
         ('c96x80_point', 96, 80, 7, 'point', 0.05, 5),
         ('c64_identical', 64, 64, 6, 'identical', 0.0, 6),
     ]
-    for name, H, W, g, mode, fs, seed in cases:
-        weights = orc.make_weights(seed, feat_scale=fs)
-        model = ref.WESUP()
-        model.load_state_dict({k: torch.from_numpy(v) for k, v in weights.items()})
-        model.train()
-        img = synth.synth_image(seed, H, W)
-        seg = synth.voronoi_labels(seed, H, W, g)
-        if mode == 'full':
-            mask = synth.pixel_mask(seed, H, W)
-        elif mode == 'point_tie':
-            mask = synth.point_mask(seed, seg, 0.3, 2, tie_every=2)
-        else:
-            mask = synth.point_mask(seed, seg, 0.25, 2)
-        t_img = torch.from_numpy(img).unsqueeze(0)
-        t_seg = torch.from_numpy(seg).long()
-        t_mask = torch.from_numpy(mask).long()
-
-        sp_maps, sp_labels = ref._preprocess_superpixels(t_seg, t_mask, epsilon=1e-7)
-        # ordering implied by the maps: argmax over N recovers new row per pixel
-        new_row = sp_maps.argmax(dim=0)
-        pred = model((t_img, sp_maps))
-        sp_features = model.sp_features
-        sp_pred = model.sp_pred
-        fm = model.feature_maps.detach()
-
-        trainer = ref.WESUPTrainer.__new__(ref.WESUPTrainer)      # compute_loss only needs these:
-        trainer.model = model
-        trainer.kwargs = {**ref.WESUPConfig().to_dict(), 'epsilon': 1e-7}
-        trainer.xentropy = ref._cross_entropy
-        metrics = {}
-        pixel_mask = t_mask.unsqueeze(0)
-        sp_feat_keep = sp_features.detach().clone()
-        sp_pred_keep = sp_pred.detach().clone()
-        loss = trainer.compute_loss(pred, (pixel_mask, sp_labels), metrics=metrics)
-        n_l = sp_labels.size(0)
-        n = sp_pred_keep.size(0)
-        if n_l < n:
-            y_u = ref._label_propagate(sp_feat_keep, sp_labels, threshold=0.8)
-            f = sp_feat_keep
-            Wfull = torch.exp(-torch.einsum('ijk,ijk->ij', f - f.unsqueeze(1), f - f.unsqueeze(1)))
-            W_ul = Wfull[n_l:, :n_l]
-            max_sim, src = W_ul.max(dim=1)
-        else:
-            y_u = torch.zeros(0, 2)
-            W_ul = torch.zeros(0, n_l)
-            max_sim = torch.zeros(0)
-            src = torch.zeros(0, dtype=torch.long)
-        model.zero_grad()
-        if loss.requires_grad:
-            loss.backward()
-        grads = {k: (p.grad.detach().clone() if p.grad is not None else torch.zeros_like(p))
-                 for k, p in model.named_parameters()}
-        post_pred = trainer.postprocess(pred.detach(), None)
-
-        fx = dict(
-            H=H, W=W, g=g, seed=seed, feat_scale=fs, mode=mode,
-            img=img, seg=seg.astype(np.int16), mask=np.packbits(mask, axis=None), mask_shape=np.array(mask.shape),
-            sp_labels=sp_labels.numpy(), new_row=new_row.numpy().astype(np.int16),
-            sp_maps_rowsum=sp_maps.sum(dim=(1, 2)).numpy(),
-            sp_maps_max=sp_maps.amax(dim=(1, 2)).numpy(),
-            fm_chan_mean=fm.mean(dim=(1, 2)).numpy(), fm_sample=fm[::37, ::5, ::7].numpy(),
-            sp_features=sp_feat_keep.numpy(), sp_pred=sp_pred_keep.numpy(),
-            pred=pred.detach().numpy(), post_pred=post_pred.numpy().astype(np.int8),
-            W_ul=W_ul.numpy(), max_sim=max_sim.numpy(), src=src.numpy().astype(np.int32),
-            y_u=y_u.numpy(), loss=np.float32(loss.item()),
-            labeled_sp_ratio=np.float64(metrics.get('labeled_sp_ratio', -1)),
-            propagated_labels=np.float64(metrics.get('propagated_labels', -1)),
-            propagate_loss=np.float64(metrics.get('propagate_loss', -1)),
-        )
-        for k in ['backbone.0.weight', 'backbone.0.bias', 'backbone.12.weight', 'backbone.28.weight',
-                  'backbone.28.bias', 'side_conv0.weight', 'side_conv0.bias', 'side_conv576.weight',
-                  'side_conv1856.weight', 'fc_layers.0.weight', 'fc_layers.2.bias', 'fc_layers.4.weight',
-                  'classifier.0.weight', 'classifier.0.bias']:
-            gk = grads[k]
-            fx['gnorm.' + k] = np.float64(gk.double().norm().item())
-            fx['gsamp.' + k] = gk.flatten()[::max(1, gk.numel() // 64)][:64].numpy()
-        np.savez_compressed(os.path.join(out_dir, name + '.npz'), **fx)
-        print(f'{name}: N={n} n_l={n_l} loss={loss.item():.6f} propagated={metrics.get("propagated_labels")}'
-              f' ploss={metrics.get("propagate_loss")}')
+    for case in cases:
+        _reference_case(ref, orc, synth, out_dir, *case)
 
     # pixel-wise inference (models/wesup.py:307-400), SURVEY.md 8(f) row 3
     weights = orc.make_weights(4, feat_scale=0.3)
@@ -271,3 +294,23 @@ def tiles_golden():
 
 if __name__ == '__main__' and 'tiles' in sys.argv[1:]:
     tiles_golden()
+
+
+def full_size_golden():
+    """BASELINE configs[0] at full size through the REAL reference: one 480x480 image, 196 superpixels (g = 14),
+    20 % point-labelled -- and the same image at the benchmark's 576 superpixels (g = 24, one image of configs[1])
+    -> tests/golden/c480_g14.npz, c480_g24.npz.  ~10 s and a few GB each on the build container's CPU
+    (the reference materialises 184 / 531 MB of dense sp_maps and re-copies the growing (C,H,W) map 12 times)."""
+    _install_standins()
+    sys.path.insert(0, REF)
+    import models.wesup as ref
+    from oracle import wesup_oracle as orc
+    from wesup_amd import synth
+    out_dir = os.path.join(ROOT, 'tests', 'golden')
+    torch.set_num_threads(8)
+    _reference_case(ref, orc, synth, out_dir, 'c480_g14', 480, 480, 14, 'point20', 1.5, 21, compact=True)
+    _reference_case(ref, orc, synth, out_dir, 'c480_g24', 480, 480, 24, 'point20', 1.5, 22, compact=True)
+
+
+if __name__ == '__main__' and 'full' in sys.argv[1:]:
+    full_size_golden()

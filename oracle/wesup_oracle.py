@@ -353,9 +353,39 @@ def dice(S, G, epsilon=EPS):
     return d.mean().item()
 
 
-def time_cpu_baseline(H=480, W=480, g=14, iters=2, warmup=1, seed=0, threads=None):
-    """Timed CPU leg for bench.py: config c1 (1 image 480x480, ~200 SP),
-    forward + loss + backward with this oracle.  Returns (img/s, cores, sample)."""
+def forward_image_faithful(w, img, sp_maps):
+    """The reference's forward AS IT EXECUTES IT (models/wesup.py:246-304): dense row-normalised (N,H,W) superpixel
+    maps, the (C,H,W) feature map grown by ``torch.cat`` after every conv layer (:258-261, the quadratic re-copy),
+    pooling as the dense ``torch.mm`` (:283-285), paint-back by ``argmax`` over the maps and a loop of N masked writes
+    (:295-302).  img (3,H,W); sp_maps (N,H,W).  Used as the "faithful" CPU baseline variant."""
+    H, W = img.shape[-2:]
+    fm = None
+    h = img.unsqueeze(0)
+    for li, (idx, off) in enumerate(zip(CONV_IDX, SIDE_OFF)):
+        y = F.conv2d(h, w[f'backbone.{idx}.weight'], w[f'backbone.{idx}.bias'], padding=1)
+        o = F.conv2d(y.clone(), w[f'side_conv{off}.weight'], w[f'side_conv{off}.bias'])            # :253
+        o = F.interpolate(o, (H, W), mode='bilinear', align_corners=True)                           # :254-255
+        fm = o.squeeze() if fm is None else torch.cat((fm, o.squeeze()))                            # :257-261
+        h = F.relu(y)
+        if POOL_AFTER[li]:
+            h = F.max_pool2d(h, 2, 2)          # the 13th pool runs too, its output is dropped (:279)
+    n = sp_maps.size(0)
+    x = torch.mm(sp_maps.view(n, -1), fm.view(fm.size(0), -1).t())                                  # :281-285
+    feats, sp_pred = mlp_head(w, x)                                                                 # :288-292
+    ids = sp_maps.view(n, H, W).argmax(dim=0)                                                       # :295
+    pred = torch.zeros(H, W, sp_pred.size(1))
+    for sp_idx in range(int(ids.max()) + 1):                                                        # :301-302
+        pred[ids == sp_idx] = sp_pred[sp_idx]
+    return dict(fm=fm, sp_features=feats, sp_pred=sp_pred, pred=pred[..., 1])
+
+
+def time_cpu_baseline(H=480, W=480, g=14, iters=5, warmup=3, seed=0, threads=None, variant='label_map'):
+    """Timed CPU leg for bench.py: config c1 (1 image 480x480, ~200 SP), forward + loss + backward with this oracle.
+    variant 'label_map': the label-map restatement (scatter-mean, no dense maps);
+    variant 'faithful': the reference's own algorithm (_preprocess_superpixels with its Python loop and dense maps,
+    dense mm pooling, incremental cat, argmax paint-back), i.e. what ``train_one_iteration`` of the reference costs on
+    this host (models/base.py:192-207 without SLIC and the optimiser step).
+    Returns (img/s, threads, sample description)."""
     import os
     from wesup_amd import synth
     if threads is None:
@@ -365,17 +395,26 @@ def time_cpu_baseline(H=480, W=480, g=14, iters=2, warmup=1, seed=0, threads=Non
     weights = make_weights(seed, feat_scale=0.05)
     imgs, labs, pts, _ = synth.make_batch(seed, 1, H, W, g)
     w = to_torch(weights, requires_grad=True)
+    t_img, t_seg, t_pts = torch.as_tensor(imgs), torch.as_tensor(labs).long(), torch.as_tensor(pts).long()
     ts = []
     for it in range(warmup + iters):
         for v in w.values():
             v.grad = None
         t0 = time.perf_counter()
-        loss, _, _ = batch_loss(w, torch.as_tensor(imgs), torch.as_tensor(labs).long(), torch.as_tensor(pts).long())
+        if variant == 'faithful':
+            sp_maps, sp_labels = preprocess_superpixels_dense(t_seg[0], t_pts[0])
+            o = forward_image_faithful(w, t_img[0], sp_maps)
+            loss = compute_loss(o['sp_pred'], o['sp_features'], sp_labels)
+        else:
+            loss, _, _ = batch_loss(w, t_img, t_seg, t_pts)
         loss.backward()
         ts.append(time.perf_counter() - t0)
     ts = ts[warmup:]
     med = sorted(ts)[len(ts) // 2]
-    sample = f'{iters} timed fwd+loss+bwd steps of 1 image {H}x{W}, {g*g} superpixels (config c1), median'
+    what = ('preprocess (dense maps) + fwd (cat, dense mm) + loss + bwd' if variant == 'faithful'
+            else 'label-map preprocess + fwd (scatter-mean) + loss + bwd')
+    sample = (f'{iters} timed steps after {warmup} warm-up, {what}, 1 image {H}x{W}, {g*g} superpixels (config c1), '
+              f'median {med:.2f} s')
     return 1.0 / med, threads, sample
 
 

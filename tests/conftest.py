@@ -15,3 +15,20 @@ def pytest_configure(config):
 @pytest.fixture(scope='session')
 def golden_dir():
     return os.path.join(ROOT, 'tests', 'golden')
+
+
+def load_full_size_case(golden_dir, name):
+    """Compact full-size golden (oracle/make_golden.py full_size_golden): the reference's outputs plus the seeds of
+    its inputs, which are regenerated here from wesup_amd.synth and verified against the stored checksums."""
+    import numpy as np
+    from wesup_amd import synth
+    fx = dict(np.load(os.path.join(golden_dir, name + '.npz')))
+    H, W, g, seed = int(fx['H']), int(fx['W']), int(fx['g']), int(fx['seed'])
+    assert str(fx['mode']) == 'point20'
+    fx['img'] = synth.synth_image(seed, H, W)
+    fx['seg'] = synth.voronoi_labels(seed, H, W, g)
+    fx['mask'] = synth.point_mask(seed, fx['seg'], 0.2, 2)
+    assert float(fx['img'].astype(np.float64).sum()) == float(fx['img_sum']), 'synthetic image generator drifted'
+    assert int(fx['seg'].astype(np.int64).sum()) == int(fx['seg_sum']) and int(fx['mask'].sum()) == int(fx['mask_sum'])
+    fx['post_pred'] = np.unpackbits(fx['post_pred_bits'])[:H * W].reshape(1, H, W).astype(np.int8)
+    return fx

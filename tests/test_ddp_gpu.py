@@ -84,3 +84,76 @@ def test_two_ranks_equal_one_rank_on_the_whole_batch():
     for k in want:
         # the parameters moved by the same update up to the fp32 resolution of the parameter itself
         assert np.abs(got[k] - want[k]).max() <= 2e-7 * max(np.abs(want[k]).max(), 1e-3), k
+
+
+def _nan_worker(rank, world, port, out):
+    import torch.distributed as dist
+    from oracle import wesup_oracle as orc
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        tr = _make(orc.make_weights(5, feat_scale=0.03))
+        tr.enable_data_parallel(bucket_bytes=8 << 20)
+        imgs, labs, pts, pix = _batch()
+        sl = slice(2 * rank, 2 * rank + 2)
+        img = torch.from_numpy(imgs[sl]).clone()
+        if rank == 1:
+            img[0, 0, 3, 3] = float('nan')              # ONE rank sees a NaN loss
+        before = tr.model._flat.clone()
+        raised = False
+        try:
+            tr.train_one_iteration('train', img, torch.from_numpy(pix[sl]).long(), torch.from_numpy(pts[sl]).long(),
+                                   torch.from_numpy(labs[sl]))
+        except ValueError as ex:
+            raised = 'nan' in str(ex).lower()
+        torch.cuda.synchronize()
+        untouched = bool(torch.equal(before, tr.model._flat))
+        # the next iteration on clean data runs normally on both ranks (no stale reducer state)
+        tr.train_one_iteration('train', torch.from_numpy(imgs[sl]), torch.from_numpy(pix[sl]).long(),
+                               torch.from_numpy(pts[sl]).long(), torch.from_numpy(labs[sl]))
+        torch.cuda.synchronize()
+        moved = not bool(torch.equal(before, tr.model._flat))
+        out.put((rank, raised, untouched, moved, float(tr.model._flat.double().sum())))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_nan_on_one_rank_stops_every_rank_before_the_update():
+    """models/base.py:202-203 under data parallelism: the rank with the NaN loss AND its peer raise ValueError before
+    optimizer.step (the peer's own loss is finite, but the all-reduced gradients are not), nobody's weights move, and
+    the next clean iteration leaves both ranks with identical parameters."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_nan_worker, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(out.get(timeout=280) for _ in range(2))
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    for rank, raised, untouched, moved, _ in res:
+        assert raised and untouched and moved, res
+    assert res[0][4] == res[1][4]                       # replicas still agree bit for bit
+
+
+def test_bench_self_launch_two_ranks_one_gpu():
+    """`python bench.py --gpus 2` with no launcher around it: the parent spawns both ranks (here on the one card, gloo
+    carrying the exchange), rank 0 prints the one JSON line."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--rehearse-on-one-gpu', '--steps', '3',
+                        '--warmup', '1', '--batch', '1', '--size', '64', '--grid', '4', '--no-cpu-baseline',
+                        '--no-kernel-timing'], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == 2 and out['config']['global_batch'] == 2 and out['config']['parallelism'] == 'dp2'
+    assert out['collective']['ranks'] == 2 and out['rank_time']['max_s'] >= out['rank_time']['min_s'] > 0
+    assert out['value'] > 0 and 'custom shape' in out['config']['workload']

@@ -1,0 +1,200 @@
+"""Parity of the HIP training step AT THE HEADLINE SIZE (480x480), on a real MI355X.
+
+  * against outputs of the REAL reference at 480x480 (tests/golden/c480_g14.npz = BASELINE configs[0]: 196 superpixels;
+    c480_g24.npz = one image of configs[1]: 576 superpixels; made by oracle/make_golden.py full from
+    /root/reference/models/wesup.py:18-139,263-304,492-531 + autograd backward);
+  * against the CPU oracle at configs[1] EXACTLY (B = 4, 480x480, 576 superpixels, 20 % point-labelled): loss, metrics,
+    every integer output bit-exact, every parameter gradient against an fp64 evaluation (tests/_gradcheck.py);
+  * size-independent properties at the per-GPU shards of configs[3] (B = 4, 800x800, 1521 SP) and configs[4]
+    (B = 8, 1024x1024, 3025 SP).
+Bars: integer outputs bit-exact; fp32 tensors within 1e-4 relative (north_star)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from conftest import load_full_size_case          # noqa: E402
+import _gradcheck                                 # noqa: E402
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def rel_err(a, b):
+    a = torch.as_tensor(a).detach().double().cpu()
+    b = torch.as_tensor(b).detach().double().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+def make_trainer(weights, **kw):
+    from wesup_amd.models import initialize_trainer
+    from wesup_amd.utils.metrics import accuracy, dice
+    trainer = initialize_trainer('wesup', device='cuda:0', **kw)
+    trainer.model.load_state_dict({k: torch.from_numpy(v) for k, v in weights.items()})
+    trainer.optimizer, trainer.scheduler = trainer.get_default_optimizer()
+    trainer.metric_funcs = [accuracy, dice]
+    trainer.model.train()
+    trainer.tracker.train()
+    return trainer
+
+
+@pytest.mark.parametrize('name', ['c480_g14', 'c480_g24'])
+def test_step_matches_the_reference_at_480(golden_dir, name):
+    """The trainer's own path (preprocess -> forward -> compute_loss -> backward) on the reference's 480x480 inputs."""
+    from oracle import wesup_oracle as orc
+    from wesup_amd import ops
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    fx = load_full_size_case(golden_dir, name)
+    d = torch.device('cuda:0')
+    H, W = int(fx['H']), int(fx['W'])
+    weights = orc.make_weights(int(fx['seed']), feat_scale=float(fx['feat_scale']))
+    trainer = make_trainer(weights)
+    model = trainer.model
+    img = torch.from_numpy(fx['img'])[None]
+    mask = torch.from_numpy(fx['mask'].astype(np.int64))[None]
+    (x, sp_maps), (pixel_mask, sp_labels) = trainer.preprocess(img, mask, mask, torch.from_numpy(fx['seg'])[None])
+    meta = sp_maps.meta
+    meta.check()
+    K = int(fx['seg'].max()) + 1
+    n_l = fx['sp_labels'].shape[0]
+    # integer outputs of _preprocess_superpixels: bit-exact (models/wesup.py:18-63)
+    assert int(meta.n_sp[0]) == K and int(meta.n_l[0]) == n_l
+    assert sp_labels.size(0) == n_l and tuple(sp_labels.shape) == fx['sp_labels'].shape      # behaves like the (N_l, C) tensor
+    assert np.array_equal(sp_labels.cpu().numpy(), fx['sp_labels'])
+    assert np.array_equal(meta.new_row[0].cpu().numpy().reshape(H, W).astype(np.int16), fx['new_row'])
+    assert rel_err(1.0 / meta.area_new[0, :K].float(), fx['sp_maps_max']) < 1e-6
+
+    pred = model((x, sp_maps))
+    assert tuple(pred.shape) == (1, H, W)
+    assert rel_err(model.sp_features, fx['sp_features']) < TOL
+    assert rel_err(model.sp_pred, fx['sp_pred']) < TOL
+    assert rel_err(pred[0, ::7, ::11], fx['pred_sample']) < TOL
+    assert np.array_equal(trainer.postprocess(pred).cpu().numpy().astype(np.int8), fx['post_pred'])
+    fm = model.feature_maps
+    assert tuple(fm.shape) == (2112, H, W)
+    assert rel_err(fm.mean(dim=(1, 2)), fx['fm_chan_mean']) < TOL
+    assert rel_err(fm[::97, ::23, ::29], fx['fm_sample']) < TOL
+    del fm
+
+    feats_padded = model._padded[0].detach().clone()
+    metrics = {}
+    loss = trainer.compute_loss(pred, (pixel_mask, sp_labels), metrics=metrics)
+    host = trainer._read_back(loss, metrics, None)
+    assert abs(host['loss'] - float(fx['loss'])) <= TOL * abs(float(fx['loss']))
+    assert metrics['propagated_labels'] == float(fx['propagated_labels'])
+    assert abs(metrics['propagate_loss'] - float(fx['propagate_loss'])) <= TOL * abs(float(fx['propagate_loss']))
+    assert abs(metrics['labeled_sp_ratio'] - float(fx['labeled_sp_ratio'])) < 1e-7
+    y_all, src, sim = ops.propagate(feats_padded, meta, 0.8)
+    assert np.array_equal(src[0, n_l:K].cpu().numpy(), fx['src'])                 # argmax indices bit-exact
+    assert np.array_equal(y_all[0, n_l:K].cpu().numpy(), fx['y_u'])
+    assert rel_err(sim[0, n_l:K], fx['max_sim']) < TOL
+
+    loss.backward()
+    # every parameter gradient: norm against the reference's, elements against the reference's samples ...
+    for k in [k[6:] for k in fx if k.startswith('gnorm.')]:
+        g = model._grad_views[k]
+        ref_norm = float(fx['gnorm.' + k])
+        assert abs(g.double().norm().item() - ref_norm) <= 2e-4 * ref_norm + 1e-12, k
+        samp = g.flatten()[::max(1, g.numel() // 64)][:64].cpu().numpy()
+        assert np.abs(samp - fx['gsamp.' + k]).max() <= 3e-4 * float(fx['gmax.' + k]), k
+    # ... and against fp64 under the same ReLU / pooling decisions: 1e-4 of each tensor's max (or <= 2x torch fp32)
+    worst, n_named = _gradcheck.check_gradients(model, weights, fx['img'][None], fx['seg'][None], fx['mask'][None])
+    print(f'{name}: worst gradient error vs fp64 {worst:.2e}, {n_named} near-tie decisions differ')
+
+
+def test_config_c2_exactly_matches_the_oracle():
+    """BASELINE configs[1] as bench.py runs it: B = 4, 480x480, 576 superpixels, 20 % point-labelled, one full
+    train_one_iteration; against the CPU oracle's training step on the same inputs."""
+    from oracle import wesup_oracle as orc
+    from wesup_amd import synth, ops
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    d = torch.device('cuda:0')
+    B, H, W, g = 4, 480, 480, 24
+    weights = orc.make_weights(0, feat_scale=1.0)                  # features spread enough that only some rows propagate
+    imgs, labs, pts, pix = synth.make_batch(5, B, H, W, g)
+    ref_loss, ref_grads, ref_new, _, outs, mets = orc.train_step(weights, imgs, labs.astype(np.int64), pts.astype(np.int64))
+
+    trainer = make_trainer(weights, max_superpixels=g * g)
+    data = (torch.from_numpy(imgs).to(d), torch.from_numpy(pix).to(d), torch.from_numpy(pts).to(d), torch.from_numpy(labs).to(d))
+    trainer.train_one_iteration('train', *data)
+    model = trainer.model
+    meta = model._last_meta
+    hist = trainer.tracker.history
+    assert abs(hist['loss'][0] - ref_loss) <= TOL * abs(ref_loss)
+    assert hist['propagated_labels'][0] == np.mean([m['propagated_labels'] for m in mets])
+    assert 0 < hist['propagated_labels'][0] < 0.8 * g * g            # some rows propagate, some do not
+    assert abs(hist['propagate_loss'][0] - np.mean([m['propagate_loss'] for m in mets])) < 1e-5
+    assert abs(hist['labeled_sp_ratio'][0] - np.mean([m['labeled_sp_ratio'] for m in mets])) < 1e-7
+    P = torch.stack([o['pred'].detach().round().long() for o in outs])
+    G = torch.from_numpy(pix).long().argmax(dim=1)
+    assert abs(hist['accuracy'][0] - np.mean([orc.accuracy(P[b], G[b]) for b in range(B)])) < 1e-6
+    assert abs(hist['dice'][0] - np.mean([orc.dice(P[b], G[b]) for b in range(B)])) < 1e-6
+    # integer outputs, per image: row order, labels, propagation sources and pseudo labels
+    bufs = model.engine._last
+    feats = bufs.feats.view(B, meta.Kmax, -1)
+    y_all, src, sim = ops.propagate(feats.contiguous(), meta, 0.8)
+    for b in range(B):
+        pp = outs[b]['pp']
+        n, n_l = pp['K'], pp['n_l']
+        assert int(meta.n_sp[b]) == n and int(meta.n_l[b]) == n_l
+        assert torch.equal(meta.perm[b, :n].cpu().long(), pp['perm'])
+        assert torch.equal(meta.sp_labels[b, :n_l].cpu(), pp['sp_labels'])
+        y_u, _, max_sim, src_ref = orc.label_propagate(outs[b]['sp_features'], pp['sp_labels'], 0.8, return_aux=True)
+        near = (max_sim - 0.8).abs() < 1e-5                                  # a similarity within rounding of the threshold
+        assert rel_err(feats[b, :n], outs[b]['sp_features']) < TOL
+        assert torch.equal(src[b, n_l:n].cpu().long()[~near], src_ref[~near])
+        assert torch.equal(y_all[b, n_l:n].cpu()[~near], y_u[~near])
+        assert torch.equal(bufs.pred[b].round().long().cpu(), outs[b]['pred'].detach().round().long())
+    # every parameter gradient against fp64 (same decisions), and the SGD update against the oracle's
+    worst, n_named = _gradcheck.check_gradients(model, weights, imgs, labs, pts)
+    new = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    for k, v in ref_new.items():
+        assert rel_err(new[k], v) < 1e-5, k
+    print(f'c2: loss {hist["loss"][0]:.6f} (oracle {ref_loss:.6f}), worst gradient error vs fp64 {worst:.2e}, '
+          f'{n_named} near-tie decisions differ')
+
+
+@pytest.mark.parametrize('H,W,g,B', [(800, 800, 39, 4), (1024, 1024, 55, 8)])
+def test_per_gpu_shards_of_c4_and_c5(H, W, g, B):
+    """Per-GPU shards of BASELINE configs[3] (CRAG 800x800, 1521 SP, 16 images over 4 GPUs) and configs[4]
+    (1024x1024, 3025 SP, 64 images over 8 GPUs) at their real batch: size-independent properties of one full training
+    iteration -- finite loss in range, label ratio, conservation of pixels, gradients finite, non-zero and LINEAR in
+    the upstream gradient, SGD moves the weights, and the whole step is bitwise reproducible."""
+    from oracle import wesup_oracle as orc
+    from wesup_amd import synth
+    d = torch.device('cuda:0')
+    trainer = make_trainer(orc.make_weights(0, feat_scale=0.05), max_superpixels=g * g)
+    imgs, labs, pts, pix = synth.make_batch(2, B, H, W, g)
+    data = (torch.from_numpy(imgs).to(d), torch.from_numpy(pix).to(d), torch.from_numpy(pts).to(d), torch.from_numpy(labs).to(d))
+    del imgs, pix
+    before = trainer.model._flat.clone()
+    trainer.train_one_iteration('train', *data)
+    h = trainer.tracker.history
+    assert np.isfinite(h['loss'][0]) and 0.0 < h['loss'][0] < 10.0
+    assert 0.15 < h['labeled_sp_ratio'][0] < 0.25            # 20 % point-labelled superpixels
+    assert 0.0 <= h['accuracy'][0] <= 1.0 and 0.0 <= h['dice'][0] <= 1.0
+    meta = trainer.model._last_meta
+    meta.check()
+    assert int(meta.n_sp.min()) == g * g and int(meta.area_new.sum()) == B * H * W
+    gflat = trainer.model._flat_grad.clone()
+    assert bool(torch.isfinite(gflat).all()) and float(gflat.abs().sum()) > 0
+    assert not torch.equal(before, trainer.model._flat)     # SGD moved the weights
+    loss0 = h['loss'][0]
+    # bitwise reproducible: restore the weights, same batch again -> identical loss and gradient bits
+    trainer.model._flat.copy_(before)
+    trainer.optimizer._first = True
+    trainer.train_one_iteration('train', *data)
+    assert trainer.tracker.history['loss'][1] == loss0
+    assert torch.equal(trainer.model._flat_grad, gflat)
+    # linearity of backward in the upstream gradient
+    trainer.model._flat.copy_(before)
+    (x, sp_maps), target = trainer.preprocess(*data)
+    pred = trainer.model((x, sp_maps))
+    loss = trainer.compute_loss(pred, target, metrics={})
+    (2.0 * loss).backward()
+    assert rel_err(trainer.model._flat_grad, 2.0 * gflat) < 1e-5
+    trainer.model.engine.release_buffers()
+    torch.cuda.empty_cache()

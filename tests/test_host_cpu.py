@@ -116,11 +116,11 @@ def test_window_functions_match_reference():
         assert np.array_equal(patches.reshape(len(coords), -1).sum(1).astype(np.int64), g[f'patch_sums{i}'])
         preds = rs.rand(patches.shape[0], ps, ps).astype(np.float64)
         combined = T.combine_patches_to_image(preds, H, W)
-        assert combined.shape == (H, W) and np.array_equal(combined.astype(np.float32), g[f'combined{i}'])
+        assert combined.shape == (H, W) and np.allclose(combined, g[f'combined{i}'], rtol=0, atol=1e-6)
         if f'patches{i}' in g.files:
             assert np.array_equal(patches, g[f'patches{i}'])
             cc = T.combine_patches_to_image(patches.astype(np.float64), H, W)
-            assert np.array_equal(cc.astype(np.float32), g[f'combined_c{i}'])
+            assert cc.shape == (H, W, 3) and np.allclose(cc, g[f'combined_c{i}'], rtol=0, atol=1e-4)
     # the merge of the windows of an image is the image again (every pixel is an average of equal values)
     img = np.random.RandomState(0).randint(0, 256, size=(70, 53, 3)).astype(np.uint8)
     back = T.combine_patches_to_image(T.divide_image_to_patches(img, 32).astype(np.float64), 70, 53)

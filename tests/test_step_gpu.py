@@ -4,10 +4,14 @@ Checked against (a) the golden vectors produced by the real reference (tests/gol
 CPU oracle on the same seeded inputs.  Bar: integer outputs (row order, propagated labels, argmax
 source indices, rounded prediction) bit-exact; fp32 tensors within 1e-4 relative."""
 import os
+import sys
 
 import numpy as np
 import pytest
 import torch
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import _gradcheck          # noqa: E402
 
 pytestmark = pytest.mark.gpu
 
@@ -99,6 +103,8 @@ def test_step_matches_reference_golden(golden_dir, name, fused):
         # gradients against an fp64 evaluation is pinned in test_gradients_at_fp32_noise_level.
         samp = g.flatten()[::max(1, g.numel() // 64)][:64].cpu().numpy()
         assert np.abs(samp - fx['gsamp.' + k]).max() <= 1e-3 * (np.abs(fx['gsamp.' + k]).max() + 1e-12), k
+    if fused:               # ... which is this: vs fp64 under the GPU's own ReLU / pooling decisions, 1e-4 of the tensor's max
+        _gradcheck.check_gradients(model, weights, fx['img'][None], fx['seg'][None].astype(np.int64), fx['mask'][None])
 
 
 def test_reference_signature_dense_sp_maps(golden_dir):
@@ -171,8 +177,8 @@ def test_batched_step_matches_oracle():
         assert abs(hist['accuracy'][0] - np.mean([orc.accuracy(P[b], G[b]) for b in range(B)])) < 1e-6
         assert abs(hist['dice'][0] - np.mean([orc.dice(P[b], G[b]) for b in range(B)])) < 1e-6
         grads = {k: trainer.model._grad_views[k].clone() for k in ref_grads}
-        for k, g in ref_grads.items():
-            assert rel_err(grads[k], g) < 3e-4, k
+        if rep == 0:        # every parameter gradient vs fp64 under the GPU's ReLU / pooling decisions: 1e-4 of its max
+            _gradcheck.check_gradients(trainer.model, weights, imgs, segs, pts)
         new = {k: v.detach().cpu() for k, v in trainer.model.state_dict().items()}
         for k, v in ref_new.items():
             assert rel_err(new[k], v) < 1e-5, k

@@ -1,0 +1,49 @@
+"""Driver for per-layer PMC collection: every conv3x3 layer of the bench shape (B=4, 480x480) x {fwd, dgrad, wgrad},
+each launched `reps` times in a fixed order, with a manifest of that order so that tools/roofline_inputs.py can map
+the dispatches of the rocprofv3 counter file back to (layer, pass).
+
+  rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d OUT -- python3 tools/layer_pmc.py MANIFEST.json
+"""
+import json
+import os
+import sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from wesup_amd import ops
+from wesup_amd.engine import CONV_CH, POOL_AFTER
+
+d = torch.device('cuda:0')
+B, H, W = 4, 480, 480
+reps = 3
+manifest = {'shape': [B, H, W], 'reps': reps, 'order': []}     # order: [layer, pass, flop] per GEMM launch group
+h, w = H, W
+for l, (ci, co) in enumerate(CONV_CH):
+    cin = 4 if l == 0 else ci
+    x = torch.randn(B, h, w, cin, device=d)
+    wt = torch.randn(co, ci, 3, 3, device=d) * 0.02
+    bias = torch.randn(co, device=d)
+    dy = torch.randn(B, h, w, co, device=d)
+    wf, wd = ops.pack_conv3x3_weight(wt, need_dgrad=(l > 0))
+    y = torch.empty(B, h, w, co, device=d)
+    dx = torch.empty(B, h, w, cin, device=d)
+    dw = torch.empty(co, ci, 3, 3, device=d)
+    db = torch.empty(co, device=d)
+    fl = 2.0 * B * h * w * ci * co * 9
+    for _ in range(reps):
+        ops.conv3x3_fwd(x, wf, bias, co, relu_in=(l > 0), out=y)
+    manifest['order'].append([l, 'fwd', fl])
+    if l > 0:
+        for _ in range(reps):
+            ops.conv3x3_dgrad(dy, wd, ci, mask_src=x, out=dx, accumulate=True)
+        manifest['order'].append([l, 'dgrad', fl])
+    for _ in range(reps):
+        ops.conv3x3_wgrad(x, dy, ci, relu_in=(l > 0), dw=dw, db=db)
+    manifest['order'].append([l, 'wgrad', fl])
+    torch.cuda.synchronize()
+    if POOL_AFTER[l]:
+        h, w = h // 2, w // 2
+    del x, wt, dy, y, dx
+if len(sys.argv) > 1:
+    with open(sys.argv[1], 'w') as f:
+        json.dump(manifest, f)
+print('layer_pmc done:', len(manifest['order']), 'launch groups')

@@ -1,0 +1,150 @@
+"""Builds profiles/rNN_roofline_inputs.json and profiles/rNN_layer_mfma.csv from the rocprofv3 --pmc passes that
+tools/collect_profiles.sh ran.  bench.py reads the JSON for `roofline.traffic`; nothing in it is typed by hand.
+
+  python tools/roofline_inputs.py OUT_DIR ROUND > summary
+
+Inputs (all under OUT_DIR):
+  pmc_bench_fetch/, pmc_bench_write/, pmc_bench_mfma/, pmc_bench_busy/ : counter passes over `bench.py` itself
+      (FETCH_SIZE; WRITE_SIZE; SQ_VALU_MFMA_BUSY_CYCLES; GRBM_GUI_ACTIVE -- passes of their own, MI355X_MICROARCH.md)
+  pmc_layer_mfma/, pmc_layer_busy/ + layer_manifest.json : the same two MFMA counters over tools/layer_pmc.py
+
+Conventions (MI355X_MICROARCH.md, HBM / rocprofv3 section): FETCH_SIZE and WRITE_SIZE are in KiB, summed over the
+XCDs; gfx950 FETCH_SIZE under-reports wide streaming reads 2x, hence HBM bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024.
+MFMA pipe utilisation = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs * GRBM_GUI_ACTIVE / 8 XCDs)  (ROCm 7.2 has no gfx950
+derived-counter section, so the ratio is formed by hand).
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import re
+import sys
+
+
+def read_pass(d):
+    """[(dispatch_id, kernel, counter, value)] with the per-XCD / per-SE rows of a dispatch summed."""
+    acc = collections.OrderedDict()
+    for f in glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True):
+        for r in csv.DictReader(open(f)):
+            k = (int(r['Dispatch_Id']), r['Kernel_Name'], r['Counter_Name'])
+            acc[k] = acc.get(k, 0.0) + float(r['Counter_Value'])
+    return [(k[0], k[1], k[2], v) for k, v in sorted(acc.items())]
+
+
+def klass(kernel):
+    """conv3x3 fwd+dgrad | conv3x3 wgrad | scatter_mean | None"""
+    m = re.search(r'gemm_nt_kernel<([^>]*)>', kernel)
+    if m:
+        mode = int(m.group(1).split(',')[5])
+        return 'conv3x3_fwd_dgrad' if mode in (1, 2) else None
+    m = re.search(r'gemm_tn_kernel<([^>]*)>', kernel)
+    if m:
+        mode = int(m.group(1).split(',')[4])
+        return 'conv3x3_wgrad' if mode in (1, 2) else None
+    if kernel.startswith('sp_pool_fwd_kernel'):
+        return 'scatter_mean'
+    return None
+
+
+def per_class(rows, counter):
+    tot, n = collections.Counter(), collections.Counter()
+    for _, kern, ctr, v in rows:
+        c = klass(kern)
+        if c and ctr == counter:
+            tot[c] += v
+            n[c] += 1
+    return tot, n
+
+
+def main():
+    out_dir, rnd = sys.argv[1], sys.argv[2]
+    B, H, W, N = 4, 480, 480, 576
+    res = {'round': rnd, 'shape': {'batch': B, 'H': H, 'W': W, 'superpixels': N},
+           'how': 'rocprofv3 --pmc passes over `python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline` (one counter '
+                  'group per pass, no trace domain beside it); per-launch means over every launch of the kernel class in '
+                  'the run; bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950 FETCH_SIZE correction)'}
+    fetch, nf = per_class(read_pass(os.path.join(out_dir, 'pmc_bench_fetch')), 'FETCH_SIZE')
+    write, nw = per_class(read_pass(os.path.join(out_dir, 'pmc_bench_write')), 'WRITE_SIZE')
+    mfma, nm = per_class(read_pass(os.path.join(out_dir, 'pmc_bench_mfma')), 'SQ_VALU_MFMA_BUSY_CYCLES')
+    busy, nb = per_class(read_pass(os.path.join(out_dir, 'pmc_bench_busy')), 'GRBM_GUI_ACTIVE')
+    # algorithmic bytes of the implicit GEMMs per step at this shape: read x once + write y once (+ weights), per layer
+    from_layers = conv_algorithmic_bytes(B, H, W)
+    for c in ('conv3x3_fwd_dgrad', 'conv3x3_wgrad', 'scatter_mean'):
+        e = {}
+        if nf[c] and nw[c]:
+            e['launches_counted'] = nf[c]
+            e['fetch_kib_per_launch'] = fetch[c] / nf[c]
+            e['write_kib_per_launch'] = write[c] / nw[c]
+            e['hbm_bytes_per_launch'] = (2.0 * fetch[c] / nf[c] + write[c] / nw[c]) * 1024.0
+        if nm[c] and nb[c]:
+            e['mfma_busy_frac'] = mfma[c] / (1024.0 * busy[c] / 8.0) if busy[c] else None
+        if c in from_layers:
+            e['algorithmic_bytes_per_launch'] = from_layers[c]
+        res[c] = e
+    res['scatter_mean']['algorithmic_bytes_per_launch'] = 4.0 * B * (2112 * H * W + H * W + N * 2112)
+    with open(os.path.join('profiles', f'{rnd}_roofline_inputs.json'), 'w') as f:
+        json.dump(res, f, indent=1)
+    print(json.dumps(res, indent=1))
+
+    # ---- per-layer table: 13 layers x {fwd, dgrad, wgrad}: MFMA pipe busy, FLOP-weighted summary
+    man_path = os.path.join(out_dir, 'layer_manifest.json')
+    if not os.path.exists(man_path):
+        return
+    man = json.load(open(man_path))
+    reps = man['reps']
+
+    def main_launches(d, counter):
+        rows = [(i, k, v) for i, k, c, v in read_pass(d) if c == counter and klass(k) in ('conv3x3_fwd_dgrad', 'conv3x3_wgrad')]
+        return [v for _, _, v in sorted(rows)]
+    m = main_launches(os.path.join(out_dir, 'pmc_layer_mfma'), 'SQ_VALU_MFMA_BUSY_CYCLES')
+    g = main_launches(os.path.join(out_dir, 'pmc_layer_busy'), 'GRBM_GUI_ACTIVE')
+    assert len(m) == len(g) == reps * len(man['order']), (len(m), len(g), reps * len(man['order']))
+    lines = ['layer,pass,gflop,mfma_busy_cycles,kernel_cycles,mfma_pipe_busy_frac,tflops_at_counter_clock']
+    wsum = collections.Counter()
+    wfl = collections.Counter()
+    for gi, (layer, pas, fl) in enumerate(man['order']):
+        mm = sum(m[gi * reps + 1:(gi + 1) * reps]) / (reps - 1)          # first launch of a group = warm-up
+        cyc = sum(g[gi * reps + 1:(gi + 1) * reps]) / (reps - 1) / 8.0
+        frac = mm / (1024.0 * cyc)
+        lines.append(f'{layer},{pas},{fl / 1e9:.2f},{mm:.0f},{cyc:.0f},{frac:.4f},')
+        wsum[pas] += frac * fl
+        wfl[pas] += fl
+    for pas in ('fwd', 'dgrad', 'wgrad'):
+        lines.append(f'all,{pas},{wfl[pas] / 1e9:.2f},,,{wsum[pas] / wfl[pas]:.4f},  # FLOP-weighted')
+    tot = sum(wsum.values()) / sum(wfl.values())
+    lines.append(f'all,all,{sum(wfl.values()) / 1e9:.2f},,,{tot:.4f},  # FLOP-weighted over 13 layers x 3 passes')
+    with open(os.path.join('profiles', f'{rnd}_layer_mfma.csv'), 'w') as f:
+        f.write('# MFMA pipe busy per conv3x3 layer and pass at the bench shape (B=4, 480x480), kernels alone on the GPU:\n'
+                '# SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE/8), rocprofv3 --pmc over tools/layer_pmc.py (two passes),\n'
+                '# mean of the launches after the first of each group; the main GEMM launch only (stream-K fix-up / split-K reduce\n'
+                '# launches carry no MFMA and are listed in the kernel-stats file).  SURVEY.md 8(d).\n')
+        f.write('\n'.join(lines) + '\n')
+    print('\n'.join(lines))
+
+
+def conv_algorithmic_bytes(B, H, W):
+    """Mean algorithmic HBM bytes per launch of the two conv kernel classes over one step: every operand read once,
+    every result written once (fwd: x, w, y; dgrad: dy, w, [mask], dx read-modify-write; wgrad: x, dy, dw)."""
+    ch = [(3, 64), (64, 64), (64, 128), (128, 128), (128, 256), (256, 256), (256, 256), (256, 512), (512, 512), (512, 512),
+          (512, 512), (512, 512), (512, 512)]
+    pool = [False, True, False, True, False, False, True, False, False, True, False, False, False]
+    h, w = H, W
+    nt, tn, n_nt, n_tn = 0.0, 0.0, 0, 0
+    for l, (ci, co) in enumerate(ch):
+        px = B * h * w
+        cin = 4 if l == 0 else ci
+        nt += 4.0 * (px * cin + 9 * cin * co + px * co)
+        n_nt += 1
+        if l > 0:
+            nt += 4.0 * (px * co + 9 * ci * co + 3 * px * ci)          # dy, w, mask + old dx + new dx
+            n_nt += 1
+        tn += 4.0 * (px * cin + px * co + 9 * ci * co)
+        n_tn += 1
+        if pool[l]:
+            h, w = h // 2, w // 2
+    return {'conv3x3_fwd_dgrad': nt / n_nt, 'conv3x3_wgrad': tn / n_tn}
+
+
+if __name__ == '__main__':
+    main()

@@ -66,8 +66,8 @@ _SIGS = {
     'wesup_propagate': (c_int, 'ppppfipppiiiip'),
     'wesup_loss_fwd': (c_int, 'ppppffppiiip'),
     'wesup_loss_bwd': (c_int, 'ppppppffpiiip'),
-    'wesup_cross_entropy_fwd': (c_int, 'ppfpiip'),
-    'wesup_cross_entropy_bwd': (c_int, 'ppppfpiip'),
+    'wesup_cross_entropy_fwd': (c_int, 'pppfpiip'),
+    'wesup_cross_entropy_bwd': (c_int, 'pppppfpiip'),
     'wesup_sgd_step': (c_int, 'pppzffffip'),
     'wesup_seg_metrics_workspace_bytes': (c_size_t, 'i'),
     'wesup_seg_metrics': (c_int, 'pppiiipzp'),
@@ -75,6 +75,7 @@ _SIGS = {
 _T = {'p': c_void_p, 'i': c_int, 'f': c_float, 'z': c_size_t, 'l': ctypes.c_long}
 
 EXPORTS = sorted(_SIGS)
+ABI_VERSION = 2          # include/wesup_hip.h; a stale libwesup_hip.so with other signatures must not be called
 
 _lib = None
 
@@ -107,6 +108,9 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the symbol is missing: fail loudly
         fn.restype = res
         fn.argtypes = [_T[a] for a in args]
+    if lib.wesup_abi_version() != ABI_VERSION:
+        raise WesupHipError(f'{LIB_PATH} has ABI version {lib.wesup_abi_version()}, this package binds version '
+                            f'{ABI_VERSION}: rebuild it (make -C wesup_amd/csrc)')
     _lib = lib
     return lib
 

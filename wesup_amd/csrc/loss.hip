@@ -236,13 +236,15 @@ extern "C" int wesup_propagate(const float* feat, const float* sp_labels, const 
 }
 
 // ------------------------------------------------------------------ loss (models/wesup.py:66-96, 492-531)
-__device__ __forceinline__ float ce_row(const float* p, const float* y, int C, float eps, float* ysum) {
+__device__ __forceinline__ float ce_row(const float* p, const float* y, int C, float eps, float* ysum,
+                                        const float* cw = nullptr) {
     float s = 0.f, ys = 0.f;
     for (int c = 0; c < C; ++c) {
         const float yc = y[c];
         ys += yc;
         const float pc = fminf(fmaxf(p[c], eps), 1.f - eps);
-        s += -yc * logf(pc);
+        const float ce = -yc * logf(pc);
+        s += cw ? ce * cw[c] : ce;               // models/wesup.py:93-94
     }
     *ysum = ys;
     return s;
@@ -330,12 +332,13 @@ extern "C" int wesup_loss_bwd(const float* pred, const float* y_all, const int32
 
 // generic _cross_entropy on (n, C)
 __global__ __launch_bounds__(256) void ce_fwd_kernel(const float* __restrict__ y_hat, const float* __restrict__ y_true,
-                                                     float eps, float* __restrict__ out2, int n, int C) {
+                                                     const float* __restrict__ cw, float eps, float* __restrict__ out2,
+                                                     int n, int C) {
     __shared__ float sh[256];
     float s = 0.f, cnt = 0.f;
     for (int r = threadIdx.x; r < n; r += 256) {
         float ys;
-        s += ce_row(y_hat + (long)r * C, y_true + (long)r * C, C, eps, &ys);
+        s += ce_row(y_hat + (long)r * C, y_true + (long)r * C, C, eps, &ys, cw);
         cnt += (ys > 0.f) ? 1.f : 0.f;
     }
     s = block_sum256(s, sh);
@@ -348,29 +351,32 @@ __global__ __launch_bounds__(256) void ce_fwd_kernel(const float* __restrict__ y
     }
 }
 __global__ void ce_bwd_kernel(const float* __restrict__ y_hat, const float* __restrict__ y_true,
-                              const float* __restrict__ out2, const float* __restrict__ dloss, float eps,
-                              float* __restrict__ dy, long total) {
+                              const float* __restrict__ cw, const float* __restrict__ out2,
+                              const float* __restrict__ dloss, float eps, float* __restrict__ dy, long total, int C) {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= total) return;
     const float cnt = out2[1];
     const float p = y_hat[idx];
     float g = 0.f;
     if (cnt > 0.f && p >= eps && p <= 1.f - eps) g = dloss[0] * (-y_true[idx] / p) / cnt;
+    if (cw) g *= cw[idx % C];
     dy[idx] = g;
 }
-extern "C" int wesup_cross_entropy_fwd(const float* y_hat, const float* y_true, float eps, float* out2, int n, int C,
-                                       void* stream) {
+extern "C" int wesup_cross_entropy_fwd(const float* y_hat, const float* y_true, const float* class_weights, float eps,
+                                       float* out2, int n, int C, void* stream) {
     if (!y_hat || !y_true || !out2 || n < 0 || C <= 0) return WESUP_ERR_INVALID;
-    hipLaunchKernelGGL(ce_fwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, y_hat, y_true, eps, out2, n, C);
+    hipLaunchKernelGGL(ce_fwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, y_hat, y_true, class_weights, eps, out2,
+                       n, C);
     WESUP_CHECK_LAUNCH();
     return WESUP_OK;
 }
-extern "C" int wesup_cross_entropy_bwd(const float* y_hat, const float* y_true, const float* out2, const float* dloss,
-                                       float eps, float* dy_hat, int n, int C, void* stream) {
+extern "C" int wesup_cross_entropy_bwd(const float* y_hat, const float* y_true, const float* class_weights,
+                                       const float* out2, const float* dloss, float eps, float* dy_hat, int n, int C,
+                                       void* stream) {
     if (!y_hat || !y_true || !out2 || !dloss || !dy_hat || n <= 0 || C <= 0) return WESUP_ERR_INVALID;
     const long total = (long)n * C;
     hipLaunchKernelGGL(ce_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, y_hat,
-                       y_true, out2, dloss, eps, dy_hat, total);
+                       y_true, class_weights, out2, dloss, eps, dy_hat, total, C);
     WESUP_CHECK_LAUNCH();
     return WESUP_OK;
 }
@@ -471,7 +477,7 @@ extern "C" int wesup_seg_metrics(const float* pred, const uint8_t* mask, float* 
 }
 
 // ------------------------------------------------------------------ misc
-extern "C" int wesup_abi_version(void) { return 1; }
+extern "C" int wesup_abi_version(void) { return 2; }
 extern "C" const char* wesup_strerror(int code) {
     switch (code) {
         case WESUP_OK: return "ok";

@@ -52,6 +52,18 @@ class GradAllReducer:
         if self.lo is not None and self.hi - self.lo >= self.bucket_elems:
             self._flush()
 
+    def reset(self):
+        """Forget a half-finished backward (an exception between the first ready() and finish()): wait for whatever
+        was launched so that no collective is still writing into the buffer, and drop the pending range."""
+        for w in self.works:
+            try:
+                w.wait()
+            except Exception:          # the peer is gone: nothing left to wait for
+                pass
+        self.works = []
+        self.lo = self.hi = None
+        self.launched = []
+
     def finish(self):
         self._flush()
         for w in self.works:
@@ -84,3 +96,21 @@ def shard_indices(n_items, rank, world, seed=0, epoch=0):
     total = (n_items + world - 1) // world * world
     perm += perm[:total - n_items]
     return perm[rank:total:world]
+
+
+class ShardSampler(torch.utils.data.Sampler):
+    """Per-rank view of shard_indices() for a DataLoader; ``set_epoch`` reshuffles (every rank draws the same
+    permutation of the epoch and takes its own stride, so the partition changes from epoch to epoch too)."""
+
+    def __init__(self, n_items, rank, world, seed=0):
+        self.n_items, self.rank, self.world, self.seed = n_items, rank, world, seed
+        self.epoch = 0
+
+    def set_epoch(self, epoch):
+        self.epoch = int(epoch)
+
+    def __iter__(self):
+        return iter(shard_indices(self.n_items, self.rank, self.world, self.seed, self.epoch))
+
+    def __len__(self):
+        return (self.n_items + self.world - 1) // self.world

@@ -13,14 +13,17 @@ iteration:
             side-branch gradient (maxpool backward where the layer was pooled)   (autograd in the reference,
             models/base.py:207)
 
-Two HIP streams: the MFMA-bound convolution chain runs on the caller's stream, the HBM-bound side branch
-(1x1 side GEMMs, upsampling, bias sums) on a second stream, joined by events; the memory-bound kernels
-then fill the tails and stalls of the matrix kernels instead of extending the critical path.
+Three HIP streams: the MFMA-bound convolution chain (forward convs, backward dgrads) runs on the caller's stream,
+the side branch (weight repacking, 1x1 side GEMMs, pooling, upsampling) on a second, the conv weight gradients on a
+third, joined by events; the memory-bound kernels and the wgrads then fill the tails and stalls of the matrix
+kernels of the chain instead of extending the critical path.
 
 Activations are NHWC fp32.  Parameter gradients are written straight into one flat buffer (the model's
 parameters are views of a flat buffer too) so that SGD is one kernel and the data-parallel all-reduce is a
 few large RCCL calls launched while the rest of backward still runs.
 """
+from collections import OrderedDict
+
 import torch
 
 from . import ops
@@ -85,7 +88,10 @@ class WesupEngine:
         self.g = grads
         self.D = D
         self.device = next(iter(params.values())).device
-        self._bufs = {}
+        self._bufs = OrderedDict()       # (B,H,W,Kmax) -> _Bufs, least recently used first, at most max_cached_shapes
+        self.max_cached_shapes = 2       # e.g. the training shape and the validation shape
+        self._last = None                # buffers of the most recent forward (feature_maps() reads these)
+        self.frozen = set()              # names of parameters with requires_grad=False (set by WESUP.forward)
         self._packed = None
         self._prefetched = None
         self.ctx = None
@@ -138,6 +144,19 @@ class WesupEngine:
     def _get_bufs(self, B, H, W, Kmax, train):
         key = (B, H, W, Kmax)
         b = self._bufs.get(key)
+        if b is not None:
+            self._bufs.move_to_end(key)
+        else:
+            # Bounded cache: training on multi-scale crops (utils/data.py: random rescale per item) or inference over
+            # images of varying size meets a new shape almost every call; every entry is a full set of activation and
+            # gradient buffers (~0.6 GB per 480x480 image in training), so only the most recent shapes are kept and the
+            # evicted buffers go back to torch's caching allocator, which hands their blocks to the next shape.
+            while len(self._bufs) >= max(1, self.max_cached_shapes):
+                _, old = self._bufs.popitem(last=False)
+                if old is self._last:
+                    self._last = None
+                if self.ctx is not None and self.ctx[0] is old:
+                    self.ctx = None
         dev = self.device
         f32 = dict(dtype=torch.float32, device=dev)
         if b is None:
@@ -214,7 +233,8 @@ class WesupEngine:
         return b
 
     def release_buffers(self):
-        self._bufs = {}
+        self._bufs.clear()
+        self._last = None
         self.ctx = None
 
     # ------------------------------------------------------------------ weights
@@ -279,6 +299,7 @@ class WesupEngine:
         Kmax = meta.Kmax
         assert (meta.B, meta.H, meta.W) == (B, H, W)
         b = self._get_bufs(B, H, W, Kmax, train)
+        self._last = b
         pk = self._pack_weights(train)
         p = self.p
         T = self.timer
@@ -357,9 +378,7 @@ class WesupEngine:
     def feature_maps(self):
         """(B,H,W,2112) pixel-major feature maps of the last forward (models/wesup.py:280).  On the fused path they
         are never needed by the step itself; they are materialised here on demand from the saved side outputs."""
-        b = None
-        for b in self._bufs.values():
-            pass
+        b = self._last
         if b is None:
             return None
         if not b.fm_valid:
@@ -381,6 +400,12 @@ class WesupEngine:
         R = B * Kmax
         D = self.D
         ready = self.on_grads_ready or (lambda names: None)
+        # Frozen backbone layers (freeze_backbone, models/wesup.py:427-429: requires_grad=False + the optimiser's filter):
+        # autograd in the reference then never computes their weight gradients nor any activation gradient that only
+        # they would need.  Same here: a frozen layer has no wgrad launch, and below the lowest trainable layer there
+        # is no dgrad chain and no side-conv dgrad at all (the side convs' own wgrads only need ds_l and y_l).
+        trainable = [not {f'backbone.{i}.weight', f'backbone.{i}.bias'} <= self.frozen for i in CONV_IDX]
+        lowest = min([l for l in range(13) if trainable[l]], default=13)
         # ---- classifier + fc_layers
         tok = T.begin('mlp_bwd')
         ops.classifier_bwd(b.feats, p['classifier.0.weight'], b.sp_pred, dpred.reshape(R, 2),
@@ -457,20 +482,21 @@ class WesupEngine:
                 T.end(tok, 4.0 * B * H * W * (co // 2))
                 tok = T.begin('side_bwd')
                 y2d = b.y[l].view(P, co)
-                ops.gemm_nt(ds2d, pk.sideT[l], None, out=b.G[l].view(P, co))
-                if self.two_streams:
-                    g_ready[l] = torch.cuda.Event()
-                    g_ready[l].record()
+                if l >= lowest:              # G_l is only needed by backbone layers that train
+                    ops.gemm_nt(ds2d, pk.sideT[l], None, out=b.G[l].view(P, co))
+                    if self.two_streams:
+                        g_ready[l] = torch.cuda.Event()
+                        g_ready[l].record()
                 ops.gemm_tn(ds2d, y2d, out=g[f'side_conv{off}.weight'].view(co // 2, co), ws_tag='side',
                             colsum=g[f'side_conv{off}.bias'])
-                T.end(tok, 4.0 * P * co * (co // 2))
+                T.end(tok, (4.0 if l >= lowest else 2.0) * P * co * (co // 2))
                 side_names += [f'side_conv{off}.weight', f'side_conv{off}.bias']
         # ---- main path, conv5_3 down to conv1_1.  The dgrad chain stays on the caller's stream; each layer's wgrad
         # (which only produces parameter gradients) goes to a third stream so that it fills the tails of the dgrad
         # kernels instead of sitting on the critical path.
         main = torch.cuda.current_stream()
         wg = self._wg() if self.two_streams else None
-        for l in range(12, -1, -1):
+        for l in range(12, lowest - 1, -1):
             ci, co = CONV_CH[l]
             h, w = b.dims[l]
             idx = CONV_IDX[l]
@@ -480,7 +506,9 @@ class WesupEngine:
                 x_in = b.x0
             else:
                 x_in = b.yp[l - 1] if POOL_AFTER[l - 1] else b.y[l - 1]
-            if wg is not None:
+            if not trainable[l]:
+                pass
+            elif wg is not None:
                 wg.wait_stream(main)                       # G_l is final here
                 with torch.cuda.stream(wg):
                     tok = T.begin('conv3x3_wgrad')
@@ -493,7 +521,7 @@ class WesupEngine:
                 ops.conv3x3_wgrad(x_in, b.G[l], ci, relu_in=(l > 0), dw=g[f'backbone.{idx}.weight'], db=g[f'backbone.{idx}.bias'])
                 T.end(tok, 2.0 * B * h * w * ci * co * 9)
                 ready([f'backbone.{idx}.weight', f'backbone.{idx}.bias'])
-            if l > 0:
+            if l > lowest:
                 if g_ready[l - 1] is not None:
                     main.wait_event(g_ready[l - 1])
                 tok = T.begin('conv3x3_dgrad')

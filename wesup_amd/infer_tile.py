@@ -3,13 +3,12 @@ pixel_infer_tile.py:41-60).
 
 Same strategy as the reference: ``ceil(H / patch) x ceil(W / patch)`` windows whose top-left corners are spread evenly
 with ``np.linspace`` (so neighbouring windows overlap when the size is not a multiple of the patch), every window goes
-through the model on its own, and overlapping predictions are merged by the reference's running average.  The three
+through the model on its own, and overlapping predictions are merged by the mean over the covering windows.  The
 window functions are numpy and pinned to the reference's own outputs (tests/golden/tiles.npz); the per-window forward
 is the HIP path (``trainer.preprocess`` with the GPU SLIC -> ``WESUP.forward`` -> ``postprocess``, or
 ``WESUPPixelInference`` for the pixel-wise variant)."""
 import argparse
 import math
-from itertools import product
 from pathlib import Path
 
 import numpy as np
@@ -18,42 +17,51 @@ import torch
 from .models import initialize_trainer
 
 
+def window_grid(height, width, patch_size):
+    """Rows and columns of the window lattice: ``ceil(size / patch)`` windows per axis, first window at 0, last window
+    flush with the far border, the others spread evenly in between (positions truncated to integers, which is what
+    ``np.linspace(..., dtype=int)`` does in infer_tile.py:26-29)."""
+    def axis(size):
+        if size < patch_size:
+            raise ValueError(f'image {height}x{width} is smaller than the patch size {patch_size}')
+        return np.linspace(0, size - patch_size, math.ceil(size / patch_size), dtype=int)
+    return axis(height), axis(width)
+
+
 def _get_top_left_coordinates(height, width, patch_size):
-    """Top-left corners of the windows (infer_tile.py:23-31)."""
-    n_h = math.ceil(height / patch_size)
-    n_w = math.ceil(width / patch_size)
-    tops = np.linspace(0, height - patch_size, n_h, dtype=int)
-    lefts = np.linspace(0, width - patch_size, n_w, dtype=int)
-    return product(tops, lefts)
+    """(top, left) of every window, row-major (the order of infer_tile.py:23-31)."""
+    tops, lefts = window_grid(height, width, patch_size)
+    return [(int(t), int(l)) for t in tops for l in lefts]
 
 
 def divide_image_to_patches(img, patch_size):
     """(H, W, 3) uint8 image -> (N, patch_size, patch_size, 3) possibly overlapping windows (infer_tile.py:34-57)."""
-    assert len(img.shape) == 3 and img.shape[-1] == 3
-    height, width, _ = img.shape
-    if height < patch_size or width < patch_size:
-        raise ValueError(f'image {height}x{width} is smaller than the patch size {patch_size}')
-    patches = [img[top:top + patch_size, left:left + patch_size]
-               for top, left in _get_top_left_coordinates(height, width, patch_size)]
-    return np.array(patches).astype('uint8')
+    if img.ndim != 3 or img.shape[-1] != 3:
+        raise AssertionError('expected an (H, W, 3) image')            # the reference asserts (infer_tile.py:46)
+    tops, lefts = window_grid(img.shape[0], img.shape[1], patch_size)
+    span = np.arange(patch_size)
+    rows = (tops[:, None] + span)[:, None, :, None]                    # (n_h, 1, p, 1)
+    cols = (lefts[:, None] + span)[None, :, None, :]                   # (1, n_w, 1, p)
+    windows = img[rows, cols]                                          # one gather: (n_h, n_w, p, p, 3)
+    return windows.reshape(-1, patch_size, patch_size, 3).astype(np.uint8)
 
 
 def combine_patches_to_image(patches, target_height, target_width):
-    """Merge window predictions (N, h, w[, C]) into one (H, W[, C]) map, averaging where windows overlap
-    (infer_tile.py:60-91: a running mean kept with a per-pixel overlap count)."""
-    counter = 0
-    patch_size = patches.shape[1]
-    if len(patches.shape) == 3:          # channel dimension is missing
-        patches = np.expand_dims(patches, -1)
-    combined = np.zeros((target_height, target_width, patches.shape[-1] + 1))
-    for top, left in _get_top_left_coordinates(target_height, target_width, patch_size):
-        patch = combined[top:top + patch_size, left:left + patch_size, :-1]
-        overlaps = combined[top:top + patch_size, left:left + patch_size, -1:]
-        patch = (patch * overlaps + patches[counter]) / (overlaps + 1)
-        combined[top:top + patch_size, left:left + patch_size, :-1] = patch
-        overlaps += 1.
-        counter += 1
-    return np.squeeze(combined[..., :-1])
+    """Merge window predictions (N, p, p[, C]) into one (H, W[, C]) map: the value of a pixel is the mean over the
+    windows that cover it (the reference keeps it as a running mean with a per-pixel overlap count,
+    infer_tile.py:60-91; here: per-pixel sum and count, divided once -- equal up to float rounding)."""
+    patches = np.asarray(patches, dtype=np.float64)
+    flat = patches.ndim == 3
+    if flat:
+        patches = patches[..., None]
+    p = patches.shape[1]
+    total = np.zeros((target_height, target_width, patches.shape[-1]))
+    cover = np.zeros((target_height, target_width, 1))
+    for window, (top, left) in zip(patches, _get_top_left_coordinates(target_height, target_width, p)):
+        total[top:top + p, left:left + p] += window
+        cover[top:top + p, left:left + p] += 1.0
+    merged = total / cover                                              # every pixel lies in at least one window
+    return merged[..., 0] if flat else np.squeeze(merged)
 
 
 def _to_tensor(patch, device):

@@ -96,8 +96,14 @@ class BaseTrainer(ABC):
             if self.scheduler is not None and 'scheduler_state_dict' in checkpoint:
                 self.scheduler.load_state_dict(checkpoint['scheduler_state_dict'])
         else:
-            self.record_dir = Path(record.prepare_record_dir())
-            record.copy_source_files(self.record_dir)
+            # one record directory per job: rank 0 creates it, the other ranks learn its path
+            path = [str(record.prepare_record_dir())] if self.rank == 0 else [None]
+            if self.world_size > 1:
+                import torch.distributed as dist
+                dist.broadcast_object_list(path, src=0)
+            self.record_dir = Path(path[0])
+            if self.rank == 0:
+                record.copy_source_files(self.record_dir)
 
     def save_checkpoint(self, ckpt_path, **kwargs):
         checkpoint = {
@@ -134,8 +140,25 @@ class BaseTrainer(ABC):
         DevicePrefetcher); its result is appended to the data tuple.  None: nothing to precompute."""
         return None
 
+    def _loss_flag(self, loss):
+        """Data parallel only: a NaN loss on ONE rank must stop EVERY rank before the weights are touched (its NaN
+        gradients reach all ranks through the all-reduce, but only that rank sees a NaN loss).  The ranks agree through
+        a MAX all-reduce of a one-element flag, queued on the side stream right behind the loss kernels so that the
+        backward pass on the main stream does not wait for it; it comes back with the loss in the step's one
+        read-back."""
+        import torch.distributed as dist
+        flag = torch.isnan(loss.detach()).float().reshape(1)
+        side = self.model.engine._side()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=self.reducer.group)
+        flag.record_stream(side)
+        return flag, side
+
     def train_one_iteration(self, phase, *data):
         from .. import ops
+        if self.reducer is not None:
+            self.reducer.reset()             # nothing may be left over from an iteration that raised
         if hasattr(self.model, 'prefetch_weights'):      # weight repacking and superpixel preprocessing go to the side
             self.model.prefetch_weights(train=(phase == 'train'))      # stream: conv1_1 only waits for its own panel
             with self.model.engine.side_stream():
@@ -161,12 +184,13 @@ class BaseTrainer(ABC):
                 # forward pass -- so the GPU does not idle while the host wakes up and walks the backward schedule.
                 # A NaN loss still raises before the weights are touched (models/base.py:202-203): only the gradient
                 # buffers have been written by then.
-                pending = self._stage_read_back(loss, metrics, seg)
+                flag = self._loss_flag(loss) if (self.reducer is not None and self.world_size > 1) else None
+                pending = self._stage_read_back(loss, metrics, seg, flag)
                 loss.backward()
                 if self.reducer is not None:
                     self.reducer.finish()
                 host = self._finish_read_back(pending, metrics)
-                if math.isnan(host['loss']):
+                if math.isnan(host['loss']) or host.get('nan_anywhere', 0.0) > 0:
                     raise ValueError('Loss is nan!')
                 metrics['loss'] = host['loss']
                 self.optimizer.step()
@@ -191,8 +215,17 @@ class BaseTrainer(ABC):
         """Bring loss, the per-image loss terms and the segmentation sums to the host in one copy."""
         return self._finish_read_back(self._stage_read_back(loss, metrics, seg), metrics)
 
-    def _stage_read_back(self, loss, metrics, seg):
-        """Queue the one device-to-host copy of the step (pinned buffer + event); no host wait here."""
+    def _stage_read_back(self, loss, metrics, seg, flag=None):
+        """Queue the one device-to-host copy of the step (pinned buffer + event); no host wait here.  With a
+        data-parallel NaN flag (see _loss_flag) the copy runs on the side stream behind the flag's all-reduce."""
+        if flag is not None:
+            flag, side = flag
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                return self._stage_read_back_on_current(loss, metrics, seg, flag)
+        return self._stage_read_back_on_current(loss, metrics, seg, None)
+
+    def _stage_read_back_on_current(self, loss, metrics, seg, flag):
         parts, layout = [], []
         if loss is not None:
             parts.append(loss.detach().reshape(1)); layout.append(('loss', 1))
@@ -203,6 +236,8 @@ class BaseTrainer(ABC):
             layout += [('terms', terms.numel()), ('n_sp', meta.B), ('n_l', meta.B)]
         if seg is not None:
             parts.append(seg.reshape(-1)); layout.append(('seg', seg.numel()))
+        if flag is not None:
+            parts.append(flag); layout.append(('nan_anywhere', 1))
         if not parts:
             return None
         flat = torch.cat(parts)
@@ -227,6 +262,8 @@ class BaseTrainer(ABC):
             o += n
         if 'loss' in out:
             out['loss'] = float(out['loss'][0])
+        if 'nan_anywhere' in out:
+            out['nan_anywhere'] = float(out['nan_anywhere'][0])
         if 'terms' in out:
             t = out['terms'].reshape(-1, 8)
             n_sp, n_l = out['n_sp'], out['n_l']
@@ -255,7 +292,16 @@ class BaseTrainer(ABC):
                 try:
                     self.train_one_iteration(phase, *data)
                 except RuntimeError as ex:
+                    # models/base.py:234-237: log and go on with the next batch.  Not under data parallelism: the other
+                    # ranks are already inside this iteration's collectives, so a rank that skips a batch leaves them
+                    # hanging or reducing mismatched buckets -- there the error ends the job (fail-stop; the launcher
+                    # tears the other ranks down) after the reducer has been brought back to a clean state.
+                    if self.reducer is not None and self.world_size > 1:
+                        self.reducer.reset()
+                        raise
                     self.logger.exception(ex)
+                    if getattr(self.model, 'engine', None) is not None:
+                        self.model.engine.ctx = None
             self.logger.info(f'Took {time.time() - start:.2f}s.')
             self.logger.info(self.tracker.log())
 
@@ -266,10 +312,15 @@ class BaseTrainer(ABC):
         if self.reducer is not None and hasattr(self.optimizer, 'grad_scale'):
             self.optimizer.grad_scale = 1.0 / self.world_size
         self.load_checkpoint(self.kwargs.get('checkpoint'))
+        if self.kwargs.get('checkpoint') is None and getattr(self.model, 'pretrained_backbone', True) is False:
+            self.logger.warning('WARNING: the VGG16 backbone starts from RANDOM weights; the reference starts from the '
+                                'ImageNet weights (vgg16(pretrained=True), models/wesup.py:199) -- pass '
+                                'backbone_weights=<file with a torchvision vgg16 state_dict> to reproduce its accuracy')
         if self.rank == 0:
             self.logger.addHandler(logging.FileHandler(self.record_dir / 'train.log'))
         serializable_kwargs = {k: v for k, v in self.kwargs.items() if isinstance(v, (int, float, str, tuple))}
-        record.save_params(self.record_dir, serializable_kwargs)
+        if self.rank == 0:
+            record.save_params(self.record_dir, serializable_kwargs)
         self.logger.info(str(serializable_kwargs) + '\n')
         self.tracker.save_path = self.record_dir / 'history.csv'
         data_root = Path(data_root)
@@ -280,8 +331,8 @@ class BaseTrainer(ABC):
 
         sampler = None
         if self.world_size > 1:
-            from ..ddp import shard_indices
-            sampler = shard_indices(len(train_dataset), self.rank, self.world_size, seed=0)
+            from ..ddp import ShardSampler
+            sampler = ShardSampler(len(train_dataset), self.rank, self.world_size, seed=0)
         workers = self.kwargs.get('num_workers', min(8, os.cpu_count() or 1))
         self.dataloaders = {
             'train': torch.utils.data.DataLoader(train_dataset, batch_size=self.kwargs.get('batch_size'),
@@ -311,6 +362,8 @@ class BaseTrainer(ABC):
         for epoch in range(self.initial_epoch, total_epochs + 1):
             self.logger.info(underline('\nEpoch {}/{}'.format(epoch, total_epochs), '-'))
             self.tracker.start_new_epoch(self.optimizer.param_groups[0]['lr'])
+            if sampler is not None:
+                sampler.set_epoch(epoch)                 # a new order and a new partition every epoch
             self.train_one_epoch(no_val=(not has_val))
             self.post_epoch_hook(epoch)
             if self.rank == 0:

@@ -9,10 +9,14 @@ Additions over the reference surface (all optional):
   * ``SuperpixelMaps``: what ``_preprocess_superpixels`` returns instead of the
     dense (N,H,W) maps -- a label-map based description; ``WESUP.forward``
     accepts it as well as a dense tensor (models/wesup.py:263-275);
+  * ``SuperpixelLabels``: what ``preprocess`` returns as ``sp_labels`` -- it behaves
+    like the reference's (N_l, C) tensor when looked at and carries the batched
+    device-side description so that ``compute_loss`` needs no host sync;
   * batches: B independent images, per-image loss as the reference computes
     it, batch loss = mean (the reference is batch-1 only, models/wesup.py:178).
 """
 import os.path as osp
+import warnings
 from functools import partial
 
 import numpy as np
@@ -50,6 +54,64 @@ class SuperpixelMaps:
         maps = (m.new_row[b][None, :] == rows).float()
         maps = maps / m.area_new[b, :n, None].float()
         return maps.view(n, m.H, m.W)
+
+
+class SuperpixelLabels:
+    """``sp_labels`` as ``WESUPTrainer.preprocess`` returns it (models/wesup.py:487-490).
+
+    To a caller it is the reference's (N_l, C) float tensor of the labelled superpixels (labelled rows first,
+    multi-hot on ties): ``size``/``shape``/``len``/indexing/``to``/torch functions resolve it lazily (one host sync to
+    learn N_l, which the reference pays in ``nonzero()``, models/wesup.py:45).  ``compute_loss`` never looks: it takes
+    the batched device-side description from ``.meta`` and stays on the device.  Without any mask the reference's
+    value is the 0-dim ``empty_tensor()`` (models/wesup.py:54), and so is this one's."""
+
+    def __init__(self, meta, has_mask=True):
+        self.meta = meta
+        self.has_mask = has_mask
+        self._t = {}
+
+    def tensor(self, b=None):
+        m = self.meta
+        if b is None:
+            if m.B != 1:
+                raise ValueError(f'sp_labels of a batch of {m.B} images: ask for one image with .tensor(b)')
+            b = 0
+        if b not in self._t:
+            if not self.has_mask:
+                self._t[b] = empty_tensor().to(m.sp_labels.device)
+            else:
+                self._t[b] = m.sp_labels[b, :int(m.n_l[b])]               # host sync
+        return self._t[b]
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        conv = lambda a: a.tensor() if isinstance(a, cls) else a
+        return func(*[conv(a) for a in args], **{k: conv(v) for k, v in (kwargs or {}).items()})
+
+    def size(self, dim=None):
+        t = self.tensor()
+        return t.size() if dim is None else t.size(dim)
+
+    shape = property(lambda self: self.tensor().shape)
+    dtype = property(lambda self: self.tensor().dtype)
+    device = property(lambda self: self.meta.sp_labels.device)
+
+    def dim(self):
+        return self.tensor().dim()
+
+    def __len__(self):
+        return len(self.tensor())
+
+    def __getitem__(self, idx):
+        return self.tensor()[idx]
+
+    def to(self, *a, **k):
+        return self                         # already on the device the step runs on
+
+    def __getattr__(self, name):            # sum(), float(), cpu(), numpy(), ... of the resolved tensor
+        if name.startswith('_'):
+            raise AttributeError(name)
+        return getattr(self.tensor(), name)
 
 
 def _to_mask_u8(mask, B, H, W):
@@ -95,33 +157,39 @@ def _preprocess_superpixels(segments, mask=None, epsilon=1e-7):
 
 class _CrossEntropyFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, y_hat, y_true, epsilon):
+    def forward(ctx, y_hat, y_true, epsilon, class_weights):
         y_hat = y_hat.contiguous()
         y_true = y_true.contiguous().float()
-        out = ops.cross_entropy_fwd(y_hat, y_true, epsilon)
+        out = ops.cross_entropy_fwd(y_hat, y_true, epsilon, class_weights)
         ctx.save_for_backward(y_hat, y_true, out)
-        ctx.eps = epsilon
+        ctx.eps, ctx.cw = epsilon, class_weights
         return out[2].clone()
 
     @staticmethod
     def backward(ctx, dloss):
         y_hat, y_true, out = ctx.saved_tensors
-        return ops.cross_entropy_bwd(y_hat, y_true, out, dloss.reshape(1).contiguous(), ctx.eps), None, None
+        return (ops.cross_entropy_bwd(y_hat, y_true, out, dloss.reshape(1).contiguous(), ctx.eps, ctx.cw),
+                None, None, None)
 
 
 def _cross_entropy(y_hat, y_true, class_weights=None, epsilon=1e-7):
     """Semi-supervised cross entropy (models/wesup.py:66-96): rows of ``y_true`` that are all zero do
-    not count; returns 0 when no row is labelled.  No host sync (the reference does one ``.item()``)."""
-    if class_weights is not None:
-        raise NotImplementedError('class_weights is never used by the reference trainer (models/wesup.py:434)')
+    not count; returns 0 when no row is labelled; ``class_weights`` (C,) scales the per-class terms
+    (models/wesup.py:93-94).  No host sync (the reference does one ``.item()``)."""
+    if isinstance(y_true, SuperpixelLabels):
+        y_true = y_true.tensor()
     if y_hat.size(0) == 0:
         return torch.zeros((), device=y_hat.device)
-    return _CrossEntropyFn.apply(y_hat, y_true, float(epsilon))
+    if class_weights is not None:
+        class_weights = torch.as_tensor(class_weights, dtype=torch.float32, device=y_hat.device).contiguous()
+    return _CrossEntropyFn.apply(y_hat, y_true, float(epsilon), class_weights)
 
 
 def _label_propagate(features, y_l, threshold=0.95):
     """Label propagation over the affinity exp(-|fi-fj|^2) (models/wesup.py:99-139).
     features (N,D) with the n_l labelled rows first, y_l (n_l,C) -> y_u (N-n_l, C)."""
+    if isinstance(y_l, SuperpixelLabels):
+        y_l = y_l.tensor()
     features = features.detach().contiguous()
     y_l = y_l.detach().float()
     N, D = features.shape
@@ -158,9 +226,27 @@ class WESUPConfig(BaseConfig):
     epochs = 300
 
 
+def load_backbone_weights(backbone, path):
+    """Load ImageNet VGG16 convolution weights into ``backbone`` from a file saved with ``torch.save``: either
+    torchvision's ``vgg16().state_dict()`` (keys ``features.N.weight``; the classifier entries are ignored) or the
+    ``features`` sub-dict (keys ``N.weight``).  The reference gets the same tensors from
+    ``vgg16(pretrained=True)`` (models/wesup.py:199), which needs network access."""
+    sd = torch.load(path, map_location='cpu')
+    sd = sd.get('state_dict', sd) if isinstance(sd, dict) else sd
+    picked = {}
+    for k, v in sd.items():
+        k = k[len('features.'):] if k.startswith('features.') else k
+        if k.split('.')[0].isdigit() and int(k.split('.')[0]) in CONV_IDX:
+            picked[k] = v
+    missing = [f'{i}.{t}' for i in CONV_IDX for t in ('weight', 'bias') if f'{i}.{t}' not in picked]
+    if missing:
+        raise ValueError(f'{path}: not a VGG16 "features" state_dict, missing {missing[:4]}...')
+    backbone.load_state_dict(picked)
+
+
 def _vgg16_features():
-    """torchvision VGG16 cfg "D" layer list (models/wesup.py:199); random init (no network for
-    the ImageNet weights the reference downloads)."""
+    """torchvision VGG16 cfg "D" layer list (models/wesup.py:199); random init unless ``backbone_weights`` names a
+    file with the ImageNet weights the reference downloads (no network here)."""
     cfg = [64, 64, 'M', 128, 128, 'M', 256, 256, 256, 'M', 512, 512, 512, 'M', 512, 512, 512, 'M']
     layers, c = [], 3
     for v in cfg:
@@ -204,6 +290,13 @@ class WESUP(nn.Module):
         self.kwargs = kwargs
         self.D = D
         self.backbone = _vgg16_features()
+        # vgg16(pretrained=True) of the reference (models/wesup.py:199) downloads the ImageNet weights; here they come
+        # from a file (``backbone_weights=<path>``); without one the backbone starts from random weights and the
+        # trainer says so loudly before training
+        self.pretrained_backbone = False
+        if kwargs.get('backbone_weights'):
+            load_backbone_weights(self.backbone, kwargs['backbone_weights'])
+            self.pretrained_backbone = True
         self.fm_channels_sum = 0
         for layer in self.backbone:
             if isinstance(layer, nn.Conv2d):
@@ -274,7 +367,7 @@ class WESUP(nn.Module):
     def feature_maps(self):
         """(2112,H,W) side-output feature maps of the last forward (models/wesup.py:280); a permuted
         view of the engine's pixel-major (H,W,2112) tensor (batched: (B,2112,H,W))."""
-        if self.engine is None or not self.engine._bufs:
+        if self.engine is None or self.engine._last is None:
             return None
         fm = self.engine.feature_maps()
         return fm[0].permute(2, 0, 1) if fm.shape[0] == 1 else fm.permute(0, 3, 1, 2)
@@ -299,6 +392,9 @@ class WESUP(nn.Module):
             meta = ops.sp_preprocess(labels, None, n, n_sp_host=[n])        # rows keep the caller's order
         img = img.contiguous().float()
         self.fm_size = (img.size(2), img.size(3))
+        # parameters with requires_grad=False (freeze_backbone, models/wesup.py:427-429): the engine skips the frozen
+        # backbone layers' wgrad and every dgrad below the lowest trainable one
+        self.engine.frozen = {n for n, p in self.named_parameters() if not p.requires_grad}
         feats, sp_pred, pred = _WesupFn.apply(self._anchor, self, img, meta)
         self._last_meta = meta
         self._padded = (feats, sp_pred)        # (B,Kmax,D), (B,Kmax,2): what the batched loss consumes
@@ -361,7 +457,8 @@ class WESUPTrainer(BaseTrainer):
 
     def __init__(self, model, **kwargs):
         config = WESUPConfig()
-        if config.freeze_backbone:
+        # the reference reads the class default only (models/wesup.py:426-429); the kwarg is honoured as well
+        if config.freeze_backbone or kwargs.get('freeze_backbone'):
             for param in model.backbone.parameters():
                 param.requires_grad = False
         kwargs = {**config.to_dict(), **kwargs}
@@ -461,14 +558,17 @@ class WESUPTrainer(BaseTrainer):
         #  max_superpixels says otherwise)
         Kmax = max(n_sp_host) if n_sp_host is not None else (
             kmax_bound or self.kwargs.get('max_superpixels') or self._slic_bound(img.size(-2), img.size(-1)))
+        # padded rows are inert: rounding up keeps the set of buffer shapes small when the superpixel count changes
+        # from batch to batch (every new (B,H,W,Kmax) is a new set of engine buffers) and keeps Kmax % 4 == 0, which
+        # the matrix form of the deep layers' pooling needs
+        Kmax = (int(Kmax) + 63) // 64 * 64
         meta = preprocess_label_maps(segments, mask, Kmax=Kmax, n_sp_host=n_sp_host)
         if self.kwargs.get('check_label_maps', False):
             meta.check()
-        sp_maps = SuperpixelMaps(meta)
-        return (img, sp_maps), (pixel_mask, sp_maps)
+        return (img, SuperpixelMaps(meta)), (pixel_mask, SuperpixelLabels(meta, has_mask=mask is not None))
 
     def compute_loss(self, pred, target, metrics=None):
-        """models/wesup.py:492-531.  ``target[1]`` is either the SuperpixelMaps from ``preprocess`` (device-side,
+        """models/wesup.py:492-531.  ``target[1]`` is either the SuperpixelLabels from ``preprocess`` (device-side,
         batched, no host sync) or a plain (N_l, C) ``sp_labels`` tensor as in the reference."""
         _, sp_labels = target
         sp_features = self.model.sp_features
@@ -476,7 +576,7 @@ class WESUPTrainer(BaseTrainer):
         if sp_pred is None:
             raise RuntimeError('You must run a forward pass before computing loss.')
 
-        if isinstance(sp_labels, SuperpixelMaps):
+        if isinstance(sp_labels, (SuperpixelLabels, SuperpixelMaps)):
             meta = sp_labels.meta
             B, Kmax = meta.B, meta.Kmax
             feats_p, pred_p = self.model._padded

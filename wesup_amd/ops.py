@@ -480,20 +480,23 @@ def loss_bwd(pred, y_all, meta, terms, dloss, eps, prop_weight, out=None):
     return out
 
 
-def cross_entropy_fwd(y_hat, y_true, eps):
+def cross_entropy_fwd(y_hat, y_true, eps, class_weights=None):
     _chk(y_hat, name='y_hat'); _chk(y_true, name='y_true')
     n, C = y_hat.shape
     assert y_true.shape == (n, C)
+    if class_weights is not None:
+        _chk(class_weights, name='class_weights'); assert class_weights.numel() == C
     out2 = torch.empty(4, dtype=torch.float32, device=y_hat.device)
-    _lib.call('wesup_cross_entropy_fwd', _p(y_hat), _p(y_true), float(eps), _p(out2), n, C, _stream())
+    _lib.call('wesup_cross_entropy_fwd', _p(y_hat), _p(y_true), _p(class_weights), float(eps), _p(out2), n, C, _stream())
     return out2
 
 
-def cross_entropy_bwd(y_hat, y_true, out2, dloss, eps):
+def cross_entropy_bwd(y_hat, y_true, out2, dloss, eps, class_weights=None):
     n, C = y_hat.shape
     dy = torch.empty_like(y_hat)
     if n > 0:
-        _lib.call('wesup_cross_entropy_bwd', _p(y_hat), _p(y_true), _p(out2), _p(dloss), float(eps), _p(dy), n, C, _stream())
+        _lib.call('wesup_cross_entropy_bwd', _p(y_hat), _p(y_true), _p(class_weights), _p(out2), _p(dloss), float(eps),
+                  _p(dy), n, C, _stream())
     return dy
 
 

@@ -18,7 +18,6 @@ class FusedSGD(torch.optim.SGD):
         self.grad_scale = grad_scale
         self._vflat = torch.zeros_like(model._flat)
         self._first = True
-        self._all = len(params) == len(list(model.parameters()))
         self._views = {}
         for name, p in model.named_parameters():
             o, n = model._offs[name], p.numel()
@@ -33,24 +32,36 @@ class FusedSGD(torch.optim.SGD):
                 st['momentum_buffer'] = view
                 self._first = False
 
+    def _trainable_ranges(self):
+        """Contiguous [lo, hi) element ranges of the flat buffers that hold parameters with requires_grad (padding
+        included, adjacent parameters merged): one range = the whole buffer when nothing is frozen, the tail behind the
+        backbone with freeze_backbone (models/wesup.py:427-429,447)."""
+        m = self.model
+        ranges = []
+        for name, p in m.named_parameters():
+            if not p.requires_grad:
+                continue
+            lo, hi = m._offs[name], m._offs[name] + (p.numel() + 63) // 64 * 64
+            if ranges and ranges[-1][1] == lo:
+                ranges[-1][1] = hi
+            else:
+                ranges.append([lo, hi])
+        return ranges
+
     @torch.no_grad()
     def step(self, closure=None):
         m = self.model
         self._sync_state_in()
         g = self.param_groups[0]
         lr, mu, wd = g['lr'], g['momentum'], g['weight_decay']
-        if self._all and all(p.grad is not None and p.grad.data_ptr() == m._grad_views[n].data_ptr()
-                             for n, p in m.named_parameters()):
-            ops.sgd_step(m._flat, m._flat_grad, self._vflat, lr, mu, wd, self.grad_scale, self._first)
-        else:                                   # frozen parameters or foreign grads: per-parameter launches
-            for name, p in m.named_parameters():
-                if not p.requires_grad or p.grad is None:
-                    continue
-                o, n = m._offs[name], (p.numel() + 63) // 64 * 64
-                gv = m._flat_grad[o:o + n]
-                if p.grad.data_ptr() != m._grad_views[name].data_ptr():
-                    m._grad_views[name].copy_(p.grad)
-                ops.sgd_step(m._flat[o:o + n], gv, self._vflat[o:o + n], lr, mu, wd, self.grad_scale, self._first)
+        for name, p in m.named_parameters():          # a gradient that is not the flat view (set by hand): adopt it
+            if p.requires_grad and p.grad is not None and p.grad.data_ptr() != m._grad_views[name].data_ptr():
+                m._grad_views[name].copy_(p.grad)
+        sig = tuple(p.requires_grad for p in m.parameters())
+        if getattr(self, '_ranges_sig', None) != sig:
+            self._ranges, self._ranges_sig = self._trainable_ranges(), sig
+        for lo, hi in self._ranges:                   # one launch per contiguous trainable range
+            ops.sgd_step(m._flat[lo:hi], m._flat_grad[lo:hi], self._vflat[lo:hi], lr, mu, wd, self.grad_scale, self._first)
         if mu != 0:
             for p, view in self._views.items():
                 if p.requires_grad:

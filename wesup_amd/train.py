@@ -31,7 +31,29 @@ def _parse_value(v):
             return cast(v)
         except ValueError:
             pass
-    return {'True': True, 'False': False}.get(v, v)
+    if v.startswith('(') and v.endswith(')'):                 # tuples such as multiscale_range (0.3,0.4)
+        return tuple(_parse_value(x.strip()) for x in v[1:-1].split(',') if x.strip())
+    return {'True': True, 'False': False, 'None': None}.get(v, v)
+
+
+def parse_cli_kwargs(tokens):
+    """``--key value``, ``--key=value`` and bare ``--flag`` (= True) -> kwargs, the way ``fire.Fire(fit)`` reads them
+    (train.py:32).  A bare flag never consumes the option that follows it."""
+    kw, i = {}, 0
+    while i < len(tokens):
+        tok = tokens[i]
+        i += 1
+        if not tok.startswith('--'):
+            raise SystemExit(f'unexpected argument {tok!r} (options look like --key value)')
+        key, eq, val = tok[2:].partition('=')
+        if not eq:
+            if i < len(tokens) and not tokens[i].startswith('--'):
+                val = tokens[i]
+                i += 1
+            else:
+                val = 'True'
+        kw[key.replace('-', '_')] = _parse_value(val)
+    return kw
 
 
 if __name__ == '__main__':
@@ -39,13 +61,4 @@ if __name__ == '__main__':
     ap.add_argument('dataset_path')
     ap.add_argument('--model', default='wesup')
     args, rest = ap.parse_known_args()
-    kw = {}
-    it = iter(rest)
-    for tok in it:
-        if tok.startswith('--'):
-            key, _, val = tok[2:].partition('=')
-            if not val:
-                nxt = next(it, None)
-                val = 'True' if nxt is None or nxt.startswith('--') else nxt
-            kw[key] = _parse_value(val)
-    fit(args.dataset_path, model=args.model, **kw)
+    fit(args.dataset_path, model=args.model, **parse_cli_kwargs(rest))

@@ -1,21 +1,37 @@
-"""Per-epoch metric bookkeeping (mirror of utils/history.py:11-81; pandas-free)."""
+"""Epoch bookkeeping of the trainer.
+
+Contract shared with the reference's ``utils/history.py`` ("Metrics / logging"): the trainer calls
+``start_new_epoch(lr)``, ``train()`` / ``eval()``, ``step(metrics)`` once per iteration, ``log()`` once per phase,
+``save()`` once per epoch and ``report()`` at the end; ``history[key]`` is the list of this epoch's values of a metric;
+validation metrics carry the ``val_`` prefix; ``history.csv`` has one row per epoch with the epoch means in sorted-key
+order followed by ``lr``.  Everything else here is this package's own (no pandas).
+"""
 import csv
-import os
 from collections import defaultdict
+from pathlib import Path
+from statistics import fmean
 
 from . import underline
+
+VAL_PREFIX = 'val_'
+_NOT_REPORTED = ('lr', 'loss', VAL_PREFIX + 'loss')
+
+
+def _fmt(pairs, template):
+    return ', '.join(template.format(name, value) for name, value in pairs)
 
 
 class HistoryTracker:
     def __init__(self, save_path=None):
-        self.history = defaultdict(list)
-        self.learning_rate = None
         self.save_path = save_path
+        self.learning_rate = None
         self.is_train = True
+        self.history = defaultdict(list)
 
+    # ---- phase / epoch switches
     def start_new_epoch(self, lr):
-        self.history.clear()
         self.learning_rate = lr
+        self.history.clear()
 
     def train(self):
         self.is_train = True
@@ -23,35 +39,45 @@ class HistoryTracker:
     def eval(self):
         self.is_train = False
 
+    # ---- per iteration
     def step(self, metrics):
-        reports = []
-        for k, v in metrics.items():
-            k = k if self.is_train else f'val_{k}'
-            self.history[k].append(v)
-            reports.append('{} = {:.4f}'.format(k, v))
-        return ', '.join(reports)
+        prefix = '' if self.is_train else VAL_PREFIX
+        named = [(prefix + key, value) for key, value in metrics.items()]
+        for key, value in named:
+            self.history[key].append(value)
+        return _fmt(named, '{} = {:.4f}')
+
+    # ---- per phase / per epoch
+    def epoch_means(self, phase=None):
+        """{key: mean over this epoch} in sorted key order; phase 'train' / 'val' keeps that phase's keys only."""
+        keys = sorted(self.history)
+        if phase is not None:
+            keys = [k for k in keys if k.startswith(VAL_PREFIX) == (phase == 'val')]
+        return {k: (fmean(self.history[k]) if self.history[k] else 0) for k in keys}
 
     def log(self):
-        metrics = {k: (sum(v) / len(v) if v else 0) for k, v in sorted(self.history.items())
-                   if k.startswith('val_') != self.is_train}
-        return ', '.join('average {} = {:.4f}'.format(n, v) for n, v in metrics.items()).capitalize()
+        means = self.epoch_means('train' if self.is_train else 'val')
+        return _fmt(means.items(), 'average {} = {:.4f}').capitalize()
 
     def save(self):
         if self.save_path is None:
             raise RuntimeError('cannot save history without setting save_path.')
-        keys = [k for k, _ in sorted(self.history.items())]
-        metrics = [sum(v) / len(v) for _, v in sorted(self.history.items())]
-        new = not os.path.exists(self.save_path)
-        with open(self.save_path, 'w' if new else 'a') as fp:
-            writer = csv.writer(fp)
-            if new:
-                writer.writerow(keys + ['lr'])
-            writer.writerow(metrics + [self.learning_rate])
+        means = self.epoch_means()
+        path = Path(self.save_path)
+        first = not path.exists()
+        with path.open('a', newline='') as fp:
+            out = csv.writer(fp)
+            if first:
+                out.writerow([*means, 'lr'])
+            out.writerow([*means.values(), self.learning_rate])
 
     def report(self, last_n_epochs=5):
-        with open(self.save_path) as fp:
-            rows = list(csv.DictReader(fp))
-        rows = rows[-last_n_epochs:]
-        keys = [k for k in (rows[0].keys() if rows else []) if k not in ('lr', 'loss', 'val_loss')]
-        lines = [f'{k:20s} {sum(float(r[k]) for r in rows) / len(rows):.4f}' for k in keys]
+        with open(self.save_path, newline='') as fp:
+            tail = list(csv.DictReader(fp))[-last_n_epochs:]
+        lines = []
+        for column in (tail[0] if tail else {}):
+            if column in _NOT_REPORTED:
+                continue
+            values = [float(row[column]) for row in tail if row[column] not in ('', None)]
+            lines.append(f'{column:20s} {fmean(values) if values else float("nan"):.4f}')
         return underline('\nTraining Summary (Avg over last 5 epochs)', style='=') + '\n' + '\n'.join(lines)
