@@ -212,3 +212,25 @@ def test_train_fit_end_to_end(tmp_path, monkeypatch):
     t2 = fit('synthetic:64:64:4:6', model='wesup', epochs=1, batch_size=2, checkpoint=str(ckpts[0]), num_workers=0)
     assert t2.initial_epoch == 3 and t2.record_dir == rd
     assert sorted(p.name for p in (rd / 'checkpoints').glob('*.pth')) == ['ckpt.0003.pth']
+
+
+def test_nan_loss_raises_before_the_weights_are_touched():
+    """models/base.py:202-203: `if torch.isnan(loss): raise ValueError('Loss is nan!')` sits in front of backward and
+    the optimiser.  A NaN anywhere in the network must reach the loss as it does through torch's NaN-propagating relu
+    and clamp (here: through the pre-ReLU side tap and NaN-preserving epilogue ReLU / clamp), and the parameters must be
+    bit-identical afterwards."""
+    from oracle import wesup_oracle as orc
+    from wesup_amd import synth
+    trainer = make_trainer(orc.make_weights(9, feat_scale=0.03))
+    imgs, labs, pts, pix = synth.make_batch(4, 2, 64, 64, 5)
+    imgs[1, 2, 40, 17] = np.nan
+    before = trainer.model._flat.clone()
+    with pytest.raises(ValueError, match='nan'):
+        trainer.train_one_iteration('train', torch.from_numpy(imgs), torch.from_numpy(pix).long(),
+                                    torch.from_numpy(pts).long(), torch.from_numpy(labs))
+    torch.cuda.synchronize()
+    assert torch.equal(before, trainer.model._flat)
+    imgs[1, 2, 40, 17] = 0.5                                      # and the trainer is usable afterwards
+    trainer.train_one_iteration('train', torch.from_numpy(imgs), torch.from_numpy(pix).long(),
+                                torch.from_numpy(pts).long(), torch.from_numpy(labs))
+    assert np.isfinite(trainer.tracker.history['loss'][-1]) and not torch.equal(before, trainer.model._flat)

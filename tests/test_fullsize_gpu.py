@@ -93,13 +93,15 @@ def test_step_matches_the_reference_at_480(golden_dir, name):
     assert rel_err(sim[0, n_l:K], fx['max_sim']) < TOL
 
     loss.backward()
-    # every parameter gradient: norm against the reference's, elements against the reference's samples ...
+    # every parameter gradient: norm against the reference's, elements against the reference's samples (the
+    # reference's own fp32 CPU gradients carry summation-order noise: conv1_1's dW sums 230 400 mixed-sign products per
+    # element, torch's CPU path is 3e-4 of the tensor's max away from fp64 there -- hence 1e-3 here) ...
     for k in [k[6:] for k in fx if k.startswith('gnorm.')]:
         g = model._grad_views[k]
         ref_norm = float(fx['gnorm.' + k])
         assert abs(g.double().norm().item() - ref_norm) <= 2e-4 * ref_norm + 1e-12, k
         samp = g.flatten()[::max(1, g.numel() // 64)][:64].cpu().numpy()
-        assert np.abs(samp - fx['gsamp.' + k]).max() <= 3e-4 * float(fx['gmax.' + k]), k
+        assert np.abs(samp - fx['gsamp.' + k]).max() <= 1e-3 * float(fx['gmax.' + k]), k
     # ... and against fp64 under the same ReLU / pooling decisions: 1e-4 of each tensor's max (or <= 2x torch fp32)
     worst, n_named = _gradcheck.check_gradients(model, weights, fx['img'][None], fx['seg'][None], fx['mask'][None])
     print(f'{name}: worst gradient error vs fp64 {worst:.2e}, {n_named} near-tie decisions differ')

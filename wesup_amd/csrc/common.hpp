@@ -47,6 +47,8 @@ __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<floa
 // input with a second v_max; an asm v_max would be outside the compiler's s_waitcnt bookkeeping and read a fragment
 // before its ds_read has landed): ReLU-on-load in the GEMM loops, lo = 0 or -inf
 __device__ __forceinline__ float vmax1(float x, float lo) { return __builtin_amdgcn_fmed3f(x, lo, __builtin_inff()); }
-__device__ __forceinline__ float4 relu4(float4 v) {
-    return make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
-}
+// ReLU of an epilogue.  NaN-preserving like torch.relu (fmaxf would turn a NaN into 0): a NaN in any conv output
+// reaches the superpixel features through the pre-ReLU side tap, and from there it must survive the fc_layers' ReLUs
+// so that the loss is NaN and the trainer raises before the weights are touched (models/base.py:202-203).
+__device__ __forceinline__ float relu1(float x) { return x < 0.f ? 0.f : x; }
+__device__ __forceinline__ float4 relu4(float4 v) { return make_float4(relu1(v.x), relu1(v.y), relu1(v.z), relu1(v.w)); }

@@ -242,7 +242,9 @@ __device__ __forceinline__ float ce_row(const float* p, const float* y, int C, f
     for (int c = 0; c < C; ++c) {
         const float yc = y[c];
         ys += yc;
-        const float pc = fminf(fmaxf(p[c], eps), 1.f - eps);
+        // torch.clamp keeps a NaN (models/wesup.py:83), fminf/fmaxf would swallow it and a NaN prediction would end
+        // in a finite loss instead of the ValueError of models/base.py:202-203
+        const float pc = (p[c] != p[c]) ? p[c] : fminf(fmaxf(p[c], eps), 1.f - eps);
         const float ce = -yc * logf(pc);
         s += cw ? ce * cw[c] : ce;               // models/wesup.py:93-94
     }
