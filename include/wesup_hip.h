@@ -63,6 +63,14 @@ int wesup_transpose(const float* in, float* out, int rows, int cols, void* strea
  * out_img fp32 [B][3][H][W] in [0,1]; out_mask uint8 one-hot [B][C][H][W] (class index 255 = no class). */
 int wesup_augment(const uint8_t* img_hwc, const uint8_t* mask_hw, const float* params, float* out_img_nchw,
                   uint8_t* out_mask_chw, int B, int H, int W, int C, void* stream);
+/* Appearance transforms that need a neighbourhood, on the un-warped uint8 images and in the reference's order
+ * (utils/data.py:119-125, 306-312): HueSaturationValue -> RandomBrightnessContrast -> CLAHE (8x8 tiles on the L channel
+ * of 8-bit Lab, OpenCV's algorithm) -> Blur (3x3 box), every stage rounding to uint8.  params: 8 floats per image
+ * {alpha, beta, hue, sat, val, clahe_clip (0 = off), blur (0/1), 0}.  img, out: [B][H][W][3] uint8 (out != img).
+ * Run wesup_augment afterwards with neutral colour parameters for the geometry, ToTensor and the one-hot mask. */
+size_t wesup_appearance_workspace_bytes(int B, int H, int W);
+int wesup_appearance(const uint8_t* img_hwc, const float* params, uint8_t* out_hwc, int B, int H, int W,
+                     void* ws, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------ VGG16 3x3 convs (K1/K2/K12)
  * replaces torchvision VGG16 Conv2d(k=3,pad=1)+ReLU (models/wesup.py:199,279) and its autograd.

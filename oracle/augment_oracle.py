@@ -119,3 +119,119 @@ def transform_points(points_xyc, M, H, W):
     keep = (xy[:, 0] >= 0) & (xy[:, 0] < W) & (xy[:, 1] >= 0) & (xy[:, 1] < H)
     out = np.concatenate([np.floor(xy[keep]), p[keep, 2:3]], 1)
     return out.astype(np.int64)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# wesup_appearance: HueSaturationValue -> RandomBrightnessContrast -> CLAHE -> Blur(3) on uint8 images.
+# Restated from the published algorithms (OpenCV's CLAHE: modules/imgproc/src/clahe.cpp; cv2.blur; 8-bit Lab), all in
+# float32 like the kernel.  PARITY UNPINNED (no OpenCV / albumentations in the image).
+# ---------------------------------------------------------------------------------------------------------------------
+F32 = np.float32
+
+
+def _sat_u8(v):
+    return np.clip(np.rint(v), 0, 255).astype(np.float32)
+
+
+def _srgb_to_linear(c):
+    return np.where(c <= F32(0.04045), c * F32(1 / 12.92), np.power((c + F32(0.055)) * F32(1 / 1.055), F32(2.4))).astype(np.float32)
+
+
+def _linear_to_srgb(c):
+    return np.where(c <= F32(0.0031308), F32(12.92) * c, F32(1.055) * np.power(c, F32(1 / 2.4)) - F32(0.055)).astype(np.float32)
+
+
+def _lab_fwd(t):
+    return np.where(t > F32(0.008856), np.cbrt(t), F32(7.787) * t + F32(16.0 / 116.0)).astype(np.float32)
+
+
+def rgb8_to_lab8(c):
+    """(...,3) float32 RGB in 0..255 -> L8, a8, b8 as OpenCV's 8-bit Lab stores them (rounded)."""
+    r, g, b = (_srgb_to_linear(c[..., k] * F32(1 / 255.0)) for k in range(3))
+    X = (F32(0.412453) * r + F32(0.357580) * g + F32(0.180423) * b) * F32(1 / 0.950456)
+    Y = F32(0.212671) * r + F32(0.715160) * g + F32(0.072169) * b
+    Z = (F32(0.019334) * r + F32(0.119193) * g + F32(0.950227) * b) * F32(1 / 1.088754)
+    fx, fy, fz = _lab_fwd(X), _lab_fwd(Y), _lab_fwd(Z)
+    L = np.where(Y > F32(0.008856), F32(116.0) * fy - F32(16.0), F32(903.3) * Y)
+    return (_sat_u8(L * F32(2.55)), _sat_u8(F32(500.0) * (fx - fy) + F32(128.0)), _sat_u8(F32(200.0) * (fy - fz) + F32(128.0)))
+
+
+def lab8_to_rgb8(L8, a8, b8):
+    L, a, b = L8 * F32(100.0 / 255.0), a8 - F32(128.0), b8 - F32(128.0)
+    fy = (L + F32(16.0)) * F32(1 / 116.0)
+    fx, fz = fy + a * F32(1 / 500.0), fy - b * F32(1 / 200.0)
+    inv = lambda f: np.where(f > F32(0.206893), f * f * f, (f - F32(16.0 / 116.0)) * F32(1 / 7.787))
+    Y = np.where(L > F32(7.9996), fy * fy * fy, L * F32(1 / 903.3))
+    X, Z = inv(fx) * F32(0.950456), inv(fz) * F32(1.088754)
+    r = F32(3.240479) * X - F32(1.537150) * Y - F32(0.498535) * Z
+    g = F32(-0.969256) * X + F32(1.875991) * Y + F32(0.041556) * Z
+    bl = F32(0.055648) * X - F32(0.204043) * Y + F32(1.057311) * Z
+    return np.stack([_sat_u8(F32(255.0) * _linear_to_srgb(np.clip(ch, 0, 1).astype(np.float32))) for ch in (r, g, bl)], -1)
+
+
+def clahe_l8(L8, clip_limit, tiles=8):
+    """OpenCV CLAHE on one uint8-valued channel (H,W) float32 -> equalised channel."""
+    H, W = L8.shape
+    Hp = H + (tiles - H % tiles) % tiles
+    Wp = W + (tiles - W % tiles) % tiles
+    ys, xs = reflect101(np.arange(Hp), H), reflect101(np.arange(Wp), W)
+    ext = L8[ys][:, xs].astype(np.int64)
+    th, tw = Hp // tiles, Wp // tiles
+    area = th * tw
+    clip = max(int(F32(clip_limit) * F32(area) / F32(256.0)), 1)
+    luts = np.zeros((tiles, tiles, 256), dtype=np.float32)
+    for ty in range(tiles):
+        for tx in range(tiles):
+            hist = np.bincount(ext[ty * th:(ty + 1) * th, tx * tw:(tx + 1) * tw].ravel(), minlength=256)
+            clipped = int(np.maximum(hist - clip, 0).sum())
+            hist = np.minimum(hist, clip)
+            batch = clipped // 256
+            residual = clipped - batch * 256
+            hist = hist + batch
+            if residual > 0:
+                step = max(256 // residual, 1)
+                i = 0
+                while i < 256 and residual > 0:
+                    hist[i] += 1
+                    i += step
+                    residual -= 1
+            luts[ty, tx] = _sat_u8(np.cumsum(hist).astype(np.float32) * (F32(255.0) / F32(area)))
+    y, x = np.meshgrid(np.arange(H, dtype=np.float32), np.arange(W, dtype=np.float32), indexing='ij')
+    tyf, txf = y * (F32(1.0) / F32(th)) - F32(0.5), x * (F32(1.0) / F32(tw)) - F32(0.5)
+    ty1, tx1 = np.floor(tyf).astype(np.int64), np.floor(txf).astype(np.int64)
+    ya, xa = (tyf - ty1).astype(np.float32), (txf - tx1).astype(np.float32)
+    ty2, tx2 = np.minimum(ty1 + 1, tiles - 1), np.minimum(tx1 + 1, tiles - 1)
+    ty1, tx1 = np.maximum(ty1, 0), np.maximum(tx1, 0)
+    v = L8.astype(np.int64)
+    res = (luts[ty1, tx1, v] * (1 - xa) + luts[ty1, tx2, v] * xa) * (1 - ya) + (luts[ty2, tx1, v] * (1 - xa) + luts[ty2, tx2, v] * xa) * ya
+    return _sat_u8(res)
+
+
+def blur3(img):
+    """cv2.blur(img, (3,3)), BORDER_REFLECT_101, on (H,W,3) uint8-valued float32."""
+    H, W = img.shape[:2]
+    acc = np.zeros_like(img, dtype=np.float32)
+    for dy in (-1, 0, 1):
+        for dx in (-1, 0, 1):
+            acc += img[reflect101(np.arange(H) + dy, H)][:, reflect101(np.arange(W) + dx, W)]
+    return _sat_u8(acc * F32(1.0 / 9.0))
+
+
+def appearance(img_u8, row):
+    """img (H,W,3) uint8, row: 8 floats {alpha, beta, hue, sat, val, clahe_clip, blur, 0} -> (H,W,3) uint8."""
+    a = np.asarray(row, dtype=np.float32)
+    c = img_u8.astype(np.float32)
+    if a[2] != 0 or a[3] != 0 or a[4] != 0:
+        h, s, v = rgb_to_hsv8(c)
+        h, s = np.rint(h), np.rint(s)
+        h = np.fmod(h + a[2] + F32(360.0), F32(180.0))
+        s = np.clip(s + a[3], 0, 255)
+        v = np.clip(v + a[4], 0, 255)
+        c = _sat_u8(hsv8_to_rgb(h.astype(np.float32), s.astype(np.float32), v.astype(np.float32)))
+    c = _sat_u8(c * a[0] + a[1] * F32(255.0))
+    if a[5] > 0:
+        L8, a8, b8 = rgb8_to_lab8(c)
+        c = lab8_to_rgb8(clahe_l8(L8, a[5]), a8, b8)
+    if a[6] != 0:
+        c = blur3(c)
+    return c.astype(np.uint8)

@@ -314,3 +314,53 @@ def full_size_golden():
 
 if __name__ == '__main__' and 'full' in sys.argv[1:]:
     full_size_golden()
+
+
+def postprocess_golden():
+    """The small-region post-processing of the reference's evaluation script (scripts/evaluate_glas.py:29-43) on seeded
+    blob masks -> tests/golden/postprocess.npz.  The script executes its whole evaluation at import, so only the
+    ``postprocess`` function is taken from it: its definition is located with ``ast`` in the file where it lies and
+    compiled from there (nothing of it is stored here); ``label`` is the same scipy stand-in for skimage.measure.label
+    as in metrics_golden()."""
+    import ast
+    from scipy import ndimage
+    path = os.path.join(REF, 'scripts', 'evaluate_glas.py')
+    tree = ast.parse(open(path).read(), filename=path)
+    fn = next(n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == 'postprocess')
+    ns = {'label': lambda a: ndimage.label(np.asarray(a) != 0, structure=np.ones((3, 3), dtype=np.int32))[0], 'np': np}
+    exec(compile(ast.Module(body=[fn], type_ignores=[]), path, 'exec'), ns)
+    ref_postprocess = ns['postprocess']
+
+    def blobs(seed, H, W, n, rmax):
+        rs = np.random.RandomState(seed)
+        yy, xx = np.mgrid[0:H, 0:W]
+        m = np.zeros((H, W), dtype=np.float64)
+        for _ in range(n):
+            cy, cx, r = rs.randint(0, H), rs.randint(0, W), rs.randint(3, rmax)
+            m[(yy - cy) ** 2 + (xx - cx) ** 2 <= r * r] = 1
+        for _ in range(n):                                        # holes of assorted sizes
+            cy, cx, r = rs.randint(0, H), rs.randint(0, W), rs.randint(2, rmax // 2)
+            m[(yy - cy) ** 2 + (xx - cx) ** 2 <= r * r] = 0
+        return m
+    out = {}
+    cases = [(1, 200, 260, 14, 40), (2, 200, 260, 30, 30), (3, 150, 150, 3, 60), (4, 120, 300, 0, 10)]
+    cases_full = [np.ones((100, 120)), np.zeros((100, 120))]
+    n = 0
+    for seed, H, W, k, rmax in cases:
+        m = blobs(seed, H, W, k, rmax)
+        out[f'in{n}'] = np.packbits(m.astype(np.uint8), axis=None)
+        out[f'shape{n}'] = np.array(m.shape)
+        out[f'out{n}'] = np.packbits(ref_postprocess(m.copy()).astype(np.uint8), axis=None)
+        print('postprocess case', n, m.shape, int(m.sum()), '->', int(np.unpackbits(out[f'out{n}'])[:m.size].sum()))
+        n += 1
+    for m in cases_full:
+        out[f'in{n}'] = np.packbits(m.astype(np.uint8), axis=None)
+        out[f'shape{n}'] = np.array(m.shape)
+        out[f'out{n}'] = np.packbits(ref_postprocess(m.astype(np.float64).copy()).astype(np.uint8), axis=None)
+        n += 1
+    out['n'] = n
+    np.savez_compressed(os.path.join(ROOT, 'tests', 'golden', 'postprocess.npz'), **out)
+
+
+if __name__ == '__main__' and 'postprocess' in sys.argv[1:]:
+    postprocess_golden()

@@ -115,3 +115,96 @@ def test_rank_sharding_partitions_an_epoch():
     assert len({len(s) for s in shards}) == 1
     assert set(sum(shards, [])) == set(range(n))
     assert shards != [shard_indices(n, r, world, seed=5, epoch=3) for r in range(world)]
+
+
+def test_area_v2_compound_and_negative_datasets(tmp_path):
+    """The remaining datasets of the reference's utils/data.py: AreaConstraintDataset (:168-277), WESUPV2Dataset
+    (:378-406), CompoundDataset (:515-528) and the Digest-2019 'negative' rule (:462-499)."""
+    from PIL import Image
+    from wesup_amd.utils import data as D
+    truth = _make_dataset(str(tmp_path), n=3, H=40, W=56)
+    fracs = [float(t[1].mean()) for t in truth]
+    with open(tmp_path / 'area.csv', 'w', newline='') as fp:
+        w = csv.writer(fp)
+        w.writerow(['img', 'area'])
+        w.writerows([[f'im{i:02d}.png', fracs[i]] for i in range(3)])
+    ds = D.AreaConstraintDataset(tmp_path)
+    img, mask, pts, area = ds[1]
+    assert img.shape == (40, 56, 3) and area.dtype == torch.float32
+    assert torch.allclose(area, torch.tensor([fracs[1], fracs[1]], dtype=torch.float32))       # equality: (a, a)
+    ds = D.AreaConstraintDataset(tmp_path, area_type='integer', constraint='individual', margin=0.1)
+    n_pos = int(truth[2][1].sum())
+    assert ds[2][3].tolist() == [int(n_pos * 0.9), int(n_pos * 1.1)] and ds[2][3].dtype == torch.int64
+    ds = D.AreaConstraintDataset(tmp_path, constraint='common')
+    assert ds[0][3].tolist() == pytest.approx([min(fracs), max(fracs)])
+    ds = D.AreaConstraintDataset(tmp_path, area_type='integer', constraint='common', target_size=(20, 28))
+    assert ds[0][3].tolist() == [int(min(fracs) * 560), int(max(fracs) * 560)]
+    # WESUPV2: per-pixel label maps from spl-masks/*.npy and the reference's coordinate map
+    os.makedirs(tmp_path / 'spl-masks')
+    rs = np.random.RandomState(1)
+    spl = [(rs.random_sample((40, 56, 2)) > 0.5).astype(np.int64) for _ in range(3)]
+    for i, m in enumerate(spl):
+        np.save(tmp_path / 'spl-masks' / f'im{i:02d}.npy', m)
+    v2 = D.WESUPV2Dataset(tmp_path, train=False)
+    img, mask, coords = v2[2]
+    assert mask.shape == (2, 40, 56) and mask.dtype == torch.int64 and np.array_equal(mask.numpy(), spl[2].transpose(2, 0, 1))
+    x, y = np.linspace(0, 1, 40), np.linspace(0, 1, 56)
+    want = np.stack([np.tile(x, 56), np.repeat(y, 40)]).astype(np.float32).reshape(2, 40, 56)     # utils/data.py:385-392
+    assert coords.shape == (2, 40, 56) and np.array_equal(coords.numpy(), want)
+    # Compound: items in lock step
+    both = D.CompoundDataset(D.SegmentationDataset(tmp_path), v2)
+    assert len(both) == 3 and len(both[1]) == 2 and torch.equal(both[1][0][0], both[1][1][0])
+    # Digest 2019: an image named negative* carries the sentinel row instead of csv points
+    Image.fromarray(np.zeros((40, 56, 3), dtype=np.uint8)).save(tmp_path / 'images' / 'negative1.png')
+    Image.fromarray(np.zeros((40, 56), dtype=np.uint8)).save(tmp_path / 'masks' / 'negative1.png')
+    (tmp_path / 'points' / 'negative1.csv').write_text('')
+    dg = D.get_dataset(tmp_path, train=True)
+    assert isinstance(dg, D.Digest2019PointDataset)
+    k = [p.name for p in dg.img_paths].index('negative1.png')
+    assert dg[k][2][0].tolist() == [-2, -2, -2] and int(dg[k][2][1:].max()) == -1
+    assert dg[0][2][0].tolist() == truth[0][2][0].tolist()
+    # validation data is always a plain SegmentationDataset (models/wesup.py:443)
+    assert type(D.get_dataset(tmp_path, train=False)) is D.SegmentationDataset
+
+
+def test_elastic_affine_and_appearance_sampling():
+    from wesup_amd.utils import data as D
+    rs = np.random.RandomState(0)
+    E = D.elastic_affine(rs, 60, 80)
+    # an affine map that moves the three control points by at most alpha_affine = 50 pixels each
+    c, sq = np.array([30.0, 40.0]), 20
+    pts1 = np.array([c + sq, [c[0] + sq, c[1] - sq], c - sq])
+    moved = pts1 @ E[:2, :2].T + E[:2, 2]
+    assert E.shape == (3, 3) and np.allclose(E[2], [0, 0, 1]) and np.abs(moved - pts1).max() <= 50.0
+    assert np.abs(moved - pts1).max() > 1.0
+    draws = [D.sample_appearance(rs, True) for _ in range(400)]
+    clips = [c for c, _ in draws if c > 0]
+    assert 0.4 < len(clips) / 400 < 0.6 and 1.0 <= min(clips) and max(clips) <= 4.0          # CLAHE p = 0.5, clip in [1, 4]
+    assert 0.4 < np.mean([b for _, b in draws]) < 0.6                                          # Blur p = 0.5
+    assert D.sample_appearance(rs, False) == (0.0, 0.0)
+    # mask pipelines draw the elastic affine (p = 0.5), point pipelines never do: their maps stay similarity transforms
+    for _ in range(20):
+        _, M = D.sample_params(rs, 64, 64, True, point_pipeline=True)
+        A = M[:, :2]
+        assert abs(abs(np.linalg.det(A)) - np.linalg.norm(A[0]) ** 2) < 1e-9
+
+
+def test_appearance_oracle_invariants():
+    """oracle/augment_oracle.py appearance(): identity, blur of a constant image, CLAHE keeps a constant image constant
+    and stretches a low-contrast one, Lab round trip within a grey level or two."""
+    from oracle import augment_oracle as ao
+    rs = np.random.RandomState(2)
+    img = rs.randint(0, 256, (37, 53, 3)).astype(np.uint8)
+    ident = np.array([1, 0, 0, 0, 0, 0, 0, 0], dtype=np.float32)
+    assert np.array_equal(ao.appearance(img, ident), img)
+    const = np.full((40, 48, 3), 137, dtype=np.uint8)
+    blur = ident.copy(); blur[6] = 1
+    assert np.array_equal(ao.appearance(const, blur), const)
+    b = ao.appearance(img, blur).astype(np.int32)
+    assert abs(b[10, 10, 0] - int(np.rint(img[9:12, 9:12, 0].mean()))) <= 0
+    flat = np.clip(128 + rs.randint(-6, 7, (64, 64, 3)), 0, 255).astype(np.uint8)
+    cl = ident.copy(); cl[5] = 4.0
+    assert ao.appearance(flat, cl).std() > 1.5 * flat.std()
+    L8, a8, b8 = ao.rgb8_to_lab8(img.astype(np.float32))
+    back = np.abs(ao.lab8_to_rgb8(L8, a8, b8) - img)          # 8-bit Lab quantises a and b: a few levels on saturated colours
+    assert back.max() <= 20 and back.mean() < 1.0 and np.percentile(back, 99) <= 8

@@ -158,3 +158,68 @@ def test_window_inference_matches_per_window_forward(tmp_path):
     one = pm(T._to_tensor(img[:ps, :ps], 'cuda:0')).cpu().numpy()[..., 1]
     # top-left corner pixels are covered by the first window only
     assert np.allclose(prob[:8, :8], one[:8, :8], atol=1e-6)
+
+
+def test_appearance_kernel_matches_the_numpy_restatement():
+    """wesup_appearance (HSV -> brightness/contrast -> CLAHE -> Blur, uint8 at every stage) against
+    oracle/augment_oracle.py; sizes that are not multiples of the 8x8 tile grid exercise the reflected padding."""
+    from oracle import augment_oracle as ao
+    from wesup_amd import ops
+    d = torch.device('cuda:0')
+    rs = np.random.RandomState(5)
+    B, H, W = 6, 75, 100
+    yy, xx = np.mgrid[0:H, 0:W]
+    img = np.zeros((B, H, W, 3), dtype=np.uint8)
+    for b in range(B):                                   # smooth H&E-like gradients + noise: real histograms, not flat ones
+        base = np.stack([150 + 60 * np.sin(xx / (9.0 + b)), 90 + 50 * np.cos(yy / (7.0 + b)), 140 + 40 * np.sin((xx + yy) / 11.0)], -1)
+        img[b] = np.clip(base + rs.randint(-25, 26, (H, W, 3)), 0, 255).astype(np.uint8)
+    rows = np.zeros((B, 8), dtype=np.float32)
+    rows[:, 0] = 1.0
+    rows[1, 5] = 2.5                                     # CLAHE only
+    rows[2, 6] = 1.0                                     # Blur only
+    rows[3] = [1.1, -0.05, 12.0, -20.0, 9.0, 3.7, 1.0, 0.0]     # everything
+    rows[4] = [0.8, 0.1, -15.0, 25.0, -12.0, 0.0, 0.0, 0.0]     # colour only
+    rows[5, 5] = 1.0                                     # the lowest clip limit
+    out = ops.appearance(torch.from_numpy(img).to(d), torch.from_numpy(rows).to(d)).cpu().numpy()
+    assert np.array_equal(out[0], img[0])                # identity parameters: untouched
+    for b in range(1, B):
+        want = ao.appearance(img[b], rows[b]).astype(np.int32)
+        diff = np.abs(out[b].astype(np.int32) - want)
+        if rows[b, 5] == 0 and (rows[b, 2:5] == 0).all():
+            assert diff.max() == 0, (b, diff.max())      # integer paths (blur, gain): exact
+        else:
+            # pow / cbrt of the sRGB <-> Lab round trip and the piecewise HSV differ in the last bit between libm and the
+            # device: single grey levels on a small share of the pixels, never more
+            assert diff.max() <= 2 and np.mean(diff > 0) < 0.05, (b, diff.max(), np.mean(diff > 0))
+    # CLAHE really equalises: the L histogram of a low-contrast image spreads out
+    flat = np.clip(128 + rs.randint(-6, 7, (1, 64, 64, 3)), 0, 255).astype(np.uint8)
+    r = np.array([[1, 0, 0, 0, 0, 4.0, 0, 0]], dtype=np.float32)
+    eq = ops.appearance(torch.from_numpy(flat).to(d), torch.from_numpy(r).to(d)).cpu().numpy()
+    assert eq.std() > 1.5 * flat.std()
+
+
+def test_prefetcher_runs_clahe_blur_and_negative_images(tmp_path):
+    """The training pipeline from disk with CLAHE / Blur drawn (p = 0.5 each) and a Digest-2019 'negative' image whose
+    pixel mask is its point annotation (utils/data.py:409-512)."""
+    from PIL import Image
+    from tests.test_data_cpu import _make_dataset
+    from wesup_amd.utils import data as D
+    _make_dataset(str(tmp_path), n=4, H=64, W=64)
+    # a "negative" image: no csv needed, its (all background) mask is the annotation
+    Image.fromarray(np.full((64, 64, 3), 200, dtype=np.uint8)).save(tmp_path / 'images' / 'negative_00.png')
+    Image.fromarray(np.zeros((64, 64), dtype=np.uint8)).save(tmp_path / 'masks' / 'negative_00.png')
+    (tmp_path / 'points' / 'negative_00.csv').write_text('')
+    ds = D.get_dataset(tmp_path, train=True)
+    assert isinstance(ds, D.Digest2019PointDataset) and len(ds) == 5
+    neg = [i for i in range(5) if ds.img_paths[i].name.startswith('negative')][0]
+    loader = torch.utils.data.DataLoader(ds, batch_size=5, shuffle=False, num_workers=0)
+    seen_app = False
+    for seed in range(4):
+        pf = D.DevicePrefetcher(loader, 'cuda:0', train=True, with_points=True, has_masks=True, seed=seed)
+        (img, pixel_mask, point_mask), = list(pf)
+        assert img.shape == (5, 3, 64, 64) and 0.0 <= float(img.min()) and float(img.max()) <= 1.0
+        assert torch.equal(point_mask[neg], pixel_mask[neg]) and int(point_mask[neg, 0].sum()) == 64 * 64
+        others = [i for i in range(5) if i != neg]
+        assert int(point_mask[others].sum()) < 5 * 64            # radius-0 dots elsewhere
+        seen_app = True
+    assert seen_app

@@ -25,6 +25,8 @@ _SIGS = {
     'wesup_debug_set_trace': (c_int, 'p'),
     'wesup_strerror': (ctypes.c_char_p, 'i'),
     'wesup_augment': (c_int, 'pppppiiiip'),
+    'wesup_appearance_workspace_bytes': (c_size_t, 'iii'),
+    'wesup_appearance': (c_int, 'pppiiipzp'),
     'wesup_pack_input': (c_int, 'ppiiip'),
     'wesup_conv3x3_kpad': (c_int, 'i'),
     'wesup_pack_conv3x3_weight': (c_int, 'pppiip'),

@@ -69,6 +69,19 @@ def augment(img_u8, mask_u8, params, n_classes=2):
     return out, om
 
 
+def appearance(img_u8, params):
+    """img (B,H,W,3) uint8, params (B,8) fp32 {alpha, beta, hue, sat, val, clahe_clip, blur, 0} -> (B,H,W,3) uint8 after
+    HueSaturationValue, RandomBrightnessContrast, CLAHE and Blur(3) in the reference's order."""
+    _chk(img_u8, torch.uint8, 'img'); _chk(params, name='params')
+    B, H, W, three = img_u8.shape
+    assert three == 3 and params.shape == (B, 8)
+    out = torch.empty_like(img_u8)
+    nb = _lib.load().wesup_appearance_workspace_bytes(B, H, W)
+    ws = workspace(nb, img_u8.device, 'appearance')
+    _lib.call('wesup_appearance', _p(img_u8), _p(params), _p(out), B, H, W, _p(ws), nb, _stream())
+    return out
+
+
 # ---------------------------------------------------------------- packing
 def pack_input(img, out=None):
     _chk(img, name='img')

@@ -9,8 +9,10 @@ brightness/contrast, ToTensor, one-hot masks); keypoints follow the same affine 
 as radius-0 dots (utils/data.py:352-362).  What comes out is the reference's item contract, batched:
 ``img f32 (B,3,H,W) in [0,1]``, ``pixel_mask (B,C,H,W)`` one-hot or the empty tensor, ``point_mask (B,C,H,W)``.
 
-Not reproduced: CLAHE, Blur, ElasticTransform of the reference's pipelines; exact skimage / OpenCV / albumentations
-numerics (all absent from the build image: parity unpinned).  ``SyntheticGlasDataset`` keeps producing
+CLAHE and Blur run on the GPU as well (``wesup_appearance``, on the un-warped image and in the reference's order),
+ElasticTransform -- with the albumentations defaults a random 3-point affine plus a displacement field of < 0.05 px --
+is folded into the affine map.  Not reproduced: exact skimage / OpenCV / albumentations numerics (all absent from the
+build image: parity unpinned).  ``SyntheticGlasDataset`` keeps producing
 GlaS-shaped items of the same contract for benchmarks ('synthetic:H:W:g:n')."""
 import csv
 from pathlib import Path
@@ -162,6 +164,113 @@ class PointSupervisionDataset(SegmentationDataset):
         return torch.from_numpy(img), torch.from_numpy(mask), torch.from_numpy(pts)
 
 
+
+class Digest2019PointDataset(PointSupervisionDataset):
+    """PointSupervisionDataset plus the Digest-2019 rule for images whose file name starts with ``negative``
+    (utils/data.py:409-512): such an image has no tumour anywhere, so instead of reading a csv its whole pixel mask IS
+    its point annotation (``point_mask = pixel_mask``, :497-499).  The raw item says so with one sentinel point row
+    (-2, -2, -2); ``DevicePrefetcher`` then copies the augmented one-hot pixel mask into the point mask."""
+    NEGATIVE = -2
+
+    def __getitem__(self, i):
+        idx = int(self.picked[i])
+        if not self.img_paths[idx].name.startswith('negative'):
+            return super().__getitem__(i)
+        img, mask, _, _ = self._load(idx)
+        if mask is None:
+            mask = np.zeros(img.shape[:2], dtype=np.uint8)              # "negative": background everywhere
+        pts = np.full((self.P_MAX, 3), -1, dtype=np.int32)
+        pts[0] = self.NEGATIVE
+        return torch.from_numpy(img), torch.from_numpy(mask), torch.from_numpy(pts)
+
+
+class AreaConstraintDataset(SegmentationDataset):
+    """images + masks + ``area.csv`` (columns ``img,area``: foreground fraction per image) -> raw item with a fourth
+    element, the (lower, upper) bound of the foreground area (utils/data.py:168-277).  ``area_type`` 'decimal' keeps
+    the fraction, 'integer' counts the positive pixels of the (resized) mask; ``constraint`` 'equality' gives
+    (a, a), 'individual' (a(1-margin), a(1+margin)) truncated to integers as the reference's ``.long()`` does,
+    'common' the dataset-wide (min, max)."""
+
+    def __init__(self, root_dir, target_size=None, rescale_factor=None, area_type='decimal', constraint='equality',
+                 margin=0.1, train=True, proportion=1.0):
+        super().__init__(root_dir, mode='area', target_size=target_size, rescale_factor=rescale_factor, train=train,
+                         proportion=proportion)
+        with open(self.root_dir / 'area.csv') as fp:
+            rows = list(csv.DictReader(fp))
+        self.area_info = np.array([float(r['area']) for r in rows], dtype=np.float64)      # row i <-> image i (:257)
+        self.area_type, self.constraint, self.margin = area_type, constraint, margin
+
+    def __getitem__(self, i):
+        idx = int(self.picked[i])
+        img, mask, pts = super().__getitem__(i)
+        if self.area_type == 'decimal':
+            area = float(self.area_info[idx])
+        else:
+            area = float((mask == 1).sum())
+        if self.constraint == 'equality':
+            bounds = torch.tensor([area, area], dtype=torch.float32)
+        elif self.constraint == 'individual':
+            bounds = torch.tensor([area * (1 - self.margin), area * (1 + self.margin)]).long()
+        else:
+            lower, upper = float(self.area_info.min()), float(self.area_info.max())
+            if self.area_type == 'integer':
+                size = self.target_size if self.target_size is not None else mask.shape
+                lower, upper = int(lower * np.prod(size)), int(upper * np.prod(size))
+            bounds = torch.tensor([lower, upper])
+        return img, mask, pts, bounds
+
+
+class WESUPV2Dataset(SegmentationDataset):
+    """images + ``spl-masks/*.npy`` (per-pixel soft label maps (H, W, C) made by scripts/generate_spl_masks.py) -> raw
+    item (img, mask (C, H, W) int64, coords (2, H, W) float32), utils/data.py:378-406.  ``coords`` is the reference's
+    normalised position map (its ``_generate_coords`` tiles ``linspace(0, 1, H)`` along the fast axis and views the
+    result as (2, H, W), which is what is reproduced here, quirk included)."""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.spl_paths = None
+        if (self.root_dir / 'spl-masks').exists():
+            self.spl_paths = sorted((self.root_dir / 'spl-masks').iterdir())
+
+    @staticmethod
+    def _generate_coords(shape):
+        x = np.linspace(0, 1, shape[0])
+        y = np.linspace(0, 1, shape[1])
+        coords = torch.as_tensor(np.stack([np.tile(x, len(y)), np.repeat(y, len(x))]), dtype=torch.float32)
+        return coords.view(2, shape[0], shape[1])
+
+    def __getitem__(self, i):
+        idx = int(self.picked[i])
+        img, _, _, _ = self._load(idx)
+        h, w = img.shape[:2]
+        if self.spl_paths is None:
+            raise FileNotFoundError(f'{self.root_dir}/spl-masks is missing')
+        spl = np.load(self.spl_paths[idx])
+        if spl.shape[:2] != (h, w):                                    # nearest resize, as for masks (utils/data.py:26-30)
+            yy = (np.arange(h) * spl.shape[0] / h).astype(np.int64)
+            xx = (np.arange(w) * spl.shape[1] / w).astype(np.int64)
+            spl = spl[yy][:, xx]
+        mask = torch.as_tensor(np.ascontiguousarray(spl.transpose(2, 0, 1)), dtype=torch.long)
+        return torch.from_numpy(img), mask, self._generate_coords(img.shape)
+
+
+class CompoundDataset(torch.utils.data.Dataset):
+    """Several datasets read in lock step: item i is the tuple of every dataset's item i (utils/data.py:515-528)."""
+
+    def __init__(self, *datasets):
+        self.datasets = datasets
+
+    def __len__(self):
+        return len(self.datasets[0])
+
+    def __getitem__(self, idx):
+        return tuple(dataset[idx] for dataset in self.datasets)
+
+    def summary(self, logger=None):
+        for dataset in self.datasets:
+            dataset.summary(logger=logger)
+
+
 def sample_params(rs, H, W, train, point_pipeline=True):
     """12 floats for wesup_augment + the forward 2x3 matrix for keypoints.  Parameter ranges are the albumentations
     defaults the reference's pipelines rely on (utils/data.py:116-133 for masks, :302-327 for points)."""
@@ -169,6 +278,8 @@ def sample_params(rs, H, W, train, point_pipeline=True):
     row = np.zeros(12, dtype=np.float32)
     row[6] = 1.0
     if train:
+        if not point_pipeline and rs.random_sample() < 0.5:      # A.ElasticTransform(p=0.5), mask pipelines only
+            M = elastic_affine(rs, H, W) @ M
         if rs.random_sample() < 0.5:
             M = np.array([[-1, 0, W - 1], [0, 1, 0], [0, 0, 1.0]]) @ M
         if rs.random_sample() < 0.5:
@@ -187,6 +298,31 @@ def sample_params(rs, H, W, train, point_pipeline=True):
     Minv = np.linalg.inv(M)
     row[0:3], row[3:6] = Minv[0], Minv[1]
     return row, M[:2]
+
+
+def elastic_affine(rs, H, W, alpha_affine=50.0):
+    """The affine part of albumentations' ElasticTransform(alpha=1, sigma=50, alpha_affine=50) (utils/data.py:124):
+    three corners of a centred square are moved by U(-alpha_affine, alpha_affine) pixels each and the affine map through
+    the three pairs is applied (cv2.getAffineTransform / warpAffine).  Its second part, a displacement field
+    gaussian_filter(U(-1, 1), sigma=50) * alpha, has a standard deviation of ~0.006 px at alpha = 1 and is dropped.
+    (albumentations builds the points from (height, width) and hands them to OpenCV as (x, y); kept.)"""
+    c = np.array([H // 2, W // 2], dtype=np.float64)
+    sq = min(H, W) // 3
+    pts1 = np.array([c + sq, [c[0] + sq, c[1] - sq], c - sq])
+    pts2 = pts1 + rs.uniform(-alpha_affine, alpha_affine, size=pts1.shape)
+    A = np.concatenate([pts1, np.ones((3, 1))], 1)
+    sol = np.linalg.solve(A, pts2)                     # rows of sol: coefficients of x, y, 1 for (x', y')
+    return np.array([[sol[0, 0], sol[1, 0], sol[2, 0]], [sol[0, 1], sol[1, 1], sol[2, 1]], [0, 0, 1.0]])
+
+
+def sample_appearance(rs, train, point_pipeline=True):
+    """(clahe clip limit or 0, blur 0/1): A.CLAHE(p=0.5) draws its clip limit from U(1, 4); A.Blur(blur_limit=3, p=0.5)
+    is always the 3x3 box (utils/data.py:122,125,309-310).  Both pipelines of the reference carry the two."""
+    if not train:
+        return 0.0, 0.0
+    clip = float(rs.uniform(1.0, 4.0)) if rs.random_sample() < 0.5 else 0.0
+    blur = 1.0 if rs.random_sample() < 0.5 else 0.0
+    return clip, blur
 
 
 def transform_points(pts_xyc, M, H, W):
@@ -234,7 +370,17 @@ class DevicePrefetcher:
         img, mask, pts = raw
         B, H, W, _ = img.shape
         rows, mats = zip(*[sample_params(self.rs, H, W, self.train, self.with_points) for _ in range(B)])
-        params = torch.from_numpy(np.stack(rows))
+        rows = np.stack(rows)
+        app = np.zeros((B, 8), dtype=np.float32)
+        app[:, 0] = 1.0
+        for b in range(B):
+            app[b, 5], app[b, 6] = sample_appearance(self.rs, self.train, self.with_points)
+        need_app = bool((app[:, 5:7] != 0).any()) and min(H, W) >= 8
+        if need_app:           # colour first, then CLAHE / Blur, all on the un-warped image; the warp gets neutral colour
+            app[:, 0:5] = rows[:, 6:11]
+            rows[:, 6], rows[:, 7:11] = 1.0, 0.0
+        params = torch.from_numpy(rows)
+        negative = [b for b in range(B) if int(pts[b][0, 2]) == Digest2019PointDataset.NEGATIVE]
         bi, ci, yi, xi = [], [], [], []
         if self.with_points:                     # keypoints follow the forward map on the host (a few hundred per image)
             for b in range(B):
@@ -245,6 +391,8 @@ class DevicePrefetcher:
             d_img = img.pin_memory().to(self.device, non_blocking=True)
             d_mask = mask.pin_memory().to(self.device, non_blocking=True) if self.has_masks else None
             d_par = params.pin_memory().to(self.device, non_blocking=True)
+            if need_app:
+                d_img = ops.appearance(d_img, torch.from_numpy(app).pin_memory().to(self.device, non_blocking=True))
             out_img, out_mask = ops.augment(d_img, d_mask, d_par, self.n_classes)
             point_mask = None
             if self.with_points:
@@ -252,6 +400,9 @@ class DevicePrefetcher:
                 if idx.shape[1]:
                     d_idx = idx.pin_memory().to(self.device, non_blocking=True)
                     point_mask[d_idx[0], d_idx[1], d_idx[2], d_idx[3]] = 1
+                for b in negative:                   # Digest-2019 "negative" images: the pixel mask IS the annotation
+                    if out_mask is not None:
+                        point_mask[b] = out_mask[b]
             segments = counts = None
             if self.segment_fn is not None:
                 segments, n_dev = self.segment_fn(out_img)
@@ -294,14 +445,16 @@ class DevicePrefetcher:
 
 
 def get_dataset(root_dir, train=True, proportion=1.0, multiscale_range=None, rescale_factor=None, target_size=None):
+    """WESUPTrainer.get_default_dataset (models/wesup.py:436-443): training data with a ``points`` directory is a
+    Digest2019PointDataset, everything else a SegmentationDataset ('synthetic:H:W:g:n' makes synthetic items)."""
     root = str(root_dir)
     if 'synthetic:' in root:
         spec = root[root.index('synthetic:'):].split('/')[0].split(':')[1:]
         H, W, g, n = (int(v) for v in (spec + ['480', '480', '24', '16'][len(spec):])[:4])
         return SyntheticGlasDataset(H, W, g, max(1, int(n * proportion)), seed=0 if train else 1)
     root_dir = Path(root_dir)
-    if (root_dir / 'points').exists():                                                 # models/wesup.py:436-443
-        return PointSupervisionDataset(root_dir, target_size=target_size, rescale_factor=rescale_factor,
-                                       multiscale_range=multiscale_range, train=train, proportion=proportion)
+    if train and (root_dir / 'points').exists():                                       # models/wesup.py:436-443
+        return Digest2019PointDataset(root_dir, target_size=target_size, rescale_factor=rescale_factor,
+                                      multiscale_range=multiscale_range, train=train, proportion=proportion)
     return SegmentationDataset(root_dir, target_size=target_size, rescale_factor=rescale_factor, train=train,
                                proportion=proportion, multiscale_range=multiscale_range)
