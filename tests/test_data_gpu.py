@@ -223,3 +223,24 @@ def test_prefetcher_runs_clahe_blur_and_negative_images(tmp_path):
         assert int(point_mask[others].sum()) < 5 * 64            # radius-0 dots elsewhere
         seen_app = True
     assert seen_app
+
+
+def test_glas_test_driver_and_scoring(tmp_path):
+    """test_glas.py:13-38 + scripts/evaluate_glas.py: checkpoint -> predictions for testA / testB under the record
+    directory -> post-processing and challenge metrics."""
+    from tests.test_data_cpu import _make_dataset
+    from wesup_amd import evaluate as E
+    from wesup_amd.models import initialize_trainer
+    for split in ('testA', 'testB'):
+        _make_dataset(str(tmp_path / 'glas' / split), n=2, H=72, W=88, with_points=False)
+    trainer = initialize_trainer('wesup', device='cuda:0', sp_area=64)
+    trainer.optimizer, _ = trainer.get_default_optimizer()
+    ck = tmp_path / 'record' / 'checkpoints' / 'ckpt.0001.pth'
+    trainer.save_checkpoint(ck, epoch=1)
+    out = E.test(ck, input_size=(64, 64), device='cuda:0', data_root=tmp_path / 'glas')
+    assert out == tmp_path / 'record' / 'results' and sorted(p.name for p in (out / 'testA').iterdir()) == ['im00.png', 'im01.png']
+    out2 = E.test(ck, scales=(0.5, 1.0), device='cuda:0', data_root=tmp_path / 'glas')
+    assert out2.name == 'results-2scale' and len(list((out2 / 'testB').iterdir())) == 2
+    res = E.evaluate_glas(out, tmp_path / 'glas', min_size=20, log=lambda s: None)
+    assert set(res) == {'testA', 'testB'} and 0.0 <= res['testA']['accuracy'] <= 1.0
+    assert (out / 'testA.csv').exists() and (tmp_path / 'record' / 'results-new' / 'testB' / 'im01.png').exists()
