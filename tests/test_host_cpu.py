@@ -127,3 +127,28 @@ def test_window_functions_match_reference():
     assert np.allclose(back, img, atol=1e-9)
     with pytest.raises(ValueError):
         T.divide_image_to_patches(img, 64)
+
+
+def test_record_dir_bookkeeping(tmp_path, monkeypatch):
+    """utils/record.py:16-107: run directory under $RECORD_ROOT, one params json per (re)start, a source snapshot,
+    learning curves from history.csv."""
+    from wesup_amd.utils import record
+    from wesup_amd.utils.history import HistoryTracker
+    monkeypatch.setenv('RECORD_ROOT', str(tmp_path))
+    rd = record.prepare_record_dir()
+    assert rd.parent == tmp_path and (rd / 'checkpoints').is_dir()
+    record.save_params(rd, {'epochs': 3})
+    record.save_params(rd, {'epochs': 5})
+    assert sorted(p.name for p in (rd / 'params').iterdir()) == ['0.json', '1.json']
+    record.copy_source_files(rd)
+    assert (rd / 'source' / 'wesup_amd' / 'engine.py').exists() and (rd / 'source' / 'wesup_amd' / 'csrc' / 'gemm.hip').exists()
+    assert (rd / 'source' / 'include' / 'wesup_hip.h').exists() and not list((rd / 'source').rglob('*.so'))
+    t = HistoryTracker(rd / 'history.csv')
+    for epoch in range(3):
+        t.start_new_epoch(5e-5)
+        t.train(); t.step({'loss': 1.0 / (epoch + 1), 'dice': 0.5 + 0.1 * epoch})
+        t.eval(); t.step({'dice': 0.4 + 0.1 * epoch})
+        t.save()
+    curves = record.plot_learning_curves(rd / 'history.csv')
+    assert sorted(p.name for p in curves) == ['dice.png', 'loss.png'] and all(p.stat().st_size > 1000 for p in curves)
+    assert 'dice' in t.report() and 'val_dice' in t.report() and 'loss' not in t.report().split('\n', 3)[-1]
