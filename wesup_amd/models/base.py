@@ -143,17 +143,19 @@ class BaseTrainer(ABC):
     def _loss_flag(self, loss):
         """Data parallel only: a NaN loss on ONE rank must stop EVERY rank before the weights are touched (its NaN
         gradients reach all ranks through the all-reduce, but only that rank sees a NaN loss).  The ranks agree through
-        a MAX all-reduce of a one-element flag, queued on the side stream right behind the loss kernels so that the
-        backward pass on the main stream does not wait for it; it comes back with the loss in the step's one
-        read-back."""
+        a MAX all-reduce of a one-element flag, queued right behind the loss kernels on a stream of its own -- neither
+        the backward pass on the main stream nor the side branch waits for it, so the rendezvous does not expose rank
+        skew in the middle of the step; it comes back with the loss in the step's one read-back."""
         import torch.distributed as dist
         flag = torch.isnan(loss.detach()).float().reshape(1)
-        side = self.model.engine._side()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
+        if getattr(self, '_flag_stream', None) is None:
+            self._flag_stream = torch.cuda.Stream(device=flag.device)
+        aux = self._flag_stream
+        aux.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(aux):
             dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=self.reducer.group)
-        flag.record_stream(side)
-        return flag, side
+        flag.record_stream(aux)
+        return flag, aux
 
     def train_one_iteration(self, phase, *data):
         from .. import ops
