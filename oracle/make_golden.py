@@ -316,6 +316,24 @@ if __name__ == '__main__' and 'full' in sys.argv[1:]:
     full_size_golden()
 
 
+def crag_size_golden():
+    """One image of BASELINE configs[3] through the REAL reference: 800x800, 1521 superpixels (g = 39), 20 %
+    point-labelled -> tests/golden/c800_g39.npz.  The reference materialises 3.9 GB of dense sp_maps and a 5.4 GB feature
+    map (plus its gradient and the re-copies of the growing map): ~30 GB peak and a few minutes on the build container."""
+    _install_standins()
+    sys.path.insert(0, REF)
+    import models.wesup as ref
+    from oracle import wesup_oracle as orc
+    from wesup_amd import synth
+    torch.set_num_threads(8)
+    _reference_case(ref, orc, synth, os.path.join(ROOT, 'tests', 'golden'), 'c800_g39', 800, 800, 39, 'point20', 1.5, 23,
+                    compact=True)
+
+
+if __name__ == '__main__' and 'crag' in sys.argv[1:]:
+    crag_size_golden()
+
+
 def postprocess_golden():
     """The small-region post-processing of the reference's evaluation script (scripts/evaluate_glas.py:29-43) on seeded
     blob masks -> tests/golden/postprocess.npz.  The script executes its whole evaluation at import, so only the

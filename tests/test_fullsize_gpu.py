@@ -1,8 +1,11 @@
-"""Parity of the HIP training step AT THE HEADLINE SIZE (480x480), on a real MI355X.
+"""Parity of the HIP training step AT THE SIZES OF THE BASELINE CONFIGS, on a real MI355X.
 
-  * against outputs of the REAL reference at 480x480 (tests/golden/c480_g14.npz = BASELINE configs[0]: 196 superpixels;
-    c480_g24.npz = one image of configs[1]: 576 superpixels; made by oracle/make_golden.py full from
+  * against outputs of the REAL reference at full size (tests/golden/c480_g14.npz = BASELINE configs[0]: 480x480, 196
+    superpixels; c480_g24.npz = one image of configs[1]: 576 superpixels; c800_g39.npz = one image of configs[3]:
+    800x800, 1521 superpixels; made by oracle/make_golden.py full / crag from
     /root/reference/models/wesup.py:18-139,263-304,492-531 + autograd backward);
+  * one image of configs[4] (1024x1024, 3025 superpixels) against the CPU oracle (the reference itself needs > 60 GB
+    there: 12.7 GB of dense sp_maps, a 8.9 GB feature map and their gradients);
   * against the CPU oracle at configs[1] EXACTLY (B = 4, 480x480, 576 superpixels, 20 % point-labelled): loss, metrics,
     every integer output bit-exact, every parameter gradient against an fp64 evaluation (tests/_gradcheck.py);
   * size-independent properties at the per-GPU shards of configs[3] (B = 4, 800x800, 1521 SP) and configs[4]
@@ -41,9 +44,9 @@ def make_trainer(weights, **kw):
     return trainer
 
 
-@pytest.mark.parametrize('name', ['c480_g14', 'c480_g24'])
-def test_step_matches_the_reference_at_480(golden_dir, name):
-    """The trainer's own path (preprocess -> forward -> compute_loss -> backward) on the reference's 480x480 inputs."""
+@pytest.mark.parametrize('name', ['c480_g14', 'c480_g24', 'c800_g39'])
+def test_step_matches_the_reference_at_full_size(golden_dir, name):
+    """The trainer's own path (preprocess -> forward -> compute_loss -> backward) on the reference's full-size inputs."""
     from oracle import wesup_oracle as orc
     from wesup_amd import ops
     torch.set_num_threads(min(16, os.cpu_count() or 1))
@@ -157,6 +160,63 @@ def test_config_c2_exactly_matches_the_oracle():
         assert rel_err(new[k], v) < 1e-5, k
     print(f'c2: loss {hist["loss"][0]:.6f} (oracle {ref_loss:.6f}), worst gradient error vs fp64 {worst:.2e}, '
           f'{n_named} near-tie decisions differ')
+
+
+def _host_memory_gb():
+    try:
+        lim = int(open('/sys/fs/cgroup/memory.max').read())
+    except Exception:
+        lim = 1 << 62
+    try:
+        avail = int(next(l for l in open('/proc/meminfo') if l.startswith('MemAvailable')).split()[1]) * 1024
+    except Exception:
+        avail = 0
+    return min(lim, avail) / 2 ** 30
+
+
+def test_one_image_of_config_c5_matches_the_oracle():
+    """BASELINE configs[4] shape: 1024x1024, 3025 superpixels, one image through train_one_iteration against the CPU
+    oracle's training step: loss, metrics, integer outputs bit-exact, every parameter gradient against fp64 under the
+    GPU's ReLU / pooling decisions.  (The fp64 evaluation holds ~90 GB on the host.)"""
+    if _host_memory_gb() < 160:
+        pytest.skip('needs ~90 GB of host memory for the fp64 evaluation at 1024x1024')
+    from oracle import wesup_oracle as orc
+    from wesup_amd import synth, ops
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    d = torch.device('cuda:0')
+    B, H, W, g = 1, 1024, 1024, 55
+    weights = orc.make_weights(0, feat_scale=1.0)
+    imgs, labs, pts, pix = synth.make_batch(7, B, H, W, g)
+    ref_loss, ref_grads, ref_new, _, outs, mets = orc.train_step(weights, imgs, labs.astype(np.int64), pts.astype(np.int64))
+    trainer = make_trainer(weights, max_superpixels=g * g)
+    trainer.train_one_iteration('train', torch.from_numpy(imgs).to(d), torch.from_numpy(pix).to(d), torch.from_numpy(pts).to(d),
+                                torch.from_numpy(labs).to(d))
+    model, hist = trainer.model, trainer.tracker.history
+    meta = model._last_meta
+    assert abs(hist['loss'][0] - ref_loss) <= TOL * abs(ref_loss)
+    assert hist['propagated_labels'][0] == mets[0]['propagated_labels'] and 0 < hist['propagated_labels'][0] < 0.8 * g * g
+    assert abs(hist['propagate_loss'][0] - mets[0]['propagate_loss']) < 1e-5
+    pp = outs[0]['pp']
+    n, n_l = pp['K'], pp['n_l']
+    assert n == g * g == int(meta.n_sp[0]) and int(meta.n_l[0]) == n_l
+    assert torch.equal(meta.perm[0, :n].cpu().long(), pp['perm']) and torch.equal(meta.sp_labels[0, :n_l].cpu(), pp['sp_labels'])
+    bufs = model.engine._last
+    feats = bufs.feats.view(1, meta.Kmax, -1)
+    assert rel_err(feats[0, :n], outs[0]['sp_features']) < TOL
+    y_all, src, sim = ops.propagate(feats.contiguous(), meta, 0.8)
+    y_u, _, max_sim, src_ref = orc.label_propagate(outs[0]['sp_features'], pp['sp_labels'], 0.8, return_aux=True)
+    near = (max_sim - 0.8).abs() < 1e-5
+    assert torch.equal(src[0, n_l:n].cpu().long()[~near], src_ref[~near]) and torch.equal(y_all[0, n_l:n].cpu()[~near], y_u[~near])
+    assert torch.equal(bufs.pred[0].round().long().cpu(), outs[0]['pred'].detach().round().long())
+    del outs, ref_grads
+    worst, n_named = _gradcheck.check_gradients(model, weights, imgs, labs, pts)
+    new = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    for k, v in ref_new.items():
+        assert rel_err(new[k], v) < 1e-5, k
+    print(f'c5 (one image): loss {hist["loss"][0]:.6f} (oracle {ref_loss:.6f}), worst gradient error vs fp64 {worst:.2e}, '
+          f'{n_named} near-tie decisions differ')
+    model.engine.release_buffers()
+    torch.cuda.empty_cache()
 
 
 @pytest.mark.parametrize('H,W,g,B', [(800, 800, 39, 4), (1024, 1024, 55, 8)])

@@ -77,11 +77,12 @@ def test_oracle_matches_reference(golden_dir, name):
         assert np.abs(samp - fx['gsamp.' + k]).max() <= 2e-4 * (np.abs(fx['gsamp.' + k]).max() + 1e-12), k
 
 
-@pytest.mark.parametrize('name', ['c480_g14'])
+@pytest.mark.parametrize('name', ['c480_g14', 'c800_g39'])
 def test_oracle_matches_reference_at_full_size(golden_dir, name):
-    """BASELINE configs[0] at its real size (480x480, 196 superpixels): the oracle against the reference's own outputs
-    (models/wesup.py:18-63, 263-304, 492-531 + backward).  c480_g24 (576 superpixels, one image of configs[1]) is
-    checked on the GPU box together with the HIP path (tests/test_fullsize_gpu.py)."""
+    """BASELINE configs[0] at its real size (480x480, 196 superpixels) and one image of configs[3] (800x800, 1521
+    superpixels): the oracle against the reference's own outputs (models/wesup.py:18-63, 263-304, 492-531 + backward).
+    c480_g24 (576 superpixels, one image of configs[1]) is checked on the GPU box together with the HIP path
+    (tests/test_fullsize_gpu.py)."""
     from conftest import load_full_size_case
     fx = load_full_size_case(golden_dir, name)
     torch.set_num_threads(8)
