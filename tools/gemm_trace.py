@@ -40,9 +40,23 @@ def run(name, fn, nblocks):
         print(f'   parts      : start p10 {np.percentile(st[pt],10):.1f} p50 {np.median(st[pt]):.1f} p90 {np.percentile(st[pt],90):.1f}, end p10 {np.percentile(en[pt],10):.1f} p50 {np.median(en[pt]):.1f} p90 {np.percentile(en[pt],90):.1f} max {en[pt].max():.1f}; duration p10 {np.percentile((en-st)[pt],10):.1f} p50 {np.median((en-st)[pt]):.1f} p90 {np.percentile((en-st)[pt],90):.1f}')
     first = st < 1.0
     print(f'   first-wave blocks: {first.sum()}  their loop p50 {np.median((le - ls)[first]):.1f}; later blocks loop p50 {np.median((le - ls)[~first]) if (~first).any() else 0:.1f}')
-M, N, K = 32768, 256, 2304
-A = torch.randn(M, K, device=d); B = torch.randn(N, K, device=d); C = torch.empty(M, N, device=d)
-run('gemm 512 tiles K=2304', lambda: ops.gemm_nt(A, B, None, out=C), 512)
-x = torch.randn(4, 120, 120, 256, device=d); w = torch.randn(256, 256, 3, 3, device=d) * 0.02
-wf, _ = ops.pack_conv3x3_weight(w, need_dgrad=False); y = torch.empty(4, 120, 120, 256, device=d); bias = torch.zeros(256, device=d)
-run('conv fwd L6 (900 tiles: 512 whole + 512 stream-K parts)', lambda: ops.conv3x3_fwd(x, wf, bias, 256, True, out=y), 1024)
+case = sys.argv[1] if len(sys.argv) > 1 else 'wide'
+if case == 'wide':
+    M, N, K = 32768, 256, 2304
+    A = torch.randn(M, K, device=d); B = torch.randn(N, K, device=d); C = torch.empty(M, N, device=d)
+    run('gemm 512 tiles K=2304', lambda: ops.gemm_nt(A, B, None, out=C), 512)
+    x = torch.randn(4, 120, 120, 256, device=d); w = torch.randn(256, 256, 3, 3, device=d) * 0.02
+    wf, _ = ops.pack_conv3x3_weight(w, need_dgrad=False); y = torch.empty(4, 120, 120, 256, device=d); bias = torch.zeros(256, device=d)
+    run('conv fwd L6 (900 tiles: 512 whole + 512 stream-K parts)', lambda: ops.conv3x3_fwd(x, wf, bias, 256, True, out=y), 1024)
+else:
+    # the 64-channel layers: conv1_2 (64 -> 64 at 480x480: 7200 tiles of 128x64, 18 K-steps each) forward and dgrad,
+    # conv2_1 (64 -> 128 at 240x240: 1800 tiles of 128x128, 18 K-steps)
+    x = torch.randn(4, 480, 480, 64, device=d); w = torch.randn(64, 64, 3, 3, device=d) * 0.05
+    wf, wd = ops.pack_conv3x3_weight(w); y = torch.empty(4, 480, 480, 64, device=d); bias = torch.zeros(64, device=d)
+    run('conv1_2 fwd (7200 tiles 128x64, K = 576)', lambda: ops.conv3x3_fwd(x, wf, bias, 64, True, out=y), 7200)
+    dx = torch.zeros(4, 480, 480, 64, device=d)
+    run('conv1_2 dgrad (mask + accumulate)', lambda: ops.conv3x3_dgrad(y, wd, 64, mask_src=x, out=dx, accumulate=True), 7200)
+    x2 = torch.randn(4, 240, 240, 64, device=d); w2 = torch.randn(128, 64, 3, 3, device=d) * 0.05
+    wf2, _ = ops.pack_conv3x3_weight(w2, need_dgrad=False); y2 = torch.empty(4, 240, 240, 128, device=d); b2 = torch.zeros(128, device=d)
+    nb = 1800 if not ops.STREAMK else 2048
+    run('conv2_1 fwd (1800 tiles 128x128, K = 576)', lambda: ops.conv3x3_fwd(x2, wf2, b2, 128, True, out=y2), 2048)

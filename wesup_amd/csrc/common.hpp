@@ -43,10 +43,16 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
-// max(x, lo) as ONE v_med3_f32 (fmaxf() goes through llvm.maxnum, which first canonicalises a possibly-signalling
-// input with a second v_max; an asm v_max would be outside the compiler's s_waitcnt bookkeeping and read a fragment
-// before its ds_read has landed): ReLU-on-load in the GEMM loops, lo = 0 or -inf
-__device__ __forceinline__ float vmax1(float x, float lo) { return __builtin_amdgcn_fmed3f(x, lo, __builtin_inff()); }
+// ReLU-on-load in the GEMM loops as ONE vector instruction: a signed-integer max of the float's bits with 0 (a float
+// with the sign bit clear is a non-negative integer and keeps its bits, one with the sign bit set -- negative values
+// and -0 -- is a negative integer and becomes +0).  fmaxf() and even __builtin_amdgcn_fmed3f(x, 0, inf) compile to
+// TWO v_max_f32 (llvm.maxnum canonicalises a possibly-signalling input first): 64 instead of 32 vector instructions
+// per K-step in both GEMM loops, and vector instructions do not overlap with MFMAs on a SIMD.  (An asm v_max would be
+// outside the compiler's s_waitcnt bookkeeping and read a fragment before its ds_read has landed.)
+__device__ __forceinline__ float vmax1(float x, float /*lo = 0*/) {
+    const int b = __float_as_int(x);
+    return __int_as_float(b > 0 ? b : 0);
+}
 // ReLU of an epilogue.  NaN-preserving like torch.relu (fmaxf would turn a NaN into 0): a NaN in any conv output
 // reaches the superpixel features through the pre-ReLU side tap, and from there it must survive the fc_layers' ReLUs
 // so that the loss is NaN and the trainer raises before the weights are touched (models/base.py:202-203).

@@ -768,6 +768,29 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnParams p) {
                         ((unsigned)ww < (unsigned)p.W);
         return ok ? b_vo[i] : WESUP_OOB;
     };
+    // MODE 1 (every lane of the block has the same tap): whether pixel k0 + j is inside the image under the tap does
+    // not depend on the lane's column, so ONE evaluation per K-step -- lane j & 31 tests pixel k0 + j -- is balloted into
+    // a scalar 32-bit mask and a staged row only tests its own bit (3 vector instructions instead of ~25 per row: the
+    // wgrad loop carried 140 vector instructions per 64 MFMAs against 52 in the forward kernel, and vector
+    // instructions do not overlap with MFMAs on a SIMD).
+    auto step_mask = [&](int k0) -> unsigned {
+        const int k0u = __builtin_amdgcn_readfirstlane(k0);
+        const int t0 = fast_div(k0u, p.dW);
+        const int w0 = k0u - t0 * p.W;
+        const int h0 = t0 - fast_div(t0, p.dH) * p.H;
+        const int r = lane & 31;
+        int w = w0 + r, h = h0;
+        const bool c1 = w >= p.W;
+        w = c1 ? w - p.W : w; h = c1 ? h + 1 : h;
+        const bool c2 = w >= p.W;
+        w = c2 ? w - p.W : w; h = c2 ? h + 1 : h;
+        h = h >= p.H ? h - p.H : h;
+        const bool ok = (k0u + r < k_end) & ((unsigned)(h + dh) < (unsigned)p.H) & ((unsigned)(w + dw) < (unsigned)p.W);
+        return (unsigned)__builtin_amdgcn_ballot_w64(ok);          // lanes 0..31 (32..63 repeat them)
+    };
+    unsigned row_bit[NB];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) row_bit[i] = 1u << (rb_row + RPB * i);
     const unsigned step_a = (unsigned)(BK * p.lda * 4), step_b = (unsigned)(BK * (MODE == 2 ? 4 : p.ldb) * 4);
     auto issue = [&](int step, const unsigned (&vb)[NB], int buf) {
         // the image is linear in tid (4*tid floats per pass): wave-uniform LDS byte addresses
@@ -803,6 +826,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnParams p) {
     __syncthreads();
     const unsigned long long tr1 = __builtin_amdgcn_s_memrealtime();
     int cur = 0;
+    unsigned smask = 0;
     for (int kk = 0; kk < nk; ++kk) {
         issue(kk + 1, vb, cur ^ 1);                // unconditional (past k_end every lane is out of range: zeros)
         const int k2 = k_begin + (kk + 2) * BK;    // its offsets are consumed by the next iteration's issue()
@@ -848,7 +872,12 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnParams p) {
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[sl][u][i], b[sl][u][j], acc[i][j], 0, 0, 0);
                 // one slice of the border arithmetic per k-pair, fenced so that it stays in this group's shadow
                 const int kp = GK * g + u;
-                if (MODE != 0 && kp < NB) vb[kp] = mask_b(k2, kp);
+                if constexpr (MODE == 1 && !TINY) {
+                    if (kp == 0) smask = step_mask(k2);
+                    else if (kp <= NB) vb[kp - 1] = (smask & row_bit[kp - 1]) ? b_vo[kp - 1] : WESUP_OOB;
+                } else if (MODE != 0 && kp < NB) {
+                    vb[kp] = mask_b(k2, kp);
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
         }
