@@ -80,7 +80,10 @@ int wesup_appearance(const uint8_t* img_hwc, const float* params, uint8_t* out_h
  * round of tiles over all block slots; without it the plain tiling is used.  Size for (Cin -> Cout); for dgrad ask
  * with the channel counts swapped.  One workspace per stream that may run concurrently. */
 size_t wesup_conv3x3_workspace_bytes(int B, int H, int W, int Cin, int Cout);
-int wesup_conv3x3_fwd(const float* x, const float* w_fwd, const float* bias, float* y,
+/* y_relu (optional, may be NULL): a second output max(y, 0).  A layer's ReLU'd output is read 9 taps x (Cout/128)
+ * times by the next layer's forward and again by its wgrad; applying the ReLU once where the value is produced instead
+ * of on every load takes 32 vector instructions per 64 MFMAs out of both loops (relu_in = 0 on the ReLU'd copy). */
+int wesup_conv3x3_fwd(const float* x, const float* w_fwd, const float* bias, float* y, float* y_relu,
                       int B, int H, int W, int Cin, int Cout, int relu_in,
                       void* ws, size_t ws_bytes, void* stream);
 /* dx = conv_transpose(dy) ; if mask_src: dx = mask_src > 0 ? dx : 0 ; if accumulate: dx += old dx */
@@ -117,8 +120,10 @@ size_t wesup_colsum_workspace_bytes(int M, int N);
 int wesup_colsum(const float* A, int lda, float* out, int M, int N, void* ws, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------ pooling / upsampling (K2/K4)
- * maxpool: nn.MaxPool2d(2,2) after ReLU == ReLU after maxpool; operates on pre-ReLU y. */
-int wesup_maxpool2_fwd(const float* y, float* yp, int B, int H, int W, int C, void* stream);
+ * maxpool: nn.MaxPool2d(2,2) after ReLU == ReLU after maxpool; operates on pre-ReLU y (relu_out applies the ReLU to
+ * the pooled values as it stores them). */
+int wesup_maxpool2_fwd(const float* y, float* yp, int B, int H, int W, int C, int relu_out /* yp = max(pool, 0) */,
+                       void* stream);
 /* dy[p] = (p is the first max of its window and y[p] > 0 ? dyp[window] : 0) (+ dy[p] if accumulate) */
 int wesup_maxpool2_bwd(const float* y, const float* dyp, float* dy, int B, int H, int W, int C,
                        int accumulate, void* stream);

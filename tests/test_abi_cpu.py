@@ -52,7 +52,7 @@ def test_host_side_queries(lib):
     assert h.wesup_gemm_tn_workspace_bytes(1024, 2112, 2400) >= 1024 * 2112 * 4
     assert h.wesup_sp_preprocess_workspace_bytes(4, 480 * 480, 2, 640) > 0
     # invalid arguments are rejected on the host before any launch
-    assert h.wesup_conv3x3_fwd(None, None, None, None, 1, 8, 8, 64, 64, 0, None, 0, None) == -1
+    assert h.wesup_conv3x3_fwd(None, None, None, None, None, 1, 8, 8, 64, 64, 0, None, 0, None) == -1
     assert h.wesup_gemm_nt(None, 0, None, 0, None, None, 0, None, 0, 1, 1, 32, 0, None, 0, None) == -1
     # stream-K workspace: a short last round of 128x128 tiles (900 tiles on 512 slots) asks for partial-tile slots
     assert h.wesup_conv3x3_workspace_bytes(4, 120, 120, 256, 256) == 512 * 2 * 128 * 128 * 4

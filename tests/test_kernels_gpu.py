@@ -79,6 +79,10 @@ def test_conv3x3_fwd(ops, B, H, W, Cin, Cout, relu_in):
     wf, _ = ops.pack_conv3x3_weight(w.to(d), need_dgrad=False)
     y = ops.conv3x3_fwd(xg, wf, b.to(d), Cout, relu_in)
     assert rel_err(nchw(y), ref) < TOL
+    # the optional second output is exactly max(y, 0) -- also on the tiles that go through the stream-K fix-up
+    y2, yr = torch.empty_like(y), torch.empty_like(y)
+    ops.conv3x3_fwd(xg, wf, b.to(d), Cout, relu_in, out=y2, out_relu=yr)
+    assert torch.equal(y2, y) and torch.equal(yr, torch.relu(y))
 
 
 @pytest.mark.parametrize('B,H,W,Cin,Cout', [c for c in CONV_CASES if c[3] != 3])
@@ -192,6 +196,7 @@ def test_maxpool(ops, B, H, W, C):
     p.backward(dyp)
     yp = ops.maxpool2_fwd(nhwc(y).to(d))
     assert torch.equal(F.relu(nchw(yp)).cpu(), p.detach())
+    assert torch.equal(nchw(ops.maxpool2_fwd(nhwc(y).to(d), relu=True)).cpu(), p.detach())       # ReLU applied as it stores
     base = rnd(B, H, W, C, seed=3)
     out = base.clone().to(d)
     ops.maxpool2_bwd(nhwc(y).to(d), nhwc(dyp).to(d), out, accumulate=True)
@@ -563,6 +568,9 @@ def test_conv3x3_streamk(ops, lib, B, H, W, Cin, Cout):
     wf, wd = ops.pack_conv3x3_weight(w.to(d))
     y = ops.conv3x3_fwd(nhwc(x).to(d), wf, bias.to(d), Cout, True)
     assert rel_err(y, nhwc(ref)) < TOL
+    yr = torch.empty_like(y)                        # the ReLU'd second output through the fix-up kernel
+    y2 = ops.conv3x3_fwd(torch.relu(nhwc(x)).to(d), wf, bias.to(d), Cout, False, out_relu=yr)
+    assert torch.equal(y2, y) and torch.equal(yr, torch.relu(y))
     dy = rnd(B, Cout, H, W, seed=4)
     refdx = F.conv_transpose2d(dy.double(), w.double(), padding=1).float()
     msk = rnd(B, Cin, H, W, seed=5)

@@ -32,7 +32,7 @@ _SIGS = {
     'wesup_pack_conv3x3_weight': (c_int, 'pppiip'),
     'wesup_transpose': (c_int, 'ppiip'),
     'wesup_conv3x3_workspace_bytes': (c_size_t, 'iiiii'),
-    'wesup_conv3x3_fwd': (c_int, 'ppppiiiiiipzp'),
+    'wesup_conv3x3_fwd': (c_int, 'pppppiiiiiipzp'),
     'wesup_conv3x3_dgrad': (c_int, 'ppppiiiiiipzp'),
     'wesup_conv3x3_wgrad_workspace_bytes': (c_size_t, 'iiiii'),
     'wesup_conv3x3_wgrad': (c_int, 'ppppiiiiiipzp'),
@@ -44,7 +44,7 @@ _SIGS = {
     'wesup_gemm_tn_batched': (c_int, 'pilpilpiliiiiipzp'),
     'wesup_colsum_workspace_bytes': (c_size_t, 'ii'),
     'wesup_colsum': (c_int, 'pipiipzp'),
-    'wesup_maxpool2_fwd': (c_int, 'ppiiiip'),
+    'wesup_maxpool2_fwd': (c_int, 'ppiiiiip'),
     'wesup_maxpool2_bwd': (c_int, 'pppiiiiip'),
     'wesup_upsample_fwd': (c_int, 'ppiiiiiiiip'),
     'wesup_upsample_bwd': (c_int, 'ppppiiiiiiiiip'),

@@ -88,10 +88,12 @@ struct NtParams {
     const float* Bw;
     const float* bias;
     float* C;
+    float* C2;           // optional second output: max(C, 0) (the ReLU'd copy the next layer reads), same layout as C
     const float* mask;
     int M, N, K;
     int lda, ldb, ldc, ldmask;
     int H, W, Cin, cin_shift;
+    FastDiv dW, dH;      // pixel index -> (image, row, column) without integer division (conv modes)
     int flags;
     int tiles_m, tiles_n;
     int full_tiles;      // blocks [0, full_tiles) own one tile each
@@ -181,19 +183,15 @@ __global__ __launch_bounds__(NW * 64, MINB) void gemm_nt_kernel(const NtParams p
             a_vo[i] = (m < p.M) ? (unsigned)(((srow + PR * i) * p.lda + 4 * schunk) * 4) : WESUP_OOB;
             a_msk[i] = 0; a_off[i] = 0;
         } else {
-            const int hw = p.H * p.W;
-            const int b = m / hw;
-            const int rem = m - b * hw;
-            const int h = rem / p.W, w = rem - h * p.W;
-            unsigned msk = 0;
-            if (m < p.M) {
-#pragma unroll
-                for (int t = 0; t < 9; ++t) {
-                    const int hh = h + t / 3 - 1, ww = w + t % 3 - 1;
-                    if (hh >= 0 && hh < p.H && ww >= 0 && ww < p.W) msk |= 1u << t;
-                }
-            }
-            a_msk[i] = msk;
+            // (b*H + h, w) by one multiply-high each: a generic integer division costs ~30 vector instructions, and
+            // the tile set-up is paid per tile by waves that share their SIMD with MFMA-bound neighbours
+            const int t = fast_div(m, p.dW);
+            const int w = m - t * p.W;
+            const int h = t - fast_div(t, p.dH) * p.H;
+            // bit t = tap t (row t/3 - 1, column t%3 - 1) lies inside the image: the outer product of two 3-bit masks
+            const unsigned wm = (w > 0 ? 1u : 0u) | 2u | (w < p.W - 1 ? 4u : 0u);
+            unsigned msk = (h > 0 ? wm : 0u) | (wm << 3) | (h < p.H - 1 ? wm << 6 : 0u);
+            a_msk[i] = (m < p.M) ? msk : 0u;
             a_off[i] = (long)m * p.Cin;
             a_vo[i] = (unsigned)(((srow + PR * i) * p.Cin + 4 * schunk) * 4);
         }
@@ -367,6 +365,7 @@ __global__ __launch_bounds__(NW * 64, MINB) void gemm_nt_kernel(const NtParams p
                     v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
                 }
                 st4(c, v);
+                if (p.C2) st4(p.C2 + (long)m * p.ldc + n, relu4(v));
             }
         }
     }
@@ -429,6 +428,7 @@ __global__ __launch_bounds__(256) void nt_fixup_kernel(const NtParams p) {
         v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
     }
     st4(c, v);
+    if (p.C2) st4(p.C2 + (long)m * p.ldc + n, relu4(v));
 }
 
 // Block shapes of the NT family.  BIG: 256x128, 8 waves (the same 64x64 wave tile), ONE block per CU: the eight waves
@@ -593,16 +593,19 @@ extern "C" int wesup_conv3x3_kpad(int Ci) {
 }
 
 static int conv_common(const float* x, const float* w, const float* bias, float* y, const float* mask, int B,
-                       int H, int W, int Cin, int Cout, int flags, void* ws, size_t ws_bytes, hipStream_t st) {
+                       int H, int W, int Cin, int Cout, int flags, void* ws, size_t ws_bytes, hipStream_t st,
+                       float* y_relu = nullptr) {
     if (!x || !w || !y || B <= 0 || H <= 0 || W <= 0) return WESUP_ERR_INVALID;
     const bool small = (Cin == 4);
     if (!small && (Cin < 32 || (Cin & (Cin - 1)))) return WESUP_ERR_INVALID;
     if ((long)B * H * W * (long)(Cin > Cout ? Cin : Cout) >= (1l << 31)) return WESUP_ERR_INVALID;
     NtParams p = {};
-    p.A = x; p.Bw = w; p.bias = bias; p.C = y; p.mask = mask;
+    if (y_relu && ((uintptr_t)y_relu & 15)) return WESUP_ERR_INVALID;
+    p.A = x; p.Bw = w; p.bias = bias; p.C = y; p.C2 = y_relu; p.mask = mask;
     p.M = B * H * W; p.N = Cout; p.K = wesup_conv3x3_kpad(Cin);
     p.lda = Cin; p.ldb = p.K; p.ldc = Cout; p.ldmask = Cout;
     p.H = H; p.W = W; p.Cin = Cin; p.cin_shift = ilog2(Cin);
+    p.dW = make_fastdiv(W); p.dH = make_fastdiv(H);
     p.flags = flags;
     return small ? dispatch_nt<2>(p, st, nullptr, 0) : dispatch_nt<1>(p, st, ws, ws_bytes);
 }
@@ -614,10 +617,10 @@ extern "C" size_t wesup_conv3x3_workspace_bytes(int B, int H, int W, int Cin, in
     return choose_nt(B * H * W, Cout, 9 * Cin, true).sk.ws_bytes;
 }
 
-extern "C" int wesup_conv3x3_fwd(const float* x, const float* w_fwd, const float* bias, float* y, int B, int H,
-                                 int W, int Cin, int Cout, int relu_in, void* ws, size_t ws_bytes, void* stream) {
+extern "C" int wesup_conv3x3_fwd(const float* x, const float* w_fwd, const float* bias, float* y, float* y_relu, int B,
+                                 int H, int W, int Cin, int Cout, int relu_in, void* ws, size_t ws_bytes, void* stream) {
     return conv_common(x, w_fwd, bias, y, nullptr, B, H, W, Cin, Cout, relu_in ? WESUP_RELU_IN : 0, ws, ws_bytes,
-                       (hipStream_t)stream);
+                       (hipStream_t)stream, y_relu);
 }
 
 extern "C" int wesup_conv3x3_dgrad(const float* dy, const float* w_dgrad, const float* mask_src, float* dx, int B,

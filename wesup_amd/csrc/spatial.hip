@@ -95,7 +95,8 @@ extern "C" int wesup_transpose(const float* in, float* out, int rows, int cols, 
 __device__ __forceinline__ float4 max4(float4 a, float4 b) {
     return make_float4(fmaxf(a.x, b.x), fmaxf(a.y, b.y), fmaxf(a.z, b.z), fmaxf(a.w, b.w));
 }
-__global__ void maxpool_fwd_kernel(const float* __restrict__ y, float* __restrict__ yp, int B, int H, int W, int C4) {
+__global__ void maxpool_fwd_kernel(const float* __restrict__ y, float* __restrict__ yp, int B, int H, int W, int C4,
+                                   int relu_out) {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const int Ho = H >> 1, Wo = W >> 1;
     if (idx >= (long)B * Ho * Wo * C4) return;
@@ -107,14 +108,15 @@ __global__ void maxpool_fwd_kernel(const float* __restrict__ y, float* __restric
     const int b = t / Ho;
     const float* s = y + (((long)b * H + 2 * yo) * W + 2 * xo) * C4 * 4 + 4 * c;
     const long rs = (long)W * C4 * 4;
-    const float4 v = max4(max4(ld4(s), ld4(s + C4 * 4)), max4(ld4(s + rs), ld4(s + rs + C4 * 4)));
+    float4 v = max4(max4(ld4(s), ld4(s + C4 * 4)), max4(ld4(s + rs), ld4(s + rs + C4 * 4)));
+    if (relu_out) v = relu4(v);
     st4(yp + idx * 4, v);
 }
-extern "C" int wesup_maxpool2_fwd(const float* y, float* yp, int B, int H, int W, int C, void* stream) {
+extern "C" int wesup_maxpool2_fwd(const float* y, float* yp, int B, int H, int W, int C, int relu_out, void* stream) {
     if (!y || !yp || B <= 0 || H < 2 || W < 2 || (C % 4)) return WESUP_ERR_INVALID;
     const long tot = (long)B * (H / 2) * (W / 2) * (C / 4);
     hipLaunchKernelGGL(maxpool_fwd_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, y, yp,
-                       B, H, W, C / 4);
+                       B, H, W, C / 4, relu_out);
     WESUP_CHECK_LAUNCH();
     return WESUP_OK;
 }

@@ -99,6 +99,7 @@ class WesupEngine:
         self.fuse_pool_fwd = True        # skip the (B,HW,2112) feature map: scatter-mean fused with the upsample
         self.matrix_pool = True          # coarse layers: upsample+scatter-mean (and backward) as GEMMs with Wm
         self.two_streams = True          # side branch on its own HIP stream
+        self.relu_on_store = True        # ReLU'd copies written by the producing kernel instead of ReLU on every load
         self._side_stream = None
         self._wgrad_stream = None
         self.timer = KernelTimer()
@@ -162,13 +163,16 @@ class WesupEngine:
         if b is None:
             b = _Bufs()
             b.x0 = torch.empty(B, H, W, 4, **f32)
-            b.y, b.yp, b.s, b.dims = [], [], [], []
+            b.y, b.yp, b.s, b.dims, b.yr = [], [], [], [], []
             h, w = H, W
             for l, (ci, co) in enumerate(CONV_CH):
                 b.dims.append((h, w))
                 b.y.append(torch.empty(B, h, w, co, **f32))
                 full = (h, w) == (H, W)
                 b.s.append(None if (full and not self.fuse_pool_fwd) else torch.empty(B, h, w, co // 2, **f32))
+                # the ReLU'd copy the next conv (forward and wgrad) reads: the pooled tensor where the layer is pooled
+                # (stored ReLU'd), a second output of the conv kernel elsewhere; the last layer has no reader
+                b.yr.append(torch.empty(B, h, w, co, **f32) if (self.relu_on_store and not POOL_AFTER[l] and l < 12) else None)
                 if POOL_AFTER[l]:
                     h, w = h // 2, w // 2
                     b.yp.append(torch.empty(B, h, w, co, **f32))
@@ -313,6 +317,7 @@ class WesupEngine:
                         ops.transpose(g.Wm[i], g.WmT[i])
                 T.end(tok, 0.0)
         cur = b.x0
+        b.relu_stored = self.relu_on_store and all(b.yr[l] is not None for l in range(12) if not POOL_AFTER[l])
         fused = self.fuse_pool_fwd
         b.fm_valid = not fused
         fm2d = None if fused else b.fm.view(B * H * W, FM_CHANNELS)
@@ -324,7 +329,8 @@ class WesupEngine:
             if l == 1 and pk.ready is not None:
                 torch.cuda.current_stream().wait_event(pk.ready)
             tok = T.begin('conv3x3_fwd')
-            ops.conv3x3_fwd(cur, pk.wf[l], p[f'backbone.{idx}.bias'], co, relu_in=(l > 0), out=b.y[l])
+            ops.conv3x3_fwd(cur, pk.wf[l], p[f'backbone.{idx}.bias'], co, relu_in=(l > 0 and not b.relu_stored),
+                            out=b.y[l], out_relu=b.yr[l])
             T.end(tok, 2.0 * B * h * w * (3 if l == 0 else ci) * co * 9)
             # side branch of this layer: 1x1 conv on the pre-ReLU tap, then either the fused upsample+scatter-mean
             # straight into the superpixel feature slice, or upsample into fm's channel slice
@@ -353,10 +359,10 @@ class WesupEngine:
                     ops.upsample_fwd(b.s[l], b.fm, off)
                     T.end(tok, 4.0 * B * H * W * (co // 2))
             if POOL_AFTER[l]:
-                ops.maxpool2_fwd(b.y[l], b.yp[l])
+                ops.maxpool2_fwd(b.y[l], b.yp[l], relu=b.relu_stored)
                 cur = b.yp[l]
             else:
-                cur = b.y[l]
+                cur = b.yr[l] if b.yr[l] is not None else b.y[l]
         self._join_side()
         if not fused:
             tok = T.begin('sp_pool_fwd')
@@ -504,21 +510,24 @@ class WesupEngine:
                 main.wait_event(g_ready[l])
             if l == 0:
                 x_in = b.x0
+            elif POOL_AFTER[l - 1]:
+                x_in = b.yp[l - 1]
             else:
-                x_in = b.yp[l - 1] if POOL_AFTER[l - 1] else b.y[l - 1]
+                x_in = b.yr[l - 1] if b.relu_stored else b.y[l - 1]
+            relu_x = l > 0 and not b.relu_stored
             if not trainable[l]:
                 pass
             elif wg is not None:
                 wg.wait_stream(main)                       # G_l is final here
                 with torch.cuda.stream(wg):
                     tok = T.begin('conv3x3_wgrad')
-                    ops.conv3x3_wgrad(x_in, b.G[l], ci, relu_in=(l > 0), dw=g[f'backbone.{idx}.weight'],
+                    ops.conv3x3_wgrad(x_in, b.G[l], ci, relu_in=relu_x, dw=g[f'backbone.{idx}.weight'],
                                       db=g[f'backbone.{idx}.bias'], ws_tag='wgrad')
                     T.end(tok, 2.0 * B * h * w * ci * co * 9)
                     ready([f'backbone.{idx}.weight', f'backbone.{idx}.bias'])
             else:
                 tok = T.begin('conv3x3_wgrad')
-                ops.conv3x3_wgrad(x_in, b.G[l], ci, relu_in=(l > 0), dw=g[f'backbone.{idx}.weight'], db=g[f'backbone.{idx}.bias'])
+                ops.conv3x3_wgrad(x_in, b.G[l], ci, relu_in=relu_x, dw=g[f'backbone.{idx}.weight'], db=g[f'backbone.{idx}.bias'])
                 T.end(tok, 2.0 * B * h * w * ci * co * 9)
                 ready([f'backbone.{idx}.weight', f'backbone.{idx}.bias'])
             if l > lowest:

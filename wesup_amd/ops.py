@@ -120,7 +120,7 @@ def transpose(a, out=None):
 
 
 # ---------------------------------------------------------------- conv 3x3
-def conv3x3_fwd(x, w_fwd, bias, Cout, relu_in, out=None):
+def conv3x3_fwd(x, w_fwd, bias, Cout, relu_in, out=None, out_relu=None):
     _chk(x, name='x'); _chk(w_fwd, name='w_fwd')
     B, H, W, Cin = x.shape
     assert w_fwd.shape == (Cout, conv3x3_kpad(Cin)), (w_fwd.shape, Cout, Cin)
@@ -129,8 +129,10 @@ def conv3x3_fwd(x, w_fwd, bias, Cout, relu_in, out=None):
     if out is None:
         out = torch.empty(B, H, W, Cout, dtype=torch.float32, device=x.device)
     assert out.shape == (B, H, W, Cout) and out.is_contiguous()
+    if out_relu is not None:
+        _chk(out_relu, name='out_relu'); assert out_relu.shape == out.shape
     nb = _lib.load().wesup_conv3x3_workspace_bytes(B, H, W, Cin, Cout)
-    _lib.call('wesup_conv3x3_fwd', _p(x), _p(w_fwd), _p(bias), _p(out), B, H, W, Cin, Cout, int(relu_in),
+    _lib.call('wesup_conv3x3_fwd', _p(x), _p(w_fwd), _p(bias), _p(out), _p(out_relu), B, H, W, Cin, Cout, int(relu_in),
               _p(_nt_workspace(nb, x.device)), nb, _stream())
     return out
 
@@ -241,13 +243,13 @@ def colsum(A, out=None, ws_tag='colsum'):
 
 
 # ---------------------------------------------------------------- pooling / upsampling
-def maxpool2_fwd(y, out=None):
+def maxpool2_fwd(y, out=None, relu=False):
     _chk(y, name='y')
     B, H, W, C = y.shape
     if out is None:
         out = torch.empty(B, H // 2, W // 2, C, dtype=torch.float32, device=y.device)
     assert out.shape == (B, H // 2, W // 2, C)
-    _lib.call('wesup_maxpool2_fwd', _p(y), _p(out), B, H, W, C, _stream())
+    _lib.call('wesup_maxpool2_fwd', _p(y), _p(out), B, H, W, C, int(relu), _stream())
     return out
 
 
