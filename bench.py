@@ -47,7 +47,8 @@ def parse_args(argv=None):
     ap.add_argument('--grid', type=int, default=24, help='superpixel grid side: g*g superpixels per image')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true')
-    ap.add_argument('--no-streamk', action='store_true', help='A/B: plain tiling in the NT GEMM family')
+    ap.add_argument('--streamk', default='', help="A/B: comma list of the uses that get a stream-K tail ('fwd', 'dgrad', "
+                                                  "'gemm', or 'all'); default: none (the step runs plain tiling, ops.py)")
     ap.add_argument('--event-every', type=int, default=4, help='steps of the timed region that carry HIP events: every n-th')
     ap.add_argument('--timed-classes', default='conv3x3_fwd,conv3x3_dgrad',
                     help="kernel classes that get HIP events inside the timed region ('all', 'none' or a comma list); an "
@@ -221,9 +222,11 @@ def worker(args):
     from wesup_amd.utils.metrics import accuracy, dice
 
     B, H, W, g = args.batch, args.size, args.size, args.grid
-    if args.no_streamk:
+    if args.streamk:
         from wesup_amd import ops as _ops
-        _ops.STREAMK = False
+        keep = set(args.streamk.split(','))
+        _ops.set_streamk(fwd='fwd' in keep or 'all' in keep, dgrad='dgrad' in keep or 'all' in keep,
+                         gemm='gemm' in keep or 'all' in keep)
     weights = orc.make_weights(0, feat_scale=0.05)
     trainer = initialize_trainer('wesup', device=str(dev), max_superpixels=g * g, force_allreduce=args.force_ddp)
     trainer.model.load_state_dict({k: torch.from_numpy(v) for k, v in weights.items()})

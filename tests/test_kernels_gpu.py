@@ -520,9 +520,17 @@ def test_sp_interp_matrix_equals_fused_upsample_pool(ops, B, H, W, g, h, w):
 
 
 # ---------------------------------------------------------------- stream-K shapes of the NT family
+@pytest.fixture
+def streamk_on(ops):
+    """The training step runs plain tiling (wesup_amd/ops.py); these tests cover the stream-K path of the kernels."""
+    ops.set_streamk(everything=True)
+    yield
+    ops.set_streamk(everything=False)
+
+
 @pytest.mark.parametrize('M,N,K', [(2336, 1024, 2112), (3600, 512, 4608), (14400, 512, 2304), (57600, 256, 1152),
                                    (130, 128, 1024), (66000, 128, 512)])
-def test_gemm_nt_streamk(ops, lib, M, N, K):
+def test_gemm_nt_streamk(ops, lib, M, N, K, streamk_on):
     """Shapes whose last round of 128x128 tiles is partial go through the stream-K blocks + fix-up kernel."""
     d = dev()
     assert lib.load().wesup_gemm_nt_workspace_bytes(M, N, K) > 0
@@ -558,7 +566,7 @@ def test_gemm_nt_short_k_under_one_round_is_plain(ops, lib, M, N, K):
 
 
 @pytest.mark.parametrize('B,H,W,Cin,Cout', [(4, 30, 30, 512, 512), (2, 60, 60, 256, 512), (1, 120, 120, 128, 256)])
-def test_conv3x3_streamk(ops, lib, B, H, W, Cin, Cout):
+def test_conv3x3_streamk(ops, lib, B, H, W, Cin, Cout, streamk_on):
     d = dev()
     assert lib.load().wesup_conv3x3_workspace_bytes(B, H, W, Cin, Cout) > 0
     x = rnd(B, Cin, H, W, seed=1)

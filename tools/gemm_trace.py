@@ -3,6 +3,7 @@ import sys, os, ctypes
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from wesup_amd import ops, _lib
+ops.set_streamk(everything=True)
 d = torch.device('cuda:0')
 lib = _lib.load()
 def run(name, fn, nblocks):
@@ -58,5 +59,4 @@ else:
     run('conv1_2 dgrad (mask + accumulate)', lambda: ops.conv3x3_dgrad(y, wd, 64, mask_src=x, out=dx, accumulate=True), 7200)
     x2 = torch.randn(4, 240, 240, 64, device=d); w2 = torch.randn(128, 64, 3, 3, device=d) * 0.05
     wf2, _ = ops.pack_conv3x3_weight(w2, need_dgrad=False); y2 = torch.empty(4, 240, 240, 128, device=d); b2 = torch.zeros(128, device=d)
-    nb = 1800 if not ops.STREAMK else 2048
     run('conv2_1 fwd (1800 tiles 128x128, K = 576)', lambda: ops.conv3x3_fwd(x2, wf2, b2, 128, True, out=y2), 2048)

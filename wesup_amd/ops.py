@@ -12,7 +12,29 @@ import torch
 from . import _lib
 
 RELU_IN, RELU_OUT, ACCUM, MASK = 1, 2, 4, 8
-STREAMK = True        # hand the NT GEMM family its stream-K workspace (False: plain tiling, for A/B measurements)
+# Stream-K tail of the NT GEMM family (the tiles of a short last round cut along K over all block slots + a fix-up
+# launch): a kernel ALONE on the GPU gains 6-7 % from it (conv forward 5.00 -> 4.70, dgrad 5.03 -> 4.69 ms per step),
+# but inside the training step two other streams fill the idle slots of a short round anyway and the fix-up launches sit
+# on the critical chain: the step is 17.52 ms with it, 17.34 ms without (17.40 forward only, 17.37 plain GEMMs only;
+# bench.py --streamk).  So the STEP runs plain tiling; the workspace is handed over only where a use is switched on
+# (single-stream callers: tools, inference experiments; tests switch all three on to cover the path).
+STREAMK_FWD = False    # conv forward
+STREAMK_DGRAD = False  # conv dgrad
+STREAMK_GEMM = False   # plain NT GEMMs (side convs, MLP)
+STREAMK = True         # master switch for the three (False: never hand out a workspace)
+
+
+def set_streamk(fwd=None, dgrad=None, gemm=None, everything=None):
+    """Switch the stream-K tail on / off per use (or all three with ``everything``)."""
+    global STREAMK_FWD, STREAMK_DGRAD, STREAMK_GEMM
+    if everything is not None:
+        fwd = dgrad = gemm = everything
+    if fwd is not None:
+        STREAMK_FWD = bool(fwd)
+    if dgrad is not None:
+        STREAMK_DGRAD = bool(dgrad)
+    if gemm is not None:
+        STREAMK_GEMM = bool(gemm)
 
 
 def _stream():
@@ -131,7 +153,7 @@ def conv3x3_fwd(x, w_fwd, bias, Cout, relu_in, out=None, out_relu=None):
     assert out.shape == (B, H, W, Cout) and out.is_contiguous()
     if out_relu is not None:
         _chk(out_relu, name='out_relu'); assert out_relu.shape == out.shape
-    nb = _lib.load().wesup_conv3x3_workspace_bytes(B, H, W, Cin, Cout)
+    nb = _lib.load().wesup_conv3x3_workspace_bytes(B, H, W, Cin, Cout) if STREAMK_FWD else 0
     _lib.call('wesup_conv3x3_fwd', _p(x), _p(w_fwd), _p(bias), _p(out), _p(out_relu), B, H, W, Cin, Cout, int(relu_in),
               _p(_nt_workspace(nb, x.device)), nb, _stream())
     return out
@@ -147,7 +169,7 @@ def conv3x3_dgrad(dy, w_dgrad, Cin, mask_src=None, out=None, accumulate=False):
         assert not accumulate
         out = torch.empty(B, H, W, Cin, dtype=torch.float32, device=dy.device)
     assert out.shape == (B, H, W, Cin) and out.is_contiguous()
-    nb = _lib.load().wesup_conv3x3_workspace_bytes(B, H, W, Cout, Cin)
+    nb = _lib.load().wesup_conv3x3_workspace_bytes(B, H, W, Cout, Cin) if STREAMK_DGRAD else 0
     _lib.call('wesup_conv3x3_dgrad', _p(dy), _p(w_dgrad), _p(mask_src), _p(out), B, H, W, Cin, Cout, int(accumulate),
               _p(_nt_workspace(nb, dy.device)), nb, _stream())
     return out
@@ -193,7 +215,7 @@ def gemm_nt(A, Bw, bias=None, out=None, mask=None, flags=0):
         flags |= MASK
     if bias is not None:
         _chk(bias, name='bias'); assert bias.numel() == N
-    nb = _lib.load().wesup_gemm_nt_workspace_bytes(M, N, K)
+    nb = _lib.load().wesup_gemm_nt_workspace_bytes(M, N, K) if STREAMK_GEMM else 0
     _lib.call('wesup_gemm_nt', _p(A), _ld(A), _p(Bw), _ld(Bw), _p(bias), _p(out), _ld(out), _p(mask), ldmask, M, N, K,
               flags, _p(_nt_workspace(nb, A.device)), nb, _stream())
     return out
