@@ -106,7 +106,8 @@ def test_conv3x3_dgrad(ops, B, H, W, Cin, Cout):
     assert rel_err(nchw(out2), x2.grad) < TOL
 
 
-@pytest.mark.parametrize('B,H,W,Cin,Cout', CONV_CASES[:5] + [(1, 120, 96, 64, 64), (2, 60, 60, 128, 128), (1, 100, 90, 3, 64)])
+@pytest.mark.parametrize('B,H,W,Cin,Cout', CONV_CASES[:5] + [(1, 120, 96, 64, 64), (2, 60, 60, 128, 128), (1, 100, 90, 3, 64),
+                                                 (3, 35, 17, 64, 64), (2, 33, 40, 32, 160), (1, 70, 50, 128, 64)])
 @pytest.mark.parametrize('relu_in', [False, True])
 def test_conv3x3_wgrad(ops, B, H, W, Cin, Cout, relu_in):
     d = dev()
