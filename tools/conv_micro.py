@@ -21,11 +21,11 @@ for it in range(reps + 1):
     if it == 1:
         ev[0].record()
     if which == 'fwd':
-        ops.conv3x3_fwd(x, wf, bias, Co, True, out=y)
+        ops.conv3x3_fwd(x, wf, bias, Co, False, out=y)
     elif which == 'dgrad':
         ops.conv3x3_dgrad(dy, wd, Ci, mask_src=x, out=dx, accumulate=True)
     else:
-        ops.conv3x3_wgrad(x, dy, Ci, True)
+        ops.conv3x3_wgrad(x, dy, Ci, False)
 ev[1].record()
 torch.cuda.synchronize()
 ms = ev[0].elapsed_time(ev[1]) / reps

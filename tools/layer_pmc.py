@@ -30,14 +30,14 @@ for l, (ci, co) in enumerate(CONV_CH):
     db = torch.empty(co, device=d)
     fl = 2.0 * B * h * w * ci * co * 9
     for _ in range(reps):
-        ops.conv3x3_fwd(x, wf, bias, co, relu_in=(l > 0), out=y)
+        ops.conv3x3_fwd(x, wf, bias, co, relu_in=False, out=y)
     manifest['order'].append([l, 'fwd', fl])
     if l > 0:
         for _ in range(reps):
             ops.conv3x3_dgrad(dy, wd, ci, mask_src=x, out=dx, accumulate=True)
         manifest['order'].append([l, 'dgrad', fl])
     for _ in range(reps):
-        ops.conv3x3_wgrad(x, dy, ci, relu_in=(l > 0), dw=dw, db=db)
+        ops.conv3x3_wgrad(x, dy, ci, relu_in=False, dw=dw, db=db)
     manifest['order'].append([l, 'wgrad', fl])
     torch.cuda.synchronize()
     if POOL_AFTER[l]:

@@ -39,9 +39,9 @@ for l, (ci, co) in enumerate(CONV_CH):
     dw = torch.empty(co, ci, 3, 3, device=d)
     db = torch.empty(co, device=d)
     fl = 2.0 * B * h * w * ci * co * 9
-    t_f = timeit(lambda: ops.conv3x3_fwd(x, wf, bias, co, relu_in=(l > 0), out=y))
+    t_f = timeit(lambda: ops.conv3x3_fwd(x, wf, bias, co, relu_in=False, out=y))
     t_d = timeit(lambda: ops.conv3x3_dgrad(dy, wd, ci, mask_src=x, out=dx, accumulate=True)) if l > 0 else 0.0
-    t_w = timeit(lambda: ops.conv3x3_wgrad(x, dy, ci, relu_in=(l > 0), dw=dw, db=db))
+    t_w = timeit(lambda: ops.conv3x3_wgrad(x, dy, ci, relu_in=False, dw=dw, db=db))
     idl = fl / 157.3e12 * 1e6
     ideal += idl
     tot['fwd'] += t_f; tot['dgrad'] += t_d; tot['wgrad'] += t_w
