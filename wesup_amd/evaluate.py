@@ -39,14 +39,17 @@ def _read_mask(path):
     return a[..., 0] if a.ndim == 3 else a
 
 
-def score(predictions, gts):
+def score(predictions, gts, binarize_gt=False):
     """Per-image rows and means of accuracy, Dice and the three object-level challenge metrics
-    (scripts/evaluate_glas.py:46-69)."""
+    (scripts/evaluate_glas.py:46-69).  The reference hands the ground-truth OBJECT maps (ids 0..n) to ``accuracy`` and
+    ``dice`` as they are -- for GlaS that compares a {0, 1} prediction with instance ids; kept by default so that the
+    numbers are the reference's, ``binarize_gt=True`` scores against ``gt > 0`` instead."""
     rows = []
     for pred, gt in zip(predictions, gts):
         gt = np.asarray(gt)
-        rows.append({'accuracy': float(M.accuracy(pred, (gt > 0).astype(pred.dtype))),
-                     'dice': float(M.dice(pred, (gt > 0).astype(pred.dtype))),
+        flat = (gt > 0).astype(pred.dtype) if binarize_gt else gt
+        rows.append({'accuracy': float(M.accuracy(pred, flat)),
+                     'dice': float(M.dice(pred, flat)),
                      'detection_f1': float(M.detection_f1(pred, gt)),
                      'object_dice': float(M.object_dice(pred, gt)),
                      'object_hausdorff': float(M.object_hausdorff(pred, gt)) if pred.any() and gt.any() else float('nan')})

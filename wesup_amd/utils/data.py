@@ -367,7 +367,7 @@ class DevicePrefetcher:
 
     def _stage(self, raw):
         from .. import ops
-        img, mask, pts = raw
+        img, mask, pts, *extra = raw             # extra: what a dataset adds to the item (area bounds, coordinate maps)
         B, H, W, _ = img.shape
         rows, mats = zip(*[sample_params(self.rs, H, W, self.train, self.with_points) for _ in range(B)])
         rows = np.stack(rows)
@@ -413,7 +413,8 @@ class DevicePrefetcher:
         pixel_mask = out_mask if self.has_masks else empty_tensor()
         if segments is not None:
             return (out_img, pixel_mask, point_mask if self.with_points else empty_tensor(), LabelMaps(segments, counts)), done
-        return ((out_img, pixel_mask, point_mask) if self.with_points else (out_img, pixel_mask)), done
+        item = (out_img, pixel_mask, point_mask) if self.with_points else (out_img, pixel_mask)
+        return item + tuple(e.to(self.device, non_blocking=True) if torch.is_tensor(e) else e for e in extra), done
 
     @staticmethod
     def _hand_over(item):
