@@ -229,6 +229,41 @@ size_t wesup_seg_metrics_workspace_bytes(int B);
 int wesup_seg_metrics(const float* pred, const uint8_t* mask, float* out4, int B, int HW, int C,
                       void* ws, size_t ws_bytes, void* stream);
 
+/* ------------------------------------------------------------------ entries by the names of SURVEY.md 8(b)
+ * One call per ATen op of the reference for a binding that replaces them one by one; each is a thin entry over the
+ * kernels above (csrc/named.hip).  Matrices are row-major with the channel / feature index contiguous (NHWC pixels). */
+/* K9 (models/wesup.py:34-42): area[B][Kmax] = pixels per superpixel id, counts[B][Kmax][C] = mask pixels per (id, class)
+ * (counts may be NULL without a mask); status[b] |= 1 when an id is outside [0, Kmax) */
+int wesup_sp_stats(const int32_t* labels, const uint8_t* mask, int B, int HW, int C, int Kmax, int32_t* area,
+                   int32_t* counts, int32_t* status, void* stream);
+/* K3 (models/wesup.py:208-209,253): Conv2d(Cin, Cout, 1) on P = B*h*w pixels; w [Cout][Cin]; w_t = w transposed */
+size_t wesup_conv1x1_workspace_bytes(int P, int Cin, int Cout);
+int wesup_conv1x1_fwd(const float* x, const float* w, const float* bias, float* y, int P, int Cin, int Cout,
+                      void* ws, size_t ws_bytes, void* stream);
+int wesup_conv1x1_dgrad(const float* dy, const float* w_t, float* dx, int P, int Cin, int Cout, int accumulate,
+                        void* ws, size_t ws_bytes, void* stream);
+int wesup_conv1x1_wgrad(const float* dy, const float* x, float* dw, float* db, int P, int Cin, int Cout,
+                        void* ws, size_t ws_bytes, void* stream);
+/* K7 (models/wesup.py:213-220,288): Linear(In, Out) [+ ReLU]; bwd: dw, db and (dx != NULL) dx = dy . w masked by
+ * relu_src > 0 when the layer's input came out of a ReLU (relu_src = that input, [R][In]) */
+size_t wesup_linear_workspace_bytes(int R, int In, int Out);
+int wesup_linear_fwd(const float* x, const float* w, const float* bias, float* y, int R, int In, int Out, int relu,
+                     void* ws, size_t ws_bytes, void* stream);
+int wesup_linear_bwd(const float* dy, const float* x, const float* w_t, const float* relu_src, float* dx, float* dw,
+                     float* db, int R, int In, int Out, void* ws, size_t ws_bytes, void* stream);
+/* K4 (models/wesup.py:254-255): F.interpolate(mode='bilinear', align_corners=True), dense form, into / from the channel
+ * slice [coff, coff + C) of a [B][H][W][ld_out] tensor */
+int wesup_upsample_bilinear_ac_fwd(const float* s, float* out, int B, int h, int w, int H, int W, int C, int ld_out,
+                                   int coff, void* stream);
+int wesup_upsample_bilinear_ac_bwd(const float* dout, float* ds, int B, int h, int w, int H, int W, int C, int ld_out,
+                                   int coff, void* stream);
+/* K11 (models/wesup.py:231 Softmax + :66-96 _cross_entropy) fused: probs = softmax(logits) is written out, out2 as in
+ * wesup_cross_entropy_fwd; bwd gives d loss / d logits */
+int wesup_softmax_ce_fwd(const float* logits, const float* y_true, const float* class_weights, float eps, float* probs,
+                         float* out2, int n, int C, void* stream);
+int wesup_softmax_ce_bwd(const float* probs, const float* y_true, const float* class_weights, const float* out2,
+                         const float* dloss, float eps, float* dlogits, int n, int C, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

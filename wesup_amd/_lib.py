@@ -73,6 +73,19 @@ _SIGS = {
     'wesup_sgd_step': (c_int, 'pppzffffip'),
     'wesup_seg_metrics_workspace_bytes': (c_size_t, 'i'),
     'wesup_seg_metrics': (c_int, 'pppiiipzp'),
+    # entries by the names of SURVEY.md 8(b) (csrc/named.hip)
+    'wesup_sp_stats': (c_int, 'ppiiiipppp'),
+    'wesup_conv1x1_workspace_bytes': (c_size_t, 'iii'),
+    'wesup_conv1x1_fwd': (c_int, 'ppppiiipzp'),
+    'wesup_conv1x1_dgrad': (c_int, 'pppiiiipzp'),
+    'wesup_conv1x1_wgrad': (c_int, 'ppppiiipzp'),
+    'wesup_linear_workspace_bytes': (c_size_t, 'iii'),
+    'wesup_linear_fwd': (c_int, 'ppppiiiipzp'),
+    'wesup_linear_bwd': (c_int, 'pppppppiiipzp'),
+    'wesup_upsample_bilinear_ac_fwd': (c_int, 'ppiiiiiiiip'),
+    'wesup_upsample_bilinear_ac_bwd': (c_int, 'ppiiiiiiiip'),
+    'wesup_softmax_ce_fwd': (c_int, 'pppfppiip'),
+    'wesup_softmax_ce_bwd': (c_int, 'pppppfpiip'),
 }
 _T = {'p': c_void_p, 'i': c_int, 'f': c_float, 'z': c_size_t, 'l': ctypes.c_long}
 
