@@ -294,12 +294,19 @@ def worker(args):
         allk = dict(timer.collect())
         timer.reset()
         eng.two_streams = False                       # kernels alone on the GPU: isolated per-launch durations
-        for i in range(2):
+        from wesup_amd import ops as _ops
+        sk_was = (_ops.STREAMK_FWD, _ops.STREAMK_DGRAD, _ops.STREAMK_GEMM)
+        _ops.set_streamk(everything=True)             # ... as a single-stream caller runs them: with the stream-K tail
+        for i in range(3):                            # (first step: workspaces are allocated)
+            if i == 1:
+                torch.cuda.synchronize()
+                timer.collect(); timer.reset()
             step(i)
         torch.cuda.synchronize()
         iso = dict(timer.collect())
         timer.enabled = False
         eng.two_streams = True
+        _ops.set_streamk(fwd=sk_was[0], dgrad=sk_was[1], gemm=sk_was[2])
         timer.reset()
         timer.totals = timed
         if rank == 0:
@@ -337,7 +344,7 @@ def worker(args):
             for tag, (ms, n, work) in sorted(allk.items()):
                 kern[tag] = {'ms_per_step': round(ms / n_extra, 4), 'launches_per_step': n / n_extra,
                              'avg_us': round(ms / n * 1e3, 2)}
-                if tag.startswith('conv3x3') or tag in ('side_fwd', 'side_bwd', 'mlp_fwd', 'mlp_bwd', 'sp_pool_mat_fwd', 'upsample_mat_bwd'):
+                if tag.startswith('conv3x3') or tag in ('side_fwd', 'side_bwd', 'mlp_fwd', 'mlp_bwd', 'mlp_wgrad', 'sp_pool_mat_fwd', 'upsample_mat_bwd'):
                     kern[tag]['tflops'] = round(work / (ms * 1e-3) / 1e12, 2)
                 elif work > 0:
                     kern[tag]['gbs'] = round(work / (ms * 1e-3) / 1e9, 1)
@@ -376,7 +383,7 @@ def worker(args):
             out['kernels'] = kern
             # whole-step view of the matrix cores: every GEMM-shaped FLOP of the step (conv fwd/dgrad/wgrad, side convs,
             # MLP, matrix pooling of the deep layers) over the wall time of the step, all streams together
-            gemm_tags = ('conv3x3_fwd', 'conv3x3_dgrad', 'conv3x3_wgrad', 'side_fwd', 'side_bwd', 'mlp_fwd', 'mlp_bwd',
+            gemm_tags = ('conv3x3_fwd', 'conv3x3_dgrad', 'conv3x3_wgrad', 'side_fwd', 'side_bwd', 'mlp_fwd', 'mlp_bwd', 'mlp_wgrad',
                          'sp_pool_mat_fwd', 'upsample_mat_bwd')
             fl_step = sum(allk[t][2] for t in gemm_tags if t in allk) / n_extra
             a = fl_step / (ms_per_step * 1e-3) / 1e12
@@ -392,7 +399,8 @@ def worker(args):
                     return round(fl / (ms * 1e-3) / 1e12, 2) if ms > 0 else None
                 a, wgr = tf(('conv3x3_fwd', 'conv3x3_dgrad')), tf(('conv3x3_wgrad',))
                 out['roofline_isolated'] = {
-                    'how': '2 extra untimed steps with single-stream scheduling, HIP events per launch',
+                    'how': '2 extra untimed steps with single-stream scheduling and the stream-K tail on (what a kernel alone on the GPU '
+                           'gains from; the 3-stream step runs plain tiling, wesup_amd/ops.py), HIP events per launch',
                     'ms_per_step': {k: round(v[0] / 2, 3) for k, v in sorted(iso.items())},
                     'conv3x3_fwd_dgrad': {'bound': 'mfma', 'achieved': a, 'peak': PEAK_MFMA_F32_TFLOPS, 'unit': 'TFLOP/s',
                                           'frac': round(a / PEAK_MFMA_F32_TFLOPS, 4)},

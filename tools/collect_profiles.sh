@@ -12,6 +12,8 @@ R=${1:-r02}
 OUT=gpurun_out/prof_$R
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
+# rocprofv3 starts the HIP runtime before python does: what bench.py sets at import time comes too late under the profiler
+export GPU_MAX_HW_QUEUES=6
 timeout -k 10 400 python3 bench.py > $OUT/bench_line.json 2> $OUT/bench_line.err || exit 1
 echo "bench done"
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> $OUT/bench_under_rocprof.err || exit 1

@@ -39,7 +39,7 @@ else:
         n = r['Kernel_Name']
         n = re.sub(r'\(.*', '', n).replace('void ', '')
         d = (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3
-        print(f"{(int(r['Start_Timestamp']) - t0) / 1e3:10.1f} {d:9.1f} us  grid {r.get('Grid_Size_X', r.get('Grid_Size', '?')):>9} wg {r.get('Workgroup_Size_X', r.get('Workgroup_Size', '?')):>4}  {n}")
+        print(f"{(int(r['Start_Timestamp']) - t0) / 1e3:10.1f} {d:9.1f} us  q{r.get('Queue_Id', '?'):>2} grid {r.get('Grid_Size_X', r.get('Grid_Size', '?')):>9} wg {r.get('Workgroup_Size_X', r.get('Workgroup_Size', '?')):>4}  {n}")
         a = agg.setdefault(n, [0, 0.0])
         a[0] += 1; a[1] += d
     print('--- totals')

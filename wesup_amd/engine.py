@@ -412,20 +412,41 @@ class WesupEngine:
         # is no dgrad chain and no side-conv dgrad at all (the side convs' own wgrads only need ds_l and y_l).
         trainable = [not {f'backbone.{i}.weight', f'backbone.{i}.bias'} <= self.frozen for i in CONV_IDX]
         lowest = min([l for l in range(13) if trainable[l]], default=13)
-        # ---- classifier + fc_layers
+        # ---- classifier + fc_layers.  Between the last forward conv and the first dgrad the step has ONE chain of small
+        # kernels (head forward, loss, head backward, pooling backward of the deepest layers: ~1.7 ms in which the chip
+        # is mostly idle), so only what that chain needs stays on it: the input-gradient GEMMs dfeat -> dh2 -> dh1 -> gsp.
+        # The three weight-gradient GEMMs of the fc layers (the largest of the head: 2304 x 2112 x 1024) produce
+        # parameter gradients only and go to the wgrad stream, where they run beside the chain.
+        head_names = ['classifier.0.weight', 'classifier.0.bias'] + [f'fc_layers.{k}.{t}' for k in (0, 2, 4) for t in ('weight', 'bias')]
         tok = T.begin('mlp_bwd')
         ops.classifier_bwd(b.feats, p['classifier.0.weight'], b.sp_pred, dpred.reshape(R, 2),
                            None if dfeat_extra is None else dfeat_extra.reshape(R, D),
                            b.dfeat, g['classifier.0.weight'], g['classifier.0.bias'])
-        ops.gemm_tn(b.dfeat, b.h2, out=g['fc_layers.4.weight'], colsum=g['fc_layers.4.bias'])
-        ops.gemm_nt(b.dfeat, pk.fcT[2], None, out=b.dh2, mask=b.h2)
-        ops.gemm_tn(b.dh2, b.h1, out=g['fc_layers.2.weight'], colsum=g['fc_layers.2.bias'])
-        ops.gemm_nt(b.dh2, pk.fcT[1], None, out=b.dh1, mask=b.h1)
-        ops.gemm_tn(b.dh1, b.sp_in.view(R, FM_CHANNELS), out=g['fc_layers.0.weight'], colsum=g['fc_layers.0.bias'])
         gsp2d = b.gsp.view(R, FM_CHANNELS)
+        off_chain = self.two_streams
+        if not off_chain:
+            ops.gemm_tn(b.dfeat, b.h2, out=g['fc_layers.4.weight'], colsum=g['fc_layers.4.bias'])
+        ops.gemm_nt(b.dfeat, pk.fcT[2], None, out=b.dh2, mask=b.h2)
+        if not off_chain:
+            ops.gemm_tn(b.dh2, b.h1, out=g['fc_layers.2.weight'], colsum=g['fc_layers.2.bias'])
+        ops.gemm_nt(b.dh2, pk.fcT[1], None, out=b.dh1, mask=b.h1)
+        if not off_chain:
+            ops.gemm_tn(b.dh1, b.sp_in.view(R, FM_CHANNELS), out=g['fc_layers.0.weight'], colsum=g['fc_layers.0.bias'])
         ops.gemm_nt(b.dh1, pk.fcT[0], None, out=gsp2d)
-        T.end(tok, 4.0 * R * (FM_CHANNELS * 1024 + 1024 * 1024 + 1024 * D))
-        ready(['classifier.0.weight', 'classifier.0.bias'] + [f'fc_layers.{k}.{t}' for k in (0, 2, 4) for t in ('weight', 'bias')])
+        T.end(tok, (4.0 if not off_chain else 2.0) * R * (FM_CHANNELS * 1024 + 1024 * 1024 + 1024 * D))
+        if off_chain:
+            wgs = self._wg()
+            wgs.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(wgs):
+                tok = T.begin('mlp_wgrad')
+                ops.gemm_tn(b.dfeat, b.h2, out=g['fc_layers.4.weight'], colsum=g['fc_layers.4.bias'], ws_tag='wgrad')
+                ops.gemm_tn(b.dh2, b.h1, out=g['fc_layers.2.weight'], colsum=g['fc_layers.2.bias'], ws_tag='wgrad')
+                ops.gemm_tn(b.dh1, b.sp_in.view(R, FM_CHANNELS), out=g['fc_layers.0.weight'], colsum=g['fc_layers.0.bias'],
+                            ws_tag='wgrad')
+                T.end(tok, 2.0 * R * (FM_CHANNELS * 1024 + 1024 * 1024 + 1024 * D))
+                ready(head_names)
+        else:
+            ready(head_names)
         # ---- scatter-mean backward (materialised) or fused into the upsample backward
         if not self.fuse_pool_bwd:
             tok = T.begin('sp_pool_bwd')
