@@ -1,6 +1,6 @@
 """Gradient yardstick for the GPU tests: an evaluation of the oracle's training step (any dtype) in which every
-DISCONTINUOUS decision of the network -- the sign of each pre-activation (ReLU) and the arg-max of each 2x2 pooling
-window -- is taken from the GPU run instead of being re-decided.
+DISCONTINUOUS decision of the network -- the sign of each pre-activation (ReLU: the 13 conv layers and the three fc
+layers) and the arg-max of each 2x2 pooling window -- is taken from the GPU run instead of being re-decided.
 
 Why: a pre-activation that fp64 puts within fp32 rounding of zero can land on the other side of the ReLU in fp32 (seen:
 +4.4e-7 vs -1.0e-7 on activations of O(1)); that unit's gradient is then dropped and every layer below moves by up to
@@ -29,8 +29,12 @@ def _windows(t):
     return t[:, :, :hh, :ww].reshape(1, C, hh // 2, 2, ww // 2, 2).permute(0, 1, 2, 4, 3, 5).reshape(1, C, hh // 2, ww // 2, 4)
 
 
-def forced_step(weights, imgs, segs, masks, y_gpu, dtype=torch.float64, tie_tol=2e-5, **loss_kw):
-    """y_gpu: 13 tensors (B,C,h,w), the GPU's pre-ReLU conv outputs.  Returns (loss, grads, disagreements) where
+def forced_step(weights, imgs, segs, masks, y_gpu, dtype=torch.float64, tie_tol=2e-5, mlp_gpu=None, pseudo_gpu=None,
+                **loss_kw):
+    """y_gpu: 13 tensors (B,C,h,w), the GPU's pre-ReLU conv outputs; mlp_gpu: the GPU's three fc-layer outputs
+    (post-ReLU: only their sign pattern is used), each (B, Kmax, width); pseudo_gpu: the label rows (B, Kmax, C) the
+    GPU's propagation produced (labelled rows first, then the propagated pseudo labels): the third discrete decision
+    (``max_sim > threshold`` and the arg-max among the labelled rows).  Returns (loss, grads, disagreements) where
     disagreements is a list of dicts naming every unit whose decision differs from this evaluation's own."""
     B = imgs.shape[0]
     w = {k: torch.from_numpy(v).to(dtype).requires_grad_(True) for k, v in weights.items()}
@@ -70,21 +74,57 @@ def forced_step(weights, imgs, segs, masks, y_gpu, dtype=torch.float64, tie_tol=
                 h = win.gather(-1, pick).squeeze(-1)
         return outs
 
-    saved = orc.backbone_side_outputs
+    def mlp(wd, sp_feat):
+        """orc.mlp_head with the GPU's ReLU pattern of the three fc layers."""
+        b = cur['b']
+        h = sp_feat
+        for li, k in enumerate((0, 2, 4)):
+            pre = F.linear(h, wd[f'fc_layers.{k}.weight'], wd[f'fc_layers.{k}.bias'])
+            on = (mlp_gpu[li][b, :pre.shape[0]] > 0).to(pre.device)
+            pd = pre.detach()
+            diff = (pd > 0) != on
+            if bool(diff.any()):
+                scale = float(pd.abs().max())
+                for (r, c) in diff.nonzero()[:64].tolist():
+                    named.append(dict(kind='fc-relu', layer=k, image=b, c=c, h=r, w=0, ref=float(pd[r, c]),
+                                      gpu=float(mlp_gpu[li][b, r, c]), near_tie=abs(float(pd[r, c])) <= tie_tol * scale))
+            h = pre * on.to(dtype)
+        pred = F.softmax(F.linear(h, wd['classifier.0.weight'], wd['classifier.0.bias']), dim=1)
+        return h, pred
+
+    saved, saved_mlp = orc.backbone_side_outputs, orc.mlp_head
     orc.backbone_side_outputs = backbone
+    if mlp_gpu is not None:
+        orc.mlp_head = mlp
     total = 0.0
     try:
         for b in range(B):                                         # one image at a time: the graph of one image is
             cur['b'] = b                                           # several GB at 480x480 in fp64
             o = orc.forward_image(w, torch.from_numpy(imgs[b]).to(dtype), torch.from_numpy(segs[b].astype(np.int64)),
                                   None if masks is None else torch.from_numpy(masks[b].astype(np.int64)))
-            loss_b = orc.compute_loss(o['sp_pred'], o['sp_features'], o['pp']['sp_labels'], **loss_kw)
+            pp = o['pp']
+            if pseudo_gpu is not None and pp['n_l'] < pp['K'] and loss_kw.get('enable_propagation', True):
+                thr = loss_kw.get('propagate_threshold', 0.8)
+                n, n_l = pp['K'], pp['n_l']
+                y_own, W_ul, max_sim, _ = orc.label_propagate(o['sp_features'], pp['sp_labels'], thr, return_aux=True)
+                y_gpu_b = pseudo_gpu[b, n_l:n].to(y_own.dtype)
+                differ = (y_gpu_b != y_own).any(dim=1)
+                if bool(differ.any()):
+                    top2 = W_ul.topk(min(2, W_ul.shape[1]), dim=1).values
+                    close = ((max_sim - thr).abs() < 1e-5) | ((top2[:, 0] - top2[:, -1]).abs() < 1e-5)
+                    for r in differ.nonzero().flatten()[:64].tolist():
+                        named.append(dict(kind='propagate', layer=-1, image=b, c=0, h=r, w=0, ref=float(max_sim[r]),
+                                          gpu=float(y_gpu_b[r].sum()), near_tie=bool(close[r])))
+                loss_b = orc.cross_entropy(o['sp_pred'][:n_l], pp['sp_labels'])
+                loss_b = loss_b + loss_kw.get('propagate_weight', 0.5) * orc.cross_entropy(o['sp_pred'][n_l:], y_gpu_b)
+            else:
+                loss_b = orc.compute_loss(o['sp_pred'], o['sp_features'], pp['sp_labels'], **loss_kw)
             if loss_b.requires_grad:
                 (loss_b / B).backward()
             total += float(loss_b.detach()) / B
             del o, loss_b
     finally:
-        orc.backbone_side_outputs = saved
+        orc.backbone_side_outputs, orc.mlp_head = saved, saved_mlp
     grads = {k: (v.grad if v.grad is not None else torch.zeros_like(v)).detach() for k, v in w.items()}
     return total, grads, named
 
@@ -95,14 +135,30 @@ def gpu_preactivations(engine):
     return [y.detach().permute(0, 3, 1, 2).float().cpu() for y in b.y]
 
 
+def gpu_mlp_outputs(engine):
+    """The three fc-layer outputs (post-ReLU) of the engine's last forward as (B, Kmax, width) CPU tensors."""
+    b = engine._last
+    B = b.shape[0]
+    return [t.detach().float().cpu().view(B, -1, t.shape[-1]) for t in (b.h1, b.h2, b.feats)]
+
+
 def check_gradients(model, weights, imgs, segs, masks, names=None, tol=1e-4, tie_tol=2e-5, **loss_kw):
     """Assert points 1 and 2 of the module docstring for the gradients the model holds after a backward pass.
     Returns (worst relative error, number of named disagreements)."""
     ys = gpu_preactivations(model.engine)
-    _, g64, named = forced_step(weights, imgs, segs, masks, ys, torch.float64, tie_tol, **loss_kw)
+    hs = gpu_mlp_outputs(model.engine)
+    pseudo = None
+    meta = getattr(model, '_last_meta', None)
+    if masks is not None and meta is not None and loss_kw.get('enable_propagation', True):
+        from wesup_amd import ops
+        b = model.engine._last
+        y_all, _, _ = ops.propagate(b.feats.view(meta.B, meta.Kmax, -1).contiguous(), meta,
+                                    loss_kw.get('propagate_threshold', 0.8))
+        pseudo = y_all.cpu()
+    _, g64, named = forced_step(weights, imgs, segs, masks, ys, torch.float64, tie_tol, mlp_gpu=hs, pseudo_gpu=pseudo, **loss_kw)
     bad = [n for n in named if not n['near_tie']]
     assert not bad, f'decisions that differ from fp64 without being near-ties: {bad[:5]}'
-    _, g32, _ = forced_step(weights, imgs, segs, masks, ys, torch.float32, tie_tol, **loss_kw)
+    _, g32, _ = forced_step(weights, imgs, segs, masks, ys, torch.float32, tie_tol, mlp_gpu=hs, pseudo_gpu=pseudo, **loss_kw)
     worst = 0.0
     for k in (names or list(g64)):
         ref = g64[k]

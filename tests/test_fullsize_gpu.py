@@ -44,6 +44,25 @@ def make_trainer(weights, **kw):
     return trainer
 
 
+def loss_under_gpu_decisions(orc, out, y_all_b, threshold=0.8, weight=0.5, tol=1e-5):
+    """The oracle's per-image loss with the pseudo labels the GPU propagated, after checking that the two only disagree
+    on rows whose best similarity is within fp32 rounding of the threshold or of the runner-up (the propagation is a
+    discrete decision: ``max_sim > threshold``, first arg-max; one such row moves the loss by ~1/n_propagated)."""
+    pp = out['pp']
+    n, n_l = pp['K'], pp['n_l']
+    feats = out['sp_features'].detach()
+    y_u, W_ul, max_sim, src = orc.label_propagate(feats, pp['sp_labels'], threshold, return_aux=True)
+    got = y_all_b[n_l:n].cpu()
+    differ = (got != y_u).any(dim=1)
+    if bool(differ.any()):
+        top2 = W_ul.topk(min(2, W_ul.shape[1]), dim=1).values
+        close = ((max_sim - threshold).abs() < tol) | ((top2[:, 0] - top2[:, -1]).abs() < tol)
+        assert bool(close[differ].all()), f'{int(differ.sum())} pseudo labels differ, not all of them near-ties'
+    loss = orc.cross_entropy(out['sp_pred'].detach()[:n_l], pp['sp_labels'])
+    loss = loss + weight * orc.cross_entropy(out['sp_pred'].detach()[n_l:], got)
+    return float(loss), int(differ.sum())
+
+
 @pytest.mark.parametrize('name', ['c480_g14', 'c480_g24', 'c800_g39'])
 def test_step_matches_the_reference_at_full_size(golden_dir, name):
     """The trainer's own path (preprocess -> forward -> compute_loss -> backward) on the reference's full-size inputs."""
@@ -128,27 +147,32 @@ def test_config_c2_exactly_matches_the_oracle():
     model = trainer.model
     meta = model._last_meta
     hist = trainer.tracker.history
-    assert abs(hist['loss'][0] - ref_loss) <= TOL * abs(ref_loss)
-    assert hist['propagated_labels'][0] == np.mean([m['propagated_labels'] for m in mets])
     assert 0 < hist['propagated_labels'][0] < 0.8 * g * g            # some rows propagate, some do not
-    assert abs(hist['propagate_loss'][0] - np.mean([m['propagate_loss'] for m in mets])) < 1e-5
     assert abs(hist['labeled_sp_ratio'][0] - np.mean([m['labeled_sp_ratio'] for m in mets])) < 1e-7
+    bufs = model.engine._last
+    feats = bufs.feats.view(B, meta.Kmax, -1)
+    y_all, src, sim = ops.propagate(feats.contiguous(), meta, 0.8)
+    per_image = [loss_under_gpu_decisions(orc, outs[b], y_all[b]) for b in range(B)]
+    n_near = sum(k for _, k in per_image)
+    assert abs(hist['loss'][0] - np.mean([l for l, _ in per_image])) <= TOL * abs(ref_loss)
+    if n_near == 0:                                                   # no near-tie row: the oracle's own numbers
+        assert abs(hist['loss'][0] - ref_loss) <= TOL * abs(ref_loss)
+        assert hist['propagated_labels'][0] == np.mean([m['propagated_labels'] for m in mets])
+        assert abs(hist['propagate_loss'][0] - np.mean([m['propagate_loss'] for m in mets])) < 1e-5
     P = torch.stack([o['pred'].detach().round().long() for o in outs])
     G = torch.from_numpy(pix).long().argmax(dim=1)
     assert abs(hist['accuracy'][0] - np.mean([orc.accuracy(P[b], G[b]) for b in range(B)])) < 1e-6
     assert abs(hist['dice'][0] - np.mean([orc.dice(P[b], G[b]) for b in range(B)])) < 1e-6
     # integer outputs, per image: row order, labels, propagation sources and pseudo labels
-    bufs = model.engine._last
-    feats = bufs.feats.view(B, meta.Kmax, -1)
-    y_all, src, sim = ops.propagate(feats.contiguous(), meta, 0.8)
     for b in range(B):
         pp = outs[b]['pp']
         n, n_l = pp['K'], pp['n_l']
         assert int(meta.n_sp[b]) == n and int(meta.n_l[b]) == n_l
         assert torch.equal(meta.perm[b, :n].cpu().long(), pp['perm'])
         assert torch.equal(meta.sp_labels[b, :n_l].cpu(), pp['sp_labels'])
-        y_u, _, max_sim, src_ref = orc.label_propagate(outs[b]['sp_features'], pp['sp_labels'], 0.8, return_aux=True)
-        near = (max_sim - 0.8).abs() < 1e-5                                  # a similarity within rounding of the threshold
+        y_u, W_ul, max_sim, src_ref = orc.label_propagate(outs[b]['sp_features'], pp['sp_labels'], 0.8, return_aux=True)
+        top2 = W_ul.topk(2, dim=1).values
+        near = ((max_sim - 0.8).abs() < 1e-5) | ((top2[:, 0] - top2[:, 1]).abs() < 1e-5)   # threshold / runner-up within rounding
         assert rel_err(feats[b, :n], outs[b]['sp_features']) < TOL
         assert torch.equal(src[b, n_l:n].cpu().long()[~near], src_ref[~near])
         assert torch.equal(y_all[b, n_l:n].cpu()[~near], y_u[~near])
@@ -193,19 +217,25 @@ def test_one_image_of_config_c5_matches_the_oracle():
                                 torch.from_numpy(labs).to(d))
     model, hist = trainer.model, trainer.tracker.history
     meta = model._last_meta
-    assert abs(hist['loss'][0] - ref_loss) <= TOL * abs(ref_loss)
-    assert hist['propagated_labels'][0] == mets[0]['propagated_labels'] and 0 < hist['propagated_labels'][0] < 0.8 * g * g
-    assert abs(hist['propagate_loss'][0] - mets[0]['propagate_loss']) < 1e-5
+    assert 0 < hist['propagated_labels'][0] < 0.8 * g * g
+    bufs = model.engine._last
+    y_all0, _, _ = ops.propagate(bufs.feats.view(1, meta.Kmax, -1).contiguous(), meta, 0.8)
+    loss_ref, n_near = loss_under_gpu_decisions(orc, outs[0], y_all0[0])
+    assert abs(hist['loss'][0] - loss_ref) <= TOL * abs(ref_loss)
+    if n_near == 0:
+        assert abs(hist['loss'][0] - ref_loss) <= TOL * abs(ref_loss)
+        assert hist['propagated_labels'][0] == mets[0]['propagated_labels']
+        assert abs(hist['propagate_loss'][0] - mets[0]['propagate_loss']) < 1e-5
     pp = outs[0]['pp']
     n, n_l = pp['K'], pp['n_l']
     assert n == g * g == int(meta.n_sp[0]) and int(meta.n_l[0]) == n_l
     assert torch.equal(meta.perm[0, :n].cpu().long(), pp['perm']) and torch.equal(meta.sp_labels[0, :n_l].cpu(), pp['sp_labels'])
-    bufs = model.engine._last
     feats = bufs.feats.view(1, meta.Kmax, -1)
     assert rel_err(feats[0, :n], outs[0]['sp_features']) < TOL
     y_all, src, sim = ops.propagate(feats.contiguous(), meta, 0.8)
-    y_u, _, max_sim, src_ref = orc.label_propagate(outs[0]['sp_features'], pp['sp_labels'], 0.8, return_aux=True)
-    near = (max_sim - 0.8).abs() < 1e-5
+    y_u, W_ul, max_sim, src_ref = orc.label_propagate(outs[0]['sp_features'], pp['sp_labels'], 0.8, return_aux=True)
+    top2 = W_ul.topk(2, dim=1).values
+    near = ((max_sim - 0.8).abs() < 1e-5) | ((top2[:, 0] - top2[:, 1]).abs() < 1e-5)     # threshold or runner-up within rounding
     assert torch.equal(src[0, n_l:n].cpu().long()[~near], src_ref[~near]) and torch.equal(y_all[0, n_l:n].cpu()[~near], y_u[~near])
     assert torch.equal(bufs.pred[0].round().long().cpu(), outs[0]['pred'].detach().round().long())
     del outs, ref_grads
@@ -213,8 +243,8 @@ def test_one_image_of_config_c5_matches_the_oracle():
     new = {k: v.detach().cpu() for k, v in model.state_dict().items()}
     for k, v in ref_new.items():
         assert rel_err(new[k], v) < 1e-5, k
-    print(f'c5 (one image): loss {hist["loss"][0]:.6f} (oracle {ref_loss:.6f}), worst gradient error vs fp64 {worst:.2e}, '
-          f'{n_named} near-tie decisions differ')
+    print(f'c5 (one image): loss {hist["loss"][0]:.6f} (oracle {ref_loss:.6f}; {n_near} pseudo labels decided by a '
+          f'near-tie), worst gradient error vs fp64 {worst:.2e}, {n_named} near-tie decisions differ')
     model.engine.release_buffers()
     torch.cuda.empty_cache()
 

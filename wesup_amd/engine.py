@@ -423,7 +423,7 @@ class WesupEngine:
                            None if dfeat_extra is None else dfeat_extra.reshape(R, D),
                            b.dfeat, g['classifier.0.weight'], g['classifier.0.bias'])
         gsp2d = b.gsp.view(R, FM_CHANNELS)
-        off_chain = self.two_streams
+        off_chain = self.two_streams and getattr(self, 'head_wgrad_off_chain', True)
         if not off_chain:
             ops.gemm_tn(b.dfeat, b.h2, out=g['fc_layers.4.weight'], colsum=g['fc_layers.4.bias'])
         ops.gemm_nt(b.dfeat, pk.fcT[2], None, out=b.dh2, mask=b.h2)
