@@ -157,3 +157,36 @@ def test_bench_self_launch_two_ranks_one_gpu():
     assert out['n_gpus'] == 2 and out['config']['global_batch'] == 2 and out['config']['parallelism'] == 'dp2'
     assert out['collective']['ranks'] == 2 and out['rank_time']['max_s'] >= out['rank_time']['min_s'] > 0
     assert out['value'] > 0 and 'custom shape' in out['config']['workload']
+
+
+def _fit_worker(rank, world, port, root, out):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK='0',
+                      RECORD_ROOT=root)
+    from wesup_amd.train import fit
+    trainer = fit('synthetic:64:64:4:8', model='wesup', epochs=2, batch_size=2, num_workers=0, dist_backend='gloo', no_val=True)
+    import torch.distributed as dist
+    out.put((rank, trainer.world_size, str(trainer.record_dir), float(trainer.model._flat.double().sum()),
+             len(trainer.tracker.history['loss'])))
+    dist.destroy_process_group()
+
+
+def test_fit_under_a_multi_process_launcher(tmp_path):
+    """`python -m torch.distributed.run ... -m wesup_amd.train DATA`: fit() sees WORLD_SIZE, joins the process group and
+    trains data-parallel -- one record directory (rank 0's), half of the 8 items per rank and epoch, replicas
+    bit-identical after two epochs."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_fit_worker, args=(r, 2, port, str(tmp_path), out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(out.get(timeout=280) for _ in range(2))
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    (r0, w0, d0, s0, n0), (r1, w1, d1, s1, n1) = res
+    assert (w0, w1) == (2, 2) and d0 == d1 and s0 == s1
+    assert n0 == n1 == 2                                   # 8 items / 2 ranks / batch 2 = 2 iterations in the last epoch
+    rd = [p for p in tmp_path.iterdir()]
+    assert len(rd) == 1 and (rd[0] / 'history.csv').exists() and len(list((rd[0] / 'checkpoints').glob('*.pth'))) == 1

@@ -12,15 +12,31 @@ from .utils.metrics import dice
 
 
 def fit(dataset_path, model='wesup', **kwargs):
+    """train.py:14-27 of the reference.  Under a multi-process launcher (``python -m torch.distributed.run --nproc-per-node N
+    -m wesup_amd.train DATA ...``: WORLD_SIZE / RANK / LOCAL_RANK in the environment) every process takes the GPU of its
+    local rank, joins the RCCL process group and trains data-parallel: batches sharded by image, gradients all-reduced
+    during backward (wesup_amd/ddp.py)."""
+    import os
     logger = logging.getLogger('Train')
     logger.setLevel(logging.DEBUG)
     if not logger.handlers:
         logger.addHandler(logging.StreamHandler())
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+        kwargs.setdefault('device', f'cuda:{local_rank}')
+        if not dist.is_initialized():
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(kwargs.pop('dist_backend', 'nccl'))
     trainer = initialize_trainer(model, logger=logger, **kwargs)
+    if world > 1:
+        trainer.enable_data_parallel()
     try:
         trainer.train(dataset_path, metrics=[accuracy, dice], **kwargs)
     finally:
-        if kwargs.get('smoke'):
+        if kwargs.get('smoke') and trainer.rank == 0 and trainer.record_dir is not None:
             rmtree(trainer.record_dir, ignore_errors=True)
     return trainer
 
