@@ -86,6 +86,13 @@ size_t wesup_conv3x3_workspace_bytes(int B, int H, int W, int Cin, int Cout);
 int wesup_conv3x3_fwd(const float* x, const float* w_fwd, const float* bias, float* y, float* y_relu,
                       int B, int H, int W, int Cin, int Cout, int relu_in,
                       void* ws, size_t ws_bytes, void* stream);
+/* The same forward for a layer with Cout in {64, 128}, with the layer's 1x1 side conv (models/wesup.py:256-266:
+ * Conv2d(Cout, Cout/2, 1) on the hooked conv output) fused into the epilogue: side_out[pixel*ld_side + c] =
+ * sum_k y[pixel][k] * side_w[c][k] + side_bias[c] for c < Cout/2, computed from the output tile while it is in LDS
+ * (y is not read a second time).  side_w row-major (Cout/2, Cout) = the Conv2d weight; side_bias may be NULL. */
+int wesup_conv3x3_fwd_side(const float* x, const float* w_fwd, const float* bias, float* y, float* y_relu,
+                           const float* side_w, const float* side_bias, float* side_out, int ld_side,
+                           int B, int H, int W, int Cin, int Cout, int relu_in, void* stream);
 /* dx = conv_transpose(dy) ; if mask_src: dx = mask_src > 0 ? dx : 0 ; if accumulate: dx += old dx */
 int wesup_conv3x3_dgrad(const float* dy, const float* w_dgrad, const float* mask_src, float* dx,
                         int B, int H, int W, int Cin, int Cout, int accumulate,

@@ -85,6 +85,58 @@ def test_conv3x3_fwd(ops, B, H, W, Cin, Cout, relu_in):
     assert torch.equal(y2, y) and torch.equal(yr, torch.relu(y))
 
 
+@pytest.mark.parametrize('B,H,W,Cin,Cout', [(1, 40, 36, 3, 64), (2, 33, 29, 64, 64), (1, 37, 41, 64, 128),
+                                            (2, 24, 24, 128, 128), (1, 11, 7, 32, 64)])
+@pytest.mark.parametrize('relu_in', [False, True])
+@pytest.mark.parametrize('into_slice', [False, True])
+def test_conv3x3_fwd_with_fused_side_conv(ops, B, H, W, Cin, Cout, relu_in, into_slice):
+    """The side conv computed in the conv's epilogue (models/wesup.py:256-266) equals Conv2d(Cout, Cout/2, 1) on the
+    conv output; the conv output and its ReLU'd copy are bit-identical to the unfused launch's; ragged last pixel tile,
+    and the side output written into a channel slice of a wider buffer (row stride > Cout/2) leaves the rest alone."""
+    d = dev()
+    x = rnd(B, Cin, H, W, seed=1)
+    w = rnd(Cout, Cin, 3, 3, seed=2, scale=(2.0 / (9 * Cin)) ** 0.5)
+    b = rnd(Cout, seed=3, scale=0.1)
+    sw = rnd(Cout // 2, Cout, seed=4, scale=(1.0 / Cout) ** 0.5)
+    sb = rnd(Cout // 2, seed=5, scale=0.1)
+    y_ref = F.conv2d(F.relu(x) if relu_in else x, w, b, padding=1)
+    s_ref = F.conv2d(y_ref.double(), sw.double().view(Cout // 2, Cout, 1, 1), sb.double()).float()
+    xg = ops.pack_input(x.to(d)) if Cin == 3 else nhwc(x).to(d)
+    wf, _ = ops.pack_conv3x3_weight(w.to(d), need_dgrad=False)
+    y0 = ops.conv3x3_fwd(xg, wf, b.to(d), Cout, relu_in)
+    P = B * H * W
+    if into_slice:
+        wide = torch.full((P, Cout // 2 + 24), 7.0, device=d)
+        sout = wide[:, 8:8 + Cout // 2]
+    else:
+        wide = None
+        sout = torch.empty(P, Cout // 2, device=d)
+    y, yr = torch.empty_like(y0), torch.empty_like(y0)
+    ops.conv3x3_fwd(xg, wf, b.to(d), Cout, relu_in, out=y, out_relu=yr, side=(sw.to(d), sb.to(d), sout))
+    assert rel_err(nchw(y), y_ref) < TOL
+    assert torch.equal(yr, torch.relu(y))
+    assert (y - y0).abs().max().item() <= 2e-6 * y0.abs().max().item()      # bias added before / after the LDS image
+    s = sout.view(B, H, W, Cout // 2)
+    assert rel_err(nchw(s), s_ref) < TOL
+    if wide is not None:
+        assert (wide[:, :8] == 7.0).all() and (wide[:, 8 + Cout // 2:] == 7.0).all()
+    # no bias on either conv
+    sout2 = torch.empty(P, Cout // 2, device=d)
+    ops.conv3x3_fwd(xg, wf, None, Cout, relu_in, out=y, side=(sw.to(d), None, sout2))
+    y_nb = F.conv2d(F.relu(x) if relu_in else x, w, None, padding=1)
+    s_nb = F.conv2d(y_nb.double(), sw.double().view(Cout // 2, Cout, 1, 1)).float()
+    assert rel_err(nchw(sout2.view(B, H, W, Cout // 2)), s_nb) < TOL
+
+
+def test_fused_side_conv_rejects_other_widths(ops, lib):
+    d = dev()
+    x = torch.zeros(1, 8, 8, 128, device=d)
+    wf = torch.zeros(256, 9 * 128, device=d)
+    y = torch.empty(1, 8, 8, 256, device=d)
+    with pytest.raises(lib.WesupHipError):
+        ops.conv3x3_fwd(x, wf, None, 256, False, out=y, side=(torch.zeros(128, 256, device=d), None, torch.empty(64, 128, device=d)))
+
+
 @pytest.mark.parametrize('B,H,W,Cin,Cout', [c for c in CONV_CASES if c[3] != 3])
 def test_conv3x3_dgrad(ops, B, H, W, Cin, Cout):
     d = dev()

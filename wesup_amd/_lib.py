@@ -33,6 +33,7 @@ _SIGS = {
     'wesup_transpose': (c_int, 'ppiip'),
     'wesup_conv3x3_workspace_bytes': (c_size_t, 'iiiii'),
     'wesup_conv3x3_fwd': (c_int, 'pppppiiiiiipzp'),
+    'wesup_conv3x3_fwd_side': (c_int, 'ppppppppiiiiiiip'),
     'wesup_conv3x3_dgrad': (c_int, 'ppppiiiiiipzp'),
     'wesup_conv3x3_wgrad_workspace_bytes': (c_size_t, 'iiiii'),
     'wesup_conv3x3_wgrad': (c_int, 'ppppiiiiiipzp'),

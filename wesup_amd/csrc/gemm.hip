@@ -100,6 +100,11 @@ struct NtParams {
     int sk_parts;        // stream-K blocks behind them (0: none) ...
     int sk_steps;        // ... sharing this many K-steps of the remaining tiles
     float* sk_ws;        // [sk_parts][2][BM*BN] partial tiles
+    // fused 1x1 side conv (SIDE instantiations, N == BN, no stream-K): side_out[m][0..N/2) = C[m][:] . side_w^T + side_bias
+    const float* side_w;     // [N/2][N] row-major
+    const float* side_bias;  // [N/2] or NULL
+    float* side_out;
+    int ld_side;
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -110,7 +115,7 @@ struct NtParams {
 // A lane's fragments for 4 consecutive MFMA k-steps are ONE ds_read_b128; MFMA t of a group uses element t of the
 // A and the B fragment: lanes 0-31 then carry k = 8g+t, lanes 32-63 k = 8g+4+t (any consistent k order is fine).
 // ---------------------------------------------------------------------------------------------
-template <int NW, int BM, int BN, int WM, int WN, int MODE, int MINB, bool RELU>
+template <int NW, int BM, int BN, int WM, int WN, int MODE, int MINB, bool RELU, bool SIDE = false>
 __global__ __launch_bounds__(NW * 64, MINB) void gemm_nt_kernel(const NtParams p) {
     constexpr int NT = NW * 64;                        // threads per block
     constexpr int PR = NW * 8;                         // rows per staging pass (8 threads fetch one 128-B row)
@@ -325,8 +330,26 @@ __global__ __launch_bounds__(NW * 64, MINB) void gemm_nt_kernel(const NtParams p
     const int n = n_blk + 4 * cq;
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
     float4 bv = zero4;
-    if (!sk && p.bias && n < p.N) bv = ld4(p.bias + n);
+    if (!SIDE && !sk && p.bias && n < p.N) bv = ld4(p.bias + n);
     float* raw = sk ? p.sk_ws + ((long)part * 2 + slot) * (BM * BN) : nullptr;
+    // Fused side conv: the LDS image of the output rows (bias already added) is the A operand of a second, small GEMM
+    // against the 1x1 side weights: wave (sr0, sc0) of an (HR/32) x (BN/64) grid computes 32 rows x 32 side channels
+    // over K = BN.  Its B fragments (side_w[sc0 + l31][8g + 4*lhi ..+3], the same k order as the A reads below) come
+    // straight from global memory (the whole matrix is <= 32 KiB and L2-resident) into the registers the main loop's
+    // fragments no longer need, before the first barrier of the epilogue.
+    constexpr int SWN = BN / 64;
+    static_assert(!SIDE || ((HR / 32) * SWN == NW && BN % 64 == 0), "side-conv wave grid covers the epilogue slab");
+    const int sr0 = (wave / (SWN > 0 ? SWN : 1)) * 32, sc0 = (wave % (SWN > 0 ? SWN : 1)) * 32;
+    float4 sb[SIDE ? BN / 8 : 1];
+    float bcol[WN];
+    float sbias = 0.f;
+    if constexpr (SIDE) {
+#pragma unroll
+        for (int g = 0; g < BN / 8; ++g) sb[g] = ld4(p.side_w + (long)(sc0 + l31) * BN + 8 * g + 4 * lhi);
+#pragma unroll
+        for (int j = 0; j < WN; ++j) bcol[j] = p.bias ? p.bias[wn0 + 32 * j + l31] : 0.f;
+        if (p.side_bias) sbias = p.side_bias[sc0 + l31];
+    }
 #pragma unroll
     for (int e = 0; e < EP; ++e) {
         if (e > 0) __syncthreads();
@@ -337,9 +360,30 @@ __global__ __launch_bounds__(NW * 64, MINB) void gemm_nt_kernel(const NtParams p
                 for (int j = 0; j < WN; ++j)
 #pragma unroll
                     for (int r = 0; r < 16; ++r)
-                        Cs[(wm0 - e * HR + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lhi) * LDC + wn0 + 32 * j + l31] = acc[i][j][r];
+                        Cs[(wm0 - e * HR + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lhi) * LDC + wn0 + 32 * j + l31] =
+                            SIDE ? acc[i][j][r] + bcol[j] : acc[i][j][r];
         }
         __syncthreads();
+        if constexpr (SIDE) {
+            f32x16 sacc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
+            const float* arow = Cs + (sr0 + l31) * LDC + 4 * lhi;
+#pragma unroll
+            for (int g = 0; g < BN / 8; ++g) {
+                const float4 a4 = ld4(arow + 8 * g);
+                sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, sb[g].x, sacc, 0, 0, 0);
+                sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, sb[g].y, sacc, 0, 0, 0);
+                sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, sb[g].z, sacc, 0, 0, 0);
+                sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, sb[g].w, sacc, 0, 0, 0);
+            }
+            float* so = p.side_out + (long)(m_blk + e * HR + sr0 + 4 * lhi) * p.ld_side + sc0 + l31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2);
+                if (m_blk + e * HR + sr0 + 4 * lhi + row < p.M) so[(long)row * p.ld_side] = sacc[r] + sbias;
+            }
+        }
         if (sk) {
 #pragma unroll 4
             for (int rr = r0; rr < HR; rr += ROWS_PER_PASS)
@@ -503,7 +547,7 @@ static NtChoice choose_nt(int M, int N, int K, bool with_ws) {
     return c;
 }
 
-template <int NW, int BM, int BN, int WM, int WN, int MODE, int MINB, bool RELU>
+template <int NW, int BM, int BN, int WM, int WN, int MODE, int MINB, bool RELU, bool SIDE = false>
 static int launch_nt(NtParams p, hipStream_t st, const SkPlan* sk = nullptr, void* ws = nullptr) {
     p.tiles_m = ceil_div(p.M, BM);
     p.tiles_n = ceil_div(p.N, BN);
@@ -513,7 +557,7 @@ static int launch_nt(NtParams p, hipStream_t st, const SkPlan* sk = nullptr, voi
         p.full_tiles = sk->full; p.sk_parts = sk->parts; p.sk_steps = sk->steps; p.sk_ws = (float*)ws;
     }
     const size_t lds = (size_t)2 * (BM + BN) * BK * sizeof(float);
-    auto kern = gemm_nt_kernel<NW, BM, BN, WM, WN, MODE, MINB, RELU>;
+    auto kern = gemm_nt_kernel<NW, BM, BN, WM, WN, MODE, MINB, RELU, SIDE>;
     if (lds > 64 * 1024) {           // more than the default dynamic LDS limit: raise it once per instantiation
         static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -542,8 +586,21 @@ static int dispatch_nt_r(NtParams p, hipStream_t st, void* ws, size_t ws_bytes) 
         default: return launch_nt<4, 64, 64, 1, 1, MODE, 2, RELU>(p, st);
     }
 }
+// conv forward with the layer's 1x1 side conv fused into the epilogue: one N-tile holds all output channels
+template <int MODE, bool RELU>
+static int dispatch_nt_side(NtParams p, hipStream_t st) {
+    if (p.N == 64) return launch_nt<4, 128, 64, 2, 1, MODE, 2, RELU, true>(p, st);
+    if constexpr (MODE == 1) {
+        if (p.N == 128) return launch_nt<4, 128, 128, 2, 2, MODE, 2, RELU, true>(p, st);
+    }
+    return WESUP_ERR_INVALID;
+}
 template <int MODE>
 static int dispatch_nt(NtParams p, hipStream_t st, void* ws, size_t ws_bytes) {
+    if (p.side_out) {
+        if constexpr (MODE == 0) return WESUP_ERR_INVALID;
+        else return (p.flags & WESUP_RELU_IN) ? dispatch_nt_side<MODE, true>(p, st) : dispatch_nt_side<MODE, false>(p, st);
+    }
     return (p.flags & WESUP_RELU_IN) ? dispatch_nt_r<MODE, true>(p, st, ws, ws_bytes)
                                      : dispatch_nt_r<MODE, false>(p, st, ws, ws_bytes);
 }
@@ -592,9 +649,16 @@ extern "C" int wesup_conv3x3_kpad(int Ci) {
     return (9 * cip + BK - 1) / BK * BK;
 }
 
+struct SideConv {
+    const float* w;      // [Cout/2][Cout]
+    const float* bias;   // [Cout/2] or NULL
+    float* out;          // [B*H*W] rows of ld floats
+    int ld;
+};
+
 static int conv_common(const float* x, const float* w, const float* bias, float* y, const float* mask, int B,
                        int H, int W, int Cin, int Cout, int flags, void* ws, size_t ws_bytes, hipStream_t st,
-                       float* y_relu = nullptr) {
+                       float* y_relu = nullptr, const SideConv* side = nullptr) {
     if (!x || !w || !y || B <= 0 || H <= 0 || W <= 0) return WESUP_ERR_INVALID;
     const bool small = (Cin == 4);
     if (!small && (Cin < 32 || (Cin & (Cin - 1)))) return WESUP_ERR_INVALID;
@@ -607,6 +671,12 @@ static int conv_common(const float* x, const float* w, const float* bias, float*
     p.H = H; p.W = W; p.Cin = Cin; p.cin_shift = ilog2(Cin);
     p.dW = make_fastdiv(W); p.dH = make_fastdiv(H);
     p.flags = flags;
+    if (side) {
+        if (!side->w || !side->out || (Cout != 64 && Cout != 128) || side->ld < Cout / 2 ||
+            (((uintptr_t)side->w | (uintptr_t)side->out | (uintptr_t)side->bias) & 15))
+            return WESUP_ERR_INVALID;
+        p.side_w = side->w; p.side_bias = side->bias; p.side_out = side->out; p.ld_side = side->ld;
+    }
     return small ? dispatch_nt<2>(p, st, nullptr, 0) : dispatch_nt<1>(p, st, ws, ws_bytes);
 }
 
@@ -621,6 +691,17 @@ extern "C" int wesup_conv3x3_fwd(const float* x, const float* w_fwd, const float
                                  int H, int W, int Cin, int Cout, int relu_in, void* ws, size_t ws_bytes, void* stream) {
     return conv_common(x, w_fwd, bias, y, nullptr, B, H, W, Cin, Cout, relu_in ? WESUP_RELU_IN : 0, ws, ws_bytes,
                        (hipStream_t)stream, y_relu);
+}
+
+// conv3x3 forward of a layer with Cout in {64, 128} together with its 1x1 side conv (models/wesup.py:246-266: the
+// hook's tap is the conv output, the side conv maps it to Cout/2 channels): side_out[pixel][0..Cout/2) =
+// y[pixel][:] . side_w^T + side_bias, computed from the output tile while it is still in LDS, so y is not read again.
+extern "C" int wesup_conv3x3_fwd_side(const float* x, const float* w_fwd, const float* bias, float* y, float* y_relu,
+                                      const float* side_w, const float* side_bias, float* side_out, int ld_side, int B,
+                                      int H, int W, int Cin, int Cout, int relu_in, void* stream) {
+    const SideConv side = {side_w, side_bias, side_out, ld_side};
+    return conv_common(x, w_fwd, bias, y, nullptr, B, H, W, Cin, Cout, relu_in ? WESUP_RELU_IN : 0, nullptr, 0,
+                       (hipStream_t)stream, y_relu, &side);
 }
 
 extern "C" int wesup_conv3x3_dgrad(const float* dy, const float* w_dgrad, const float* mask_src, float* dx, int B,

@@ -99,6 +99,10 @@ class WesupEngine:
         self.fuse_pool_fwd = True        # skip the (B,HW,2112) feature map: scatter-mean fused with the upsample
         self.matrix_pool = True          # coarse layers: upsample+scatter-mean (and backward) as GEMMs with Wm
         self.two_streams = True          # side branch on its own HIP stream
+        # side convs of the 64/128-channel layers inside the conv epilogue: correct and tested, OFF by default -- it
+        # saves the side stream 0.33 ms of GEMMs that ran beside the chain anyway and puts 5-11 % more work on the conv
+        # chain, which is the step's critical path (17.60 -> 17.88 ms)
+        self.fuse_side_fwd = False
         self.relu_on_store = True        # ReLU'd copies written by the producing kernel instead of ReLU on every load
         self._side_stream = None
         self._wgrad_stream = None
@@ -328,21 +332,24 @@ class WesupEngine:
                 torch.cuda.current_stream().wait_event(pk.ready0)
             if l == 1 and pk.ready is not None:
                 torch.cuda.current_stream().wait_event(pk.ready)
+            ws = p[f'side_conv{off}.weight'].view(co // 2, co)
+            # unfused, full resolution: the side conv writes its slice of fm directly
+            s2d = fm2d[:, off:off + co // 2] if b.s[l] is None else b.s[l].view(B * h * w, co // 2)
+            # optional: the side conv of the four widest layers (64 / 128 channels at 480^2 / 240^2: the y re-read is
+            # 236 / 118 MB) in the conv's epilogue, where the output tile sits in LDS anyway
+            side_in_conv = self.fuse_side_fwd and co <= 128
             tok = T.begin('conv3x3_fwd')
             ops.conv3x3_fwd(cur, pk.wf[l], p[f'backbone.{idx}.bias'], co, relu_in=(l > 0 and not b.relu_stored),
-                            out=b.y[l], out_relu=b.yr[l])
-            T.end(tok, 2.0 * B * h * w * (3 if l == 0 else ci) * co * 9)
+                            out=b.y[l], out_relu=b.yr[l],
+                            side=(ws, p[f'side_conv{off}.bias'], s2d) if side_in_conv else None)
+            T.end(tok, 2.0 * B * h * w * co * ((3 if l == 0 else ci) * 9 + (co // 2 if side_in_conv else 0)))
             # side branch of this layer: 1x1 conv on the pre-ReLU tap, then either the fused upsample+scatter-mean
             # straight into the superpixel feature slice, or upsample into fm's channel slice
             with self._OnSide(self):
-                y2d = b.y[l].view(B * h * w, co)
-                ws = p[f'side_conv{off}.weight'].view(co // 2, co)
-                tok = T.begin('side_fwd')
-                if b.s[l] is None:       # unfused, full resolution: the side conv writes its slice of fm directly
-                    ops.gemm_nt(y2d, ws, p[f'side_conv{off}.bias'], out=fm2d[:, off:off + co // 2])
-                else:
-                    ops.gemm_nt(y2d, ws, p[f'side_conv{off}.bias'], out=b.s[l].view(B * h * w, co // 2))
-                T.end(tok, 2.0 * B * h * w * co * (co // 2))
+                if not side_in_conv:
+                    tok = T.begin('side_fwd')
+                    ops.gemm_nt(b.y[l].view(B * h * w, co), ws, p[f'side_conv{off}.bias'], out=s2d)
+                    T.end(tok, 2.0 * B * h * w * co * (co // 2))
                 if b.group_of[l] is not None:
                     g = b.groups[b.group_of[l]]
                     if l == g.layers[-1]:        # all side outputs of this resolution are in: sp_in slice = Wm . s

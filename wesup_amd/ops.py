@@ -142,7 +142,9 @@ def transpose(a, out=None):
 
 
 # ---------------------------------------------------------------- conv 3x3
-def conv3x3_fwd(x, w_fwd, bias, Cout, relu_in, out=None, out_relu=None):
+def conv3x3_fwd(x, w_fwd, bias, Cout, relu_in, out=None, out_relu=None, side=None):
+    """side = (side_w (Cout/2, Cout), side_bias or None, side_out 2-D view with row stride >= Cout/2): the layer's 1x1
+    side conv computed in the conv's epilogue (Cout 64 / 128 only)."""
     _chk(x, name='x'); _chk(w_fwd, name='w_fwd')
     B, H, W, Cin = x.shape
     assert w_fwd.shape == (Cout, conv3x3_kpad(Cin)), (w_fwd.shape, Cout, Cin)
@@ -153,6 +155,16 @@ def conv3x3_fwd(x, w_fwd, bias, Cout, relu_in, out=None, out_relu=None):
     assert out.shape == (B, H, W, Cout) and out.is_contiguous()
     if out_relu is not None:
         _chk(out_relu, name='out_relu'); assert out_relu.shape == out.shape
+    if side is not None:
+        sw, sbias, sout = side
+        _chk(sw, name='side_w'); assert sw.shape == (Cout // 2, Cout)
+        if sbias is not None:
+            _chk(sbias, name='side_bias'); assert sbias.numel() == Cout // 2
+        assert sout.dtype == torch.float32 and sout.is_cuda and sout.dim() == 2 and sout.stride(1) == 1
+        assert sout.shape == (B * H * W, Cout // 2) and sout.stride(0) >= Cout // 2
+        _lib.call('wesup_conv3x3_fwd_side', _p(x), _p(w_fwd), _p(bias), _p(out), _p(out_relu), _p(sw), _p(sbias), _p(sout),
+                  sout.stride(0), B, H, W, Cin, Cout, int(relu_in), _stream())
+        return out
     nb = _lib.load().wesup_conv3x3_workspace_bytes(B, H, W, Cin, Cout) if STREAMK_FWD else 0
     _lib.call('wesup_conv3x3_fwd', _p(x), _p(w_fwd), _p(bias), _p(out), _p(out_relu), B, H, W, Cin, Cout, int(relu_in),
               _p(_nt_workspace(nb, x.device)), nb, _stream())
