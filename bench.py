@@ -51,6 +51,8 @@ def parse_args(argv=None):
                                                   "'gemm', or 'all'); default: none (the step runs plain tiling, ops.py)")
     ap.add_argument('--side-fusion', action='store_true', help='A/B: side convs of the 64/128-channel layers in the conv '
                                                                'epilogue instead of as GEMMs on the side stream')
+    ap.add_argument('--direct-wgrad', action='store_true', help='A/B: every conv weight gradient with the direct '
+                                                                'implicit-GEMM kernel (no Winograd-domain wgrad)')
     ap.add_argument('--event-every', type=int, default=4, help='steps of the timed region that carry HIP events: every n-th')
     ap.add_argument('--timed-classes', default='conv3x3_fwd,conv3x3_dgrad',
                     help="kernel classes that get HIP events inside the timed region ('all', 'none' or a comma list); an "
@@ -238,6 +240,7 @@ def worker(args):
     trainer.tracker.train()
     trainer.model.engine.fuse_pool_bwd = not args.unfused_pool_bwd
     trainer.model.engine.fuse_side_fwd = args.side_fusion
+    trainer.model.engine.wgrad_winograd = not args.direct_wgrad
     if use_dist and args.ddp_probe != 'pg':
         trainer.enable_data_parallel(bucket_bytes=args.bucket_mb << 20)
 

@@ -103,6 +103,15 @@ size_t wesup_conv3x3_wgrad_workspace_bytes(int B, int H, int W, int Ci, int Cout
 int wesup_conv3x3_wgrad(const float* x, const float* dy, float* dw_kcrs, float* db,
                         int B, int H, int W, int Ci, int Cout, int relu_in,
                         void* ws, size_t ws_bytes, void* stream);
+/* The same dw / db through the Winograd F(2x2,3x3) domain (the scheme of the non-fused Winograd backward-filter algorithms
+ * of vendor conv libraries; it replaces autograd of the reference's Conv2d(k=3,pad=1), models/wesup.py:199): both tensors are transformed per 2x2 output tile (workspace: 16 x tiles x
+ * (Ci + Cout) floats + split-K slabs), 16 TN GEMMs with K = tiles accumulate the transformed filter gradient, and
+ * G^T (.) G maps it back to 3x3.  2.25x fewer multiply-adds than the direct form; same result up to fp32 summation
+ * order.  Ci, Cout multiples of 4, >= 32 (meant for the 256/512-channel layers); x has Ci channels. */
+size_t wesup_conv3x3_wgrad_winograd_workspace_bytes(int B, int H, int W, int Ci, int Cout);
+int wesup_conv3x3_wgrad_winograd(const float* x, const float* dy, float* dw_kcrs, float* db,
+                                 int B, int H, int W, int Ci, int Cout, int relu_in,
+                                 void* ws, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------ generic fp32 MFMA GEMMs
  * side 1x1 convs (models/wesup.py:208-209,253), fc_layers (models/wesup.py:213-220,288) and their grads.

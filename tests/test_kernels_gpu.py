@@ -137,6 +137,29 @@ def test_fused_side_conv_rejects_other_widths(ops, lib):
         ops.conv3x3_fwd(x, wf, None, 256, False, out=y, side=(torch.zeros(128, 256, device=d), None, torch.empty(64, 128, device=d)))
 
 
+@pytest.mark.parametrize('B,H,W,Cin,Cout', [(1, 12, 10, 32, 32), (2, 37, 41, 64, 128), (1, 30, 30, 256, 256),
+                                            (2, 60, 60, 128, 256), (3, 15, 15, 512, 512), (1, 7, 9, 256, 512), (1, 1, 1, 32, 64)])
+@pytest.mark.parametrize('relu_in', [False, True])
+def test_conv3x3_wgrad_winograd(ops, B, H, W, Cin, Cout, relu_in):
+    """The Winograd-domain weight gradient equals autograd's (fp64) to fp32 noise -- odd heights / widths (tiles that
+    hang over the border), one-pixel images, K not a multiple of the GEMM step -- and sits next to the direct kernel."""
+    d = dev()
+    x = rnd(B, Cin, H, W, seed=1)
+    dy = rnd(B, Cout, H, W, seed=4)
+    w = torch.zeros(Cout, Cin, 3, 3, dtype=torch.float64, requires_grad=True)
+    xin = (F.relu(x) if relu_in else x).double()
+    F.conv2d(xin, w, torch.zeros(Cout, dtype=torch.float64), padding=1).backward(dy.double())
+    ref = w.grad
+    xg, dyg = nhwc(x).to(d), nhwc(dy).to(d)
+    dw, db = ops.conv3x3_wgrad_winograd(xg, dyg, relu_in)
+    dw0, db0 = ops.conv3x3_wgrad(xg, dyg, Cin, relu_in)
+    e_w, e_0 = rel_err(dw, ref), rel_err(dw0, ref)
+    assert e_w < max(TOL / 10, 4 * e_0), (e_w, e_0)
+    assert rel_err(db, dy.double().sum(dim=(0, 2, 3))) < TOL / 10
+    dw2, db2 = ops.conv3x3_wgrad_winograd(xg, dyg, relu_in)                 # deterministic (fixed split-K order)
+    assert torch.equal(dw, dw2) and torch.equal(db, db2)
+
+
 @pytest.mark.parametrize('B,H,W,Cin,Cout', [c for c in CONV_CASES if c[3] != 3])
 def test_conv3x3_dgrad(ops, B, H, W, Cin, Cout):
     d = dev()

@@ -104,7 +104,11 @@ def test_step_matches_reference_golden(golden_dir, name, fused):
         # cancellation-heavy sums (conv1_1 dW sums 4096 mixed-sign products); the accuracy of the HIP
         # gradients against an fp64 evaluation is pinned in test_gradients_at_fp32_noise_level.
         samp = g.flatten()[::max(1, g.numel() // 64)][:64].cpu().numpy()
-        assert np.abs(samp - fx['gsamp.' + k]).max() <= 1e-3 * (np.abs(fx['gsamp.' + k]).max() + 1e-12), k
+        # scale: the samples' own maximum, or the tensor's RMS where the sampled elements are (near) zero -- c32's conv5_3
+        # samples are products with a dead input pixel: exactly 0 in a direct sum, 1e-6 of the tensor's scale after
+        # the Winograd-domain sum, whose terms cancel only in exact arithmetic
+        scale = max(np.abs(fx['gsamp.' + k]).max(), ref_norm / np.sqrt(g.numel()))
+        assert np.abs(samp - fx['gsamp.' + k]).max() <= 1e-3 * (scale + 1e-12), k
     if fused:               # ... which is this: vs fp64 under the GPU's own ReLU / pooling decisions, 1e-4 of the tensor's max
         _gradcheck.check_gradients(model, weights, fx['img'][None], fx['seg'][None].astype(np.int64), fx['mask'][None])
 

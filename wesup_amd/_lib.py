@@ -37,6 +37,8 @@ _SIGS = {
     'wesup_conv3x3_dgrad': (c_int, 'ppppiiiiiipzp'),
     'wesup_conv3x3_wgrad_workspace_bytes': (c_size_t, 'iiiii'),
     'wesup_conv3x3_wgrad': (c_int, 'ppppiiiiiipzp'),
+    'wesup_conv3x3_wgrad_winograd_workspace_bytes': (c_size_t, 'iiiii'),
+    'wesup_conv3x3_wgrad_winograd': (c_int, 'ppppiiiiiipzp'),
     'wesup_gemm_nt_workspace_bytes': (c_size_t, 'iii'),
     'wesup_gemm_nt': (c_int, 'pipippipiiiiipzp'),
     'wesup_gemm_tn_workspace_bytes': (c_size_t, 'iii'),

@@ -730,6 +730,7 @@ struct TnParams {
     float* slab;     // [S][slab_stride]: M x Nslab partial products, then M column sums of A (bias gradient)
     long slab_stride;
     int want_colsum;
+    int colsum_batch;                  // want_colsum: only the blocks of this batch entry sum A's columns (-1: every entry)
     long batchA, batchB, batch_slab;   // grid.z = batch index: element strides of A, B and the slab stack per batch entry
     int M, N, K;     // N: columns per tap (MODE 1) or total
     int lda, ldb;
@@ -898,7 +899,8 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnParams p) {
     const int l31 = lane & 31, lhi = lane >> 5;
     const int nk = (k_end - k_begin + BK - 1) / BK;
 
-    const bool do_cs = p.want_colsum && tile_n == 0 && tap == 0 && tid < BM;     // wave-uniform (BM % 64 == 0)
+    const bool do_cs = p.want_colsum && (p.colsum_batch < 0 || (int)blockIdx.z == p.colsum_batch) && tile_n == 0 &&
+                       tap == 0 && tid < BM;     // wave-uniform (BM % 64 == 0)
     float csum = 0.f;
     unsigned vb[NB];
 #pragma unroll
@@ -1168,7 +1170,7 @@ extern "C" int wesup_gemm_tn(const float* A, int lda, const float* B, int ldb, f
     TnParams p = {};
     p.A = A; p.Bx = B; p.slab = (float*)ws; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb;
     p.relu_b = relu_b; p.H = 1; p.W = 1; p.dW = make_fastdiv(1); p.dH = make_fastdiv(1);
-    p.slab_stride = (long)tn_slab_stride(M, pl.Nslab); p.want_colsum = colsum_a != nullptr;
+    p.slab_stride = (long)tn_slab_stride(M, pl.Nslab); p.want_colsum = colsum_a != nullptr; p.colsum_batch = -1;
     hipStream_t st = (hipStream_t)stream;
     int rc = launch_tn<0>(p, pl, st);
     if (rc) return rc;
@@ -1200,7 +1202,7 @@ extern "C" int wesup_gemm_tn_batched(const float* A, int lda, long strideA, cons
     TnParams p = {};
     p.A = A; p.Bx = B; p.slab = (float*)ws; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb;
     p.relu_b = relu_b; p.H = 1; p.W = 1; p.dW = make_fastdiv(1); p.dH = make_fastdiv(1);
-    p.slab_stride = (long)tn_slab_stride(M, pl.Nslab); p.want_colsum = 0;
+    p.slab_stride = (long)tn_slab_stride(M, pl.Nslab); p.want_colsum = 0; p.colsum_batch = -1;
     p.batchA = strideA; p.batchB = strideB; p.batch_slab = (long)pl.S * p.slab_stride;
     hipStream_t st = (hipStream_t)stream;
     int rc = launch_tn<0>(p, pl, st, nbatch);
@@ -1294,7 +1296,7 @@ extern "C" int wesup_conv3x3_wgrad(const float* x, const float* dy, float* dw_kc
     TnParams p = {};
     p.A = dy; p.Bx = x; p.slab = (float*)ws; p.M = Cout; p.K = B * H * W; p.lda = Cout;
     p.relu_b = relu_in; p.H = H; p.W = W; p.dW = make_fastdiv(W); p.dH = make_fastdiv(H);
-    p.slab_stride = (long)tn_slab_stride(Cout, pl.Nslab); p.want_colsum = db != nullptr;
+    p.slab_stride = (long)tn_slab_stride(Cout, pl.Nslab); p.want_colsum = db != nullptr; p.colsum_batch = -1;
     int rc;
     if (small) {
         p.N = 64; p.ldb = 4;
@@ -1311,6 +1313,204 @@ extern "C" int wesup_conv3x3_wgrad(const float* x, const float* dy, float* dw_kc
     const float* src = slab_fold((const float*)ws, S, p.slab_stride, (float*)((char*)ws + slab_b), st);
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((tot + Cout + 255) / 256)), dim3(256), 0, st, src,
                        p.slab_stride, dw_kcrs, Cout, Ci, small ? 4 : Ci, pl.Nslab, S, db);
+    WESUP_CHECK_LAUNCH();
+    return WESUP_OK;
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// conv3x3 weight gradient in the Winograd F(2x2, 3x3) domain (the same dW as wesup_conv3x3_wgrad; torch autograd of
+// Conv2d(k=3, pad=1) in the reference, models/wesup.py:199; the scheme of the non-fused Winograd backward-filter
+// algorithms of vendor conv libraries).  With  Y = A^T [ (G g G^T) o (B^T d B) ] A  per 2x2 output tile:
+//     V_p[t][ci]  = (B^T d B)_p      d  = the 4x4 input patch of tile t (zero outside the image)      p = 4*xi + nu
+//     dM_p[t][co] = (A dY A^T)_p     dY = the tile's 2x2 output gradients (zero outside)
+//     dU_p[co][ci] = sum_t dM_p[t][co] * V_p[t][ci]          16 independent TN GEMMs with K = #tiles = pixels / 4
+//     dg[co][ci]   = G^T dU G                                 4x4 -> 3x3
+// i.e. 16 x (P/4) = 4 P multiply-adds per (co, ci) pair instead of 9 P: 2.25x less MFMA work for 4x the operand bytes
+// (V and dM are four times the activations) plus two memory-bound transform passes.  It pays where the direct
+// kernel is MFMA-bound and the channel counts make the GEMMs' arithmetic intensity high: the 256/512-channel layers.
+// The bias gradient is the column sum of dM_5 (A dY A^T at (1,1) = the sum of the tile's four gradients).
+// ---------------------------------------------------------------------------------------------
+struct WinoGeom {
+    int H, W, C, Th, Tw;
+    long T;              // tiles = B * Th * Tw
+    FastDiv dTw, dTh, dQ;
+};
+
+// thread = (tile, 4 channels): 16 float4 loads, B^T d B, 16 float4 stores (c fastest across lanes: coalesced both ways)
+__global__ __launch_bounds__(256) void wino_input_transform_kernel(const float* __restrict__ x, float* __restrict__ V,
+                                                                   const WinoGeom g, int relu) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    const int Q = g.C >> 2;
+    if (idx >= g.T * Q) return;
+    const int t = fast_div((int)idx, g.dQ);
+    const int cq = (int)idx - t * Q;
+    const int bi = fast_div(t, g.dTw);
+    const int j = t - bi * g.Tw;
+    const int b = fast_div(bi, g.dTh);
+    const int i = bi - b * g.Th;
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 d[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int h = 2 * i - 1 + r;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int w = 2 * j - 1 + c;
+            const bool in = (unsigned)h < (unsigned)g.H && (unsigned)w < (unsigned)g.W;
+            float4 v = in ? ld4(x + (((long)b * g.H + h) * g.W + w) * g.C + 4 * cq) : z;
+            d[r][c] = relu ? relu4(v) : v;
+        }
+    }
+#define F4(op, a, b) make_float4(a.x op b.x, a.y op b.y, a.z op b.z, a.w op b.w)
+    float4 m[4][4];      // rows: B^T d
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        m[0][c] = F4(-, d[0][c], d[2][c]);
+        m[1][c] = F4(+, d[1][c], d[2][c]);
+        m[2][c] = F4(-, d[2][c], d[1][c]);
+        m[3][c] = F4(-, d[1][c], d[3][c]);
+    }
+    float* out = V + (long)t * g.C + 4 * cq;
+    const long ps = g.T * g.C;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {   // columns: (.) B
+        st4(out + (4 * r + 0) * ps, F4(-, m[r][0], m[r][2]));
+        st4(out + (4 * r + 1) * ps, F4(+, m[r][1], m[r][2]));
+        st4(out + (4 * r + 2) * ps, F4(-, m[r][2], m[r][1]));
+        st4(out + (4 * r + 3) * ps, F4(-, m[r][1], m[r][3]));
+    }
+}
+
+// thread = (tile, 4 channels): the tile's 2x2 gradients -> A dY A^T with A = [[1,0],[1,1],[1,-1],[0,-1]]
+__global__ __launch_bounds__(256) void wino_outgrad_transform_kernel(const float* __restrict__ dy, float* __restrict__ dM,
+                                                                     const WinoGeom g) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    const int Q = g.C >> 2;
+    if (idx >= g.T * Q) return;
+    const int t = fast_div((int)idx, g.dQ);
+    const int cq = (int)idx - t * Q;
+    const int bi = fast_div(t, g.dTw);
+    const int j = t - bi * g.Tw;
+    const int b = fast_div(bi, g.dTh);
+    const int i = bi - b * g.Th;
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 y[2][2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int h = 2 * i + r, w = 2 * j + c;
+            y[r][c] = (h < g.H && w < g.W) ? ld4(dy + (((long)b * g.H + h) * g.W + w) * g.C + 4 * cq) : z;
+        }
+    float4 m[4][2];      // rows: A dY
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        m[0][c] = y[0][c];
+        m[1][c] = F4(+, y[0][c], y[1][c]);
+        m[2][c] = F4(-, y[0][c], y[1][c]);
+        m[3][c] = F4(-, z, y[1][c]);
+    }
+    float* out = dM + (long)t * g.C + 4 * cq;
+    const long ps = g.T * g.C;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {   // columns: (.) A^T
+        st4(out + (4 * r + 0) * ps, m[r][0]);
+        st4(out + (4 * r + 1) * ps, F4(+, m[r][0], m[r][1]));
+        st4(out + (4 * r + 2) * ps, F4(-, m[r][0], m[r][1]));
+        st4(out + (4 * r + 3) * ps, F4(-, z, m[r][1]));
+    }
+}
+#undef F4
+
+// dw[co][ci][3][3] = G^T (sum_s slab[p][s][co][ci]) G ;  db[co] = sum_s (column sums of dM_5)
+__global__ void wino_wgrad_reduce_kernel(const float* __restrict__ slab, long stride, long batch_slab, float* __restrict__ dw,
+                                         int Co, int Ci, int S, float* __restrict__ db) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)Co * Ci) {
+        const long m = idx - (long)Co * Ci;
+        if (db && m < Co) {
+            float s = 0.f;
+            for (int k = 0; k < S; ++k) s += slab[5 * batch_slab + (long)k * stride + (long)Co * Ci + m];
+            db[m] = s;
+        }
+        return;
+    }
+    float u[4][4];
+#pragma unroll
+    for (int p = 0; p < 16; ++p) {
+        float s = 0.f;
+        for (int k = 0; k < S; ++k) s += slab[p * batch_slab + (long)k * stride + idx];
+        u[p >> 2][p & 3] = s;
+    }
+    float r[3][4];       // G^T u
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const float hs = 0.5f * (u[1][c] + u[2][c]), hd = 0.5f * (u[1][c] - u[2][c]);
+        r[0][c] = u[0][c] + hs;
+        r[1][c] = hd;
+        r[2][c] = hs + u[3][c];
+    }
+    float* d = dw + idx * 9;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float hs = 0.5f * (r[a][1] + r[a][2]), hd = 0.5f * (r[a][1] - r[a][2]);
+        d[3 * a + 0] = r[a][0] + hs;
+        d[3 * a + 1] = hd;
+        d[3 * a + 2] = hs + r[a][3];
+    }
+}
+
+static long wino_tiles(int B, int H, int W) { return (long)B * ((H + 1) / 2) * ((W + 1) / 2); }
+static bool wino_shape_ok(int B, int H, int W, int Ci, int Cout) {
+    if (B <= 0 || H <= 0 || W <= 0 || Ci < 32 || Cout < 32 || (Ci % 4) || (Cout % 4)) return false;
+    const long T = wino_tiles(B, H, W);
+    const long cmax = Ci > Cout ? Ci : Cout;
+    // thread index and the FastDiv range (n * d < 2^40, quotient < 2^24)
+    return T < (1l << 24) && T * (cmax / 4) < (1l << 31) && T * (cmax / 4) * (cmax / 4) < (1l << 40);
+}
+// workspace layout: [V: 16 T Ci][dM: 16 T Cout][slabs: 16 S (Cout Ci + Cout)]
+extern "C" size_t wesup_conv3x3_wgrad_winograd_workspace_bytes(int B, int H, int W, int Ci, int Cout) {
+    if (!wino_shape_ok(B, H, W, Ci, Cout)) return 0;
+    const long T = wino_tiles(B, H, W);
+    const TnPlan pl = plan_tn(Cout, Ci, (int)T, 1, 16);
+    return align_up((size_t)16 * T * Ci * sizeof(float), 256) + align_up((size_t)16 * T * Cout * sizeof(float), 256) +
+           (size_t)16 * pl.S * tn_slab_stride(Cout, pl.Nslab) * sizeof(float);
+}
+extern "C" int wesup_conv3x3_wgrad_winograd(const float* x, const float* dy, float* dw_kcrs, float* db, int B, int H,
+                                            int W, int Ci, int Cout, int relu_in, void* ws, size_t ws_bytes,
+                                            void* stream) {
+    if (!x || !dy || !dw_kcrs || !ws || !wino_shape_ok(B, H, W, Ci, Cout) ||
+        (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)ws) & 15))
+        return WESUP_ERR_INVALID;
+    if (ws_bytes < wesup_conv3x3_wgrad_winograd_workspace_bytes(B, H, W, Ci, Cout)) return WESUP_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    const long T = wino_tiles(B, H, W);
+    float* V = (float*)ws;
+    float* dM = (float*)((char*)ws + align_up((size_t)16 * T * Ci * sizeof(float), 256));
+    float* slab = (float*)((char*)dM + align_up((size_t)16 * T * Cout * sizeof(float), 256));
+    WinoGeom g;
+    g.H = H; g.W = W; g.Th = (H + 1) / 2; g.Tw = (W + 1) / 2; g.T = T;
+    g.dTw = make_fastdiv(g.Tw); g.dTh = make_fastdiv(g.Th);
+    g.C = Ci; g.dQ = make_fastdiv(Ci / 4);
+    hipLaunchKernelGGL(wino_input_transform_kernel, dim3((unsigned)ceil_div(T * (Ci / 4), 256l)), dim3(256), 0, st, x, V, g,
+                       relu_in);
+    WESUP_CHECK_LAUNCH();
+    g.C = Cout; g.dQ = make_fastdiv(Cout / 4);
+    hipLaunchKernelGGL(wino_outgrad_transform_kernel, dim3((unsigned)ceil_div(T * (Cout / 4), 256l)), dim3(256), 0, st, dy,
+                       dM, g);
+    WESUP_CHECK_LAUNCH();
+    const TnPlan pl = plan_tn(Cout, Ci, (int)T, 1, 16);
+    TnParams p = {};
+    p.A = dM; p.Bx = V; p.slab = slab; p.M = Cout; p.N = Ci; p.K = (int)T; p.lda = Cout; p.ldb = Ci;
+    p.relu_b = 0; p.H = 1; p.W = 1; p.dW = make_fastdiv(1); p.dH = make_fastdiv(1);
+    p.slab_stride = (long)tn_slab_stride(Cout, pl.Nslab); p.want_colsum = db != nullptr; p.colsum_batch = 5;
+    p.batchA = T * Cout; p.batchB = T * Ci; p.batch_slab = (long)pl.S * p.slab_stride;
+    const int rc = launch_tn<0>(p, pl, st, 16);
+    if (rc) return rc;
+    const long tot = (long)Cout * Ci;
+    hipLaunchKernelGGL(wino_wgrad_reduce_kernel, dim3((unsigned)((tot + Cout + 255) / 256)), dim3(256), 0, st,
+                       (const float*)slab, p.slab_stride, p.batch_slab, dw_kcrs, Cout, Ci, pl.S, db);
     WESUP_CHECK_LAUNCH();
     return WESUP_OK;
 }

@@ -82,6 +82,11 @@ class _Bufs:
 
 
 class WesupEngine:
+    # layers whose weight gradient goes through the Winograd domain when wgrad_winograd is on: measured per layer at the
+    # bench shape (tools/wino_table.py) -- faster from 128 -> 256 channels up, slower below (the transformed operands
+    # are 4x the activations and the 64/128-channel GEMMs cannot amortise them)
+    WINOGRAD_MIN_CI, WINOGRAD_MIN_CO = 128, 256
+
     def __init__(self, params, grads, D=32):
         """params/grads: dict name -> tensor (views of the flat parameter / gradient buffers)."""
         self.p = params
@@ -99,6 +104,10 @@ class WesupEngine:
         self.fuse_pool_fwd = True        # skip the (B,HW,2112) feature map: scatter-mean fused with the upsample
         self.matrix_pool = True          # coarse layers: upsample+scatter-mean (and backward) as GEMMs with Wm
         self.two_streams = True          # side branch on its own HIP stream
+        # Weight gradients of the wide layers (conv3_1 ... conv5_3) in the Winograd F(2x2,3x3) domain: 2.25x less MFMA
+        # work in a step that is MFMA-bound, for memory-bound transform passes that run beside the dgrad chain
+        # (alone on the GPU: 3.14 -> 2.11 ms for these nine layers, tools/wino_table.py)
+        self.wgrad_winograd = True
         # side convs of the 64/128-channel layers inside the conv epilogue: correct and tested, OFF by default -- it
         # saves the side stream 0.33 ms of GEMMs that ran beside the chain anyway and puts 5-11 % more work on the conv
         # chain, which is the step's critical path (17.60 -> 17.88 ms)
@@ -543,21 +552,25 @@ class WesupEngine:
             else:
                 x_in = b.yr[l - 1] if b.relu_stored else b.y[l - 1]
             relu_x = l > 0 and not b.relu_stored
+            def wgrad(ws_tag):
+                tok = T.begin('conv3x3_wgrad')
+                dw, db = g[f'backbone.{idx}.weight'], g[f'backbone.{idx}.bias']
+                if self.wgrad_winograd and ci >= self.WINOGRAD_MIN_CI and co >= self.WINOGRAD_MIN_CO:
+                    ops.conv3x3_wgrad_winograd(x_in, b.G[l], relu_in=relu_x, dw=dw, db=db, ws_tag=ws_tag)
+                    # the FLOPs the MFMA pipe executes: 16 positions x (2x2 tiles) instead of 9 taps x pixels
+                    T.end(tok, 2.0 * 16 * B * ((h + 1) // 2) * ((w + 1) // 2) * ci * co)
+                else:
+                    ops.conv3x3_wgrad(x_in, b.G[l], ci, relu_in=relu_x, dw=dw, db=db, ws_tag=ws_tag)
+                    T.end(tok, 2.0 * B * h * w * ci * co * 9)
+                ready([f'backbone.{idx}.weight', f'backbone.{idx}.bias'])
             if not trainable[l]:
                 pass
             elif wg is not None:
                 wg.wait_stream(main)                       # G_l is final here
                 with torch.cuda.stream(wg):
-                    tok = T.begin('conv3x3_wgrad')
-                    ops.conv3x3_wgrad(x_in, b.G[l], ci, relu_in=relu_x, dw=g[f'backbone.{idx}.weight'],
-                                      db=g[f'backbone.{idx}.bias'], ws_tag='wgrad')
-                    T.end(tok, 2.0 * B * h * w * ci * co * 9)
-                    ready([f'backbone.{idx}.weight', f'backbone.{idx}.bias'])
+                    wgrad('wgrad')
             else:
-                tok = T.begin('conv3x3_wgrad')
-                ops.conv3x3_wgrad(x_in, b.G[l], ci, relu_in=relu_x, dw=g[f'backbone.{idx}.weight'], db=g[f'backbone.{idx}.bias'])
-                T.end(tok, 2.0 * B * h * w * ci * co * 9)
-                ready([f'backbone.{idx}.weight', f'backbone.{idx}.bias'])
+                wgrad('default')
             if l > lowest:
                 if g_ready[l - 1] is not None:
                     main.wait_event(g_ready[l - 1])

@@ -203,6 +203,27 @@ def conv3x3_wgrad(x, dy, Ci, relu_in, dw=None, db=None, ws_tag='default'):
     return dw, db
 
 
+def conv3x3_wgrad_winograd(x, dy, relu_in, dw=None, db=None, ws_tag='default'):
+    """The same (dw, db) as conv3x3_wgrad through the Winograd F(2x2,3x3) domain: 2.25x fewer multiply-adds, 4x the
+    operand bytes; for the wide layers (Ci, Cout >= 128)."""
+    _chk(x, name='x'); _chk(dy, name='dy')
+    B, H, W, Ci = x.shape
+    Cout = dy.shape[3]
+    assert dy.shape[:3] == (B, H, W)
+    if dw is None:
+        dw = torch.empty(Cout, Ci, 3, 3, dtype=torch.float32, device=x.device)
+    if db is None:
+        db = torch.empty(Cout, dtype=torch.float32, device=x.device)
+    assert dw.is_contiguous() and dw.numel() == Cout * Ci * 9 and db.numel() == Cout
+    nb = _lib.load().wesup_conv3x3_wgrad_winograd_workspace_bytes(B, H, W, Ci, Cout)
+    if not nb:
+        raise _lib.WesupHipError(f'conv3x3_wgrad_winograd: unsupported shape {(B, H, W, Ci, Cout)}')
+    ws = workspace(nb, x.device, ws_tag)
+    _lib.call('wesup_conv3x3_wgrad_winograd', _p(x), _p(dy), _p(dw), _p(db), B, H, W, Ci, Cout, int(relu_in), _p(ws), nb,
+              _stream())
+    return dw, db
+
+
 # ---------------------------------------------------------------- GEMMs
 def _ld(t):
     assert t.dim() == 2 and t.stride(1) == 1
