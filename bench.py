@@ -51,10 +51,12 @@ def parse_args(argv=None):
                                                   "'gemm', or 'all'); default: none (the step runs plain tiling, ops.py)")
     ap.add_argument('--side-fusion', action='store_true', help='A/B: side convs of the 64/128-channel layers in the conv '
                                                                'epilogue instead of as GEMMs on the side stream')
+    ap.add_argument('--direct-conv', action='store_true', help='A/B: forward and input gradient of every conv layer with '
+                                                               'the direct implicit-GEMM kernel (no Winograd-domain conv)')
     ap.add_argument('--direct-wgrad', action='store_true', help='A/B: every conv weight gradient with the direct '
                                                                 'implicit-GEMM kernel (no Winograd-domain wgrad)')
     ap.add_argument('--event-every', type=int, default=4, help='steps of the timed region that carry HIP events: every n-th')
-    ap.add_argument('--timed-classes', default='conv3x3_fwd,conv3x3_dgrad',
+    ap.add_argument('--timed-classes', default='conv3x3_fwd,conv3x3_dgrad,winograd_gemm',
                     help="kernel classes that get HIP events inside the timed region ('all', 'none' or a comma list); an "
                          "event record fences its queue, so only the dominant kernel is timed there by default and the "
                          "other classes are timed in extra untimed steps")
@@ -241,6 +243,7 @@ def worker(args):
     trainer.model.engine.fuse_pool_bwd = not args.unfused_pool_bwd
     trainer.model.engine.fuse_side_fwd = args.side_fusion
     trainer.model.engine.wgrad_winograd = not args.direct_wgrad
+    trainer.model.engine.conv_winograd = not args.direct_conv
     if use_dist and args.ddp_probe != 'pg':
         trainer.enable_data_parallel(bucket_bytes=args.bucket_mb << 20)
 
@@ -350,17 +353,22 @@ def worker(args):
             for tag, (ms, n, work) in sorted(allk.items()):
                 kern[tag] = {'ms_per_step': round(ms / n_extra, 4), 'launches_per_step': n / n_extra,
                              'avg_us': round(ms / n * 1e3, 2)}
-                if tag.startswith('conv3x3') or tag in ('side_fwd', 'side_bwd', 'mlp_fwd', 'mlp_bwd', 'mlp_wgrad', 'sp_pool_mat_fwd', 'upsample_mat_bwd'):
+                if tag.startswith('conv3x3') or tag in ('winograd_gemm', 'side_fwd', 'side_bwd', 'mlp_fwd', 'mlp_bwd', 'mlp_wgrad', 'sp_pool_mat_fwd', 'upsample_mat_bwd'):
                     kern[tag]['tflops'] = round(work / (ms * 1e-3) / 1e12, 2)
                 elif work > 0:
                     kern[tag]['gbs'] = round(work / (ms * 1e-3) / 1e9, 1)
-            # dominant kernel: the implicit-GEMM 3x3 convolution (forward + dgrad share gemm_nt_kernel<..,1>)
-            ms = sum(tot[t][0] for t in ('conv3x3_fwd', 'conv3x3_dgrad') if t in tot)
-            fl = sum(tot[t][2] for t in ('conv3x3_fwd', 'conv3x3_dgrad') if t in tot)
-            nl = sum(tot[t][1] for t in ('conv3x3_fwd', 'conv3x3_dgrad') if t in tot)
+            # dominant kernel: gemm_nt_kernel, the GEMM of every conv forward and input gradient -- the implicit-GEMM form
+            # (MODE 1/2) for the 3/64-channel layers, the 16-position batched form (MODE 3) over Winograd-domain operands
+            # for the layers with >= 128 input channels.  FLOPs = what the MFMA pipe executes (the Winograd form needs
+            # 4/9 of the direct form's).
+            conv_tags = ('conv3x3_fwd', 'conv3x3_dgrad', 'winograd_gemm')
+            ms = sum(tot[t][0] for t in conv_tags if t in tot)
+            fl = sum(tot[t][2] for t in conv_tags if t in tot)
+            nl = sum(tot[t][1] for t in conv_tags if t in tot)
             ach = fl / (ms * 1e-3) / 1e12
             conv_in = (rin or {}).get('conv3x3_fwd_dgrad', {})
-            out['roofline'] = {'bound': 'mfma', 'kernel': 'gemm_nt_kernel (conv3x3 implicit GEMM fwd+dgrad, fp32 MFMA 32x32x2)',
+            out['roofline'] = {'bound': 'mfma', 'kernel': 'gemm_nt_kernel (conv3x3 fwd+dgrad GEMMs: implicit GEMM for conv1_1..conv2_1, '
+                                                          'batched Winograd-domain GEMMs for conv2_2..conv5_3; fp32 MFMA 32x32x2)',
                                'achieved': round(ach, 2), 'peak': PEAK_MFMA_F32_TFLOPS, 'unit': 'TFLOP/s',
                                'frac': round(ach / PEAK_MFMA_F32_TFLOPS, 4),
                                'traffic': conv_in.get('hbm_bytes_per_launch'),
@@ -383,13 +391,13 @@ def worker(args):
                 if wg_in:
                     out['roofline_wgrad']['traffic'] = wg_in.get('hbm_bytes_per_launch')
                     out['roofline_wgrad']['mfma_pipe_busy_frac'] = wg_in.get('mfma_busy_frac')
-            out['roofline']['note'] = (f'HIP events on the launch stream around every conv3x3 fwd/dgrad launch of {n_ev} of the '
+            out['roofline']['note'] = (f'HIP events on the launch stream around every conv fwd/dgrad GEMM launch of {n_ev} of the '
                                        f'{args.steps} timed steps; the side-branch and wgrad streams run concurrently '
                                        '(roofline_isolated has the same kernels alone on the GPU)')
             out['kernels'] = kern
             # whole-step view of the matrix cores: every GEMM-shaped FLOP of the step (conv fwd/dgrad/wgrad, side convs,
             # MLP, matrix pooling of the deep layers) over the wall time of the step, all streams together
-            gemm_tags = ('conv3x3_fwd', 'conv3x3_dgrad', 'conv3x3_wgrad', 'side_fwd', 'side_bwd', 'mlp_fwd', 'mlp_bwd', 'mlp_wgrad',
+            gemm_tags = ('conv3x3_fwd', 'conv3x3_dgrad', 'winograd_gemm', 'conv3x3_wgrad', 'side_fwd', 'side_bwd', 'mlp_fwd', 'mlp_bwd', 'mlp_wgrad',
                          'sp_pool_mat_fwd', 'upsample_mat_bwd')
             fl_step = sum(allk[t][2] for t in gemm_tags if t in allk) / n_extra
             a = fl_step / (ms_per_step * 1e-3) / 1e12
@@ -403,7 +411,7 @@ def worker(args):
                     ms = sum(iso[t][0] for t in tags if t in iso)
                     fl = sum(iso[t][2] for t in tags if t in iso)
                     return round(fl / (ms * 1e-3) / 1e12, 2) if ms > 0 else None
-                a, wgr = tf(('conv3x3_fwd', 'conv3x3_dgrad')), tf(('conv3x3_wgrad',))
+                a, wgr = tf(('conv3x3_fwd', 'conv3x3_dgrad', 'winograd_gemm')), tf(('conv3x3_wgrad',))
                 out['roofline_isolated'] = {
                     'how': '2 extra untimed steps with single-stream scheduling and the stream-K tail on (what a kernel alone on the GPU '
                            'gains from; the 3-stream step runs plain tiling, wesup_amd/ops.py), HIP events per launch',

@@ -109,9 +109,36 @@ int wesup_conv3x3_wgrad(const float* x, const float* dy, float* dw_kcrs, float* 
  * G^T (.) G maps it back to 3x3.  2.25x fewer multiply-adds than the direct form; same result up to fp32 summation
  * order.  Ci, Cout multiples of 4, >= 32 (meant for the 256/512-channel layers); x has Ci channels. */
 size_t wesup_conv3x3_wgrad_winograd_workspace_bytes(int B, int H, int W, int Ci, int Cout);
-int wesup_conv3x3_wgrad_winograd(const float* x, const float* dy, float* dw_kcrs, float* db,
+/* v_pre (optional): the transformed input [16][tiles][Ci] kept by wesup_conv3x3_fwd_winograd of the same layer; then x
+ * may be NULL and its transform pass is skipped. */
+int wesup_conv3x3_wgrad_winograd(const float* x, const float* v_pre, const float* dy, float* dw_kcrs, float* db,
                                  int B, int H, int W, int Ci, int Cout, int relu_in,
                                  void* ws, size_t ws_bytes, void* stream);
+/* Forward and input gradient of the deep layers in the same domain:  V = B^T d B per 4x4 input patch, 16 batched NT
+ * GEMMs M_p = V_p . U_p^T (one launch), Y = A^T M A + the epilogue of wesup_conv3x3_fwd / _dgrad (bias, second ReLU'd
+ * output / ReLU mask, accumulate).  U = G g G^T comes from wesup_winograd_pack_weight (once per step):
+ * u_fwd [16][Cout][Cin], u_dgrad [16][Cin][Cout] (rotated filter), 16*Cin*Cout floats each.  Workspace: transformed
+ * input + transformed output, 16 x tiles x (Cin + Cout) floats (dgrad: ask with the channel counts swapped).
+ * v_keep (optional): where the forward leaves V for the weight gradient (16 x tiles x Cin floats).
+ * Cin % 32 == 0, Cout % 4 == 0; the results equal the direct kernels' up to fp32 summation order. */
+size_t wesup_winograd_weight_floats(int Cin, int Cout);
+int wesup_winograd_pack_weight(const float* w_kcrs, float* u_fwd, float* u_dgrad, int Cout, int Cin, void* stream);
+size_t wesup_conv3x3_winograd_workspace_bytes(int B, int H, int W, int Cin, int Cout);
+int wesup_conv3x3_fwd_winograd(const float* x, const float* u_fwd, const float* bias, float* y, float* y_relu,
+                               float* v_keep, int B, int H, int W, int Cin, int Cout, int relu_in,
+                               void* ws, size_t ws_bytes, void* stream);
+int wesup_conv3x3_dgrad_winograd(const float* dy, const float* u_dgrad, const float* mask_src, float* dx,
+                                 int B, int H, int W, int Cin, int Cout, int accumulate,
+                                 void* ws, size_t ws_bytes, void* stream);
+/* The three passes on their own (the two entries above chain them): x (B,H,W,C) -> V [16][tiles][C];
+ * nbatch NT products of one shape in one launch, C_b = A_b . B_b^T (element strides between the entries; K % 32 == 0);
+ * Mt [16][tiles][C] -> y = A^T M A + bias, masked by mask_src > 0, added to the old y if accumulate, with the optional
+ * second output y_relu = max(y, 0).  tiles = B * ceil(H/2) * ceil(W/2). */
+int wesup_winograd_input_transform(const float* x, float* V, int B, int H, int W, int C, int relu_in, void* stream);
+int wesup_gemm_nt_batched(const float* A, int lda, long strideA, const float* B, int ldb, long strideB,
+                          float* C, int ldc, long strideC, int nbatch, int M, int N, int K, void* stream);
+int wesup_winograd_output_transform(const float* Mt, const float* bias, const float* mask_src, float* y, float* y_relu,
+                                    int B, int H, int W, int C, int accumulate, void* stream);
 
 /* ------------------------------------------------------------------ generic fp32 MFMA GEMMs
  * side 1x1 convs (models/wesup.py:208-209,253), fc_layers (models/wesup.py:213-220,288) and their grads.

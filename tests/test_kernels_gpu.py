@@ -160,6 +160,67 @@ def test_conv3x3_wgrad_winograd(ops, B, H, W, Cin, Cout, relu_in):
     assert torch.equal(dw, dw2) and torch.equal(db, db2)
 
 
+WINO_CASES = [(1, 12, 10, 32, 32), (2, 37, 41, 64, 128), (1, 30, 30, 256, 256), (2, 60, 60, 256, 512), (3, 15, 15, 512, 512),
+              (1, 7, 9, 512, 256), (1, 1, 1, 32, 64), (4, 30, 30, 512, 512)]
+
+
+@pytest.mark.parametrize('B,H,W,Cin,Cout', WINO_CASES)
+@pytest.mark.parametrize('relu_in', [False, True])
+def test_conv3x3_fwd_winograd(ops, B, H, W, Cin, Cout, relu_in):
+    """Forward through the Winograd domain = Conv2d(k=3, pad=1) to fp32 noise (odd sizes, one-pixel image, one full
+    round of tiles), second ReLU'd output exact, the kept transformed input serves the Winograd weight gradient."""
+    d = dev()
+    x = rnd(B, Cin, H, W, seed=1)
+    w = rnd(Cout, Cin, 3, 3, seed=2, scale=(2.0 / (9 * Cin)) ** 0.5)
+    b = rnd(Cout, seed=3, scale=0.1)
+    ref = F.conv2d((F.relu(x) if relu_in else x).double(), w.double(), b.double(), padding=1)
+    xg = nhwc(x).to(d)
+    uf, ud = ops.winograd_pack_weight(w.to(d))
+    assert ud.shape == (16, Cin, Cout)
+    T = ops.winograd_tiles(B, H, W)
+    v_keep = torch.empty(16, T, Cin, device=d)
+    y = torch.empty(B, H, W, Cout, device=d)
+    yr = torch.empty_like(y)
+    ops.conv3x3_fwd_winograd(xg, uf, b.to(d), relu_in, out=y, out_relu=yr, v_keep=v_keep)
+    wf, _ = ops.pack_conv3x3_weight(w.to(d), need_dgrad=False)
+    y0 = ops.conv3x3_fwd(xg, wf, b.to(d), Cout, relu_in)
+    e_w, e_0 = rel_err(nchw(y), ref), rel_err(nchw(y0), ref)
+    assert e_w < max(TOL / 10, 4 * e_0), (e_w, e_0)
+    assert torch.equal(yr, torch.relu(y))
+    y2 = ops.conv3x3_fwd_winograd(xg, uf, None, relu_in)                       # no bias, workspace V
+    assert rel_err(nchw(y2), ref - b.double().view(1, -1, 1, 1)) < max(TOL / 10, 4 * e_0)
+    dy = rnd(B, Cout, H, W, seed=4)
+    dyg = nhwc(dy).to(d)
+    dw1, db1 = ops.conv3x3_wgrad_winograd(xg, dyg, relu_in, v_pre=v_keep)
+    dw2, db2 = ops.conv3x3_wgrad_winograd(xg, dyg, relu_in)
+    assert torch.equal(dw1, dw2) and torch.equal(db1, db2)
+
+
+@pytest.mark.parametrize('B,H,W,Cin,Cout', WINO_CASES)
+def test_conv3x3_dgrad_winograd(ops, B, H, W, Cin, Cout):
+    d = dev()
+    x = rnd(B, Cin, H, W, seed=1).requires_grad_(True)
+    w = rnd(Cout, Cin, 3, 3, seed=2, scale=(2.0 / (9 * Cin)) ** 0.5)
+    dy = rnd(B, Cout, H, W, seed=4)
+    F.conv2d(F.relu(x).double(), w.double(), None, padding=1).backward(dy.double())
+    ref = x.grad.double()                                  # includes the ReLU mask (x > 0)
+    _, ud = ops.winograd_pack_weight(w.to(d), need_fwd=False)
+    _, wd = ops.pack_conv3x3_weight(w.to(d))
+    base = rnd(B, H, W, Cin, seed=5)
+    out = base.clone().to(d)
+    mask = nhwc(x.detach()).to(d)
+    ops.conv3x3_dgrad_winograd(nhwc(dy).to(d), ud, mask_src=mask, out=out, accumulate=True)
+    out0 = base.clone().to(d)
+    ops.conv3x3_dgrad(nhwc(dy).to(d), wd, Cin, mask_src=mask, out=out0, accumulate=True)
+    e_w, e_0 = rel_err(nchw(out.cpu() - base), ref), rel_err(nchw(out0.cpu() - base), ref)
+    assert e_w < max(TOL / 10, 4 * e_0), (e_w, e_0)
+    # plain (no mask, no accumulate)
+    x2 = rnd(B, Cin, H, W, seed=1).requires_grad_(True)
+    F.conv2d(x2.double(), w.double(), None, padding=1).backward(dy.double())
+    out2 = ops.conv3x3_dgrad_winograd(nhwc(dy).to(d), ud)
+    assert rel_err(nchw(out2), x2.grad) < TOL / 10
+
+
 @pytest.mark.parametrize('B,H,W,Cin,Cout', [c for c in CONV_CASES if c[3] != 3])
 def test_conv3x3_dgrad(ops, B, H, W, Cin, Cout):
     d = dev()

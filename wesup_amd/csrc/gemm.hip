@@ -100,6 +100,10 @@ struct NtParams {
     int sk_parts;        // stream-K blocks behind them (0: none) ...
     int sk_steps;        // ... sharing this many K-steps of the remaining tiles
     float* sk_ws;        // [sk_parts][2][BM*BN] partial tiles
+    // batched plain GEMMs (MODE 0, no stream-K): nbatch products of one shape in one launch; tile ids run batch-major
+    int nbatch;              // 0 / 1: a single product
+    FastDiv dTiles;          // tiles per product
+    long batchA, batchB, batchC;   // element strides between the products' operands
     // fused 1x1 side conv (SIDE instantiations, N == BN, no stream-K): side_out[m][0..N/2) = C[m][:] . side_w^T + side_bias
     const float* side_w;     // [N/2][N] row-major
     const float* side_bias;  // [N/2] or NULL
@@ -110,7 +114,7 @@ struct NtParams {
 // ---------------------------------------------------------------------------------------------
 // NT kernel:  C[M][N] = A[M][K] * Bw[N][K]^T   with A either a plain row-major matrix or the implicit
 // im2col view of an NHWC tensor under a 3x3/pad-1 window (K order = (32-channel chunk, tap, channel in chunk)).
-// MODE 0: plain; 1: conv3x3 with Cin % 32 == 0; 2: conv3x3 with Cin == 4 (image layer, K padded to 64).
+// MODE 0: plain; 1: conv3x3 with Cin % 32 == 0; 2: conv3x3 with Cin == 4 (image layer, K padded to 64); 3: plain, batched.
 // LDS image of both operands: [row][32 floats], chunk c of row r stored at chunk position c ^ ((r>>1)&7).
 // A lane's fragments for 4 consecutive MFMA k-steps are ONE ds_read_b128; MFMA t of a group uses element t of the
 // A and the B fragment: lanes 0-31 then carry k = 8g+t, lanes 32-63 k = 8g+4+t (any consistent k order is fine).
@@ -170,6 +174,12 @@ __global__ __launch_bounds__(NW * 64, MINB) void gemm_nt_kernel(const NtParams p
     }
     // n fastest: the N-tiles of one pixel tile run together and share the activation rows through their XCD's L2
     // (the m-fastest order, which keeps a weight slab in L2 instead, measured within 1 %)
+    long zA = 0, zB = 0, zC = 0;
+    if (MODE == 3) {      // batched plain GEMMs: an instantiation of its own (and a kernel name of its own in profiles)
+        const int z = fast_div(lt, p.dTiles);
+        lt -= z * p.tiles_m * p.tiles_n;
+        zA = z * p.batchA; zB = z * p.batchB; zC = z * p.batchC;
+    }
     const int tile_n = lt % p.tiles_n, tile_m = lt / p.tiles_n;
     const int m_blk = tile_m * BM, n_blk = tile_n * BN;
 
@@ -179,12 +189,13 @@ __global__ __launch_bounds__(NW * 64, MINB) void gemm_nt_kernel(const NtParams p
     long a_off[RA];
     unsigned a_msk[RA], a_vo[RA], b_vo[RB];
     const int margin = (MODE == 1) ? (p.W + 1) * p.Cin : 0;
-    const float* a_base = (MODE == 0) ? p.A + (long)m_blk * p.lda : p.A + ((long)m_blk * p.Cin - margin);
-    const i32x4 srdA = make_srd(a_base), srdB = make_srd(p.Bw + (long)n_blk * p.ldb);
+    constexpr bool PLAIN = (MODE == 0 || MODE == 3);
+    const float* a_base = PLAIN ? p.A + zA + (long)m_blk * p.lda : p.A + ((long)m_blk * p.Cin - margin);
+    const i32x4 srdA = make_srd(a_base), srdB = make_srd(p.Bw + zB + (long)n_blk * p.ldb);
 #pragma unroll
     for (int i = 0; i < RA; ++i) {
         const int m = m_blk + srow + PR * i;
-        if (MODE == 0) {
+        if (PLAIN) {
             a_vo[i] = (m < p.M) ? (unsigned)(((srow + PR * i) * p.lda + 4 * schunk) * 4) : WESUP_OOB;
             a_msk[i] = 0; a_off[i] = 0;
         } else {
@@ -217,7 +228,7 @@ __global__ __launch_bounds__(NW * 64, MINB) void gemm_nt_kernel(const NtParams p
 #pragma unroll
         for (int i = 0; i < RA; ++i) {
             if (i != q) continue;
-            if (MODE == 0) {
+            if (PLAIN) {
                 bglds16(a_vo[i], srdA, (unsigned)(kk * BK * 4), adst);
             } else if (MODE == 1) {
                 // K order = (32-channel chunk, tap, channel in chunk): the 9 taps of one chunk are consecutive K-steps,
@@ -403,7 +414,7 @@ __global__ __launch_bounds__(NW * 64, MINB) void gemm_nt_kernel(const NtParams p
                     v.z = mk.z > 0.f ? v.z : 0.f;
                     v.w = mk.w > 0.f ? v.w : 0.f;
                 }
-                float* c = p.C + (long)m * p.ldc + n;
+                float* c = p.C + zC + (long)m * p.ldc + n;
                 if (accum) {
                     const float4 o = ld4(c);
                     v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
@@ -551,7 +562,8 @@ template <int NW, int BM, int BN, int WM, int WN, int MODE, int MINB, bool RELU,
 static int launch_nt(NtParams p, hipStream_t st, const SkPlan* sk = nullptr, void* ws = nullptr) {
     p.tiles_m = ceil_div(p.M, BM);
     p.tiles_n = ceil_div(p.N, BN);
-    p.full_tiles = p.tiles_m * p.tiles_n;
+    p.full_tiles = p.tiles_m * p.tiles_n * (p.nbatch > 1 ? p.nbatch : 1);
+    p.dTiles = make_fastdiv(p.tiles_m * p.tiles_n);
     p.sk_parts = 0; p.sk_steps = 0; p.sk_ws = nullptr;
     if (sk && sk->parts > 0) {
         p.full_tiles = sk->full; p.sk_parts = sk->parts; p.sk_steps = sk->steps; p.sk_ws = (float*)ws;
@@ -1477,11 +1489,11 @@ extern "C" size_t wesup_conv3x3_wgrad_winograd_workspace_bytes(int B, int H, int
     return align_up((size_t)16 * T * Ci * sizeof(float), 256) + align_up((size_t)16 * T * Cout * sizeof(float), 256) +
            (size_t)16 * pl.S * tn_slab_stride(Cout, pl.Nslab) * sizeof(float);
 }
-extern "C" int wesup_conv3x3_wgrad_winograd(const float* x, const float* dy, float* dw_kcrs, float* db, int B, int H,
-                                            int W, int Ci, int Cout, int relu_in, void* ws, size_t ws_bytes,
-                                            void* stream) {
-    if (!x || !dy || !dw_kcrs || !ws || !wino_shape_ok(B, H, W, Ci, Cout) ||
-        (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)ws) & 15))
+extern "C" int wesup_conv3x3_wgrad_winograd(const float* x, const float* v_pre, const float* dy, float* dw_kcrs, float* db,
+                                            int B, int H, int W, int Ci, int Cout, int relu_in, void* ws,
+                                            size_t ws_bytes, void* stream) {
+    if ((!x && !v_pre) || !dy || !dw_kcrs || !ws || !wino_shape_ok(B, H, W, Ci, Cout) ||
+        (((uintptr_t)x | (uintptr_t)v_pre | (uintptr_t)dy | (uintptr_t)ws) & 15))
         return WESUP_ERR_INVALID;
     if (ws_bytes < wesup_conv3x3_wgrad_winograd_workspace_bytes(B, H, W, Ci, Cout)) return WESUP_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
@@ -1493,9 +1505,13 @@ extern "C" int wesup_conv3x3_wgrad_winograd(const float* x, const float* dy, flo
     g.H = H; g.W = W; g.Th = (H + 1) / 2; g.Tw = (W + 1) / 2; g.T = T;
     g.dTw = make_fastdiv(g.Tw); g.dTh = make_fastdiv(g.Th);
     g.C = Ci; g.dQ = make_fastdiv(Ci / 4);
-    hipLaunchKernelGGL(wino_input_transform_kernel, dim3((unsigned)ceil_div(T * (Ci / 4), 256l)), dim3(256), 0, st, x, V, g,
-                       relu_in);
-    WESUP_CHECK_LAUNCH();
+    if (v_pre) {             // the transformed input the Winograd forward of this layer kept
+        V = const_cast<float*>(v_pre);
+    } else {
+        hipLaunchKernelGGL(wino_input_transform_kernel, dim3((unsigned)ceil_div(T * (Ci / 4), 256l)), dim3(256), 0, st, x, V,
+                           g, relu_in);
+        WESUP_CHECK_LAUNCH();
+    }
     g.C = Cout; g.dQ = make_fastdiv(Cout / 4);
     hipLaunchKernelGGL(wino_outgrad_transform_kernel, dim3((unsigned)ceil_div(T * (Cout / 4), 256l)), dim3(256), 0, st, dy,
                        dM, g);
@@ -1513,4 +1529,214 @@ extern "C" int wesup_conv3x3_wgrad_winograd(const float* x, const float* dy, flo
                        (const float*)slab, p.slab_stride, p.batch_slab, dw_kcrs, Cout, Ci, pl.S, db);
     WESUP_CHECK_LAUNCH();
     return WESUP_OK;
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// conv3x3 forward / input gradient in the Winograd F(2x2, 3x3) domain for the deep layers (256/512 channels at
+// 120^2 and below), where the channel counts make the 16 per-position GEMMs (tiles x Cin) . (Cout x Cin)^T efficient
+// and the 4x larger transformed tensors small:   V = B^T d B  ->  M_p = V_p . U_p^T  ->  Y = A^T M A (+ epilogue).
+// U = G g G^T per (co, ci) is re-derived from the weights once per step (pack kernel below); the input gradient is
+// the same pipeline over dy with the filter rotated by 180 degrees and its channel roles swapped.
+// ---------------------------------------------------------------------------------------------
+// mode 0: U[p][co][ci] (forward);  mode 1: Ud[p][ci][co] from the rotated filter (dgrad).  thread = one (row, col)
+// of the output matrix, col fastest (coalesced stores)
+__global__ void wino_weight_transform_kernel(const float* __restrict__ w, float* __restrict__ U, int Co, int Ci, int mode) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)Co * Ci) return;
+    int co, ci;
+    if (mode == 0) { co = idx / Ci; ci = idx - (long)co * Ci; }
+    else { ci = idx / Co; co = idx - (long)ci * Co; }
+    const float* gsrc = w + ((long)co * Ci + ci) * 9;
+    float g[3][3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) g[a][b] = mode == 0 ? gsrc[3 * a + b] : gsrc[8 - (3 * a + b)];
+    float r[4][3];       // G g
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+        const float hs = 0.5f * (g[0][b] + g[2][b]), hm = 0.5f * g[1][b];
+        r[0][b] = g[0][b];
+        r[1][b] = hs + hm;
+        r[2][b] = hs - hm;
+        r[3][b] = g[2][b];
+    }
+    const long ps = (long)Co * Ci;
+    float* out = U + idx;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {   // (.) G^T
+        const float hs = 0.5f * (r[a][0] + r[a][2]), hm = 0.5f * r[a][1];
+        out[(4 * a + 0) * ps] = r[a][0];
+        out[(4 * a + 1) * ps] = hs + hm;
+        out[(4 * a + 2) * ps] = hs - hm;
+        out[(4 * a + 3) * ps] = r[a][2];
+    }
+}
+
+// thread = (tile, 4 channels): Y = A^T M A for the tile's 2x2 outputs, then the conv epilogue (bias / mask /
+// accumulate / second ReLU'd output) on the pixels inside the image
+__global__ __launch_bounds__(256) void wino_output_transform_kernel(const float* __restrict__ Mt, const float* __restrict__ bias,
+                                                                    const float* __restrict__ mask, float* __restrict__ y,
+                                                                    float* __restrict__ y_relu, const WinoGeom g, int accum) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    const int Q = g.C >> 2;
+    if (idx >= g.T * Q) return;
+    const int t = fast_div((int)idx, g.dQ);
+    const int cq = (int)idx - t * Q;
+    const int bi = fast_div(t, g.dTw);
+    const int j = t - bi * g.Tw;
+    const int b = fast_div(bi, g.dTh);
+    const int i = bi - b * g.Th;
+    const float* src = Mt + (long)t * g.C + 4 * cq;
+    const long ps = g.T * g.C;
+#define F4(op, a, b) make_float4(a.x op b.x, a.y op b.y, a.z op b.z, a.w op b.w)
+    float4 s[2][4];      // rows: A^T m
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const float4 m0 = ld4(src + (0 + c) * ps), m1 = ld4(src + (4 + c) * ps), m2 = ld4(src + (8 + c) * ps),
+                     m3 = ld4(src + (12 + c) * ps);
+        const float4 t12 = F4(+, m1, m2), d12 = F4(-, m1, m2);
+        s[0][c] = F4(+, m0, t12);
+        s[1][c] = F4(-, d12, m3);
+    }
+    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (bias) bv = ld4(bias + 4 * cq);
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int h = 2 * i + r;
+        if (h >= g.H) break;
+        const float4 t12 = F4(+, s[r][1], s[r][2]), d12 = F4(-, s[r][1], s[r][2]);
+        float4 o[2];
+        o[0] = F4(+, s[r][0], t12);
+        o[1] = F4(-, d12, s[r][3]);
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int w = 2 * j + c;
+            if (w >= g.W) break;
+            const long off = (((long)b * g.H + h) * g.W + w) * g.C + 4 * cq;
+            float4 v = F4(+, o[c], bv);
+            if (mask) {
+                const float4 mk = ld4(mask + off);
+                v.x = mk.x > 0.f ? v.x : 0.f; v.y = mk.y > 0.f ? v.y : 0.f;
+                v.z = mk.z > 0.f ? v.z : 0.f; v.w = mk.w > 0.f ? v.w : 0.f;
+            }
+            if (accum) {
+                const float4 old = ld4(y + off);
+                v = F4(+, v, old);
+            }
+            st4(y + off, v);
+            if (y_relu) st4(y_relu + off, relu4(v));
+        }
+    }
+#undef F4
+}
+
+extern "C" size_t wesup_winograd_weight_floats(int Cin, int Cout) { return (size_t)16 * Cin * Cout; }
+
+// w (Cout,Cin,3,3) -> u_fwd [16][Cout][Cin] and/or u_dgrad [16][Cin][Cout] (either may be NULL)
+extern "C" int wesup_winograd_pack_weight(const float* w, float* u_fwd, float* u_dgrad, int Cout, int Cin, void* stream) {
+    if (!w || Cout <= 0 || Cin <= 0 || (!u_fwd && !u_dgrad)) return WESUP_ERR_INVALID;
+    const long tot = (long)Cout * Cin;
+    hipStream_t st = (hipStream_t)stream;
+    if (u_fwd) {
+        hipLaunchKernelGGL(wino_weight_transform_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, w, u_fwd, Cout,
+                           Cin, 0);
+        WESUP_CHECK_LAUNCH();
+    }
+    if (u_dgrad) {
+        hipLaunchKernelGGL(wino_weight_transform_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, w, u_dgrad, Cout,
+                           Cin, 1);
+        WESUP_CHECK_LAUNCH();
+    }
+    return WESUP_OK;
+}
+
+// workspace of one forward / dgrad call: [V: 16 T Cin][M: 16 T Cout] (for dgrad ask with the channel counts swapped)
+extern "C" size_t wesup_conv3x3_winograd_workspace_bytes(int B, int H, int W, int Cin, int Cout) {
+    if (!wino_shape_ok(B, H, W, Cin, Cout) || (Cin % 32)) return 0;
+    const long T = wino_tiles(B, H, W);
+    return align_up((size_t)16 * T * Cin * sizeof(float), 256) + align_up((size_t)16 * T * Cout * sizeof(float), 256);
+}
+
+static WinoGeom wino_geom(int B, int H, int W, int C) {
+    WinoGeom g;
+    g.H = H; g.W = W; g.Th = (H + 1) / 2; g.Tw = (W + 1) / 2; g.T = wino_tiles(B, H, W);
+    g.dTw = make_fastdiv(g.Tw); g.dTh = make_fastdiv(g.Th);
+    g.C = C; g.dQ = make_fastdiv(C / 4);
+    return g;
+}
+
+// ---- the three passes as entries of their own (the engine calls these, so that the GEMM can be timed apart from the
+// memory-bound transforms); wesup_conv3x3_fwd_winograd / _dgrad_winograd below chain them.
+// x (B,H,W,C) -> V [16][tiles][C]
+extern "C" int wesup_winograd_input_transform(const float* x, float* V, int B, int H, int W, int C, int relu_in, void* stream) {
+    if (!x || !V || !wino_shape_ok(B, H, W, C, C) || (((uintptr_t)x | (uintptr_t)V) & 15)) return WESUP_ERR_INVALID;
+    const WinoGeom g = wino_geom(B, H, W, C);
+    hipLaunchKernelGGL(wino_input_transform_kernel, dim3((unsigned)ceil_div(g.T * (C / 4), 256l)), dim3(256), 0,
+                       (hipStream_t)stream, x, V, g, relu_in);
+    WESUP_CHECK_LAUNCH();
+    return WESUP_OK;
+}
+// Mt [16][tiles][C] -> y (B,H,W,C) = A^T M A + bias, masked by mask_src > 0, added to the old y if accumulate;
+// y_relu: optional second output max(y, 0)
+extern "C" int wesup_winograd_output_transform(const float* Mt, const float* bias, const float* mask_src, float* y,
+                                               float* y_relu, int B, int H, int W, int C, int accumulate, void* stream) {
+    if (!Mt || !y || !wino_shape_ok(B, H, W, C, C) ||
+        (((uintptr_t)Mt | (uintptr_t)y | (uintptr_t)y_relu | (uintptr_t)mask_src | (uintptr_t)bias) & 15))
+        return WESUP_ERR_INVALID;
+    const WinoGeom g = wino_geom(B, H, W, C);
+    hipLaunchKernelGGL(wino_output_transform_kernel, dim3((unsigned)ceil_div(g.T * (C / 4), 256l)), dim3(256), 0,
+                       (hipStream_t)stream, Mt, bias, mask_src, y, y_relu, g, accumulate);
+    WESUP_CHECK_LAUNCH();
+    return WESUP_OK;
+}
+// nbatch products C_b[M][N] = A_b[M][K] . B_b[N][K]^T of one shape in one launch (element strides between the entries)
+extern "C" int wesup_gemm_nt_batched(const float* A, int lda, long strideA, const float* Bw, int ldb, long strideB, float* C,
+                                     int ldc, long strideC, int nbatch, int M, int N, int K, void* stream) {
+    if (!A || !Bw || !C || nbatch <= 0 || M <= 0 || N <= 0 || K <= 0 || (K % BK) || (lda % 4) || (ldb % 4) || (N % 4) ||
+        (ldc % 4) || (strideA % 4) || (strideB % 4) || (strideC % 4) || (((uintptr_t)A | (uintptr_t)Bw | (uintptr_t)C) & 15))
+        return WESUP_ERR_INVALID;
+    const long t128 = (long)ceil_div(M, 128) * ceil_div(N, 128) * nbatch, t64 = (long)ceil_div(M, 64) * ceil_div(N, 64) * nbatch;
+    if (t64 >= (1l << 31) / 2) return WESUP_ERR_INVALID;
+    NtParams p = {};
+    p.A = A; p.Bw = Bw; p.C = C;
+    p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldmask = ldc;
+    p.nbatch = nbatch; p.batchA = strideA; p.batchB = strideB; p.batchC = strideC;
+    hipStream_t st = (hipStream_t)stream;
+    if (N > 64 && t128 >= 384) return launch_nt<4, 128, 128, 2, 2, 3, 2, false>(p, st);
+    return launch_nt<4, 64, 64, 1, 1, 3, 2, false>(p, st);
+}
+
+// in (B,H,W,Cin) --Winograd conv with u [16][Cout][Cin]--> out (B,H,W,Cout) with the conv epilogue.
+// v_keep (optional): the transformed input is written there instead of the workspace (16 T Cin floats).
+static int wino_conv(const float* in, const float* u, const float* bias, const float* mask, float* out, float* out_relu,
+                     float* v_keep, int B, int H, int W, int Cin, int Cout, int relu_in, int accum, void* ws,
+                     size_t ws_bytes, void* st) {
+    if (!in || !u || !out || !ws || !wino_shape_ok(B, H, W, Cin, Cout) || (Cin % 32) ||
+        (((uintptr_t)u | (uintptr_t)v_keep | (uintptr_t)ws) & 15))
+        return WESUP_ERR_INVALID;
+    if (ws_bytes < wesup_conv3x3_winograd_workspace_bytes(B, H, W, Cin, Cout)) return WESUP_ERR_WORKSPACE;
+    const long T = wino_tiles(B, H, W);
+    float* V = v_keep ? v_keep : (float*)ws;
+    float* Mt = (float*)((char*)ws + align_up((size_t)16 * T * Cin * sizeof(float), 256));
+    int rc = wesup_winograd_input_transform(in, V, B, H, W, Cin, relu_in, st);
+    if (rc) return rc;
+    rc = wesup_gemm_nt_batched(V, Cin, T * Cin, u, Cin, (long)Cout * Cin, Mt, Cout, T * Cout, 16, (int)T, Cout, Cin, st);
+    if (rc) return rc;
+    return wesup_winograd_output_transform(Mt, bias, mask, out, out_relu, B, H, W, Cout, accum, st);
+}
+
+extern "C" int wesup_conv3x3_fwd_winograd(const float* x, const float* u_fwd, const float* bias, float* y, float* y_relu,
+                                          float* v_keep, int B, int H, int W, int Cin, int Cout, int relu_in, void* ws,
+                                          size_t ws_bytes, void* stream) {
+    return wino_conv(x, u_fwd, bias, nullptr, y, y_relu, v_keep, B, H, W, Cin, Cout, relu_in, 0, ws, ws_bytes, stream);
+}
+
+// dx = conv_transpose(dy) through the same pipeline: input dy (Cout channels), filter u_dgrad [16][Cin][Cout]
+extern "C" int wesup_conv3x3_dgrad_winograd(const float* dy, const float* u_dgrad, const float* mask_src, float* dx, int B,
+                                            int H, int W, int Cin, int Cout, int accumulate, void* ws, size_t ws_bytes,
+                                            void* stream) {
+    return wino_conv(dy, u_dgrad, nullptr, mask_src, dx, nullptr, nullptr, B, H, W, Cout, Cin, 0, accumulate, ws, ws_bytes,
+                     stream);
 }

@@ -86,6 +86,11 @@ class WesupEngine:
     # bench shape (tools/wino_table.py) -- faster from 128 -> 256 channels up, slower below (the transformed operands
     # are 4x the activations and the 64/128-channel GEMMs cannot amortise them)
     WINOGRAD_MIN_CI, WINOGRAD_MIN_CO = 128, 256
+    # layers whose forward and input gradient go through the Winograd domain when conv_winograd is on: every layer
+    # with >= 128 input channels (conv2_2 ... conv5_3) is faster that way at the bench shape (fwd 4.06 -> 2.73 ms, dgrad
+    # 4.12 -> 2.72 ms alone on the GPU, differences to the direct kernels 1-3e-6 of the tensor's max); the 3- and
+    # 64-channel layers stay on the implicit-GEMM kernel (their transformed tensors would be HBM-bound)
+    WINOGRAD_CONV_MIN_CI = 128
 
     def __init__(self, params, grads, D=32):
         """params/grads: dict name -> tensor (views of the flat parameter / gradient buffers)."""
@@ -108,6 +113,7 @@ class WesupEngine:
         # work in a step that is MFMA-bound, for memory-bound transform passes that run beside the dgrad chain
         # (alone on the GPU: 3.14 -> 2.11 ms for these nine layers, tools/wino_table.py)
         self.wgrad_winograd = True
+        self.conv_winograd = True        # forward / dgrad of the layers with >= 128 input channels likewise
         # side convs of the 64/128-channel layers inside the conv epilogue: correct and tested, OFF by default -- it
         # saves the side stream 0.33 ms of GEMMs that ran beside the chain anyway and puts 5-11 % more work on the conv
         # chain, which is the step's critical path (17.60 -> 17.88 ms)
@@ -177,6 +183,7 @@ class WesupEngine:
             b = _Bufs()
             b.x0 = torch.empty(B, H, W, 4, **f32)
             b.y, b.yp, b.s, b.dims, b.yr = [], [], [], [], []
+            b.V = [None] * 13            # Winograd-transformed layer inputs (training forward), allocated on first use
             h, w = H, W
             for l, (ci, co) in enumerate(CONV_CH):
                 b.dims.append((h, w))
@@ -260,6 +267,8 @@ class WesupEngine:
         if pk is None:
             pk = _Bufs()
             pk.wf, pk.wd = [], []
+            pk.uf, pk.ud = [None] * 13, [None] * 13          # Winograd-domain filters, allocated on first use
+            pk.wino = None
             for l, (ci, co) in enumerate(CONV_CH):
                 pk.wf.append(torch.empty(co, ops.conv3x3_kpad(ci), dtype=torch.float32, device=self.device))
                 pk.wd.append(None if l == 0 else torch.empty(ci, 9 * co, dtype=torch.float32, device=self.device))
@@ -268,15 +277,24 @@ class WesupEngine:
                       torch.empty(1024, 1024, dtype=torch.float32, device=self.device),
                       torch.empty(1024, self.D, dtype=torch.float32, device=self.device)]
             self._packed = pk
-        if self._prefetched == train:          # prefetch_weights() already queued exactly this for the current step
+        wino = [self._wino(l) for l in range(13)]
+        if self._prefetched == train and pk.wino == wino:     # prefetch_weights() already queued exactly this for the current step
             self._prefetched = None
             return pk
         self._prefetched = None
+        pk.wino = wino
         # ~40 launch-latency-bound repack kernels go to the side stream (idle at this point) and are joined in front of
         # the first convolution; the trainer queues them before the superpixel preprocessing (prefetch_weights)
         with self._OnSide(self):
             pk.ready0 = pk.ready = None
             for l, idx in enumerate(CONV_IDX):     # forward panels first: conv1_1 only waits for its own
+                if self._wino(l):
+                    if pk.uf[l] is None:
+                        ci, co = CONV_CH[l]
+                        pk.uf[l] = torch.empty(16, co, ci, dtype=torch.float32, device=self.device)
+                        pk.ud[l] = torch.empty(16, ci, co, dtype=torch.float32, device=self.device)
+                    ops.winograd_pack_weight(self.p[f'backbone.{idx}.weight'], need_dgrad=False, u_fwd=pk.uf[l])
+                    continue
                 ops.pack_conv3x3_weight(self.p[f'backbone.{idx}.weight'], pk.wf[l], None, need_dgrad=False)
                 if l == 0 and self.two_streams:
                     pk.ready0 = torch.cuda.Event()
@@ -286,7 +304,9 @@ class WesupEngine:
                 pk.ready.record()
             if train:
                 for l, idx in enumerate(CONV_IDX):
-                    if l > 0:
+                    if self._wino(l):
+                        ops.winograd_pack_weight(self.p[f'backbone.{idx}.weight'], need_fwd=False, u_dgrad=pk.ud[l])
+                    elif l > 0:
                         ops.pack_conv3x3_weight(self.p[f'backbone.{idx}.weight'], None, pk.wd[l], need_fwd=False)
                 for l, off in enumerate(SIDE_OFF):
                     co = CONV_CH[l][1]
@@ -294,6 +314,9 @@ class WesupEngine:
                 for i, k in enumerate((0, 2, 4)):
                     ops.transpose(self.p[f'fc_layers.{k}.weight'], pk.fcT[i])
         return pk
+
+    def _wino(self, l):
+        return self.conv_winograd and CONV_CH[l][0] >= self.WINOGRAD_CONV_MIN_CI
 
     def prefetch_weights(self, train=True):
         """Queue the weight repacking of the coming forward now (side stream, behind everything queued so far, i.e.
@@ -330,6 +353,7 @@ class WesupEngine:
                         ops.transpose(g.Wm[i], g.WmT[i])
                 T.end(tok, 0.0)
         cur = b.x0
+        b.wino_fwd = [self._wino(l) for l in range(13)]
         b.relu_stored = self.relu_on_store and all(b.yr[l] is not None for l in range(12) if not POOL_AFTER[l])
         fused = self.fuse_pool_fwd
         b.fm_valid = not fused
@@ -346,12 +370,19 @@ class WesupEngine:
             s2d = fm2d[:, off:off + co // 2] if b.s[l] is None else b.s[l].view(B * h * w, co // 2)
             # optional: the side conv of the four widest layers (64 / 128 channels at 480^2 / 240^2: the y re-read is
             # 236 / 118 MB) in the conv's epilogue, where the output tile sits in LDS anyway
-            side_in_conv = self.fuse_side_fwd and co <= 128
-            tok = T.begin('conv3x3_fwd')
-            ops.conv3x3_fwd(cur, pk.wf[l], p[f'backbone.{idx}.bias'], co, relu_in=(l > 0 and not b.relu_stored),
-                            out=b.y[l], out_relu=b.yr[l],
-                            side=(ws, p[f'side_conv{off}.bias'], s2d) if side_in_conv else None)
-            T.end(tok, 2.0 * B * h * w * co * ((3 if l == 0 else ci) * 9 + (co // 2 if side_in_conv else 0)))
+            side_in_conv = self.fuse_side_fwd and co <= 128 and not self._wino(l)
+            if self._wino(l):
+                if train and b.V[l] is None:         # the transformed input, kept for the weight gradient
+                    b.V[l] = torch.empty(16, ops.winograd_tiles(B, h, w), ci, dtype=torch.float32, device=self.device)
+                # timed as 'winograd_gemm' (executed MFMA FLOPs: 4/9 of the direct form's) + 'winograd_transform' (bytes)
+                ops.conv3x3_fwd_winograd(cur, pk.uf[l], p[f'backbone.{idx}.bias'], relu_in=not b.relu_stored, out=b.y[l],
+                                         out_relu=b.yr[l], v_keep=b.V[l] if train else None, ws_tag='wino_main', timer=T)
+            else:
+                tok = T.begin('conv3x3_fwd')
+                ops.conv3x3_fwd(cur, pk.wf[l], p[f'backbone.{idx}.bias'], co, relu_in=(l > 0 and not b.relu_stored),
+                                out=b.y[l], out_relu=b.yr[l],
+                                side=(ws, p[f'side_conv{off}.bias'], s2d) if side_in_conv else None)
+                T.end(tok, 2.0 * B * h * w * co * ((3 if l == 0 else ci) * 9 + (co // 2 if side_in_conv else 0)))
             # side branch of this layer: 1x1 conv on the pre-ReLU tap, then either the fused upsample+scatter-mean
             # straight into the superpixel feature slice, or upsample into fm's channel slice
             with self._OnSide(self):
@@ -555,8 +586,9 @@ class WesupEngine:
             def wgrad(ws_tag):
                 tok = T.begin('conv3x3_wgrad')
                 dw, db = g[f'backbone.{idx}.weight'], g[f'backbone.{idx}.bias']
-                if self.wgrad_winograd and ci >= self.WINOGRAD_MIN_CI and co >= self.WINOGRAD_MIN_CO:
-                    ops.conv3x3_wgrad_winograd(x_in, b.G[l], relu_in=relu_x, dw=dw, db=db, ws_tag=ws_tag)
+                v_pre = b.V[l] if b.wino_fwd[l] else None      # this forward went through the Winograd domain
+                if self.wgrad_winograd and ci >= self.WINOGRAD_MIN_CI and (co >= self.WINOGRAD_MIN_CO or v_pre is not None):
+                    ops.conv3x3_wgrad_winograd(x_in, b.G[l], relu_in=relu_x, dw=dw, db=db, ws_tag=ws_tag, v_pre=v_pre)
                     # the FLOPs the MFMA pipe executes: 16 positions x (2x2 tiles) instead of 9 taps x pixels
                     T.end(tok, 2.0 * 16 * B * ((h + 1) // 2) * ((w + 1) // 2) * ci * co)
                 else:
@@ -574,12 +606,19 @@ class WesupEngine:
             if l > lowest:
                 if g_ready[l - 1] is not None:
                     main.wait_event(g_ready[l - 1])
-                tok = T.begin('conv3x3_dgrad')
-                if POOL_AFTER[l - 1]:
-                    ops.conv3x3_dgrad(b.G[l], pk.wd[l], ci, out=b.dxp[l - 1])
+                if b.wino_fwd[l]:
+                    if POOL_AFTER[l - 1]:
+                        ops.conv3x3_dgrad_winograd(b.G[l], pk.ud[l], out=b.dxp[l - 1], ws_tag='wino_main', timer=T)
+                    else:
+                        ops.conv3x3_dgrad_winograd(b.G[l], pk.ud[l], mask_src=b.y[l - 1], out=b.G[l - 1], accumulate=True,
+                                                   ws_tag='wino_main', timer=T)
                 else:
-                    ops.conv3x3_dgrad(b.G[l], pk.wd[l], ci, mask_src=b.y[l - 1], out=b.G[l - 1], accumulate=True)
-                T.end(tok, 2.0 * B * h * w * ci * co * 9)
+                    tok = T.begin('conv3x3_dgrad')
+                    if POOL_AFTER[l - 1]:
+                        ops.conv3x3_dgrad(b.G[l], pk.wd[l], ci, out=b.dxp[l - 1])
+                    else:
+                        ops.conv3x3_dgrad(b.G[l], pk.wd[l], ci, mask_src=b.y[l - 1], out=b.G[l - 1], accumulate=True)
+                    T.end(tok, 2.0 * B * h * w * ci * co * 9)
                 if POOL_AFTER[l - 1]:
                     ops.maxpool2_bwd(b.y[l - 1], b.dxp[l - 1], b.G[l - 1], accumulate=True)
         if wg is not None:

@@ -203,7 +203,89 @@ def conv3x3_wgrad(x, dy, Ci, relu_in, dw=None, db=None, ws_tag='default'):
     return dw, db
 
 
-def conv3x3_wgrad_winograd(x, dy, relu_in, dw=None, db=None, ws_tag='default'):
+def winograd_pack_weight(w, need_fwd=True, need_dgrad=True, u_fwd=None, u_dgrad=None):
+    """w (Cout,Cin,3,3) -> (u_fwd (16,Cout,Cin), u_dgrad (16,Cin,Cout)): G g G^T per channel pair, the second from the
+    rotated filter."""
+    _chk(w, name='w')
+    Cout, Cin = w.shape[:2]
+    if need_fwd and u_fwd is None:
+        u_fwd = torch.empty(16, Cout, Cin, dtype=torch.float32, device=w.device)
+    if need_dgrad and u_dgrad is None:
+        u_dgrad = torch.empty(16, Cin, Cout, dtype=torch.float32, device=w.device)
+    _lib.call('wesup_winograd_pack_weight', _p(w), _p(u_fwd if need_fwd else None), _p(u_dgrad if need_dgrad else None),
+              Cout, Cin, _stream())
+    return u_fwd if need_fwd else None, u_dgrad if need_dgrad else None
+
+
+def winograd_tiles(B, H, W):
+    return B * ((H + 1) // 2) * ((W + 1) // 2)
+
+
+def _winograd_conv(inp, u, bias, mask_src, out, out_relu, v_keep, relu_in, accumulate, ws_tag, timer):
+    """The three passes of a Winograd-domain conv (input transform, 16 batched NT GEMMs, output transform + epilogue).
+    timer (optional, engine.KernelTimer-like): the GEMM and the two transforms are bracketed as classes of their own."""
+    B, H, W, Cin = inp.shape
+    Cout = u.shape[1]
+    lib = _lib.load()
+    nb = lib.wesup_conv3x3_winograd_workspace_bytes(B, H, W, Cin, Cout)
+    if not nb:
+        raise _lib.WesupHipError(f'winograd conv: unsupported shape {(B, H, W, Cin, Cout)}')
+    T = winograd_tiles(B, H, W)
+    ws = workspace(nb, inp.device, ws_tag)
+    v_bytes = (16 * T * Cin * 4 + 255) // 256 * 256
+    V = v_keep if v_keep is not None else ws[:v_bytes]
+    Mt = ws[v_bytes:]
+    st = _stream()
+    tok = timer.begin('winograd_transform') if timer else None
+    _lib.call('wesup_winograd_input_transform', _p(inp), _p(V), B, H, W, Cin, int(relu_in), st)
+    if timer:
+        timer.end(tok, 4.0 * 5 * inp.numel())              # bytes: read x, write 4x
+        tok = timer.begin('winograd_gemm')
+    _lib.call('wesup_gemm_nt_batched', _p(V), Cin, T * Cin, _p(u), Cin, Cout * Cin, _p(Mt), Cout, T * Cout, 16, T, Cout, Cin, st)
+    if timer:
+        timer.end(tok, 2.0 * 16 * T * Cin * Cout)
+        tok = timer.begin('winograd_transform')
+    _lib.call('wesup_winograd_output_transform', _p(Mt), _p(bias), _p(mask_src), _p(out), _p(out_relu), B, H, W, Cout,
+              int(accumulate), st)
+    if timer:
+        n_io = 1 + (out_relu is not None) + (mask_src is not None) + bool(accumulate)
+        timer.end(tok, 4.0 * (4 + n_io) * out.numel())
+    return out
+
+
+def conv3x3_fwd_winograd(x, u_fwd, bias, relu_in, out=None, out_relu=None, v_keep=None, ws_tag='default', timer=None):
+    """conv3x3_fwd through the Winograd domain (deep layers); v_keep (16, tiles, Cin) receives the transformed input."""
+    _chk(x, name='x'); _chk(u_fwd, name='u_fwd')
+    B, H, W, Cin = x.shape
+    Cout = u_fwd.shape[1]
+    assert u_fwd.shape == (16, Cout, Cin)
+    if bias is not None:
+        _chk(bias, name='bias'); assert bias.numel() == Cout
+    if out is None:
+        out = torch.empty(B, H, W, Cout, dtype=torch.float32, device=x.device)
+    assert out.shape == (B, H, W, Cout) and out.is_contiguous()
+    if out_relu is not None:
+        _chk(out_relu, name='out_relu'); assert out_relu.shape == out.shape
+    if v_keep is not None:
+        _chk(v_keep, name='v_keep'); assert v_keep.numel() == 16 * winograd_tiles(B, H, W) * Cin
+    return _winograd_conv(x, u_fwd, bias, None, out, out_relu, v_keep, relu_in, False, ws_tag, timer)
+
+
+def conv3x3_dgrad_winograd(dy, u_dgrad, mask_src=None, out=None, accumulate=False, ws_tag='default', timer=None):
+    _chk(dy, name='dy'); _chk(u_dgrad, name='u_dgrad')
+    B, H, W, Cout = dy.shape
+    Cin = u_dgrad.shape[1]
+    assert u_dgrad.shape == (16, Cin, Cout)
+    if mask_src is not None:
+        _chk(mask_src, name='mask_src'); assert mask_src.shape == (B, H, W, Cin)
+    if out is None:
+        assert not accumulate
+        out = torch.empty(B, H, W, Cin, dtype=torch.float32, device=dy.device)
+    assert out.shape == (B, H, W, Cin) and out.is_contiguous()
+    return _winograd_conv(dy, u_dgrad, None, mask_src, out, None, None, False, accumulate, ws_tag, timer)
+
+
+def conv3x3_wgrad_winograd(x, dy, relu_in, dw=None, db=None, ws_tag='default', v_pre=None):
     """The same (dw, db) as conv3x3_wgrad through the Winograd F(2x2,3x3) domain: 2.25x fewer multiply-adds, 4x the
     operand bytes; for the wide layers (Ci, Cout >= 128)."""
     _chk(x, name='x'); _chk(dy, name='dy')
@@ -219,8 +301,10 @@ def conv3x3_wgrad_winograd(x, dy, relu_in, dw=None, db=None, ws_tag='default'):
     if not nb:
         raise _lib.WesupHipError(f'conv3x3_wgrad_winograd: unsupported shape {(B, H, W, Ci, Cout)}')
     ws = workspace(nb, x.device, ws_tag)
-    _lib.call('wesup_conv3x3_wgrad_winograd', _p(x), _p(dy), _p(dw), _p(db), B, H, W, Ci, Cout, int(relu_in), _p(ws), nb,
-              _stream())
+    if v_pre is not None:
+        _chk(v_pre, name='v_pre'); assert v_pre.numel() == 16 * winograd_tiles(B, H, W) * Ci
+    _lib.call('wesup_conv3x3_wgrad_winograd', _p(x), _p(v_pre), _p(dy), _p(dw), _p(db), B, H, W, Ci, Cout, int(relu_in),
+              _p(ws), nb, _stream())
     return dw, db
 
 
