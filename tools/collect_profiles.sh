@@ -5,7 +5,8 @@
 # 3. PMC counters over bench.py itself, one rocprofv3 run per counter group with no trace domain beside it
 #    (MI355X_MICROARCH.md: FETCH_SIZE and WRITE_SIZE in passes of their own) -> traffic and MFMA-busy per kernel class;
 # 4. the same two MFMA counters over tools/layer_pmc.py -> 13 layers x {fwd, dgrad, wgrad} table;
-# 5. tools/layer_table.py (HIP-event times per layer and pass, kernels alone);
+# 5. tools/layer_table.py (HIP-event times per layer and pass, direct kernels alone) and tools/wino_table.py (direct vs
+#    Winograd-domain per layer);
 # 6. tools/roofline_inputs.py turns 3+4 into profiles/rNN_roofline_inputs.json (read by bench.py) and rNN_layer_mfma.csv.
 set -o pipefail
 R=${1:-r02}
@@ -35,6 +36,7 @@ pmc layer_busy "GRBM_GUI_ACTIVE" tools/layer_pmc.py $OUT/layer_manifest.json &&
 pmc conv_lds "SQ_INSTS_LDS SQ_INSTS_VALU SQ_LDS_BANK_CONFLICT" tools/conv_micro.py fwd 4 120 120 256 256 &&
 pmc wgrad_lds "SQ_INSTS_LDS SQ_INSTS_VALU SQ_LDS_BANK_CONFLICT" tools/conv_micro.py wgrad 4 120 120 256 256
 timeout -k 10 200 python3 tools/layer_table.py 5 > $OUT/layer_table.txt 2>&1
+timeout -k 10 200 python3 tools/wino_table.py 5 > $OUT/wino_table.txt 2>&1
 python3 tools/pmc_summary.py $OUT/pmc_conv_lds $OUT/pmc_wgrad_lds > $OUT/pmc_lds_summary.csv
 python3 tools/roofline_inputs.py $OUT $R > $OUT/roofline_inputs.log 2>&1 || { echo "roofline_inputs failed"; tail -5 $OUT/roofline_inputs.log; }
 cp profiles/${R}_roofline_inputs.json profiles/${R}_layer_mfma.csv $OUT/ 2>/dev/null

@@ -1,4 +1,5 @@
-"""Driver for per-layer PMC collection: every conv3x3 layer of the bench shape (B=4, 480x480) x {fwd, dgrad, wgrad},
+"""Driver for per-layer PMC collection: every conv3x3 layer of the bench shape (B=4, 480x480) x {fwd, dgrad, wgrad}
+(as the engine routes them: implicit GEMM below 128 input channels, Winograd domain from there up),
 each launched `reps` times in a fixed order, with a manifest of that order so that tools/roofline_inputs.py can map
 the dispatches of the rocprofv3 counter file back to (layer, pass).
 
@@ -10,7 +11,7 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from wesup_amd import ops
-from wesup_amd.engine import CONV_CH, POOL_AFTER
+from wesup_amd.engine import CONV_CH, POOL_AFTER, WesupEngine
 
 d = torch.device('cuda:0')
 B, H, W = 4, 480, 480
@@ -28,16 +29,30 @@ for l, (ci, co) in enumerate(CONV_CH):
     dx = torch.empty(B, h, w, cin, device=d)
     dw = torch.empty(co, ci, 3, 3, device=d)
     db = torch.empty(co, device=d)
-    fl = 2.0 * B * h * w * ci * co * 9
+    wino = ci >= WesupEngine.WINOGRAD_CONV_MIN_CI          # the engine's routing: Winograd domain from 128 input channels up
+    # FLOPs the MFMA pipe executes in the main GEMM launch of the group (Winograd: 16 positions x 2x2 tiles)
+    fl = 2.0 * 16 * ops.winograd_tiles(B, h, w) * ci * co if wino else 2.0 * B * h * w * ci * co * 9
+    if wino:
+        uf, ud = ops.winograd_pack_weight(wt)
+        v_keep = torch.empty(16, ops.winograd_tiles(B, h, w), ci, device=d)
     for _ in range(reps):
-        ops.conv3x3_fwd(x, wf, bias, co, relu_in=False, out=y)
+        if wino:
+            ops.conv3x3_fwd_winograd(x, uf, bias, False, out=y, v_keep=v_keep)
+        else:
+            ops.conv3x3_fwd(x, wf, bias, co, relu_in=False, out=y)
     manifest['order'].append([l, 'fwd', fl])
     if l > 0:
         for _ in range(reps):
-            ops.conv3x3_dgrad(dy, wd, ci, mask_src=x, out=dx, accumulate=True)
+            if wino:
+                ops.conv3x3_dgrad_winograd(dy, ud, mask_src=x, out=dx, accumulate=True)
+            else:
+                ops.conv3x3_dgrad(dy, wd, ci, mask_src=x, out=dx, accumulate=True)
         manifest['order'].append([l, 'dgrad', fl])
     for _ in range(reps):
-        ops.conv3x3_wgrad(x, dy, ci, relu_in=False, dw=dw, db=db)
+        if wino:
+            ops.conv3x3_wgrad_winograd(x, dy, False, dw=dw, db=db, v_pre=v_keep)
+        else:
+            ops.conv3x3_wgrad(x, dy, ci, relu_in=False, dw=dw, db=db)
     manifest['order'].append([l, 'wgrad', fl])
     torch.cuda.synchronize()
     if POOL_AFTER[l]:

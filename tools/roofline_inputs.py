@@ -33,15 +33,16 @@ def read_pass(d):
 
 
 def klass(kernel):
-    """conv3x3 fwd+dgrad | conv3x3 wgrad | scatter_mean | None"""
+    """conv3x3 fwd+dgrad GEMMs | conv3x3 wgrad GEMMs | scatter_mean | None.  gemm_nt_kernel MODE 1/2 = implicit-GEMM conv,
+    MODE 3 = the batched Winograd-domain products (MODE 0: side convs / MLP, not counted here); gemm_tn_kernel likewise."""
     m = re.search(r'gemm_nt_kernel<([^>]*)>', kernel)
     if m:
         mode = int(m.group(1).split(',')[5])
-        return 'conv3x3_fwd_dgrad' if mode in (1, 2) else None
+        return 'conv3x3_fwd_dgrad' if mode in (1, 2, 3) else None
     m = re.search(r'gemm_tn_kernel<([^>]*)>', kernel)
     if m:
         mode = int(m.group(1).split(',')[4])
-        return 'conv3x3_wgrad' if mode in (1, 2) else None
+        return 'conv3x3_wgrad' if mode in (1, 2, 3) else None
     if kernel.startswith('sp_pool_fwd_kernel'):
         return 'scatter_mean'
     return None
@@ -123,9 +124,12 @@ def main():
     print('\n'.join(lines))
 
 
-def conv_algorithmic_bytes(B, H, W):
-    """Mean algorithmic HBM bytes per launch of the two conv kernel classes over one step: every operand read once,
-    every result written once (fwd: x, w, y; dgrad: dy, w, [mask], dx read-modify-write; wgrad: x, dy, dw)."""
+def conv_algorithmic_bytes(B, H, W, wino_min_ci=128):
+    """Mean algorithmic HBM bytes per GEMM launch of the two conv kernel classes over one step: every operand read once,
+    every result written once.  Direct layers (below wino_min_ci input channels) -- fwd: x, w, y; dgrad: dy, w, mask +
+    old dx + new dx; wgrad: x, dy, dw.  Winograd-domain layers -- the GEMM launch reads the transformed input (16 x
+    tiles x Cin), the transformed filter (16 x Cin x Cout) and writes the transformed output (16 x tiles x Cout); the
+    wgrad launch reads both transformed tensors and writes 16 filter-gradient slabs."""
     ch = [(3, 64), (64, 64), (64, 128), (128, 128), (128, 256), (256, 256), (256, 256), (256, 512), (512, 512), (512, 512),
           (512, 512), (512, 512), (512, 512)]
     pool = [False, True, False, True, False, False, True, False, False, True, False, False, False]
@@ -134,13 +138,20 @@ def conv_algorithmic_bytes(B, H, W):
     for l, (ci, co) in enumerate(ch):
         px = B * h * w
         cin = 4 if l == 0 else ci
-        nt += 4.0 * (px * cin + 9 * cin * co + px * co)
-        n_nt += 1
-        if l > 0:
-            nt += 4.0 * (px * co + 9 * ci * co + 3 * px * ci)          # dy, w, mask + old dx + new dx
+        if ci >= wino_min_ci:
+            T = B * ((h + 1) // 2) * ((w + 1) // 2)
+            nt += 2 * 4.0 * 16 * (T * ci + ci * co + T * co)          # fwd and dgrad launches
+            n_nt += 2
+            tn += 4.0 * 16 * (T * ci + T * co + ci * co)
+            n_tn += 1
+        else:
+            nt += 4.0 * (px * cin + 9 * cin * co + px * co)
             n_nt += 1
-        tn += 4.0 * (px * cin + px * co + 9 * ci * co)
-        n_tn += 1
+            if l > 0:
+                nt += 4.0 * (px * co + 9 * ci * co + 3 * px * ci)
+                n_nt += 1
+            tn += 4.0 * (px * cin + px * co + 9 * ci * co)
+            n_tn += 1
         if pool[l]:
             h, w = h // 2, w // 2
     return {'conv3x3_fwd_dgrad': nt / n_nt, 'conv3x3_wgrad': tn / n_tn}

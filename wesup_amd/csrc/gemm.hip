@@ -755,8 +755,9 @@ struct TnParams {
     int w_old, w_young;   // > 0: weighted split of a single-round grid (see the kernel); 0: equal splits
 };
 
-template <int BM, int BN, int WM, int WN, int MODE, bool RELU, bool TINY>
+template <int BM, int BN, int WM, int WN, int MODE_, bool RELU, bool TINY>
 __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnParams p) {
+    constexpr int MODE = (MODE_ == 3) ? 0 : MODE_;     // 3 = plain like 0: the batched Winograd-domain products, under a kernel name of their own
     constexpr int QA = BM / 4, RPA = 256 / QA, NA = BK / RPA;
     constexpr int QB = BN / 4, RPB = 256 / QB, NB = BK / RPB;
     constexpr int WAVES_N = BN / (32 * WN);
@@ -1146,13 +1147,13 @@ static int launch_tn(TnParams p, const TnPlan& pl, hipStream_t st, int nbatch = 
     const long kmax = p.w_old > 0 ? 2l * pl.k_per_split : pl.k_per_split;      // a weighted range stays below twice the mean
     if ((kmax + 2 * BK) * ldmax * 4 + (1l << 22) >= (1l << 31)) return WESUP_ERR_INVALID;
     dim3 grid(pl.tiles_m * pl.tiles_n * pl.taps, pl.S, nbatch);
-    const bool tiny = MODE != 0 && (p.W < 16 || p.H < 2);
+    const bool tiny = (MODE == 1 || MODE == 2) && (p.W < 16 || p.H < 2);
 #define WESUP_TN_LAUNCH(BM_, WM_, RELU_, TINY_)                                                                        \
     hipLaunchKernelGGL((gemm_tn_kernel<BM_, BM_, WM_, WM_, MODE, RELU_, TINY_>), grid, dim3(256),                     \
                        (size_t)2 * BK * (BM_ + BM_) * sizeof(float), st, p)
 #define WESUP_TN_PICK(BM_, WM_)                                                                                        \
     do {                                                                                                               \
-        if (tiny) { if (p.relu_b) WESUP_TN_LAUNCH(BM_, WM_, true, (MODE != 0)); else WESUP_TN_LAUNCH(BM_, WM_, false, (MODE != 0)); } \
+        if (tiny) { if (p.relu_b) WESUP_TN_LAUNCH(BM_, WM_, true, (MODE == 1 || MODE == 2)); else WESUP_TN_LAUNCH(BM_, WM_, false, (MODE == 1 || MODE == 2)); } \
         else { if (p.relu_b) WESUP_TN_LAUNCH(BM_, WM_, true, false); else WESUP_TN_LAUNCH(BM_, WM_, false, false); }  \
     } while (0)
     if (pl.bm == 128) WESUP_TN_PICK(128, 2);
@@ -1522,7 +1523,7 @@ extern "C" int wesup_conv3x3_wgrad_winograd(const float* x, const float* v_pre, 
     p.relu_b = 0; p.H = 1; p.W = 1; p.dW = make_fastdiv(1); p.dH = make_fastdiv(1);
     p.slab_stride = (long)tn_slab_stride(Cout, pl.Nslab); p.want_colsum = db != nullptr; p.colsum_batch = 5;
     p.batchA = T * Cout; p.batchB = T * Ci; p.batch_slab = (long)pl.S * p.slab_stride;
-    const int rc = launch_tn<0>(p, pl, st, 16);
+    const int rc = launch_tn<3>(p, pl, st, 16);
     if (rc) return rc;
     const long tot = (long)Cout * Ci;
     hipLaunchKernelGGL(wino_wgrad_reduce_kernel, dim3((unsigned)((tot + Cout + 255) / 256)), dim3(256), 0, st,

@@ -352,7 +352,8 @@ class WesupEngine:
                     for i in range(B):
                         ops.transpose(g.Wm[i], g.WmT[i])
                 T.end(tok, 0.0)
-        cur = b.x0
+        cur, cur_relu = b.x0, False      # the layer's input tensor, and whether its ReLU is still to be applied on load
+        b.x_in, b.x_relu = [None] * 13, [False] * 13
         b.wino_fwd = [self._wino(l) for l in range(13)]
         b.relu_stored = self.relu_on_store and all(b.yr[l] is not None for l in range(12) if not POOL_AFTER[l])
         fused = self.fuse_pool_fwd
@@ -371,16 +372,22 @@ class WesupEngine:
             # optional: the side conv of the four widest layers (64 / 128 channels at 480^2 / 240^2: the y re-read is
             # 236 / 118 MB) in the conv's epilogue, where the output tile sits in LDS anyway
             side_in_conv = self.fuse_side_fwd and co <= 128 and not self._wino(l)
+            b.x_in[l], b.x_relu[l] = cur, cur_relu
+            # The ReLU'd copy of this layer's output exists for the next layer's 9-tap re-reads and its weight gradient.
+            # A Winograd-domain consumer reads its input once (input transform) and its weight gradient reads the kept V:
+            # then the copy is not written at all and the transform applies the ReLU while loading y.
+            yr = b.yr[l]
+            if yr is not None and l < 12 and self._wino(l + 1) and (self.wgrad_winograd or not train):
+                yr = None
             if self._wino(l):
                 if train and b.V[l] is None:         # the transformed input, kept for the weight gradient
                     b.V[l] = torch.empty(16, ops.winograd_tiles(B, h, w), ci, dtype=torch.float32, device=self.device)
                 # timed as 'winograd_gemm' (executed MFMA FLOPs: 4/9 of the direct form's) + 'winograd_transform' (bytes)
-                ops.conv3x3_fwd_winograd(cur, pk.uf[l], p[f'backbone.{idx}.bias'], relu_in=not b.relu_stored, out=b.y[l],
-                                         out_relu=b.yr[l], v_keep=b.V[l] if train else None, ws_tag='wino_main', timer=T)
+                ops.conv3x3_fwd_winograd(cur, pk.uf[l], p[f'backbone.{idx}.bias'], relu_in=cur_relu, out=b.y[l],
+                                         out_relu=yr, v_keep=b.V[l] if train else None, ws_tag='wino_main', timer=T)
             else:
                 tok = T.begin('conv3x3_fwd')
-                ops.conv3x3_fwd(cur, pk.wf[l], p[f'backbone.{idx}.bias'], co, relu_in=(l > 0 and not b.relu_stored),
-                                out=b.y[l], out_relu=b.yr[l],
+                ops.conv3x3_fwd(cur, pk.wf[l], p[f'backbone.{idx}.bias'], co, relu_in=cur_relu, out=b.y[l], out_relu=yr,
                                 side=(ws, p[f'side_conv{off}.bias'], s2d) if side_in_conv else None)
                 T.end(tok, 2.0 * B * h * w * co * ((3 if l == 0 else ci) * 9 + (co // 2 if side_in_conv else 0)))
             # side branch of this layer: 1x1 conv on the pre-ReLU tap, then either the fused upsample+scatter-mean
@@ -407,9 +414,11 @@ class WesupEngine:
                     T.end(tok, 4.0 * B * H * W * (co // 2))
             if POOL_AFTER[l]:
                 ops.maxpool2_fwd(b.y[l], b.yp[l], relu=b.relu_stored)
-                cur = b.yp[l]
+                cur, cur_relu = b.yp[l], not b.relu_stored
+            elif yr is not None:
+                cur, cur_relu = yr, False
             else:
-                cur = b.yr[l] if b.yr[l] is not None else b.y[l]
+                cur, cur_relu = b.y[l], True
         self._join_side()
         if not fused:
             tok = T.begin('sp_pool_fwd')
@@ -576,13 +585,7 @@ class WesupEngine:
             idx = CONV_IDX[l]
             if g_ready[l] is not None:
                 main.wait_event(g_ready[l])
-            if l == 0:
-                x_in = b.x0
-            elif POOL_AFTER[l - 1]:
-                x_in = b.yp[l - 1]
-            else:
-                x_in = b.yr[l - 1] if b.relu_stored else b.y[l - 1]
-            relu_x = l > 0 and not b.relu_stored
+            x_in, relu_x = b.x_in[l], b.x_relu[l]      # what the forward of this layer read
             def wgrad(ws_tag):
                 tok = T.begin('conv3x3_wgrad')
                 dw, db = g[f'backbone.{idx}.weight'], g[f'backbone.{idx}.bias']
