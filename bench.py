@@ -53,6 +53,8 @@ def parse_args(argv=None):
                                                                'epilogue instead of as GEMMs on the side stream')
     ap.add_argument('--direct-conv', action='store_true', help='A/B: forward and input gradient of every conv layer with '
                                                                'the direct implicit-GEMM kernel (no Winograd-domain conv)')
+    ap.add_argument('--winograd-pipeline', action='store_true', help='A/B: Winograd-domain convs with the half-batch '
+                                                                      'pipeline over a helper stream')
     ap.add_argument('--direct-wgrad', action='store_true', help='A/B: every conv weight gradient with the direct '
                                                                 'implicit-GEMM kernel (no Winograd-domain wgrad)')
     ap.add_argument('--event-every', type=int, default=4, help='steps of the timed region that carry HIP events: every n-th')
@@ -244,6 +246,9 @@ def worker(args):
     trainer.model.engine.fuse_side_fwd = args.side_fusion
     trainer.model.engine.wgrad_winograd = not args.direct_wgrad
     trainer.model.engine.conv_winograd = not args.direct_conv
+    if args.winograd_pipeline:
+        from wesup_amd import ops as _ops2
+        _ops2.PIPELINE_WINOGRAD = True
     if use_dist and args.ddp_probe != 'pg':
         trainer.enable_data_parallel(bucket_bytes=args.bucket_mb << 20)
 

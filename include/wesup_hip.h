@@ -133,12 +133,15 @@ int wesup_conv3x3_dgrad_winograd(const float* dy, const float* u_dgrad, const fl
 /* The three passes on their own (the two entries above chain them): x (B,H,W,C) -> V [16][tiles][C];
  * nbatch NT products of one shape in one launch, C_b = A_b . B_b^T (element strides between the entries; K % 32 == 0);
  * Mt [16][tiles][C] -> y = A^T M A + bias, masked by mask_src > 0, added to the old y if accumulate, with the optional
- * second output y_relu = max(y, 0).  tiles = B * ceil(H/2) * ceil(W/2). */
-int wesup_winograd_input_transform(const float* x, float* V, int B, int H, int W, int C, int relu_in, void* stream);
+ * second output y_relu = max(y, 0).  tiles = B * ceil(H/2) * ceil(W/2).  plane_elems: elements between two of the 16
+ * position planes of V / Mt (0: tiles * C); larger when a sub-batch works inside the planes of a whole batch, which is
+ * how the engine pipelines the memory-bound transforms of one half of the batch under the GEMM of the other. */
+int wesup_winograd_input_transform(const float* x, float* V, long plane_elems, int B, int H, int W, int C, int relu_in,
+                                   void* stream);
 int wesup_gemm_nt_batched(const float* A, int lda, long strideA, const float* B, int ldb, long strideB,
                           float* C, int ldc, long strideC, int nbatch, int M, int N, int K, void* stream);
-int wesup_winograd_output_transform(const float* Mt, const float* bias, const float* mask_src, float* y, float* y_relu,
-                                    int B, int H, int W, int C, int accumulate, void* stream);
+int wesup_winograd_output_transform(const float* Mt, long plane_elems, const float* bias, const float* mask_src, float* y,
+                                    float* y_relu, int B, int H, int W, int C, int accumulate, void* stream);
 
 /* ------------------------------------------------------------------ generic fp32 MFMA GEMMs
  * side 1x1 convs (models/wesup.py:208-209,253), fc_layers (models/wesup.py:213-220,288) and their grads.

@@ -196,6 +196,36 @@ def test_conv3x3_fwd_winograd(ops, B, H, W, Cin, Cout, relu_in):
     assert torch.equal(dw1, dw2) and torch.equal(db1, db2)
 
 
+@pytest.mark.parametrize('B,H,W,Cin,Cout', [(2, 13, 11, 64, 128), (4, 30, 30, 256, 256), (6, 9, 9, 128, 64)])
+def test_winograd_conv_pipelined_halves_are_bit_identical(ops, B, H, W, Cin, Cout):
+    """The two halves of the batch pipelined over the helper stream (transforms of one half under the GEMM of the other)
+    give bit for bit the outputs, the kept V and the accumulate/mask epilogue of the unsplit call."""
+    d = dev()
+    x = nhwc(rnd(B, Cin, H, W, seed=1)).to(d)
+    w = rnd(Cout, Cin, 3, 3, seed=2, scale=(2.0 / (9 * Cin)) ** 0.5).to(d)
+    b = rnd(Cout, seed=3, scale=0.1).to(d)
+    dy = nhwc(rnd(B, Cout, H, W, seed=4)).to(d)
+    base = rnd(B, H, W, Cin, seed=5).to(d)
+    uf, ud = ops.winograd_pack_weight(w)
+    T = ops.winograd_tiles(B, H, W)
+    res = []
+    was = ops.PIPELINE_WINOGRAD, ops.PIPELINE_MIN_BLOCKS
+    try:
+        for pipelined in (False, True):
+            ops.PIPELINE_WINOGRAD, ops.PIPELINE_MIN_BLOCKS = pipelined, 0
+            v = torch.zeros(16, T, Cin, device=d)
+            y, yr = torch.empty(B, H, W, Cout, device=d), torch.empty(B, H, W, Cout, device=d)
+            ops.conv3x3_fwd_winograd(x, uf, b, True, out=y, out_relu=yr, v_keep=v)
+            dx = base.clone()
+            ops.conv3x3_dgrad_winograd(dy, ud, mask_src=x, out=dx, accumulate=True)
+            torch.cuda.synchronize()
+            res.append((y, yr, v, dx))
+    finally:
+        ops.PIPELINE_WINOGRAD, ops.PIPELINE_MIN_BLOCKS = was
+    for a, bb in zip(*res):
+        assert torch.equal(a, bb)
+
+
 @pytest.mark.parametrize('B,H,W,Cin,Cout', WINO_CASES)
 def test_conv3x3_dgrad_winograd(ops, B, H, W, Cin, Cout):
     d = dev()

@@ -44,9 +44,9 @@ _SIGS = {
     'wesup_conv3x3_winograd_workspace_bytes': (c_size_t, 'iiiii'),
     'wesup_conv3x3_fwd_winograd': (c_int, 'ppppppiiiiiipzp'),
     'wesup_conv3x3_dgrad_winograd': (c_int, 'ppppiiiiiipzp'),
-    'wesup_winograd_input_transform': (c_int, 'ppiiiiip'),
+    'wesup_winograd_input_transform': (c_int, 'ppliiiiip'),
     'wesup_gemm_nt_batched': (c_int, 'pilpilpiliiiip'),
-    'wesup_winograd_output_transform': (c_int, 'pppppiiiiip'),
+    'wesup_winograd_output_transform': (c_int, 'plppppiiiiip'),
     'wesup_gemm_nt_workspace_bytes': (c_size_t, 'iii'),
     'wesup_gemm_nt': (c_int, 'pipippipiiiiipzp'),
     'wesup_gemm_tn_workspace_bytes': (c_size_t, 'iii'),

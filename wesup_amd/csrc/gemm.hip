@@ -1346,6 +1346,8 @@ extern "C" int wesup_conv3x3_wgrad(const float* x, const float* dy, float* dw_kc
 // ---------------------------------------------------------------------------------------------
 struct WinoGeom {
     int H, W, C, Th, Tw;
+    long ps;             // elements between two position planes of the transformed tensor (>= T * C: a sub-batch may
+                         // write its rows into the planes of the whole batch)
     long T;              // tiles = B * Th * Tw
     FastDiv dTw, dTh, dQ;
 };
@@ -1385,7 +1387,7 @@ __global__ __launch_bounds__(256) void wino_input_transform_kernel(const float* 
         m[3][c] = F4(-, d[1][c], d[3][c]);
     }
     float* out = V + (long)t * g.C + 4 * cq;
-    const long ps = g.T * g.C;
+    const long ps = g.ps;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {   // columns: (.) B
         st4(out + (4 * r + 0) * ps, F4(-, m[r][0], m[r][2]));
@@ -1425,7 +1427,7 @@ __global__ __launch_bounds__(256) void wino_outgrad_transform_kernel(const float
         m[3][c] = F4(-, z, y[1][c]);
     }
     float* out = dM + (long)t * g.C + 4 * cq;
-    const long ps = g.T * g.C;
+    const long ps = g.ps;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {   // columns: (.) A^T
         st4(out + (4 * r + 0) * ps, m[r][0]);
@@ -1505,7 +1507,7 @@ extern "C" int wesup_conv3x3_wgrad_winograd(const float* x, const float* v_pre, 
     WinoGeom g;
     g.H = H; g.W = W; g.Th = (H + 1) / 2; g.Tw = (W + 1) / 2; g.T = T;
     g.dTw = make_fastdiv(g.Tw); g.dTh = make_fastdiv(g.Th);
-    g.C = Ci; g.dQ = make_fastdiv(Ci / 4);
+    g.C = Ci; g.dQ = make_fastdiv(Ci / 4); g.ps = T * Ci;
     if (v_pre) {             // the transformed input the Winograd forward of this layer kept
         V = const_cast<float*>(v_pre);
     } else {
@@ -1513,7 +1515,7 @@ extern "C" int wesup_conv3x3_wgrad_winograd(const float* x, const float* v_pre, 
                            g, relu_in);
         WESUP_CHECK_LAUNCH();
     }
-    g.C = Cout; g.dQ = make_fastdiv(Cout / 4);
+    g.C = Cout; g.dQ = make_fastdiv(Cout / 4); g.ps = T * Cout;
     hipLaunchKernelGGL(wino_outgrad_transform_kernel, dim3((unsigned)ceil_div(T * (Cout / 4), 256l)), dim3(256), 0, st, dy,
                        dM, g);
     WESUP_CHECK_LAUNCH();
@@ -1590,7 +1592,7 @@ __global__ __launch_bounds__(256) void wino_output_transform_kernel(const float*
     const int b = fast_div(bi, g.dTh);
     const int i = bi - b * g.Th;
     const float* src = Mt + (long)t * g.C + 4 * cq;
-    const long ps = g.T * g.C;
+    const long ps = g.ps;
 #define F4(op, a, b) make_float4(a.x op b.x, a.y op b.y, a.z op b.z, a.w op b.w)
     float4 s[2][4];      // rows: A^T m
 #pragma unroll
@@ -1660,9 +1662,10 @@ extern "C" size_t wesup_conv3x3_winograd_workspace_bytes(int B, int H, int W, in
     return align_up((size_t)16 * T * Cin * sizeof(float), 256) + align_up((size_t)16 * T * Cout * sizeof(float), 256);
 }
 
-static WinoGeom wino_geom(int B, int H, int W, int C) {
+static WinoGeom wino_geom(int B, int H, int W, int C, long plane_elems = 0) {
     WinoGeom g;
     g.H = H; g.W = W; g.Th = (H + 1) / 2; g.Tw = (W + 1) / 2; g.T = wino_tiles(B, H, W);
+    g.ps = plane_elems > 0 ? plane_elems : g.T * C;
     g.dTw = make_fastdiv(g.Tw); g.dTh = make_fastdiv(g.Th);
     g.C = C; g.dQ = make_fastdiv(C / 4);
     return g;
@@ -1671,9 +1674,12 @@ static WinoGeom wino_geom(int B, int H, int W, int C) {
 // ---- the three passes as entries of their own (the engine calls these, so that the GEMM can be timed apart from the
 // memory-bound transforms); wesup_conv3x3_fwd_winograd / _dgrad_winograd below chain them.
 // x (B,H,W,C) -> V [16][tiles][C]
-extern "C" int wesup_winograd_input_transform(const float* x, float* V, int B, int H, int W, int C, int relu_in, void* stream) {
-    if (!x || !V || !wino_shape_ok(B, H, W, C, C) || (((uintptr_t)x | (uintptr_t)V) & 15)) return WESUP_ERR_INVALID;
-    const WinoGeom g = wino_geom(B, H, W, C);
+extern "C" int wesup_winograd_input_transform(const float* x, float* V, long plane_elems, int B, int H, int W, int C,
+                                              int relu_in, void* stream) {
+    if (!x || !V || !wino_shape_ok(B, H, W, C, C) || (((uintptr_t)x | (uintptr_t)V) & 15) || (plane_elems % 4) ||
+        (plane_elems > 0 && plane_elems < wino_tiles(B, H, W) * C))
+        return WESUP_ERR_INVALID;
+    const WinoGeom g = wino_geom(B, H, W, C, plane_elems);
     hipLaunchKernelGGL(wino_input_transform_kernel, dim3((unsigned)ceil_div(g.T * (C / 4), 256l)), dim3(256), 0,
                        (hipStream_t)stream, x, V, g, relu_in);
     WESUP_CHECK_LAUNCH();
@@ -1681,12 +1687,14 @@ extern "C" int wesup_winograd_input_transform(const float* x, float* V, int B, i
 }
 // Mt [16][tiles][C] -> y (B,H,W,C) = A^T M A + bias, masked by mask_src > 0, added to the old y if accumulate;
 // y_relu: optional second output max(y, 0)
-extern "C" int wesup_winograd_output_transform(const float* Mt, const float* bias, const float* mask_src, float* y,
-                                               float* y_relu, int B, int H, int W, int C, int accumulate, void* stream) {
-    if (!Mt || !y || !wino_shape_ok(B, H, W, C, C) ||
+extern "C" int wesup_winograd_output_transform(const float* Mt, long plane_elems, const float* bias, const float* mask_src,
+                                               float* y, float* y_relu, int B, int H, int W, int C, int accumulate,
+                                               void* stream) {
+    if (!Mt || !y || !wino_shape_ok(B, H, W, C, C) || (plane_elems % 4) ||
+        (plane_elems > 0 && plane_elems < wino_tiles(B, H, W) * C) ||
         (((uintptr_t)Mt | (uintptr_t)y | (uintptr_t)y_relu | (uintptr_t)mask_src | (uintptr_t)bias) & 15))
         return WESUP_ERR_INVALID;
-    const WinoGeom g = wino_geom(B, H, W, C);
+    const WinoGeom g = wino_geom(B, H, W, C, plane_elems);
     hipLaunchKernelGGL(wino_output_transform_kernel, dim3((unsigned)ceil_div(g.T * (C / 4), 256l)), dim3(256), 0,
                        (hipStream_t)stream, Mt, bias, mask_src, y, y_relu, g, accumulate);
     WESUP_CHECK_LAUNCH();
@@ -1721,11 +1729,11 @@ static int wino_conv(const float* in, const float* u, const float* bias, const f
     const long T = wino_tiles(B, H, W);
     float* V = v_keep ? v_keep : (float*)ws;
     float* Mt = (float*)((char*)ws + align_up((size_t)16 * T * Cin * sizeof(float), 256));
-    int rc = wesup_winograd_input_transform(in, V, B, H, W, Cin, relu_in, st);
+    int rc = wesup_winograd_input_transform(in, V, 0, B, H, W, Cin, relu_in, st);
     if (rc) return rc;
     rc = wesup_gemm_nt_batched(V, Cin, T * Cin, u, Cin, (long)Cout * Cin, Mt, Cout, T * Cout, 16, (int)T, Cout, Cin, st);
     if (rc) return rc;
-    return wesup_winograd_output_transform(Mt, bias, mask, out, out_relu, B, H, W, Cout, accum, st);
+    return wesup_winograd_output_transform(Mt, 0, bias, mask, out, out_relu, B, H, W, Cout, accum, st);
 }
 
 extern "C" int wesup_conv3x3_fwd_winograd(const float* x, const float* u_fwd, const float* bias, float* y, float* y_relu,
