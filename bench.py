@@ -49,8 +49,8 @@ def parse_args(argv=None):
     ap.add_argument('--no-kernel-timing', action='store_true')
     ap.add_argument('--streamk', default='', help="A/B: comma list of the uses that get a stream-K tail ('fwd', 'dgrad', "
                                                   "'gemm', or 'all'); default: none (the step runs plain tiling, ops.py)")
-    ap.add_argument('--side-fusion', action='store_true', help='A/B: side convs of the 64/128-channel layers in the conv '
-                                                               'epilogue instead of as GEMMs on the side stream')
+    ap.add_argument('--no-side-fusion', action='store_true', help='A/B: side convs of conv1_1..conv2_1 as GEMMs on the side '
+                                                                  'stream instead of in the conv epilogue')
     ap.add_argument('--direct-conv', action='store_true', help='A/B: forward and input gradient of every conv layer with '
                                                                'the direct implicit-GEMM kernel (no Winograd-domain conv)')
     ap.add_argument('--winograd-pipeline', action='store_true', help='A/B: Winograd-domain convs with the half-batch '
@@ -243,7 +243,7 @@ def worker(args):
     trainer.model.train()
     trainer.tracker.train()
     trainer.model.engine.fuse_pool_bwd = not args.unfused_pool_bwd
-    trainer.model.engine.fuse_side_fwd = args.side_fusion
+    trainer.model.engine.fuse_side_fwd = not args.no_side_fusion
     trainer.model.engine.wgrad_winograd = not args.direct_wgrad
     trainer.model.engine.conv_winograd = not args.direct_conv
     if args.winograd_pipeline:
@@ -379,6 +379,21 @@ def worker(args):
                                'traffic': conv_in.get('hbm_bytes_per_launch'),
                                'avg_launch_us': round(ms / nl * 1e3, 2), 'launches_per_step': nl / n_ev,
                                'flop_per_step': fl / n_ev, 'event_timed_steps': n_ev}
+            # the same conv forward + input-gradient work priced in direct-form FLOPs over GEMM + transform time: what the
+            # Winograd routing buys (a rate above the MFMA peak would be possible here; it is not a utilisation)
+            if 'winograd_transform' in allk:
+                ms_all = sum(allk[t][0] for t in conv_tags + ('winograd_transform',) if t in allk) / n_extra
+                fl_direct = 0.0
+                hh, ww = H, W
+                for l, (ci, co) in enumerate(((3, 64), (64, 64), (64, 128), (128, 128), (128, 256), (256, 256), (256, 256),
+                                              (256, 512), (512, 512), (512, 512), (512, 512), (512, 512), (512, 512))):
+                    fl_direct += 2.0 * B * hh * ww * ci * co * 9 * (2 if l > 0 else 1)
+                    if l in (1, 3, 6, 9):
+                        hh, ww = hh // 2, ww // 2
+                out['roofline']['direct_equivalent'] = {
+                    'what': 'direct-form FLOPs of all conv forward + input-gradient ops of a step / event time of their GEMM '
+                            'and transform launches (extra untimed steps, same 3-stream schedule)',
+                    'tflops': round(fl_direct / (ms_all * 1e-3) / 1e12, 2), 'ms_per_step': round(ms_all, 3)}
             if conv_in:
                 out['roofline']['traffic_how'] = (f"{rin['file']}: rocprofv3 --pmc over this command, FETCH_SIZE x2 (gfx950 "
                                                   'correction) + WRITE_SIZE, separate passes, mean over the conv fwd+dgrad '
@@ -388,7 +403,9 @@ def worker(args):
             if 'conv3x3_wgrad' in allk:
                 ms, n, fl = allk['conv3x3_wgrad']
                 a = fl / (ms * 1e-3) / 1e12
-                out['roofline_wgrad'] = {'bound': 'mfma', 'kernel': 'gemm_tn_kernel + reduce (conv3x3 wgrad)',
+                out['roofline_wgrad'] = {'bound': 'mfma', 'kernel': 'conv3x3 wgrad ops: gemm_tn_kernel + reduce, implicit GEMM for conv1_1..conv2_1, '
+                                                                    'Winograd-domain (outgrad transform + 16 batched TN GEMMs + G^T.G reduce) above; '
+                                                                    'executed FLOPs over the whole op',
                                          'achieved': round(a, 2), 'peak': PEAK_MFMA_F32_TFLOPS, 'unit': 'TFLOP/s',
                                          'frac': round(a / PEAK_MFMA_F32_TFLOPS, 4),
                                          'how': f'{n_extra} extra untimed steps, same 3-stream schedule'}

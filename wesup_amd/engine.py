@@ -114,10 +114,11 @@ class WesupEngine:
         # (alone on the GPU: 3.14 -> 2.11 ms for these nine layers, tools/wino_table.py)
         self.wgrad_winograd = True
         self.conv_winograd = True        # forward / dgrad of the layers with >= 128 input channels likewise
-        # side convs of the 64/128-channel layers inside the conv epilogue: correct and tested, OFF by default -- it
-        # saves the side stream 0.33 ms of GEMMs that ran beside the chain anyway and puts 5-11 % more work on the conv
-        # chain, which is the step's critical path (17.60 -> 17.88 ms)
-        self.fuse_side_fwd = False
+        # side convs of the direct-form layers with <= 128 output channels (conv1_1 ... conv2_1) inside the conv epilogue.
+        # While every conv was an implicit GEMM and the conv chain bound the step this was slower (17.60 -> 17.88 ms: the
+        # epilogue work sat on the chain, the GEMMs it removed had run beside it); with the wide layers in the Winograd
+        # domain the step is the sum of its kernels' times and the fusion wins a little (13.77 -> 13.70 ms, 3 A/B pairs)
+        self.fuse_side_fwd = True
         self.relu_on_store = True        # ReLU'd copies written by the producing kernel instead of ReLU on every load
         self._side_stream = None
         self._wgrad_stream = None
