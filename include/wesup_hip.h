@@ -120,12 +120,15 @@ int wesup_conv3x3_wgrad_winograd(const float* x, const float* v_pre, const float
  * u_fwd [16][Cout][Cin], u_dgrad [16][Cin][Cout] (rotated filter), 16*Cin*Cout floats each.  Workspace: transformed
  * input + transformed output, 16 x tiles x (Cin + Cout) floats (dgrad: ask with the channel counts swapped).
  * v_keep (optional): where the forward leaves V for the weight gradient (16 x tiles x Cin floats).
+ * y_pool (optional): a third output (B, H/2, W/2, Cout) = the 2x2 / stride-2 max-pool that follows the layer
+ * (models/wesup.py:199, torchvision's MaxPool2d(2, 2); a 2x2 output tile is one pooling window), ReLU'd if pool_relu.
  * Cin % 32 == 0, Cout % 4 == 0; the results equal the direct kernels' up to fp32 summation order. */
 size_t wesup_winograd_weight_floats(int Cin, int Cout);
 int wesup_winograd_pack_weight(const float* w_kcrs, float* u_fwd, float* u_dgrad, int Cout, int Cin, void* stream);
 size_t wesup_conv3x3_winograd_workspace_bytes(int B, int H, int W, int Cin, int Cout);
 int wesup_conv3x3_fwd_winograd(const float* x, const float* u_fwd, const float* bias, float* y, float* y_relu,
-                               float* v_keep, int B, int H, int W, int Cin, int Cout, int relu_in,
+                               float* y_pool, int pool_relu, float* v_keep,
+                               int B, int H, int W, int Cin, int Cout, int relu_in,
                                void* ws, size_t ws_bytes, void* stream);
 int wesup_conv3x3_dgrad_winograd(const float* dy, const float* u_dgrad, const float* mask_src, float* dx,
                                  int B, int H, int W, int Cin, int Cout, int accumulate,
@@ -141,7 +144,14 @@ int wesup_winograd_input_transform(const float* x, float* V, long plane_elems, i
 int wesup_gemm_nt_batched(const float* A, int lda, long strideA, const float* B, int ldb, long strideB,
                           float* C, int ldc, long strideC, int nbatch, int M, int N, int K, void* stream);
 int wesup_winograd_output_transform(const float* Mt, long plane_elems, const float* bias, const float* mask_src, float* y,
-                                    float* y_relu, int B, int H, int W, int C, int accumulate, void* stream);
+                                    float* y_relu, float* y_pool, int pool_relu, int B, int H, int W, int C,
+                                    int accumulate, void* stream);
+/* The weight gradient's own transforms: dy (B,H,W,C) -> dM [16][tiles][C] = A dY A^T per 2x2 tile; and the way back from
+ * the split-K slabs of the 16 transformed filter gradients ([16][S][Cout*Cin + Cout], each slab followed by the Cout
+ * column sums of its dM operand) to dw (Cout,Cin,3,3) = G^T (sum over S) G and db = the column sums of position 5. */
+int wesup_winograd_outgrad_transform(const float* dy, float* dM, int B, int H, int W, int C, void* stream);
+int wesup_winograd_filter_grad(const float* slabs, long slab_stride, long batch_stride, int S, float* dw_kcrs, float* db,
+                               int Cout, int Cin, void* stream);
 
 /* ------------------------------------------------------------------ generic fp32 MFMA GEMMs
  * side 1x1 convs (models/wesup.py:208-209,253), fc_layers (models/wesup.py:213-220,288) and their grads.

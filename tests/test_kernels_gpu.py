@@ -187,6 +187,13 @@ def test_conv3x3_fwd_winograd(ops, B, H, W, Cin, Cout, relu_in):
     e_w, e_0 = rel_err(nchw(y), ref), rel_err(nchw(y0), ref)
     assert e_w < max(TOL / 10, 4 * e_0), (e_w, e_0)
     assert torch.equal(yr, torch.relu(y))
+    if H >= 2 and W >= 2:      # the pooled third output = the max-pool kernel on y, bit for bit (odd borders: floor mode)
+        for pool_relu in (False, True):
+            yp = torch.full((B, H // 2, W // 2, Cout), 7.0, device=d)
+            y3 = torch.empty_like(y)
+            ops.conv3x3_fwd_winograd(xg, uf, b.to(d), relu_in, out=y3, out_pool=yp, pool_relu=pool_relu)
+            assert torch.equal(y3, y)
+            assert torch.equal(yp, ops.maxpool2_fwd(y, torch.empty_like(yp), relu=pool_relu))
     y2 = ops.conv3x3_fwd_winograd(xg, uf, None, relu_in)                       # no bias, workspace V
     assert rel_err(nchw(y2), ref - b.double().view(1, -1, 1, 1)) < max(TOL / 10, 4 * e_0)
     dy = rnd(B, Cout, H, W, seed=4)

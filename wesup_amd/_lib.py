@@ -42,11 +42,13 @@ _SIGS = {
     'wesup_winograd_weight_floats': (c_size_t, 'ii'),
     'wesup_winograd_pack_weight': (c_int, 'pppiip'),
     'wesup_conv3x3_winograd_workspace_bytes': (c_size_t, 'iiiii'),
-    'wesup_conv3x3_fwd_winograd': (c_int, 'ppppppiiiiiipzp'),
+    'wesup_conv3x3_fwd_winograd': (c_int, 'ppppppipiiiiiipzp'),
     'wesup_conv3x3_dgrad_winograd': (c_int, 'ppppiiiiiipzp'),
     'wesup_winograd_input_transform': (c_int, 'ppliiiiip'),
     'wesup_gemm_nt_batched': (c_int, 'pilpilpiliiiip'),
-    'wesup_winograd_output_transform': (c_int, 'plppppiiiiip'),
+    'wesup_winograd_output_transform': (c_int, 'plpppppiiiiiip'),
+    'wesup_winograd_outgrad_transform': (c_int, 'ppiiiip'),
+    'wesup_winograd_filter_grad': (c_int, 'pllippiip'),
     'wesup_gemm_nt_workspace_bytes': (c_size_t, 'iii'),
     'wesup_gemm_nt': (c_int, 'pipippipiiiiipzp'),
     'wesup_gemm_tn_workspace_bytes': (c_size_t, 'iii'),

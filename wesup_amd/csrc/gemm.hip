@@ -1332,170 +1332,20 @@ extern "C" int wesup_conv3x3_wgrad(const float* x, const float* dy, float* dw_kc
 
 
 // ---------------------------------------------------------------------------------------------
-// conv3x3 weight gradient in the Winograd F(2x2, 3x3) domain (the same dW as wesup_conv3x3_wgrad; torch autograd of
-// Conv2d(k=3, pad=1) in the reference, models/wesup.py:199; the scheme of the non-fused Winograd backward-filter
-// algorithms of vendor conv libraries).  With  Y = A^T [ (G g G^T) o (B^T d B) ] A  per 2x2 output tile:
-//     V_p[t][ci]  = (B^T d B)_p      d  = the 4x4 input patch of tile t (zero outside the image)      p = 4*xi + nu
-//     dM_p[t][co] = (A dY A^T)_p     dY = the tile's 2x2 output gradients (zero outside)
-//     dU_p[co][ci] = sum_t dM_p[t][co] * V_p[t][ci]          16 independent TN GEMMs with K = #tiles = pixels / 4
-//     dg[co][ci]   = G^T dU G                                 4x4 -> 3x3
-// i.e. 16 x (P/4) = 4 P multiply-adds per (co, ci) pair instead of 9 P: 2.25x less MFMA work for 4x the operand bytes
-// (V and dM are four times the activations) plus two memory-bound transform passes.  It pays where the direct
-// kernel is MFMA-bound and the channel counts make the GEMMs' arithmetic intensity high: the 256/512-channel layers.
-// The bias gradient is the column sum of dM_5 (A dY A^T at (1,1) = the sum of the tile's four gradients).
+// Winograd F(2x2, 3x3)-domain convolutions: the GEMM side.  The transforms between activations / filters and the
+// [16 positions][tiles][C] operands are in winograd.hip (entries wesup_winograd_*); here are the batched products and the
+// three conv passes that chain transforms and products.  Per 2x2 output tile
+//     Y = A^T [ (G g G^T) o (B^T d B) ] A ,
+// so with V = B^T d B and U = G g G^T the sum over input channels is, for each of the 16 positions p, ONE matrix product
+//     forward:          M_p[tiles][Cout] = V_p[tiles][Cin] . U_p[Cout][Cin]^T           (NT, K = Cin)
+//     input gradient:   the same over dy with the rotated filter, channel roles swapped   (NT, K = Cout)
+//     weight gradient:  dU_p[Cout][Cin]  = dM_p[tiles][Cout]^T . V_p[tiles][Cin]         (TN, K = tiles, split-K)
+// i.e. 16 x (P/4) = 4 P multiply-adds per (co, ci) pair instead of 9 P: 2.25x less MFMA work for 4x the operand bytes and
+// two memory-bound transform passes.  It pays where the direct kernel is MFMA-bound and the channel counts make the
+// products' arithmetic intensity high: from 128 input channels up (tools/wino_table.py).
 // ---------------------------------------------------------------------------------------------
-struct WinoGeom {
-    int H, W, C, Th, Tw;
-    long ps;             // elements between two position planes of the transformed tensor (>= T * C: a sub-batch may
-                         // write its rows into the planes of the whole batch)
-    long T;              // tiles = B * Th * Tw
-    FastDiv dTw, dTh, dQ;
-};
+#include "winograd.hpp"
 
-// thread = (tile, 4 channels): 16 float4 loads, B^T d B, 16 float4 stores (c fastest across lanes: coalesced both ways)
-__global__ __launch_bounds__(256) void wino_input_transform_kernel(const float* __restrict__ x, float* __restrict__ V,
-                                                                   const WinoGeom g, int relu) {
-    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
-    const int Q = g.C >> 2;
-    if (idx >= g.T * Q) return;
-    const int t = fast_div((int)idx, g.dQ);
-    const int cq = (int)idx - t * Q;
-    const int bi = fast_div(t, g.dTw);
-    const int j = t - bi * g.Tw;
-    const int b = fast_div(bi, g.dTh);
-    const int i = bi - b * g.Th;
-    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-    float4 d[4][4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int h = 2 * i - 1 + r;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const int w = 2 * j - 1 + c;
-            const bool in = (unsigned)h < (unsigned)g.H && (unsigned)w < (unsigned)g.W;
-            float4 v = in ? ld4(x + (((long)b * g.H + h) * g.W + w) * g.C + 4 * cq) : z;
-            d[r][c] = relu ? relu4(v) : v;
-        }
-    }
-#define F4(op, a, b) make_float4(a.x op b.x, a.y op b.y, a.z op b.z, a.w op b.w)
-    float4 m[4][4];      // rows: B^T d
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        m[0][c] = F4(-, d[0][c], d[2][c]);
-        m[1][c] = F4(+, d[1][c], d[2][c]);
-        m[2][c] = F4(-, d[2][c], d[1][c]);
-        m[3][c] = F4(-, d[1][c], d[3][c]);
-    }
-    float* out = V + (long)t * g.C + 4 * cq;
-    const long ps = g.ps;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {   // columns: (.) B
-        st4(out + (4 * r + 0) * ps, F4(-, m[r][0], m[r][2]));
-        st4(out + (4 * r + 1) * ps, F4(+, m[r][1], m[r][2]));
-        st4(out + (4 * r + 2) * ps, F4(-, m[r][2], m[r][1]));
-        st4(out + (4 * r + 3) * ps, F4(-, m[r][1], m[r][3]));
-    }
-}
-
-// thread = (tile, 4 channels): the tile's 2x2 gradients -> A dY A^T with A = [[1,0],[1,1],[1,-1],[0,-1]]
-__global__ __launch_bounds__(256) void wino_outgrad_transform_kernel(const float* __restrict__ dy, float* __restrict__ dM,
-                                                                     const WinoGeom g) {
-    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
-    const int Q = g.C >> 2;
-    if (idx >= g.T * Q) return;
-    const int t = fast_div((int)idx, g.dQ);
-    const int cq = (int)idx - t * Q;
-    const int bi = fast_div(t, g.dTw);
-    const int j = t - bi * g.Tw;
-    const int b = fast_div(bi, g.dTh);
-    const int i = bi - b * g.Th;
-    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-    float4 y[2][2];
-#pragma unroll
-    for (int r = 0; r < 2; ++r)
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
-            const int h = 2 * i + r, w = 2 * j + c;
-            y[r][c] = (h < g.H && w < g.W) ? ld4(dy + (((long)b * g.H + h) * g.W + w) * g.C + 4 * cq) : z;
-        }
-    float4 m[4][2];      // rows: A dY
-#pragma unroll
-    for (int c = 0; c < 2; ++c) {
-        m[0][c] = y[0][c];
-        m[1][c] = F4(+, y[0][c], y[1][c]);
-        m[2][c] = F4(-, y[0][c], y[1][c]);
-        m[3][c] = F4(-, z, y[1][c]);
-    }
-    float* out = dM + (long)t * g.C + 4 * cq;
-    const long ps = g.ps;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {   // columns: (.) A^T
-        st4(out + (4 * r + 0) * ps, m[r][0]);
-        st4(out + (4 * r + 1) * ps, F4(+, m[r][0], m[r][1]));
-        st4(out + (4 * r + 2) * ps, F4(-, m[r][0], m[r][1]));
-        st4(out + (4 * r + 3) * ps, F4(-, z, m[r][1]));
-    }
-}
-#undef F4
-
-// dw[co][ci][3][3] = G^T (sum_s slab[p][s][co][ci]) G ;  db[co] = sum_s (column sums of dM_5)
-// block = 16 (co, ci) pairs x 16 positions: a thread adds the S split-K slabs of ONE position (a thread per pair walked
-// 16 x S dependent loads -- 512 at conv2_2 -- with only Co*Ci/256 blocks on the chip: 113 us per launch on average,
-// 1.1 ms per step); the 16 sums of a pair meet in LDS and one thread per pair applies G^T (.) G.  Fixed order.
-__global__ __launch_bounds__(256) void wino_wgrad_reduce_kernel(const float* __restrict__ slab, long stride, long batch_slab,
-                                                                float* __restrict__ dw, int Co, int Ci, int S,
-                                                                float* __restrict__ db, int pair_blocks) {
-    __shared__ float us[16][17];
-    const int tid = threadIdx.x;
-    if ((int)blockIdx.x >= pair_blocks) {                // bias gradient: the blocks behind the pair blocks
-        const long m = (long)(blockIdx.x - pair_blocks) * 256 + tid;
-        if (db && m < Co) {
-            float s = 0.f;
-            for (int k = 0; k < S; ++k) s += slab[5 * batch_slab + (long)k * stride + (long)Co * Ci + m];
-            db[m] = s;
-        }
-        return;
-    }
-    const int i = tid & 15, p = tid >> 4;
-    const long idx = (long)blockIdx.x * 16 + i;
-    const bool ok = idx < (long)Co * Ci;
-    float s0 = 0.f, s1 = 0.f;
-    if (ok) {
-        const float* src = slab + p * batch_slab + idx;
-        int k = 0;
-        for (; k + 1 < S; k += 2) { s0 += src[(long)k * stride]; s1 += src[(long)(k + 1) * stride]; }
-        if (k < S) s0 += src[(long)k * stride];
-    }
-    us[p][i] = s0 + s1;
-    __syncthreads();
-    if (tid >= 16 || !ok) return;
-    float r[3][4];       // G^T u
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        const float u0 = us[c][i], u1 = us[4 + c][i], u2 = us[8 + c][i], u3 = us[12 + c][i];
-        const float hs = 0.5f * (u1 + u2), hd = 0.5f * (u1 - u2);
-        r[0][c] = u0 + hs;
-        r[1][c] = hd;
-        r[2][c] = hs + u3;
-    }
-    float* d = dw + idx * 9;
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-        const float hs = 0.5f * (r[a][1] + r[a][2]), hd = 0.5f * (r[a][1] - r[a][2]);
-        d[3 * a + 0] = r[a][0] + hs;
-        d[3 * a + 1] = hd;
-        d[3 * a + 2] = hs + r[a][3];
-    }
-}
-
-static long wino_tiles(int B, int H, int W) { return (long)B * ((H + 1) / 2) * ((W + 1) / 2); }
-static bool wino_shape_ok(int B, int H, int W, int Ci, int Cout) {
-    if (B <= 0 || H <= 0 || W <= 0 || Ci < 32 || Cout < 32 || (Ci % 4) || (Cout % 4)) return false;
-    const long T = wino_tiles(B, H, W);
-    const long cmax = Ci > Cout ? Ci : Cout;
-    // thread index and the FastDiv range (n * d < 2^40, quotient < 2^24)
-    return T < (1l << 24) && T * (cmax / 4) < (1l << 31) && T * (cmax / 4) * (cmax / 4) < (1l << 40);
-}
 // workspace layout: [V: 16 T Ci][dM: 16 T Cout][slabs: 16 S (Cout Ci + Cout)]
 extern "C" size_t wesup_conv3x3_wgrad_winograd_workspace_bytes(int B, int H, int W, int Ci, int Cout) {
     if (!wino_shape_ok(B, H, W, Ci, Cout)) return 0;
@@ -1504,6 +1354,9 @@ extern "C" size_t wesup_conv3x3_wgrad_winograd_workspace_bytes(int B, int H, int
     return align_up((size_t)16 * T * Ci * sizeof(float), 256) + align_up((size_t)16 * T * Cout * sizeof(float), 256) +
            (size_t)16 * pl.S * tn_slab_stride(Cout, pl.Nslab) * sizeof(float);
 }
+// The same dW / db as wesup_conv3x3_wgrad (torch autograd of Conv2d(k=3, pad=1), models/wesup.py:199; the scheme of the
+// non-fused Winograd backward-filter algorithms of vendor conv libraries).  The bias gradient is the column sum of dM at
+// position 5 (A dY A^T at (1,1) = the sum of a tile's four gradients), taken from the staged A tiles of that batch entry.
 extern "C" int wesup_conv3x3_wgrad_winograd(const float* x, const float* v_pre, const float* dy, float* dw_kcrs, float* db,
                                             int B, int H, int W, int Ci, int Cout, int relu_in, void* ws,
                                             size_t ws_bytes, void* stream) {
@@ -1516,156 +1369,21 @@ extern "C" int wesup_conv3x3_wgrad_winograd(const float* x, const float* v_pre, 
     float* V = (float*)ws;
     float* dM = (float*)((char*)ws + align_up((size_t)16 * T * Ci * sizeof(float), 256));
     float* slab = (float*)((char*)dM + align_up((size_t)16 * T * Cout * sizeof(float), 256));
-    WinoGeom g;
-    g.H = H; g.W = W; g.Th = (H + 1) / 2; g.Tw = (W + 1) / 2; g.T = T;
-    g.dTw = make_fastdiv(g.Tw); g.dTh = make_fastdiv(g.Th);
-    g.C = Ci; g.dQ = make_fastdiv(Ci / 4); g.ps = T * Ci;
+    int rc;
     if (v_pre) {             // the transformed input the Winograd forward of this layer kept
         V = const_cast<float*>(v_pre);
-    } else {
-        hipLaunchKernelGGL(wino_input_transform_kernel, dim3((unsigned)ceil_div(T * (Ci / 4), 256l)), dim3(256), 0, st, x, V,
-                           g, relu_in);
-        WESUP_CHECK_LAUNCH();
+    } else if ((rc = wesup_winograd_input_transform(x, V, 0, B, H, W, Ci, relu_in, stream))) {
+        return rc;
     }
-    g.C = Cout; g.dQ = make_fastdiv(Cout / 4); g.ps = T * Cout;
-    hipLaunchKernelGGL(wino_outgrad_transform_kernel, dim3((unsigned)ceil_div(T * (Cout / 4), 256l)), dim3(256), 0, st, dy,
-                       dM, g);
-    WESUP_CHECK_LAUNCH();
+    if ((rc = wesup_winograd_outgrad_transform(dy, dM, B, H, W, Cout, stream))) return rc;
     const TnPlan pl = plan_tn(Cout, Ci, (int)T, 1, 16);
     TnParams p = {};
     p.A = dM; p.Bx = V; p.slab = slab; p.M = Cout; p.N = Ci; p.K = (int)T; p.lda = Cout; p.ldb = Ci;
     p.relu_b = 0; p.H = 1; p.W = 1; p.dW = make_fastdiv(1); p.dH = make_fastdiv(1);
     p.slab_stride = (long)tn_slab_stride(Cout, pl.Nslab); p.want_colsum = db != nullptr; p.colsum_batch = 5;
     p.batchA = T * Cout; p.batchB = T * Ci; p.batch_slab = (long)pl.S * p.slab_stride;
-    const int rc = launch_tn<3>(p, pl, st, 16);
-    if (rc) return rc;
-    const long tot = (long)Cout * Ci;
-    const int pair_blocks = (int)((tot + 15) / 16);
-    hipLaunchKernelGGL(wino_wgrad_reduce_kernel, dim3((unsigned)(pair_blocks + (Cout + 255) / 256)), dim3(256), 0, st,
-                       (const float*)slab, p.slab_stride, p.batch_slab, dw_kcrs, Cout, Ci, pl.S, db, pair_blocks);
-    WESUP_CHECK_LAUNCH();
-    return WESUP_OK;
-}
-
-
-// ---------------------------------------------------------------------------------------------
-// conv3x3 forward / input gradient in the Winograd F(2x2, 3x3) domain for the deep layers (256/512 channels at
-// 120^2 and below), where the channel counts make the 16 per-position GEMMs (tiles x Cin) . (Cout x Cin)^T efficient
-// and the 4x larger transformed tensors small:   V = B^T d B  ->  M_p = V_p . U_p^T  ->  Y = A^T M A (+ epilogue).
-// U = G g G^T per (co, ci) is re-derived from the weights once per step (pack kernel below); the input gradient is
-// the same pipeline over dy with the filter rotated by 180 degrees and its channel roles swapped.
-// ---------------------------------------------------------------------------------------------
-// mode 0: U[p][co][ci] (forward);  mode 1: Ud[p][ci][co] from the rotated filter (dgrad).  thread = one (row, col)
-// of the output matrix, col fastest (coalesced stores)
-__global__ void wino_weight_transform_kernel(const float* __restrict__ w, float* __restrict__ U, int Co, int Ci, int mode) {
-    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (long)Co * Ci) return;
-    int co, ci;
-    if (mode == 0) { co = idx / Ci; ci = idx - (long)co * Ci; }
-    else { ci = idx / Co; co = idx - (long)ci * Co; }
-    const float* gsrc = w + ((long)co * Ci + ci) * 9;
-    float g[3][3];
-#pragma unroll
-    for (int a = 0; a < 3; ++a)
-#pragma unroll
-        for (int b = 0; b < 3; ++b) g[a][b] = mode == 0 ? gsrc[3 * a + b] : gsrc[8 - (3 * a + b)];
-    float r[4][3];       // G g
-#pragma unroll
-    for (int b = 0; b < 3; ++b) {
-        const float hs = 0.5f * (g[0][b] + g[2][b]), hm = 0.5f * g[1][b];
-        r[0][b] = g[0][b];
-        r[1][b] = hs + hm;
-        r[2][b] = hs - hm;
-        r[3][b] = g[2][b];
-    }
-    const long ps = (long)Co * Ci;
-    float* out = U + idx;
-#pragma unroll
-    for (int a = 0; a < 4; ++a) {   // (.) G^T
-        const float hs = 0.5f * (r[a][0] + r[a][2]), hm = 0.5f * r[a][1];
-        out[(4 * a + 0) * ps] = r[a][0];
-        out[(4 * a + 1) * ps] = hs + hm;
-        out[(4 * a + 2) * ps] = hs - hm;
-        out[(4 * a + 3) * ps] = r[a][2];
-    }
-}
-
-// thread = (tile, 4 channels): Y = A^T M A for the tile's 2x2 outputs, then the conv epilogue (bias / mask /
-// accumulate / second ReLU'd output) on the pixels inside the image
-__global__ __launch_bounds__(256) void wino_output_transform_kernel(const float* __restrict__ Mt, const float* __restrict__ bias,
-                                                                    const float* __restrict__ mask, float* __restrict__ y,
-                                                                    float* __restrict__ y_relu, const WinoGeom g, int accum) {
-    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
-    const int Q = g.C >> 2;
-    if (idx >= g.T * Q) return;
-    const int t = fast_div((int)idx, g.dQ);
-    const int cq = (int)idx - t * Q;
-    const int bi = fast_div(t, g.dTw);
-    const int j = t - bi * g.Tw;
-    const int b = fast_div(bi, g.dTh);
-    const int i = bi - b * g.Th;
-    const float* src = Mt + (long)t * g.C + 4 * cq;
-    const long ps = g.ps;
-#define F4(op, a, b) make_float4(a.x op b.x, a.y op b.y, a.z op b.z, a.w op b.w)
-    float4 s[2][4];      // rows: A^T m
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        const float4 m0 = ld4(src + (0 + c) * ps), m1 = ld4(src + (4 + c) * ps), m2 = ld4(src + (8 + c) * ps),
-                     m3 = ld4(src + (12 + c) * ps);
-        const float4 t12 = F4(+, m1, m2), d12 = F4(-, m1, m2);
-        s[0][c] = F4(+, m0, t12);
-        s[1][c] = F4(-, d12, m3);
-    }
-    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (bias) bv = ld4(bias + 4 * cq);
-#pragma unroll
-    for (int r = 0; r < 2; ++r) {
-        const int h = 2 * i + r;
-        if (h >= g.H) break;
-        const float4 t12 = F4(+, s[r][1], s[r][2]), d12 = F4(-, s[r][1], s[r][2]);
-        float4 o[2];
-        o[0] = F4(+, s[r][0], t12);
-        o[1] = F4(-, d12, s[r][3]);
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
-            const int w = 2 * j + c;
-            if (w >= g.W) break;
-            const long off = (((long)b * g.H + h) * g.W + w) * g.C + 4 * cq;
-            float4 v = F4(+, o[c], bv);
-            if (mask) {
-                const float4 mk = ld4(mask + off);
-                v.x = mk.x > 0.f ? v.x : 0.f; v.y = mk.y > 0.f ? v.y : 0.f;
-                v.z = mk.z > 0.f ? v.z : 0.f; v.w = mk.w > 0.f ? v.w : 0.f;
-            }
-            if (accum) {
-                const float4 old = ld4(y + off);
-                v = F4(+, v, old);
-            }
-            st4(y + off, v);
-            if (y_relu) st4(y_relu + off, relu4(v));
-        }
-    }
-#undef F4
-}
-
-extern "C" size_t wesup_winograd_weight_floats(int Cin, int Cout) { return (size_t)16 * Cin * Cout; }
-
-// w (Cout,Cin,3,3) -> u_fwd [16][Cout][Cin] and/or u_dgrad [16][Cin][Cout] (either may be NULL)
-extern "C" int wesup_winograd_pack_weight(const float* w, float* u_fwd, float* u_dgrad, int Cout, int Cin, void* stream) {
-    if (!w || Cout <= 0 || Cin <= 0 || (!u_fwd && !u_dgrad)) return WESUP_ERR_INVALID;
-    const long tot = (long)Cout * Cin;
-    hipStream_t st = (hipStream_t)stream;
-    if (u_fwd) {
-        hipLaunchKernelGGL(wino_weight_transform_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, w, u_fwd, Cout,
-                           Cin, 0);
-        WESUP_CHECK_LAUNCH();
-    }
-    if (u_dgrad) {
-        hipLaunchKernelGGL(wino_weight_transform_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, w, u_dgrad, Cout,
-                           Cin, 1);
-        WESUP_CHECK_LAUNCH();
-    }
-    return WESUP_OK;
+    if ((rc = launch_tn<3>(p, pl, st, 16))) return rc;
+    return wesup_winograd_filter_grad(slab, p.slab_stride, p.batch_slab, pl.S, dw_kcrs, db, Cout, Ci, stream);
 }
 
 // workspace of one forward / dgrad call: [V: 16 T Cin][M: 16 T Cout] (for dgrad ask with the channel counts swapped)
@@ -1675,44 +1393,6 @@ extern "C" size_t wesup_conv3x3_winograd_workspace_bytes(int B, int H, int W, in
     return align_up((size_t)16 * T * Cin * sizeof(float), 256) + align_up((size_t)16 * T * Cout * sizeof(float), 256);
 }
 
-static WinoGeom wino_geom(int B, int H, int W, int C, long plane_elems = 0) {
-    WinoGeom g;
-    g.H = H; g.W = W; g.Th = (H + 1) / 2; g.Tw = (W + 1) / 2; g.T = wino_tiles(B, H, W);
-    g.ps = plane_elems > 0 ? plane_elems : g.T * C;
-    g.dTw = make_fastdiv(g.Tw); g.dTh = make_fastdiv(g.Th);
-    g.C = C; g.dQ = make_fastdiv(C / 4);
-    return g;
-}
-
-// ---- the three passes as entries of their own (the engine calls these, so that the GEMM can be timed apart from the
-// memory-bound transforms); wesup_conv3x3_fwd_winograd / _dgrad_winograd below chain them.
-// x (B,H,W,C) -> V [16][tiles][C]
-extern "C" int wesup_winograd_input_transform(const float* x, float* V, long plane_elems, int B, int H, int W, int C,
-                                              int relu_in, void* stream) {
-    if (!x || !V || !wino_shape_ok(B, H, W, C, C) || (((uintptr_t)x | (uintptr_t)V) & 15) || (plane_elems % 4) ||
-        (plane_elems > 0 && plane_elems < wino_tiles(B, H, W) * C))
-        return WESUP_ERR_INVALID;
-    const WinoGeom g = wino_geom(B, H, W, C, plane_elems);
-    hipLaunchKernelGGL(wino_input_transform_kernel, dim3((unsigned)ceil_div(g.T * (C / 4), 256l)), dim3(256), 0,
-                       (hipStream_t)stream, x, V, g, relu_in);
-    WESUP_CHECK_LAUNCH();
-    return WESUP_OK;
-}
-// Mt [16][tiles][C] -> y (B,H,W,C) = A^T M A + bias, masked by mask_src > 0, added to the old y if accumulate;
-// y_relu: optional second output max(y, 0)
-extern "C" int wesup_winograd_output_transform(const float* Mt, long plane_elems, const float* bias, const float* mask_src,
-                                               float* y, float* y_relu, int B, int H, int W, int C, int accumulate,
-                                               void* stream) {
-    if (!Mt || !y || !wino_shape_ok(B, H, W, C, C) || (plane_elems % 4) ||
-        (plane_elems > 0 && plane_elems < wino_tiles(B, H, W) * C) ||
-        (((uintptr_t)Mt | (uintptr_t)y | (uintptr_t)y_relu | (uintptr_t)mask_src | (uintptr_t)bias) & 15))
-        return WESUP_ERR_INVALID;
-    const WinoGeom g = wino_geom(B, H, W, C, plane_elems);
-    hipLaunchKernelGGL(wino_output_transform_kernel, dim3((unsigned)ceil_div(g.T * (C / 4), 256l)), dim3(256), 0,
-                       (hipStream_t)stream, Mt, bias, mask_src, y, y_relu, g, accumulate);
-    WESUP_CHECK_LAUNCH();
-    return WESUP_OK;
-}
 // nbatch products C_b[M][N] = A_b[M][K] . B_b[N][K]^T of one shape in one launch (element strides between the entries)
 extern "C" int wesup_gemm_nt_batched(const float* A, int lda, long strideA, const float* Bw, int ldb, long strideB, float* C,
                                      int ldc, long strideC, int nbatch, int M, int N, int K, void* stream) {
@@ -1733,8 +1413,8 @@ extern "C" int wesup_gemm_nt_batched(const float* A, int lda, long strideA, cons
 // in (B,H,W,Cin) --Winograd conv with u [16][Cout][Cin]--> out (B,H,W,Cout) with the conv epilogue.
 // v_keep (optional): the transformed input is written there instead of the workspace (16 T Cin floats).
 static int wino_conv(const float* in, const float* u, const float* bias, const float* mask, float* out, float* out_relu,
-                     float* v_keep, int B, int H, int W, int Cin, int Cout, int relu_in, int accum, void* ws,
-                     size_t ws_bytes, void* st) {
+                     float* out_pool, int pool_relu, float* v_keep, int B, int H, int W, int Cin, int Cout, int relu_in,
+                     int accum, void* ws, size_t ws_bytes, void* st) {
     if (!in || !u || !out || !ws || !wino_shape_ok(B, H, W, Cin, Cout) || (Cin % 32) ||
         (((uintptr_t)u | (uintptr_t)v_keep | (uintptr_t)ws) & 15))
         return WESUP_ERR_INVALID;
@@ -1746,19 +1426,20 @@ static int wino_conv(const float* in, const float* u, const float* bias, const f
     if (rc) return rc;
     rc = wesup_gemm_nt_batched(V, Cin, T * Cin, u, Cin, (long)Cout * Cin, Mt, Cout, T * Cout, 16, (int)T, Cout, Cin, st);
     if (rc) return rc;
-    return wesup_winograd_output_transform(Mt, 0, bias, mask, out, out_relu, B, H, W, Cout, accum, st);
+    return wesup_winograd_output_transform(Mt, 0, bias, mask, out, out_relu, out_pool, pool_relu, B, H, W, Cout, accum, st);
 }
 
 extern "C" int wesup_conv3x3_fwd_winograd(const float* x, const float* u_fwd, const float* bias, float* y, float* y_relu,
-                                          float* v_keep, int B, int H, int W, int Cin, int Cout, int relu_in, void* ws,
-                                          size_t ws_bytes, void* stream) {
-    return wino_conv(x, u_fwd, bias, nullptr, y, y_relu, v_keep, B, H, W, Cin, Cout, relu_in, 0, ws, ws_bytes, stream);
+                                          float* y_pool, int pool_relu, float* v_keep, int B, int H, int W, int Cin,
+                                          int Cout, int relu_in, void* ws, size_t ws_bytes, void* stream) {
+    return wino_conv(x, u_fwd, bias, nullptr, y, y_relu, y_pool, pool_relu, v_keep, B, H, W, Cin, Cout, relu_in, 0, ws,
+                     ws_bytes, stream);
 }
 
 // dx = conv_transpose(dy) through the same pipeline: input dy (Cout channels), filter u_dgrad [16][Cin][Cout]
 extern "C" int wesup_conv3x3_dgrad_winograd(const float* dy, const float* u_dgrad, const float* mask_src, float* dx, int B,
                                             int H, int W, int Cin, int Cout, int accumulate, void* ws, size_t ws_bytes,
                                             void* stream) {
-    return wino_conv(dy, u_dgrad, nullptr, mask_src, dx, nullptr, nullptr, B, H, W, Cout, Cin, 0, accumulate, ws, ws_bytes,
-                     stream);
+    return wino_conv(dy, u_dgrad, nullptr, mask_src, dx, nullptr, nullptr, 0, nullptr, B, H, W, Cout, Cin, 0, accumulate, ws,
+                     ws_bytes, stream);
 }

@@ -384,8 +384,11 @@ class WesupEngine:
                 if train and b.V[l] is None:         # the transformed input, kept for the weight gradient
                     b.V[l] = torch.empty(16, ops.winograd_tiles(B, h, w), ci, dtype=torch.float32, device=self.device)
                 # timed as 'winograd_gemm' (executed MFMA FLOPs: 4/9 of the direct form's) + 'winograd_transform' (bytes)
+                # (a 2x2 output tile is one window of the max-pool behind conv2_2 / conv3_3 / conv4_3: the output transform
+                # writes the pooled tensor too and the max-pool launch below is skipped)
                 ops.conv3x3_fwd_winograd(cur, pk.uf[l], p[f'backbone.{idx}.bias'], relu_in=cur_relu, out=b.y[l],
-                                         out_relu=yr, v_keep=b.V[l] if train else None, ws_tag='wino_main', timer=T)
+                                         out_relu=yr, v_keep=b.V[l] if train else None, ws_tag='wino_main', timer=T,
+                                         out_pool=b.yp[l] if POOL_AFTER[l] else None, pool_relu=b.relu_stored)
             else:
                 tok = T.begin('conv3x3_fwd')
                 ops.conv3x3_fwd(cur, pk.wf[l], p[f'backbone.{idx}.bias'], co, relu_in=cur_relu, out=b.y[l], out_relu=yr,
@@ -414,7 +417,8 @@ class WesupEngine:
                     ops.upsample_fwd(b.s[l], b.fm, off)
                     T.end(tok, 4.0 * B * H * W * (co // 2))
             if POOL_AFTER[l]:
-                ops.maxpool2_fwd(b.y[l], b.yp[l], relu=b.relu_stored)
+                if not self._wino(l):
+                    ops.maxpool2_fwd(b.y[l], b.yp[l], relu=b.relu_stored)
                 cur, cur_relu = b.yp[l], not b.relu_stored
             elif yr is not None:
                 cur, cur_relu = yr, False

@@ -239,7 +239,8 @@ def _aux_stream(device):
     return main, st
 
 
-def _winograd_conv(inp, u, bias, mask_src, out, out_relu, v_keep, relu_in, accumulate, ws_tag, timer):
+def _winograd_conv(inp, u, bias, mask_src, out, out_relu, v_keep, relu_in, accumulate, ws_tag, timer, out_pool=None,
+                   pool_relu=False):
     """The three passes of a Winograd-domain conv (input transform, 16 batched NT GEMMs, output transform + epilogue).
     timer (optional, engine.KernelTimer-like): the GEMM and the two transforms are bracketed as classes of their own.
 
@@ -283,9 +284,9 @@ def _winograd_conv(inp, u, bias, mask_src, out, out_relu, v_keep, relu_in, accum
         sl = slice(b0, b0 + nb_)
         _lib.call('wesup_winograd_output_transform', ctypes.c_void_p(Mt.data_ptr() + 4 * t0 * Cout), T * Cout, _p(bias),
                   _p(None if mask_src is None else mask_src[sl]), _p(out[sl]), _p(None if out_relu is None else out_relu[sl]),
-                  nb_, H, W, Cout, int(accumulate), st)
+                  _p(None if out_pool is None else out_pool[sl]), int(pool_relu), nb_, H, W, Cout, int(accumulate), st)
         if timer:
-            timer.end(tok, 4.0 * (4 + n_io) * nb_ * H * W * Cout)
+            timer.end(tok, 4.0 * (4 + n_io + (0.25 if out_pool is not None else 0)) * nb_ * H * W * Cout)
 
     half_blocks = ((T // 2 + 127) // 128) * ((Cout + 127) // 128) * 16
     if not (PIPELINE_WINOGRAD and B % 2 == 0 and half_blocks >= PIPELINE_MIN_BLOCKS):
@@ -313,8 +314,10 @@ def _winograd_conv(inp, u, bias, mask_src, out, out_relu, v_keep, relu_in, accum
     return out
 
 
-def conv3x3_fwd_winograd(x, u_fwd, bias, relu_in, out=None, out_relu=None, v_keep=None, ws_tag='default', timer=None):
-    """conv3x3_fwd through the Winograd domain (deep layers); v_keep (16, tiles, Cin) receives the transformed input."""
+def conv3x3_fwd_winograd(x, u_fwd, bias, relu_in, out=None, out_relu=None, v_keep=None, ws_tag='default', timer=None,
+                         out_pool=None, pool_relu=False):
+    """conv3x3_fwd through the Winograd domain (deep layers); v_keep (16, tiles, Cin) receives the transformed input;
+    out_pool (B, H//2, W//2, Cout) the 2x2 max-pool of the output (ReLU'd if pool_relu), written by the output transform."""
     _chk(x, name='x'); _chk(u_fwd, name='u_fwd')
     B, H, W, Cin = x.shape
     Cout = u_fwd.shape[1]
@@ -328,7 +331,9 @@ def conv3x3_fwd_winograd(x, u_fwd, bias, relu_in, out=None, out_relu=None, v_kee
         _chk(out_relu, name='out_relu'); assert out_relu.shape == out.shape
     if v_keep is not None:
         _chk(v_keep, name='v_keep'); assert v_keep.numel() == 16 * winograd_tiles(B, H, W) * Cin
-    return _winograd_conv(x, u_fwd, bias, None, out, out_relu, v_keep, relu_in, False, ws_tag, timer)
+    if out_pool is not None:
+        _chk(out_pool, name='out_pool'); assert out_pool.shape == (B, H // 2, W // 2, Cout) and out_pool.is_contiguous()
+    return _winograd_conv(x, u_fwd, bias, None, out, out_relu, v_keep, relu_in, False, ws_tag, timer, out_pool, pool_relu)
 
 
 def conv3x3_dgrad_winograd(dy, u_dgrad, mask_src=None, out=None, accumulate=False, ws_tag='default', timer=None):
