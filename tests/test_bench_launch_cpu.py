@@ -18,7 +18,10 @@ def _env():
 
 
 def _one_json_line(stdout):
-    lines = [l for l in stdout.splitlines() if l.strip() and not l.startswith('[Gloo]')]     # gloo's own chatter
+    # gloo prints its own connection chatter on the ranks' stdout at rendezvous ("[Gloo] Rank 0 is connected to ..."), and
+    # the lines of two ranks can interleave into fragments that no longer start with "[Gloo]"; the benchmark's line is the
+    # one that is a JSON object (RCCL, the backend of the GPU runs, prints nothing)
+    lines = [l for l in stdout.splitlines() if l.startswith('{')]
     assert len(lines) == 1, stdout
     return json.loads(lines[0])
 
