@@ -58,7 +58,7 @@ def parse_args(argv=None):
     ap.add_argument('--direct-wgrad', action='store_true', help='A/B: every conv weight gradient with the direct '
                                                                 'implicit-GEMM kernel (no Winograd-domain wgrad)')
     ap.add_argument('--event-every', type=int, default=4, help='steps of the timed region that carry HIP events: every n-th')
-    ap.add_argument('--timed-classes', default='conv3x3_fwd,conv3x3_dgrad,winograd_gemm',
+    ap.add_argument('--timed-classes', default='conv3x3_fwd,conv3x3_dgrad,winograd_gemm,winograd_transform',
                     help="kernel classes that get HIP events inside the timed region ('all', 'none' or a comma list); an "
                          "event record fences its queue, so only the dominant kernel is timed there by default and the "
                          "other classes are timed in extra untimed steps")
@@ -362,38 +362,47 @@ def worker(args):
                     kern[tag]['tflops'] = round(work / (ms * 1e-3) / 1e12, 2)
                 elif work > 0:
                     kern[tag]['gbs'] = round(work / (ms * 1e-3) / 1e9, 1)
-            # dominant kernel: gemm_nt_kernel, the GEMM of every conv forward and input gradient -- the implicit-GEMM form
+            # Dominant kernel: gemm_nt_kernel, the GEMM of every conv forward and input gradient -- the implicit-GEMM form
             # (MODE 1/2) for the 3/64-channel layers, the 16-position batched form (MODE 3) over Winograd-domain operands
-            # for the layers with >= 128 input channels.  FLOPs = what the MFMA pipe executes (the Winograd form needs
-            # 4/9 of the direct form's).
-            conv_tags = ('conv3x3_fwd', 'conv3x3_dgrad', 'winograd_gemm')
-            ms = sum(tot[t][0] for t in conv_tags if t in tot)
-            fl = sum(tot[t][2] for t in conv_tags if t in tot)
-            nl = sum(tot[t][1] for t in conv_tags if t in tot)
-            ach = fl / (ms * 1e-3) / 1e12
+            # for the layers with >= 128 input channels, whose two memory-bound transform passes per op belong to the same
+            # work.  `achieved` follows SURVEY.md 8(d): ALGORITHMIC FLOPs of the conv forward + input gradient (direct form,
+            # 2*H*W*Cin*Cout*9 per layer and pass) over the event time of every launch that carries them out (GEMMs and
+            # transforms).  `mfma_executed` is the matrix-core view of the GEMM launches alone: the FLOPs the MFMA pipe
+            # executes (the Winograd form needs 4/9 of the direct form's) over their event time.
+            gemm_tags = ('conv3x3_fwd', 'conv3x3_dgrad', 'winograd_gemm')
+            conv_tags = gemm_tags + ('winograd_transform',)
+            if any(t in allk and t not in tot for t in conv_tags):          # a class was left out of --timed-classes
+                tot, n_ev = allk, n_extra
+            ms_gemm = sum(tot[t][0] for t in gemm_tags if t in tot)
+            fl_exec = sum(tot[t][2] for t in gemm_tags if t in tot)
+            nl = sum(tot[t][1] for t in gemm_tags if t in tot)
+            ms_all = sum(tot[t][0] for t in conv_tags if t in tot)
+            fl_alg, hh, ww = 0.0, H, W
+            for l, (ci, co) in enumerate(((3, 64), (64, 64), (64, 128), (128, 128), (128, 256), (256, 256), (256, 256),
+                                          (256, 512), (512, 512), (512, 512), (512, 512), (512, 512), (512, 512))):
+                fl_alg += 2.0 * B * hh * ww * ci * co * 9 * (2 if l > 0 else 1)          # conv1_1 has no input gradient
+                if l in (1, 3, 6, 9):
+                    hh, ww = hh // 2, ww // 2
+            ach = fl_alg * n_ev / (ms_all * 1e-3) / 1e12
+            ach_exec = fl_exec / (ms_gemm * 1e-3) / 1e12
             conv_in = (rin or {}).get('conv3x3_fwd_dgrad', {})
-            out['roofline'] = {'bound': 'mfma', 'kernel': 'gemm_nt_kernel (conv3x3 fwd+dgrad GEMMs: implicit GEMM for conv1_1..conv2_1, '
-                                                          'batched Winograd-domain GEMMs for conv2_2..conv5_3; fp32 MFMA 32x32x2)',
+            out['roofline'] = {'bound': 'mfma',
+                               'kernel': 'gemm_nt_kernel (conv3x3 fwd+dgrad: implicit GEMM for conv1_1..conv2_1, 16-position batched '
+                                         'GEMMs over Winograd F(2x2,3x3)-domain operands for conv2_2..conv5_3; fp32 MFMA 32x32x2) '
+                                         '+ the Winograd transform passes of the same ops',
                                'achieved': round(ach, 2), 'peak': PEAK_MFMA_F32_TFLOPS, 'unit': 'TFLOP/s',
                                'frac': round(ach / PEAK_MFMA_F32_TFLOPS, 4),
                                'traffic': conv_in.get('hbm_bytes_per_launch'),
-                               'avg_launch_us': round(ms / nl * 1e3, 2), 'launches_per_step': nl / n_ev,
-                               'flop_per_step': fl / n_ev, 'event_timed_steps': n_ev}
-            # the same conv forward + input-gradient work priced in direct-form FLOPs over GEMM + transform time: what the
-            # Winograd routing buys (a rate above the MFMA peak would be possible here; it is not a utilisation)
-            if 'winograd_transform' in allk:
-                ms_all = sum(allk[t][0] for t in conv_tags + ('winograd_transform',) if t in allk) / n_extra
-                fl_direct = 0.0
-                hh, ww = H, W
-                for l, (ci, co) in enumerate(((3, 64), (64, 64), (64, 128), (128, 128), (128, 256), (256, 256), (256, 256),
-                                              (256, 512), (512, 512), (512, 512), (512, 512), (512, 512), (512, 512))):
-                    fl_direct += 2.0 * B * hh * ww * ci * co * 9 * (2 if l > 0 else 1)
-                    if l in (1, 3, 6, 9):
-                        hh, ww = hh // 2, ww // 2
-                out['roofline']['direct_equivalent'] = {
-                    'what': 'direct-form FLOPs of all conv forward + input-gradient ops of a step / event time of their GEMM '
-                            'and transform launches (extra untimed steps, same 3-stream schedule)',
-                    'tflops': round(fl_direct / (ms_all * 1e-3) / 1e12, 2), 'ms_per_step': round(ms_all, 3)}
+                               'avg_launch_us': round(ms_gemm / nl * 1e3, 2), 'launches_per_step': nl / n_ev,
+                               'flop_per_step': fl_alg, 'event_timed_steps': n_ev,
+                               'what': 'SURVEY 8(d) algorithmic (direct-form) FLOPs of all conv forward + input-gradient ops / HIP-event '
+                                       'time of their GEMM and transform launches; avg_launch_us / launches_per_step / traffic are '
+                                       'the GEMM launches\' (the kernel rocprofv3 --stats lists as gemm_nt_kernel<..,1|2|3,..>)',
+                               'ms_per_step': {'gemm': round(ms_gemm / n_ev, 3), 'transforms': round((ms_all - ms_gemm) / n_ev, 3)},
+                               'mfma_executed': {'what': 'FLOPs the MFMA pipe executes in the GEMM launches (Winograd: 4/9 of the direct '
+                                                         'form) / their event time',
+                                                 'achieved': round(ach_exec, 2), 'frac': round(ach_exec / PEAK_MFMA_F32_TFLOPS, 4),
+                                                 'flop_per_step': fl_exec / n_ev}}
             if conv_in:
                 out['roofline']['traffic_how'] = (f"{rin['file']}: rocprofv3 --pmc over this command, FETCH_SIZE x2 (gfx950 "
                                                   'correction) + WRITE_SIZE, separate passes, mean over the conv fwd+dgrad '
@@ -423,7 +432,7 @@ def worker(args):
                          'sp_pool_mat_fwd', 'upsample_mat_bwd')
             fl_step = sum(allk[t][2] for t in gemm_tags if t in allk) / n_extra
             a = fl_step / (ms_per_step * 1e-3) / 1e12
-            out['roofline_step'] = {'bound': 'mfma', 'what': 'all GEMM FLOPs of one step / wall time of the step (3 streams)',
+            out['roofline_step'] = {'bound': 'mfma', 'what': 'all GEMM FLOPs one step EXECUTES (Winograd-domain passes: 4/9 of the direct form) / wall time of the step (3 streams)',
                                     'achieved': round(a, 2), 'peak': PEAK_MFMA_F32_TFLOPS, 'unit': 'TFLOP/s',
                                     'frac': round(a / PEAK_MFMA_F32_TFLOPS, 4), 'flop_per_step': fl_step}
             out['kernels_how'] = (f'{n_extra} extra untimed steps with events on every kernel class (same 3-stream '
@@ -433,11 +442,12 @@ def worker(args):
                     ms = sum(iso[t][0] for t in tags if t in iso)
                     fl = sum(iso[t][2] for t in tags if t in iso)
                     return round(fl / (ms * 1e-3) / 1e12, 2) if ms > 0 else None
-                a, wgr = tf(('conv3x3_fwd', 'conv3x3_dgrad', 'winograd_gemm')), tf(('conv3x3_wgrad',))
+                a, wgr = tf(('conv3x3_fwd', 'conv3x3_dgrad', 'winograd_gemm')), tf(('conv3x3_wgrad',))       # executed FLOPs
                 out['roofline_isolated'] = {
                     'how': '2 extra untimed steps with single-stream scheduling and the stream-K tail on (what a kernel alone on the GPU '
                            'gains from; the 3-stream step runs plain tiling, wesup_amd/ops.py), HIP events per launch',
                     'ms_per_step': {k: round(v[0] / 2, 3) for k, v in sorted(iso.items())},
+                    'flops': 'executed (GEMM launches only; Winograd-domain passes run 4/9 of the direct form)',
                     'conv3x3_fwd_dgrad': {'bound': 'mfma', 'achieved': a, 'peak': PEAK_MFMA_F32_TFLOPS, 'unit': 'TFLOP/s',
                                           'frac': round(a / PEAK_MFMA_F32_TFLOPS, 4)},
                     'conv3x3_wgrad': {'bound': 'mfma', 'achieved': wgr, 'peak': PEAK_MFMA_F32_TFLOPS, 'unit': 'TFLOP/s',
