@@ -203,6 +203,64 @@ def test_conv3x3_fwd_winograd(ops, B, H, W, Cin, Cout, relu_in):
     assert torch.equal(dw1, dw2) and torch.equal(db1, db2)
 
 
+@pytest.mark.parametrize('B,H,W,Ci,Co', [(2, 7, 9, 32, 64), (1, 12, 12, 64, 32), (3, 5, 4, 128, 128)])
+def test_winograd_building_blocks_match_the_numpy_oracle(ops, B, H, W, Ci, Co):
+    """Every stage entry on its own against oracle/winograd_oracle.py (itself checked against torch's Conv2d and autograd
+    in tests/test_winograd_oracle_cpu.py): the two activation transforms, the filter transforms, the batched product,
+    the output transform with each epilogue option, and the way back from split-K slabs to (dw, db)."""
+    from oracle import winograd_oracle as wo
+    d = dev()
+    f32 = np.float32
+    x = nhwc(rnd(B, Ci, H, W, seed=1))
+    dy = nhwc(rnd(B, Co, H, W, seed=2))
+    w = rnd(Co, Ci, 3, 3, seed=3, scale=0.1)
+    bias = rnd(Co, seed=4)
+    xg, dyg = x.to(d), dy.to(d)
+    T = wo.tiles(B, H, W)
+    # transforms (adds and halves only: fp32 results equal the fp32 oracle to rounding of differently ordered sums)
+    for relu in (False, True):
+        V = ops.winograd_input_transform(xg, relu=relu)
+        assert V.shape == (16, T, Ci)
+        assert np.abs(V.cpu().numpy() - wo.input_transform(x.numpy(), relu)).max() < 1e-5
+    dM = ops.winograd_outgrad_transform(dyg)
+    assert np.abs(dM.cpu().numpy() - wo.outgrad_transform(dy.numpy())).max() < 1e-5
+    uf, ud = ops.winograd_pack_weight(w.to(d))
+    uf_o, ud_o = wo.pack_weight(w.numpy())
+    assert np.abs(uf.cpu().numpy() - uf_o).max() < 1e-6 and np.abs(ud.cpu().numpy() - ud_o).max() < 1e-6
+    # batched product
+    V = ops.winograd_input_transform(xg)
+    M = ops.gemm_nt_batched(V, uf)
+    M_o = wo.products_nt(V.cpu().numpy().astype(np.float64), uf.cpu().numpy().astype(np.float64))
+    assert np.abs(M.cpu().numpy() - M_o).max() < 1e-4 * np.abs(M_o).max()
+    # output transform: plain + bias + second (ReLU'd) output + pooled output; then mask + accumulate
+    y_o = wo.output_transform(M.cpu().numpy(), B, H, W, bias.numpy())
+    yr = torch.empty(B, H, W, Co, device=d)
+    yp = torch.empty(B, H // 2, W // 2, Co, device=d)
+    y = ops.winograd_output_transform(M, B, H, W, bias=bias.to(d), out_relu=yr, out_pool=yp, pool_relu=True)
+    assert np.abs(y.cpu().numpy() - y_o).max() < 1e-5 * max(1.0, np.abs(y_o).max())
+    assert torch.equal(yr, torch.relu(y))
+    assert torch.equal(yp, torch.relu(F.max_pool2d(y.permute(0, 3, 1, 2), 2).permute(0, 2, 3, 1)))
+    base = rnd(B, H, W, Co, seed=6).to(d)
+    mask = rnd(B, H, W, Co, seed=7).to(d)
+    acc = base.clone()
+    ops.winograd_output_transform(M, B, H, W, mask_src=mask, out=acc, accumulate=True)
+    y_nb = wo.output_transform(M.cpu().numpy(), B, H, W)
+    expect = base.cpu().numpy() + np.where(mask.cpu().numpy() > 0, y_nb, 0.0)
+    assert np.abs(acc.cpu().numpy() - expect).max() < 1e-5 * max(1.0, np.abs(expect).max())
+    # filter gradient from split-K slabs: two splits whose sum is dU, column sums behind each slab
+    dU = np.einsum('pto,pti->poi', wo.outgrad_transform(dy.numpy()), wo.input_transform(x.numpy()))
+    half = np.random.default_rng(0).standard_normal(dU.shape)
+    cs = wo.outgrad_transform(dy.numpy()).sum(axis=1)                          # (16, Co)
+    slabs = np.zeros((16, 2, Co * Ci + Co), dtype=f32)
+    slabs[:, 0, :Co * Ci] = (dU - half).reshape(16, -1); slabs[:, 1, :Co * Ci] = half.reshape(16, -1)
+    slabs[:, 0, Co * Ci:] = cs * 0.25; slabs[:, 1, Co * Ci:] = cs * 0.75
+    dw = torch.empty(Co, Ci, 3, 3, device=d); db = torch.empty(Co, device=d)
+    ops.winograd_filter_grad(torch.from_numpy(slabs).to(d), dw, db)
+    dw_o, db_o = wo.conv_wgrad(x.numpy(), dy.numpy())
+    assert np.abs(dw.cpu().numpy() - dw_o).max() < 1e-4 * np.abs(dw_o).max()
+    assert np.abs(db.cpu().numpy() - db_o).max() < 1e-4 * np.abs(db_o).max()
+
+
 @pytest.mark.parametrize('B,H,W,Cin,Cout', [(2, 13, 11, 64, 128), (4, 30, 30, 256, 256), (6, 9, 9, 128, 64)])
 def test_winograd_conv_pipelined_halves_are_bit_identical(ops, B, H, W, Cin, Cout):
     """The two halves of the batch pipelined over the helper stream (transforms of one half under the GEMM of the other)

@@ -1,0 +1,49 @@
+"""The numpy restatement of the Winograd F(2x2,3x3) passes (oracle/winograd_oracle.py) against torch's Conv2d(k=3,pad=1)
+and its autograd on the CPU, fp64: the transform matrices, the tile / position layout and the border handling the HIP
+entries are held to in tests/test_kernels_gpu.py."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import winograd_oracle as wo          # noqa: E402
+
+
+def nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous().numpy()
+
+
+@pytest.mark.parametrize('B,H,W,Ci,Co', [(1, 4, 4, 3, 5), (2, 7, 9, 4, 6), (1, 1, 1, 2, 3), (2, 6, 5, 8, 4)])
+@pytest.mark.parametrize('relu_in', [False, True])
+def test_three_passes_equal_conv2d_and_its_autograd(B, H, W, Ci, Co, relu_in):
+    g = torch.Generator().manual_seed(B * 100 + H * 10 + W)
+    x = torch.randn(B, Ci, H, W, generator=g, dtype=torch.float64).requires_grad_(True)
+    w = torch.randn(Co, Ci, 3, 3, generator=g, dtype=torch.float64).requires_grad_(True)
+    b = torch.randn(Co, generator=g, dtype=torch.float64).requires_grad_(True)
+    dy = torch.randn(B, Co, H, W, generator=g, dtype=torch.float64)
+    xin = torch.relu(x) if relu_in else x
+    y = F.conv2d(xin, w, b, padding=1)
+    dxin, dw, db = torch.autograd.grad(y, (xin, w, b), dy)
+    xn, dyn = nhwc(x.detach()), nhwc(dy)
+    assert np.allclose(wo.conv_fwd(xn, w.detach().numpy(), b.detach().numpy(), relu_in), nhwc(y.detach()), atol=1e-12)
+    assert np.allclose(wo.conv_dgrad(dyn, w.detach().numpy()), nhwc(dxin), atol=1e-12)
+    dw_w, db_w = wo.conv_wgrad(xn, dyn, relu_in)
+    assert np.allclose(dw_w, dw.numpy(), atol=1e-11) and np.allclose(db_w, db.numpy(), atol=1e-11)
+
+
+def test_layout_of_a_transformed_tensor():
+    """(16, tiles, C): position p = 4*xi + nu, tiles in (image, tile row, tile column) order; odd borders are zero-padded."""
+    x = np.arange(2 * 3 * 5 * 1, dtype=np.float64).reshape(2, 3, 5, 1) + 1
+    V = wo.input_transform(x)
+    assert V.shape == (16, wo.tiles(2, 3, 5), 1) == (16, 2 * 2 * 3, 1)
+    # position (1,1) of tile (image 1, row 0, column 2) = d[1][1] + d[1][2] + d[2][1] + d[2][2] of its patch: pixels
+    # (0,4), (0,5: outside), (1,4), (1,5: outside)
+    t = 1 * (2 * 3) + 0 * 3 + 2
+    assert V[5, t, 0] == x[1, 0, 4, 0] + x[1, 1, 4, 0]
+    dM = wo.outgrad_transform(x)
+    assert dM[0, t, 0] == x[1, 0, 4, 0]                       # A dY A^T at (0,0) is the tile's first pixel
+    assert dM[5, t, 0] == x[1, 0, 4, 0] + x[1, 1, 4, 0]       # ... at (1,1) the sum of its (in-image) pixels

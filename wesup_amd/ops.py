@@ -221,6 +221,69 @@ def winograd_tiles(B, H, W):
     return B * ((H + 1) // 2) * ((W + 1) // 2)
 
 
+def winograd_input_transform(x, relu=False, out=None):
+    """x (B,H,W,C) -> V (16, tiles, C) = B^T d B of every 4x4 input patch."""
+    _chk(x, name='x')
+    B, H, W, C = x.shape
+    T = winograd_tiles(B, H, W)
+    if out is None:
+        out = torch.empty(16, T, C, dtype=torch.float32, device=x.device)
+    assert out.shape == (16, T, C) and out.is_contiguous()
+    _lib.call('wesup_winograd_input_transform', _p(x), _p(out), 0, B, H, W, C, int(relu), _stream())
+    return out
+
+
+def winograd_outgrad_transform(dy, out=None):
+    """dy (B,H,W,C) -> dM (16, tiles, C) = A dY A^T of every 2x2 output tile."""
+    _chk(dy, name='dy')
+    B, H, W, C = dy.shape
+    T = winograd_tiles(B, H, W)
+    if out is None:
+        out = torch.empty(16, T, C, dtype=torch.float32, device=dy.device)
+    assert out.shape == (16, T, C) and out.is_contiguous()
+    _lib.call('wesup_winograd_outgrad_transform', _p(dy), _p(out), B, H, W, C, _stream())
+    return out
+
+
+def winograd_output_transform(Mt, B, H, W, bias=None, mask_src=None, out=None, out_relu=None, out_pool=None, pool_relu=False,
+                              accumulate=False):
+    """Mt (16, tiles, C) -> y (B,H,W,C) = A^T M A + bias [masked by mask_src > 0] [+ old y]."""
+    _chk(Mt, name='Mt')
+    C = Mt.shape[2]
+    assert Mt.shape == (16, winograd_tiles(B, H, W), C)
+    if out is None:
+        assert not accumulate
+        out = torch.empty(B, H, W, C, dtype=torch.float32, device=Mt.device)
+    _lib.call('wesup_winograd_output_transform', _p(Mt), 0, _p(bias), _p(mask_src), _p(out), _p(out_relu), _p(out_pool),
+              int(pool_relu), B, H, W, C, int(accumulate), _stream())
+    return out
+
+
+def gemm_nt_batched(A, Bw, out=None):
+    """out[b] = A[b] @ Bw[b]^T for contiguous (nbatch, M, K) x (nbatch, N, K) -> (nbatch, M, N), one launch."""
+    _chk(A, name='A'); _chk(Bw, name='B')
+    nb, M, K = A.shape
+    N = Bw.shape[1]
+    assert Bw.shape == (nb, N, K)
+    if out is None:
+        out = torch.empty(nb, M, N, dtype=torch.float32, device=A.device)
+    assert out.shape == (nb, M, N) and out.is_contiguous()
+    _lib.call('wesup_gemm_nt_batched', _p(A), K, M * K, _p(Bw), K, N * K, _p(out), N, M * N, nb, M, N, K, _stream())
+    return out
+
+
+def winograd_filter_grad(slabs, dw=None, db=None):
+    """slabs (16, S, Cout*Cin + Cout): split-K partial products of the 16 transformed filter gradients, each followed by
+    the column sums of its dM operand -> (dw (Cout,Cin,3,3) = G^T (sum over S) G, db (Cout) from position 5).
+    Cout, Cin are taken from dw."""
+    _chk(slabs, name='slabs'); _chk(dw, name='dw'); _chk(db, name='db')
+    Cout, Cin = dw.shape[:2]
+    S = slabs.shape[1]
+    assert slabs.shape == (16, S, Cout * Cin + Cout) and slabs.is_contiguous()
+    _lib.call('wesup_winograd_filter_grad', _p(slabs), slabs.stride(1), slabs.stride(0), S, _p(dw), _p(db), Cout, Cin, _stream())
+    return dw, db
+
+
 _aux_streams = {}
 # transforms of one half of the batch under the GEMM of the other half (helper stream): bit-identical and tested, OFF --
 # measured 13.74 -> 13.97 ms per step (DESIGN.md 6: the step is bound by the chip's total throughput, not by its chain)
