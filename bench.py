@@ -57,7 +57,7 @@ def parse_args(argv=None):
                                                                       'pipeline over a helper stream')
     ap.add_argument('--direct-wgrad', action='store_true', help='A/B: every conv weight gradient with the direct '
                                                                 'implicit-GEMM kernel (no Winograd-domain wgrad)')
-    ap.add_argument('--event-every', type=int, default=4, help='steps of the timed region that carry HIP events: every n-th')
+    ap.add_argument('--event-every', type=int, default=10, help='steps of the timed region that carry HIP events: every n-th')
     ap.add_argument('--timed-classes', default='conv3x3_fwd,conv3x3_dgrad,winograd_gemm,winograd_transform',
                     help="kernel classes that get HIP events inside the timed region ('all', 'none' or a comma list); an "
                          "event record fences its queue, so only the dominant kernel is timed there by default and the "
