@@ -1,3 +1,6 @@
+"""smoke()'s 64x64 case under the three conv routings (direct / Winograd wgrad / Winograd everything): loss, the five
+worst gradients against the oracle's raw fp32 gradients, and the fp64 check under the GPU's own discrete decisions
+(tests/_gradcheck.py).  Shows that a 1e-2 gradient difference against the raw oracle is ONE near-tie ReLU decision."""
 import sys, os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch
