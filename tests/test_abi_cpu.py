@@ -64,3 +64,25 @@ def test_product_path_fails_loudly_without_gpu_tensors(lib):
     from wesup_amd import ops
     with pytest.raises(lib.WesupHipError):
         ops.pack_input(torch.zeros(1, 3, 4, 4))          # CPU tensor: no fallback
+
+
+def test_winograd_host_side_queries_and_argument_checks(lib):
+    """Sizes of the Winograd-domain operands (16 x tiles x C floats each, tiles = B * ceil(H/2) * ceil(W/2)) and the
+    rejection of bad arguments on the host, before any launch."""
+    h = lib.load()
+    T = 4 * 30 * 30                                        # conv4_2 at the bench shape: 4 images of 60x60, 512 channels
+    assert h.wesup_winograd_weight_floats(512, 512) == 16 * 512 * 512
+    assert h.wesup_conv3x3_winograd_workspace_bytes(4, 60, 60, 512, 512) == 2 * 16 * T * 512 * 4
+    assert h.wesup_conv3x3_winograd_workspace_bytes(1, 7, 9, 256, 512) == 16 * 4 * 5 * (256 + 512) * 4      # odd borders round up
+    assert h.wesup_conv3x3_wgrad_winograd_workspace_bytes(4, 60, 60, 512, 512) > 2 * 16 * T * 512 * 4       # + split-K slabs
+    assert h.wesup_conv3x3_winograd_workspace_bytes(4, 60, 60, 3, 64) == 0                                   # image layer: not for this path
+    assert h.wesup_conv3x3_fwd_winograd(None, None, None, None, None, None, 0, None, 4, 60, 60, 512, 512, 0, None, 0, None) == -1
+    assert h.wesup_conv3x3_dgrad_winograd(None, None, None, None, 4, 60, 60, 512, 512, 0, None, 0, None) == -1
+    assert h.wesup_conv3x3_wgrad_winograd(None, None, None, None, None, 4, 60, 60, 512, 512, 0, None, 0, None) == -1
+    assert h.wesup_gemm_nt_batched(None, 0, 0, None, 0, 0, None, 0, 0, 16, 128, 128, 32, None) == -1
+    assert h.wesup_winograd_input_transform(None, None, 0, 1, 8, 8, 64, 0, None) == -1
+    assert h.wesup_winograd_output_transform(None, 0, None, None, None, None, None, 0, 1, 8, 8, 64, 0, None) == -1
+    assert h.wesup_winograd_outgrad_transform(None, None, 1, 8, 8, 64, None) == -1
+    assert h.wesup_winograd_filter_grad(None, 0, 0, 1, None, None, 64, 64, None) == -1
+    assert h.wesup_winograd_pack_weight(None, None, None, 64, 64, None) == -1
+    assert h.wesup_conv3x3_fwd_side(None, None, None, None, None, None, None, None, 32, 1, 8, 8, 64, 64, 0, None) == -1
