@@ -55,6 +55,8 @@ def parse_args(argv=None):
                                                                'the direct implicit-GEMM kernel (no Winograd-domain conv)')
     ap.add_argument('--winograd-pipeline', action='store_true', help='A/B: Winograd-domain convs with the half-batch '
                                                                       'pipeline over a helper stream')
+    ap.add_argument('--winograd-min-ci', type=int, default=0, help='A/B: input-channel count from which forward / input '
+                                                                    'gradient go through the Winograd domain (default: 128)')
     ap.add_argument('--direct-wgrad', action='store_true', help='A/B: every conv weight gradient with the direct '
                                                                 'implicit-GEMM kernel (no Winograd-domain wgrad)')
     ap.add_argument('--event-every', type=int, default=10, help='steps of the timed region that carry HIP events: every n-th')
@@ -246,6 +248,8 @@ def worker(args):
     trainer.model.engine.fuse_side_fwd = not args.no_side_fusion
     trainer.model.engine.wgrad_winograd = not args.direct_wgrad
     trainer.model.engine.conv_winograd = not args.direct_conv
+    if args.winograd_min_ci:
+        trainer.model.engine.WINOGRAD_CONV_MIN_CI = args.winograd_min_ci
     if args.winograd_pipeline:
         from wesup_amd import ops as _ops2
         _ops2.PIPELINE_WINOGRAD = True
