@@ -57,6 +57,8 @@ def parse_args(argv=None):
                                                                       'pipeline over a helper stream')
     ap.add_argument('--winograd-min-ci', type=int, default=0, help='A/B: input-channel count from which forward / input '
                                                                     'gradient go through the Winograd domain (default: 128)')
+    ap.add_argument('--winograd-tile', type=int, default=0, choices=(0, 2, 4),
+                    help='A/B: m of the Winograd F(m x m, 3x3) domain for the wide layers (default: the engine\'s, 4; 2 = round 2)')
     ap.add_argument('--direct-wgrad', action='store_true', help='A/B: every conv weight gradient with the direct '
                                                                 'implicit-GEMM kernel (no Winograd-domain wgrad)')
     ap.add_argument('--event-every', type=int, default=10, help='steps of the timed region that carry HIP events: every n-th')
@@ -249,7 +251,9 @@ def worker(args):
     trainer.model.engine.wgrad_winograd = not args.direct_wgrad
     trainer.model.engine.conv_winograd = not args.direct_conv
     if args.winograd_min_ci:
-        trainer.model.engine.WINOGRAD_CONV_MIN_CI = args.winograd_min_ci
+        type(trainer.model.engine).WINOGRAD_CONV_MIN_CI = args.winograd_min_ci
+    if args.winograd_tile:
+        type(trainer.model.engine).WINOGRAD_TILE = args.winograd_tile
     if args.winograd_pipeline:
         from wesup_amd import ops as _ops2
         _ops2.PIPELINE_WINOGRAD = True

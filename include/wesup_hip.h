@@ -36,7 +36,10 @@ extern "C" {
 #define WESUP_MASK 8       /* result := mask > 0 ? result : 0 (ReLU backward) */
 
 int wesup_abi_version(void);
-/* debug, host-synchronous: shader clock (MHz) held during the main loop of the last wesup_gemm_nt / conv3x3 fwd /
+/* The two debug entries only work in the debug build of the library (make -C wesup_amd/csrc debug ->
+ * libwesup_hip_debug.so, GEMM kernels compiled with the in-kernel clock probe and the per-block trace); the shipped
+ * library's kernels carry neither and both entries return WESUP_ERR_INVALID there.
+ * debug, host-synchronous: shader clock (MHz) held during the main loop of the last wesup_gemm_nt / conv3x3 fwd /
  * dgrad launch (s_memtime / s_memrealtime of block 0) */
 int wesup_debug_clock(double* mhz_out /* host */);
 /* debug, host-synchronous: per-block {start, loop start, loop end, end} timestamps (100 MHz ticks) of NT launches */
@@ -103,55 +106,60 @@ size_t wesup_conv3x3_wgrad_workspace_bytes(int B, int H, int W, int Ci, int Cout
 int wesup_conv3x3_wgrad(const float* x, const float* dy, float* dw_kcrs, float* db,
                         int B, int H, int W, int Ci, int Cout, int relu_in,
                         void* ws, size_t ws_bytes, void* stream);
-/* The same dw / db through the Winograd F(2x2,3x3) domain (the scheme of the non-fused Winograd backward-filter algorithms
- * of vendor conv libraries; it replaces autograd of the reference's Conv2d(k=3,pad=1), models/wesup.py:199): both tensors are transformed per 2x2 output tile (workspace: 16 x tiles x
- * (Ci + Cout) floats + split-K slabs), 16 TN GEMMs with K = tiles accumulate the transformed filter gradient, and
- * G^T (.) G maps it back to 3x3.  2.25x fewer multiply-adds than the direct form; same result up to fp32 summation
- * order.  Ci, Cout multiples of 4, >= 32 (meant for the 256/512-channel layers); x has Ci channels. */
-size_t wesup_conv3x3_wgrad_winograd_workspace_bytes(int B, int H, int W, int Ci, int Cout);
-/* v_pre (optional): the transformed input [16][tiles][Ci] kept by wesup_conv3x3_fwd_winograd of the same layer; then x
- * may be NULL and its transform pass is skipped. */
+/* The same dw / db through the Winograd F(m x m, 3x3) domain, m = 2 or 4 (the scheme of the non-fused Winograd
+ * backward-filter algorithms of vendor conv libraries; it replaces autograd of the reference's Conv2d(k=3,pad=1),
+ * models/wesup.py:199): both tensors are transformed per m x m output tile (workspace: P x tiles x (Ci + Cout) floats +
+ * split-K slabs, P = (m+2)^2 positions, tiles = B * ceil(H/m) * ceil(W/m)), P TN GEMMs with K = tiles accumulate the
+ * transformed filter gradient, and G^T (.) G maps it back to 3x3.  2.25x (m = 2) / 4x (m = 4) fewer multiply-adds than
+ * the direct form; same result up to fp32 rounding (m = 2: like the direct kernel's summation-order error; m = 4:
+ * ~5e-6 of the tensor's maximum).  Ci, Cout multiples of 4, >= 32 (meant for the 128..512-channel layers); x has Ci
+ * channels. */
+size_t wesup_conv3x3_wgrad_winograd_workspace_bytes(int B, int H, int W, int Ci, int Cout, int m);
+/* v_pre (optional): the transformed input [P][tiles][Ci] kept by wesup_conv3x3_fwd_winograd of the same layer and the
+ * same m; then x may be NULL and its transform pass is skipped. */
 int wesup_conv3x3_wgrad_winograd(const float* x, const float* v_pre, const float* dy, float* dw_kcrs, float* db,
-                                 int B, int H, int W, int Ci, int Cout, int relu_in,
+                                 int B, int H, int W, int Ci, int Cout, int relu_in, int m,
                                  void* ws, size_t ws_bytes, void* stream);
-/* Forward and input gradient of the deep layers in the same domain:  V = B^T d B per 4x4 input patch, 16 batched NT
- * GEMMs M_p = V_p . U_p^T (one launch), Y = A^T M A + the epilogue of wesup_conv3x3_fwd / _dgrad (bias, second ReLU'd
+/* Forward and input gradient of the deep layers in the same domain:  V = B^T d B per (m+2) x (m+2) input patch, P batched
+ * NT GEMMs M_p = V_p . U_p^T (one launch), Y = A^T M A + the epilogue of wesup_conv3x3_fwd / _dgrad (bias, second ReLU'd
  * output / ReLU mask, accumulate).  U = G g G^T comes from wesup_winograd_pack_weight (once per step):
- * u_fwd [16][Cout][Cin], u_dgrad [16][Cin][Cout] (rotated filter), 16*Cin*Cout floats each.  Workspace: transformed
- * input + transformed output, 16 x tiles x (Cin + Cout) floats (dgrad: ask with the channel counts swapped).
- * v_keep (optional): where the forward leaves V for the weight gradient (16 x tiles x Cin floats).
+ * u_fwd [P][Cout][Cin], u_dgrad [P][Cin][Cout] (rotated filter), P*Cin*Cout floats each.  Workspace: transformed
+ * input + transformed output, P x tiles x (Cin + Cout) floats (dgrad: ask with the channel counts swapped).
+ * v_keep (optional): where the forward leaves V for the weight gradient (P x tiles x Cin floats).
  * y_pool (optional): a third output (B, H/2, W/2, Cout) = the 2x2 / stride-2 max-pool that follows the layer
- * (models/wesup.py:199, torchvision's MaxPool2d(2, 2); a 2x2 output tile is one pooling window), ReLU'd if pool_relu.
- * Cin % 32 == 0, Cout % 4 == 0; the results equal the direct kernels' up to fp32 summation order. */
-size_t wesup_winograd_weight_floats(int Cin, int Cout);
-int wesup_winograd_pack_weight(const float* w_kcrs, float* u_fwd, float* u_dgrad, int Cout, int Cin, void* stream);
-size_t wesup_conv3x3_winograd_workspace_bytes(int B, int H, int W, int Cin, int Cout);
+ * (models/wesup.py:199, torchvision's MaxPool2d(2, 2); an m x m output tile holds (m/2)^2 pooling windows), ReLU'd if
+ * pool_relu.  Cin % 32 == 0, Cout % 4 == 0; the results equal the direct kernels' up to fp32 rounding (see above). */
+size_t wesup_winograd_weight_floats(int Cin, int Cout, int m);
+long wesup_winograd_tiles(int B, int H, int W, int m);
+int wesup_winograd_pack_weight(const float* w_kcrs, float* u_fwd, float* u_dgrad, int Cout, int Cin, int m, void* stream);
+size_t wesup_conv3x3_winograd_workspace_bytes(int B, int H, int W, int Cin, int Cout, int m);
 int wesup_conv3x3_fwd_winograd(const float* x, const float* u_fwd, const float* bias, float* y, float* y_relu,
                                float* y_pool, int pool_relu, float* v_keep,
-                               int B, int H, int W, int Cin, int Cout, int relu_in,
+                               int B, int H, int W, int Cin, int Cout, int relu_in, int m,
                                void* ws, size_t ws_bytes, void* stream);
 int wesup_conv3x3_dgrad_winograd(const float* dy, const float* u_dgrad, const float* mask_src, float* dx,
-                                 int B, int H, int W, int Cin, int Cout, int accumulate,
+                                 int B, int H, int W, int Cin, int Cout, int accumulate, int m,
                                  void* ws, size_t ws_bytes, void* stream);
-/* The three passes on their own (the two entries above chain them): x (B,H,W,C) -> V [16][tiles][C];
+/* The three passes on their own (the two entries above chain them): x (B,H,W,C) -> V [P][tiles][C];
  * nbatch NT products of one shape in one launch, C_b = A_b . B_b^T (element strides between the entries; K % 32 == 0);
- * Mt [16][tiles][C] -> y = A^T M A + bias, masked by mask_src > 0, added to the old y if accumulate, with the optional
- * second output y_relu = max(y, 0).  tiles = B * ceil(H/2) * ceil(W/2).  plane_elems: elements between two of the 16
- * position planes of V / Mt (0: tiles * C); larger when a sub-batch works inside the planes of a whole batch, which is
- * how the engine pipelines the memory-bound transforms of one half of the batch under the GEMM of the other. */
+ * Mt [P][tiles][C] -> y = A^T M A + bias, masked by mask_src > 0, added to the old y if accumulate, with the optional
+ * second output y_relu = max(y, 0).  plane_elems: elements between two of the P position planes of V / Mt (0: tiles * C);
+ * larger when a sub-batch works inside the planes of a whole batch, which is how the engine can pipeline the memory-bound
+ * transforms of one half of the batch under the GEMM of the other. */
 int wesup_winograd_input_transform(const float* x, float* V, long plane_elems, int B, int H, int W, int C, int relu_in,
-                                   void* stream);
+                                   int m, void* stream);
 int wesup_gemm_nt_batched(const float* A, int lda, long strideA, const float* B, int ldb, long strideB,
                           float* C, int ldc, long strideC, int nbatch, int M, int N, int K, void* stream);
 int wesup_winograd_output_transform(const float* Mt, long plane_elems, const float* bias, const float* mask_src, float* y,
                                     float* y_relu, float* y_pool, int pool_relu, int B, int H, int W, int C,
-                                    int accumulate, void* stream);
-/* The weight gradient's own transforms: dy (B,H,W,C) -> dM [16][tiles][C] = A dY A^T per 2x2 tile; and the way back from
- * the split-K slabs of the 16 transformed filter gradients ([16][S][Cout*Cin + Cout], each slab followed by the Cout
- * column sums of its dM operand) to dw (Cout,Cin,3,3) = G^T (sum over S) G and db = the column sums of position 5. */
-int wesup_winograd_outgrad_transform(const float* dy, float* dM, int B, int H, int W, int C, void* stream);
+                                    int accumulate, int m, void* stream);
+/* The weight gradient's own transforms: dy (B,H,W,C) -> dM [P][tiles][C] = A dY A^T per m x m tile; and the way back from
+ * the split-K slabs of the P transformed filter gradients ([P][S][Cout*Cin + Cout], each slab followed by the Cout
+ * column sums of its dM operand) to dw (Cout,Cin,3,3) = G^T (sum over S) G and db = the column sums of position (1,1)
+ * (index m + 3). */
+int wesup_winograd_outgrad_transform(const float* dy, float* dM, int B, int H, int W, int C, int m, void* stream);
 int wesup_winograd_filter_grad(const float* slabs, long slab_stride, long batch_stride, int S, float* dw_kcrs, float* db,
-                               int Cout, int Cin, void* stream);
+                               int Cout, int Cin, int m, void* stream);
 
 /* ------------------------------------------------------------------ generic fp32 MFMA GEMMs
  * side 1x1 convs (models/wesup.py:208-209,253), fc_layers (models/wesup.py:213-220,288) and their grads.

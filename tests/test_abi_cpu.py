@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _header_decls():
     hdr = open(os.path.join(ROOT, 'include', 'wesup_hip.h')).read()
     hdr = re.sub(r'/\*.*?\*/', '', hdr, flags=re.S)
-    return re.findall(r'\n\s*(?:int|size_t|const char\*)\s+(wesup_\w+)\s*\(([^;]*?)\)\s*;', hdr, flags=re.S)
+    return re.findall(r'\n\s*(?:int|long|size_t|const char\*)\s+(wesup_\w+)\s*\(([^;]*?)\)\s*;', hdr, flags=re.S)
 
 
 @pytest.fixture(scope='module')
@@ -45,7 +45,7 @@ def test_ctypes_signatures_match_header(lib):
 
 def test_host_side_queries(lib):
     h = lib.load()
-    assert h.wesup_abi_version() == 2
+    assert h.wesup_abi_version() == lib.ABI_VERSION == 3
     assert h.wesup_conv3x3_kpad(3) == 64 and h.wesup_conv3x3_kpad(64) == 576 and h.wesup_conv3x3_kpad(512) == 4608
     assert h.wesup_strerror(0) == b'ok' and b'workspace' in h.wesup_strerror(-3)
     assert h.wesup_conv3x3_wgrad_workspace_bytes(4, 480, 480, 64, 64) > 0
@@ -67,22 +67,34 @@ def test_product_path_fails_loudly_without_gpu_tensors(lib):
 
 
 def test_winograd_host_side_queries_and_argument_checks(lib):
-    """Sizes of the Winograd-domain operands (16 x tiles x C floats each, tiles = B * ceil(H/2) * ceil(W/2)) and the
-    rejection of bad arguments on the host, before any launch."""
+    """Sizes of the Winograd-domain operands (P x tiles x C floats each; P = (m+2)^2 positions, tiles = B * ceil(H/m) *
+    ceil(W/m) for F(m x m, 3x3), m = 2 or 4) and the rejection of bad arguments on the host, before any launch."""
     h = lib.load()
     T = 4 * 30 * 30                                        # conv4_2 at the bench shape: 4 images of 60x60, 512 channels
-    assert h.wesup_winograd_weight_floats(512, 512) == 16 * 512 * 512
-    assert h.wesup_conv3x3_winograd_workspace_bytes(4, 60, 60, 512, 512) == 2 * 16 * T * 512 * 4
-    assert h.wesup_conv3x3_winograd_workspace_bytes(1, 7, 9, 256, 512) == 16 * 4 * 5 * (256 + 512) * 4      # odd borders round up
-    assert h.wesup_conv3x3_wgrad_winograd_workspace_bytes(4, 60, 60, 512, 512) > 2 * 16 * T * 512 * 4       # + split-K slabs
-    assert h.wesup_conv3x3_winograd_workspace_bytes(4, 60, 60, 3, 64) == 0                                   # image layer: not for this path
-    assert h.wesup_conv3x3_fwd_winograd(None, None, None, None, None, None, 0, None, 4, 60, 60, 512, 512, 0, None, 0, None) == -1
-    assert h.wesup_conv3x3_dgrad_winograd(None, None, None, None, 4, 60, 60, 512, 512, 0, None, 0, None) == -1
-    assert h.wesup_conv3x3_wgrad_winograd(None, None, None, None, None, 4, 60, 60, 512, 512, 0, None, 0, None) == -1
+    assert h.wesup_winograd_weight_floats(512, 512, 2) == 16 * 512 * 512
+    assert h.wesup_winograd_weight_floats(512, 512, 4) == 36 * 512 * 512
+    assert h.wesup_winograd_weight_floats(512, 512, 3) == 0                                                      # only F(2x2) and F(4x4)
+    assert h.wesup_winograd_tiles(4, 60, 60, 2) == T and h.wesup_winograd_tiles(4, 60, 60, 4) == 4 * 15 * 15
+    assert h.wesup_winograd_tiles(1, 7, 9, 4) == 2 * 3 and h.wesup_winograd_tiles(1, 7, 9, 8) == 0
+    assert h.wesup_conv3x3_winograd_workspace_bytes(4, 60, 60, 512, 512, 2) == 2 * 16 * T * 512 * 4
+    assert h.wesup_conv3x3_winograd_workspace_bytes(4, 60, 60, 512, 512, 4) == 2 * 36 * (T // 4) * 512 * 4      # 2.25x instead of 4x
+    assert h.wesup_conv3x3_winograd_workspace_bytes(1, 7, 9, 256, 512, 2) == 16 * 4 * 5 * (256 + 512) * 4      # odd borders round up
+    assert h.wesup_conv3x3_winograd_workspace_bytes(1, 7, 9, 256, 512, 4) == 36 * 2 * 3 * (256 + 512) * 4
+    assert h.wesup_conv3x3_wgrad_winograd_workspace_bytes(4, 60, 60, 512, 512, 2) > 2 * 16 * T * 512 * 4       # + split-K slabs
+    assert h.wesup_conv3x3_wgrad_winograd_workspace_bytes(4, 60, 60, 512, 512, 4) > 2 * 36 * (T // 4) * 512 * 4
+    assert h.wesup_conv3x3_winograd_workspace_bytes(4, 60, 60, 3, 64, 2) == 0                                   # image layer: not for this path
+    assert h.wesup_conv3x3_winograd_workspace_bytes(4, 60, 60, 512, 512, 3) == 0
+    for m in (2, 4):
+        assert h.wesup_conv3x3_fwd_winograd(None, None, None, None, None, None, 0, None, 4, 60, 60, 512, 512, 0, m, None, 0, None) == -1
+        assert h.wesup_conv3x3_dgrad_winograd(None, None, None, None, 4, 60, 60, 512, 512, 0, m, None, 0, None) == -1
+        assert h.wesup_conv3x3_wgrad_winograd(None, None, None, None, None, 4, 60, 60, 512, 512, 0, m, None, 0, None) == -1
+        assert h.wesup_winograd_input_transform(None, None, 0, 1, 8, 8, 64, 0, m, None) == -1
+        assert h.wesup_winograd_output_transform(None, 0, None, None, None, None, None, 0, 1, 8, 8, 64, 0, m, None) == -1
+        assert h.wesup_winograd_outgrad_transform(None, None, 1, 8, 8, 64, m, None) == -1
+        assert h.wesup_winograd_filter_grad(None, 0, 0, 1, None, None, 64, 64, m, None) == -1
+        assert h.wesup_winograd_pack_weight(None, None, None, 64, 64, m, None) == -1
     assert h.wesup_gemm_nt_batched(None, 0, 0, None, 0, 0, None, 0, 0, 16, 128, 128, 32, None) == -1
-    assert h.wesup_winograd_input_transform(None, None, 0, 1, 8, 8, 64, 0, None) == -1
-    assert h.wesup_winograd_output_transform(None, 0, None, None, None, None, None, 0, 1, 8, 8, 64, 0, None) == -1
-    assert h.wesup_winograd_outgrad_transform(None, None, 1, 8, 8, 64, None) == -1
-    assert h.wesup_winograd_filter_grad(None, 0, 0, 1, None, None, 64, 64, None) == -1
-    assert h.wesup_winograd_pack_weight(None, None, None, 64, 64, None) == -1
+    # the debug entries only exist in `make debug`'s library: the shipped one refuses them
+    import ctypes
+    assert h.wesup_debug_clock(ctypes.byref(ctypes.c_double())) == -1 and h.wesup_debug_set_trace(None) == -1
     assert h.wesup_conv3x3_fwd_side(None, None, None, None, None, None, None, None, 32, 1, 8, 8, 64, 64, 0, None) == -1

@@ -154,6 +154,14 @@ def test_area_v2_compound_and_negative_datasets(tmp_path):
     # Compound: items in lock step
     both = D.CompoundDataset(D.SegmentationDataset(tmp_path), v2)
     assert len(both) == 3 and len(both[1]) == 2 and torch.equal(both[1][0][0], both[1][1][0])
+    # the prefetcher stages raw (img, class-index mask, points) items only: WESUPV2 / Compound items are refused by
+    # name instead of being mis-read (their third element is a coordinate map, not points)
+    collate = torch.utils.data.default_collate
+    with pytest.raises(TypeError, match='mask must be a uint8 class-index map'):
+        D.DevicePrefetcher._check_item(collate([v2[0], v2[1]]))
+    with pytest.raises(TypeError, match='CompoundDataset'):
+        D.DevicePrefetcher._check_item(collate([both[0], both[1]]))
+    D.DevicePrefetcher._check_item(collate([D.SegmentationDataset(tmp_path)[0], D.SegmentationDataset(tmp_path)[1]]))
     # Digest 2019: an image named negative* carries the sentinel row instead of csv points
     Image.fromarray(np.zeros((40, 56, 3), dtype=np.uint8)).save(tmp_path / 'images' / 'negative1.png')
     Image.fromarray(np.zeros((40, 56), dtype=np.uint8)).save(tmp_path / 'masks' / 'negative1.png')

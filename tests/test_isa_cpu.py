@@ -74,6 +74,17 @@ def test_no_scratch_and_no_foreign_m0_reader(kernels):
         assert n_dma >= 4, (name, n_dma)                       # and the staging really is LDS-DMA
 
 
+def test_no_clock_read_in_the_shipped_gemm_kernels(kernels):
+    """The in-kernel clock probe and the per-block trace are debug instrumentation (csrc/gemm.hip, WESUP_GEMM_DEBUG): they
+    exist only in `make debug`'s libwesup_hip_debug.so; the shipped kernels read no clock and no trace pointer."""
+    if os.environ.get('WESUP_HIP_LIB'):
+        pytest.skip('another build of the library was selected through WESUP_HIP_LIB')
+    for name, code in _gemm(kernels).items():
+        for ins in code:
+            op = ins.split()[0]
+            assert op not in ('s_memrealtime', 's_memtime') and not op.startswith('s_getreg'), (name, ins)
+
+
 def test_mfma_count_of_the_unrolled_k_step(kernels):
     for name, code in _gemm(kernels).items():
         n = sum(ins.startswith('v_mfma_f32_32x32x2_f32') or ins.startswith('v_mfma_f32_32x32x2f32') for ins in code)

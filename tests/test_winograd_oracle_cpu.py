@@ -1,4 +1,4 @@
-"""The numpy restatement of the Winograd F(2x2,3x3) passes (oracle/winograd_oracle.py) against torch's Conv2d(k=3,pad=1)
+"""The numpy restatement of the Winograd F(2x2,3x3) and F(4x4,3x3) passes (oracle/winograd_oracle.py) against torch's Conv2d(k=3,pad=1)
 and its autograd on the CPU, fp64: the transform matrices, the tile / position layout and the border handling the HIP
 entries are held to in tests/test_kernels_gpu.py."""
 import os
@@ -17,9 +17,10 @@ def nhwc(t):
     return t.permute(0, 2, 3, 1).contiguous().numpy()
 
 
-@pytest.mark.parametrize('B,H,W,Ci,Co', [(1, 4, 4, 3, 5), (2, 7, 9, 4, 6), (1, 1, 1, 2, 3), (2, 6, 5, 8, 4)])
+@pytest.mark.parametrize('B,H,W,Ci,Co', [(1, 4, 4, 3, 5), (2, 7, 9, 4, 6), (1, 1, 1, 2, 3), (2, 6, 5, 8, 4), (1, 8, 12, 2, 2)])
 @pytest.mark.parametrize('relu_in', [False, True])
-def test_three_passes_equal_conv2d_and_its_autograd(B, H, W, Ci, Co, relu_in):
+@pytest.mark.parametrize('m', [2, 4])
+def test_three_passes_equal_conv2d_and_its_autograd(B, H, W, Ci, Co, relu_in, m):
     g = torch.Generator().manual_seed(B * 100 + H * 10 + W)
     x = torch.randn(B, Ci, H, W, generator=g, dtype=torch.float64).requires_grad_(True)
     w = torch.randn(Co, Ci, 3, 3, generator=g, dtype=torch.float64).requires_grad_(True)
@@ -29,10 +30,10 @@ def test_three_passes_equal_conv2d_and_its_autograd(B, H, W, Ci, Co, relu_in):
     y = F.conv2d(xin, w, b, padding=1)
     dxin, dw, db = torch.autograd.grad(y, (xin, w, b), dy)
     xn, dyn = nhwc(x.detach()), nhwc(dy)
-    assert np.allclose(wo.conv_fwd(xn, w.detach().numpy(), b.detach().numpy(), relu_in), nhwc(y.detach()), atol=1e-12)
-    assert np.allclose(wo.conv_dgrad(dyn, w.detach().numpy()), nhwc(dxin), atol=1e-12)
-    dw_w, db_w = wo.conv_wgrad(xn, dyn, relu_in)
-    assert np.allclose(dw_w, dw.numpy(), atol=1e-11) and np.allclose(db_w, db.numpy(), atol=1e-11)
+    assert np.allclose(wo.conv_fwd(xn, w.detach().numpy(), b.detach().numpy(), relu_in, m=m), nhwc(y.detach()), atol=1e-11)
+    assert np.allclose(wo.conv_dgrad(dyn, w.detach().numpy(), m=m), nhwc(dxin), atol=1e-11)
+    dw_w, db_w = wo.conv_wgrad(xn, dyn, relu_in, m=m)
+    assert np.allclose(dw_w, dw.numpy(), atol=1e-10) and np.allclose(db_w, db.numpy(), atol=1e-10)
 
 
 def test_layout_of_a_transformed_tensor():
@@ -47,3 +48,22 @@ def test_layout_of_a_transformed_tensor():
     dM = wo.outgrad_transform(x)
     assert dM[0, t, 0] == x[1, 0, 4, 0]                       # A dY A^T at (0,0) is the tile's first pixel
     assert dM[5, t, 0] == x[1, 0, 4, 0] + x[1, 1, 4, 0]       # ... at (1,1) the sum of its (in-image) pixels
+
+
+def test_layout_of_an_f4_transformed_tensor():
+    """m = 4: (36, tiles, C), position p = 6*xi + nu, tiles = B * ceil(H/4) * ceil(W/4); the patch of tile (i, j) starts at
+    pixel (4i-1, 4j-1)."""
+    x = np.arange(1 * 6 * 9 * 1, dtype=np.float64).reshape(1, 6, 9, 1) + 1
+    V = wo.input_transform(x, m=4)
+    assert V.shape == (36, wo.tiles(1, 6, 9, 4), 1) == (36, 2 * 3, 1)
+    # position (5,5) = row 5 of B^T on both sides = 4 d1 - 5 d3 + d5 along each axis; tile (1, 2): patch rows 3..8, columns
+    # 7..12 (pixels with row > 5 or column > 8 are outside)
+    bt5 = np.array([0, 4, 0, -5, 0, 1.0])
+    patch = np.zeros((6, 6))
+    patch[:3, :2] = x[0, 3:6, 7:9, 0]
+    assert np.isclose(V[35, 1 * 3 + 2, 0], bt5 @ patch @ bt5)
+    dM = wo.outgrad_transform(x, m=4)
+    t = 0 * 3 + 1                                               # tile (0, 1): pixels rows 0..3, columns 4..7
+    assert dM[0, t, 0] == x[0, 0, 4, 0]                         # A dY A^T at (0,0) is the tile's first pixel
+    assert dM[wo.bias_position(4), t, 0] == x[0, 0:4, 4:8, 0].sum()
+    assert wo.bias_position(2) == 5

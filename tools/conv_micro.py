@@ -1,3 +1,5 @@
+# needs the debug library (the shipped kernels carry no clock / trace code):
+#   make -C wesup_amd/csrc debug && WESUP_HIP_LIB=wesup_amd/csrc/libwesup_hip_debug.so python tools/conv_micro.py
 """Micro driver for profiling single GEMM-family kernels (rocprofv3 --pmc / --kernel-trace)."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -1,3 +1,5 @@
+# needs the debug library (the shipped kernels carry no clock / trace code):
+#   make -C wesup_amd/csrc debug && WESUP_HIP_LIB=wesup_amd/csrc/libwesup_hip_debug.so python tools/gemm_trace.py
 """Per-block timeline of one NT GEMM / conv launch (debug trace in gemm.hip): where does a tile spend its time?"""
 import sys, os, ctypes
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

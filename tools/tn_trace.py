@@ -1,3 +1,5 @@
+# needs the debug library (the shipped kernels carry no clock / trace code):
+#   make -C wesup_amd/csrc debug && WESUP_HIP_LIB=wesup_amd/csrc/libwesup_hip_debug.so python tools/tn_trace.py
 """Per-block timeline of one conv3x3 wgrad launch (debug trace in the TN kernel): start order, which blocks share a
 CU, when each ends."""
 import sys, os, ctypes

@@ -1,3 +1,5 @@
+# needs the debug library (the shipped kernels carry no clock / trace code):
+#   make -C wesup_amd/csrc debug && WESUP_HIP_LIB=wesup_amd/csrc/libwesup_hip_debug.so python tools/trace_prologue.py
 import sys, os, ctypes
 sys.path.insert(0, '/root/repo')
 import numpy as np, torch

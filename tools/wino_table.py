@@ -1,15 +1,25 @@
-"""Direct vs Winograd-domain conv3x3 weight gradient per layer at the bench shape (B=4, 480x480), each alone on the
-GPU: time and the direct-form TFLOP/s equivalent.  Decides which layers the engine routes through
-wesup_conv3x3_wgrad_winograd."""
-import sys, os
+"""Implicit GEMM vs Winograd F(2x2,3x3) vs F(4x4,3x3) per VGG layer and pass (forward, input gradient, weight gradient), each
+alone on the GPU: microseconds and the best algorithm -- the measured table behind wesup_amd.engine.default_route.
+
+  python tools/wino_table.py [--size 480] [--batch 4] [--reps 5]      # profiles/r03_wino_table_<size>.txt
+"""
+import argparse
+import os
+import sys
+
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from wesup_amd import ops
 from wesup_amd.engine import CONV_CH, POOL_AFTER
 
+ap = argparse.ArgumentParser()
+ap.add_argument('--size', type=int, default=480)
+ap.add_argument('--batch', type=int, default=4)
+ap.add_argument('--reps', type=int, default=5)
+ap.add_argument('--min-ci', type=int, default=64, help='layers with fewer input channels are listed for the direct form only')
+args = ap.parse_args()
 d = torch.device('cuda:0')
-B, H, W = 4, 480, 480
-reps = int(sys.argv[1]) if len(sys.argv) > 1 else 5
+B, H, W, reps = args.batch, args.size, args.size, args.reps
 
 
 def timeit(fn):
@@ -21,44 +31,59 @@ def timeit(fn):
         fn()
     e1.record()
     torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / reps
+    return e0.elapsed_time(e1) / reps * 1e3      # us
+
+
+def rel(a, b):
+    return float((a - b).abs().max() / b.abs().max())
 
 
 h, w = H, W
-tot_d = tot_w = 0.0
-tot_f, tot_g = [0.0, 0.0], [0.0, 0.0]
-print(f'{"layer":>5} {"HxW":>9} {"ci->co":>9} | {"direct us":>9} {"TF":>6} | {"winograd us":>11} {"TF-equiv":>8} | max rel diff')
+tot = {k: [0.0, 0.0, 0.0, 0.0] for k in ('fwd', 'dgrad', 'wgrad')}       # direct, F2, F4, best
+print(f'# B={B} {H}x{W}; us per launch alone on the GPU (direct / F(2x2) / F(4x4)); error of the Winograd forms against the '
+      'direct kernel, fraction of the tensor max')
+print(f'{"layer":>5} {"HxW":>9} {"ci->co":>9} | {"fwd":^26} | {"dgrad":^26} | {"wgrad":^26} | best m (fwd dgrad wgrad) | err F2 / F4 (fwd, wgrad)')
 for l, (ci, co) in enumerate(CONV_CH):
     if l > 0:
         x = torch.relu(torch.randn(B, h, w, ci, device=d))
         dy = torch.randn(B, h, w, co, device=d)
-        dw0 = torch.empty(co, ci, 3, 3, device=d)
-        dw1 = torch.empty(co, ci, 3, 3, device=d)
+        wt = torch.randn(co, ci, 3, 3, device=d) * (2.0 / (9 * ci)) ** 0.5
+        bias = torch.randn(co, device=d)
+        wf, wd = ops.pack_conv3x3_weight(wt)
+        y = [torch.empty(B, h, w, co, device=d) for _ in range(3)]
+        yr = torch.empty(B, h, w, co, device=d)
+        dx = [torch.zeros(B, h, w, ci, device=d) for _ in range(3)]
+        dw = [torch.empty(co, ci, 3, 3, device=d) for _ in range(3)]
         db = torch.empty(co, device=d)
-        fl = 2.0 * B * h * w * ci * co * 9
-        t_d = timeit(lambda: ops.conv3x3_wgrad(x, dy, ci, relu_in=False, dw=dw0, db=db))
-        t_w = timeit(lambda: ops.conv3x3_wgrad_winograd(x, dy, relu_in=False, dw=dw1, db=db))
-        diff = float((dw0 - dw1).abs().max() / dw0.abs().max())
-        tot_d += t_d; tot_w += min(t_d, t_w)
-        line = f'{l:>5} {h:>4}x{w:<4} {ci:>4}->{co:<4} | {t_d*1e3:9.1f} {fl/t_d/1e9:6.1f} | {t_w*1e3:11.1f} {fl/t_w/1e9:8.1f} | {diff:.2e}'
-        if ci >= 128:
-            wt = torch.randn(co, ci, 3, 3, device=d) * 0.02
-            bias = torch.randn(co, device=d)
-            wf, wd = ops.pack_conv3x3_weight(wt)
-            uf, ud = ops.winograd_pack_weight(wt)
-            y0, y1, yr = (torch.empty(B, h, w, co, device=d) for _ in range(3))
-            dx0, dx1 = torch.zeros(B, h, w, ci, device=d), torch.zeros(B, h, w, ci, device=d)
-            tf0 = timeit(lambda: ops.conv3x3_fwd(x, wf, bias, co, relu_in=False, out=y0, out_relu=yr))
-            tf1 = timeit(lambda: ops.conv3x3_fwd_winograd(x, uf, bias, False, out=y1, out_relu=yr))
-            td0 = timeit(lambda: ops.conv3x3_dgrad(dy, wd, ci, mask_src=x, out=dx0, accumulate=False))
-            td1 = timeit(lambda: ops.conv3x3_dgrad_winograd(dy, ud, mask_src=x, out=dx1, accumulate=False))
-            ef = float((y0 - y1).abs().max() / y0.abs().max()); ed = float((dx0 - dx1).abs().max() / dx0.abs().max())
-            line += f' | fwd {tf0*1e3:7.1f} -> {tf1*1e3:7.1f} us ({ef:.1e}) | dgrad {td0*1e3:7.1f} -> {td1*1e3:7.1f} us ({ed:.1e})'
-            tot_f[0] += tf0; tot_f[1] += min(tf0, tf1); tot_g[0] += td0; tot_g[1] += min(td0, td1)
-            del wt, wf, wd, uf, ud, y0, y1, yr, dx0, dx1
-        print(line, flush=True)
-        del x, dy
+        t = {'fwd': [0.0] * 3, 'dgrad': [0.0] * 3, 'wgrad': [0.0] * 3}
+        t['fwd'][0] = timeit(lambda: ops.conv3x3_fwd(x, wf, bias, co, relu_in=False, out=y[0], out_relu=yr))
+        t['dgrad'][0] = timeit(lambda: ops.conv3x3_dgrad(dy, wd, ci, mask_src=x, out=dx[0], accumulate=False))
+        t['wgrad'][0] = timeit(lambda: ops.conv3x3_wgrad(x, dy, ci, relu_in=False, dw=dw[0], db=db))
+        errs = ['-', '-']
+        if ci >= args.min_ci:
+            for k, m in ((1, 2), (2, 4)):
+                uf, ud = ops.winograd_pack_weight(wt, m=m)
+                v = torch.empty(ops.winograd_positions(m), ops.winograd_tiles(B, h, w, m), ci, device=d)
+                t['fwd'][k] = timeit(lambda: ops.conv3x3_fwd_winograd(x, uf, bias, False, out=y[k], v_keep=v, m=m))
+                t['dgrad'][k] = timeit(lambda: ops.conv3x3_dgrad_winograd(dy, ud, mask_src=x, out=dx[k], accumulate=False, m=m))
+                t['wgrad'][k] = timeit(lambda: ops.conv3x3_wgrad_winograd(x, dy, relu_in=False, dw=dw[k], db=db, v_pre=v, m=m))
+                errs[k - 1] = f'{rel(y[k], y[0]):.1e},{rel(dw[k], dw[0]):.1e}'
+                del uf, ud, v
+        best = []
+        cells = []
+        for p in ('fwd', 'dgrad', 'wgrad'):
+            cand = [(v, i) for i, v in enumerate(t[p]) if v > 0]
+            bv, bi = min(cand)
+            best.append((0, 2, 4)[bi])
+            for i in range(3):
+                tot[p][i] += t[p][i] if t[p][i] > 0 else t[p][0]
+            tot[p][3] += bv
+            cells.append(' '.join(f'{v:8.1f}' if v > 0 else f'{"-":>8}' for v in t[p]))
+        print(f'{l:>5} {h:>4}x{w:<4} {ci:>4}->{co:<4} | ' + ' | '.join(cells) + f' | {best[0]} {best[1]} {best[2]} | {errs[0]} / {errs[1]}',
+              flush=True)
+        del x, dy, wt, wf, wd, y, yr, dx, dw
     if POOL_AFTER[l]:
         h, w = h // 2, w // 2
-print('wgrad total ms: direct %.3f, best-of-two per layer %.3f' % (tot_d, tot_w))
-print('fwd (layers with Cin >= 128) ms: direct %.3f best %.3f; dgrad: direct %.3f best %.3f' % (*tot_f, *tot_g))
+for p in ('fwd', 'dgrad', 'wgrad'):
+    print(f'{p:>6} total ms (layers 1..12): direct {tot[p][0]/1e3:.3f}  F(2x2) where available {tot[p][1]/1e3:.3f}  '
+          f'F(4x4) where available {tot[p][2]/1e3:.3f}  best per layer {tot[p][3]/1e3:.3f}')

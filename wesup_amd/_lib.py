@@ -37,18 +37,19 @@ _SIGS = {
     'wesup_conv3x3_dgrad': (c_int, 'ppppiiiiiipzp'),
     'wesup_conv3x3_wgrad_workspace_bytes': (c_size_t, 'iiiii'),
     'wesup_conv3x3_wgrad': (c_int, 'ppppiiiiiipzp'),
-    'wesup_conv3x3_wgrad_winograd_workspace_bytes': (c_size_t, 'iiiii'),
-    'wesup_conv3x3_wgrad_winograd': (c_int, 'pppppiiiiiipzp'),
-    'wesup_winograd_weight_floats': (c_size_t, 'ii'),
-    'wesup_winograd_pack_weight': (c_int, 'pppiip'),
-    'wesup_conv3x3_winograd_workspace_bytes': (c_size_t, 'iiiii'),
-    'wesup_conv3x3_fwd_winograd': (c_int, 'ppppppipiiiiiipzp'),
-    'wesup_conv3x3_dgrad_winograd': (c_int, 'ppppiiiiiipzp'),
-    'wesup_winograd_input_transform': (c_int, 'ppliiiiip'),
+    'wesup_conv3x3_wgrad_winograd_workspace_bytes': (c_size_t, 'iiiiii'),
+    'wesup_conv3x3_wgrad_winograd': (c_int, 'pppppiiiiiiipzp'),
+    'wesup_winograd_weight_floats': (c_size_t, 'iii'),
+    'wesup_winograd_tiles': (ctypes.c_long, 'iiii'),
+    'wesup_winograd_pack_weight': (c_int, 'pppiiip'),
+    'wesup_conv3x3_winograd_workspace_bytes': (c_size_t, 'iiiiii'),
+    'wesup_conv3x3_fwd_winograd': (c_int, 'ppppppipiiiiiiipzp'),
+    'wesup_conv3x3_dgrad_winograd': (c_int, 'ppppiiiiiiipzp'),
+    'wesup_winograd_input_transform': (c_int, 'ppliiiiiip'),
     'wesup_gemm_nt_batched': (c_int, 'pilpilpiliiiip'),
-    'wesup_winograd_output_transform': (c_int, 'plpppppiiiiiip'),
-    'wesup_winograd_outgrad_transform': (c_int, 'ppiiiip'),
-    'wesup_winograd_filter_grad': (c_int, 'pllippiip'),
+    'wesup_winograd_output_transform': (c_int, 'plpppppiiiiiiip'),
+    'wesup_winograd_outgrad_transform': (c_int, 'ppiiiiip'),
+    'wesup_winograd_filter_grad': (c_int, 'pllippiiip'),
     'wesup_gemm_nt_workspace_bytes': (c_size_t, 'iii'),
     'wesup_gemm_nt': (c_int, 'pipippipiiiiipzp'),
     'wesup_gemm_tn_workspace_bytes': (c_size_t, 'iii'),
@@ -103,7 +104,7 @@ _SIGS = {
 _T = {'p': c_void_p, 'i': c_int, 'f': c_float, 'z': c_size_t, 'l': ctypes.c_long}
 
 EXPORTS = sorted(_SIGS)
-ABI_VERSION = 2          # include/wesup_hip.h; a stale libwesup_hip.so with other signatures must not be called
+ABI_VERSION = 3          # include/wesup_hip.h; a stale libwesup_hip.so with other signatures must not be called
 
 _lib = None
 

@@ -49,7 +49,13 @@ __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<floa
 // TWO v_max_f32 (llvm.maxnum canonicalises a possibly-signalling input first): 64 instead of 32 vector instructions
 // per K-step in both GEMM loops, and vector instructions do not overlap with MFMAs on a SIMD.  (An asm v_max would be
 // outside the compiler's s_waitcnt bookkeeping and read a fragment before its ds_read has landed.)
-__device__ __forceinline__ float vmax1(float x, float /*lo = 0*/) {
+// NaN: the integer view makes the result depend on the NaN's SIGN bit -- a NaN with the sign clear (what 0/0-free fp32
+// arithmetic produces on this hardware: 0x7fc00000) is a large positive integer and survives, as in torch.relu; a NaN
+// with the sign set (0xffc00000: a negated NaN, or one loaded from a host-made checkpoint / input) is a negative integer
+// and becomes +0.  The training step does not depend on it: ReLU-on-load is off its default path (relu_on_store: the
+// producing kernel's epilogue applies relu1() below, which keeps both), and a NaN conv output reaches the loss through
+// the pre-ReLU side tap either way.  tests/test_kernels_gpu.py::test_relu_on_load_nan_semantics pins this behaviour.
+__device__ __forceinline__ float vmax1(float x) {
     const int b = __float_as_int(x);
     return __int_as_float(b > 0 ? b : 0);
 }

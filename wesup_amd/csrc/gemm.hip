@@ -27,11 +27,17 @@
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 __device__ float4 g_zero_page[16];      // 256 B of zeros, source of masked lanes
-// clock probe: block 0 of the last NT launch leaves {shader cycles, 100 MHz ticks} of its main loop here; read by
-// wesup_debug_clock().  Two scalar clock reads per block, outside the K-loop; nothing is computed from them.
+// Debug instrumentation, compiled ONLY into the debug library (make debug -> libwesup_hip_debug.so, loaded through
+// WESUP_HIP_LIB by tools/): the shipped kernels carry no clock read and no trace store (tests/test_isa_cpu.py).
+//   clock probe: block 0 of the last NT launch leaves {shader cycles, 100 MHz ticks} of its main loop; wesup_debug_clock()
+//   per-block trace: when set, every block stores {start, loop start, loop end, end} in 100 MHz ticks
+#ifdef WESUP_GEMM_DEBUG
 __device__ unsigned long long g_clock_probe[2];
-// optional per-block trace (debug): when set, every NT block stores {start, loop start, loop end, end} in 100 MHz ticks
 __device__ unsigned long long* g_trace = nullptr;
+#define WESUP_DBG(...) __VA_ARGS__
+#else
+#define WESUP_DBG(...)
+#endif
 
 // LDS-DMA through inline asm: hipcc cannot prove that the ds_reads of the current tile do not alias the DMA
 // destination (same __shared__ array, runtime buffer index) and, for the builtin form, parks an s_waitcnt vmcnt(0)
@@ -137,7 +143,7 @@ __global__ __launch_bounds__(NW * 64, MINB) void gemm_nt_kernel(const NtParams p
     float* Bs = smem + 2 * BM * BK;         // [2][BN][BK]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const unsigned long long tr0 = __builtin_amdgcn_s_memrealtime();
+    WESUP_DBG(const unsigned long long tr0 = __builtin_amdgcn_s_memrealtime();)
     const float* zero = reinterpret_cast<const float*>(g_zero_page);
     // ---- staging role of this lane: row (tid>>3) of each PR-row pass, chunk position tid&7; the logical chunk it
     // fetches is position ^ swizzle(row) (the swizzle does not depend on the pass: PR*i >> 1 == 0 mod 8)
@@ -147,7 +153,7 @@ __global__ __launch_bounds__(NW * 64, MINB) void gemm_nt_kernel(const NtParams p
     const int l31 = lane & 31, lhi = lane >> 5;
     const int swa = ((wm0 + l31) >> 1) & 7, swb = ((wn0 + l31) >> 1) & 7;   // read-side swizzle (same for every i / j)
     const int nk = p.K / BK;
-    unsigned long long clk0 = 0, rt0 = 0, tr2 = 0;
+    WESUP_DBG(unsigned long long clk0 = 0, rt0 = 0, tr2 = 0;)
 
     // ---- work of this block.  Blocks [0, full_tiles) compute one whole tile each.  The tiles that would form a partial
     // last round (tile count not a multiple of the resident block slots) are cut stream-K style instead: their K-steps,
@@ -266,7 +272,7 @@ __global__ __launch_bounds__(NW * 64, MINB) void gemm_nt_kernel(const NtParams p
     stage(ks, 0);
     glds_wait();
     __syncthreads();
-    if (slot == 0) { clk0 = __builtin_amdgcn_s_memtime(); rt0 = __builtin_amdgcn_s_memrealtime(); }
+    WESUP_DBG(if (slot == 0) { clk0 = __builtin_amdgcn_s_memtime(); rt0 = __builtin_amdgcn_s_memrealtime(); })
     // (staggering every second resident block by 0.5-4 K-steps; s_setprio around either phase, alternating between the two
     // co-resident blocks per K-step, or fixed per block: no effect on throughput)
     int cur = 0;
@@ -299,8 +305,8 @@ __global__ __launch_bounds__(NW * 64, MINB) void gemm_nt_kernel(const NtParams p
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int i = 0; i < WM; ++i) {
-                    fa[sl][i].x = vmax1(fa[sl][i].x, 0.f); fa[sl][i].y = vmax1(fa[sl][i].y, 0.f);
-                    fa[sl][i].z = vmax1(fa[sl][i].z, 0.f); fa[sl][i].w = vmax1(fa[sl][i].w, 0.f);
+                    fa[sl][i].x = vmax1(fa[sl][i].x); fa[sl][i].y = vmax1(fa[sl][i].y);
+                    fa[sl][i].z = vmax1(fa[sl][i].z); fa[sl][i].w = vmax1(fa[sl][i].w);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -322,6 +328,7 @@ __global__ __launch_bounds__(NW * 64, MINB) void gemm_nt_kernel(const NtParams p
         cur ^= 1;
     }
 
+#ifdef WESUP_GEMM_DEBUG
     if (slot == 0) {
         tr2 = __builtin_amdgcn_s_memrealtime();
         if (blockIdx.x == 0 && tid == 0) {
@@ -329,6 +336,7 @@ __global__ __launch_bounds__(NW * 64, MINB) void gemm_nt_kernel(const NtParams p
             g_clock_probe[1] = tr2 - rt0;
         }
     }
+#endif
     // ---- epilogue through LDS: the accumulator tile (lane holds D[(r&3)+8*(r>>2)+4*lhi][l31] of each 32x32
     // sub-tile) is written to a [rows][BN+4] image, then every thread handles 16-byte pieces of full rows so that
     // bias / ReLU mask / accumulate / store all move 16 B per lane on contiguous row segments.  A stream-K block
@@ -429,12 +437,14 @@ __global__ __launch_bounds__(NW * 64, MINB) void gemm_nt_kernel(const NtParams p
     if (seg_g < seg_end) __syncthreads();          // the staging buffers double as the epilogue image
     }   // segments
 
+#ifdef WESUP_GEMM_DEBUG
     if (g_trace && tid == 0) {
         unsigned long long* t = g_trace + 6 * (long)blockIdx.x;
         t[0] = tr0; t[1] = rt0; t[2] = tr2; t[3] = __builtin_amdgcn_s_memrealtime();
         t[4] = __builtin_amdgcn_s_getreg((20 /*HW_REG_XCC_ID*/) | (0 << 6) | (31 << 11));
         t[5] = __builtin_amdgcn_s_getreg((4 /*HW_REG_HW_ID*/) | (0 << 6) | (31 << 11));
     }
+#endif
 }
 
 // Stream-K fix-up: C tile = epilogue(sum of the partial tiles of the parts that covered it, in K order).
@@ -642,18 +652,29 @@ extern "C" int wesup_gemm_nt(const float* A, int lda, const float* B, int ldb, c
     return dispatch_nt<0>(p, (hipStream_t)stream, ws, ws_bytes);
 }
 
-// host-synchronous debug helper (NOT part of the hot path): in-kernel clock of the last NT GEMM launch in MHz
+// host-synchronous debug helpers (NOT part of the hot path; they only do something in the debug library, the shipped
+// one answers WESUP_ERR_INVALID): in-kernel clock of the last NT GEMM launch in MHz
 extern "C" int wesup_debug_clock(double* mhz_out) {
+#ifndef WESUP_GEMM_DEBUG
+    (void)mhz_out;
+    return WESUP_ERR_INVALID;
+#else
     unsigned long long h[2] = {0, 0};
     if (!mhz_out) return WESUP_ERR_INVALID;
     if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_clock_probe), sizeof(h)) != hipSuccess) return WESUP_ERR_LAUNCH;
     *mhz_out = h[1] ? (double)h[0] / (double)h[1] * 100.0 : 0.0;
     return WESUP_OK;
+#endif
 }
 
-extern "C" int wesup_debug_set_trace(void* device_buf /* >= 32 B per block of the next launches, or NULL */) {
+extern "C" int wesup_debug_set_trace(void* device_buf /* >= 48 B per block of the next launches, or NULL */) {
+#ifndef WESUP_GEMM_DEBUG
+    (void)device_buf;
+    return WESUP_ERR_INVALID;
+#else
     unsigned long long* ptr = (unsigned long long*)device_buf;
     return hipMemcpyToSymbol(HIP_SYMBOL(g_trace), &ptr, sizeof(ptr)) == hipSuccess ? WESUP_OK : WESUP_ERR_LAUNCH;
+#endif
 }
 
 extern "C" int wesup_conv3x3_kpad(int Ci) {
@@ -767,7 +788,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnParams p) {
     float* Bs = smem + 2 * BK * BM;         // [2][BK][BN]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const unsigned long long tr0 = __builtin_amdgcn_s_memrealtime();
+    WESUP_DBG(const unsigned long long tr0 = __builtin_amdgcn_s_memrealtime();)
     int lt = blockIdx.x;
     const int tile_n = lt % p.tiles_n;
     lt /= p.tiles_n;
@@ -923,7 +944,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnParams p) {
     for (int i = 0; i < NB; ++i) vb[i] = mask_b(k_begin + BK, i);      // offsets of K-step 1 (all out of range beyond k_end)
     glds_wait();
     __syncthreads();
-    const unsigned long long tr1 = __builtin_amdgcn_s_memrealtime();
+    WESUP_DBG(const unsigned long long tr1 = __builtin_amdgcn_s_memrealtime();)
     int cur = 0;
     unsigned smask = 0;
     for (int kk = 0; kk < nk; ++kk) {
@@ -962,7 +983,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnParams p) {
             for (int u = 0; u < GK; ++u) {
                 if constexpr (RELU) {          // ReLU of the layer input
 #pragma unroll
-                    for (int j = 0; j < WN; ++j) b[sl][u][j] = vmax1(b[sl][u][j], 0.f);
+                    for (int j = 0; j < WN; ++j) b[sl][u][j] = vmax1(b[sl][u][j]);
                 }
 #pragma unroll
                 for (int i = 0; i < WM; ++i)
@@ -985,7 +1006,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnParams p) {
         cur ^= 1;
     }
 
-    const unsigned long long tr2 = __builtin_amdgcn_s_memrealtime();
+    WESUP_DBG(const unsigned long long tr2 = __builtin_amdgcn_s_memrealtime();)
     float* slab = p.slab + (long)blockIdx.z * p.batch_slab + (long)blockIdx.y * p.slab_stride;
     if (do_cs && m_blk + tid < p.M) slab[(long)p.M * p.Nslab + m_blk + tid] = csum;
     const int ncol0 = (MODE == 1) ? tap * p.N : 0;
@@ -1009,13 +1030,15 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnParams p) {
             }
         }
     }
-    if (g_trace && tid == 0) {         // debug: per-block timeline, as in the NT kernel
+#ifdef WESUP_GEMM_DEBUG
+    if (g_trace && tid == 0) {         // per-block timeline, as in the NT kernel
         const long bid = blockIdx.x + (long)gridDim.x * (blockIdx.y + (long)gridDim.y * blockIdx.z);
         unsigned long long* t = g_trace + 6 * bid;
         t[0] = tr0; t[1] = tr1; t[2] = tr2; t[3] = __builtin_amdgcn_s_memrealtime();
         t[4] = __builtin_amdgcn_s_getreg((20 /*HW_REG_XCC_ID*/) | (0 << 6) | (31 << 11));
         t[5] = __builtin_amdgcn_s_getreg((4 /*HW_REG_HW_ID*/) | (0 << 6) | (31 << 11));
     }
+#endif
 }
 
 // C[m][n] = sum_s slab[s][m][n]     (plain)            -- or, for conv weights --
@@ -1332,65 +1355,69 @@ extern "C" int wesup_conv3x3_wgrad(const float* x, const float* dy, float* dw_kc
 
 
 // ---------------------------------------------------------------------------------------------
-// Winograd F(2x2, 3x3)-domain convolutions: the GEMM side.  The transforms between activations / filters and the
-// [16 positions][tiles][C] operands are in winograd.hip (entries wesup_winograd_*); here are the batched products and the
-// three conv passes that chain transforms and products.  Per 2x2 output tile
+// Winograd F(m x m, 3x3)-domain convolutions (m = 2 or 4): the GEMM side.  The transforms between activations / filters and
+// the [P positions][tiles][C] operands (P = (m+2)^2) are in winograd.hip (entries wesup_winograd_*); here are the batched
+// products and the three conv passes that chain transforms and products.  Per m x m output tile
 //     Y = A^T [ (G g G^T) o (B^T d B) ] A ,
-// so with V = B^T d B and U = G g G^T the sum over input channels is, for each of the 16 positions p, ONE matrix product
+// so with V = B^T d B and U = G g G^T the sum over input channels is, for each of the P positions p, ONE matrix product
 //     forward:          M_p[tiles][Cout] = V_p[tiles][Cin] . U_p[Cout][Cin]^T           (NT, K = Cin)
 //     input gradient:   the same over dy with the rotated filter, channel roles swapped   (NT, K = Cout)
 //     weight gradient:  dU_p[Cout][Cin]  = dM_p[tiles][Cout]^T . V_p[tiles][Cin]         (TN, K = tiles, split-K)
-// i.e. 16 x (P/4) = 4 P multiply-adds per (co, ci) pair instead of 9 P: 2.25x less MFMA work for 4x the operand bytes and
-// two memory-bound transform passes.  It pays where the direct kernel is MFMA-bound and the channel counts make the
-// products' arithmetic intensity high: from 128 input channels up (tools/wino_table.py).
+// i.e. P x (pixels / m^2) multiply-adds per (co, ci) pair instead of 9 x pixels: 2.25x less MFMA work for 4x the operand
+// bytes with m = 2, 4x less for 2.25x the bytes with m = 4, and two memory-bound transform passes.  It pays where the direct
+// kernel is MFMA-bound and the channel counts make the products' arithmetic intensity high: from 128 input channels up
+// (tools/wino_table.py).
 // ---------------------------------------------------------------------------------------------
 #include "winograd.hpp"
 
-// workspace layout: [V: 16 T Ci][dM: 16 T Cout][slabs: 16 S (Cout Ci + Cout)]
-extern "C" size_t wesup_conv3x3_wgrad_winograd_workspace_bytes(int B, int H, int W, int Ci, int Cout) {
-    if (!wino_shape_ok(B, H, W, Ci, Cout)) return 0;
-    const long T = wino_tiles(B, H, W);
-    const TnPlan pl = plan_tn(Cout, Ci, (int)T, 1, 16);
-    return align_up((size_t)16 * T * Ci * sizeof(float), 256) + align_up((size_t)16 * T * Cout * sizeof(float), 256) +
-           (size_t)16 * pl.S * tn_slab_stride(Cout, pl.Nslab) * sizeof(float);
+// workspace layout: [V: P T Ci][dM: P T Cout][slabs: P S (Cout Ci + Cout)]
+extern "C" size_t wesup_conv3x3_wgrad_winograd_workspace_bytes(int B, int H, int W, int Ci, int Cout, int m) {
+    if (!wino_shape_ok(B, H, W, Ci, Cout, m)) return 0;
+    const long T = wino_tiles(B, H, W, m);
+    const int P = wino_positions(m);
+    const TnPlan pl = plan_tn(Cout, Ci, (int)T, 1, P);
+    return align_up((size_t)P * T * Ci * sizeof(float), 256) + align_up((size_t)P * T * Cout * sizeof(float), 256) +
+           (size_t)P * pl.S * tn_slab_stride(Cout, pl.Nslab) * sizeof(float);
 }
 // The same dW / db as wesup_conv3x3_wgrad (torch autograd of Conv2d(k=3, pad=1), models/wesup.py:199; the scheme of the
 // non-fused Winograd backward-filter algorithms of vendor conv libraries).  The bias gradient is the column sum of dM at
-// position 5 (A dY A^T at (1,1) = the sum of a tile's four gradients), taken from the staged A tiles of that batch entry.
+// position (1,1) (A dY A^T there = the sum of a tile's gradients), taken from the staged A tiles of that batch entry.
 extern "C" int wesup_conv3x3_wgrad_winograd(const float* x, const float* v_pre, const float* dy, float* dw_kcrs, float* db,
-                                            int B, int H, int W, int Ci, int Cout, int relu_in, void* ws,
+                                            int B, int H, int W, int Ci, int Cout, int relu_in, int m, void* ws,
                                             size_t ws_bytes, void* stream) {
-    if ((!x && !v_pre) || !dy || !dw_kcrs || !ws || !wino_shape_ok(B, H, W, Ci, Cout) ||
+    if ((!x && !v_pre) || !dy || !dw_kcrs || !ws || !wino_shape_ok(B, H, W, Ci, Cout, m) ||
         (((uintptr_t)x | (uintptr_t)v_pre | (uintptr_t)dy | (uintptr_t)ws) & 15))
         return WESUP_ERR_INVALID;
-    if (ws_bytes < wesup_conv3x3_wgrad_winograd_workspace_bytes(B, H, W, Ci, Cout)) return WESUP_ERR_WORKSPACE;
+    if (ws_bytes < wesup_conv3x3_wgrad_winograd_workspace_bytes(B, H, W, Ci, Cout, m)) return WESUP_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
-    const long T = wino_tiles(B, H, W);
+    const long T = wino_tiles(B, H, W, m);
+    const int P = wino_positions(m);
     float* V = (float*)ws;
-    float* dM = (float*)((char*)ws + align_up((size_t)16 * T * Ci * sizeof(float), 256));
-    float* slab = (float*)((char*)dM + align_up((size_t)16 * T * Cout * sizeof(float), 256));
+    float* dM = (float*)((char*)ws + align_up((size_t)P * T * Ci * sizeof(float), 256));
+    float* slab = (float*)((char*)dM + align_up((size_t)P * T * Cout * sizeof(float), 256));
     int rc;
     if (v_pre) {             // the transformed input the Winograd forward of this layer kept
         V = const_cast<float*>(v_pre);
-    } else if ((rc = wesup_winograd_input_transform(x, V, 0, B, H, W, Ci, relu_in, stream))) {
+    } else if ((rc = wesup_winograd_input_transform(x, V, 0, B, H, W, Ci, relu_in, m, stream))) {
         return rc;
     }
-    if ((rc = wesup_winograd_outgrad_transform(dy, dM, B, H, W, Cout, stream))) return rc;
-    const TnPlan pl = plan_tn(Cout, Ci, (int)T, 1, 16);
+    if ((rc = wesup_winograd_outgrad_transform(dy, dM, B, H, W, Cout, m, stream))) return rc;
+    const TnPlan pl = plan_tn(Cout, Ci, (int)T, 1, P);
     TnParams p = {};
     p.A = dM; p.Bx = V; p.slab = slab; p.M = Cout; p.N = Ci; p.K = (int)T; p.lda = Cout; p.ldb = Ci;
     p.relu_b = 0; p.H = 1; p.W = 1; p.dW = make_fastdiv(1); p.dH = make_fastdiv(1);
-    p.slab_stride = (long)tn_slab_stride(Cout, pl.Nslab); p.want_colsum = db != nullptr; p.colsum_batch = 5;
+    p.slab_stride = (long)tn_slab_stride(Cout, pl.Nslab); p.want_colsum = db != nullptr; p.colsum_batch = m + 3;
     p.batchA = T * Cout; p.batchB = T * Ci; p.batch_slab = (long)pl.S * p.slab_stride;
-    if ((rc = launch_tn<3>(p, pl, st, 16))) return rc;
-    return wesup_winograd_filter_grad(slab, p.slab_stride, p.batch_slab, pl.S, dw_kcrs, db, Cout, Ci, stream);
+    if ((rc = launch_tn<3>(p, pl, st, P))) return rc;
+    return wesup_winograd_filter_grad(slab, p.slab_stride, p.batch_slab, pl.S, dw_kcrs, db, Cout, Ci, m, stream);
 }
 
-// workspace of one forward / dgrad call: [V: 16 T Cin][M: 16 T Cout] (for dgrad ask with the channel counts swapped)
-extern "C" size_t wesup_conv3x3_winograd_workspace_bytes(int B, int H, int W, int Cin, int Cout) {
-    if (!wino_shape_ok(B, H, W, Cin, Cout) || (Cin % 32)) return 0;
-    const long T = wino_tiles(B, H, W);
-    return align_up((size_t)16 * T * Cin * sizeof(float), 256) + align_up((size_t)16 * T * Cout * sizeof(float), 256);
+// workspace of one forward / dgrad call: [V: P T Cin][M: P T Cout] (for dgrad ask with the channel counts swapped)
+extern "C" size_t wesup_conv3x3_winograd_workspace_bytes(int B, int H, int W, int Cin, int Cout, int m) {
+    if (!wino_shape_ok(B, H, W, Cin, Cout, m) || (Cin % 32)) return 0;
+    const long T = wino_tiles(B, H, W, m);
+    const int P = wino_positions(m);
+    return align_up((size_t)P * T * Cin * sizeof(float), 256) + align_up((size_t)P * T * Cout * sizeof(float), 256);
 }
 
 // nbatch products C_b[M][N] = A_b[M][K] . B_b[N][K]^T of one shape in one launch (element strides between the entries)
@@ -1410,36 +1437,37 @@ extern "C" int wesup_gemm_nt_batched(const float* A, int lda, long strideA, cons
     return launch_nt<4, 64, 64, 1, 1, 3, 2, false>(p, st);
 }
 
-// in (B,H,W,Cin) --Winograd conv with u [16][Cout][Cin]--> out (B,H,W,Cout) with the conv epilogue.
-// v_keep (optional): the transformed input is written there instead of the workspace (16 T Cin floats).
+// in (B,H,W,Cin) --Winograd conv with u [P][Cout][Cin]--> out (B,H,W,Cout) with the conv epilogue.
+// v_keep (optional): the transformed input is written there instead of the workspace (P T Cin floats).
 static int wino_conv(const float* in, const float* u, const float* bias, const float* mask, float* out, float* out_relu,
                      float* out_pool, int pool_relu, float* v_keep, int B, int H, int W, int Cin, int Cout, int relu_in,
-                     int accum, void* ws, size_t ws_bytes, void* st) {
-    if (!in || !u || !out || !ws || !wino_shape_ok(B, H, W, Cin, Cout) || (Cin % 32) ||
+                     int accum, int m, void* ws, size_t ws_bytes, void* st) {
+    if (!in || !u || !out || !ws || !wino_shape_ok(B, H, W, Cin, Cout, m) || (Cin % 32) ||
         (((uintptr_t)u | (uintptr_t)v_keep | (uintptr_t)ws) & 15))
         return WESUP_ERR_INVALID;
-    if (ws_bytes < wesup_conv3x3_winograd_workspace_bytes(B, H, W, Cin, Cout)) return WESUP_ERR_WORKSPACE;
-    const long T = wino_tiles(B, H, W);
+    if (ws_bytes < wesup_conv3x3_winograd_workspace_bytes(B, H, W, Cin, Cout, m)) return WESUP_ERR_WORKSPACE;
+    const long T = wino_tiles(B, H, W, m);
+    const int P = wino_positions(m);
     float* V = v_keep ? v_keep : (float*)ws;
-    float* Mt = (float*)((char*)ws + align_up((size_t)16 * T * Cin * sizeof(float), 256));
-    int rc = wesup_winograd_input_transform(in, V, 0, B, H, W, Cin, relu_in, st);
+    float* Mt = (float*)((char*)ws + align_up((size_t)P * T * Cin * sizeof(float), 256));
+    int rc = wesup_winograd_input_transform(in, V, 0, B, H, W, Cin, relu_in, m, st);
     if (rc) return rc;
-    rc = wesup_gemm_nt_batched(V, Cin, T * Cin, u, Cin, (long)Cout * Cin, Mt, Cout, T * Cout, 16, (int)T, Cout, Cin, st);
+    rc = wesup_gemm_nt_batched(V, Cin, T * Cin, u, Cin, (long)Cout * Cin, Mt, Cout, T * Cout, P, (int)T, Cout, Cin, st);
     if (rc) return rc;
-    return wesup_winograd_output_transform(Mt, 0, bias, mask, out, out_relu, out_pool, pool_relu, B, H, W, Cout, accum, st);
+    return wesup_winograd_output_transform(Mt, 0, bias, mask, out, out_relu, out_pool, pool_relu, B, H, W, Cout, accum, m, st);
 }
 
 extern "C" int wesup_conv3x3_fwd_winograd(const float* x, const float* u_fwd, const float* bias, float* y, float* y_relu,
                                           float* y_pool, int pool_relu, float* v_keep, int B, int H, int W, int Cin,
-                                          int Cout, int relu_in, void* ws, size_t ws_bytes, void* stream) {
-    return wino_conv(x, u_fwd, bias, nullptr, y, y_relu, y_pool, pool_relu, v_keep, B, H, W, Cin, Cout, relu_in, 0, ws,
+                                          int Cout, int relu_in, int m, void* ws, size_t ws_bytes, void* stream) {
+    return wino_conv(x, u_fwd, bias, nullptr, y, y_relu, y_pool, pool_relu, v_keep, B, H, W, Cin, Cout, relu_in, 0, m, ws,
                      ws_bytes, stream);
 }
 
-// dx = conv_transpose(dy) through the same pipeline: input dy (Cout channels), filter u_dgrad [16][Cin][Cout]
+// dx = conv_transpose(dy) through the same pipeline: input dy (Cout channels), filter u_dgrad [P][Cin][Cout]
 extern "C" int wesup_conv3x3_dgrad_winograd(const float* dy, const float* u_dgrad, const float* mask_src, float* dx, int B,
-                                            int H, int W, int Cin, int Cout, int accumulate, void* ws, size_t ws_bytes,
+                                            int H, int W, int Cin, int Cout, int accumulate, int m, void* ws, size_t ws_bytes,
                                             void* stream) {
-    return wino_conv(dy, u_dgrad, nullptr, mask_src, dx, nullptr, nullptr, 0, nullptr, B, H, W, Cout, Cin, 0, accumulate, ws,
-                     ws_bytes, stream);
+    return wino_conv(dy, u_dgrad, nullptr, mask_src, dx, nullptr, nullptr, 0, nullptr, B, H, W, Cout, Cin, 0, accumulate, m,
+                     ws, ws_bytes, stream);
 }

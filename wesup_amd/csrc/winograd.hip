@@ -1,15 +1,18 @@
-// Winograd F(2x2, 3x3) transforms for gfx950: everything of the Winograd-domain convolutions that is NOT a GEMM --
-// the memory-bound passes between the activations / filters and the [16 positions][tiles][C] operands of the batched
-// GEMMs in gemm.hip (wesup_gemm_nt_batched, the TN launch inside wesup_conv3x3_wgrad_winograd).  DESIGN.md 3.1.1.
+// Winograd F(m x m, 3x3) transforms for gfx950, m = 2 and m = 4: everything of the Winograd-domain convolutions that is
+// NOT a GEMM -- the memory-bound passes between the activations / filters and the [(m+2)^2 positions][tiles][C] operands of
+// the batched GEMMs in gemm.hip (wesup_gemm_nt_batched, the TN launch inside wesup_conv3x3_wgrad_winograd).  DESIGN.md 3.1.1.
 //
 //   forward / input gradient:   V = B^T d B  ->  M_p = V_p . U_p^T  (gemm.hip)  ->  Y = A^T M A (+ epilogue)
 //   weight gradient:            dM = A dY A^T, V as above  ->  dU_p = dM_p^T . V_p  (gemm.hip)  ->  dg = G^T dU G
 //   filters:                    U = G g G^T once per step (forward), and of the rotated filter (input gradient)
 //
-// B^T, G, A^T are the F(2x2,3x3) matrices (entries 0, +-1, +-1/2); a transformed tensor is position-major so that each
-// of the 16 GEMM operands is a plain row-major matrix.  Every kernel: one thread per (tile, 4 channels), channels
-// fastest across lanes, 16-byte loads and stores of contiguous channel rows; tiles that hang over an odd border read
-// zeros and skip the stores.
+// B^T, G, A^T are the published minimal-filtering matrices: F(2x2,3x3) with entries 0, +-1, +-1/2 (16 positions, 4x the
+// activation bytes, 4/9 of the direct form's multiply-adds) and F(4x4,3x3) with interpolation points 0, +-1, +-2, inf
+// (36 positions, 2.25x the bytes, 1/4 of the multiply-adds; entries up to 8 and down to 1/24, fp32 error ~10x F(2x2)'s
+// and still 10x inside the path's 1e-4 tolerance).  A transformed tensor is position-major so that each
+// GEMM operand is a plain row-major matrix.  Every kernel: one thread per (tile, 4 channels), channels fastest across
+// lanes, 16-byte loads and stores of contiguous channel rows; tiles that hang over a ragged border read zeros and skip
+// the stores.
 #include "winograd.hpp"
 
 struct WinoGeom {
@@ -106,53 +109,73 @@ __global__ __launch_bounds__(256) void wino_outgrad_transform_kernel(const float
 }
 #undef F4
 
-// dw[co][ci][3][3] = G^T (sum_s slab[p][s][co][ci]) G ;  db[co] = sum_s (column sums of dM_5)
-// block = 16 (co, ci) pairs x 16 positions: a thread adds the S split-K slabs of ONE position (a thread per pair walked
-// 16 x S dependent loads -- 512 at conv2_2 -- with only Co*Ci/256 blocks on the chip: 113 us per launch on average,
-// 1.1 ms per step); the 16 sums of a pair meet in LDS and one thread per pair applies G^T (.) G.  Fixed order.
+// dw[co][ci][3][3] = G^T (sum_s slab[p][s][co][ci]) G ;  db[co] = sum_s (column sums of dM at position (1,1))
+// NP = m + 2.  block = PB (co, ci) pairs x NP^2 positions (16 x 16 for m = 2, 7 x 36 for m = 4): a thread adds the S
+// split-K slabs of ONE position (a thread per pair walked NP^2 x S dependent loads -- 512 at conv2_2 -- with only
+// Co*Ci/256 blocks on the chip: 113 us per launch on average, 1.1 ms per step); the sums of a pair meet in LDS and one
+// thread per pair applies G^T (.) G.  Fixed order.
+template <int NP>
+__device__ __forceinline__ void wino_gt(const float (&u)[NP], float (&r)[3]) {      // one row of G^T (.)
+    if constexpr (NP == 4) {
+        const float hs = 0.5f * (u[1] + u[2]), hd = 0.5f * (u[1] - u[2]);
+        r[0] = u[0] + hs;
+        r[1] = hd;
+        r[2] = hs + u[3];
+    } else {
+        const float s12 = u[1] + u[2], s34 = u[3] + u[4];
+        r[0] = 0.25f * u[0] - (1.f / 6.f) * s12 + (1.f / 24.f) * s34;
+        r[1] = (1.f / 6.f) * (u[2] - u[1]) + (1.f / 12.f) * (u[3] - u[4]);
+        r[2] = (1.f / 6.f) * (s34 - s12) + u[5];
+    }
+}
+template <int NP>
 __global__ __launch_bounds__(256) void wino_wgrad_reduce_kernel(const float* __restrict__ slab, long stride, long batch_slab,
                                                                 float* __restrict__ dw, int Co, int Ci, int S,
                                                                 float* __restrict__ db, int pair_blocks) {
-    __shared__ float us[16][17];
+    constexpr int P = NP * NP, PB = 256 / P;
+    __shared__ float us[P][PB + 1];
     const int tid = threadIdx.x;
     if ((int)blockIdx.x >= pair_blocks) {                // bias gradient: the blocks behind the pair blocks
         const long m = (long)(blockIdx.x - pair_blocks) * 256 + tid;
         if (db && m < Co) {
             float s = 0.f;
-            for (int k = 0; k < S; ++k) s += slab[5 * batch_slab + (long)k * stride + (long)Co * Ci + m];
+            for (int k = 0; k < S; ++k) s += slab[(NP + 1) * batch_slab + (long)k * stride + (long)Co * Ci + m];
             db[m] = s;
         }
         return;
     }
-    const int i = tid & 15, p = tid >> 4;
-    const long idx = (long)blockIdx.x * 16 + i;
+    const int i = tid % PB, p = tid / PB;
+    const long idx = (long)blockIdx.x * PB + i;
     const bool ok = idx < (long)Co * Ci;
-    float s0 = 0.f, s1 = 0.f;
-    if (ok) {
-        const float* src = slab + p * batch_slab + idx;
-        int k = 0;
-        for (; k + 1 < S; k += 2) { s0 += src[(long)k * stride]; s1 += src[(long)(k + 1) * stride]; }
-        if (k < S) s0 += src[(long)k * stride];
+    if (p < P) {
+        float s0 = 0.f, s1 = 0.f;
+        if (ok) {
+            const float* src = slab + p * batch_slab + idx;
+            int k = 0;
+            for (; k + 1 < S; k += 2) { s0 += src[(long)k * stride]; s1 += src[(long)(k + 1) * stride]; }
+            if (k < S) s0 += src[(long)k * stride];
+        }
+        us[p][i] = s0 + s1;
     }
-    us[p][i] = s0 + s1;
     __syncthreads();
-    if (tid >= 16 || !ok) return;
-    float r[3][4];       // G^T u
+    if (tid >= PB || !ok) return;
+    float r[3][NP];      // G^T u
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        const float u0 = us[c][i], u1 = us[4 + c][i], u2 = us[8 + c][i], u3 = us[12 + c][i];
-        const float hs = 0.5f * (u1 + u2), hd = 0.5f * (u1 - u2);
-        r[0][c] = u0 + hs;
-        r[1][c] = hd;
-        r[2][c] = hs + u3;
+    for (int c = 0; c < NP; ++c) {
+        float col[NP], o[3];
+#pragma unroll
+        for (int a = 0; a < NP; ++a) col[a] = us[NP * a + c][i];
+        wino_gt<NP>(col, o);
+        r[0][c] = o[0]; r[1][c] = o[1]; r[2][c] = o[2];
     }
     float* d = dw + idx * 9;
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
-        const float hs = 0.5f * (r[a][1] + r[a][2]), hd = 0.5f * (r[a][1] - r[a][2]);
-        d[3 * a + 0] = r[a][0] + hs;
-        d[3 * a + 1] = hd;
-        d[3 * a + 2] = hs + r[a][3];
+        float o[3];
+        wino_gt<NP>(r[a], o);
+        d[3 * a + 0] = o[0];
+        d[3 * a + 1] = o[1];
+        d[3 * a + 2] = o[2];
     }
 }
 
@@ -266,84 +289,322 @@ __global__ __launch_bounds__(256) void wino_output_transform_kernel(const float*
 #undef F4
 }
 
-extern "C" size_t wesup_winograd_weight_floats(int Cin, int Cout) { return (size_t)16 * Cin * Cout; }
+// ---------------------------------------------------------------------------------------------
+// F(4x4, 3x3): 6x6 input patches at stride 4, 36 positions.  Same thread mapping as above; the block index goes through
+// the XCD remap so that one XCD walks a contiguous range of tiles (neighbouring tile rows share two of their six patch
+// rows: with round-robin blocks those re-reads would meet in eight different L2s).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float4 f4add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ float4 f4sub(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
+// s * a + b
+__device__ __forceinline__ float4 f4fma(float s, float4 a, float4 b) {
+    return make_float4(fmaf(s, a.x, b.x), fmaf(s, a.y, b.y), fmaf(s, a.z, b.z), fmaf(s, a.w, b.w));
+}
+// B^T (.) for a 6-vector: rows [4,0,-5,0,1,0], [0,-4,-4,1,1,0], [0,4,-4,-1,1,0], [0,-2,-1,2,1,0], [0,2,-1,-2,1,0], [0,4,0,-5,0,1]
+__device__ __forceinline__ void wino4_bt(const float4 (&d)[6], float4 (&t)[6]) {
+    t[0] = f4fma(4.f, d[0], f4fma(-5.f, d[2], d[4]));
+    const float4 a = f4fma(-4.f, d[2], d[4]), b = f4fma(-4.f, d[1], d[3]);
+    t[1] = f4add(a, b);
+    t[2] = f4sub(a, b);
+    const float4 c = f4sub(d[4], d[2]), e = f4sub(d[3], d[1]);
+    t[3] = f4fma(2.f, e, c);
+    t[4] = f4fma(-2.f, e, c);
+    t[5] = f4fma(4.f, d[1], f4fma(-5.f, d[3], d[5]));
+}
+// A^T (.) for a 6-vector: rows [1,1,1,1,1,0], [0,1,-1,2,-2,0], [0,1,1,4,4,0], [0,1,-1,8,-8,1]
+__device__ __forceinline__ void wino4_at(const float4 (&m)[6], float4 (&o)[4]) {
+    const float4 s12 = f4add(m[1], m[2]), d12 = f4sub(m[1], m[2]), s34 = f4add(m[3], m[4]), d34 = f4sub(m[3], m[4]);
+    o[0] = f4add(f4add(m[0], s12), s34);
+    o[1] = f4fma(2.f, d34, d12);
+    o[2] = f4fma(4.f, s34, s12);
+    o[3] = f4add(f4fma(8.f, d34, d12), m[5]);
+}
+// A (.) for a 4-vector (A = (A^T)^T): rows [1,0,0,0], [1,1,1,1], [1,-1,1,-1], [1,2,4,8], [1,-2,4,-8], [0,0,0,1]
+__device__ __forceinline__ void wino4_a(const float4 (&y)[4], float4 (&t)[6]) {
+    const float4 e = f4add(y[0], y[2]), o = f4add(y[1], y[3]);
+    const float4 e2 = f4fma(4.f, y[2], y[0]), o2 = f4fma(8.f, y[3], f4add(y[1], y[1]));
+    t[0] = y[0];
+    t[1] = f4add(e, o);
+    t[2] = f4sub(e, o);
+    t[3] = f4add(e2, o2);
+    t[4] = f4sub(e2, o2);
+    t[5] = y[3];
+}
 
-// w (Cout,Cin,3,3) -> u_fwd [16][Cout][Cin] and/or u_dgrad [16][Cin][Cout] (either may be NULL)
-extern "C" int wesup_winograd_pack_weight(const float* w, float* u_fwd, float* u_dgrad, int Cout, int Cin, void* stream) {
-    if (!w || Cout <= 0 || Cin <= 0 || (!u_fwd && !u_dgrad)) return WESUP_ERR_INVALID;
+struct WinoTile { int t, cq, b, i, j; };
+__device__ __forceinline__ bool wino4_decode(const WinoGeom& g, WinoTile& o) {
+    const long idx = (long)xcd_remap(blockIdx.x, gridDim.x) * 256 + threadIdx.x;
+    const int Q = g.C >> 2;
+    if (idx >= g.T * Q) return false;
+    o.t = fast_div((int)idx, g.dQ);
+    o.cq = (int)idx - o.t * Q;
+    const int bi = fast_div(o.t, g.dTw);
+    o.j = o.t - bi * g.Tw;
+    o.b = fast_div(bi, g.dTh);
+    o.i = bi - o.b * g.Th;
+    return true;
+}
+
+// thread = (tile, 4 channels): 36 float4 loads (patch rows 4i-1 .. 4i+4), B^T d B, 36 float4 stores
+__global__ __launch_bounds__(256) void wino4_input_transform_kernel(const float* __restrict__ x, float* __restrict__ V,
+                                                                    const WinoGeom g, int relu) {
+    WinoTile q;
+    if (!wino4_decode(g, q)) return;
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 m[6][6];      // B^T d
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+        const int w = 4 * q.j - 1 + c;
+        float4 d[6], t[6];
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {
+            const int h = 4 * q.i - 1 + r;
+            const bool in = (unsigned)h < (unsigned)g.H && (unsigned)w < (unsigned)g.W;
+            const float4 v = in ? ld4(x + (((long)q.b * g.H + h) * g.W + w) * g.C + 4 * q.cq) : z;
+            d[r] = relu ? relu4(v) : v;
+        }
+        wino4_bt(d, t);
+#pragma unroll
+        for (int r = 0; r < 6; ++r) m[r][c] = t[r];
+    }
+    float* out = V + (long)q.t * g.C + 4 * q.cq;
+    const long ps = g.ps;
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {   // (.) B
+        float4 o[6];
+        wino4_bt(m[r], o);
+#pragma unroll
+        for (int c = 0; c < 6; ++c) st4(out + (6 * r + c) * ps, o[c]);
+    }
+}
+
+// thread = (tile, 4 channels): the tile's 4x4 gradients -> A dY A^T (6x6)
+__global__ __launch_bounds__(256) void wino4_outgrad_transform_kernel(const float* __restrict__ dy, float* __restrict__ dM,
+                                                                      const WinoGeom g) {
+    WinoTile q;
+    if (!wino4_decode(g, q)) return;
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 m[6][4];      // A dY
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int w = 4 * q.j + c;
+        float4 y[4], t[6];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int h = 4 * q.i + r;
+            y[r] = (h < g.H && w < g.W) ? ld4(dy + (((long)q.b * g.H + h) * g.W + w) * g.C + 4 * q.cq) : z;
+        }
+        wino4_a(y, t);
+#pragma unroll
+        for (int r = 0; r < 6; ++r) m[r][c] = t[r];
+    }
+    float* out = dM + (long)q.t * g.C + 4 * q.cq;
+    const long ps = g.ps;
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {   // (.) A^T
+        float4 o[6];
+        wino4_a(m[r], o);
+#pragma unroll
+        for (int c = 0; c < 6; ++c) st4(out + (6 * r + c) * ps, o[c]);
+    }
+}
+
+// thread = (tile, 4 channels): Y = A^T M A for the tile's 4x4 outputs, then the conv epilogue on the pixels inside the
+// image; a 4x4 output tile holds four windows of the 2x2 / stride-2 max-pool that may follow the layer
+__global__ __launch_bounds__(256) void wino4_output_transform_kernel(const float* __restrict__ Mt, const float* __restrict__ bias,
+                                                                     const float* __restrict__ mask, float* __restrict__ y,
+                                                                     float* __restrict__ y_relu, float* __restrict__ y_pool,
+                                                                     int pool_relu, const WinoGeom g, int accum) {
+    WinoTile q;
+    if (!wino4_decode(g, q)) return;
+    const float* src = Mt + (long)q.t * g.C + 4 * q.cq;
+    const long ps = g.ps;
+    float4 s[4][6];      // A^T m
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+        float4 m[6], o[4];
+#pragma unroll
+        for (int r = 0; r < 6; ++r) m[r] = ld4(src + (6 * r + c) * ps);
+        wino4_at(m, o);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s[r][c] = o[r];
+    }
+    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (bias) bv = ld4(bias + 4 * q.cq);
+    const float ninf = -__builtin_inff();
+    const int Hp = g.H >> 1, Wp = g.W >> 1;
+    float4 pm[2];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int h = 4 * q.i + r;
+        if ((r & 1) == 0) pm[0] = pm[1] = make_float4(ninf, ninf, ninf, ninf);
+        if (h < g.H) {
+            float4 o[4];
+            wino4_at(s[r], o);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int w = 4 * q.j + c;
+                if (w >= g.W) break;
+                const long off = (((long)q.b * g.H + h) * g.W + w) * g.C + 4 * q.cq;
+                float4 v = f4add(o[c], bv);
+                if (mask) {
+                    const float4 mk = ld4(mask + off);
+                    v.x = mk.x > 0.f ? v.x : 0.f; v.y = mk.y > 0.f ? v.y : 0.f;
+                    v.z = mk.z > 0.f ? v.z : 0.f; v.w = mk.w > 0.f ? v.w : 0.f;
+                }
+                if (accum) v = f4add(v, ld4(y + off));
+                st4(y + off, v);
+                if (y_relu) st4(y_relu + off, relu4(v));
+                float4& p = pm[c >> 1];
+                p.x = fmaxf(p.x, v.x); p.y = fmaxf(p.y, v.y); p.z = fmaxf(p.z, v.z); p.w = fmaxf(p.w, v.w);
+            }
+        }
+        if (y_pool && (r & 1)) {         // rows 4i + r - 1 and 4i + r are done: pooled row 2i + r/2 (floor mode)
+            const int ph = 2 * q.i + (r >> 1);
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int pw = 2 * q.j + k;
+                if (ph < Hp && pw < Wp)
+                    st4(y_pool + (((long)q.b * Hp + ph) * Wp + pw) * g.C + 4 * q.cq, pool_relu ? relu4(pm[k]) : pm[k]);
+            }
+        }
+    }
+}
+
+// F(4x4,3x3) filters: U = G g G^T (6x6) per (co, ci); mode as in wino_weight_transform_kernel
+__device__ __forceinline__ void wino4_g(float g0, float g1, float g2, float (&u)[6]) {
+    const float a = -(1.f / 6.f) * (g0 + g2), b = (1.f / 6.f) * g1;
+    const float c = fmaf(1.f / 24.f, g0, (1.f / 6.f) * g2), d = (1.f / 12.f) * g1;
+    u[0] = 0.25f * g0;
+    u[1] = a - b;
+    u[2] = a + b;
+    u[3] = c + d;
+    u[4] = c - d;
+    u[5] = g2;
+}
+__global__ void wino4_weight_transform_kernel(const float* __restrict__ w, float* __restrict__ U, int Co, int Ci, int mode) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)Co * Ci) return;
+    int co, ci;
+    if (mode == 0) { co = idx / Ci; ci = idx - (long)co * Ci; }
+    else { ci = idx / Co; co = idx - (long)ci * Co; }
+    const float* gsrc = w + ((long)co * Ci + ci) * 9;
+    float g[3][3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) g[a][b] = mode == 0 ? gsrc[3 * a + b] : gsrc[8 - (3 * a + b)];
+    float r[6][3];       // G g
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+        float u[6];
+        wino4_g(g[0][b], g[1][b], g[2][b], u);
+#pragma unroll
+        for (int a = 0; a < 6; ++a) r[a][b] = u[a];
+    }
+    const long ps = (long)Co * Ci;
+    float* out = U + idx;
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {   // (.) G^T
+        float u[6];
+        wino4_g(r[a][0], r[a][1], r[a][2], u);
+#pragma unroll
+        for (int b = 0; b < 6; ++b) out[(6 * a + b) * ps] = u[b];
+    }
+}
+
+extern "C" size_t wesup_winograd_weight_floats(int Cin, int Cout, int m) {
+    return wino_m_ok(m) ? (size_t)wino_positions(m) * Cin * Cout : 0;
+}
+extern "C" long wesup_winograd_tiles(int B, int H, int W, int m) { return wino_m_ok(m) ? wino_tiles(B, H, W, m) : 0; }
+
+// w (Cout,Cin,3,3) -> u_fwd [P][Cout][Cin] and/or u_dgrad [P][Cin][Cout] (either may be NULL), P = (m+2)^2
+extern "C" int wesup_winograd_pack_weight(const float* w, float* u_fwd, float* u_dgrad, int Cout, int Cin, int m, void* stream) {
+    if (!w || Cout <= 0 || Cin <= 0 || (!u_fwd && !u_dgrad) || !wino_m_ok(m)) return WESUP_ERR_INVALID;
     const long tot = (long)Cout * Cin;
     hipStream_t st = (hipStream_t)stream;
-    if (u_fwd) {
-        hipLaunchKernelGGL(wino_weight_transform_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, w, u_fwd, Cout,
-                           Cin, 0);
-        WESUP_CHECK_LAUNCH();
-    }
-    if (u_dgrad) {
-        hipLaunchKernelGGL(wino_weight_transform_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, w, u_dgrad, Cout,
-                           Cin, 1);
+    const dim3 grid((unsigned)((tot + 255) / 256));
+    for (int mode = 0; mode < 2; ++mode) {
+        float* u = mode == 0 ? u_fwd : u_dgrad;
+        if (!u) continue;
+        if (m == 2) hipLaunchKernelGGL(wino_weight_transform_kernel, grid, dim3(256), 0, st, w, u, Cout, Cin, mode);
+        else hipLaunchKernelGGL(wino4_weight_transform_kernel, grid, dim3(256), 0, st, w, u, Cout, Cin, mode);
         WESUP_CHECK_LAUNCH();
     }
     return WESUP_OK;
 }
 
-static WinoGeom wino_geom(int B, int H, int W, int C, long plane_elems = 0) {
+static WinoGeom wino_geom(int B, int H, int W, int C, int m, long plane_elems = 0) {
     WinoGeom g;
-    g.H = H; g.W = W; g.Th = (H + 1) / 2; g.Tw = (W + 1) / 2; g.T = wino_tiles(B, H, W);
+    g.H = H; g.W = W; g.Th = (H + m - 1) / m; g.Tw = (W + m - 1) / m; g.T = wino_tiles(B, H, W, m);
     g.ps = plane_elems > 0 ? plane_elems : g.T * C;
     g.dTw = make_fastdiv(g.Tw); g.dTh = make_fastdiv(g.Th);
     g.C = C; g.dQ = make_fastdiv(C / 4);
     return g;
 }
 
-// x (B,H,W,C) -> V [16][tiles][C]
+// x (B,H,W,C) -> V [P][tiles][C]
 extern "C" int wesup_winograd_input_transform(const float* x, float* V, long plane_elems, int B, int H, int W, int C,
-                                              int relu_in, void* stream) {
-    if (!x || !V || !wino_shape_ok(B, H, W, C, C) || (((uintptr_t)x | (uintptr_t)V) & 15) || (plane_elems % 4) ||
-        (plane_elems > 0 && plane_elems < wino_tiles(B, H, W) * C))
+                                              int relu_in, int m, void* stream) {
+    if (!x || !V || !wino_shape_ok(B, H, W, C, C, m) || (((uintptr_t)x | (uintptr_t)V) & 15) || (plane_elems % 4) ||
+        (plane_elems > 0 && plane_elems < wino_tiles(B, H, W, m) * C))
         return WESUP_ERR_INVALID;
-    const WinoGeom g = wino_geom(B, H, W, C, plane_elems);
-    hipLaunchKernelGGL(wino_input_transform_kernel, dim3((unsigned)ceil_div(g.T * (C / 4), 256l)), dim3(256), 0,
-                       (hipStream_t)stream, x, V, g, relu_in);
+    const WinoGeom g = wino_geom(B, H, W, C, m, plane_elems);
+    const dim3 grid((unsigned)ceil_div(g.T * (C / 4), 256l));
+    if (m == 2) hipLaunchKernelGGL(wino_input_transform_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, V, g, relu_in);
+    else hipLaunchKernelGGL(wino4_input_transform_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, V, g, relu_in);
     WESUP_CHECK_LAUNCH();
     return WESUP_OK;
 }
-// Mt [16][tiles][C] -> y (B,H,W,C) = A^T M A + bias, masked by mask_src > 0, added to the old y if accumulate;
+// Mt [P][tiles][C] -> y (B,H,W,C) = A^T M A + bias, masked by mask_src > 0, added to the old y if accumulate;
 // y_relu: optional second output max(y, 0);  y_pool: optional third output (B,H/2,W/2,C) = the 2x2 / stride-2 max-pool
-// of y (a tile is one pooling window), ReLU'd if pool_relu
+// of y (an output tile is one pooling window for m = 2, four for m = 4), ReLU'd if pool_relu
 extern "C" int wesup_winograd_output_transform(const float* Mt, long plane_elems, const float* bias, const float* mask_src,
                                                float* y, float* y_relu, float* y_pool, int pool_relu, int B, int H, int W,
-                                               int C, int accumulate, void* stream) {
-    if (!Mt || !y || !wino_shape_ok(B, H, W, C, C) || (plane_elems % 4) ||
-        (plane_elems > 0 && plane_elems < wino_tiles(B, H, W) * C) ||
+                                               int C, int accumulate, int m, void* stream) {
+    if (!Mt || !y || !wino_shape_ok(B, H, W, C, C, m) || (plane_elems % 4) ||
+        (plane_elems > 0 && plane_elems < wino_tiles(B, H, W, m) * C) ||
         (((uintptr_t)Mt | (uintptr_t)y | (uintptr_t)y_relu | (uintptr_t)y_pool | (uintptr_t)mask_src | (uintptr_t)bias) & 15))
         return WESUP_ERR_INVALID;
-    const WinoGeom g = wino_geom(B, H, W, C, plane_elems);
-    hipLaunchKernelGGL(wino_output_transform_kernel, dim3((unsigned)ceil_div(g.T * (C / 4), 256l)), dim3(256), 0,
-                       (hipStream_t)stream, Mt, bias, mask_src, y, y_relu, y_pool, pool_relu, g, accumulate);
+    const WinoGeom g = wino_geom(B, H, W, C, m, plane_elems);
+    const dim3 grid((unsigned)ceil_div(g.T * (C / 4), 256l));
+    if (m == 2)
+        hipLaunchKernelGGL(wino_output_transform_kernel, grid, dim3(256), 0, (hipStream_t)stream, Mt, bias, mask_src, y, y_relu,
+                           y_pool, pool_relu, g, accumulate);
+    else
+        hipLaunchKernelGGL(wino4_output_transform_kernel, grid, dim3(256), 0, (hipStream_t)stream, Mt, bias, mask_src, y, y_relu,
+                           y_pool, pool_relu, g, accumulate);
     WESUP_CHECK_LAUNCH();
     return WESUP_OK;
 }
-// dy (B,H,W,C) -> dM [16][tiles][C] = A dY A^T per 2x2 tile (the weight gradient's second operand)
-extern "C" int wesup_winograd_outgrad_transform(const float* dy, float* dM, int B, int H, int W, int C, void* stream) {
-    if (!dy || !dM || !wino_shape_ok(B, H, W, C, C) || (((uintptr_t)dy | (uintptr_t)dM) & 15)) return WESUP_ERR_INVALID;
-    const WinoGeom g = wino_geom(B, H, W, C);
-    hipLaunchKernelGGL(wino_outgrad_transform_kernel, dim3((unsigned)ceil_div(g.T * (C / 4), 256l)), dim3(256), 0,
-                       (hipStream_t)stream, dy, dM, g);
+// dy (B,H,W,C) -> dM [P][tiles][C] = A dY A^T per m x m tile (the weight gradient's second operand)
+extern "C" int wesup_winograd_outgrad_transform(const float* dy, float* dM, int B, int H, int W, int C, int m, void* stream) {
+    if (!dy || !dM || !wino_shape_ok(B, H, W, C, C, m) || (((uintptr_t)dy | (uintptr_t)dM) & 15)) return WESUP_ERR_INVALID;
+    const WinoGeom g = wino_geom(B, H, W, C, m);
+    const dim3 grid((unsigned)ceil_div(g.T * (C / 4), 256l));
+    if (m == 2) hipLaunchKernelGGL(wino_outgrad_transform_kernel, grid, dim3(256), 0, (hipStream_t)stream, dy, dM, g);
+    else hipLaunchKernelGGL(wino4_outgrad_transform_kernel, grid, dim3(256), 0, (hipStream_t)stream, dy, dM, g);
     WESUP_CHECK_LAUNCH();
     return WESUP_OK;
 }
-// slabs [16][S][Cout*Cin + Cout] (split-K partial products of dU_p, each followed by Cout column sums of dM_p) ->
-// dw (Cout,Cin,3,3) = G^T (sum over S) G, db (Cout) = the column sums of position 5.  slab_stride = elements between two
-// splits, batch_stride = between two positions.
+// slabs [P][S][Cout*Cin + Cout] (split-K partial products of dU_p, each followed by Cout column sums of dM_p) ->
+// dw (Cout,Cin,3,3) = G^T (sum over S) G, db (Cout) = the column sums of position (1,1) (= m + 3).  slab_stride = elements
+// between two splits, batch_stride = between two positions.
 extern "C" int wesup_winograd_filter_grad(const float* slabs, long slab_stride, long batch_stride, int S, float* dw_kcrs,
-                                          float* db, int Cout, int Cin, void* stream) {
+                                          float* db, int Cout, int Cin, int m, void* stream) {
     if (!slabs || !dw_kcrs || S <= 0 || Cout <= 0 || Cin <= 0 || slab_stride < (long)Cout * Cin + Cout ||
-        batch_stride < (long)S * slab_stride)
+        batch_stride < (long)S * slab_stride || !wino_m_ok(m))
         return WESUP_ERR_INVALID;
     const long tot = (long)Cout * Cin;
-    const int pair_blocks = (int)((tot + 15) / 16);
-    hipLaunchKernelGGL(wino_wgrad_reduce_kernel, dim3((unsigned)(pair_blocks + (Cout + 255) / 256)), dim3(256), 0,
-                       (hipStream_t)stream, slabs, slab_stride, batch_stride, dw_kcrs, Cout, Cin, S, db, pair_blocks);
+    const int pb = 256 / wino_positions(m);
+    const int pair_blocks = (int)((tot + pb - 1) / pb);
+    const dim3 grid((unsigned)(pair_blocks + (Cout + 255) / 256));
+    if (m == 2)
+        hipLaunchKernelGGL(wino_wgrad_reduce_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, slabs, slab_stride,
+                           batch_stride, dw_kcrs, Cout, Cin, S, db, pair_blocks);
+    else
+        hipLaunchKernelGGL(wino_wgrad_reduce_kernel<6>, grid, dim3(256), 0, (hipStream_t)stream, slabs, slab_stride,
+                           batch_stride, dw_kcrs, Cout, Cin, S, db, pair_blocks);
     WESUP_CHECK_LAUNCH();
     return WESUP_OK;
 }

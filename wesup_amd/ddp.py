@@ -7,6 +7,8 @@ first, conv1_1 last); each time a range of >= ``bucket_bytes`` is complete, an a
 all-reduce of that slice is queued on RCCL's stream while backward continues on the compute
 stream.  ``finish()`` joins the streams before the optimiser; the 1/world_size average is folded
 into the SGD kernel.  Works with any torch.distributed backend (gloo on CPU for tests)."""
+import warnings
+
 import torch
 import torch.distributed as dist
 
@@ -58,8 +60,9 @@ class GradAllReducer:
         for w in self.works:
             try:
                 w.wait()
-            except Exception:          # the peer is gone: nothing left to wait for
-                pass
+            except RuntimeError as e:  # what a failed collective raises (dist.DistBackendError / gloo's RuntimeError): the
+                # peer is gone, there is nothing left to wait for.  Anything else (a programming error) propagates.
+                warnings.warn(f'GradAllReducer.reset: dropped a failed all-reduce ({type(e).__name__}: {e})')
         self.works = []
         self.lo = self.hi = None
         self.launched = []

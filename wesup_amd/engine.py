@@ -81,16 +81,27 @@ class _Bufs:
     pass
 
 
+def default_route(ci, co, h, w, B):
+    """The convolution algorithm of one 3x3 layer: 0 = implicit GEMM (direct form), 2 = Winograd F(2x2,3x3), 4 = Winograd
+    F(4x4,3x3).  Measured per layer and pass at the three benchmark shapes (tools/wino_table.py; profiles/r03_wino_table_*.txt):
+    every layer with >= 128 input channels is fastest in the F(4x4) domain (1/4 of the direct form's multiply-adds, 2.25x
+    the activation bytes) down to 8x8-tile maps; with 64 input channels (conv1_2, conv2_1) the transformed tensors make
+    everything HBM-bound and the implicit-GEMM kernel wins; the image layer (3 channels) has no Winograd form."""
+    if ci < WesupEngine.WINOGRAD_CONV_MIN_CI:
+        return 0
+    return WesupEngine.WINOGRAD_TILE
+
+
 class WesupEngine:
-    # layers whose weight gradient goes through the Winograd domain when wgrad_winograd is on: measured per layer at the
-    # bench shape (tools/wino_table.py) -- faster from 128 -> 256 channels up, slower below (the transformed operands
-    # are 4x the activations and the 64/128-channel GEMMs cannot amortise them)
+    # layers whose weight gradient goes through the Winograd domain when wgrad_winograd is on AND the layer's forward did
+    # not (then the forward's kept V decides): measured per layer at the bench shape (tools/wino_table.py) -- faster from
+    # 128 -> 256 channels up, slower below (the transformed operands cannot be amortised by the 64/128-channel GEMMs)
     WINOGRAD_MIN_CI, WINOGRAD_MIN_CO = 128, 256
     # layers whose forward and input gradient go through the Winograd domain when conv_winograd is on: every layer
-    # with >= 128 input channels (conv2_2 ... conv5_3) is faster that way at the bench shape (fwd 4.06 -> 2.73 ms, dgrad
-    # 4.12 -> 2.72 ms alone on the GPU, differences to the direct kernels 1-3e-6 of the tensor's max); the 3- and
-    # 64-channel layers stay on the implicit-GEMM kernel (their transformed tensors would be HBM-bound)
+    # with >= 128 input channels (conv2_2 ... conv5_3); the 3- and 64-channel layers stay on the implicit-GEMM kernel
+    # (their transformed tensors would be HBM-bound).  bench.py --winograd-min-ci / --winograd-tile for the A/B.
     WINOGRAD_CONV_MIN_CI = 128
+    WINOGRAD_TILE = 4                    # m of F(m x m, 3x3) for those layers: 4 (default) or 2 (round 2's routing)
 
     def __init__(self, params, grads, D=32):
         """params/grads: dict name -> tensor (views of the flat parameter / gradient buffers)."""
@@ -120,6 +131,8 @@ class WesupEngine:
         # domain the step is the sum of its kernels' times and the fusion wins a little (13.77 -> 13.70 ms, 3 A/B pairs)
         self.fuse_side_fwd = True
         self.relu_on_store = True        # ReLU'd copies written by the producing kernel instead of ReLU on every load
+        self.route_fn = default_route    # (ci, co, h, w, B) -> 0 | 2 | 4, consulted per layer and shape
+        self._route = None               # the 13 tile sizes of the current / most recent shape
         self._side_stream = None
         self._wgrad_stream = None
         self.timer = KernelTimer()
@@ -263,6 +276,16 @@ class WesupEngine:
         self.ctx = None
 
     # ------------------------------------------------------------------ weights
+    def route(self, B, H, W):
+        """Per layer: m of the Winograd domain its forward / input gradient (and, with the kept V, weight gradient) run in,
+        or 0 for the implicit-GEMM kernel."""
+        r, h, w = [], H, W
+        for l, (ci, co) in enumerate(CONV_CH):
+            r.append(int(self.route_fn(ci, co, h, w, B)) if (self.conv_winograd and ci >= 32) else 0)
+            if POOL_AFTER[l]:
+                h, w = h // 2, w // 2
+        return r
+
     def _pack_weights(self, train):
         pk = self._packed
         if pk is None:
@@ -278,7 +301,7 @@ class WesupEngine:
                       torch.empty(1024, 1024, dtype=torch.float32, device=self.device),
                       torch.empty(1024, self.D, dtype=torch.float32, device=self.device)]
             self._packed = pk
-        wino = [self._wino(l) for l in range(13)]
+        wino = list(self._route) if self._route is not None else self.route(4, 480, 480)
         if self._prefetched == train and pk.wino == wino:     # prefetch_weights() already queued exactly this for the current step
             self._prefetched = None
             return pk
@@ -289,12 +312,14 @@ class WesupEngine:
         with self._OnSide(self):
             pk.ready0 = pk.ready = None
             for l, idx in enumerate(CONV_IDX):     # forward panels first: conv1_1 only waits for its own
-                if self._wino(l):
-                    if pk.uf[l] is None:
+                m = wino[l]
+                if m:
+                    P = ops.winograd_positions(m)
+                    if pk.uf[l] is None or pk.uf[l].shape[0] != P:
                         ci, co = CONV_CH[l]
-                        pk.uf[l] = torch.empty(16, co, ci, dtype=torch.float32, device=self.device)
-                        pk.ud[l] = torch.empty(16, ci, co, dtype=torch.float32, device=self.device)
-                    ops.winograd_pack_weight(self.p[f'backbone.{idx}.weight'], need_dgrad=False, u_fwd=pk.uf[l])
+                        pk.uf[l] = torch.empty(P, co, ci, dtype=torch.float32, device=self.device)
+                        pk.ud[l] = torch.empty(P, ci, co, dtype=torch.float32, device=self.device)
+                    ops.winograd_pack_weight(self.p[f'backbone.{idx}.weight'], need_dgrad=False, u_fwd=pk.uf[l], m=m)
                     continue
                 ops.pack_conv3x3_weight(self.p[f'backbone.{idx}.weight'], pk.wf[l], None, need_dgrad=False)
                 if l == 0 and self.two_streams:
@@ -305,8 +330,8 @@ class WesupEngine:
                 pk.ready.record()
             if train:
                 for l, idx in enumerate(CONV_IDX):
-                    if self._wino(l):
-                        ops.winograd_pack_weight(self.p[f'backbone.{idx}.weight'], need_fwd=False, u_dgrad=pk.ud[l])
+                    if wino[l]:
+                        ops.winograd_pack_weight(self.p[f'backbone.{idx}.weight'], need_fwd=False, u_dgrad=pk.ud[l], m=wino[l])
                     elif l > 0:
                         ops.pack_conv3x3_weight(self.p[f'backbone.{idx}.weight'], None, pk.wd[l], need_fwd=False)
                 for l, off in enumerate(SIDE_OFF):
@@ -317,7 +342,8 @@ class WesupEngine:
         return pk
 
     def _wino(self, l):
-        return self.conv_winograd and CONV_CH[l][0] >= self.WINOGRAD_CONV_MIN_CI
+        """m of the Winograd domain layer l runs in at the current shape (0: implicit GEMM)."""
+        return self._route[l]
 
     def prefetch_weights(self, train=True):
         """Queue the weight repacking of the coming forward now (side stream, behind everything queued so far, i.e.
@@ -341,6 +367,7 @@ class WesupEngine:
         assert (meta.B, meta.H, meta.W) == (B, H, W)
         b = self._get_bufs(B, H, W, Kmax, train)
         self._last = b
+        self._route = self.route(B, H, W)
         pk = self._pack_weights(train)
         p = self.p
         T = self.timer
@@ -355,7 +382,7 @@ class WesupEngine:
                 T.end(tok, 0.0)
         cur, cur_relu = b.x0, False      # the layer's input tensor, and whether its ReLU is still to be applied on load
         b.x_in, b.x_relu = [None] * 13, [False] * 13
-        b.wino_fwd = [self._wino(l) for l in range(13)]
+        b.wino_fwd = list(self._route)
         b.relu_stored = self.relu_on_store and all(b.yr[l] is not None for l in range(12) if not POOL_AFTER[l])
         fused = self.fuse_pool_fwd
         b.fm_valid = not fused
@@ -380,15 +407,17 @@ class WesupEngine:
             yr = b.yr[l]
             if yr is not None and l < 12 and self._wino(l + 1) and (self.wgrad_winograd or not train):
                 yr = None
-            if self._wino(l):
-                if train and b.V[l] is None:         # the transformed input, kept for the weight gradient
-                    b.V[l] = torch.empty(16, ops.winograd_tiles(B, h, w), ci, dtype=torch.float32, device=self.device)
-                # timed as 'winograd_gemm' (executed MFMA FLOPs: 4/9 of the direct form's) + 'winograd_transform' (bytes)
-                # (a 2x2 output tile is one window of the max-pool behind conv2_2 / conv3_3 / conv4_3: the output transform
-                # writes the pooled tensor too and the max-pool launch below is skipped)
+            m = self._wino(l)
+            if m:
+                vshape = (ops.winograd_positions(m), ops.winograd_tiles(B, h, w, m), ci)
+                if train and (b.V[l] is None or b.V[l].shape != vshape):      # the transformed input, kept for the weight gradient
+                    b.V[l] = torch.empty(vshape, dtype=torch.float32, device=self.device)
+                # timed as 'winograd_gemm' (executed MFMA FLOPs: 4/9 resp. 1/4 of the direct form's) + 'winograd_transform'
+                # (bytes).  (An m x m output tile holds whole windows of the max-pool behind conv2_2 / conv3_3 / conv4_3: the
+                # output transform writes the pooled tensor too and the max-pool launch below is skipped)
                 ops.conv3x3_fwd_winograd(cur, pk.uf[l], p[f'backbone.{idx}.bias'], relu_in=cur_relu, out=b.y[l],
                                          out_relu=yr, v_keep=b.V[l] if train else None, ws_tag='wino_main', timer=T,
-                                         out_pool=b.yp[l] if POOL_AFTER[l] else None, pool_relu=b.relu_stored)
+                                         out_pool=b.yp[l] if POOL_AFTER[l] else None, pool_relu=b.relu_stored, m=m)
             else:
                 tok = T.begin('conv3x3_fwd')
                 ops.conv3x3_fwd(cur, pk.wf[l], p[f'backbone.{idx}.bias'], co, relu_in=cur_relu, out=b.y[l], out_relu=yr,
@@ -594,11 +623,13 @@ class WesupEngine:
             def wgrad(ws_tag):
                 tok = T.begin('conv3x3_wgrad')
                 dw, db = g[f'backbone.{idx}.weight'], g[f'backbone.{idx}.bias']
-                v_pre = b.V[l] if b.wino_fwd[l] else None      # this forward went through the Winograd domain
+                mw = b.wino_fwd[l]                             # this forward went through the Winograd domain: its V was kept
+                v_pre = b.V[l] if mw else None
                 if self.wgrad_winograd and ci >= self.WINOGRAD_MIN_CI and (co >= self.WINOGRAD_MIN_CO or v_pre is not None):
-                    ops.conv3x3_wgrad_winograd(x_in, b.G[l], relu_in=relu_x, dw=dw, db=db, ws_tag=ws_tag, v_pre=v_pre)
-                    # the FLOPs the MFMA pipe executes: 16 positions x (2x2 tiles) instead of 9 taps x pixels
-                    T.end(tok, 2.0 * 16 * B * ((h + 1) // 2) * ((w + 1) // 2) * ci * co)
+                    mw = mw or self.WINOGRAD_TILE
+                    ops.conv3x3_wgrad_winograd(x_in, b.G[l], relu_in=relu_x, dw=dw, db=db, ws_tag=ws_tag, v_pre=v_pre, m=mw)
+                    # the FLOPs the MFMA pipe executes: (m+2)^2 positions x (m x m tiles) instead of 9 taps x pixels
+                    T.end(tok, 2.0 * ops.winograd_positions(mw) * ops.winograd_tiles(B, h, w, mw) * ci * co)
                 else:
                     ops.conv3x3_wgrad(x_in, b.G[l], ci, relu_in=relu_x, dw=dw, db=db, ws_tag=ws_tag)
                     T.end(tok, 2.0 * B * h * w * ci * co * 9)
@@ -616,10 +647,11 @@ class WesupEngine:
                     main.wait_event(g_ready[l - 1])
                 if b.wino_fwd[l]:
                     if POOL_AFTER[l - 1]:
-                        ops.conv3x3_dgrad_winograd(b.G[l], pk.ud[l], out=b.dxp[l - 1], ws_tag='wino_main', timer=T)
+                        ops.conv3x3_dgrad_winograd(b.G[l], pk.ud[l], out=b.dxp[l - 1], ws_tag='wino_main', timer=T,
+                                                   m=b.wino_fwd[l])
                     else:
                         ops.conv3x3_dgrad_winograd(b.G[l], pk.ud[l], mask_src=b.y[l - 1], out=b.G[l - 1], accumulate=True,
-                                                   ws_tag='wino_main', timer=T)
+                                                   ws_tag='wino_main', timer=T, m=b.wino_fwd[l])
                 else:
                     tok = T.begin('conv3x3_dgrad')
                     if POOL_AFTER[l - 1]:

@@ -203,59 +203,73 @@ def conv3x3_wgrad(x, dy, Ci, relu_in, dw=None, db=None, ws_tag='default'):
     return dw, db
 
 
-def winograd_pack_weight(w, need_fwd=True, need_dgrad=True, u_fwd=None, u_dgrad=None):
-    """w (Cout,Cin,3,3) -> (u_fwd (16,Cout,Cin), u_dgrad (16,Cin,Cout)): G g G^T per channel pair, the second from the
-    rotated filter."""
+def winograd_positions(m=2):
+    """Positions of the F(m x m, 3x3) domain: (m+2)^2 = 16 for m = 2, 36 for m = 4."""
+    assert m in (2, 4), m
+    return (m + 2) * (m + 2)
+
+
+def winograd_pack_weight(w, need_fwd=True, need_dgrad=True, u_fwd=None, u_dgrad=None, m=2):
+    """w (Cout,Cin,3,3) -> (u_fwd (P,Cout,Cin), u_dgrad (P,Cin,Cout)): G g G^T per channel pair, the second from the
+    rotated filter; P = (m+2)^2 positions of F(m x m, 3x3)."""
     _chk(w, name='w')
     Cout, Cin = w.shape[:2]
+    P = winograd_positions(m)
     if need_fwd and u_fwd is None:
-        u_fwd = torch.empty(16, Cout, Cin, dtype=torch.float32, device=w.device)
+        u_fwd = torch.empty(P, Cout, Cin, dtype=torch.float32, device=w.device)
     if need_dgrad and u_dgrad is None:
-        u_dgrad = torch.empty(16, Cin, Cout, dtype=torch.float32, device=w.device)
-    _lib.call('wesup_winograd_pack_weight', _p(w), _p(u_fwd if need_fwd else None), _p(u_dgrad if need_dgrad else None),
-              Cout, Cin, _stream())
+        u_dgrad = torch.empty(P, Cin, Cout, dtype=torch.float32, device=w.device)
+    for u, shape in ((u_fwd if need_fwd else None, (P, Cout, Cin)), (u_dgrad if need_dgrad else None, (P, Cin, Cout))):
+        if u is not None:
+            _chk(u, name='u'); assert u.shape == shape, (u.shape, shape)
+    _lib.call('wesup_winograd_pack_weight', _p(w), _p(u_fwd if need_fwd else None),
+              _p(u_dgrad if need_dgrad else None), Cout, Cin, m, _stream())
     return u_fwd if need_fwd else None, u_dgrad if need_dgrad else None
 
 
-def winograd_tiles(B, H, W):
-    return B * ((H + 1) // 2) * ((W + 1) // 2)
+def winograd_tiles(B, H, W, m=2):
+    return B * ((H + m - 1) // m) * ((W + m - 1) // m)
 
 
-def winograd_input_transform(x, relu=False, out=None):
-    """x (B,H,W,C) -> V (16, tiles, C) = B^T d B of every 4x4 input patch."""
+def winograd_input_transform(x, relu=False, out=None, m=2):
+    """x (B,H,W,C) -> V (P, tiles, C) = B^T d B of every (m+2) x (m+2) input patch."""
     _chk(x, name='x')
     B, H, W, C = x.shape
-    T = winograd_tiles(B, H, W)
+    T, P = winograd_tiles(B, H, W, m), winograd_positions(m)
     if out is None:
-        out = torch.empty(16, T, C, dtype=torch.float32, device=x.device)
-    assert out.shape == (16, T, C) and out.is_contiguous()
-    _lib.call('wesup_winograd_input_transform', _p(x), _p(out), 0, B, H, W, C, int(relu), _stream())
+        out = torch.empty(P, T, C, dtype=torch.float32, device=x.device)
+    assert out.shape == (P, T, C) and out.is_contiguous()
+    _lib.call('wesup_winograd_input_transform', _p(x), _p(out), 0, B, H, W, C, int(relu), m, _stream())
     return out
 
 
-def winograd_outgrad_transform(dy, out=None):
-    """dy (B,H,W,C) -> dM (16, tiles, C) = A dY A^T of every 2x2 output tile."""
+def winograd_outgrad_transform(dy, out=None, m=2):
+    """dy (B,H,W,C) -> dM (P, tiles, C) = A dY A^T of every m x m output tile."""
     _chk(dy, name='dy')
     B, H, W, C = dy.shape
-    T = winograd_tiles(B, H, W)
+    T, P = winograd_tiles(B, H, W, m), winograd_positions(m)
     if out is None:
-        out = torch.empty(16, T, C, dtype=torch.float32, device=dy.device)
-    assert out.shape == (16, T, C) and out.is_contiguous()
-    _lib.call('wesup_winograd_outgrad_transform', _p(dy), _p(out), B, H, W, C, _stream())
+        out = torch.empty(P, T, C, dtype=torch.float32, device=dy.device)
+    assert out.shape == (P, T, C) and out.is_contiguous()
+    _lib.call('wesup_winograd_outgrad_transform', _p(dy), _p(out), B, H, W, C, m, _stream())
     return out
 
 
 def winograd_output_transform(Mt, B, H, W, bias=None, mask_src=None, out=None, out_relu=None, out_pool=None, pool_relu=False,
-                              accumulate=False):
-    """Mt (16, tiles, C) -> y (B,H,W,C) = A^T M A + bias [masked by mask_src > 0] [+ old y]."""
+                              accumulate=False, m=2):
+    """Mt (P, tiles, C) -> y (B,H,W,C) = A^T M A + bias [masked by mask_src > 0] [+ old y]."""
     _chk(Mt, name='Mt')
     C = Mt.shape[2]
-    assert Mt.shape == (16, winograd_tiles(B, H, W), C)
+    assert Mt.shape == (winograd_positions(m), winograd_tiles(B, H, W, m), C)
     if out is None:
         assert not accumulate
         out = torch.empty(B, H, W, C, dtype=torch.float32, device=Mt.device)
+    assert out.shape == (B, H, W, C) and out.is_contiguous()
+    for t, shape in ((out_relu, out.shape), (mask_src, out.shape), (out_pool, (B, H // 2, W // 2, C))):
+        if t is not None:
+            _chk(t, name='operand'); assert t.shape == shape, (t.shape, shape)
     _lib.call('wesup_winograd_output_transform', _p(Mt), 0, _p(bias), _p(mask_src), _p(out), _p(out_relu), _p(out_pool),
-              int(pool_relu), B, H, W, C, int(accumulate), _stream())
+              int(pool_relu), B, H, W, C, int(accumulate), m, _stream())
     return out
 
 
@@ -272,15 +286,17 @@ def gemm_nt_batched(A, Bw, out=None):
     return out
 
 
-def winograd_filter_grad(slabs, dw=None, db=None):
-    """slabs (16, S, Cout*Cin + Cout): split-K partial products of the 16 transformed filter gradients, each followed by
-    the column sums of its dM operand -> (dw (Cout,Cin,3,3) = G^T (sum over S) G, db (Cout) from position 5).
+def winograd_filter_grad(slabs, dw=None, db=None, m=2):
+    """slabs (P, S, Cout*Cin + Cout): split-K partial products of the P transformed filter gradients, each followed by
+    the column sums of its dM operand -> (dw (Cout,Cin,3,3) = G^T (sum over S) G, db (Cout) from position (1,1)).
     Cout, Cin are taken from dw."""
     _chk(slabs, name='slabs'); _chk(dw, name='dw'); _chk(db, name='db')
     Cout, Cin = dw.shape[:2]
     S = slabs.shape[1]
-    assert slabs.shape == (16, S, Cout * Cin + Cout) and slabs.is_contiguous()
-    _lib.call('wesup_winograd_filter_grad', _p(slabs), slabs.stride(1), slabs.stride(0), S, _p(dw), _p(db), Cout, Cin, _stream())
+    assert slabs.shape == (winograd_positions(m), S, Cout * Cin + Cout) and slabs.is_contiguous()
+    assert dw.shape == (Cout, Cin, 3, 3) and db.numel() == Cout
+    _lib.call('wesup_winograd_filter_grad', _p(slabs), slabs.stride(1), slabs.stride(0), S, _p(dw), _p(db), Cout, Cin, m,
+              _stream())
     return dw, db
 
 
@@ -303,7 +319,7 @@ def _aux_stream(device):
 
 
 def _winograd_conv(inp, u, bias, mask_src, out, out_relu, v_keep, relu_in, accumulate, ws_tag, timer, out_pool=None,
-                   pool_relu=False):
+                   pool_relu=False, m=2):
     """The three passes of a Winograd-domain conv (input transform, 16 batched NT GEMMs, output transform + epilogue).
     timer (optional, engine.KernelTimer-like): the GEMM and the two transforms are bracketed as classes of their own.
 
@@ -315,43 +331,43 @@ def _winograd_conv(inp, u, bias, mask_src, out, out_relu, v_keep, relu_in, accum
     B, H, W, Cin = inp.shape
     Cout = u.shape[1]
     lib = _lib.load()
-    nb = lib.wesup_conv3x3_winograd_workspace_bytes(B, H, W, Cin, Cout)
+    nb = lib.wesup_conv3x3_winograd_workspace_bytes(B, H, W, Cin, Cout, m)
     if not nb:
-        raise _lib.WesupHipError(f'winograd conv: unsupported shape {(B, H, W, Cin, Cout)}')
-    T = winograd_tiles(B, H, W)
+        raise _lib.WesupHipError(f'winograd conv: unsupported shape {(B, H, W, Cin, Cout, m)}')
+    T, P = winograd_tiles(B, H, W, m), winograd_positions(m)
     ws = workspace(nb, inp.device, ws_tag)
-    v_bytes = (16 * T * Cin * 4 + 255) // 256 * 256
+    v_bytes = (P * T * Cin * 4 + 255) // 256 * 256
     V = v_keep if v_keep is not None else ws[:v_bytes]
     Mt = ws[v_bytes:]
     n_io = 1 + (out_relu is not None) + (mask_src is not None) + bool(accumulate)
 
     def t_in(b0, nb_, st):
         tok = timer.begin('winograd_transform') if timer else None
-        t0 = winograd_tiles(b0, H, W)
+        t0 = winograd_tiles(b0, H, W, m)
         _lib.call('wesup_winograd_input_transform', _p(inp[b0:b0 + nb_]), ctypes.c_void_p(V.data_ptr() + 4 * t0 * Cin), T * Cin,
-                  nb_, H, W, Cin, int(relu_in), st)
-        if timer:
-            timer.end(tok, 4.0 * 5 * nb_ * H * W * Cin)              # bytes: read x, write 4x
+                  nb_, H, W, Cin, int(relu_in), m, st)
+        if timer:       # bytes: read x, write the P / m^2-fold expansion (4x for m = 2, 2.25x for m = 4)
+            timer.end(tok, 4.0 * (nb_ * H * W + P * winograd_tiles(nb_, H, W, m)) * Cin)
 
     def gemm(b0, nb_, st):
         tok = timer.begin('winograd_gemm') if timer else None
-        t0, tn = winograd_tiles(b0, H, W), winograd_tiles(nb_, H, W)
+        t0, tn = winograd_tiles(b0, H, W, m), winograd_tiles(nb_, H, W, m)
         _lib.call('wesup_gemm_nt_batched', ctypes.c_void_p(V.data_ptr() + 4 * t0 * Cin), Cin, T * Cin, _p(u), Cin, Cout * Cin,
-                  ctypes.c_void_p(Mt.data_ptr() + 4 * t0 * Cout), Cout, T * Cout, 16, tn, Cout, Cin, st)
+                  ctypes.c_void_p(Mt.data_ptr() + 4 * t0 * Cout), Cout, T * Cout, P, tn, Cout, Cin, st)
         if timer:
-            timer.end(tok, 2.0 * 16 * tn * Cin * Cout)
+            timer.end(tok, 2.0 * P * tn * Cin * Cout)
 
     def t_out(b0, nb_, st):
         tok = timer.begin('winograd_transform') if timer else None
-        t0 = winograd_tiles(b0, H, W)
+        t0 = winograd_tiles(b0, H, W, m)
         sl = slice(b0, b0 + nb_)
         _lib.call('wesup_winograd_output_transform', ctypes.c_void_p(Mt.data_ptr() + 4 * t0 * Cout), T * Cout, _p(bias),
                   _p(None if mask_src is None else mask_src[sl]), _p(out[sl]), _p(None if out_relu is None else out_relu[sl]),
-                  _p(None if out_pool is None else out_pool[sl]), int(pool_relu), nb_, H, W, Cout, int(accumulate), st)
+                  _p(None if out_pool is None else out_pool[sl]), int(pool_relu), nb_, H, W, Cout, int(accumulate), m, st)
         if timer:
-            timer.end(tok, 4.0 * (4 + n_io + (0.25 if out_pool is not None else 0)) * nb_ * H * W * Cout)
+            timer.end(tok, 4.0 * (P * winograd_tiles(nb_, H, W, m) + (n_io + (0.25 if out_pool is not None else 0)) * nb_ * H * W) * Cout)
 
-    half_blocks = ((T // 2 + 127) // 128) * ((Cout + 127) // 128) * 16
+    half_blocks = ((T // 2 + 127) // 128) * ((Cout + 127) // 128) * P
     if not (PIPELINE_WINOGRAD and B % 2 == 0 and half_blocks >= PIPELINE_MIN_BLOCKS):
         st = _stream()
         t_in(0, B, st); gemm(0, B, st); t_out(0, B, st)
@@ -378,13 +394,14 @@ def _winograd_conv(inp, u, bias, mask_src, out, out_relu, v_keep, relu_in, accum
 
 
 def conv3x3_fwd_winograd(x, u_fwd, bias, relu_in, out=None, out_relu=None, v_keep=None, ws_tag='default', timer=None,
-                         out_pool=None, pool_relu=False):
-    """conv3x3_fwd through the Winograd domain (deep layers); v_keep (16, tiles, Cin) receives the transformed input;
-    out_pool (B, H//2, W//2, Cout) the 2x2 max-pool of the output (ReLU'd if pool_relu), written by the output transform."""
+                         out_pool=None, pool_relu=False, m=2):
+    """conv3x3_fwd through the Winograd F(m x m, 3x3) domain (deep layers); v_keep (P, tiles, Cin) receives the transformed
+    input; out_pool (B, H//2, W//2, Cout) the 2x2 max-pool of the output (ReLU'd if pool_relu), written by the output
+    transform."""
     _chk(x, name='x'); _chk(u_fwd, name='u_fwd')
     B, H, W, Cin = x.shape
     Cout = u_fwd.shape[1]
-    assert u_fwd.shape == (16, Cout, Cin)
+    assert u_fwd.shape == (winograd_positions(m), Cout, Cin)
     if bias is not None:
         _chk(bias, name='bias'); assert bias.numel() == Cout
     if out is None:
@@ -393,29 +410,29 @@ def conv3x3_fwd_winograd(x, u_fwd, bias, relu_in, out=None, out_relu=None, v_kee
     if out_relu is not None:
         _chk(out_relu, name='out_relu'); assert out_relu.shape == out.shape
     if v_keep is not None:
-        _chk(v_keep, name='v_keep'); assert v_keep.numel() == 16 * winograd_tiles(B, H, W) * Cin
+        _chk(v_keep, name='v_keep'); assert v_keep.numel() == winograd_positions(m) * winograd_tiles(B, H, W, m) * Cin
     if out_pool is not None:
         _chk(out_pool, name='out_pool'); assert out_pool.shape == (B, H // 2, W // 2, Cout) and out_pool.is_contiguous()
-    return _winograd_conv(x, u_fwd, bias, None, out, out_relu, v_keep, relu_in, False, ws_tag, timer, out_pool, pool_relu)
+    return _winograd_conv(x, u_fwd, bias, None, out, out_relu, v_keep, relu_in, False, ws_tag, timer, out_pool, pool_relu, m)
 
 
-def conv3x3_dgrad_winograd(dy, u_dgrad, mask_src=None, out=None, accumulate=False, ws_tag='default', timer=None):
+def conv3x3_dgrad_winograd(dy, u_dgrad, mask_src=None, out=None, accumulate=False, ws_tag='default', timer=None, m=2):
     _chk(dy, name='dy'); _chk(u_dgrad, name='u_dgrad')
     B, H, W, Cout = dy.shape
     Cin = u_dgrad.shape[1]
-    assert u_dgrad.shape == (16, Cin, Cout)
+    assert u_dgrad.shape == (winograd_positions(m), Cin, Cout)
     if mask_src is not None:
         _chk(mask_src, name='mask_src'); assert mask_src.shape == (B, H, W, Cin)
     if out is None:
         assert not accumulate
         out = torch.empty(B, H, W, Cin, dtype=torch.float32, device=dy.device)
     assert out.shape == (B, H, W, Cin) and out.is_contiguous()
-    return _winograd_conv(dy, u_dgrad, None, mask_src, out, None, None, False, accumulate, ws_tag, timer)
+    return _winograd_conv(dy, u_dgrad, None, mask_src, out, None, None, False, accumulate, ws_tag, timer, m=m)
 
 
-def conv3x3_wgrad_winograd(x, dy, relu_in, dw=None, db=None, ws_tag='default', v_pre=None):
-    """The same (dw, db) as conv3x3_wgrad through the Winograd F(2x2,3x3) domain: 2.25x fewer multiply-adds, 4x the
-    operand bytes; for the wide layers (Ci, Cout >= 128)."""
+def conv3x3_wgrad_winograd(x, dy, relu_in, dw=None, db=None, ws_tag='default', v_pre=None, m=2):
+    """The same (dw, db) as conv3x3_wgrad through the Winograd F(m x m, 3x3) domain: 2.25x (m = 2) / 4x (m = 4) fewer
+    multiply-adds, 4x / 2.25x the operand bytes; for the wide layers (Ci, Cout >= 128)."""
     _chk(x, name='x'); _chk(dy, name='dy')
     B, H, W, Ci = x.shape
     Cout = dy.shape[3]
@@ -425,13 +442,13 @@ def conv3x3_wgrad_winograd(x, dy, relu_in, dw=None, db=None, ws_tag='default', v
     if db is None:
         db = torch.empty(Cout, dtype=torch.float32, device=x.device)
     assert dw.is_contiguous() and dw.numel() == Cout * Ci * 9 and db.numel() == Cout
-    nb = _lib.load().wesup_conv3x3_wgrad_winograd_workspace_bytes(B, H, W, Ci, Cout)
+    nb = _lib.load().wesup_conv3x3_wgrad_winograd_workspace_bytes(B, H, W, Ci, Cout, m)
     if not nb:
-        raise _lib.WesupHipError(f'conv3x3_wgrad_winograd: unsupported shape {(B, H, W, Ci, Cout)}')
+        raise _lib.WesupHipError(f'conv3x3_wgrad_winograd: unsupported shape {(B, H, W, Ci, Cout, m)}')
     ws = workspace(nb, x.device, ws_tag)
     if v_pre is not None:
-        _chk(v_pre, name='v_pre'); assert v_pre.numel() == 16 * winograd_tiles(B, H, W) * Ci
-    _lib.call('wesup_conv3x3_wgrad_winograd', _p(x), _p(v_pre), _p(dy), _p(dw), _p(db), B, H, W, Ci, Cout, int(relu_in),
+        _chk(v_pre, name='v_pre'); assert v_pre.numel() == winograd_positions(m) * winograd_tiles(B, H, W, m) * Ci
+    _lib.call('wesup_conv3x3_wgrad_winograd', _p(x), _p(v_pre), _p(dy), _p(dw), _p(db), B, H, W, Ci, Cout, int(relu_in), m,
               _p(ws), nb, _stream())
     return dw, db
 

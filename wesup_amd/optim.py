@@ -32,14 +32,16 @@ class FusedSGD(torch.optim.SGD):
                 st['momentum_buffer'] = view
                 self._first = False
 
-    def _trainable_ranges(self):
-        """Contiguous [lo, hi) element ranges of the flat buffers that hold parameters with requires_grad (padding
+    def _trainable_ranges(self, with_grad):
+        """Contiguous [lo, hi) element ranges of the flat buffers that hold parameters that are stepped (padding
         included, adjacent parameters merged): one range = the whole buffer when nothing is frozen, the tail behind the
-        backbone with freeze_backbone (models/wesup.py:427-429,447)."""
+        backbone with freeze_backbone (models/wesup.py:427-429,447).  with_grad: one flag per parameter -- like
+        torch.optim.SGD, a parameter whose ``grad`` is None (no backward since zero_grad(): a raised or partial backward,
+        step() called twice) is skipped, not updated with whatever the flat gradient buffer still holds."""
         m = self.model
         ranges = []
-        for name, p in m.named_parameters():
-            if not p.requires_grad:
+        for (name, p), has in zip(m.named_parameters(), with_grad):
+            if not has:
                 continue
             lo, hi = m._offs[name], m._offs[name] + (p.numel() + 63) // 64 * 64
             if ranges and ranges[-1][1] == lo:
@@ -57,14 +59,14 @@ class FusedSGD(torch.optim.SGD):
         for name, p in m.named_parameters():          # a gradient that is not the flat view (set by hand): adopt it
             if p.requires_grad and p.grad is not None and p.grad.data_ptr() != m._grad_views[name].data_ptr():
                 m._grad_views[name].copy_(p.grad)
-        sig = tuple(p.requires_grad for p in m.parameters())
+        sig = tuple(p.requires_grad and p.grad is not None for p in m.parameters())
         if getattr(self, '_ranges_sig', None) != sig:
-            self._ranges, self._ranges_sig = self._trainable_ranges(), sig
+            self._ranges, self._ranges_sig = self._trainable_ranges(sig), sig
         for lo, hi in self._ranges:                   # one launch per contiguous trainable range
             ops.sgd_step(m._flat[lo:hi], m._flat_grad[lo:hi], self._vflat[lo:hi], lr, mu, wd, self.grad_scale, self._first)
         if mu != 0:
             for p, view in self._views.items():
-                if p.requires_grad:
+                if p.requires_grad and p.grad is not None:
                     self.state[p]['momentum_buffer'] = view
         self._first = False
         return None

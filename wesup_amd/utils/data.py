@@ -367,6 +367,7 @@ class DevicePrefetcher:
 
     def _stage(self, raw):
         from .. import ops
+        self._check_item(raw)
         img, mask, pts, *extra = raw             # extra: what a dataset adds to the item (area bounds, coordinate maps)
         B, H, W, _ = img.shape
         rows, mats = zip(*[sample_params(self.rs, H, W, self.train, self.with_points) for _ in range(B)])
@@ -415,6 +416,24 @@ class DevicePrefetcher:
             return (out_img, pixel_mask, point_mask if self.with_points else empty_tensor(), LabelMaps(segments, counts)), done
         item = (out_img, pixel_mask, point_mask) if self.with_points else (out_img, pixel_mask)
         return item + tuple(e.to(self.device, non_blocking=True) if torch.is_tensor(e) else e for e in extra), done
+
+    @staticmethod
+    def _check_item(raw):
+        """The raw-item layout this prefetcher stages: ``(img uint8 (B,H,W,3), mask uint8 (B,H,W), pts int (B,P,3), ...)``
+        -- what the raw datasets of this module collate to.  Anything else (WESUPV2Dataset's ``(img, mask (C,H,W), coords
+        (2,H,W))``, CompoundDataset's tuples of items) is refused here, by name, instead of being mis-read further down."""
+        if not isinstance(raw, (tuple, list)) or len(raw) < 3 or not all(torch.is_tensor(t) for t in raw[:3]):
+            raise TypeError('DevicePrefetcher: expected raw items (img, mask, points, ...) of tensors, got '
+                            f'{type(raw).__name__} of {[type(t).__name__ for t in raw] if isinstance(raw, (tuple, list)) else "?"} '
+                            '(CompoundDataset items are tuples of items: prefetch its member datasets separately)')
+        img, mask, pts = raw[:3]
+        if img.dtype != torch.uint8 or img.dim() != 4 or img.shape[-1] != 3:
+            raise TypeError(f'DevicePrefetcher: img must be uint8 (B,H,W,3) (a raw, un-normalised item), got {img.dtype} {tuple(img.shape)}')
+        if mask.dtype != torch.uint8 or mask.dim() != 3:
+            raise TypeError(f'DevicePrefetcher: mask must be a uint8 class-index map (B,H,W), got {mask.dtype} {tuple(mask.shape)} '
+                            '(one-hot (C,H,W) int64 masks, e.g. WESUPV2Dataset items, are tensors for the trainer, not raw items)')
+        if pts.dim() != 3 or pts.shape[-1] != 3 or pts.is_floating_point():
+            raise TypeError(f'DevicePrefetcher: points must be integer (B,P,3) rows of (x, y, class), got {pts.dtype} {tuple(pts.shape)}')
 
     @staticmethod
     def _hand_over(item):
