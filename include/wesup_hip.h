@@ -111,8 +111,8 @@ int wesup_conv3x3_wgrad(const float* x, const float* dy, float* dw_kcrs, float* 
  * models/wesup.py:199): both tensors are transformed per m x m output tile (workspace: P x tiles x (Ci + Cout) floats +
  * split-K slabs, P = (m+2)^2 positions, tiles = B * ceil(H/m) * ceil(W/m)), P TN GEMMs with K = tiles accumulate the
  * transformed filter gradient, and G^T (.) G maps it back to 3x3.  2.25x (m = 2) / 4x (m = 4) fewer multiply-adds than
- * the direct form; same result up to fp32 rounding (m = 2: like the direct kernel's summation-order error; m = 4:
- * ~5e-6 of the tensor's maximum).  Ci, Cout multiples of 4, >= 32 (meant for the 128..512-channel layers); x has Ci
+ * the direct form; same result up to fp32 rounding (1-3e-6 of the tensor's maximum, the direct kernels' own level: m = 4
+ * uses the interpolation points 0, +-3/4, +-3/2, inf, ~4x more accurate in fp32 than the textbook 0, +-1, +-2, inf).  Ci, Cout multiples of 4, >= 32 (meant for the 128..512-channel layers); x has Ci
  * channels. */
 size_t wesup_conv3x3_wgrad_winograd_workspace_bytes(int B, int H, int W, int Ci, int Cout, int m);
 /* v_pre (optional): the transformed input [P][tiles][Ci] kept by wesup_conv3x3_fwd_winograd of the same layer and the
@@ -155,9 +155,13 @@ int wesup_winograd_output_transform(const float* Mt, long plane_elems, const flo
                                     int accumulate, int m, void* stream);
 /* The weight gradient's own transforms: dy (B,H,W,C) -> dM [P][tiles][C] = A dY A^T per m x m tile; and the way back from
  * the split-K slabs of the P transformed filter gradients ([P][S][Cout*Cin + Cout], each slab followed by the Cout
- * column sums of its dM operand) to dw (Cout,Cin,3,3) = G^T (sum over S) G and db = the column sums of position (1,1)
- * (index m + 3). */
-int wesup_winograd_outgrad_transform(const float* dy, float* dM, int B, int H, int W, int C, int m, void* stream);
+ * column sums of its dM operand) to dw (Cout,Cin,3,3) = G^T (sum over S) G.  The bias gradient db = sum over pixels of dy:
+ * m = 2, the column sums of dM at position (1,1) (index 5; filter_grad's db); m = 4 (its point set 0, +-3/4, +-3/2, inf
+ * has no position that is a plain sum), the optional db of the outgrad transform, summed from the values it loads anyway
+ * (ws: wesup_winograd_outgrad_workspace_bytes; db must be NULL for m = 2 there, and for m = 4 in filter_grad). */
+size_t wesup_winograd_outgrad_workspace_bytes(int B, int H, int W, int C, int m);
+int wesup_winograd_outgrad_transform(const float* dy, float* dM, float* db, int B, int H, int W, int C, int m,
+                                     void* ws, size_t ws_bytes, void* stream);
 int wesup_winograd_filter_grad(const float* slabs, long slab_stride, long batch_stride, int S, float* dw_kcrs, float* db,
                                int Cout, int Cin, int m, void* stream);
 

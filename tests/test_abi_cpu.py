@@ -90,10 +90,14 @@ def test_winograd_host_side_queries_and_argument_checks(lib):
         assert h.wesup_conv3x3_wgrad_winograd(None, None, None, None, None, 4, 60, 60, 512, 512, 0, m, None, 0, None) == -1
         assert h.wesup_winograd_input_transform(None, None, 0, 1, 8, 8, 64, 0, m, None) == -1
         assert h.wesup_winograd_output_transform(None, 0, None, None, None, None, None, 0, 1, 8, 8, 64, 0, m, None) == -1
-        assert h.wesup_winograd_outgrad_transform(None, None, 1, 8, 8, 64, m, None) == -1
+        assert h.wesup_winograd_outgrad_transform(None, None, None, 1, 8, 8, 64, m, None, 0, None) == -1
         assert h.wesup_winograd_filter_grad(None, 0, 0, 1, None, None, 64, 64, m, None) == -1
         assert h.wesup_winograd_pack_weight(None, None, None, 64, 64, m, None) == -1
     assert h.wesup_gemm_nt_batched(None, 0, 0, None, 0, 0, None, 0, 0, 16, 128, 128, 32, None) == -1
+    # the bias gradient of the F(4x4) weight gradient is summed inside the outgrad transform: per-block rows + colsum workspace
+    assert h.wesup_winograd_outgrad_workspace_bytes(4, 60, 60, 512, 2) == 0
+    blocks = -(-4 * 15 * 15 * 128 // 256)
+    assert h.wesup_winograd_outgrad_workspace_bytes(4, 60, 60, 512, 4) == blocks * 512 * 4 + h.wesup_colsum_workspace_bytes(blocks, 512)
     # the debug entries only exist in `make debug`'s library: the shipped one refuses them
     import ctypes
     assert h.wesup_debug_clock(ctypes.byref(ctypes.c_double())) == -1 and h.wesup_debug_set_trace(None) == -1

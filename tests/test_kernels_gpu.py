@@ -267,6 +267,12 @@ def test_winograd_building_blocks_match_the_numpy_oracle(ops, B, H, W, Ci, Co, m
         assert close(V, wo.input_transform(x.numpy(), relu, m=m))
     dM = ops.winograd_outgrad_transform(dyg, m=m)
     assert close(dM, wo.outgrad_transform(dy.numpy(), m=m))
+    if m == 4:       # the bias gradient rides in the outgrad transform (F(2x2): in the filter-gradient reduce, below)
+        dbo = torch.empty(Co, device=d)
+        dM2 = ops.winograd_outgrad_transform(dyg, m=m, db=dbo)
+        assert torch.equal(dM2, dM)
+        want = dy.double().sum(dim=(0, 1, 2))
+        assert float((dbo.cpu().double() - want).abs().max()) < 1e-5 * float(want.abs().max() + 1)
     uf, ud = ops.winograd_pack_weight(w.to(d), m=m)
     uf_o, ud_o = wo.pack_weight(w.numpy(), m=m)
     assert np.abs(uf.cpu().numpy() - uf_o).max() < 1e-6 and np.abs(ud.cpu().numpy() - ud_o).max() < 1e-6
@@ -299,11 +305,12 @@ def test_winograd_building_blocks_match_the_numpy_oracle(ops, B, H, W, Ci, Co, m
     slabs = np.zeros((P, 2, Co * Ci + Co), dtype=f32)
     slabs[:, 0, :Co * Ci] = (dU - half).reshape(P, -1); slabs[:, 1, :Co * Ci] = half.reshape(P, -1)
     slabs[:, 0, Co * Ci:] = cs * 0.25; slabs[:, 1, Co * Ci:] = cs * 0.75
-    dw = torch.empty(Co, Ci, 3, 3, device=d); db = torch.empty(Co, device=d)
+    dw = torch.empty(Co, Ci, 3, 3, device=d); db = torch.empty(Co, device=d) if m == 2 else None
     ops.winograd_filter_grad(torch.from_numpy(slabs).to(d), dw, db, m=m)
     dw_o, db_o = wo.conv_wgrad(x.numpy(), dy.numpy(), m=m)
     assert np.abs(dw.cpu().numpy() - dw_o).max() < 1e-4 * np.abs(dw_o).max()
-    assert np.abs(db.cpu().numpy() - db_o).max() < 1e-4 * np.abs(db_o).max()
+    if m == 2:
+        assert np.abs(db.cpu().numpy() - db_o).max() < 1e-4 * np.abs(db_o).max()
 
 
 @pytest.mark.parametrize('B,H,W,Cin,Cout', [(2, 13, 11, 64, 128), (4, 30, 30, 256, 256), (6, 9, 9, 128, 64)])

@@ -56,14 +56,35 @@ def test_layout_of_an_f4_transformed_tensor():
     x = np.arange(1 * 6 * 9 * 1, dtype=np.float64).reshape(1, 6, 9, 1) + 1
     V = wo.input_transform(x, m=4)
     assert V.shape == (36, wo.tiles(1, 6, 9, 4), 1) == (36, 2 * 3, 1)
-    # position (5,5) = row 5 of B^T on both sides = 4 d1 - 5 d3 + d5 along each axis; tile (1, 2): patch rows 3..8, columns
-    # 7..12 (pixels with row > 5 or column > 8 are outside)
-    bt5 = np.array([0, 4, 0, -5, 0, 1.0])
+    # position (5,5) = row 5 of B^T on both sides = 81/64 d1 - 45/16 d3 + d5 along each axis; tile (1, 2): patch rows 3..8,
+    # columns 7..12 (pixels with row > 5 or column > 8 are outside)
+    bt5 = np.array([0, 81 / 64, 0, -45 / 16, 0, 1.0])
     patch = np.zeros((6, 6))
     patch[:3, :2] = x[0, 3:6, 7:9, 0]
     assert np.isclose(V[35, 1 * 3 + 2, 0], bt5 @ patch @ bt5)
     dM = wo.outgrad_transform(x, m=4)
     t = 0 * 3 + 1                                               # tile (0, 1): pixels rows 0..3, columns 4..7
-    assert dM[0, t, 0] == x[0, 0, 4, 0]                         # A dY A^T at (0,0) is the tile's first pixel
-    assert dM[wo.bias_position(4), t, 0] == x[0, 0:4, 4:8, 0].sum()
+    assert dM[0, t, 0] == x[0, 0, 4, 0]                         # A dY A^T at (0,0) is the tile's first pixel (point 0)
+    assert dM[35, t, 0] == x[0, 3, 7, 0]                        # ... at (5,5) its last one (the point at infinity)
     assert wo.bias_position(2) == 5
+
+
+def test_literal_matrices_are_the_toom_cook_construction():
+    """The matrices typed into the oracle (and, as formulas, into csrc/winograd.hip) equal the exact Toom-Cook construction
+    over their interpolation points; every entry of the F(4x4,3x3) B^T and A^T is a dyadic rational, i.e. exact in fp32."""
+    at, g, bt = wo.toom_cook(wo.F4_POINTS, 4)
+    assert np.array_equal(at, wo._AT[4]) and np.allclose(g, wo._G[4], rtol=1e-15, atol=0) and np.array_equal(bt, wo._BT[4])
+    # (the published F(2x2,3x3) matrices are the construction over 0, +-1, inf with the signs of two points flipped in pairs)
+    for m, mats in ((2, wo.toom_cook((0, 1, -1), 2)), (2, (wo._AT[2], wo._G[2], wo._BT[2])), (4, (wo._AT[4], wo._G[4], wo._BT[4]))):
+        at, g, bt = mats
+        ident = np.einsum('ij,jk,jl->ikl', at, g, bt)                 # the defining identity: y_i = sum_k g_k d_{i+k}
+        want = np.zeros_like(ident)
+        for i in range(m):
+            for k in range(3):
+                want[i, k, i + k] = 1
+        assert np.allclose(ident, want, atol=1e-14)
+    for M in (wo._BT[4], wo._AT[4]):
+        assert np.array_equal(M.astype(np.float32).astype(np.float64), M)
+    # the textbook F(4x4,3x3) point set gives a valid algorithm too (it is what this one was compared against)
+    at, g, bt = wo.toom_cook((0, 1, -1, 2, -2), 4)
+    assert at[3].tolist() == [0, 1, -1, 8, -8, 1] and bt[0].tolist() == [4, 0, -5, 0, 1, 0]

@@ -48,7 +48,8 @@ _SIGS = {
     'wesup_winograd_input_transform': (c_int, 'ppliiiiiip'),
     'wesup_gemm_nt_batched': (c_int, 'pilpilpiliiiip'),
     'wesup_winograd_output_transform': (c_int, 'plpppppiiiiiiip'),
-    'wesup_winograd_outgrad_transform': (c_int, 'ppiiiiip'),
+    'wesup_winograd_outgrad_workspace_bytes': (c_size_t, 'iiiii'),
+    'wesup_winograd_outgrad_transform': (c_int, 'pppiiiiipzp'),
     'wesup_winograd_filter_grad': (c_int, 'pllippiiip'),
     'wesup_gemm_nt_workspace_bytes': (c_size_t, 'iii'),
     'wesup_gemm_nt': (c_int, 'pipippipiiiiipzp'),

@@ -1377,11 +1377,13 @@ extern "C" size_t wesup_conv3x3_wgrad_winograd_workspace_bytes(int B, int H, int
     const int P = wino_positions(m);
     const TnPlan pl = plan_tn(Cout, Ci, (int)T, 1, P);
     return align_up((size_t)P * T * Ci * sizeof(float), 256) + align_up((size_t)P * T * Cout * sizeof(float), 256) +
-           (size_t)P * pl.S * tn_slab_stride(Cout, pl.Nslab) * sizeof(float);
+           align_up((size_t)P * pl.S * tn_slab_stride(Cout, pl.Nslab) * sizeof(float), 256) +
+           wesup_winograd_outgrad_workspace_bytes(B, H, W, Cout, m);
 }
 // The same dW / db as wesup_conv3x3_wgrad (torch autograd of Conv2d(k=3, pad=1), models/wesup.py:199; the scheme of the
-// non-fused Winograd backward-filter algorithms of vendor conv libraries).  The bias gradient is the column sum of dM at
-// position (1,1) (A dY A^T there = the sum of a tile's gradients), taken from the staged A tiles of that batch entry.
+// non-fused Winograd backward-filter algorithms of vendor conv libraries).  The bias gradient: m = 2, the column sum of dM
+// at position (1,1) (A dY A^T there = the sum of a tile's gradients), taken from the staged A tiles of that batch entry;
+// m = 4 (no such position in its point set), summed per block inside the outgrad transform from the values it loads.
 extern "C" int wesup_conv3x3_wgrad_winograd(const float* x, const float* v_pre, const float* dy, float* dw_kcrs, float* db,
                                             int B, int H, int W, int Ci, int Cout, int relu_in, int m, void* ws,
                                             size_t ws_bytes, void* stream) {
@@ -1401,15 +1403,19 @@ extern "C" int wesup_conv3x3_wgrad_winograd(const float* x, const float* v_pre, 
     } else if ((rc = wesup_winograd_input_transform(x, V, 0, B, H, W, Ci, relu_in, m, stream))) {
         return rc;
     }
-    if ((rc = wesup_winograd_outgrad_transform(dy, dM, B, H, W, Cout, m, stream))) return rc;
     const TnPlan pl = plan_tn(Cout, Ci, (int)T, 1, P);
+    char* ows = (char*)slab + align_up((size_t)P * pl.S * tn_slab_stride(Cout, pl.Nslab) * sizeof(float), 256);
+    if ((rc = wesup_winograd_outgrad_transform(dy, dM, m == 4 ? db : nullptr, B, H, W, Cout, m, ows,
+                                               wesup_winograd_outgrad_workspace_bytes(B, H, W, Cout, m), stream)))
+        return rc;
     TnParams p = {};
     p.A = dM; p.Bx = V; p.slab = slab; p.M = Cout; p.N = Ci; p.K = (int)T; p.lda = Cout; p.ldb = Ci;
     p.relu_b = 0; p.H = 1; p.W = 1; p.dW = make_fastdiv(1); p.dH = make_fastdiv(1);
-    p.slab_stride = (long)tn_slab_stride(Cout, pl.Nslab); p.want_colsum = db != nullptr; p.colsum_batch = m + 3;
+    p.slab_stride = (long)tn_slab_stride(Cout, pl.Nslab); p.want_colsum = (db != nullptr && m == 2); p.colsum_batch = 5;
     p.batchA = T * Cout; p.batchB = T * Ci; p.batch_slab = (long)pl.S * p.slab_stride;
     if ((rc = launch_tn<3>(p, pl, st, P))) return rc;
-    return wesup_winograd_filter_grad(slab, p.slab_stride, p.batch_slab, pl.S, dw_kcrs, db, Cout, Ci, m, stream);
+    return wesup_winograd_filter_grad(slab, p.slab_stride, p.batch_slab, pl.S, dw_kcrs, m == 2 ? db : nullptr, Cout, Ci, m,
+                                      stream);
 }
 
 // workspace of one forward / dgrad call: [V: P T Cin][M: P T Cout] (for dgrad ask with the channel counts swapped)

@@ -6,10 +6,12 @@
 //   weight gradient:            dM = A dY A^T, V as above  ->  dU_p = dM_p^T . V_p  (gemm.hip)  ->  dg = G^T dU G
 //   filters:                    U = G g G^T once per step (forward), and of the rotated filter (input gradient)
 //
-// B^T, G, A^T are the published minimal-filtering matrices: F(2x2,3x3) with entries 0, +-1, +-1/2 (16 positions, 4x the
-// activation bytes, 4/9 of the direct form's multiply-adds) and F(4x4,3x3) with interpolation points 0, +-1, +-2, inf
-// (36 positions, 2.25x the bytes, 1/4 of the multiply-adds; entries up to 8 and down to 1/24, fp32 error ~10x F(2x2)'s
-// and still 10x inside the path's 1e-4 tolerance).  A transformed tensor is position-major so that each
+// B^T, G, A^T: F(2x2,3x3) are the published minimal-filtering matrices (points 0, +-1, inf; entries 0, +-1, +-1/2; 16
+// positions, 4x the activation bytes, 4/9 of the direct form's multiply-adds).  F(4x4,3x3) (36 positions, 2.25x the bytes,
+// 1/4 of the multiply-adds) is the same Toom-Cook construction over the points 0, +-3/4, +-3/2, inf instead of the textbook
+// 0, +-1, +-2, inf: ~4x less fp32 error (about 1e-6 of the tensor's maximum, the level of the direct kernels; the textbook
+// set gave 4-7e-6), every entry of B^T and A^T a dyadic rational (exact in fp32), the +- pairs share their sub-expressions
+// (oracle/winograd_oracle.py toom_cook()).  A transformed tensor is position-major so that each
 // GEMM operand is a plain row-major matrix.  Every kernel: one thread per (tile, 4 channels), channels fastest across
 // lanes, 16-byte loads and stores of contiguous channel rows; tiles that hang over a ragged border read zeros and skip
 // the stores.
@@ -109,7 +111,7 @@ __global__ __launch_bounds__(256) void wino_outgrad_transform_kernel(const float
 }
 #undef F4
 
-// dw[co][ci][3][3] = G^T (sum_s slab[p][s][co][ci]) G ;  db[co] = sum_s (column sums of dM at position (1,1))
+// dw[co][ci][3][3] = G^T (sum_s slab[p][s][co][ci]) G ;  db[co] (F(2x2) only) = sum_s (column sums of dM at position (1,1))
 // NP = m + 2.  block = PB (co, ci) pairs x NP^2 positions (16 x 16 for m = 2, 7 x 36 for m = 4): a thread adds the S
 // split-K slabs of ONE position (a thread per pair walked NP^2 x S dependent loads -- 512 at conv2_2 -- with only
 // Co*Ci/256 blocks on the chip: 113 us per launch on average, 1.1 ms per step); the sums of a pair meet in LDS and one
@@ -122,10 +124,10 @@ __device__ __forceinline__ void wino_gt(const float (&u)[NP], float (&r)[3]) {  
         r[1] = hd;
         r[2] = hs + u[3];
     } else {
-        const float s12 = u[1] + u[2], s34 = u[3] + u[4];
-        r[0] = 0.25f * u[0] - (1.f / 6.f) * s12 + (1.f / 24.f) * s34;
-        r[1] = (1.f / 6.f) * (u[2] - u[1]) + (1.f / 12.f) * (u[3] - u[4]);
-        r[2] = (1.f / 6.f) * (s34 - s12) + u[5];
+        const float s12 = u[1] + u[2], s34 = u[3] + u[4];        // G^T of the F(4x4,3x3) point set (columns of wino4_g)
+        r[0] = (64.f / 81.f) * u[0] - (128.f / 243.f) * s12 + (32.f / 243.f) * s34;
+        r[1] = (32.f / 81.f) * (u[2] - u[1]) + (16.f / 81.f) * (u[3] - u[4]);
+        r[2] = (8.f / 27.f) * (s34 - s12) + u[5];
     }
 }
 template <int NP>
@@ -296,38 +298,41 @@ __global__ __launch_bounds__(256) void wino_output_transform_kernel(const float*
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ float4 f4add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 __device__ __forceinline__ float4 f4sub(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
+__device__ __forceinline__ float4 f4scale(float s, float4 a) { return make_float4(s * a.x, s * a.y, s * a.z, s * a.w); }
 // s * a + b
 __device__ __forceinline__ float4 f4fma(float s, float4 a, float4 b) {
     return make_float4(fmaf(s, a.x, b.x), fmaf(s, a.y, b.y), fmaf(s, a.z, b.z), fmaf(s, a.w, b.w));
 }
-// B^T (.) for a 6-vector: rows [4,0,-5,0,1,0], [0,-4,-4,1,1,0], [0,4,-4,-1,1,0], [0,-2,-1,2,1,0], [0,2,-1,-2,1,0], [0,4,0,-5,0,1]
+// 1-D transforms over the points 0, +-3/4, +-3/2, inf (rows as in oracle/winograd_oracle.py _BT[4], _AT[4]).
+// B^T (.) for a 6-vector: rows [81/64,0,-45/16,0,1,0], [0,-27/16,-9/4,3/4,1,0], [0,27/16,-9/4,-3/4,1,0],
+// [0,-27/32,-9/16,3/2,1,0], [0,27/32,-9/16,-3/2,1,0], [0,81/64,0,-45/16,0,1]
 __device__ __forceinline__ void wino4_bt(const float4 (&d)[6], float4 (&t)[6]) {
-    t[0] = f4fma(4.f, d[0], f4fma(-5.f, d[2], d[4]));
-    const float4 a = f4fma(-4.f, d[2], d[4]), b = f4fma(-4.f, d[1], d[3]);
-    t[1] = f4add(a, b);
-    t[2] = f4sub(a, b);
-    const float4 c = f4sub(d[4], d[2]), e = f4sub(d[3], d[1]);
-    t[3] = f4fma(2.f, e, c);
-    t[4] = f4fma(-2.f, e, c);
-    t[5] = f4fma(4.f, d[1], f4fma(-5.f, d[3], d[5]));
+    t[0] = f4fma(81.f / 64.f, d[0], f4fma(-45.f / 16.f, d[2], d[4]));
+    const float4 a = f4fma(-9.f / 4.f, d[2], d[4]), b = f4fma(-9.f / 4.f, d[1], d[3]);        // b: (3/4) b below
+    t[1] = f4fma(0.75f, b, a);
+    t[2] = f4fma(-0.75f, b, a);
+    const float4 c = f4fma(-9.f / 16.f, d[2], d[4]), e = f4fma(-9.f / 16.f, d[1], d[3]);
+    t[3] = f4fma(1.5f, e, c);
+    t[4] = f4fma(-1.5f, e, c);
+    t[5] = f4fma(81.f / 64.f, d[1], f4fma(-45.f / 16.f, d[3], d[5]));
 }
-// A^T (.) for a 6-vector: rows [1,1,1,1,1,0], [0,1,-1,2,-2,0], [0,1,1,4,4,0], [0,1,-1,8,-8,1]
+// A^T (.) for a 6-vector: rows [1,1,1,1,1,0], [0,3/4,-3/4,3/2,-3/2,0], [0,9/16,9/16,9/4,9/4,0], [0,27/64,-27/64,27/8,-27/8,1]
 __device__ __forceinline__ void wino4_at(const float4 (&m)[6], float4 (&o)[4]) {
     const float4 s12 = f4add(m[1], m[2]), d12 = f4sub(m[1], m[2]), s34 = f4add(m[3], m[4]), d34 = f4sub(m[3], m[4]);
     o[0] = f4add(f4add(m[0], s12), s34);
-    o[1] = f4fma(2.f, d34, d12);
-    o[2] = f4fma(4.f, s34, s12);
-    o[3] = f4add(f4fma(8.f, d34, d12), m[5]);
+    o[1] = f4fma(1.5f, d34, f4scale(0.75f, d12));
+    o[2] = f4fma(9.f / 4.f, s34, f4scale(9.f / 16.f, s12));
+    o[3] = f4add(f4fma(27.f / 8.f, d34, f4scale(27.f / 64.f, d12)), m[5]);
 }
-// A (.) for a 4-vector (A = (A^T)^T): rows [1,0,0,0], [1,1,1,1], [1,-1,1,-1], [1,2,4,8], [1,-2,4,-8], [0,0,0,1]
+// A (.) for a 4-vector (A = (A^T)^T): rows [1,0,0,0], [1,+-3/4,9/16,+-27/64], [1,+-3/2,9/4,+-27/8], [0,0,0,1]
 __device__ __forceinline__ void wino4_a(const float4 (&y)[4], float4 (&t)[6]) {
-    const float4 e = f4add(y[0], y[2]), o = f4add(y[1], y[3]);
-    const float4 e2 = f4fma(4.f, y[2], y[0]), o2 = f4fma(8.f, y[3], f4add(y[1], y[1]));
+    const float4 e1 = f4fma(9.f / 16.f, y[2], y[0]), o1 = f4fma(9.f / 16.f, y[3], y[1]);
+    const float4 e2 = f4fma(9.f / 4.f, y[2], y[0]), o2 = f4fma(9.f / 4.f, y[3], y[1]);
     t[0] = y[0];
-    t[1] = f4add(e, o);
-    t[2] = f4sub(e, o);
-    t[3] = f4add(e2, o2);
-    t[4] = f4sub(e2, o2);
+    t[1] = f4fma(0.75f, o1, e1);
+    t[2] = f4fma(-0.75f, o1, e1);
+    t[3] = f4fma(1.5f, o2, e2);
+    t[4] = f4fma(-1.5f, o2, e2);
     t[5] = y[3];
 }
 
@@ -378,34 +383,52 @@ __global__ __launch_bounds__(256) void wino4_input_transform_kernel(const float*
     }
 }
 
-// thread = (tile, 4 channels): the tile's 4x4 gradients -> A dY A^T (6x6)
+// thread = (tile, 4 channels): the tile's 4x4 gradients -> A dY A^T (6x6).
+// colsum_part (optional, [blocks][C]): the bias gradient rides along.  This point set has no point 1, so no single position
+// of dM is the plain sum of a tile's gradients (for F(2x2) position (1,1) is, and the TN GEMM sums its column); instead
+// every thread adds up the 16 gradients it has loaded anyway, the tiles of a block meet in LDS in a fixed order (needs
+// C/4 | 256), and wesup_colsum folds the per-block rows: dy is not read a second time, no float atomics.
 __global__ __launch_bounds__(256) void wino4_outgrad_transform_kernel(const float* __restrict__ dy, float* __restrict__ dM,
-                                                                      const WinoGeom g) {
+                                                                      const WinoGeom g, float* __restrict__ colsum_part) {
+    __shared__ float4 sh[256];
     WinoTile q;
-    if (!wino4_decode(g, q)) return;
+    const bool active = wino4_decode(g, q);
     const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-    float4 m[6][4];      // A dY
+    float4 tot = z;
+    if (active) {
+        float4 m[6][4];      // A dY
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        const int w = 4 * q.j + c;
-        float4 y[4], t[6];
+        for (int c = 0; c < 4; ++c) {
+            const int w = 4 * q.j + c;
+            float4 y[4], t[6];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int h = 4 * q.i + r;
-            y[r] = (h < g.H && w < g.W) ? ld4(dy + (((long)q.b * g.H + h) * g.W + w) * g.C + 4 * q.cq) : z;
+            for (int r = 0; r < 4; ++r) {
+                const int h = 4 * q.i + r;
+                y[r] = (h < g.H && w < g.W) ? ld4(dy + (((long)q.b * g.H + h) * g.W + w) * g.C + 4 * q.cq) : z;
+            }
+            tot = f4add(tot, f4add(f4add(y[0], y[1]), f4add(y[2], y[3])));
+            wino4_a(y, t);
+#pragma unroll
+            for (int r = 0; r < 6; ++r) m[r][c] = t[r];
         }
-        wino4_a(y, t);
+        float* out = dM + (long)q.t * g.C + 4 * q.cq;
+        const long ps = g.ps;
 #pragma unroll
-        for (int r = 0; r < 6; ++r) m[r][c] = t[r];
+        for (int r = 0; r < 6; ++r) {   // (.) A^T
+            float4 o[6];
+            wino4_a(m[r], o);
+#pragma unroll
+            for (int c = 0; c < 6; ++c) st4(out + (6 * r + c) * ps, o[c]);
+        }
     }
-    float* out = dM + (long)q.t * g.C + 4 * q.cq;
-    const long ps = g.ps;
-#pragma unroll
-    for (int r = 0; r < 6; ++r) {   // (.) A^T
-        float4 o[6];
-        wino4_a(m[r], o);
-#pragma unroll
-        for (int c = 0; c < 6; ++c) st4(out + (6 * r + c) * ps, o[c]);
+    if (!colsum_part) return;            // uniform
+    const int Q = g.C >> 2, tid = threadIdx.x;
+    sh[tid] = tot;
+    __syncthreads();
+    if (tid < Q) {
+        float4 s = sh[tid];
+        for (int k = tid + Q; k < 256; k += Q) s = f4add(s, sh[k]);
+        st4(colsum_part + (long)xcd_remap(blockIdx.x, gridDim.x) * g.C + 4 * tid, s);
     }
 }
 
@@ -472,10 +495,11 @@ __global__ __launch_bounds__(256) void wino4_output_transform_kernel(const float
 }
 
 // F(4x4,3x3) filters: U = G g G^T (6x6) per (co, ci); mode as in wino_weight_transform_kernel
+// G (.) for a 3-vector: rows [64/81,0,0], [-128/243,-+32/81,-8/27], [32/243,+-16/81,8/27], [0,0,1]
 __device__ __forceinline__ void wino4_g(float g0, float g1, float g2, float (&u)[6]) {
-    const float a = -(1.f / 6.f) * (g0 + g2), b = (1.f / 6.f) * g1;
-    const float c = fmaf(1.f / 24.f, g0, (1.f / 6.f) * g2), d = (1.f / 12.f) * g1;
-    u[0] = 0.25f * g0;
+    const float a = fmaf(-128.f / 243.f, g0, (-8.f / 27.f) * g2), b = (32.f / 81.f) * g1;
+    const float c = fmaf(32.f / 243.f, g0, (8.f / 27.f) * g2), d = (16.f / 81.f) * g1;
+    u[0] = (64.f / 81.f) * g0;
     u[1] = a - b;
     u[2] = a + b;
     u[3] = c + d;
@@ -577,23 +601,48 @@ extern "C" int wesup_winograd_output_transform(const float* Mt, long plane_elems
     WESUP_CHECK_LAUNCH();
     return WESUP_OK;
 }
-// dy (B,H,W,C) -> dM [P][tiles][C] = A dY A^T per m x m tile (the weight gradient's second operand)
-extern "C" int wesup_winograd_outgrad_transform(const float* dy, float* dM, int B, int H, int W, int C, int m, void* stream) {
-    if (!dy || !dM || !wino_shape_ok(B, H, W, C, C, m) || (((uintptr_t)dy | (uintptr_t)dM) & 15)) return WESUP_ERR_INVALID;
+// dy (B,H,W,C) -> dM [P][tiles][C] = A dY A^T per m x m tile (the weight gradient's second operand).
+// db (optional, m = 4 only, [C]): the bias gradient sum_pixels dy, from the values the transform loads anyway (m = 2 takes it
+// from the TN GEMM: the column sums of position (1,1)).  Workspace: per-block partial sums + wesup_colsum's own.
+static bool wino4_block_colsum_ok(int C) { const int Q = C / 4; return Q <= 256 && 256 % Q == 0; }
+extern "C" size_t wesup_winograd_outgrad_workspace_bytes(int B, int H, int W, int C, int m) {
+    if (m != 4 || !wino_shape_ok(B, H, W, C, C, m)) return 0;
+    if (!wino4_block_colsum_ok(C)) return wesup_colsum_workspace_bytes(B * H * W, C);
+    const long blocks = ceil_div(wino_tiles(B, H, W, m) * (C / 4), 256l);
+    return align_up((size_t)blocks * C * sizeof(float), 256) + wesup_colsum_workspace_bytes((int)blocks, C);
+}
+extern "C" int wesup_winograd_outgrad_transform(const float* dy, float* dM, float* db, int B, int H, int W, int C, int m,
+                                                void* ws, size_t ws_bytes, void* stream) {
+    if (!dy || !dM || !wino_shape_ok(B, H, W, C, C, m) || (((uintptr_t)dy | (uintptr_t)dM | (uintptr_t)ws) & 15))
+        return WESUP_ERR_INVALID;
+    if (db && m != 4) return WESUP_ERR_INVALID;
+    if (db && (!ws || ws_bytes < wesup_winograd_outgrad_workspace_bytes(B, H, W, C, m))) return WESUP_ERR_WORKSPACE;
     const WinoGeom g = wino_geom(B, H, W, C, m);
-    const dim3 grid((unsigned)ceil_div(g.T * (C / 4), 256l));
-    if (m == 2) hipLaunchKernelGGL(wino_outgrad_transform_kernel, grid, dim3(256), 0, (hipStream_t)stream, dy, dM, g);
-    else hipLaunchKernelGGL(wino4_outgrad_transform_kernel, grid, dim3(256), 0, (hipStream_t)stream, dy, dM, g);
+    const long blocks = ceil_div(g.T * (C / 4), 256l);
+    const dim3 grid((unsigned)blocks);
+    if (m == 2) {
+        hipLaunchKernelGGL(wino_outgrad_transform_kernel, grid, dim3(256), 0, (hipStream_t)stream, dy, dM, g);
+        WESUP_CHECK_LAUNCH();
+        return WESUP_OK;
+    }
+    const bool in_kernel = db && wino4_block_colsum_ok(C);
+    float* part = in_kernel ? (float*)ws : nullptr;
+    hipLaunchKernelGGL(wino4_outgrad_transform_kernel, grid, dim3(256), 0, (hipStream_t)stream, dy, dM, g, part);
     WESUP_CHECK_LAUNCH();
+    if (in_kernel) {
+        const size_t pb = align_up((size_t)blocks * C * sizeof(float), 256);
+        return wesup_colsum(part, C, db, (int)blocks, C, (char*)ws + pb, ws_bytes - pb, stream);
+    }
+    if (db) return wesup_colsum(dy, C, db, B * H * W, C, ws, ws_bytes, stream);
     return WESUP_OK;
 }
 // slabs [P][S][Cout*Cin + Cout] (split-K partial products of dU_p, each followed by Cout column sums of dM_p) ->
-// dw (Cout,Cin,3,3) = G^T (sum over S) G, db (Cout) = the column sums of position (1,1) (= m + 3).  slab_stride = elements
-// between two splits, batch_stride = between two positions.
+// dw (Cout,Cin,3,3) = G^T (sum over S) G; db (Cout, m = 2 only, else NULL) = the column sums of position (1,1) (index 5).
+// slab_stride = elements between two splits, batch_stride = between two positions.
 extern "C" int wesup_winograd_filter_grad(const float* slabs, long slab_stride, long batch_stride, int S, float* dw_kcrs,
                                           float* db, int Cout, int Cin, int m, void* stream) {
     if (!slabs || !dw_kcrs || S <= 0 || Cout <= 0 || Cin <= 0 || slab_stride < (long)Cout * Cin + Cout ||
-        batch_stride < (long)S * slab_stride || !wino_m_ok(m))
+        batch_stride < (long)S * slab_stride || !wino_m_ok(m) || (db && m != 2))
         return WESUP_ERR_INVALID;
     const long tot = (long)Cout * Cin;
     const int pb = 256 / wino_positions(m);

@@ -243,15 +243,21 @@ def winograd_input_transform(x, relu=False, out=None, m=2):
     return out
 
 
-def winograd_outgrad_transform(dy, out=None, m=2):
-    """dy (B,H,W,C) -> dM (P, tiles, C) = A dY A^T of every m x m output tile."""
+def winograd_outgrad_transform(dy, out=None, m=2, db=None):
+    """dy (B,H,W,C) -> dM (P, tiles, C) = A dY A^T of every m x m output tile.  db (C,), m = 4 only: also the bias gradient
+    sum_pixels dy (m = 2 gets it from winograd_filter_grad: position (1,1) of dM)."""
     _chk(dy, name='dy')
     B, H, W, C = dy.shape
     T, P = winograd_tiles(B, H, W, m), winograd_positions(m)
     if out is None:
         out = torch.empty(P, T, C, dtype=torch.float32, device=dy.device)
     assert out.shape == (P, T, C) and out.is_contiguous()
-    _lib.call('wesup_winograd_outgrad_transform', _p(dy), _p(out), B, H, W, C, m, _stream())
+    ws, nb = None, 0
+    if db is not None:
+        _chk(db, name='db'); assert db.numel() == C and m == 4
+        nb = _lib.load().wesup_winograd_outgrad_workspace_bytes(B, H, W, C, m)
+        ws = workspace(nb, dy.device, 'wino_outgrad')
+    _lib.call('wesup_winograd_outgrad_transform', _p(dy), _p(out), _p(db), B, H, W, C, m, _p(ws), nb, _stream())
     return out
 
 
@@ -288,13 +294,15 @@ def gemm_nt_batched(A, Bw, out=None):
 
 def winograd_filter_grad(slabs, dw=None, db=None, m=2):
     """slabs (P, S, Cout*Cin + Cout): split-K partial products of the P transformed filter gradients, each followed by
-    the column sums of its dM operand -> (dw (Cout,Cin,3,3) = G^T (sum over S) G, db (Cout) from position (1,1)).
-    Cout, Cin are taken from dw."""
-    _chk(slabs, name='slabs'); _chk(dw, name='dw'); _chk(db, name='db')
+    the column sums of its dM operand -> (dw (Cout,Cin,3,3) = G^T (sum over S) G, db (Cout) from position (1,1): m = 2
+    only, pass None for m = 4 -- winograd_outgrad_transform(db=...) has it there).  Cout, Cin are taken from dw."""
+    _chk(slabs, name='slabs'); _chk(dw, name='dw')
     Cout, Cin = dw.shape[:2]
     S = slabs.shape[1]
     assert slabs.shape == (winograd_positions(m), S, Cout * Cin + Cout) and slabs.is_contiguous()
-    assert dw.shape == (Cout, Cin, 3, 3) and db.numel() == Cout
+    assert dw.shape == (Cout, Cin, 3, 3)
+    if db is not None:
+        _chk(db, name='db'); assert db.numel() == Cout and m == 2
     _lib.call('wesup_winograd_filter_grad', _p(slabs), slabs.stride(1), slabs.stride(0), S, _p(dw), _p(db), Cout, Cin, m,
               _stream())
     return dw, db
