@@ -136,16 +136,14 @@ def roofline_inputs(B, H, W, g):
     """Counter-derived inputs of the roofline objects, read from the newest profiles/rNN_roofline_inputs.json
     (written by tools/roofline_inputs.py from the rocprofv3 --pmc passes of tools/collect_profiles.sh).  Only used
     when the file was collected at this very shape; no number is typed into this file."""
-    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_roofline_inputs.json')))
-    if not files:
-        return None
-    with open(files[-1]) as f:
-        d = json.load(f)
-    sh = d.get('shape', {})
-    if (sh.get('batch'), sh.get('H'), sh.get('W'), sh.get('superpixels')) != (B, H, W, g * g):
-        return None
-    d['file'] = os.path.relpath(files[-1], ROOT)
-    return d
+    for path in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*roofline_inputs.json')), reverse=True):
+        with open(path) as f:
+            d = json.load(f)
+        sh = d.get('shape', {})
+        if (sh.get('batch'), sh.get('H'), sh.get('W'), sh.get('superpixels')) == (B, H, W, g * g):
+            d['file'] = os.path.relpath(path, ROOT)
+            return d
+    return None
 
 
 def host_cpu():
@@ -278,21 +276,35 @@ def worker(args):
     for i in range(args.warmup):
         step(i)
     timer = trainer.model.engine.timer
+    from wesup_amd import ops as _ops_t
+    _ops_t.set_timer(timer)                           # sp_preprocess / propagate / paint / sgd launch outside the engine
     timer.reset()
     timing_on = not args.no_kernel_timing and args.timed_classes != 'none'
     timer.only = None if args.timed_classes == 'all' else set(args.timed_classes.split(','))
     n_sampled = 0
+    reducer = getattr(trainer, 'reducer', None)
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]      # one record per step: its end
     barrier()
     t0 = time.perf_counter()
+    marks[0].record()
     for i in range(args.steps):
         # an event record fences its queue (events on the 25 conv launches of every step cost 3 % of the step, on every
         # kernel class 16 %): inside the timed region only every --event-every'th step carries events
         timer.enabled = timing_on and i % args.event_every == 0
         n_sampled += int(timer.enabled)
+        if reducer is not None:                       # bucket launch offsets + exposed all-reduce tail of the same steps
+            reducer.profile = (i % args.event_every == 0)
         step(i)
+        marks[i + 1].record()
     barrier()
     elapsed = time.perf_counter() - t0
     timer.enabled = False
+    step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+    median_ms = step_ms[len(step_ms) // 2] if len(step_ms) % 2 else 0.5 * (step_ms[len(step_ms) // 2 - 1] + step_ms[len(step_ms) // 2])
+    ddp_stats = None
+    if reducer is not None:
+        reducer.profile = False
+        ddp_stats = reducer.collect_stats()
     rank_time = None
     if use_dist:
         t = torch.tensor([elapsed, -elapsed], device=dev, dtype=torch.float64)
@@ -351,6 +363,7 @@ def worker(args):
         out = {
             'metric': 'training images/sec, GlaS 480x480 VGG16 ~600 SP/img', 'value': round(value, 3), 'unit': 'images/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 3),
+            'ms_per_step_median': round(median_ms, 3),      # of the per-step GPU times (an event at the end of every step)
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': workload_label(B, H, W, g),
                        'global_batch': world * B, 'image': [H, W], 'superpixels': g * g,
@@ -368,8 +381,18 @@ def worker(args):
                              'avg_us': round(ms / n * 1e3, 2)}
                 if tag.startswith('conv3x3') or tag in ('winograd_gemm', 'side_fwd', 'side_bwd', 'mlp_fwd', 'mlp_bwd', 'mlp_wgrad', 'sp_pool_mat_fwd', 'upsample_mat_bwd'):
                     kern[tag]['tflops'] = round(work / (ms * 1e-3) / 1e12, 2)
-                elif work > 0:
+                elif work > 0:       # memory-bound classes: algorithmic bytes / event time, against the HBM peak
                     kern[tag]['gbs'] = round(work / (ms * 1e-3) / 1e9, 1)
+                    kern[tag]['frac_of_hbm_peak'] = round(work / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)
+            if iso is not None:      # the same classes alone on the GPU (single-stream steps)
+                for tag, (ms, n, work) in iso.items():
+                    if tag in kern and ms > 0:
+                        kern[tag]['alone_ms_per_step'] = round(ms / 2, 4)
+                        if 'gbs' in kern[tag] and work > 0:
+                            kern[tag]['alone_gbs'] = round(work / (ms * 1e-3) / 1e9, 1)
+            kern['_note'] = ('propagate = wesup_propagate (label propagation); sp_preprocess = wesup_sp_preprocess + '
+                             'wesup_sp_segments (histograms, reference ordering, counting sort, segment table); paint = '
+                             'wesup_paint_fwd; sgd = wesup_sgd_step (20 B per parameter).  gbs = algorithmic bytes / event time')
             # Dominant kernel: gemm_nt_kernel, the GEMM of every conv forward and input gradient -- the implicit-GEMM form
             # (MODE 1/2) for the 3/64-channel layers, the 16-position batched form (MODE 3) over Winograd-domain operands
             # for the layers with >= 128 input channels, whose two memory-bound transform passes per op belong to the same
@@ -391,26 +414,30 @@ def worker(args):
                 fl_alg += 2.0 * B * hh * ww * ci * co * 9 * (2 if l > 0 else 1)          # conv1_1 has no input gradient
                 if l in (1, 3, 6, 9):
                     hh, ww = hh // 2, ww // 2
-            ach = fl_alg * n_ev / (ms_all * 1e-3) / 1e12
+            eff = fl_alg * n_ev / (ms_all * 1e-3) / 1e12
             ach_exec = fl_exec / (ms_gemm * 1e-3) / 1e12
             conv_in = (rin or {}).get('conv3x3_fwd_dgrad', {})
+            # `achieved` / `frac`: what is compared with the hardware peak -- the FLOPs the MFMA pipe EXECUTES in the GEMM
+            # launches over their event time.  The direct-form (SURVEY 8(d) algorithmic) FLOPs over GEMM + transform time are an
+            # effective rate of the whole op (the Winograd forms execute 4/9 resp. 1/4 of them; it can exceed the peak) and
+            # carry no fraction of the peak.
             out['roofline'] = {'bound': 'mfma',
-                               'kernel': 'gemm_nt_kernel (conv3x3 fwd+dgrad: implicit GEMM for conv1_1..conv2_1, 16-position batched '
-                                         'GEMMs over Winograd F(2x2,3x3)-domain operands for conv2_2..conv5_3; fp32 MFMA 32x32x2) '
-                                         '+ the Winograd transform passes of the same ops',
-                               'achieved': round(ach, 2), 'peak': PEAK_MFMA_F32_TFLOPS, 'unit': 'TFLOP/s',
-                               'frac': round(ach / PEAK_MFMA_F32_TFLOPS, 4),
+                               'kernel': 'gemm_nt_kernel (conv3x3 fwd+dgrad GEMM launches: implicit GEMM for the 3/64-channel layers, '
+                                         'batched GEMMs over Winograd F(4x4,3x3)-domain operands for the layers with >= 128 input '
+                                         'channels; fp32 MFMA 32x32x2)',
+                               'achieved': round(ach_exec, 2), 'peak': PEAK_MFMA_F32_TFLOPS, 'unit': 'TFLOP/s',
+                               'frac': round(ach_exec / PEAK_MFMA_F32_TFLOPS, 4),
                                'traffic': conv_in.get('hbm_bytes_per_launch'),
                                'avg_launch_us': round(ms_gemm / nl * 1e3, 2), 'launches_per_step': nl / n_ev,
-                               'flop_per_step': fl_alg, 'event_timed_steps': n_ev,
-                               'what': 'SURVEY 8(d) algorithmic (direct-form) FLOPs of all conv forward + input-gradient ops / HIP-event '
-                                       'time of their GEMM and transform launches; avg_launch_us / launches_per_step / traffic are '
-                                       'the GEMM launches\' (the kernel rocprofv3 --stats lists as gemm_nt_kernel<..,1|2|3,..>)',
+                               'flop_per_step': fl_exec / n_ev, 'event_timed_steps': n_ev,
+                               'what': 'FLOPs the MFMA pipe executes in the conv forward + input-gradient GEMM launches (the kernel '
+                                       'rocprofv3 --stats lists as gemm_nt_kernel<..,1|2|3,..>) / their HIP-event time inside the '
+                                       'timed region',
                                'ms_per_step': {'gemm': round(ms_gemm / n_ev, 3), 'transforms': round((ms_all - ms_gemm) / n_ev, 3)},
-                               'mfma_executed': {'what': 'FLOPs the MFMA pipe executes in the GEMM launches (Winograd: 4/9 of the direct '
-                                                         'form) / their event time',
-                                                 'achieved': round(ach_exec, 2), 'frac': round(ach_exec / PEAK_MFMA_F32_TFLOPS, 4),
-                                                 'flop_per_step': fl_exec / n_ev}}
+                               'effective_direct_form': {'tflops': round(eff, 2), 'flop_per_step': fl_alg,
+                                                         'what': 'SURVEY 8(d) algorithmic (direct-form 2*H*W*Cin*Cout*9) FLOPs of '
+                                                                 'the same ops / event time of their GEMM AND transform launches: an '
+                                                                 'effective rate of the ops, not a utilisation of the MFMA pipe'}}
             if conv_in:
                 out['roofline']['traffic_how'] = (f"{rin['file']}: rocprofv3 --pmc over this command, FETCH_SIZE x2 (gfx950 "
                                                   'correction) + WRITE_SIZE, separate passes, mean over the conv fwd+dgrad '
@@ -421,7 +448,7 @@ def worker(args):
                 ms, n, fl = allk['conv3x3_wgrad']
                 a = fl / (ms * 1e-3) / 1e12
                 out['roofline_wgrad'] = {'bound': 'mfma', 'kernel': 'conv3x3 wgrad ops: gemm_tn_kernel + reduce, implicit GEMM for conv1_1..conv2_1, '
-                                                                    'Winograd-domain (outgrad transform + 16 batched TN GEMMs + G^T.G reduce) above; '
+                                                                    'Winograd-domain (outgrad transform + batched TN GEMMs + G^T.G reduce) above; '
                                                                     'executed FLOPs over the whole op',
                                          'achieved': round(a, 2), 'peak': PEAK_MFMA_F32_TFLOPS, 'unit': 'TFLOP/s',
                                          'frac': round(a / PEAK_MFMA_F32_TFLOPS, 4),
@@ -440,7 +467,7 @@ def worker(args):
                          'sp_pool_mat_fwd', 'upsample_mat_bwd')
             fl_step = sum(allk[t][2] for t in gemm_tags if t in allk) / n_extra
             a = fl_step / (ms_per_step * 1e-3) / 1e12
-            out['roofline_step'] = {'bound': 'mfma', 'what': 'all GEMM FLOPs one step EXECUTES (Winograd-domain passes: 4/9 of the direct form) / wall time of the step (3 streams)',
+            out['roofline_step'] = {'bound': 'mfma', 'what': 'all GEMM FLOPs one step EXECUTES (Winograd-domain passes: 1/4 resp. 4/9 of the direct form) / wall time of the step (3 streams)',
                                     'achieved': round(a, 2), 'peak': PEAK_MFMA_F32_TFLOPS, 'unit': 'TFLOP/s',
                                     'frac': round(a / PEAK_MFMA_F32_TFLOPS, 4), 'flop_per_step': fl_step}
             out['kernels_how'] = (f'{n_extra} extra untimed steps with events on every kernel class (same 3-stream '
@@ -455,7 +482,7 @@ def worker(args):
                     'how': '2 extra untimed steps with single-stream scheduling and the stream-K tail on (what a kernel alone on the GPU '
                            'gains from; the 3-stream step runs plain tiling, wesup_amd/ops.py), HIP events per launch',
                     'ms_per_step': {k: round(v[0] / 2, 3) for k, v in sorted(iso.items())},
-                    'flops': 'executed (GEMM launches only; Winograd-domain passes run 4/9 of the direct form)',
+                    'flops': 'executed (GEMM launches only; Winograd-domain passes run 1/4 resp. 4/9 of the direct form)',
                     'conv3x3_fwd_dgrad': {'bound': 'mfma', 'achieved': a, 'peak': PEAK_MFMA_F32_TFLOPS, 'unit': 'TFLOP/s',
                                           'frac': round(a / PEAK_MFMA_F32_TFLOPS, 4)},
                     'conv3x3_wgrad': {'bound': 'mfma', 'achieved': wgr, 'peak': PEAK_MFMA_F32_TFLOPS, 'unit': 'TFLOP/s',
@@ -474,15 +501,61 @@ def worker(args):
                     'traffic_how': (f"{rin['file']}: FETCH_SIZE x2 + WRITE_SIZE of sp_pool_fwd_kernel in the PMC passes over "
                                     'this command') if sm_in else None,
                     'avg_launch_us': round(pool_ms * 1e3, 2), 'algorithmic_bytes': by}
+                # the scatter-mean the STEP runs: fused upsample + pooling of the shallow layers (sp_pool_up_fwd), the
+                # interpolation-pooling matrix of the deep layers and its application (interp_matrix + sp_pool_mat_fwd)
+                ftags = ('sp_pool_up_fwd', 'sp_pool_mat_fwd', 'interp_matrix')
+                f_in = sum(allk[t][0] for t in ftags if t in allk) / n_extra
+                f_alone = sum(iso[t][0] for t in ftags if t in iso) / 2 if iso is not None else None
+                dims, hh, ww = [], H, W
+                for l, co in enumerate((64, 64, 128, 128, 256, 256, 256, 512, 512, 512, 512, 512, 512)):
+                    dims.append((hh, ww, co // 2))
+                    if l in (1, 3, 6, 9):
+                        hh, ww = hh // 2, ww // 2
+                own = 0.0
+                for (h_, w_, c_) in dims:
+                    own += 4.0 * h_ * w_ * c_                                    # the side output, read once
+                    matrix = (h_, w_) != (H, W) and h_ * w_ <= 4096
+                    own += 0.0 if matrix else 4.0 * H * W                        # gather layers: the sorted pixel list
+                for (h_, w_) in sorted({(h_, w_) for (h_, w_, _) in dims if (h_, w_) != (H, W) and h_ * w_ <= 4096}):
+                    own += 4 * 4.0 * g * g * h_ * w_                             # Wm and its transpose: written, then read
+                own = B * (own + 4.0 * g * g * 2112)
+                fused = {'kernels': 'sp_pool_up_fwd_kernel (7 shallow layers) + sp_interp_matrix_kernel + gemm_tn (6 deep layers)',
+                         'ms_per_step_in_step': round(f_in, 4), 'ms_per_step_alone': None if f_alone is None else round(f_alone, 4),
+                         'materialised_model': {'bytes': by, 'what': 'SURVEY 8(d): 2112*HW*4 + HW*4 + N*2112*4 per image -- the bytes of '
+                                                                     'the scatter-mean over a materialised feature map, which these '
+                                                                     'kernels never read: the fraction may exceed 1'},
+                         'own_model': {'bytes': own, 'what': 'side outputs at native resolution + pixel lists of the gather layers + '
+                                                             'the interpolation-pooling matrices (written and read) + N*2112*4'}}
+                for key, bts in (('materialised_model', by), ('own_model', own)):
+                    for nm, ms_ in (('in_step', f_in), ('alone', f_alone)):
+                        if ms_:
+                            gb = bts / (ms_ * 1e-3) / 1e9
+                            fused[key][f'gbs_{nm}'] = round(gb, 1)
+                            fused[key][f'frac_{nm}'] = round(gb / PEAK_HBM_GBS, 4)
+                out['roofline_scatter_mean']['fused'] = fused
         if use_dist:
             out['rank_time'] = rank_time              # spread of the per-rank wall time of the timed region
             out['collective'] = {'backend': backend, 'ranks': dist.get_world_size(),
                                  'what': 'bucketed all-reduce(sum) of the flat fp32 gradient buffer, 1/world folded into SGD',
-                                 'bucket_mb': args.bucket_mb}
+                                 'bucket_mb': args.bucket_mb, 'exposed_ms': None, 'buckets': None}
+            if ddp_stats:
+                ex = sorted(st['exposed_ms'] for st in ddp_stats if 'exposed_ms' in st)
+                last = ddp_stats[-1]
+                out['collective']['exposed_ms'] = {
+                    'median': ex[len(ex) // 2], 'max': ex[-1], 'steps': len(ex),
+                    'what': 'rank 0, main stream: from the end of its last backward kernel to the end of the last all-reduce '
+                            '(events around GradAllReducer.finish()) = what the collectives add behind backward'} if ex else None
+                out['collective']['buckets'] = {'bytes': last['bucket_bytes'], 'launch_offset_ms': last['launch_offset_ms'],
+                                                'backward_ms': last.get('backward_ms'),
+                                                'what': 'launch = the point on the producing stream (wgrad / side) behind which the '
+                                                        'bucket\'s all-reduce is ordered, ms after the start of backward; last '
+                                                        'profiled step'}
         if world == 1 and not args.no_cpu_baseline:
             variants = {}
             for name in ('faithful', 'label_map'):
                 v, cores, sample = orc.time_cpu_baseline(iters=5, warmup=3, variant=name)
+                sample += (f'; {cores} threads chosen, {os.cpu_count()} logical cores available (torch CPU collapses when '
+                           'oversubscribed on this host: 63 s/step at 256 threads)')
                 variants[name] = {'value': round(v, 4), 'unit': 'images/s', 'cores': cores, 'sample': sample}
             f = variants['faithful']
             out['cpu_baseline'] = {'value': f['value'], 'unit': 'images/s', 'cores': f['cores'], 'kind': 'port',

@@ -19,10 +19,10 @@ def _free_port():
     return p
 
 
-def _make(weights):
+def _make(weights, device='cuda:0'):
     from wesup_amd.models import initialize_trainer
     from wesup_amd.utils.metrics import accuracy, dice
-    tr = initialize_trainer('wesup', device='cuda:0')
+    tr = initialize_trainer('wesup', device=device)
     tr.model.load_state_dict({k: torch.from_numpy(v) for k, v in weights.items()})
     tr.optimizer, _ = tr.get_default_optimizer()
     tr.metric_funcs = [accuracy, dice]
@@ -35,14 +35,21 @@ def _batch():
     return synth.make_batch(21, 4, 64, 64, 6)
 
 
-def _worker(rank, world, port, out):
+def _worker(rank, world, port, out, backend='gloo'):
     import torch.distributed as dist
     from oracle import wesup_oracle as orc
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
-    dist.init_process_group('gloo', rank=rank, world_size=world)
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    dev = 'cuda:0'
+    if backend == 'nccl':                                # RCCL: one rank per device
+        dev = f'cuda:{rank}'
+        torch.cuda.set_device(rank)
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device(dev))
+    else:
+        dist.init_process_group('gloo', rank=rank, world_size=world)
     try:
-        tr = _make(orc.make_weights(5, feat_scale=0.03))
+        tr = _make(orc.make_weights(5, feat_scale=0.03), dev)
         tr.enable_data_parallel(bucket_bytes=8 << 20)
         imgs, labs, pts, pix = _batch()
         sl = slice(2 * rank, 2 * rank + 2)
@@ -57,12 +64,43 @@ def _worker(rank, world, port, out):
 
 
 def test_two_ranks_equal_one_rank_on_the_whole_batch():
+    _two_ranks_equal_one_rank('gloo')
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason='RCCL needs one device per rank: runs on a box with >= 2 GPUs')
+def test_rccl_two_ranks_equal_one_rank():
+    """The same statement with RCCL carrying the exchange (backend "nccl", one rank per device, fresh processes): the
+    asynchronous bucketed all-reduces launched from the wgrad and side streams during backward, finish() ordering the
+    optimiser behind them.  Skipped on the one-GPU test box; a multi-GPU box picks it up under `pytest -m gpu`."""
+    _two_ranks_equal_one_rank('nccl')
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason='needs one device per rank')
+def test_bench_two_ranks_over_rccl_reports_the_collective():
+    """`python bench.py --gpus 2` on two devices: RCCL ranks, and the line carries the measured exposed all-reduce time and
+    the bucket launch offsets (overlap as a measurement, not a claim)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '6', '--warmup', '2',
+                        '--no-cpu-baseline', '--no-kernel-timing'], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][-1])
+    col = out['collective']
+    assert out['n_gpus'] == 2 and col['ranks'] == 2 and col['backend'] == 'nccl'
+    assert col['exposed_ms'] is not None and col['exposed_ms']['median'] >= 0 and len(col['buckets']['bytes']) >= 2
+    assert sum(col['buckets']['bytes']) >= 18868194 * 4
+
+
+def _two_ranks_equal_one_rank(backend):
     import torch.multiprocessing as mp
     from oracle import wesup_oracle as orc
     ctx = mp.get_context('spawn')
     out = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, out)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, out, backend)) for r in range(2)]
     for p in procs:
         p.start()
     got, got_grads = out.get(timeout=280)

@@ -1,5 +1,6 @@
 """Driver for per-layer PMC collection: every conv3x3 layer of the bench shape (B=4, 480x480) x {fwd, dgrad, wgrad}
-(as the engine routes them: implicit GEMM below 128 input channels, Winograd domain from there up),
+(as the engine routes them -- wesup_amd.engine.default_route: implicit GEMM below 128 input channels, Winograd F(4x4,3x3)
+domain from there up),
 each launched `reps` times in a fixed order, with a manifest of that order so that tools/roofline_inputs.py can map
 the dispatches of the rocprofv3 counter file back to (layer, pass).
 
@@ -11,7 +12,7 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from wesup_amd import ops
-from wesup_amd.engine import CONV_CH, POOL_AFTER, WesupEngine
+from wesup_amd.engine import CONV_CH, POOL_AFTER, default_route
 
 d = torch.device('cuda:0')
 B, H, W = 4, 480, 480
@@ -29,28 +30,29 @@ for l, (ci, co) in enumerate(CONV_CH):
     dx = torch.empty(B, h, w, cin, device=d)
     dw = torch.empty(co, ci, 3, 3, device=d)
     db = torch.empty(co, device=d)
-    wino = ci >= WesupEngine.WINOGRAD_CONV_MIN_CI          # the engine's routing: Winograd domain from 128 input channels up
-    # FLOPs the MFMA pipe executes in the main GEMM launch of the group (Winograd: 16 positions x 2x2 tiles)
-    fl = 2.0 * 16 * ops.winograd_tiles(B, h, w) * ci * co if wino else 2.0 * B * h * w * ci * co * 9
+    m = default_route(ci, co, h, w, B) if ci >= 32 else 0      # the engine's routing
+    wino = m > 0
+    # FLOPs the MFMA pipe executes in the main GEMM launch of the group (Winograd: (m+2)^2 positions x m-by-m tiles)
+    fl = 2.0 * ops.winograd_positions(m) * ops.winograd_tiles(B, h, w, m) * ci * co if wino else 2.0 * B * h * w * ci * co * 9
     if wino:
-        uf, ud = ops.winograd_pack_weight(wt)
-        v_keep = torch.empty(16, ops.winograd_tiles(B, h, w), ci, device=d)
+        uf, ud = ops.winograd_pack_weight(wt, m=m)
+        v_keep = torch.empty(ops.winograd_positions(m), ops.winograd_tiles(B, h, w, m), ci, device=d)
     for _ in range(reps):
         if wino:
-            ops.conv3x3_fwd_winograd(x, uf, bias, False, out=y, v_keep=v_keep)
+            ops.conv3x3_fwd_winograd(x, uf, bias, False, out=y, v_keep=v_keep, m=m)
         else:
             ops.conv3x3_fwd(x, wf, bias, co, relu_in=False, out=y)
     manifest['order'].append([l, 'fwd', fl])
     if l > 0:
         for _ in range(reps):
             if wino:
-                ops.conv3x3_dgrad_winograd(dy, ud, mask_src=x, out=dx, accumulate=True)
+                ops.conv3x3_dgrad_winograd(dy, ud, mask_src=x, out=dx, accumulate=True, m=m)
             else:
                 ops.conv3x3_dgrad(dy, wd, ci, mask_src=x, out=dx, accumulate=True)
         manifest['order'].append([l, 'dgrad', fl])
     for _ in range(reps):
         if wino:
-            ops.conv3x3_wgrad_winograd(x, dy, False, dw=dw, db=db, v_pre=v_keep)
+            ops.conv3x3_wgrad_winograd(x, dy, False, dw=dw, db=db, v_pre=v_keep, m=m)
         else:
             ops.conv3x3_wgrad(x, dy, ci, relu_in=False, dw=dw, db=db)
     manifest['order'].append([l, 'wgrad', fl])

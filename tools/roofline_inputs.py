@@ -1,7 +1,7 @@
 """Builds profiles/rNN_roofline_inputs.json and profiles/rNN_layer_mfma.csv from the rocprofv3 --pmc passes that
 tools/collect_profiles.sh ran.  bench.py reads the JSON for `roofline.traffic`; nothing in it is typed by hand.
 
-  python tools/roofline_inputs.py OUT_DIR ROUND > summary
+  python tools/roofline_inputs.py OUT_DIR TAG [BATCH SIZE GRID] > summary      (TAG: r03, r03_c4, ...; default shape 4 480 24)
 
 Inputs (all under OUT_DIR):
   pmc_bench_fetch/, pmc_bench_write/, pmc_bench_mfma/, pmc_bench_busy/ : counter passes over `bench.py` itself
@@ -60,9 +60,10 @@ def per_class(rows, counter):
 
 def main():
     out_dir, rnd = sys.argv[1], sys.argv[2]
-    B, H, W, N = 4, 480, 480, 576
+    B, H, g = (int(v) for v in sys.argv[3:6]) if len(sys.argv) >= 6 else (4, 480, 24)
+    W, N = H, g * g
     res = {'round': rnd, 'shape': {'batch': B, 'H': H, 'W': W, 'superpixels': N},
-           'how': 'rocprofv3 --pmc passes over `python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline` (one counter '
+           'how': f'rocprofv3 --pmc passes over `python3 bench.py --batch {B} --size {H} --grid {g} --steps 2 --warmup 1 --no-cpu-baseline` (one counter '
                   'group per pass, no trace domain beside it); per-launch means over every launch of the kernel class in '
                   'the run; bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950 FETCH_SIZE correction)'}
     fetch, nf = per_class(read_pass(os.path.join(out_dir, 'pmc_bench_fetch')), 'FETCH_SIZE')
@@ -71,6 +72,7 @@ def main():
     busy, nb = per_class(read_pass(os.path.join(out_dir, 'pmc_bench_busy')), 'GRBM_GUI_ACTIVE')
     # algorithmic bytes of the implicit GEMMs per step at this shape: read x once + write y once (+ weights), per layer
     from_layers = conv_algorithmic_bytes(B, H, W)
+    res['memory_bound'] = memory_bound_classes(out_dir)
     for c in ('conv3x3_fwd_dgrad', 'conv3x3_wgrad', 'scatter_mean'):
         e = {}
         if nf[c] and nw[c]:
@@ -116,7 +118,7 @@ def main():
     tot = sum(wsum.values()) / sum(wfl.values())
     lines.append(f'all,all,{sum(wfl.values()) / 1e9:.2f},,,{tot:.4f},  # FLOP-weighted over 13 layers x 3 passes')
     with open(os.path.join('profiles', f'{rnd}_layer_mfma.csv'), 'w') as f:
-        f.write('# MFMA pipe busy per conv3x3 layer and pass at the bench shape (B=4, 480x480), kernels alone on the GPU:\n'
+        f.write(f'# MFMA pipe busy per conv3x3 layer and pass at B={man["shape"][0]}, {man["shape"][1]}x{man["shape"][2]}, kernels alone on the GPU (the engine\'s routing):\n'
                 '# SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE/8), rocprofv3 --pmc over tools/layer_pmc.py (two passes),\n'
                 '# mean of the launches after the first of each group; the main GEMM launch only (stream-K fix-up / split-K reduce\n'
                 '# launches carry no MFMA and are listed in the kernel-stats file).  SURVEY.md 8(d).\n')
@@ -124,12 +126,43 @@ def main():
     print('\n'.join(lines))
 
 
-def conv_algorithmic_bytes(B, H, W, wino_min_ci=128):
+MEM_KERNELS = {      # kernel-name prefix -> class of the memory-bound report (per-launch counter traffic next to the event times)
+    'sgd_kernel': 'sgd', 'prop_kernel': 'propagate', 'paint_kernel': 'paint', 'sp_hist_kernel': 'sp_preprocess',
+    'sp_order_kernel': 'sp_preprocess', 'sp_chunk_base_kernel': 'sp_preprocess', 'sp_place_kernel': 'sp_preprocess',
+    'sp_segments_kernel': 'sp_preprocess', 'sp_pool_up_fwd_kernel': 'sp_pool_up_fwd', 'sp_interp_matrix_kernel': 'interp_matrix',
+    'wino4_input_transform_kernel': 'winograd_transform', 'wino4_output_transform_kernel': 'winograd_transform',
+    'wino_input_transform_kernel': 'winograd_transform', 'wino_output_transform_kernel': 'winograd_transform',
+    'wino4_outgrad_transform_kernel': 'winograd_outgrad_transform', 'upsample_bwd_cell_kernel': 'upsample_bwd',
+    'maxpool_bwd_kernel': 'maxpool_bwd'}
+
+
+def memory_bound_classes(out_dir):
+    """Counter HBM bytes per LAUNCH ((2*FETCH + WRITE) * 1024) of the memory-bound kernel classes in the bench passes."""
+    fetch = read_pass(os.path.join(out_dir, 'pmc_bench_fetch'))
+    write = read_pass(os.path.join(out_dir, 'pmc_bench_write'))
+    acc = {}
+    for rows, key in ((fetch, 'fetch_kib'), (write, 'write_kib')):
+        for _, kern, ctr, v in rows:
+            name = re.sub(r'^void ', '', kern).split('(')[0].split('<')[0]
+            c = MEM_KERNELS.get(name)
+            if c:
+                e = acc.setdefault(c, {'fetch_kib': 0.0, 'write_kib': 0.0, 'n_fetch_kib': 0, 'n_write_kib': 0})
+                e[key] += v
+                e['n_' + key] += 1
+    out = {}
+    for c, e in acc.items():
+        if e['n_fetch_kib'] and e['n_write_kib']:
+            out[c] = {'launches_counted': e['n_fetch_kib'],
+                      'hbm_bytes_per_launch': (2.0 * e['fetch_kib'] / e['n_fetch_kib'] + e['write_kib'] / e['n_write_kib']) * 1024.0}
+    return out
+
+
+def conv_algorithmic_bytes(B, H, W, wino_min_ci=128, m=4):
     """Mean algorithmic HBM bytes per GEMM launch of the two conv kernel classes over one step: every operand read once,
     every result written once.  Direct layers (below wino_min_ci input channels) -- fwd: x, w, y; dgrad: dy, w, mask +
-    old dx + new dx; wgrad: x, dy, dw.  Winograd-domain layers -- the GEMM launch reads the transformed input (16 x
-    tiles x Cin), the transformed filter (16 x Cin x Cout) and writes the transformed output (16 x tiles x Cout); the
-    wgrad launch reads both transformed tensors and writes 16 filter-gradient slabs."""
+    old dx + new dx; wgrad: x, dy, dw.  Winograd-domain layers (F(m x m,3x3), P = (m+2)^2 positions) -- the GEMM launch
+    reads the transformed input (P x tiles x Cin), the transformed filter (P x Cin x Cout) and writes the transformed
+    output (P x tiles x Cout); the wgrad launch reads both transformed tensors and writes P filter-gradient slabs."""
     ch = [(3, 64), (64, 64), (64, 128), (128, 128), (128, 256), (256, 256), (256, 256), (256, 512), (512, 512), (512, 512),
           (512, 512), (512, 512), (512, 512)]
     pool = [False, True, False, True, False, False, True, False, False, True, False, False, False]
@@ -139,10 +172,10 @@ def conv_algorithmic_bytes(B, H, W, wino_min_ci=128):
         px = B * h * w
         cin = 4 if l == 0 else ci
         if ci >= wino_min_ci:
-            T = B * ((h + 1) // 2) * ((w + 1) // 2)
-            nt += 2 * 4.0 * 16 * (T * ci + ci * co + T * co)          # fwd and dgrad launches
+            T, P = B * ((h + m - 1) // m) * ((w + m - 1) // m), (m + 2) ** 2
+            nt += 2 * 4.0 * P * (T * ci + ci * co + T * co)           # fwd and dgrad launches
             n_nt += 2
-            tn += 4.0 * 16 * (T * ci + T * co + ci * co)
+            tn += 4.0 * P * (T * ci + T * co + ci * co)
             n_tn += 1
         else:
             nt += 4.0 * (px * cin + 9 * cin * co + px * co)

@@ -1404,9 +1404,13 @@ extern "C" int wesup_conv3x3_wgrad_winograd(const float* x, const float* v_pre, 
         return rc;
     }
     const TnPlan pl = plan_tn(Cout, Ci, (int)T, 1, P);
-    char* ows = (char*)slab + align_up((size_t)P * pl.S * tn_slab_stride(Cout, pl.Nslab) * sizeof(float), 256);
-    if ((rc = wesup_winograd_outgrad_transform(dy, dM, m == 4 ? db : nullptr, B, H, W, Cout, m, ows,
-                                               wesup_winograd_outgrad_workspace_bytes(B, H, W, Cout, m), stream)))
+    // bias gradient: m = 2 from the TN GEMM (column sums of position (1,1)); m = 4 as per-block rows of the outgrad transform
+    // that the filter-gradient reduce folds (or, for channel counts the block sum does not cover, a column sum of dy)
+    float* ows = (float*)((char*)slab + align_up((size_t)P * pl.S * tn_slab_stride(Cout, pl.Nslab) * sizeof(float), 256));
+    const int bias_rows = (m == 4 && db) ? (int)wino4_bias_rows(B, H, W, Cout) : 0;
+    if ((rc = wino_outgrad_launch(dy, dM, bias_rows ? ows : nullptr, B, H, W, Cout, m, stream))) return rc;
+    if (m == 4 && db && !bias_rows &&
+        (rc = wesup_colsum(dy, Cout, db, B * H * W, Cout, ows, wesup_colsum_workspace_bytes(B * H * W, Cout), stream)))
         return rc;
     TnParams p = {};
     p.A = dM; p.Bx = V; p.slab = slab; p.M = Cout; p.N = Ci; p.K = (int)T; p.lda = Cout; p.ldb = Ci;
@@ -1414,8 +1418,8 @@ extern "C" int wesup_conv3x3_wgrad_winograd(const float* x, const float* v_pre, 
     p.slab_stride = (long)tn_slab_stride(Cout, pl.Nslab); p.want_colsum = (db != nullptr && m == 2); p.colsum_batch = 5;
     p.batchA = T * Cout; p.batchB = T * Ci; p.batch_slab = (long)pl.S * p.slab_stride;
     if ((rc = launch_tn<3>(p, pl, st, P))) return rc;
-    return wesup_winograd_filter_grad(slab, p.slab_stride, p.batch_slab, pl.S, dw_kcrs, m == 2 ? db : nullptr, Cout, Ci, m,
-                                      stream);
+    return wino_filter_grad_launch(slab, p.slab_stride, p.batch_slab, pl.S, dw_kcrs, (m == 2 || bias_rows) ? db : nullptr, Cout,
+                                   Ci, m, bias_rows ? ows : nullptr, bias_rows, stream);
 }
 
 // workspace of one forward / dgrad call: [V: P T Cin][M: P T Cout] (for dgrad ask with the channel counts swapped)

@@ -112,10 +112,8 @@ __global__ __launch_bounds__(256) void wino_outgrad_transform_kernel(const float
 #undef F4
 
 // dw[co][ci][3][3] = G^T (sum_s slab[p][s][co][ci]) G ;  db[co] (F(2x2) only) = sum_s (column sums of dM at position (1,1))
-// NP = m + 2.  block = PB (co, ci) pairs x NP^2 positions (16 x 16 for m = 2, 7 x 36 for m = 4): a thread adds the S
-// split-K slabs of ONE position (a thread per pair walked NP^2 x S dependent loads -- 512 at conv2_2 -- with only
-// Co*Ci/256 blocks on the chip: 113 us per launch on average, 1.1 ms per step); the sums of a pair meet in LDS and one
-// thread per pair applies G^T (.) G.  Fixed order.
+// NP = m + 2.  (A thread per pair walked NP^2 x S dependent loads -- 512 at conv2_2 -- with only Co*Ci/256 blocks on the
+// chip: 113 us per launch on average, 1.1 ms per step; hence a thread per (pair, position group).)  Fixed order.
 template <int NP>
 __device__ __forceinline__ void wino_gt(const float (&u)[NP], float (&r)[3]) {      // one row of G^T (.)
     if constexpr (NP == 4) {
@@ -130,26 +128,56 @@ __device__ __forceinline__ void wino_gt(const float (&u)[NP], float (&r)[3]) {  
         r[2] = (8.f / 27.f) * (s34 - s12) + u[5];
     }
 }
+// block = 64 (co, ci) pairs x all NP^2 positions: thread t adds the S split-K slabs of pair t & 63 at the positions
+// t >> 6, (t >> 6) + 4, ... -- every load instruction of a wave reads 256 consecutive bytes of one slab (with 7 pairs per
+// block, as many as fit one thread per (pair, position) at 36 positions, the rows were 28 bytes: 65 us per launch, 0.65 ms
+// per step); the sums of a pair meet in LDS and 64 threads apply G^T (.) G.
+// Bias gradient, in the blocks behind the pair blocks: F(2x2) from the column sums stored behind each slab of position
+// (1,1); F(4x4) from the per-block rows wino4_outgrad_transform_kernel left (bias_part [bias_rows][Co]): a block takes 16
+// channels, 64 row groups of 4 lanes each walk the rows, LDS folds the groups in a fixed order.
 template <int NP>
 __global__ __launch_bounds__(256) void wino_wgrad_reduce_kernel(const float* __restrict__ slab, long stride, long batch_slab,
                                                                 float* __restrict__ dw, int Co, int Ci, int S,
-                                                                float* __restrict__ db, int pair_blocks) {
-    constexpr int P = NP * NP, PB = 256 / P;
-    __shared__ float us[P][PB + 1];
+                                                                float* __restrict__ db, int pair_blocks,
+                                                                const float* __restrict__ bias_part, int bias_rows) {
+    constexpr int P = NP * NP, PB = 64;
+    __shared__ __attribute__((aligned(16))) float us[P][PB + 1];
     const int tid = threadIdx.x;
-    if ((int)blockIdx.x >= pair_blocks) {                // bias gradient: the blocks behind the pair blocks
-        const long m = (long)(blockIdx.x - pair_blocks) * 256 + tid;
-        if (db && m < Co) {
+    if ((int)blockIdx.x >= pair_blocks) {                // bias gradient
+        const int bb = blockIdx.x - pair_blocks;
+        if (!db) return;
+        if (bias_part) {
+            float4* sh = reinterpret_cast<float4*>(&us[0][0]);       // 256 float4 = 4 KiB <= sizeof(us)
+            const int cq = tid & 3, rg = tid >> 2, c = 16 * bb + 4 * cq;
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (c < Co)
+                for (int r = rg; r < bias_rows; r += 64) {
+                    const float4 v = ld4(bias_part + (long)r * Co + c);
+                    acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+                }
+            sh[tid] = acc;
+            __syncthreads();
+            if (tid < 4 && c < Co) {
+                for (int k = 1; k < 64; ++k) {
+                    const float4 v = sh[4 * k + tid];
+                    acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+                }
+                st4(db + c, acc);
+            }
+            return;
+        }
+        const long m = (long)bb * 256 + tid;
+        if (m < Co) {
             float s = 0.f;
             for (int k = 0; k < S; ++k) s += slab[(NP + 1) * batch_slab + (long)k * stride + (long)Co * Ci + m];
             db[m] = s;
         }
         return;
     }
-    const int i = tid % PB, p = tid / PB;
+    const int i = tid & (PB - 1);
     const long idx = (long)blockIdx.x * PB + i;
     const bool ok = idx < (long)Co * Ci;
-    if (p < P) {
+    for (int p = tid >> 6; p < P; p += 4) {
         float s0 = 0.f, s1 = 0.f;
         if (ok) {
             const float* src = slab + p * batch_slab + idx;
@@ -605,11 +633,24 @@ extern "C" int wesup_winograd_output_transform(const float* Mt, long plane_elems
 // db (optional, m = 4 only, [C]): the bias gradient sum_pixels dy, from the values the transform loads anyway (m = 2 takes it
 // from the TN GEMM: the column sums of position (1,1)).  Workspace: per-block partial sums + wesup_colsum's own.
 static bool wino4_block_colsum_ok(int C) { const int Q = C / 4; return Q <= 256 && 256 % Q == 0; }
+static long wino_transform_blocks(int B, int H, int W, int C, int m) { return ceil_div(wino_tiles(B, H, W, m) * (C / 4), 256l); }
+// internal (winograd.hpp): rows of per-block column sums the F(4x4) outgrad transform leaves for a bias gradient
+long wino4_bias_rows(int B, int H, int W, int C) { return wino4_block_colsum_ok(C) ? wino_transform_blocks(B, H, W, C, 4) : 0; }
+
 extern "C" size_t wesup_winograd_outgrad_workspace_bytes(int B, int H, int W, int C, int m) {
     if (m != 4 || !wino_shape_ok(B, H, W, C, C, m)) return 0;
     if (!wino4_block_colsum_ok(C)) return wesup_colsum_workspace_bytes(B * H * W, C);
-    const long blocks = ceil_div(wino_tiles(B, H, W, m) * (C / 4), 256l);
+    const long blocks = wino_transform_blocks(B, H, W, C, m);
     return align_up((size_t)blocks * C * sizeof(float), 256) + wesup_colsum_workspace_bytes((int)blocks, C);
+}
+// internal (winograd.hpp): the transform with the per-block sums written to bias_part ([wino4_bias_rows][C], m = 4) or not
+int wino_outgrad_launch(const float* dy, float* dM, float* bias_part, int B, int H, int W, int C, int m, void* stream) {
+    const WinoGeom g = wino_geom(B, H, W, C, m);
+    const dim3 grid((unsigned)wino_transform_blocks(B, H, W, C, m));
+    if (m == 2) hipLaunchKernelGGL(wino_outgrad_transform_kernel, grid, dim3(256), 0, (hipStream_t)stream, dy, dM, g);
+    else hipLaunchKernelGGL(wino4_outgrad_transform_kernel, grid, dim3(256), 0, (hipStream_t)stream, dy, dM, g, bias_part);
+    WESUP_CHECK_LAUNCH();
+    return WESUP_OK;
 }
 extern "C" int wesup_winograd_outgrad_transform(const float* dy, float* dM, float* db, int B, int H, int W, int C, int m,
                                                 void* ws, size_t ws_bytes, void* stream) {
@@ -617,23 +658,31 @@ extern "C" int wesup_winograd_outgrad_transform(const float* dy, float* dM, floa
         return WESUP_ERR_INVALID;
     if (db && m != 4) return WESUP_ERR_INVALID;
     if (db && (!ws || ws_bytes < wesup_winograd_outgrad_workspace_bytes(B, H, W, C, m))) return WESUP_ERR_WORKSPACE;
-    const WinoGeom g = wino_geom(B, H, W, C, m);
-    const long blocks = ceil_div(g.T * (C / 4), 256l);
-    const dim3 grid((unsigned)blocks);
-    if (m == 2) {
-        hipLaunchKernelGGL(wino_outgrad_transform_kernel, grid, dim3(256), 0, (hipStream_t)stream, dy, dM, g);
-        WESUP_CHECK_LAUNCH();
-        return WESUP_OK;
-    }
     const bool in_kernel = db && wino4_block_colsum_ok(C);
-    float* part = in_kernel ? (float*)ws : nullptr;
-    hipLaunchKernelGGL(wino4_outgrad_transform_kernel, grid, dim3(256), 0, (hipStream_t)stream, dy, dM, g, part);
-    WESUP_CHECK_LAUNCH();
+    int rc = wino_outgrad_launch(dy, dM, in_kernel ? (float*)ws : nullptr, B, H, W, C, m, stream);
+    if (rc) return rc;
     if (in_kernel) {
+        const long blocks = wino_transform_blocks(B, H, W, C, m);
         const size_t pb = align_up((size_t)blocks * C * sizeof(float), 256);
-        return wesup_colsum(part, C, db, (int)blocks, C, (char*)ws + pb, ws_bytes - pb, stream);
+        return wesup_colsum((const float*)ws, C, db, (int)blocks, C, (char*)ws + pb, ws_bytes - pb, stream);
     }
     if (db) return wesup_colsum(dy, C, db, B * H * W, C, ws, ws_bytes, stream);
+    return WESUP_OK;
+}
+// internal (winograd.hpp): wesup_winograd_filter_grad with the F(4x4) bias rows of wino_outgrad_launch
+int wino_filter_grad_launch(const float* slabs, long slab_stride, long batch_stride, int S, float* dw_kcrs, float* db, int Cout,
+                            int Cin, int m, const float* bias_part, int bias_rows, void* stream) {
+    const long tot = (long)Cout * Cin;
+    const int pair_blocks = (int)((tot + 63) / 64);
+    const int bias_blocks = !db ? 0 : bias_part ? (Cout + 15) / 16 : (Cout + 255) / 256;
+    const dim3 grid((unsigned)(pair_blocks + bias_blocks));
+    if (m == 2)
+        hipLaunchKernelGGL(wino_wgrad_reduce_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, slabs, slab_stride,
+                           batch_stride, dw_kcrs, Cout, Cin, S, db, pair_blocks, (const float*)nullptr, 0);
+    else
+        hipLaunchKernelGGL(wino_wgrad_reduce_kernel<6>, grid, dim3(256), 0, (hipStream_t)stream, slabs, slab_stride,
+                           batch_stride, dw_kcrs, Cout, Cin, S, db, pair_blocks, bias_part, bias_rows);
+    WESUP_CHECK_LAUNCH();
     return WESUP_OK;
 }
 // slabs [P][S][Cout*Cin + Cout] (split-K partial products of dU_p, each followed by Cout column sums of dM_p) ->
@@ -644,16 +693,5 @@ extern "C" int wesup_winograd_filter_grad(const float* slabs, long slab_stride, 
     if (!slabs || !dw_kcrs || S <= 0 || Cout <= 0 || Cin <= 0 || slab_stride < (long)Cout * Cin + Cout ||
         batch_stride < (long)S * slab_stride || !wino_m_ok(m) || (db && m != 2))
         return WESUP_ERR_INVALID;
-    const long tot = (long)Cout * Cin;
-    const int pb = 256 / wino_positions(m);
-    const int pair_blocks = (int)((tot + pb - 1) / pb);
-    const dim3 grid((unsigned)(pair_blocks + (Cout + 255) / 256));
-    if (m == 2)
-        hipLaunchKernelGGL(wino_wgrad_reduce_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, slabs, slab_stride,
-                           batch_stride, dw_kcrs, Cout, Cin, S, db, pair_blocks);
-    else
-        hipLaunchKernelGGL(wino_wgrad_reduce_kernel<6>, grid, dim3(256), 0, (hipStream_t)stream, slabs, slab_stride,
-                           batch_stride, dw_kcrs, Cout, Cin, S, db, pair_blocks);
-    WESUP_CHECK_LAUNCH();
-    return WESUP_OK;
+    return wino_filter_grad_launch(slabs, slab_stride, batch_stride, S, dw_kcrs, db, Cout, Cin, m, nullptr, 0, stream);
 }

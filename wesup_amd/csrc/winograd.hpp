@@ -13,3 +13,10 @@ static inline bool wino_shape_ok(int B, int H, int W, int Ci, int Cout, int m) {
     // thread index and the FastDiv range (n * d < 2^40, quotient < 2^24)
     return T < (1l << 24) && T * (cmax / 4) < (1l << 31) && T * (cmax / 4) * (cmax / 4) < (1l << 40);
 }
+
+// internal entry points of winograd.hip used by the weight-gradient pass in gemm.hip (not part of the C ABI): the F(4x4)
+// bias gradient travels as per-block rows from the outgrad transform to the filter-gradient reduce, with no launch of its own
+long wino4_bias_rows(int B, int H, int W, int C);          // 0: C / 4 does not divide 256 (use wesup_colsum on dy instead)
+int wino_outgrad_launch(const float* dy, float* dM, float* bias_part, int B, int H, int W, int C, int m, void* stream);
+int wino_filter_grad_launch(const float* slabs, long slab_stride, long batch_stride, int S, float* dw_kcrs, float* db, int Cout,
+                            int Cin, int m, const float* bias_part, int bias_rows, void* stream);

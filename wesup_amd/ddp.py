@@ -25,21 +25,47 @@ class GradAllReducer:
         self.lo = self.hi = None
         self.launched = []           # (lo, hi) ranges, for tests
         self.force = False           # also all-reduce with a single rank (exercises the RCCL path)
+        self._pending_stream = None  # the stream whose work completes the pending range (GPU only)
+        # measurement (bench.py): per bucket an event at its launch, an event pair around the waits of finish()
+        self.profile = False
+        self.t_backward = None       # event recorded by the trainer in front of backward()
+        self._marks, self._finish_marks = [], None
+        self._mark_history = []      # (t_backward, bucket marks, finish marks) of the profiled iterations not yet collected
 
     def _flush(self):
         if self.lo is None:
             return
+        if self.flat.is_cuda and self._pending_stream is not None and \
+                self._pending_stream != torch.cuda.current_stream(self.flat.device):
+            with torch.cuda.stream(self._pending_stream):      # behind the stream that produced the range
+                return self._flush()
         seg = self.flat[self.lo:self.hi]
+        if self.profile and self.flat.is_cuda:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()              # on the stream the collective is ordered behind
+            self._marks.append((ev, (self.hi - self.lo) * 4))
         if dist.is_initialized() and (dist.get_world_size(self.group) > 1 or self.force):
             self.works.append(dist.all_reduce(seg, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
         self.launched.append((self.lo, self.hi))
         self.lo = self.hi = None
+        self._pending_stream = None
 
     def ready(self, names):
         """Called by the engine when the gradients of ``names`` are complete.  Backward finishes the flat buffer from
         its end towards its start, so within one call the names are taken in descending offset order: (weight, bias)
         pairs then extend the pending range downwards instead of looking non-adjacent and forcing a flush per layer
-        (28 small all-reduces and ~1 ms of host time per step instead of 6 buckets)."""
+        (28 small all-reduces and ~1 ms of host time per step instead of 6 buckets).
+
+        Streams: the engine reports a range from the stream that produced it (head and backbone weight gradients: the
+        wgrad stream; side convs: the side stream), and an asynchronous collective is ordered behind the stream that is
+        current when it is launched.  So a bucket never mixes streams: when a call arrives on another stream than the one
+        the pending range was reported on, that range is launched first, behind ITS stream (no stream waits for another:
+        a cross-stream wait here would park the side branch behind the wgrad stream's queue in the middle of backward)."""
+        if self.flat.is_cuda:
+            cur = torch.cuda.current_stream(self.flat.device)
+            if self.lo is not None and self._pending_stream is not None and self._pending_stream != cur:
+                self._flush()
+            self._pending_stream = cur
         for n in sorted(names, key=lambda k: -self.off[k]):
             lo, hi = self.off[n], self.off[n] + self.size[n]
             if self.lo is None:
@@ -66,14 +92,48 @@ class GradAllReducer:
         self.works = []
         self.lo = self.hi = None
         self.launched = []
+        self._pending_stream = None
+        self._stash_marks()
+
+    def _stash_marks(self):
+        if self._marks or self._finish_marks is not None:
+            self._mark_history.append((self.t_backward, self._marks, self._finish_marks))
+        self._marks, self._finish_marks, self.t_backward = [], None, None
 
     def finish(self):
+        """Launch what is pending and make the current stream wait for every bucket (the host does not block: an NCCL
+        work's wait() orders the current stream behind the collective)."""
         self._flush()
+        prof = self.profile and self.flat.is_cuda
+        if prof:
+            e0 = torch.cuda.Event(enable_timing=True)
+            e0.record()              # behind the last backward kernel of the current stream
         for w in self.works:
             w.wait()
+        if prof:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()              # behind the last collective: e0 -> e1 is what backward did not hide
+            self._finish_marks = (e0, e1)
         self.works = []
         done, self.launched = self.launched, []
         return done
+
+    def collect_stats(self):
+        """After a device sync: the events of the profiled iterations since the last call as one dict per iteration --
+        bucket sizes, their launch offsets from the start of backward (ms), the time backward took on the caller's stream
+        and the exposed tail of finish() (ms): what the all-reduces added behind backward."""
+        self._stash_marks()
+        out = []
+        for t0, marks, fin in self._mark_history:
+            st = {'bucket_bytes': [b for _, b in marks],
+                  'launch_offset_ms': [round(t0.elapsed_time(ev), 3) for ev, _ in marks] if t0 is not None else None}
+            if fin is not None:
+                st['exposed_ms'] = round(fin[0].elapsed_time(fin[1]), 4)
+                if t0 is not None:
+                    st['backward_ms'] = round(t0.elapsed_time(fin[0]), 3)
+            out.append(st)
+        self._mark_history = []
+        return out
 
 
 def attach(model, group=None, bucket_bytes=16 << 20):

@@ -546,7 +546,6 @@ class WesupEngine:
         # ---- side branches (side stream), deepest layer first: ds_l, side-conv wgrad, side-conv dgrad -> G_l.
         # g_ready[l] marks "G_l holds the side-branch gradient"; the main chain accumulates into it afterwards.
         g_ready = [None] * 13
-        side_names = []
         # The gather-style upsample backward of the shallow layers only needs gsp.  Queued in layer order on the side
         # stream it sat between the side GEMMs of layers 7..1 and the dgrad chain waited for it (~0.75 ms with no MFMA
         # kernel in flight); on a stream of its own it runs under the deep layers' GEMMs.
@@ -607,7 +606,9 @@ class WesupEngine:
                 ops.gemm_tn(ds2d, y2d, out=g[f'side_conv{off}.weight'].view(co // 2, co), ws_tag='side',
                             colsum=g[f'side_conv{off}.bias'])
                 T.end(tok, (4.0 if l >= lowest else 2.0) * P * co * (co // 2))
-                side_names += [f'side_conv{off}.weight', f'side_conv{off}.bias']
+                # reported from the side stream, layer by layer (the reducer orders a bucket behind every stream that
+                # contributed to it): the side-conv gradients leave with the head's bucket instead of after the final join
+                ready([f'side_conv{off}.weight', f'side_conv{off}.bias'])
         # ---- main path, conv5_3 down to conv1_1.  The dgrad chain stays on the caller's stream; each layer's wgrad
         # (which only produces parameter gradients) goes to a third stream so that it fills the tails of the dgrad
         # kernels instead of sitting on the critical path.
@@ -664,5 +665,4 @@ class WesupEngine:
         if wg is not None:
             main.wait_stream(wg)
         self._join_side()
-        ready(side_names)
         self.ctx = None

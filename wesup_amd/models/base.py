@@ -188,6 +188,9 @@ class BaseTrainer(ABC):
                 # buffers have been written by then.
                 flag = self._loss_flag(loss) if (self.reducer is not None and self.world_size > 1) else None
                 pending = self._stage_read_back(loss, metrics, seg, flag)
+                if self.reducer is not None and self.reducer.profile:
+                    self.reducer.t_backward = torch.cuda.Event(enable_timing=True)
+                    self.reducer.t_backward.record()
                 loss.backward()
                 if self.reducer is not None:
                     self.reducer.finish()

@@ -41,6 +41,25 @@ def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+# Optional HIP-event timing of the kernel classes that are launched outside the engine's schedule (superpixel
+# preprocessing, label propagation + loss, SGD): bench.py hands the engine's KernelTimer over; None = no events.
+_timer = None
+
+
+def set_timer(timer):
+    global _timer
+    _timer = timer
+
+
+def _tbegin(tag):
+    return _timer.begin(tag) if _timer is not None else None
+
+
+def _tend(tok, work):
+    if tok is not None:
+        _timer.end(tok, work)
+
+
 def _chk(t, dtype=torch.float32, name='tensor'):
     if not isinstance(t, torch.Tensor) or not t.is_cuda:
         raise _lib.WesupHipError(f'{name}: expected a CUDA/HIP tensor (the HIP path has no CPU fallback)')
@@ -627,6 +646,7 @@ def sp_preprocess(labels, mask, Kmax, n_classes=2, n_sp_host=None):
     m.pix_sorted = torch.empty(B, HW, **i32); m.status = torch.empty(B, **i32)
     nb = _lib.load().wesup_sp_preprocess_workspace_bytes(B, HW, C, Kmax)
     ws = workspace(nb, dev, 'sp')
+    tok = _tbegin('sp_preprocess')
     _lib.call('wesup_sp_preprocess', _p(labels), _p(mask), B, HW, C, Kmax, _p(m.n_sp), _p(m.n_l), _p(m.perm),
               _p(m.inv_perm), _p(m.area_new), _p(m.sp_labels), _p(m.new_row), _p(m.row_start), _p(m.pix_sorted),
               _p(m.status), _p(ws), nb, _stream())
@@ -635,6 +655,8 @@ def sp_preprocess(labels, mask, Kmax, n_classes=2, n_sp_host=None):
     m.seg_start = torch.empty(B, Kmax + 1, **i32)
     m.unit_row = torch.empty(B, m.Umax, **i32)
     _lib.call('wesup_sp_segments', _p(m.row_start), B, int(Kmax), m.Umax, _p(m.seg_start), _p(m.unit_row), _stream())
+    # algorithmic bytes: the label map and the mask in, the row of every pixel and the row-sorted pixel list out
+    _tend(tok, float(B) * HW * (4 + (C if mask is not None else 0) + 4 + 4))
     return m
 
 
@@ -705,7 +727,9 @@ def paint_fwd(sp_pred, meta, cls=1, out=None):
     assert B == meta.B and Kmax == meta.Kmax
     if out is None:
         out = torch.empty(B, meta.H, meta.W, dtype=torch.float32, device=sp_pred.device)
+    tok = _tbegin('paint')
     _lib.call('wesup_paint_fwd', _p(sp_pred), _p(meta.new_row), _p(out), B, meta.H * meta.W, Kmax, C, cls, _stream())
+    _tend(tok, 8.0 * B * meta.H * meta.W + 4.0 * B * Kmax * C)
     return out
 
 
@@ -761,8 +785,10 @@ def propagate(feat, meta, threshold, enable=True):
     y_all = torch.empty(B, Kmax, meta.C, dtype=torch.float32, device=dev)
     src = torch.empty(B, Kmax, dtype=torch.int32, device=dev)
     sim = torch.empty(B, Kmax, dtype=torch.float32, device=dev)
+    tok = _tbegin('propagate')
     _lib.call('wesup_propagate', _p(feat), _p(meta.sp_labels), _p(meta.n_sp), _p(meta.n_l), float(threshold), int(enable),
               _p(y_all), _p(src), _p(sim), B, Kmax, D, meta.C, _stream())
+    _tend(tok, 4.0 * B * Kmax * (D + 2 * meta.C + 2))
     return y_all, src, sim
 
 
@@ -811,8 +837,10 @@ def sgd_step(p, g, v, lr, momentum, weight_decay, grad_scale, first_step):
     for t, n in ((p, 'p'), (g, 'g'), (v, 'v')):
         _chk(t, name=n)
     assert p.numel() == g.numel() == v.numel()
+    tok = _tbegin('sgd')
     _lib.call('wesup_sgd_step', _p(p), _p(g), _p(v), p.numel(), float(lr), float(momentum), float(weight_decay),
               float(grad_scale), int(first_step), _stream())
+    _tend(tok, 20.0 * p.numel())                     # read p, g, v; write p, v
 
 
 def seg_metrics(pred, mask):
