@@ -56,11 +56,13 @@ def parse_args(argv=None):
     ap.add_argument('--winograd-pipeline', action='store_true', help='A/B: Winograd-domain convs with the half-batch '
                                                                       'pipeline over a helper stream')
     ap.add_argument('--winograd-min-ci', type=int, default=0, help='A/B: input-channel count from which forward / input '
-                                                                    'gradient go through the Winograd domain (default: 128)')
+                                                                    'gradient go through the Winograd domain (default: 64)')
     ap.add_argument('--winograd-tile', type=int, default=0, choices=(0, 2, 4),
                     help='A/B: m of the Winograd F(m x m, 3x3) domain for the wide layers (default: the engine\'s, 4; 2 = round 2)')
     ap.add_argument('--direct-wgrad', action='store_true', help='A/B: every conv weight gradient with the direct '
                                                                 'implicit-GEMM kernel (no Winograd-domain wgrad)')
+    ap.add_argument('--chain-priority', type=int, default=0, help='experiment: run the step on a stream of this priority '
+                                                                  '(negative = higher than the side / wgrad streams)')
     ap.add_argument('--event-every', type=int, default=10, help='steps of the timed region that carry HIP events: every n-th')
     ap.add_argument('--timed-classes', default='conv3x3_fwd,conv3x3_dgrad,winograd_gemm,winograd_transform',
                     help="kernel classes that get HIP events inside the timed region ('all', 'none' or a comma list); an "
@@ -265,8 +267,13 @@ def worker(args):
         pool.append((torch.from_numpy(imgs).to(dev), torch.from_numpy(pix).to(dev), torch.from_numpy(pts).to(dev),
                      torch.from_numpy(labs).to(dev)))
 
+    chain = torch.cuda.Stream(device=dev, priority=args.chain_priority) if args.chain_priority else None
+
     def step(i):
-        trainer.train_one_iteration('train', *pool[i % len(pool)])
+        if chain is None:
+            return trainer.train_one_iteration('train', *pool[i % len(pool)])
+        with torch.cuda.stream(chain):
+            trainer.train_one_iteration('train', *pool[i % len(pool)])
 
     def barrier():
         if use_dist:
@@ -286,7 +293,9 @@ def worker(args):
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]      # one record per step: its end
     barrier()
     t0 = time.perf_counter()
-    marks[0].record()
+    if chain is not None:
+        chain.wait_stream(torch.cuda.current_stream())
+    marks[0].record(chain)
     for i in range(args.steps):
         # an event record fences its queue (events on the 25 conv launches of every step cost 3 % of the step, on every
         # kernel class 16 %): inside the timed region only every --event-every'th step carries events
@@ -295,7 +304,7 @@ def worker(args):
         if reducer is not None:                       # bucket launch offsets + exposed all-reduce tail of the same steps
             reducer.profile = (i % args.event_every == 0)
         step(i)
-        marks[i + 1].record()
+        marks[i + 1].record(chain)
     barrier()
     elapsed = time.perf_counter() - t0
     timer.enabled = False

@@ -140,6 +140,15 @@ int wesup_conv3x3_fwd_winograd(const float* x, const float* u_fwd, const float* 
 int wesup_conv3x3_dgrad_winograd(const float* dy, const float* u_dgrad, const float* mask_src, float* dx,
                                  int B, int H, int W, int Cin, int Cout, int accumulate, int m,
                                  void* ws, size_t ws_bytes, void* stream);
+/* The input gradient of a layer that FOLLOWS a max-pool, taken straight through the pooling's backward (autograd of
+ * ReLU -> MaxPool2d(2,2), models/wesup.py:199; m = 4 only): dy (B,H,W,Cout) at pooled resolution; nothing is written at
+ * that resolution -- every value is added to unpool_dst (B,Hu,Wu,Cin), the gradient w.r.t. the pre-pool activations
+ * unpool_src (same shape; H == Hu/2, W == Wu/2), at the FIRST maximum of its 2x2 window (torch's scan order) if that
+ * maximum is positive.  Same result as wesup_conv3x3_dgrad_winograd + wesup_maxpool2_bwd(accumulate = 1), which read and
+ * re-wrote all four positions of every window. */
+int wesup_conv3x3_dgrad_winograd_unpool(const float* dy, const float* u_dgrad, const float* unpool_src, float* unpool_dst,
+                                        int B, int H, int W, int Hu, int Wu, int Cin, int Cout, int m,
+                                        void* ws, size_t ws_bytes, void* stream);
 /* The three passes on their own (the two entries above chain them): x (B,H,W,C) -> V [P][tiles][C];
  * nbatch NT products of one shape in one launch, C_b = A_b . B_b^T (element strides between the entries; K % 32 == 0);
  * Mt [P][tiles][C] -> y = A^T M A + bias, masked by mask_src > 0, added to the old y if accumulate, with the optional
@@ -153,6 +162,10 @@ int wesup_gemm_nt_batched(const float* A, int lda, long strideA, const float* B,
 int wesup_winograd_output_transform(const float* Mt, long plane_elems, const float* bias, const float* mask_src, float* y,
                                     float* y_relu, float* y_pool, int pool_relu, int B, int H, int W, int C,
                                     int accumulate, int m, void* stream);
+/* ... with the max-pool backward as its epilogue (the last pass of wesup_conv3x3_dgrad_winograd_unpool; m = 4) */
+int wesup_winograd_output_transform_unpool(const float* Mt, long plane_elems, const float* bias, const float* mask_src,
+                                           const float* unpool_src, float* unpool_dst, int B, int H, int W, int Hu, int Wu,
+                                           int C, int m, void* stream);
 /* The weight gradient's own transforms: dy (B,H,W,C) -> dM [P][tiles][C] = A dY A^T per m x m tile; and the way back from
  * the split-K slabs of the P transformed filter gradients ([P][S][Cout*Cin + Cout], each slab followed by the Cout
  * column sums of its dM operand) to dw (Cout,Cin,3,3) = G^T (sum over S) G.  The bias gradient db = sum over pixels of dy:

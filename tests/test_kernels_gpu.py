@@ -370,6 +370,44 @@ def test_conv3x3_dgrad_winograd(ops, B, H, W, Cin, Cout, m):
     assert rel_err(nchw(out2), x2.grad) < wino_bar(m, TOL / 40)
 
 
+@pytest.mark.parametrize('B,Hu,Wu,Cin,Cout', [(2, 24, 16, 64, 128), (1, 37, 41, 128, 64), (3, 9, 8, 256, 256), (1, 2, 2, 32, 32),
+                                              (1, 120, 120, 128, 256)])
+def test_conv3x3_dgrad_winograd_through_the_maxpool_backward(ops, B, Hu, Wu, Cin, Cout):
+    """The input gradient of a layer behind a 2x2 max-pool with the pooling's backward as its epilogue equals the two
+    separate launches (Winograd input gradient at pooled resolution, then wesup_maxpool2_bwd accumulating into the side-
+    branch gradient): odd pre-pool sizes (the trailing row / column belongs to no window), ties (first maximum), windows
+    whose maximum is not positive (ReLU: no gradient)."""
+    d = dev()
+    H, W = Hu // 2, Wu // 2
+    ypre = rnd(B, Hu, Wu, Cin, seed=1)
+    ypre[0, 0:2, 0:2, :8] = 0.37                              # a four-way tie: the first position wins
+    if Wu >= 4:
+        ypre[0, 0:2, 2:4, :8] = -1.0                          # a dead window
+    w = rnd(Cout, Cin, 3, 3, seed=2, scale=(2.0 / (9 * Cin)) ** 0.5)
+    dy = nhwc(rnd(B, Cout, H, W, seed=4)).to(d)
+    base = rnd(B, Hu, Wu, Cin, seed=5)
+    _, ud = ops.winograd_pack_weight(w.to(d), need_fwd=False, m=4)
+    ypre_g = ypre.to(d)
+    fused = base.clone().to(d)
+    ops.conv3x3_dgrad_winograd_unpool(dy, ud, ypre_g, fused)
+    dxp = ops.conv3x3_dgrad_winograd(dy, ud, m=4)
+    two = base.clone().to(d)
+    ops.maxpool2_bwd(ypre_g, dxp, two, accumulate=True)
+    assert torch.equal(fused, two)
+    # and against autograd of relu -> max_pool2d -> conv on the CPU
+    yp = nchw(ypre).double().requires_grad_(True)
+    out = F.conv2d(F.max_pool2d(F.relu(yp), 2), w.double(), None, padding=1)
+    out.backward(nchw(dy.cpu()).double())
+    assert rel_err(nchw(fused.cpu() - base), yp.grad) < 2e-5
+    # the timed form (three bracketed passes) is the same computation
+    class _T:
+        def begin(self, tag): return tag
+        def end(self, tok, work): pass
+    again = base.clone().to(d)
+    ops.conv3x3_dgrad_winograd_unpool(dy, ud, ypre_g, again, timer=_T())
+    assert torch.equal(again, fused)
+
+
 @pytest.mark.parametrize('B,H,W,Cin,Cout', [c for c in CONV_CASES if c[3] != 3])
 def test_conv3x3_dgrad(ops, B, H, W, Cin, Cout):
     d = dev()

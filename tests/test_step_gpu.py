@@ -59,6 +59,7 @@ def test_step_matches_reference_golden(golden_dir, name, fused):
     fused = bool(fused)
     model.engine.fuse_pool_bwd = fused
     model.engine.fuse_pool_fwd = fused
+    model.engine.fuse_unpool = fused          # False: input gradient at pooled resolution + the separate max-pool backward
     img = torch.from_numpy(fx['img'])[None].to(d)
     seg = torch.from_numpy(fx['seg'].astype(np.int32))[None].to(d)
     mask = torch.from_numpy(fx['mask'].astype(np.uint8))[None].to(d)

@@ -157,7 +157,7 @@ def memory_bound_classes(out_dir):
     return out
 
 
-def conv_algorithmic_bytes(B, H, W, wino_min_ci=128, m=4):
+def conv_algorithmic_bytes(B, H, W, wino_min_ci=64, m=4):
     """Mean algorithmic HBM bytes per GEMM launch of the two conv kernel classes over one step: every operand read once,
     every result written once.  Direct layers (below wino_min_ci input channels) -- fwd: x, w, y; dgrad: dy, w, mask +
     old dx + new dx; wgrad: x, dy, dw.  Winograd-domain layers (F(m x m,3x3), P = (m+2)^2 positions) -- the GEMM launch

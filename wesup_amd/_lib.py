@@ -45,6 +45,8 @@ _SIGS = {
     'wesup_conv3x3_winograd_workspace_bytes': (c_size_t, 'iiiiii'),
     'wesup_conv3x3_fwd_winograd': (c_int, 'ppppppipiiiiiiipzp'),
     'wesup_conv3x3_dgrad_winograd': (c_int, 'ppppiiiiiiipzp'),
+    'wesup_conv3x3_dgrad_winograd_unpool': (c_int, 'ppppiiiiiiiipzp'),
+    'wesup_winograd_output_transform_unpool': (c_int, 'plppppiiiiiiip'),
     'wesup_winograd_input_transform': (c_int, 'ppliiiiiip'),
     'wesup_gemm_nt_batched': (c_int, 'pilpilpiliiiip'),
     'wesup_winograd_output_transform': (c_int, 'plpppppiiiiiiip'),

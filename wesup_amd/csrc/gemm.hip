@@ -1451,8 +1451,9 @@ extern "C" int wesup_gemm_nt_batched(const float* A, int lda, long strideA, cons
 // v_keep (optional): the transformed input is written there instead of the workspace (P T Cin floats).
 static int wino_conv(const float* in, const float* u, const float* bias, const float* mask, float* out, float* out_relu,
                      float* out_pool, int pool_relu, float* v_keep, int B, int H, int W, int Cin, int Cout, int relu_in,
-                     int accum, int m, void* ws, size_t ws_bytes, void* st) {
-    if (!in || !u || !out || !ws || !wino_shape_ok(B, H, W, Cin, Cout, m) || (Cin % 32) ||
+                     int accum, int m, void* ws, size_t ws_bytes, void* st, const float* unpool_src = nullptr,
+                     float* unpool_dst = nullptr, int Hu = 0, int Wu = 0) {
+    if (!in || !u || (!out && !unpool_src) || !ws || !wino_shape_ok(B, H, W, Cin, Cout, m) || (Cin % 32) ||
         (((uintptr_t)u | (uintptr_t)v_keep | (uintptr_t)ws) & 15))
         return WESUP_ERR_INVALID;
     if (ws_bytes < wesup_conv3x3_winograd_workspace_bytes(B, H, W, Cin, Cout, m)) return WESUP_ERR_WORKSPACE;
@@ -1464,6 +1465,8 @@ static int wino_conv(const float* in, const float* u, const float* bias, const f
     if (rc) return rc;
     rc = wesup_gemm_nt_batched(V, Cin, T * Cin, u, Cin, (long)Cout * Cin, Mt, Cout, T * Cout, P, (int)T, Cout, Cin, st);
     if (rc) return rc;
+    if (unpool_src)
+        return wesup_winograd_output_transform_unpool(Mt, 0, bias, mask, unpool_src, unpool_dst, B, H, W, Hu, Wu, Cout, m, st);
     return wesup_winograd_output_transform(Mt, 0, bias, mask, out, out_relu, out_pool, pool_relu, B, H, W, Cout, accum, m, st);
 }
 
@@ -1480,4 +1483,15 @@ extern "C" int wesup_conv3x3_dgrad_winograd(const float* dy, const float* u_dgra
                                             void* stream) {
     return wino_conv(dy, u_dgrad, nullptr, mask_src, dx, nullptr, nullptr, 0, nullptr, B, H, W, Cout, Cin, 0, accumulate, m,
                      ws, ws_bytes, stream);
+}
+
+// The input gradient of a layer that follows a max-pool, taken straight through the pooling's backward (m = 4): nothing is
+// written at pooled resolution; every value is added to unpool_dst (B,Hu,Wu,Cin) -- the gradient w.r.t. the pre-pool
+// activations unpool_src, which already holds the side-branch gradient -- at the first positive maximum of its window.
+extern "C" int wesup_conv3x3_dgrad_winograd_unpool(const float* dy, const float* u_dgrad, const float* unpool_src,
+                                                   float* unpool_dst, int B, int H, int W, int Hu, int Wu, int Cin, int Cout,
+                                                   int m, void* ws, size_t ws_bytes, void* stream) {
+    if (!unpool_src || !unpool_dst) return WESUP_ERR_INVALID;
+    return wino_conv(dy, u_dgrad, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, B, H, W, Cout, Cin, 0, 0, m, ws,
+                     ws_bytes, stream, unpool_src, unpool_dst, Hu, Wu);
 }

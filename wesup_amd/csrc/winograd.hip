@@ -460,12 +460,46 @@ __global__ __launch_bounds__(256) void wino4_outgrad_transform_kernel(const floa
     }
 }
 
+// The max-pool backward that follows an input gradient at pooled resolution (autograd of ReLU -> MaxPool2d(2,2),
+// models/wesup.py:199): the gradient v of pooled pixel (h, w) goes to the FIRST maximum of its 2x2 window of the pre-pool
+// activations (torch's scan order) if that maximum is positive, and is ADDED to what dst holds there (the side-branch
+// gradient).  Only the chosen position is touched: the separate kernel read and re-wrote all four.
+struct WinoUnpool {
+    const float* src;    // pre-pool activations (B, Hu, Wu, C), or NULL: no unpooling
+    float* dst;          // gradient w.r.t. them, same shape, accumulated into
+    int Hu, Wu;
+};
+__device__ __forceinline__ void wino_unpool_add(const WinoUnpool& u, int b, int h, int w, int C, int c0, float4 v) {
+    const long rs = (long)u.Wu * C;
+    const long o00 = (((long)b * u.Hu + 2 * h) * u.Wu + 2 * w) * C + c0;
+    const float4 a0 = ld4(u.src + o00), a1 = ld4(u.src + o00 + C), a2 = ld4(u.src + o00 + rs), a3 = ld4(u.src + o00 + rs + C);
+    auto pick = [](float p0, float p1, float p2, float p3) {
+        int best = 0;
+        float m = p0;
+        if (p1 > m) { m = p1; best = 1; }
+        if (p2 > m) { m = p2; best = 2; }
+        if (p3 > m) { m = p3; best = 3; }
+        return m > 0.f ? best : -1;
+    };
+    const int kx = pick(a0.x, a1.x, a2.x, a3.x), ky = pick(a0.y, a1.y, a2.y, a3.y), kz = pick(a0.z, a1.z, a2.z, a3.z),
+              kw = pick(a0.w, a1.w, a2.w, a3.w);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (kx != k && ky != k && kz != k && kw != k) continue;
+        float* d = u.dst + o00 + (k >> 1) * rs + (k & 1) * C;
+        float4 old = ld4(d);
+        old.x += kx == k ? v.x : 0.f; old.y += ky == k ? v.y : 0.f; old.z += kz == k ? v.z : 0.f; old.w += kw == k ? v.w : 0.f;
+        st4(d, old);
+    }
+}
+
 // thread = (tile, 4 channels): Y = A^T M A for the tile's 4x4 outputs, then the conv epilogue on the pixels inside the
 // image; a 4x4 output tile holds four windows of the 2x2 / stride-2 max-pool that may follow the layer
 __global__ __launch_bounds__(256) void wino4_output_transform_kernel(const float* __restrict__ Mt, const float* __restrict__ bias,
                                                                      const float* __restrict__ mask, float* __restrict__ y,
                                                                      float* __restrict__ y_relu, float* __restrict__ y_pool,
-                                                                     int pool_relu, const WinoGeom g, int accum) {
+                                                                     int pool_relu, const WinoGeom g, int accum,
+                                                                     const WinoUnpool up) {
     WinoTile q;
     if (!wino4_decode(g, q)) return;
     const float* src = Mt + (long)q.t * g.C + 4 * q.cq;
@@ -502,6 +536,10 @@ __global__ __launch_bounds__(256) void wino4_output_transform_kernel(const float
                     const float4 mk = ld4(mask + off);
                     v.x = mk.x > 0.f ? v.x : 0.f; v.y = mk.y > 0.f ? v.y : 0.f;
                     v.z = mk.z > 0.f ? v.z : 0.f; v.w = mk.w > 0.f ? v.w : 0.f;
+                }
+                if (up.src) {        // input gradient at pooled resolution: straight through the max-pool backward
+                    wino_unpool_add(up, q.b, h, w, g.C, 4 * q.cq, v);
+                    continue;
                 }
                 if (accum) v = f4add(v, ld4(y + off));
                 st4(y + off, v);
@@ -611,13 +649,17 @@ extern "C" int wesup_winograd_input_transform(const float* x, float* V, long pla
 // Mt [P][tiles][C] -> y (B,H,W,C) = A^T M A + bias, masked by mask_src > 0, added to the old y if accumulate;
 // y_relu: optional second output max(y, 0);  y_pool: optional third output (B,H/2,W/2,C) = the 2x2 / stride-2 max-pool
 // of y (an output tile is one pooling window for m = 2, four for m = 4), ReLU'd if pool_relu
-extern "C" int wesup_winograd_output_transform(const float* Mt, long plane_elems, const float* bias, const float* mask_src,
-                                               float* y, float* y_relu, float* y_pool, int pool_relu, int B, int H, int W,
-                                               int C, int accumulate, int m, void* stream) {
-    if (!Mt || !y || !wino_shape_ok(B, H, W, C, C, m) || (plane_elems % 4) ||
+static int wino_output_launch(const float* Mt, long plane_elems, const float* bias, const float* mask_src, float* y,
+                              float* y_relu, float* y_pool, int pool_relu, int B, int H, int W, int C, int accumulate, int m,
+                              const WinoUnpool& up, void* stream) {
+    if (!Mt || (!y && !up.src) || !wino_shape_ok(B, H, W, C, C, m) || (plane_elems % 4) ||
         (plane_elems > 0 && plane_elems < wino_tiles(B, H, W, m) * C) ||
-        (((uintptr_t)Mt | (uintptr_t)y | (uintptr_t)y_relu | (uintptr_t)y_pool | (uintptr_t)mask_src | (uintptr_t)bias) & 15))
+        (((uintptr_t)Mt | (uintptr_t)y | (uintptr_t)y_relu | (uintptr_t)y_pool | (uintptr_t)mask_src | (uintptr_t)bias |
+          (uintptr_t)up.src | (uintptr_t)up.dst) & 15))
         return WESUP_ERR_INVALID;
+    // the unpooling epilogue: F(4x4) only, in place of the plain store (no second / pooled output, no accumulate into y);
+    // the pooled map is floor(Hu / 2) x floor(Wu / 2)
+    if (up.src && (m != 4 || !up.dst || y_relu || y_pool || accumulate || up.Hu / 2 != H || up.Wu / 2 != W)) return WESUP_ERR_INVALID;
     const WinoGeom g = wino_geom(B, H, W, C, m, plane_elems);
     const dim3 grid((unsigned)ceil_div(g.T * (C / 4), 256l));
     if (m == 2)
@@ -625,9 +667,26 @@ extern "C" int wesup_winograd_output_transform(const float* Mt, long plane_elems
                            y_pool, pool_relu, g, accumulate);
     else
         hipLaunchKernelGGL(wino4_output_transform_kernel, grid, dim3(256), 0, (hipStream_t)stream, Mt, bias, mask_src, y, y_relu,
-                           y_pool, pool_relu, g, accumulate);
+                           y_pool, pool_relu, g, accumulate, up);
     WESUP_CHECK_LAUNCH();
     return WESUP_OK;
+}
+extern "C" int wesup_winograd_output_transform(const float* Mt, long plane_elems, const float* bias, const float* mask_src,
+                                               float* y, float* y_relu, float* y_pool, int pool_relu, int B, int H, int W,
+                                               int C, int accumulate, int m, void* stream) {
+    return wino_output_launch(Mt, plane_elems, bias, mask_src, y, y_relu, y_pool, pool_relu, B, H, W, C, accumulate, m,
+                              WinoUnpool{nullptr, nullptr, 0, 0}, stream);
+}
+// The same transform with the max-pool backward as its epilogue (m = 4): Mt -> the input gradient at pooled resolution
+// (B,H,W,C), each value added to unpool_dst (B,Hu,Wu,C) at the first positive maximum of its 2x2 window of unpool_src;
+// H == Hu / 2, W == Wu / 2.  Replaces wesup_winograd_output_transform + wesup_maxpool2_bwd(accumulate) for the layers
+// behind a pooling step; mask_src (optional) applies to the pooled-resolution gradient first.
+extern "C" int wesup_winograd_output_transform_unpool(const float* Mt, long plane_elems, const float* bias,
+                                                      const float* mask_src, const float* unpool_src, float* unpool_dst,
+                                                      int B, int H, int W, int Hu, int Wu, int C, int m, void* stream) {
+    if (!unpool_src || !unpool_dst) return WESUP_ERR_INVALID;
+    return wino_output_launch(Mt, plane_elems, bias, mask_src, nullptr, nullptr, nullptr, 0, B, H, W, C, 0, m,
+                              WinoUnpool{unpool_src, unpool_dst, Hu, Wu}, stream);
 }
 // dy (B,H,W,C) -> dM [P][tiles][C] = A dY A^T per m x m tile (the weight gradient's second operand).
 // db (optional, m = 4 only, [C]): the bias gradient sum_pixels dy, from the values the transform loads anyway (m = 2 takes it

@@ -84,9 +84,11 @@ class _Bufs:
 def default_route(ci, co, h, w, B):
     """The convolution algorithm of one 3x3 layer: 0 = implicit GEMM (direct form), 2 = Winograd F(2x2,3x3), 4 = Winograd
     F(4x4,3x3).  Measured per layer and pass at the three benchmark shapes (tools/wino_table.py; profiles/r03_wino_table_*.txt):
-    every layer with >= 128 input channels is fastest in the F(4x4) domain (1/4 of the direct form's multiply-adds, 2.25x
-    the activation bytes) down to 8x8-tile maps; with 64 input channels (conv1_2, conv2_1) the transformed tensors make
-    everything HBM-bound and the implicit-GEMM kernel wins; the image layer (3 channels) has no Winograd form."""
+    every layer with >= 64 input channels is fastest in the F(4x4) domain (1/4 of the direct form's multiply-adds, 2.25x
+    the activation bytes) at 480x480, 800x800 and 1024x1024, down to the 8x8-tile maps of conv5_x; F(2x2) (4/9 of the
+    multiply-adds, 4x the bytes) is slower than F(4x4) everywhere and slower than the direct kernel at 64 input channels.
+    Inside the step the two 64-channel layers (conv1_2, conv2_1: HBM-bound in the domain) gain 0.5 % at 480x480 and 2 % at
+    800x800 / 1024x1024 (bench.py --winograd-min-ci 128 for the A/B); the image layer (3 channels) has no Winograd form."""
     if ci < WesupEngine.WINOGRAD_CONV_MIN_CI:
         return 0
     return WesupEngine.WINOGRAD_TILE
@@ -98,9 +100,9 @@ class WesupEngine:
     # 128 -> 256 channels up, slower below (the transformed operands cannot be amortised by the 64/128-channel GEMMs)
     WINOGRAD_MIN_CI, WINOGRAD_MIN_CO = 128, 256
     # layers whose forward and input gradient go through the Winograd domain when conv_winograd is on: every layer
-    # with >= 128 input channels (conv2_2 ... conv5_3); the 3- and 64-channel layers stay on the implicit-GEMM kernel
-    # (their transformed tensors would be HBM-bound).  bench.py --winograd-min-ci / --winograd-tile for the A/B.
-    WINOGRAD_CONV_MIN_CI = 128
+    # with >= 64 input channels (conv1_2 ... conv5_3); the image layer stays on the implicit-GEMM kernel.
+    # bench.py --winograd-min-ci / --winograd-tile for the A/B.
+    WINOGRAD_CONV_MIN_CI = 64
     WINOGRAD_TILE = 4                    # m of F(m x m, 3x3) for those layers: 4 (default) or 2 (round 2's routing)
 
     def __init__(self, params, grads, D=32):
@@ -131,6 +133,9 @@ class WesupEngine:
         # domain the step is the sum of its kernels' times and the fusion wins a little (13.77 -> 13.70 ms, 3 A/B pairs)
         self.fuse_side_fwd = True
         self.relu_on_store = True        # ReLU'd copies written by the producing kernel instead of ReLU on every load
+        # the max-pool backward behind conv2_1 / conv3_1 / conv4_1 / conv5_1 as the epilogue of their F(4x4) input gradient:
+        # no gradient tensor at pooled resolution, one position of each window updated instead of four re-written
+        self.fuse_unpool = True
         self.route_fn = default_route    # (ci, co, h, w, B) -> 0 | 2 | 4, consulted per layer and shape
         self._route = None               # the 13 tile sizes of the current / most recent shape
         self._side_stream = None
@@ -646,8 +651,12 @@ class WesupEngine:
             if l > lowest:
                 if g_ready[l - 1] is not None:
                     main.wait_event(g_ready[l - 1])
+                unpooled = False
                 if b.wino_fwd[l]:
-                    if POOL_AFTER[l - 1]:
+                    if POOL_AFTER[l - 1] and self.fuse_unpool and b.wino_fwd[l] == 4:
+                        ops.conv3x3_dgrad_winograd_unpool(b.G[l], pk.ud[l], b.y[l - 1], b.G[l - 1], ws_tag='wino_main', timer=T)
+                        unpooled = True
+                    elif POOL_AFTER[l - 1]:
                         ops.conv3x3_dgrad_winograd(b.G[l], pk.ud[l], out=b.dxp[l - 1], ws_tag='wino_main', timer=T,
                                                    m=b.wino_fwd[l])
                     else:
@@ -660,7 +669,7 @@ class WesupEngine:
                     else:
                         ops.conv3x3_dgrad(b.G[l], pk.wd[l], ci, mask_src=b.y[l - 1], out=b.G[l - 1], accumulate=True)
                     T.end(tok, 2.0 * B * h * w * ci * co * 9)
-                if POOL_AFTER[l - 1]:
+                if POOL_AFTER[l - 1] and not unpooled:
                     ops.maxpool2_bwd(b.y[l - 1], b.dxp[l - 1], b.G[l - 1], accumulate=True)
         if wg is not None:
             main.wait_stream(wg)

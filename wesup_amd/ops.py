@@ -457,6 +457,44 @@ def conv3x3_dgrad_winograd(dy, u_dgrad, mask_src=None, out=None, accumulate=Fals
     return _winograd_conv(dy, u_dgrad, None, mask_src, out, None, None, False, accumulate, ws_tag, timer, m=m)
 
 
+def conv3x3_dgrad_winograd_unpool(dy, u_dgrad, unpool_src, unpool_dst, ws_tag='default', timer=None, m=4):
+    """Input gradient of a layer that follows a 2x2 max-pool, added straight into the gradient of the PRE-pool activations:
+    dy (B,H,W,Cout) at pooled resolution, unpool_src / unpool_dst (B,Hu,Wu,Cin) with H == Hu // 2, W == Wu // 2.  Equals
+    conv3x3_dgrad_winograd(out=dxp) followed by maxpool2_bwd(unpool_src, dxp, unpool_dst, accumulate=True)."""
+    _chk(dy, name='dy'); _chk(u_dgrad, name='u_dgrad'); _chk(unpool_src, name='unpool_src'); _chk(unpool_dst, name='unpool_dst')
+    B, H, W, Cout = dy.shape
+    Cin = u_dgrad.shape[1]
+    assert m == 4 and u_dgrad.shape == (winograd_positions(m), Cin, Cout)
+    _, Hu, Wu, _ = unpool_src.shape
+    assert unpool_src.shape == (B, Hu, Wu, Cin) == unpool_dst.shape and (Hu // 2, Wu // 2) == (H, W)
+    lib = _lib.load()
+    nb = lib.wesup_conv3x3_winograd_workspace_bytes(B, H, W, Cout, Cin, m)
+    if not nb:
+        raise _lib.WesupHipError(f'winograd dgrad: unsupported shape {(B, H, W, Cout, Cin, m)}')
+    ws = workspace(nb, dy.device, ws_tag)
+    if timer is None:
+        _lib.call('wesup_conv3x3_dgrad_winograd_unpool', _p(dy), _p(u_dgrad), _p(unpool_src), _p(unpool_dst), B, H, W, Hu, Wu,
+                  Cin, Cout, m, _p(ws), nb, _stream())
+        return unpool_dst
+    # the three passes bracketed as classes of their own, as in _winograd_conv
+    T, P = winograd_tiles(B, H, W, m), winograd_positions(m)
+    v_bytes = (P * T * Cout * 4 + 255) // 256 * 256
+    V, Mt = ws[:v_bytes], ws[v_bytes:]
+    st = _stream()
+    tok = timer.begin('winograd_transform')
+    _lib.call('wesup_winograd_input_transform', _p(dy), _p(V), 0, B, H, W, Cout, 0, m, st)
+    timer.end(tok, 4.0 * (B * H * W + P * T) * Cout)
+    tok = timer.begin('winograd_gemm')
+    _lib.call('wesup_gemm_nt_batched', _p(V), Cout, T * Cout, _p(u_dgrad), Cout, Cin * Cout, _p(Mt), Cin, T * Cin, P, T, Cin, Cout, st)
+    timer.end(tok, 2.0 * P * T * Cin * Cout)
+    tok = timer.begin('winograd_transform')
+    _lib.call('wesup_winograd_output_transform_unpool', _p(Mt), 0, None, None, _p(unpool_src), _p(unpool_dst), B, H, W, Hu, Wu,
+              Cin, m, st)
+    # bytes: the transformed gradient in, the windows of the pre-pool activations, one position of four read and re-written
+    timer.end(tok, 4.0 * (P * T + (4 + 2) * B * H * W) * Cin)
+    return unpool_dst
+
+
 def conv3x3_wgrad_winograd(x, dy, relu_in, dw=None, db=None, ws_tag='default', v_pre=None, m=2):
     """The same (dw, db) as conv3x3_wgrad through the Winograd F(m x m, 3x3) domain: 2.25x (m = 2) / 4x (m = 4) fewer
     multiply-adds, 4x / 2.25x the operand bytes; for the wide layers (Ci, Cout >= 128)."""
