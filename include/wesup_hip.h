@@ -63,8 +63,14 @@ int wesup_transpose(const float* in, float* out, int rows, int cols, void* strea
  * resized uint8 images: flips + shift/scale/rotate as ONE inverse affine map per image (bilinear image, nearest mask,
  * reflect-101 borders), HueSaturationValue, RandomBrightnessContrast, ToTensor.  params: 12 floats per image
  * {a00,a01,a02,a10,a11,a12 (output pixel -> source), alpha, beta, hue, sat, val, 0}.  mask_hw / out_mask may be NULL.
- * out_img fp32 [B][3][H][W] in [0,1]; out_mask uint8 one-hot [B][C][H][W] (class index 255 = no class). */
-int wesup_augment(const uint8_t* img_hwc, const uint8_t* mask_hw, const float* params, float* out_img_nchw,
+ * out_img fp32 [B][3][H][W] in [0,1]; out_mask uint8 one-hot [B][C][H][W] (class index 255 = no class).
+ * elastic_field (optional, NULL = none): ElasticTransform's displacement field (utils/data.py:124, albumentations
+ * ElasticTransform(alpha=1, sigma=50): gaussian_filter(U(-1,1), sigma) * alpha per axis), as a coarse grid [B][2][hc][wc]
+ * (dx plane, dy plane; one value per cell x cell pixels, already smoothed -- wesup_amd.utils.data.elastic_field), sampled
+ * bilinearly; elastic_params: 12 floats per image {e00,e01,e02,e10,e11,e12 (source grid -> the grid the field is defined
+ * on = the transform's own forward affine), l00,l01,l10,l11 (linear part of its inverse), on (0/1), 0}. */
+int wesup_augment(const uint8_t* img_hwc, const uint8_t* mask_hw, const float* params, const float* elastic_field,
+                  const float* elastic_params, int hc, int wc, int cell, float* out_img_nchw,
                   uint8_t* out_mask_chw, int B, int H, int W, int C, void* stream);
 /* Appearance transforms that need a neighbourhood, on the un-warped uint8 images and in the reference's order
  * (utils/data.py:119-125, 306-312): HueSaturationValue -> RandomBrightnessContrast -> CLAHE (8x8 tiles on the L channel

@@ -78,13 +78,56 @@ def hsv8_to_rgb(h, s, v):
     return np.stack([r, g, b], -1).astype(np.float32)
 
 
-def augment(img_u8, mask_u8, row, C=2):
-    """img (H,W,3) uint8, mask (H,W) uint8 class index (or None), row: 12 floats -> (img f32 (3,H,W), mask u8 (C,H,W))."""
+def gaussian_filter_reflect(a, sigma, truncate=4.0):
+    """scipy.ndimage.gaussian_filter(a, sigma) (mode='reflect', truncate=4) restated: separable, taps at integer offsets up to
+    int(truncate * sigma + 0.5), normalised, reflection about the edge of the border samples."""
+    r = int(truncate * sigma + 0.5)
+    k = np.exp(-0.5 * (np.arange(-r, r + 1) / sigma) ** 2)
+    k /= k.sum()
+    out = np.asarray(a, dtype=np.float64)
+    for axis in (0, 1):
+        n = out.shape[axis]
+        idx = np.arange(-r, n + r)
+        idx = np.mod(idx, 2 * n)
+        idx = np.where(idx < n, idx, 2 * n - 1 - idx)
+        padded = np.take(out, idx, axis=axis)
+        out = sum(wgt * np.take(padded, np.arange(o, o + n), axis=axis) for o, wgt in enumerate(k))
+    return out
+
+
+def elastic_displacement(field, cell, qx, qy):
+    """The coarse displacement grid (2, hc, wc) sampled bilinearly at pixel positions (qx, qy), as the kernel does: cell
+    centres sit at (i + 1/2) * cell - 1/2, positions outside the grid take the border value."""
+    _, hc, wc = field.shape
+    f32 = np.float32
+    inv = f32(1.0) / f32(cell)
+    u = np.clip((qx + f32(0.5)) * inv - f32(0.5), 0, wc - 1).astype(f32)
+    v = np.clip((qy + f32(0.5)) * inv - f32(0.5), 0, hc - 1).astype(f32)
+    u0, v0 = u.astype(np.int64), v.astype(np.int64)
+    u1, v1 = np.minimum(u0 + 1, wc - 1), np.minimum(v0 + 1, hc - 1)
+    wu, wv = u - u0.astype(f32), v - v0.astype(f32)
+    out = []
+    for f in field.astype(f32):
+        out.append((1 - wv) * ((1 - wu) * f[v0, u0] + wu * f[v0, u1]) + wv * ((1 - wu) * f[v1, u0] + wu * f[v1, u1]))
+    return out[0].astype(f32), out[1].astype(f32)
+
+
+def augment(img_u8, mask_u8, row, C=2, elastic=None):
+    """img (H,W,3) uint8, mask (H,W) uint8 class index (or None), row: 12 floats -> (img f32 (3,H,W), mask u8 (C,H,W)).
+    elastic = (field (2,hc,wc), params (12,), cell): ElasticTransform's displacement field (albumentations
+    functional.elastic_transform: the affinely warped image is re-sampled at (x + dx, y + dy)), placed by its 12 floats
+    {E (source grid -> field grid), L (linear part of E^-1), on}."""
     H, W = img_u8.shape[:2]
     a = row.astype(np.float32)
     y, x = np.meshgrid(np.arange(H, dtype=np.float32), np.arange(W, dtype=np.float32), indexing='ij')
     sx = a[0] * x + a[1] * y + a[2]
     sy = a[3] * x + a[4] * y + a[5]
+    if elastic is not None and elastic[1][10] != 0:
+        field, e, cell = elastic
+        e = e.astype(np.float32)
+        qx, qy = e[0] * sx + e[1] * sy + e[2], e[3] * sx + e[4] * sy + e[5]
+        dx, dy = elastic_displacement(field, cell, qx, qy)
+        sx, sy = sx + (e[6] * dx + e[7] * dy), sy + (e[8] * dx + e[9] * dy)
     fx, fy = np.floor(sx), np.floor(sy)
     wx, wy = (sx - fx)[..., None], (sy - fy)[..., None]
     x0, x1 = reflect101(fx.astype(np.int64), W), reflect101(fx.astype(np.int64) + 1, W)

@@ -162,7 +162,7 @@ def gpu_mlp_outputs(engine):
     return [t.detach().float().cpu().view(B, -1, t.shape[-1]) for t in (b.h1, b.h2, b.feats)]
 
 
-def check_gradients(model, weights, imgs, segs, masks, names=None, tol=1e-4, tie_tol=2e-5, **loss_kw):
+def check_gradients(model, weights, imgs, segs, masks, names=None, tol=1e-4, tie_tol=2e-5, case=None, **loss_kw):
     """Assert points 1 and 2 of the module docstring for the gradients the model holds after a backward pass.
     Returns (worst relative error, number of named disagreements)."""
     ys = gpu_preactivations(model.engine)
@@ -195,5 +195,10 @@ def check_gradients(model, weights, imgs, segs, masks, names=None, tol=1e-4, tie
         e_cpu = float((g32[k].double() - ref).abs().max()) / scale
         assert e_gpu < max(tol, 2 * e_cpu), (k, e_gpu, e_cpu, [(n['kind'], n['layer']) for n in named][:8])
         worst = max(worst, e_gpu)
+        if case is not None:
+            import _tol
+            _tol.within(case, 'gradients vs fp64 (GPU decisions)', e_gpu, max(tol, 2 * e_cpu),
+                        'max |g - g64| / max |g64| per parameter tensor; bar 1e-4, or 2x the error of torch CPU fp32 under the same decisions')
+            _tol.within(case, 'torch CPU fp32 gradients vs fp64 (yardstick, no bar)', e_cpu, 1.0, 'the same measure for torch\'s own fp32 path')
     check_gradients.last_named = named
     return worst, named.total

@@ -4,8 +4,9 @@ import sys
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-if ROOT not in sys.path:
-    sys.path.insert(0, ROOT)
+for _p in (ROOT, os.path.join(ROOT, 'tests')):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
 
 
 def pytest_configure(config):
@@ -32,3 +33,18 @@ def load_full_size_case(golden_dir, name):
     assert int(fx['seg'].astype(np.int64).sum()) == int(fx['seg_sum']) and int(fx['mask'].sum()) == int(fx['mask_sum'])
     fx['post_pred'] = np.unpackbits(fx['post_pred_bits'])[:H * W].reshape(1, H, W).astype(np.int8)
     return fx
+
+
+def pytest_sessionfinish(session, exitstatus):
+    """The tolerances the parity tests pinned in this session (tests/_tol.py), per tensor class: bar used, worst observed."""
+    import json
+    try:
+        import _tol
+    except ImportError:
+        return
+    if not _tol.RECORDS:
+        return
+    out_dir = os.path.join(ROOT, 'gpurun_out')
+    os.makedirs(out_dir, exist_ok=True)
+    with open(os.path.join(out_dir, 'tolerances.json'), 'w') as f:
+        json.dump({'per_class': _tol.summary(), 'records': _tol.RECORDS}, f, indent=1)

@@ -216,3 +216,50 @@ def test_appearance_oracle_invariants():
     L8, a8, b8 = ao.rgb8_to_lab8(img.astype(np.float32))
     back = np.abs(ao.lab8_to_rgb8(L8, a8, b8) - img)          # 8-bit Lab quantises a and b: a few levels on saturated colours
     assert back.max() <= 20 and back.mean() < 1.0 and np.percentile(back, 99) <= 8
+
+
+def test_elastic_displacement_field():
+    """ElasticTransform's second part (utils/data.py:124, albumentations ElasticTransform(alpha=1, sigma=50)): the coarse
+    grid the kernel interpolates equals gaussian_filter(per-pixel U(-1,1) noise, 50) on the same noise to < 0.001 px; the
+    field is tiny at the reference's parameters (which is why round 2 dropped it -- it is modelled now); the 12 floats
+    that place it hold the transform's forward affine and the linear part of its inverse."""
+    from oracle import augment_oracle as ao
+    from wesup_amd.utils import data as D
+    H, W = 120, 200
+    rs = np.random.RandomState(3)
+    st = rs.get_state()
+    f = D.elastic_field(rs, H, W)
+    assert f.shape == (2, 15, 25) and f.dtype == np.float32
+    rs.set_state(st)
+    yy, xx = np.meshgrid(np.arange(H, dtype=np.float32), np.arange(W, dtype=np.float32), indexing='ij')
+    got = ao.elastic_displacement(f, D.ELASTIC_CELL, xx, yy)
+    for a in range(2):
+        exact = ao.gaussian_filter_reflect(rs.rand(H, W) * 2.0 - 1.0, 50.0)      # what the reference computes per pixel
+        assert np.abs(got[a] - exact).max() < 1e-3
+        assert 0.001 < exact.std() < 0.01 and np.abs(exact).max() < 0.05
+    # alpha scales it; the sampler hands the field over only for the mask pipeline's ElasticTransform draws
+    rs = np.random.RandomState(5)
+    assert np.allclose(D.elastic_field(np.random.RandomState(9), 64, 64, alpha=300.0), 300.0 * D.elastic_field(np.random.RandomState(9), 64, 64), rtol=1e-5)
+    n_on = 0
+    for _ in range(40):
+        out = []
+        row, M = D.sample_params(rs, 64, 80, True, point_pipeline=False, elastic_out=out)
+        assert len(out) == 1
+        if out[0] is not None:
+            n_on += 1
+            field, par = out[0]
+            E = np.array([par[0:3], par[3:6], [0, 0, 1]], dtype=np.float64)
+            assert par[10] == 1.0 and np.allclose(np.linalg.inv(E)[:2, :2].reshape(-1), par[6:10], atol=1e-6)
+            assert field.shape == (2, 8, 10)
+        out = []
+        D.sample_params(rs, 64, 80, True, point_pipeline=True, elastic_out=out)
+        assert out == [None]                                   # the point pipeline has no ElasticTransform
+    assert 8 <= n_on <= 32                                     # p = 0.5
+    # the oracle's augment with a field: identity geometry + a constant displacement of (+1, 0) px reads the right neighbour
+    img = np.random.RandomState(1).randint(0, 256, (16, 24, 3)).astype(np.uint8)
+    row = np.zeros(12, dtype=np.float32); row[0] = row[4] = row[6] = 1.0
+    par = np.zeros(12, dtype=np.float32); par[0] = par[4] = par[6] = par[9] = par[10] = 1.0
+    field = np.zeros((2, 2, 3), dtype=np.float32); field[0] = 1.0
+    out, _ = ao.augment(img, None, row, elastic=(field, par, 8))
+    want = np.concatenate([img[:, 1:], img[:, -2:-1]], 1).transpose(2, 0, 1) / 255.0         # reflect-101 at the right border
+    assert np.allclose(out, want, atol=1e-6)

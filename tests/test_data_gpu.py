@@ -44,6 +44,49 @@ def test_augment_kernel_matches_the_numpy_restatement():
     assert np.array_equal(out[0], (img[0].transpose(2, 0, 1).astype(np.float32) * np.float32(1 / 255.0)))
 
 
+def test_augment_kernel_with_the_elastic_displacement_field():
+    """ElasticTransform (utils/data.py:124) = its random affine (folded into the one inverse map) + a displacement field, the
+    kernel's bilinear look-up into the coarse grid against the numpy restatement: at the reference's alpha = 1 (a field of
+    ~0.01 px) and at alpha = 400 (several pixels, so that a wrong sign / axis / frame of the look-up cannot hide); images
+    of the batch that did not draw the transform are untouched by the field argument."""
+    from oracle import augment_oracle as ao
+    from wesup_amd import ops
+    from wesup_amd.utils import data as D
+    d = torch.device('cuda:0')
+    rs = np.random.RandomState(11)
+    B, H, W = 4, 72, 100
+    yy, xx = np.mgrid[0:H, 0:W]
+    img = np.stack([np.stack([(xx * 3 + b * 17) % 256, (yy * 4) % 256, (xx + 2 * yy) % 256], -1) for b in range(B)]).astype(np.uint8)
+    mask = ((xx // 9 + yy // 7) % 2).astype(np.uint8)[None].repeat(B, 0)
+    cell = D.ELASTIC_CELL
+    hc, wc = -(-H // cell), -(-W // cell)
+    for alpha in (1.0, 400.0):
+        rows, fields, pars = [], np.zeros((B, 2, hc, wc), np.float32), np.zeros((B, 12), np.float32)
+        for b in range(B):
+            got = []
+            while True:                                   # images 0..2 with the transform, image 3 without
+                got.clear()
+                row, _ = D.sample_params(rs, H, W, True, point_pipeline=False, elastic_out=got)
+                if (got[0] is not None) == (b < 3):
+                    break
+            row[8:11] = 0                                 # geometry + gain only: colours comparable to 2e-5
+            rows.append(row)
+            if got[0] is not None:
+                fields[b], pars[b] = got[0][0] * alpha, got[0][1]
+        params = np.stack(rows)
+        out, om = ops.augment(torch.from_numpy(img).to(d), torch.from_numpy(mask).to(d), torch.from_numpy(params).to(d),
+                              elastic=(torch.from_numpy(fields).to(d), torch.from_numpy(pars).to(d), cell))
+        plain, pm = ops.augment(torch.from_numpy(img).to(d), torch.from_numpy(mask).to(d), torch.from_numpy(params).to(d))
+        out, om, plain, pm = out.cpu().numpy(), om.cpu().numpy(), plain.cpu().numpy(), pm.cpu().numpy()
+        for b in range(B):
+            want, wm = ao.augment(img[b], mask[b], params[b], elastic=(fields[b], pars[b], cell))
+            assert np.mean(om[b] != wm) < (1e-3 if alpha > 1 else 1e-4), (alpha, b)      # a label may sit within rounding of a cell edge
+            assert np.abs(out[b] - want).max() < (2e-3 if alpha > 1 else 2e-5), (alpha, b, np.abs(out[b] - want).max())
+        assert np.array_equal(out[3], plain[3]) and np.array_equal(om[3], pm[3])
+        moved = np.abs(out[0] - plain[0]).max()
+        assert (moved > 0.02) if alpha > 1 else (moved < 0.02)          # the field does something at 400x, next to nothing at 1x
+
+
 def test_prefetcher_feeds_the_trainer_from_disk(tmp_path):
     from tests.test_data_cpu import _make_dataset
     from wesup_amd.utils import data as D

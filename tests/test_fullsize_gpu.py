@@ -20,7 +20,8 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from conftest import load_full_size_case          # noqa: E402
-import _gradcheck                                 # noqa: E402
+import _gradcheck
+import _tol                                 # noqa: E402
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-4
@@ -91,28 +92,30 @@ def test_step_matches_the_reference_at_full_size(golden_dir, name):
 
     pred = model((x, sp_maps))
     assert tuple(pred.shape) == (1, H, W)
-    assert rel_err(model.sp_features, fx['sp_features']) < TOL
-    assert rel_err(model.sp_pred, fx['sp_pred']) < TOL
-    assert rel_err(pred[0, ::7, ::11], fx['pred_sample']) < TOL
+    ref = 'max |a - b| / max |b| against the real reference (tests/golden)'
+    assert _tol.within(name, 'sp_features vs reference', rel_err(model.sp_features, fx['sp_features']), TOL, ref)
+    assert _tol.within(name, 'sp_pred vs reference', rel_err(model.sp_pred, fx['sp_pred']), TOL, ref)
+    assert _tol.within(name, 'pred (painted) vs reference', rel_err(pred[0, ::7, ::11], fx['pred_sample']), TOL, ref)
     assert np.array_equal(trainer.postprocess(pred).cpu().numpy().astype(np.int8), fx['post_pred'])
     fm = model.feature_maps
     assert tuple(fm.shape) == (2112, H, W)
-    assert rel_err(fm.mean(dim=(1, 2)), fx['fm_chan_mean']) < TOL
-    assert rel_err(fm[::97, ::23, ::29], fx['fm_sample']) < TOL
+    assert _tol.within(name, 'feature map channel means vs reference', rel_err(fm.mean(dim=(1, 2)), fx['fm_chan_mean']), TOL, ref)
+    assert _tol.within(name, 'feature map samples vs reference', rel_err(fm[::97, ::23, ::29], fx['fm_sample']), TOL, ref)
     del fm
 
     feats_padded = model._padded[0].detach().clone()
     metrics = {}
     loss = trainer.compute_loss(pred, (pixel_mask, sp_labels), metrics=metrics)
     host = trainer._read_back(loss, metrics, None)
-    assert abs(host['loss'] - float(fx['loss'])) <= TOL * abs(float(fx['loss']))
+    assert _tol.within(name, 'loss vs reference', abs(host['loss'] - float(fx['loss'])) / abs(float(fx['loss'])), TOL, 'relative')
     assert metrics['propagated_labels'] == float(fx['propagated_labels'])
-    assert abs(metrics['propagate_loss'] - float(fx['propagate_loss'])) <= TOL * abs(float(fx['propagate_loss']))
+    assert _tol.within(name, 'propagate_loss vs reference',
+                       abs(metrics['propagate_loss'] - float(fx['propagate_loss'])) / abs(float(fx['propagate_loss'])), TOL, 'relative')
     assert abs(metrics['labeled_sp_ratio'] - float(fx['labeled_sp_ratio'])) < 1e-7
     y_all, src, sim = ops.propagate(feats_padded, meta, 0.8)
     assert np.array_equal(src[0, n_l:K].cpu().numpy(), fx['src'])                 # argmax indices bit-exact
     assert np.array_equal(y_all[0, n_l:K].cpu().numpy(), fx['y_u'])
-    assert rel_err(sim[0, n_l:K], fx['max_sim']) < TOL
+    assert _tol.within(name, 'max_sim vs reference', rel_err(sim[0, n_l:K], fx['max_sim']), TOL, ref)
 
     loss.backward()
     # every parameter gradient: norm against the reference's, elements against the reference's samples (the
@@ -121,11 +124,14 @@ def test_step_matches_the_reference_at_full_size(golden_dir, name):
     for k in [k[6:] for k in fx if k.startswith('gnorm.')]:
         g = model._grad_views[k]
         ref_norm = float(fx['gnorm.' + k])
-        assert abs(g.double().norm().item() - ref_norm) <= 2e-4 * ref_norm + 1e-12, k
+        assert _tol.within(name, 'gradient norms vs reference (fp32 CPU)', abs(g.double().norm().item() - ref_norm) / ref_norm, 2e-4,
+                           '| ||g|| - ||g_ref|| | / ||g_ref||, every parameter tensor'), k
         samp = g.flatten()[::max(1, g.numel() // 64)][:64].cpu().numpy()
-        assert np.abs(samp - fx['gsamp.' + k]).max() <= 1e-3 * float(fx['gmax.' + k]), k
+        assert _tol.within(name, 'gradient samples vs reference (fp32 CPU)', np.abs(samp - fx['gsamp.' + k]).max() / float(fx['gmax.' + k]),
+                           1e-3, '64 elements per tensor, error / max |g_ref|; the reference\'s own fp32 sums carry up to 3e-4 '
+                                 '(conv1_1 dW: 230 400 mixed-sign products per element)'), k
     # ... and against fp64 under the same ReLU / pooling decisions: 1e-4 of each tensor's max (or <= 2x torch fp32)
-    worst, n_named = _gradcheck.check_gradients(model, weights, fx['img'][None], fx['seg'][None], fx['mask'][None])
+    worst, n_named = _gradcheck.check_gradients(model, weights, fx['img'][None], fx['seg'][None], fx['mask'][None], case=name)
     print(f'{name}: worst gradient error vs fp64 {worst:.2e}, {n_named} near-tie decisions differ')
 
 
@@ -154,7 +160,7 @@ def test_config_c2_exactly_matches_the_oracle():
     y_all, src, sim = ops.propagate(feats.contiguous(), meta, 0.8)
     per_image = [loss_under_gpu_decisions(orc, outs[b], y_all[b]) for b in range(B)]
     n_near = sum(k for _, k in per_image)
-    assert abs(hist['loss'][0] - np.mean([l for l, _ in per_image])) <= TOL * abs(ref_loss)
+    assert _tol.within('c2_exact', 'loss vs oracle', abs(hist['loss'][0] - np.mean([l for l, _ in per_image])) / abs(ref_loss), TOL, 'relative')
     if n_near == 0:                                                   # no near-tie row: the oracle's own numbers
         assert abs(hist['loss'][0] - ref_loss) <= TOL * abs(ref_loss)
         assert hist['propagated_labels'][0] == np.mean([m['propagated_labels'] for m in mets])
@@ -173,15 +179,15 @@ def test_config_c2_exactly_matches_the_oracle():
         y_u, W_ul, max_sim, src_ref = orc.label_propagate(outs[b]['sp_features'], pp['sp_labels'], 0.8, return_aux=True)
         top2 = W_ul.topk(2, dim=1).values
         near = ((max_sim - 0.8).abs() < 1e-5) | ((top2[:, 0] - top2[:, 1]).abs() < 1e-5)   # threshold / runner-up within rounding
-        assert rel_err(feats[b, :n], outs[b]['sp_features']) < TOL
+        assert _tol.within('c2_exact', 'sp_features vs oracle', rel_err(feats[b, :n], outs[b]['sp_features']), TOL)
         assert torch.equal(src[b, n_l:n].cpu().long()[~near], src_ref[~near])
         assert torch.equal(y_all[b, n_l:n].cpu()[~near], y_u[~near])
         assert torch.equal(bufs.pred[b].round().long().cpu(), outs[b]['pred'].detach().round().long())
     # every parameter gradient against fp64 (same decisions), and the SGD update against the oracle's
-    worst, n_named = _gradcheck.check_gradients(model, weights, imgs, labs, pts)
+    worst, n_named = _gradcheck.check_gradients(model, weights, imgs, labs, pts, case='c2_exact')
     new = {k: v.detach().cpu() for k, v in model.state_dict().items()}
     for k, v in ref_new.items():
-        assert rel_err(new[k], v) < 1e-5, k
+        assert _tol.within('c2_exact', 'updated parameters (SGD) vs oracle', rel_err(new[k], v), 1e-5), k
     print(f'c2: loss {hist["loss"][0]:.6f} (oracle {ref_loss:.6f}), worst gradient error vs fp64 {worst:.2e}, '
           f'{n_named} near-tie decisions differ')
 
@@ -239,10 +245,10 @@ def test_one_image_of_config_c5_matches_the_oracle():
     assert torch.equal(src[0, n_l:n].cpu().long()[~near], src_ref[~near]) and torch.equal(y_all[0, n_l:n].cpu()[~near], y_u[~near])
     assert torch.equal(bufs.pred[0].round().long().cpu(), outs[0]['pred'].detach().round().long())
     del outs, ref_grads
-    worst, n_named = _gradcheck.check_gradients(model, weights, imgs, labs, pts)
+    worst, n_named = _gradcheck.check_gradients(model, weights, imgs, labs, pts, case='c2_exact')
     new = {k: v.detach().cpu() for k, v in model.state_dict().items()}
     for k, v in ref_new.items():
-        assert rel_err(new[k], v) < 1e-5, k
+        assert _tol.within('c2_exact', 'updated parameters (SGD) vs oracle', rel_err(new[k], v), 1e-5), k
     print(f'c5 (one image): loss {hist["loss"][0]:.6f} (oracle {ref_loss:.6f}; {n_near} pseudo labels decided by a '
           f'near-tie), worst gradient error vs fp64 {worst:.2e}, {n_named} near-tie decisions differ')
     model.engine.release_buffers()

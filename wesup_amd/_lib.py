@@ -24,7 +24,7 @@ _SIGS = {
     'wesup_debug_clock': (c_int, 'p'),
     'wesup_debug_set_trace': (c_int, 'p'),
     'wesup_strerror': (ctypes.c_char_p, 'i'),
-    'wesup_augment': (c_int, 'pppppiiiip'),
+    'wesup_augment': (c_int, 'pppppiiippiiiip'),
     'wesup_appearance_workspace_bytes': (c_size_t, 'iii'),
     'wesup_appearance': (c_int, 'pppiiipzp'),
     'wesup_pack_input': (c_int, 'ppiiip'),

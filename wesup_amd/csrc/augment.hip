@@ -65,16 +65,56 @@ __device__ __forceinline__ void hsv8_to_rgb(float h, float s, float v, float& r,
     }
 }
 
+// ElasticTransform's displacement field (albumentations ElasticTransform(alpha=1, sigma=50), utils/data.py:124:
+// dx, dy = gaussian_filter(U(-1, 1) per pixel, sigma) * alpha, the image is re-sampled at (x + dx, y + dy) AFTER the
+// transform's own random affine).  The field is smooth on the scale of sigma, so it arrives as a coarse grid (one value
+// per cell x cell pixels, already smoothed: host side, utils/data.py elastic_field) and is interpolated bilinearly here.
+// Per image 12 floats: E (2x3: source grid -> the grid the field lives on, i.e. the forward affine of the transform),
+// L (2x2: linear part of E^-1, which takes the displacement back to the source grid), on (0/1), pad.
+struct ElasticParams {
+    float e00, e01, e02, e10, e11, e12;
+    float l00, l01, l10, l11;
+    float on, pad;
+};
+struct ElasticField {
+    const float* field;          // [B][2][hc][wc] (dx plane, dy plane), or NULL
+    const ElasticParams* par;    // [B]
+    int hc, wc, cell;
+};
+__device__ __forceinline__ float elastic_sample(const float* f, int hc, int wc, float u, float v) {
+    u = fminf(fmaxf(u, 0.f), (float)(wc - 1));
+    v = fminf(fmaxf(v, 0.f), (float)(hc - 1));
+    const int u0 = (int)u, v0 = (int)v;
+    const int u1 = min(u0 + 1, wc - 1), v1 = min(v0 + 1, hc - 1);
+    const float wu = u - (float)u0, wv = v - (float)v0;
+    return (1.f - wv) * ((1.f - wu) * f[v0 * wc + u0] + wu * f[v0 * wc + u1]) +
+           wv * ((1.f - wu) * f[v1 * wc + u0] + wu * f[v1 * wc + u1]);
+}
+
 __global__ void augment_kernel(const uint8_t* __restrict__ img, const uint8_t* __restrict__ mask,
                                const AugParams* __restrict__ params, float* __restrict__ out_img,
-                               uint8_t* __restrict__ out_mask, int H, int W, int C) {
+                               uint8_t* __restrict__ out_mask, int H, int W, int C, const ElasticField el) {
     const int b = blockIdx.y;
     const long HW = (long)H * W;
     const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= HW) return;
     const int y = p / W, x = p - (long)y * W;
     const AugParams a = params[b];
-    const float sx = a.a00 * x + a.a01 * y + a.a02, sy = a.a10 * x + a.a11 * y + a.a12;
+    float sx = a.a00 * x + a.a01 * y + a.a02, sy = a.a10 * x + a.a11 * y + a.a12;
+    if (el.field) {
+        const ElasticParams e = el.par[b];
+        if (e.on != 0.f) {
+            // q: this output pixel on the grid of the affinely warped image, where the field is defined
+            const float qx = e.e00 * sx + e.e01 * sy + e.e02, qy = e.e10 * sx + e.e11 * sy + e.e12;
+            const float inv = 1.f / (float)el.cell;
+            const float u = (qx + 0.5f) * inv - 0.5f, v = (qy + 0.5f) * inv - 0.5f;      // cell centres sit at (i + 1/2) cell - 1/2
+            const float* f = el.field + (long)b * 2 * el.hc * el.wc;
+            const float dx = elastic_sample(f, el.hc, el.wc, u, v);
+            const float dy = elastic_sample(f + el.hc * el.wc, el.hc, el.wc, u, v);
+            sx += e.l00 * dx + e.l01 * dy;
+            sy += e.l10 * dx + e.l11 * dy;
+        }
+    }
     const float fx = floorf(sx), fy = floorf(sy);
     const float wx = sx - fx, wy = sy - fy;
     const int x0 = reflect101((int)fx, W), x1 = reflect101((int)fx + 1, W);
@@ -109,13 +149,16 @@ __global__ void augment_kernel(const uint8_t* __restrict__ img, const uint8_t* _
     }
 }
 
-extern "C" int wesup_augment(const uint8_t* img_hwc, const uint8_t* mask_hw, const float* params, float* out_img_nchw,
+extern "C" int wesup_augment(const uint8_t* img_hwc, const uint8_t* mask_hw, const float* params, const float* elastic_field,
+                             const float* elastic_params, int hc, int wc, int cell, float* out_img_nchw,
                              uint8_t* out_mask_chw, int B, int H, int W, int C, void* stream) {
     if (!img_hwc || !params || !out_img_nchw || B <= 0 || H <= 0 || W <= 0 || C <= 0 || B > 65535) return WESUP_ERR_INVALID;
     if (mask_hw && !out_mask_chw) return WESUP_ERR_INVALID;
+    if (elastic_field && (!elastic_params || hc <= 0 || wc <= 0 || cell <= 0)) return WESUP_ERR_INVALID;
     const long HW = (long)H * W;
+    const ElasticField el = {elastic_field, reinterpret_cast<const ElasticParams*>(elastic_params), hc, wc, cell};
     hipLaunchKernelGGL(augment_kernel, dim3((unsigned)((HW + 255) / 256), B), dim3(256), 0, (hipStream_t)stream, img_hwc,
-                       mask_hw, reinterpret_cast<const AugParams*>(params), out_img_nchw, out_mask_chw, H, W, C);
+                       mask_hw, reinterpret_cast<const AugParams*>(params), out_img_nchw, out_mask_chw, H, W, C, el);
     WESUP_CHECK_LAUNCH();
     return WESUP_OK;
 }

@@ -95,9 +95,10 @@ def _nt_workspace(nbytes, device):
 
 
 # ---------------------------------------------------------------- input pipeline
-def augment(img_u8, mask_u8, params, n_classes=2):
+def augment(img_u8, mask_u8, params, n_classes=2, elastic=None):
     """img (B,H,W,3) uint8, mask (B,H,W) uint8 class index or None, params (B,12) fp32 -> img f32 (B,3,H,W) in [0,1],
-    one-hot mask uint8 (B,C,H,W) or None."""
+    one-hot mask uint8 (B,C,H,W) or None.  elastic = (field (B,2,hc,wc) fp32, params (B,12) fp32, cell): the displacement
+    field of ElasticTransform on a coarse grid (utils.data.elastic_field) for the images whose params row has on = 1."""
     _chk(img_u8, torch.uint8, 'img'); _chk(params, name='params')
     B, H, W, three = img_u8.shape
     assert three == 3 and params.shape == (B, 12)
@@ -106,7 +107,15 @@ def augment(img_u8, mask_u8, params, n_classes=2):
     if mask_u8 is not None:
         _chk(mask_u8, torch.uint8, 'mask'); assert mask_u8.shape == (B, H, W)
         om = torch.empty(B, n_classes, H, W, dtype=torch.uint8, device=img_u8.device)
-    _lib.call('wesup_augment', _p(img_u8), _p(mask_u8), _p(params), _p(out), _p(om), B, H, W, n_classes, _stream())
+    ef = ep = None
+    hc = wc = cell = 0
+    if elastic is not None:
+        ef, ep, cell = elastic
+        _chk(ef, name='elastic field'); _chk(ep, name='elastic params')
+        hc, wc = ef.shape[2:]
+        assert ef.shape == (B, 2, hc, wc) and ep.shape == (B, 12) and cell > 0 and hc * cell >= H and wc * cell >= W
+    _lib.call('wesup_augment', _p(img_u8), _p(mask_u8), _p(params), _p(ef), _p(ep), hc, wc, int(cell), _p(out), _p(om), B, H, W,
+              n_classes, _stream())
     return out, om
 
 

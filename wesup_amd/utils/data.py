@@ -10,7 +10,7 @@ as radius-0 dots (utils/data.py:352-362).  What comes out is the reference's ite
 ``img f32 (B,3,H,W) in [0,1]``, ``pixel_mask (B,C,H,W)`` one-hot or the empty tensor, ``point_mask (B,C,H,W)``.
 
 CLAHE and Blur run on the GPU as well (``wesup_appearance``, on the un-warped image and in the reference's order),
-ElasticTransform -- with the albumentations defaults a random 3-point affine plus a displacement field of < 0.05 px --
+ElasticTransform -- with the albumentations defaults a random 3-point affine plus a displacement field of < 0.02 px, both modelled --
 is folded into the affine map.  Not reproduced: exact skimage / OpenCV / albumentations numerics (all absent from the
 build image: parity unpinned).  ``SyntheticGlasDataset`` keeps producing
 GlaS-shaped items of the same contract for benchmarks ('synthetic:H:W:g:n')."""
@@ -271,15 +271,28 @@ class CompoundDataset(torch.utils.data.Dataset):
             dataset.summary(logger=logger)
 
 
-def sample_params(rs, H, W, train, point_pipeline=True):
+ELASTIC_CELL = 8       # pixels per cell of the coarse displacement grid (sigma = 50 px: the field is smooth on that scale)
+
+
+def sample_params(rs, H, W, train, point_pipeline=True, elastic_out=None):
     """12 floats for wesup_augment + the forward 2x3 matrix for keypoints.  Parameter ranges are the albumentations
-    defaults the reference's pipelines rely on (utils/data.py:116-133 for masks, :302-327 for points)."""
+    defaults the reference's pipelines rely on (utils/data.py:116-133 for masks, :302-327 for points).
+    elastic_out (optional list): when ElasticTransform is drawn, its displacement field and the 12 floats that place it are
+    appended as ``(field (2, hc, wc) float32, params (12,) float32)`` (else ``None``) -- ``ops.augment(elastic=...)``."""
     M = np.eye(3)
     row = np.zeros(12, dtype=np.float32)
     row[6] = 1.0
+    el = None
     if train:
         if not point_pipeline and rs.random_sample() < 0.5:      # A.ElasticTransform(p=0.5), mask pipelines only
-            M = elastic_affine(rs, H, W) @ M
+            E = elastic_affine(rs, H, W)
+            M = E @ M
+            if elastic_out is not None:
+                par = np.zeros(12, dtype=np.float32)
+                par[0:3], par[3:6] = E[0], E[1]
+                par[6:10] = np.linalg.inv(E)[:2, :2].reshape(-1)
+                par[10] = 1.0
+                el = (elastic_field(rs, H, W), par)
         if rs.random_sample() < 0.5:
             M = np.array([[-1, 0, W - 1], [0, 1, 0], [0, 0, 1.0]]) @ M
         if rs.random_sample() < 0.5:
@@ -297,14 +310,52 @@ def sample_params(rs, H, W, train, point_pipeline=True):
         row[8], row[9], row[10] = rs.uniform(-lim_h, lim_h), rs.uniform(-lim_s, lim_s), rs.uniform(-lim_v, lim_v)
     Minv = np.linalg.inv(M)
     row[0:3], row[3:6] = Minv[0], Minv[1]
+    if elastic_out is not None:
+        elastic_out.append(el)
     return row, M[:2]
+
+
+def _gauss_matrix(n, sigma, truncate=4.0):
+    """(n, n) matrix of a 1-D Gaussian filter with scipy.ndimage's conventions: taps at integer offsets up to
+    int(truncate * sigma + 0.5), normalised, borders handled by reflection about the edge of the first / last sample
+    (mode='reflect': d c b a | a b c d | d c b a)."""
+    r = int(truncate * sigma + 0.5)
+    k = np.exp(-0.5 * (np.arange(-r, r + 1) / sigma) ** 2)
+    k /= k.sum()
+    K = np.zeros((n, n))
+    idx = np.arange(n)
+    for o, wgt in zip(range(-r, r + 1), k):
+        j = np.mod(idx + o, 2 * n)
+        j = np.where(j < n, j, 2 * n - 1 - j)
+        np.add.at(K, (idx, j), wgt)
+    return K
+
+
+def elastic_field(rs, H, W, alpha=1.0, sigma=50.0, cell=ELASTIC_CELL):
+    """The displacement field of albumentations' ElasticTransform(alpha=1, sigma=50) (utils/data.py:124) on a coarse grid:
+    (2, hc, wc) float32, plane 0 = dx, plane 1 = dy, hc = ceil(H / cell).  The reference's field is
+    gaussian_filter(U(-1, 1) per pixel, sigma) * alpha; a Gaussian of width sigma over per-pixel noise equals, up to the
+    discretisation of the kernel, a Gaussian of width sigma / cell over the cell-averaged noise, so the per-pixel noise is
+    drawn as the reference draws it, averaged over cell x cell blocks (partial blocks at the border over the pixels they
+    have) and smoothed on the coarse grid; the kernel interpolates bilinearly.  Against the per-pixel filter on the same
+    noise the interpolated field differs by < 0.001 px (tests/test_data_cpu.py); the field itself has a standard deviation
+    of ~0.0034 px and a maximum of ~0.01-0.02 px per image at alpha = 1."""
+    hc, wc = -(-H // cell), -(-W // cell)
+    out = np.empty((2, hc, wc), dtype=np.float32)
+    Ky, Kx = _gauss_matrix(hc, sigma / cell), _gauss_matrix(wc, sigma / cell)
+    cnt = np.add.reduceat(np.add.reduceat(np.ones((H, W)), np.arange(0, H, cell), 0), np.arange(0, W, cell), 1)
+    for a in range(2):
+        noise = rs.rand(H, W) * 2.0 - 1.0
+        blk = np.add.reduceat(np.add.reduceat(noise, np.arange(0, H, cell), 0), np.arange(0, W, cell), 1) / cnt
+        out[a] = (Ky @ blk @ Kx.T * alpha).astype(np.float32)
+    return out
 
 
 def elastic_affine(rs, H, W, alpha_affine=50.0):
     """The affine part of albumentations' ElasticTransform(alpha=1, sigma=50, alpha_affine=50) (utils/data.py:124):
     three corners of a centred square are moved by U(-alpha_affine, alpha_affine) pixels each and the affine map through
-    the three pairs is applied (cv2.getAffineTransform / warpAffine).  Its second part, a displacement field
-    gaussian_filter(U(-1, 1), sigma=50) * alpha, has a standard deviation of ~0.006 px at alpha = 1 and is dropped.
+    the three pairs is applied (cv2.getAffineTransform / warpAffine).  Its second part, the displacement field
+    gaussian_filter(U(-1, 1), sigma=50) * alpha (standard deviation 0.0034 px, up to ~0.02 px), is ``elastic_field``.
     (albumentations builds the points from (height, width) and hands them to OpenCV as (x, y); kept.)"""
     c = np.array([H // 2, W // 2], dtype=np.float64)
     sq = min(H, W) // 3
@@ -370,8 +421,17 @@ class DevicePrefetcher:
         self._check_item(raw)
         img, mask, pts, *extra = raw             # extra: what a dataset adds to the item (area bounds, coordinate maps)
         B, H, W, _ = img.shape
-        rows, mats = zip(*[sample_params(self.rs, H, W, self.train, self.with_points) for _ in range(B)])
+        els = []
+        rows, mats = zip(*[sample_params(self.rs, H, W, self.train, self.with_points, elastic_out=els) for _ in range(B)])
         rows = np.stack(rows)
+        elastic = None
+        if any(e is not None for e in els):      # ElasticTransform's displacement field for the images that drew it
+            hc, wc = -(-H // ELASTIC_CELL), -(-W // ELASTIC_CELL)
+            ef, ep = np.zeros((B, 2, hc, wc), dtype=np.float32), np.zeros((B, 12), dtype=np.float32)
+            for b, e in enumerate(els):
+                if e is not None:
+                    ef[b], ep[b] = e
+            elastic = (torch.from_numpy(ef), torch.from_numpy(ep))
         app = np.zeros((B, 8), dtype=np.float32)
         app[:, 0] = 1.0
         for b in range(B):
@@ -394,7 +454,11 @@ class DevicePrefetcher:
             d_par = params.pin_memory().to(self.device, non_blocking=True)
             if need_app:
                 d_img = ops.appearance(d_img, torch.from_numpy(app).pin_memory().to(self.device, non_blocking=True))
-            out_img, out_mask = ops.augment(d_img, d_mask, d_par, self.n_classes)
+            d_el = None
+            if elastic is not None:
+                d_el = (elastic[0].pin_memory().to(self.device, non_blocking=True),
+                        elastic[1].pin_memory().to(self.device, non_blocking=True), ELASTIC_CELL)
+            out_img, out_mask = ops.augment(d_img, d_mask, d_par, self.n_classes, elastic=d_el)
             point_mask = None
             if self.with_points:
                 point_mask = torch.zeros(B, self.n_classes, H, W, dtype=torch.uint8, device=self.device)
