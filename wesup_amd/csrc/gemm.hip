@@ -774,6 +774,7 @@ struct TnParams {
     int tiles_m, tiles_n, taps;
     int k_per_split;  // multiple of BK
     int w_old, w_young;   // > 0: weighted split of a single-round grid (see the kernel); 0: equal splits
+    int xcd_group;        // walk the grid XCD by XCD in tile-fastest order (see the kernel)
 };
 
 template <int BM, int BN, int WM, int WN, int MODE_, bool RELU, bool TINY>
@@ -789,7 +790,19 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnParams p) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     WESUP_DBG(const unsigned long long tr0 = __builtin_amdgcn_s_memrealtime();)
-    int lt = blockIdx.x;
+    // Block -> (tile, split, batch entry).  xcd_group: the grid is walked so that each XCD gets a contiguous range of the
+    // tile-fastest order -- the tiles of one (batch entry, split), which read the same K range of both operands, then sit
+    // behind ONE L2 instead of being dealt round-robin over eight (blocks b and b + 8 share an XCD).
+    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    if (p.xcd_group) {
+        const int gx = gridDim.x, gy = gridDim.y;
+        const int L = xcd_remap(bx + gx * (by + gy * bz), gx * gy * (int)gridDim.z);
+        const int q = L / gx;
+        bx = L - q * gx;
+        bz = q / gy;
+        by = q - bz * gy;
+    }
+    int lt = bx;
     const int tile_n = lt % p.tiles_n;
     lt /= p.tiles_n;
     const int tile_m = lt % p.tiles_m;
@@ -803,7 +816,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnParams p) {
     // partition [0, K) exactly, and the pairs end together.  Static, so the summation order stays fixed.
     int k_begin, k_end;
     if (p.w_old > 0) {
-        const int gx = gridDim.x, S = gridDim.y, y = blockIdx.y;
+        const int gx = gridDim.x, S = gridDim.y, y = by;                  // (weighted splits: never with xcd_group)
         const int T = (p.K + BK - 1) / BK;
         const int n_o = ((int)blockIdx.x < 256) ? min(S, (255 - (int)blockIdx.x) / gx + 1) : 0;   // splits of this tile among the first 256 blocks
         const long wtot = (long)p.w_old * n_o + (long)p.w_young * (S - n_o);
@@ -812,11 +825,11 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnParams p) {
         k_begin = (int)(T * w0 / wtot) * BK;
         k_end = min(p.K, (int)(T * w1 / wtot) * BK);
     } else {
-        k_begin = blockIdx.y * p.k_per_split;
+        k_begin = by * p.k_per_split;
         k_end = min(p.K, k_begin + p.k_per_split);
     }
-    const float* Ab = p.A + (long)blockIdx.z * p.batchA;
-    const float* Bb = p.Bx + (long)blockIdx.z * p.batchB;
+    const float* Ab = p.A + (long)bz * p.batchA;
+    const float* Bb = p.Bx + (long)bz * p.batchB;
 
     const int qa = tid % QA, ra_row = tid / QA;
     const int qb = tid % QB, rb_row = tid / QB;
@@ -933,7 +946,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnParams p) {
     const int l31 = lane & 31, lhi = lane >> 5;
     const int nk = (k_end - k_begin + BK - 1) / BK;
 
-    const bool do_cs = p.want_colsum && (p.colsum_batch < 0 || (int)blockIdx.z == p.colsum_batch) && tile_n == 0 &&
+    const bool do_cs = p.want_colsum && (p.colsum_batch < 0 || bz == p.colsum_batch) && tile_n == 0 &&
                        tap == 0 && tid < BM;     // wave-uniform (BM % 64 == 0)
     float csum = 0.f;
     unsigned vb[NB];
@@ -1007,7 +1020,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnParams p) {
     }
 
     WESUP_DBG(const unsigned long long tr2 = __builtin_amdgcn_s_memrealtime();)
-    float* slab = p.slab + (long)blockIdx.z * p.batch_slab + (long)blockIdx.y * p.slab_stride;
+    float* slab = p.slab + (long)bz * p.batch_slab + (long)by * p.slab_stride;
     if (do_cs && m_blk + tid < p.M) slab[(long)p.M * p.Nslab + m_blk + tid] = csum;
     const int ncol0 = (MODE == 1) ? tap * p.N : 0;
     // accumulator register r of sub-tile (i, j): row wm0 + WM*q + i with q = (r&3) + 8*(r>>2) + 4*lhi, column
@@ -1167,6 +1180,11 @@ static int launch_tn(TnParams p, const TnPlan& pl, hipStream_t st, int nbatch = 
         }();
         p.w_old = wts / 1024; p.w_young = wts % 1024;
     }
+    // XCD grouping where several tiles share a K range and the weighted split (which reasons about dispatch order) is off;
+    // WESUP_TN_XCD=0 switches it off for the A/B
+    static const int xcd_on = [] { const char* e = getenv("WESUP_TN_XCD"); return (e && e[0] == '0') ? 0 : 1; }();
+    p.xcd_group = (xcd_on && p.w_old == 0 && (long)pl.tiles_m * pl.tiles_n * pl.taps > 1 &&
+                   (long)grid_blocks(pl) * nbatch < (1l << 30)) ? 1 : 0;
     const long kmax = p.w_old > 0 ? 2l * pl.k_per_split : pl.k_per_split;      // a weighted range stays below twice the mean
     if ((kmax + 2 * BK) * ldmax * 4 + (1l << 22) >= (1l << 31)) return WESUP_ERR_INVALID;
     dim3 grid(pl.tiles_m * pl.tiles_n * pl.taps, pl.S, nbatch);

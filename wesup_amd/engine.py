@@ -631,7 +631,9 @@ class WesupEngine:
                 dw, db = g[f'backbone.{idx}.weight'], g[f'backbone.{idx}.bias']
                 mw = b.wino_fwd[l]                             # this forward went through the Winograd domain: its V was kept
                 v_pre = b.V[l] if mw else None
-                if self.wgrad_winograd and ci >= self.WINOGRAD_MIN_CI and (co >= self.WINOGRAD_MIN_CO or v_pre is not None):
+                # the forward's kept V decides; without one (direct forward) only the layers where a transform pass of
+                # its own still pays
+                if self.wgrad_winograd and (v_pre is not None or (ci >= self.WINOGRAD_MIN_CI and co >= self.WINOGRAD_MIN_CO)):
                     mw = mw or self.WINOGRAD_TILE
                     ops.conv3x3_wgrad_winograd(x_in, b.G[l], relu_in=relu_x, dw=dw, db=db, ws_tag=ws_tag, v_pre=v_pre, m=mw)
                     # the FLOPs the MFMA pipe executes: (m+2)^2 positions x (m x m tiles) instead of 9 taps x pixels
