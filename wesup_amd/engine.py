@@ -569,7 +569,9 @@ class WesupEngine:
                         tok = T.begin('upsample_bwd')
                         ops.upsample_bwd_fused(b.gsp, meta.new_row, meta.area_new, H, W, SIDE_OFF[l], h, w,
                                                CONV_CH[l][1] // 2, out=b.ds[l])
-                        T.end(tok, 4.0 * B * H * W * (CONV_CH[l][1] // 2))
+                        # own byte model (pool-backward fused in): the gradient at native resolution out, the pixel labels
+                        # and one row of g per superpixel in -- not the (H, W, C/2) slice of a materialised gradient
+                        T.end(tok, 4.0 * B * (h * w * (CONV_CH[l][1] // 2) + H * W + Kmax * (CONV_CH[l][1] // 2)))
                         ds_ready[l] = torch.cuda.Event()
                         ds_ready[l].record()
         with self._OnSide(self):
@@ -600,7 +602,7 @@ class WesupEngine:
                 else:
                     ops.upsample_bwd(b.dfm, off, h, w, co // 2, out=b.ds[l])
                     ds2d = b.ds[l].view(P, co // 2)
-                T.end(tok, 4.0 * B * H * W * (co // 2))
+                T.end(tok, 4.0 * B * ((h * w * (co // 2) + H * W + Kmax * (co // 2)) if self.fuse_pool_bwd else H * W * (co // 2)))
                 tok = T.begin('side_bwd')
                 y2d = b.y[l].view(P, co)
                 if l >= lowest:              # G_l is only needed by backbone layers that train
