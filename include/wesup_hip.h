@@ -172,6 +172,18 @@ int wesup_winograd_output_transform(const float* Mt, long plane_elems, const flo
 int wesup_winograd_output_transform_unpool(const float* Mt, long plane_elems, const float* bias, const float* mask_src,
                                            const float* unpool_src, float* unpool_dst, int B, int H, int W, int Hu, int Wu,
                                            int C, int m, void* stream);
+/* The batched products and the output transform in ONE kernel (m = 4; K = 64 or 128 channels of the product, N % 64 == 0):
+ * V [36][tiles][K] x U [36][N][K] -> y (B,H,W,N) = A^T (V_p . U_p^T) A + the epilogue of wesup_winograd_output_transform
+ * (bias, mask_src, accumulate, y_pool) or of its _unpool form (unpool_src / unpool_dst (B,Hu,Wu,N), y = NULL): the
+ * transformed output [36][tiles][N] is never written.  At these widths the separate passes are HBM-bound on exactly that
+ * tensor; wesup_conv3x3_fwd/dgrad_winograd[_unpool] take this route by themselves (WESUP_WINO_FUSED=0: never, 1: forward only).
+ * Results equal the two-kernel route's up to fp32 summation order. */
+int wesup_winograd_fused_supported(int K, int N, int m);      /* 0: no; 1: the conv entries take the one-kernel route for this
+                                                                 product in the forward; 2: in the input gradient as well */
+int wesup_winograd_gemm_output_transform(const float* V, long plane_elems, const float* U, const float* bias,
+                                         const float* mask_src, float* y, float* y_pool, int pool_relu,
+                                         const float* unpool_src, float* unpool_dst, int Hu, int Wu,
+                                         int B, int H, int W, int K, int N, int accumulate, void* stream);
 /* The weight gradient's own transforms: dy (B,H,W,C) -> dM [P][tiles][C] = A dY A^T per m x m tile; and the way back from
  * the split-K slabs of the P transformed filter gradients ([P][S][Cout*Cin + Cout], each slab followed by the Cout
  * column sums of its dM operand) to dw (Cout,Cin,3,3) = G^T (sum over S) G.  The bias gradient db = sum over pixels of dy:

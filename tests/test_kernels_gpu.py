@@ -191,6 +191,11 @@ def test_conv3x3_wgrad_winograd(ops, B, H, W, Cin, Cout, relu_in, m):
     assert torch.equal(dw, dw2) and torch.equal(db, db2)
 
 
+def _lib_mod():
+    from wesup_amd import _lib
+    return _lib
+
+
 def wino_bar(m, e_direct):
     """Error bar of a Winograd-domain conv pass against fp64, as a fraction of the tensor's maximum."""
     return max(TOL / 10, 4 * e_direct) if m == 2 else 2e-5
@@ -231,8 +236,13 @@ def test_conv3x3_fwd_winograd(ops, B, H, W, Cin, Cout, relu_in, m):
             yp = torch.full((B, H // 2, W // 2, Cout), 7.0, device=d)
             y3 = torch.empty_like(y)
             ops.conv3x3_fwd_winograd(xg, uf, b.to(d), relu_in, out=y3, out_pool=yp, pool_relu=pool_relu, m=m)
-            assert torch.equal(y3, y)
-            assert torch.equal(yp, ops.maxpool2_fwd(y, torch.empty_like(yp), relu=pool_relu))
+            if _lib_mod().load().wesup_winograd_fused_supported(Cin, Cout, m):
+                # without a second (ReLU'd) output, short products take the one-kernel route: the same sums in another order
+                assert float((y3 - y).abs().max()) < 4e-6 * float(y.abs().max()) * 25
+                assert torch.equal(yp, ops.maxpool2_fwd(y3, torch.empty_like(yp), relu=pool_relu))
+            else:
+                assert torch.equal(y3, y)
+                assert torch.equal(yp, ops.maxpool2_fwd(y, torch.empty_like(yp), relu=pool_relu))
     y2 = ops.conv3x3_fwd_winograd(xg, uf, None, relu_in, m=m)                  # no bias, workspace V
     assert rel_err(nchw(y2), ref - b.double().view(1, -1, 1, 1)) < wino_bar(m, e_0)
     dy = rnd(B, Cout, H, W, seed=4)
@@ -370,6 +380,55 @@ def test_conv3x3_dgrad_winograd(ops, B, H, W, Cin, Cout, m):
     assert rel_err(nchw(out2), x2.grad) < wino_bar(m, TOL / 40)
 
 
+@pytest.mark.parametrize('B,H,W,K,N', [(2, 24, 16, 64, 64), (1, 37, 41, 64, 128), (3, 9, 8, 128, 64), (1, 2, 2, 64, 64),
+                                       (1, 120, 120, 128, 128), (2, 30, 30, 128, 256)])
+def test_winograd_products_and_output_transform_in_one_kernel(ops, B, H, W, K, N):
+    """wesup_winograd_gemm_output_transform (short products: the batched GEMM and the output transform in one kernel, the
+    transformed output never written) against the two separate entries on the same transformed input, for every epilogue
+    the conv passes use: bias + pooled output (forward), mask + accumulate (input gradient), the max-pool backward; ragged
+    tile grids, fewer than 32 tiles, several blocks along both grid axes.  Also against the fp64 oracle."""
+    from oracle import winograd_oracle as wo
+    d = dev()
+    x = nhwc(rnd(B, K, H, W, seed=1))
+    w = rnd(N, K, 3, 3, seed=2, scale=(2.0 / (9 * K)) ** 0.5)
+    bias = rnd(N, seed=3, scale=0.1)
+    xg = x.to(d)
+    uf, _ = ops.winograd_pack_weight(w.to(d), need_dgrad=False, m=4)
+    V = ops.winograd_input_transform(xg, m=4)
+    Mt = ops.gemm_nt_batched(V, uf)
+    scale = float(Mt.abs().max())
+    # forward epilogue: bias (+ pooled output)
+    yp2 = torch.full((B, H // 2, W // 2, N), 7.0, device=d) if H >= 2 and W >= 2 else None
+    yp1 = None if yp2 is None else torch.full_like(yp2, 7.0)
+    y2 = ops.winograd_output_transform(Mt, B, H, W, bias=bias.to(d), out_pool=yp2, pool_relu=True, m=4)
+    y1 = ops.winograd_gemm_output_transform(V, uf, B, H, W, bias=bias.to(d), out_pool=yp1, pool_relu=True)
+    tol = 4e-6 * scale                       # the same sums in another order, outputs ~100x below the transformed values
+    assert float((y1 - y2).abs().max()) < tol
+    if yp1 is not None:
+        assert float((yp1 - yp2).abs().max()) < tol and torch.equal(yp1, torch.relu(F.max_pool2d(y1.permute(0, 3, 1, 2), 2).permute(0, 2, 3, 1)))
+    ref = wo.conv_fwd(x.numpy(), w.numpy(), bias.numpy(), m=4)
+    assert np.abs(y1.cpu().numpy() - ref).max() < 2e-5 * np.abs(ref).max()
+    # input-gradient epilogue: ReLU mask of the layer below + accumulation
+    base, mask = rnd(B, H, W, N, seed=6).to(d), rnd(B, H, W, N, seed=7).to(d)
+    a1, a2 = base.clone(), base.clone()
+    ops.winograd_gemm_output_transform(V, uf, B, H, W, mask_src=mask, out=a1, accumulate=True)
+    ops.winograd_output_transform(Mt, B, H, W, mask_src=mask, out=a2, accumulate=True, m=4)
+    assert float((a1 - a2).abs().max()) < tol and torch.equal(a1[mask <= 0], base[mask <= 0])
+    # max-pool backward epilogue (ties and dead windows included)
+    Hu, Wu = 2 * H + 1, 2 * W
+    ypre = rnd(B, Hu, Wu, N, seed=8)
+    ypre[0, 0:2, 0:2, :8] = 0.37
+    ypre[0, 0:2, 2:4, :8] = -1.0
+    ypre = ypre.to(d)
+    g0 = rnd(B, Hu, Wu, N, seed=9).to(d)
+    u1, u2 = g0.clone(), g0.clone()
+    ops.winograd_gemm_output_transform(V, uf, B, H, W, unpool=(ypre, u1))
+    dxp = ops.winograd_output_transform(Mt, B, H, W, m=4)
+    ops.maxpool2_bwd(ypre, dxp, u2, accumulate=True)
+    assert float((u1 - u2).abs().max()) < tol
+    assert torch.equal((u1 != g0), (u2 != g0)) or float(((u1 != g0) != (u2 != g0)).float().mean()) < 1e-4      # same positions touched
+
+
 @pytest.mark.parametrize('B,Hu,Wu,Cin,Cout', [(2, 24, 16, 64, 128), (1, 37, 41, 128, 64), (3, 9, 8, 256, 256), (1, 2, 2, 32, 32),
                                               (1, 120, 120, 128, 256)])
 def test_conv3x3_dgrad_winograd_through_the_maxpool_backward(ops, B, Hu, Wu, Cin, Cout):
@@ -393,7 +452,12 @@ def test_conv3x3_dgrad_winograd_through_the_maxpool_backward(ops, B, Hu, Wu, Cin
     dxp = ops.conv3x3_dgrad_winograd(dy, ud, m=4)
     two = base.clone().to(d)
     ops.maxpool2_bwd(ypre_g, dxp, two, accumulate=True)
-    assert torch.equal(fused, two)
+    if _lib_mod().load().wesup_winograd_fused_supported(Cout, Cin, 4) == 1:
+        # forward-only fusion: the plain input gradient of a short product takes the one-kernel route, the unpooling one
+        # the two-kernel route -- the same sums in another order
+        assert float((fused - two).abs().max()) < 1e-4 * float((two - base.to(d)).abs().max())
+    else:
+        assert torch.equal(fused, two)       # the same product kernel on both sides
     # and against autograd of relu -> max_pool2d -> conv on the CPU
     yp = nchw(ypre).double().requires_grad_(True)
     out = F.conv2d(F.max_pool2d(F.relu(yp), 2), w.double(), None, padding=1)

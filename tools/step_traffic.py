@@ -1,0 +1,32 @@
+"""Traffic past L2 of one whole training step, per kernel, from rocprofv3 --pmc passes over bench.py:
+  rocprofv3 --pmc FETCH_SIZE --output-format csv -d OUT/f -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing
+  rocprofv3 --pmc WRITE_SIZE ... -d OUT/w ...
+  python tools/step_traffic.py OUT/f OUT/w STEPS(=3)
+bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 (MI355X_MICROARCH.md: gfx950 FETCH_SIZE under-reports wide streaming reads 2x)."""
+import collections, csv, glob, os, re, sys
+
+
+def read(d, ctr):
+    acc = {}
+    for f in glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True):
+        for r in csv.DictReader(open(f)):
+            if r['Counter_Name'] == ctr:
+                k = (int(r['Dispatch_Id']), r['Kernel_Name'])
+                acc[k] = acc.get(k, 0.0) + float(r['Counter_Value'])
+    out = collections.Counter()
+    n = collections.Counter()
+    for (_, kern), v in acc.items():
+        name = re.sub(r'^void ', '', kern).split('(')[0]
+        out[name] += v
+        n[name] += 1
+    return out, n
+
+
+f, nf = read(sys.argv[1], 'FETCH_SIZE')
+w, _ = read(sys.argv[2], 'WRITE_SIZE')
+steps = int(sys.argv[3]) if len(sys.argv) > 3 else 3
+rows = sorted(((2 * f[k] + w[k]) * 1024 / steps, k) for k in set(f) | set(w))
+tot = sum(r[0] for r in rows)
+print(f'total {(tot) / 1e9:.2f} GB per step (fetch x2 {sum(f.values()) * 2048 / steps / 1e9:.2f}, write {sum(w.values()) * 1024 / steps / 1e9:.2f})')
+for b, k in reversed(rows[-28:]):
+    print(f'{b / 1e6:10.1f} MB/step  {nf[k] / steps:6.1f} launches  {k[:110]}')

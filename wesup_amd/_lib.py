@@ -47,6 +47,8 @@ _SIGS = {
     'wesup_conv3x3_dgrad_winograd': (c_int, 'ppppiiiiiiipzp'),
     'wesup_conv3x3_dgrad_winograd_unpool': (c_int, 'ppppiiiiiiiipzp'),
     'wesup_winograd_output_transform_unpool': (c_int, 'plppppiiiiiiip'),
+    'wesup_winograd_fused_supported': (c_int, 'iii'),
+    'wesup_winograd_gemm_output_transform': (c_int, 'plpppppippiiiiiiiip'),
     'wesup_winograd_input_transform': (c_int, 'ppliiiiiip'),
     'wesup_gemm_nt_batched': (c_int, 'pilpilpiliiiip'),
     'wesup_winograd_output_transform': (c_int, 'plpppppiiiiiiip'),

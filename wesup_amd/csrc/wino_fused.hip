@@ -1,0 +1,304 @@
+// Winograd F(4x4,3x3): the batched products and the output transform in ONE kernel, for the layers whose products are
+// short (K = 64 or 128 input channels of the product).  DESIGN.md 3.1.1.
+//
+// The unfused pipeline writes the transformed output Mt [36][tiles][N] (2.25x the activation) from the batched GEMM and
+// reads it back in the output transform; at 64 / 128 channels those products are HBM-bound (conv1_2: 531 MB in and 531 MB
+// out for 17 GFLOP), so the two passes over Mt are most of the layer's time.  Here a block owns 32 tiles x 64 output
+// channels, walks the 36 positions itself -- per position one small product M_p[32][64] = V_p[32][K] . U_p[64][K]^T on
+// the fp32 MFMA (v_mfma_f32_16x16x4_f32: a wave holds 16 tiles x 32 channels) -- and folds A^T M A into 16 output
+// accumulators per (tile, channel) as it goes (separably: Z[jj] += A^T[jj][nu] M over a row of positions, then
+// Y[i][jj] += A^T[i][xi] Z[jj]).  Mt never exists; V is read once, y written once, and the filter planes (16 / 32 KB per
+// position and block) come from L2.  Operand staging is the LDS-DMA of gemm.hip (buffer form, XOR-swizzled 16-byte
+// chunks, double-buffered over the positions).  The epilogue is the output transform's: bias, ReLU mask of the layer
+// below, accumulation, the 2x2 max-pool behind the layer, or the max-pool backward (wesup_conv3x3_dgrad_winograd_unpool).
+#include "winograd.hpp"
+#include "ldsdma.hpp"
+#include <cstdlib>
+#include <type_traits>
+
+struct FusedParams {
+    const float* V;          // [36][plane_v] transformed input, rows of K floats
+    long plane_v;            // elements between two position planes of V
+    const float* U;          // [36][N][K]
+    const float* bias;       // [N] or NULL
+    const float* mask;       // (B,H,W,N) or NULL: result kept where mask > 0
+    float* y;                // (B,H,W,N), or NULL in unpool mode
+    float* y_pool;           // (B,H/2,W/2,N) or NULL
+    int pool_relu, accum;
+    const float* up_src;     // unpool mode: pre-pool activations (B,Hu,Wu,N)
+    float* up_dst;           // ... and the gradient they receive (accumulated into)
+    int Hu, Wu;
+    int H, W, Th, Tw;
+    long T;                  // tiles
+    int N;
+    FastDiv dTw, dTh;
+};
+
+// rows of A^T for the points 0, +-3/4, +-3/2, inf (oracle/winograd_oracle.py _AT[4])
+__device__ __constant__ float c_wino4_at[4][6] = {{1.f, 1.f, 1.f, 1.f, 1.f, 0.f},
+                                                  {0.f, 0.75f, -0.75f, 1.5f, -1.5f, 0.f},
+                                                  {0.f, 0.5625f, 0.5625f, 2.25f, 2.25f, 0.f},
+                                                  {0.f, 27.f / 64.f, -27.f / 64.f, 27.f / 8.f, -27.f / 8.f, 1.f}};
+template <int JJ, int NU>
+struct WinoAT {      // the same entries at compile time (zero weights drop out of the unrolled accumulation)
+    static constexpr float v = JJ == 0 ? (NU < 5 ? 1.f : 0.f)
+                             : NU == 0 ? 0.f
+                             : NU == 5 ? (JJ == 3 ? 1.f : 0.f)
+                             : JJ == 1 ? (NU == 1 ? 0.75f : NU == 2 ? -0.75f : NU == 3 ? 1.5f : -1.5f)
+                             : JJ == 2 ? (NU <= 2 ? 0.5625f : 2.25f)
+                             : (NU == 1 ? 27.f / 64.f : NU == 2 ? -27.f / 64.f : NU == 3 ? 27.f / 8.f : -27.f / 8.f);
+};
+
+__device__ __forceinline__ f32x4 fma4(float s, f32x4 a, f32x4 b) {
+    f32x4 r;
+    r[0] = fmaf(s, a[0], b[0]); r[1] = fmaf(s, a[1], b[1]); r[2] = fmaf(s, a[2], b[2]); r[3] = fmaf(s, a[3], b[3]);
+    return r;
+}
+
+__device__ __forceinline__ void glds_wait6() { asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); }
+
+template <int KC>      // K = 64 * KC channels of the product
+__global__ __launch_bounds__(256, 2) void wino4_gemm_out_kernel(const FusedParams p) {
+    constexpr int K = 64 * KC;
+    constexpr int S = 36 * KC;                               // stages: (position, 64-channel chunk)
+    constexpr int STG = (32 + 64) * 64;                      // floats per stage: A [32 tiles][64], B [64 channels][64]
+    constexpr int ES = 8 * 64 + 4;                           // epilogue image: floats per tile (2 rows x 4 columns x 64 channels, padded)
+    extern __shared__ __attribute__((aligned(16))) float smem[];      // ring of 3 stages (72 KB); the epilogue image reuses it
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int t0 = blockIdx.x * 32, n0 = blockIdx.y * 64;
+    const int wa = wave & 1, wb = wave >> 1;                 // this wave: tiles 16 wa .. +15, channels 32 wb .. +31
+    const int l15 = lane & 15, kq = lane >> 4;
+
+    // ---- staging roles.  A wave-instruction fills 1 KiB = 4 rows of 64 floats; lane i supplies chunk position i & 15 of
+    // row i >> 4 and fetches the logical chunk position ^ (row & 15) (the same involution on the read side).  A stage is
+    // 6 DMA instructions per wave; the ring is three stages deep (a position's 32 MFMAs last ~0.5 us, less than the
+    // latency of a DMA under load: with one stage in flight the kernel waited on every position).
+    const int rows_valid = (int)min((long)32, p.T - t0);
+    unsigned a_vo[2], b_vo[4];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int row = 4 * (2 * wave + q) + (lane >> 4);
+        a_vo[q] = (unsigned)((row * K + 4 * ((lane & 15) ^ (row & 15))) * 4);      // rows >= rows_valid fall behind num_records
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int row = 4 * (4 * wave + q) + (lane >> 4);
+        b_vo[q] = (unsigned)((row * K + 4 * ((lane & 15) ^ (row & 15))) * 4);
+    }
+    auto stage = [&](int s, int buf) {
+        const int pos = s / KC, c = s - pos * KC;
+        const i32x4 srdA = make_srd(p.V + (long)pos * p.plane_v + (long)t0 * K, (unsigned)rows_valid * (unsigned)K * 4u);
+        const i32x4 srdB = make_srd(p.U + ((long)pos * p.N + n0) * K, 64u * (unsigned)K * 4u);
+        // wave-uniform LDS byte addresses (the DMA takes them through M0): this wave's 2 resp. 4 KiB of the stage
+        const unsigned adst = __builtin_amdgcn_readfirstlane(lds_addr(smem + buf * STG + wave * 2 * 256));
+        const unsigned bdst = __builtin_amdgcn_readfirstlane(lds_addr(smem + buf * STG + 32 * 64 + wave * 4 * 256));
+#pragma unroll
+        for (int q = 0; q < 2; ++q) bglds16(a_vo[q], srdA, (unsigned)(c * 256), adst + q * 1024);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) bglds16(b_vo[q], srdB, (unsigned)(c * 256), bdst + q * 1024);
+    };
+
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 Y[4][4][2];        // [output row i][output column jj][MFMA block j]: component r = tile 4 kq + r of the wave
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) Y[i][jj][0] = Y[i][jj][1] = zero4;
+
+    stage(0, 0);
+    stage(1, 1);
+    glds_wait6();               // stage 0 has landed (stage 1: six instructions in flight)
+    __syncthreads();
+    int cur = 0, s = 0;
+    const int arow = (16 * wa + l15) * 64, brow = 32 * 64 + (32 * wb + l15) * 64;
+    for (int xi = 0; xi < 6; ++xi) {
+        f32x4 Z[4][2];
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) Z[jj][0] = Z[jj][1] = zero4;
+        auto position = [&](auto NU) {
+            constexpr int nu = decltype(NU)::value;
+            f32x4 acc0 = zero4, acc1 = zero4;
+#pragma unroll
+            for (int c = 0; c < KC; ++c, ++s) {
+                const float* as = smem + cur * STG + arow;
+                const float* bs = smem + cur * STG + brow;
+                // fragment double buffering: the reads of group g + 1 fly under the 8 MFMAs of group g
+                float4 fa[2], fb0[2], fb1[2];
+                auto load_frag = [&](int g, int sl) {        // lane (row, kq) holds k = 16 g + 4 kq + t, t = step within the group
+                    const int ch = ((4 * g + kq) ^ l15) << 2;
+                    fa[sl] = ld4(as + ch);
+                    fb0[sl] = ld4(bs + ch);
+                    fb1[sl] = ld4(bs + 16 * 64 + ch);
+                };
+                load_frag(0, 0);
+                const int nxt = cur == 0 ? 2 : cur - 1;      // (cur + 2) % 3: everybody left that buffer before the last barrier
+                if (s + 2 < S) stage(s + 2, nxt);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int sl = g & 1;
+                    if (g + 1 < 4) load_frag(g + 1, sl ^ 1);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[sl].x, fb0[sl].x, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[sl].x, fb1[sl].x, acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[sl].y, fb0[sl].y, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[sl].y, fb1[sl].y, acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[sl].z, fb0[sl].z, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[sl].z, fb1[sl].z, acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[sl].w, fb0[sl].w, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[sl].w, fb1[sl].w, acc1, 0, 0, 0);
+                }
+                if (s + 2 < S) glds_wait6();    // stage s + 1 has landed, stage s + 2 may still fly
+                else glds_wait();
+                __syncthreads();                // ... for everybody; every wave is done reading buf[cur]
+                cur = cur == 2 ? 0 : cur + 1;
+            }
+            // (.) A over the row of positions: Z[jj] += A^T[jj][nu] M_(xi, nu)
+            if constexpr (WinoAT<0, nu>::v != 0.f) { Z[0][0] = fma4(WinoAT<0, nu>::v, acc0, Z[0][0]); Z[0][1] = fma4(WinoAT<0, nu>::v, acc1, Z[0][1]); }
+            if constexpr (WinoAT<1, nu>::v != 0.f) { Z[1][0] = fma4(WinoAT<1, nu>::v, acc0, Z[1][0]); Z[1][1] = fma4(WinoAT<1, nu>::v, acc1, Z[1][1]); }
+            if constexpr (WinoAT<2, nu>::v != 0.f) { Z[2][0] = fma4(WinoAT<2, nu>::v, acc0, Z[2][0]); Z[2][1] = fma4(WinoAT<2, nu>::v, acc1, Z[2][1]); }
+            if constexpr (WinoAT<3, nu>::v != 0.f) { Z[3][0] = fma4(WinoAT<3, nu>::v, acc0, Z[3][0]); Z[3][1] = fma4(WinoAT<3, nu>::v, acc1, Z[3][1]); }
+        };
+        position(std::integral_constant<int, 0>{});
+        position(std::integral_constant<int, 1>{});
+        position(std::integral_constant<int, 2>{});
+        position(std::integral_constant<int, 3>{});
+        position(std::integral_constant<int, 4>{});
+        position(std::integral_constant<int, 5>{});
+        // A^T (.) down the rows of positions: Y[i][jj] += A^T[i][xi] Z[jj]
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float wi = c_wino4_at[i][xi];
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                Y[i][jj][0] = fma4(wi, Z[jj][0], Y[i][jj][0]);
+                Y[i][jj][1] = fma4(wi, Z[jj][1], Y[i][jj][1]);
+            }
+        }
+    }
+
+    // ---- epilogue through LDS, two output rows of every tile per pass.  D of a 16x16 block: lane (l15, kq), component r =
+    // row 4 kq + r, column l15 -- this lane owns tiles 16 wa + 4 kq + r at channels 32 wb + 16 j + l15.  The image
+    // E[tile][row & 1][column][channel] (tile stride padded by 4 floats: the four kq groups land 16 banks apart) is read
+    // back as 16-byte channel quads, a thread per (pixel, quad), so that bias / mask / accumulate / pooling / unpooling and
+    // the stores move 16 B per lane on 256-byte channel segments -- the output transform's own epilogue.
+    const int Hp = p.H >> 1, Wp = p.W >> 1;
+    const WinoUnpool up = {p.up_src, p.up_dst, p.Hu, p.Wu};
+    const int q4 = tid & 15, slot = (tid >> 4) & 7, tsel = tid >> 7;          // reader: channel quad, (row & 1, column), tile parity
+    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p.bias) bv = ld4(p.bias + n0 + 4 * q4);
+#pragma unroll
+    for (int ip = 0; ip < 2; ++ip) {
+        // (the main loop ended with a barrier: the ring is free)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int i2 = 0; i2 < 2; ++i2)
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj)
+                        smem[(16 * wa + 4 * kq + r) * ES + (4 * i2 + jj) * 64 + 32 * wb + 16 * j + l15] = Y[2 * ip + i2][jj][j][r];
+        __syncthreads();
+        const int i = 2 * ip + (slot >> 2), jj = slot & 3;
+#pragma unroll 4
+        for (int it = 0; it < 16; ++it) {
+            const int tl = 2 * it + tsel;
+            const long tile = (long)t0 + tl;
+            if (tile >= p.T) break;
+            const int bi = fast_div((int)tile, p.dTw);
+            const int tj = (int)tile - bi * p.Tw;
+            const int b = fast_div(bi, p.dTh);
+            const int ti = bi - b * p.Th;
+            const int h = 4 * ti + i, w = 4 * tj + jj;
+            if (h >= p.H || w >= p.W) continue;
+            const float4 e = ld4(smem + tl * ES + slot * 64 + 4 * q4);
+            float4 v = make_float4(e.x + bv.x, e.y + bv.y, e.z + bv.z, e.w + bv.w);
+            const long off = (((long)b * p.H + h) * p.W + w) * p.N + n0 + 4 * q4;
+            if (p.mask) {
+                const float4 mk = ld4(p.mask + off);
+                v.x = mk.x > 0.f ? v.x : 0.f; v.y = mk.y > 0.f ? v.y : 0.f;
+                v.z = mk.z > 0.f ? v.z : 0.f; v.w = mk.w > 0.f ? v.w : 0.f;
+            }
+            if (up.src) {            // input gradient at pooled resolution: straight through the max-pool backward
+                wino_unpool_add(up, b, h, w, p.N, n0 + 4 * q4, v);
+                continue;
+            }
+            if (p.accum) {
+                const float4 old = ld4(p.y + off);
+                v = make_float4(v.x + old.x, v.y + old.y, v.z + old.z, v.w + old.w);
+            }
+            st4(p.y + off, v);
+        }
+        if (p.y_pool) {              // forward only (v = Y + bias): the two pooled rows 2 ti + ip of every tile
+            // thread = (tile, window column k, quad): 32 x 2 x 16 = 1024 items
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int item = it * 256 + tid;
+                const int q = item & 15, k = (item >> 4) & 1, tl = item >> 5;
+                const long tile = (long)t0 + tl;
+                if (tile >= p.T) continue;
+                const int bi = fast_div((int)tile, p.dTw);
+                const int tj = (int)tile - bi * p.Tw;
+                const int b = fast_div(bi, p.dTh);
+                const int ti = bi - b * p.Th;
+                const int ph = 2 * ti + ip, pw = 2 * tj + k;
+                if (ph >= Hp || pw >= Wp) continue;
+                const float* e = smem + tl * ES + 4 * q;
+                const float4 b4 = p.bias ? ld4(p.bias + n0 + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+                const float4 e0 = ld4(e + (2 * k) * 64), e1 = ld4(e + (2 * k + 1) * 64), e2 = ld4(e + (4 + 2 * k) * 64), e3 = ld4(e + (5 + 2 * k) * 64);
+                float4 m;
+                m.x = fmaxf(fmaxf(e0.x, e1.x), fmaxf(e2.x, e3.x)) + b4.x;
+                m.y = fmaxf(fmaxf(e0.y, e1.y), fmaxf(e2.y, e3.y)) + b4.y;
+                m.z = fmaxf(fmaxf(e0.z, e1.z), fmaxf(e2.z, e3.z)) + b4.z;
+                m.w = fmaxf(fmaxf(e0.w, e1.w), fmaxf(e2.w, e3.w)) + b4.w;
+                st4(p.y_pool + (((long)b * Hp + ph) * Wp + pw) * p.N + n0 + 4 * q, p.pool_relu ? relu4(m) : m);
+            }
+        }
+        if (ip == 0) __syncthreads();      // everybody has read the image before the second row pair overwrites it
+    }
+}
+
+// WESUP_WINO_FUSED: 0 = never, 1 = forward epilogues only (bias, pooled output), 2 = every epilogue (default)
+static int fused_env_level() {
+    static const int v = [] { const char* e = getenv("WESUP_WINO_FUSED"); return (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 2; }();
+    return v;
+}
+// internal (winograd.hpp): 0 = the fused products + output transform do not cover this product shape; 1 = they do for the
+// forward epilogue; 2 = for every epilogue
+int wino_fused_supported(int K, int N, int m) {
+    return (m == 4 && (K == 64 || K == 128) && N >= 64 && (N % 64) == 0) ? fused_env_level() : 0;
+}
+
+extern "C" int wesup_winograd_fused_supported(int K, int N, int m) { return wino_fused_supported(K, N, m); }
+
+// V [36][tiles][K] (plane stride plane_elems, 0 = tiles * K) x U [36][N][K] -> y = A^T (V_p . U_p^T) A + the output
+// transform's epilogue (wesup_winograd_output_transform / _unpool), without the transformed output in between.
+extern "C" int wesup_winograd_gemm_output_transform(const float* V, long plane_elems, const float* U, const float* bias,
+                                                    const float* mask_src, float* y, float* y_pool, int pool_relu,
+                                                    const float* unpool_src, float* unpool_dst, int Hu, int Wu, int B, int H,
+                                                    int W, int K, int N, int accumulate, void* stream) {
+    if (!V || !U || (!y && !unpool_src) || !wino_shape_ok(B, H, W, K, N, 4) || !(K == 64 || K == 128) || N < 64 || (N % 64) ||
+        (((uintptr_t)V | (uintptr_t)U) & 15) || (plane_elems % 4))
+        return WESUP_ERR_INVALID;
+    const long T = wino_tiles(B, H, W, 4);
+    if (plane_elems > 0 && plane_elems < T * K) return WESUP_ERR_INVALID;
+    if (unpool_src && (!unpool_dst || y_pool || accumulate || Hu / 2 != H || Wu / 2 != W)) return WESUP_ERR_INVALID;
+    if (T > (1l << 31) / 64 || (long)32 * K * 4 >= (1l << 31)) return WESUP_ERR_INVALID;
+    FusedParams p = {};
+    p.V = V; p.plane_v = plane_elems > 0 ? plane_elems : T * K; p.U = U; p.bias = bias; p.mask = mask_src; p.y = y;
+    p.y_pool = y_pool; p.pool_relu = pool_relu; p.accum = accumulate; p.up_src = unpool_src; p.up_dst = unpool_dst;
+    p.Hu = Hu; p.Wu = Wu; p.H = H; p.W = W; p.Th = (H + 3) / 4; p.Tw = (W + 3) / 4; p.T = T; p.N = N;
+    p.dTw = make_fastdiv(p.Tw); p.dTh = make_fastdiv(p.Th);
+    const dim3 grid((unsigned)ceil_div(T, 32l), (unsigned)(N / 64));
+    const size_t lds = (size_t)3 * (32 + 64) * 64 * sizeof(float);       // 72 KiB: above the default dynamic limit
+    {
+        static const hipError_t attr1 = hipFuncSetAttribute(reinterpret_cast<const void*>(wino4_gemm_out_kernel<1>),
+                                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        static const hipError_t attr2 = hipFuncSetAttribute(reinterpret_cast<const void*>(wino4_gemm_out_kernel<2>),
+                                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (attr1 != hipSuccess || attr2 != hipSuccess) return WESUP_ERR_LAUNCH;
+    }
+    if (K == 64) hipLaunchKernelGGL(wino4_gemm_out_kernel<1>, grid, dim3(256), lds, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(wino4_gemm_out_kernel<2>, grid, dim3(256), lds, (hipStream_t)stream, p);
+    WESUP_CHECK_LAUNCH();
+    return WESUP_OK;
+}

@@ -460,39 +460,6 @@ __global__ __launch_bounds__(256) void wino4_outgrad_transform_kernel(const floa
     }
 }
 
-// The max-pool backward that follows an input gradient at pooled resolution (autograd of ReLU -> MaxPool2d(2,2),
-// models/wesup.py:199): the gradient v of pooled pixel (h, w) goes to the FIRST maximum of its 2x2 window of the pre-pool
-// activations (torch's scan order) if that maximum is positive, and is ADDED to what dst holds there (the side-branch
-// gradient).  Only the chosen position is touched: the separate kernel read and re-wrote all four.
-struct WinoUnpool {
-    const float* src;    // pre-pool activations (B, Hu, Wu, C), or NULL: no unpooling
-    float* dst;          // gradient w.r.t. them, same shape, accumulated into
-    int Hu, Wu;
-};
-__device__ __forceinline__ void wino_unpool_add(const WinoUnpool& u, int b, int h, int w, int C, int c0, float4 v) {
-    const long rs = (long)u.Wu * C;
-    const long o00 = (((long)b * u.Hu + 2 * h) * u.Wu + 2 * w) * C + c0;
-    const float4 a0 = ld4(u.src + o00), a1 = ld4(u.src + o00 + C), a2 = ld4(u.src + o00 + rs), a3 = ld4(u.src + o00 + rs + C);
-    auto pick = [](float p0, float p1, float p2, float p3) {
-        int best = 0;
-        float m = p0;
-        if (p1 > m) { m = p1; best = 1; }
-        if (p2 > m) { m = p2; best = 2; }
-        if (p3 > m) { m = p3; best = 3; }
-        return m > 0.f ? best : -1;
-    };
-    const int kx = pick(a0.x, a1.x, a2.x, a3.x), ky = pick(a0.y, a1.y, a2.y, a3.y), kz = pick(a0.z, a1.z, a2.z, a3.z),
-              kw = pick(a0.w, a1.w, a2.w, a3.w);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        if (kx != k && ky != k && kz != k && kw != k) continue;
-        float* d = u.dst + o00 + (k >> 1) * rs + (k & 1) * C;
-        float4 old = ld4(d);
-        old.x += kx == k ? v.x : 0.f; old.y += ky == k ? v.y : 0.f; old.z += kz == k ? v.z : 0.f; old.w += kw == k ? v.w : 0.f;
-        st4(d, old);
-    }
-}
-
 // thread = (tile, 4 channels): Y = A^T M A for the tile's 4x4 outputs, then the conv epilogue on the pixels inside the
 // image; a 4x4 output tile holds four windows of the 2x2 / stride-2 max-pool that may follow the layer
 __global__ __launch_bounds__(256) void wino4_output_transform_kernel(const float* __restrict__ Mt, const float* __restrict__ bias,

@@ -14,9 +14,47 @@ static inline bool wino_shape_ok(int B, int H, int W, int Ci, int Cout, int m) {
     return T < (1l << 24) && T * (cmax / 4) < (1l << 31) && T * (cmax / 4) * (cmax / 4) < (1l << 40);
 }
 
+#ifdef __HIPCC__
+// The max-pool backward that follows an input gradient at pooled resolution (autograd of ReLU -> MaxPool2d(2,2),
+// models/wesup.py:199): the gradient v of pooled pixel (h, w) goes to the FIRST maximum of its 2x2 window of the pre-pool
+// activations (torch's scan order) if that maximum is positive, and is ADDED to what dst holds there (the side-branch
+// gradient).  Only the chosen position is touched: the separate kernel read and re-wrote all four.
+struct WinoUnpool {
+    const float* src;    // pre-pool activations (B, Hu, Wu, C), or NULL: no unpooling
+    float* dst;          // gradient w.r.t. them, same shape, accumulated into
+    int Hu, Wu;
+};
+__device__ __forceinline__ void wino_unpool_add(const WinoUnpool& u, int b, int h, int w, int C, int c0, float4 v) {
+    const long rs = (long)u.Wu * C;
+    const long o00 = (((long)b * u.Hu + 2 * h) * u.Wu + 2 * w) * C + c0;
+    const float4 a0 = ld4(u.src + o00), a1 = ld4(u.src + o00 + C), a2 = ld4(u.src + o00 + rs), a3 = ld4(u.src + o00 + rs + C);
+    auto pick = [](float p0, float p1, float p2, float p3) {
+        int best = 0;
+        float m = p0;
+        if (p1 > m) { m = p1; best = 1; }
+        if (p2 > m) { m = p2; best = 2; }
+        if (p3 > m) { m = p3; best = 3; }
+        return m > 0.f ? best : -1;
+    };
+    const int kx = pick(a0.x, a1.x, a2.x, a3.x), ky = pick(a0.y, a1.y, a2.y, a3.y), kz = pick(a0.z, a1.z, a2.z, a3.z),
+              kw = pick(a0.w, a1.w, a2.w, a3.w);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (kx != k && ky != k && kz != k && kw != k) continue;
+        float* d = u.dst + o00 + (k >> 1) * rs + (k & 1) * C;
+        float4 old = ld4(d);
+        old.x += kx == k ? v.x : 0.f; old.y += ky == k ? v.y : 0.f; old.z += kz == k ? v.z : 0.f; old.w += kw == k ? v.w : 0.f;
+        st4(d, old);
+    }
+}
+
+#endif
+
 // internal entry points of winograd.hip used by the weight-gradient pass in gemm.hip (not part of the C ABI): the F(4x4)
 // bias gradient travels as per-block rows from the outgrad transform to the filter-gradient reduce, with no launch of its own
 long wino4_bias_rows(int B, int H, int W, int C);          // 0: C / 4 does not divide 256 (use wesup_colsum on dy instead)
 int wino_outgrad_launch(const float* dy, float* dM, float* bias_part, int B, int H, int W, int C, int m, void* stream);
 int wino_filter_grad_launch(const float* slabs, long slab_stride, long batch_stride, int S, float* dw_kcrs, float* db, int Cout,
                             int Cin, int m, const float* bias_part, int bias_rows, void* stream);
+// wino_fused.hip: the batched products and the output transform in one kernel (K = 64 / 128, N % 64 == 0, m = 4)
+int wino_fused_supported(int K, int N, int m);      // 0 no, 1 forward epilogue only, 2 every epilogue

@@ -307,6 +307,34 @@ def winograd_output_transform(Mt, B, H, W, bias=None, mask_src=None, out=None, o
     return out
 
 
+def winograd_gemm_output_transform(V, U, B, H, W, bias=None, mask_src=None, out=None, out_pool=None, pool_relu=False,
+                                   accumulate=False, unpool=None):
+    """V (36, tiles, K) x U (36, N, K) -> y (B,H,W,N) = A^T (V_p . U_p^T) A + epilogue, in one kernel (F(4x4,3x3); K = 64 or
+    128, N % 64 == 0).  unpool = (src, dst) (B,Hu,Wu,N): the max-pool backward as the epilogue instead of the store."""
+    _chk(V, name='V'); _chk(U, name='U')
+    P, T, K = V.shape
+    N = U.shape[1]
+    assert P == 36 and U.shape == (36, N, K) and T == winograd_tiles(B, H, W, 4)
+    Hu = Wu = 0
+    us = ud = None
+    if unpool is not None:
+        us, ud = unpool
+        _chk(us, name='unpool_src'); _chk(ud, name='unpool_dst')
+        _, Hu, Wu, _ = us.shape
+        assert us.shape == (B, Hu, Wu, N) == ud.shape and (Hu // 2, Wu // 2) == (H, W) and out is None
+    else:
+        if out is None:
+            assert not accumulate
+            out = torch.empty(B, H, W, N, dtype=torch.float32, device=V.device)
+        assert out.shape == (B, H, W, N) and out.is_contiguous()
+    for t, shape in ((mask_src, (B, H, W, N)), (out_pool, (B, H // 2, W // 2, N))):
+        if t is not None:
+            _chk(t, name='operand'); assert t.shape == shape, (t.shape, shape)
+    _lib.call('wesup_winograd_gemm_output_transform', _p(V), 0, _p(U), _p(bias), _p(mask_src), _p(out), _p(out_pool), int(pool_relu),
+              _p(us), _p(ud), Hu, Wu, B, H, W, K, N, int(accumulate), _stream())
+    return ud if unpool is not None else out
+
+
 def gemm_nt_batched(A, Bw, out=None):
     """out[b] = A[b] @ Bw[b]^T for contiguous (nbatch, M, K) x (nbatch, N, K) -> (nbatch, M, N), one launch."""
     _chk(A, name='A'); _chk(Bw, name='B')
@@ -403,6 +431,17 @@ def _winograd_conv(inp, u, bias, mask_src, out, out_relu, v_keep, relu_in, accum
         if timer:
             timer.end(tok, 4.0 * (P * winograd_tiles(nb_, H, W, m) + (n_io + (0.25 if out_pool is not None else 0)) * nb_ * H * W) * Cout)
 
+    fused = 0 if out_relu is not None else lib.wesup_winograd_fused_supported(Cin, Cout, m)
+    if fused == 2 or (fused == 1 and mask_src is None and not accumulate):
+        # short products (64 / 128 channels): the batched products and the output transform in one kernel
+        st = _stream()
+        t_in(0, B, st)
+        tok = timer.begin('winograd_gemm') if timer else None
+        _lib.call('wesup_winograd_gemm_output_transform', _p(V), T * Cin, _p(u), _p(bias), _p(mask_src), _p(out), _p(out_pool),
+                  int(pool_relu), None, None, 0, 0, B, H, W, Cin, Cout, int(accumulate), st)
+        if timer:
+            timer.end(tok, 2.0 * P * T * Cin * Cout)
+        return out
     half_blocks = ((T // 2 + 127) // 128) * ((Cout + 127) // 128) * P
     if not (PIPELINE_WINOGRAD and B % 2 == 0 and half_blocks >= PIPELINE_MIN_BLOCKS):
         st = _stream()
@@ -493,6 +532,12 @@ def conv3x3_dgrad_winograd_unpool(dy, u_dgrad, unpool_src, unpool_dst, ws_tag='d
     tok = timer.begin('winograd_transform')
     _lib.call('wesup_winograd_input_transform', _p(dy), _p(V), 0, B, H, W, Cout, 0, m, st)
     timer.end(tok, 4.0 * (B * H * W + P * T) * Cout)
+    if lib.wesup_winograd_fused_supported(Cout, Cin, m) == 2:
+        tok = timer.begin('winograd_gemm')
+        _lib.call('wesup_winograd_gemm_output_transform', _p(V), 0, _p(u_dgrad), None, None, None, None, 0, _p(unpool_src),
+                  _p(unpool_dst), Hu, Wu, B, H, W, Cout, Cin, 0, st)
+        timer.end(tok, 2.0 * P * T * Cin * Cout)
+        return unpool_dst
     tok = timer.begin('winograd_gemm')
     _lib.call('wesup_gemm_nt_batched', _p(V), Cout, T * Cout, _p(u_dgrad), Cout, Cin * Cout, _p(Mt), Cin, T * Cin, P, T, Cin, Cout, st)
     timer.end(tok, 2.0 * P * T * Cin * Cout)
