@@ -53,6 +53,12 @@ def _gemm(kernels):
     return {k: v for k, v in kernels.items() if 'gemm_nt_kernel' in k or 'gemm_tn_kernel' in k}
 
 
+def _dma_kernels(kernels):
+    """Every kernel that stages through the LDS-DMA inline asm (the M0 contract applies to all of them): the GEMM family
+    and the fused Winograd products + output transform (csrc/wino_fused.hip)."""
+    return {k: v for k, v in kernels.items() if 'gemm_nt_kernel' in k or 'gemm_tn_kernel' in k or 'wino4_gemm_out_kernel' in k}
+
+
 def test_every_gemm_instantiation_is_there(kernels):
     names = list(_gemm(kernels))
     assert sum('gemm_nt_kernel' in n for n in names) >= 24 and sum('gemm_tn_kernel' in n for n in names) >= 20, names
@@ -60,7 +66,8 @@ def test_every_gemm_instantiation_is_there(kernels):
 
 def test_no_scratch_and_no_foreign_m0_reader(kernels):
     dma = re.compile(r'^(buffer_load_dword\w* .* lds|global_load_lds_dword\w*)')
-    for name, code in _gemm(kernels).items():
+    assert any('wino4_gemm_out_kernel' in k for k in kernels)
+    for name, code in _dma_kernels(kernels).items():
         n_dma = 0
         for ins in code:
             op = ins.split()[0]
@@ -104,9 +111,25 @@ def test_mfma_count_of_the_unrolled_k_step(kernels):
         assert other == 0 and n == BK // 2 * wm * wn + extra, (name, n, other, wm, wn, extra)
 
 
+FP32_MFMA = ('v_mfma_f32_32x32x2_f32', 'v_mfma_f32_32x32x2f32', 'v_mfma_f32_16x16x4_f32', 'v_mfma_f32_16x16x4f32')
+
+
 def test_fp32_mfma_only(kernels):
-    """north_star: fp32 arithmetic -- no reduced-precision matrix instruction anywhere in the library."""
+    """north_star: fp32 arithmetic -- no reduced-precision matrix instruction anywhere in the library (the GEMM family uses
+    the 32x32x2 fp32 MFMA, the fused Winograd kernel the 16x16x4 one: both multiply and accumulate in fp32)."""
     for name, code in kernels.items():
         for ins in code:
             if ins.startswith('v_mfma') or ins.startswith('v_smfmac'):
-                assert ins.startswith('v_mfma_f32_32x32x2_f32') or ins.startswith('v_mfma_f32_32x32x2f32'), (name, ins)
+                assert ins.startswith(FP32_MFMA), (name, ins)
+
+
+def test_fused_winograd_kernel_holds_its_mfmas(kernels):
+    """wino4_gemm_out_kernel<KC>: six positions are unrolled per pass of the position-row loop, 32 KC MFMAs each (K = 64 KC
+    in steps of 4, two 16x16 blocks per wave); a lost unroll shows up as another count, a spill as a scratch instruction."""
+    for name, code in kernels.items():
+        if 'wino4_gemm_out_kernel' not in name:
+            continue
+        kc = int(re.findall(r'Li(\d+)E', name)[0])
+        n = sum(ins.startswith(('v_mfma_f32_16x16x4_f32', 'v_mfma_f32_16x16x4f32')) for ins in code)
+        assert n in (6 * 32 * kc, 36 * 32 * kc), (name, n)         # row loop rolled or fully unrolled
+        assert not any(ins.split()[0].startswith('scratch_') for ins in code), name

@@ -264,8 +264,12 @@ static int fused_env_level() {
 }
 // internal (winograd.hpp): 0 = the fused products + output transform do not cover this product shape; 1 = they do for the
 // forward epilogue; 2 = for every epilogue
+static int fused_max_k() {      // WESUP_WINO_FUSED_MAXK (experiment): the longest product that takes this route (default 256)
+    static const int v = [] { const char* e = getenv("WESUP_WINO_FUSED_MAXK"); const int k = e ? atoi(e) : 256; return (k == 64 || k == 128 || k == 256) ? k : 256; }();
+    return v;
+}
 int wino_fused_supported(int K, int N, int m) {
-    return (m == 4 && (K == 64 || K == 128) && N >= 64 && (N % 64) == 0) ? fused_env_level() : 0;
+    return (m == 4 && (K == 64 || K == 128 || K == 256) && K <= fused_max_k() && N >= 64 && (N % 64) == 0) ? fused_env_level() : 0;
 }
 
 extern "C" int wesup_winograd_fused_supported(int K, int N, int m) { return wino_fused_supported(K, N, m); }
@@ -276,7 +280,7 @@ extern "C" int wesup_winograd_gemm_output_transform(const float* V, long plane_e
                                                     const float* mask_src, float* y, float* y_pool, int pool_relu,
                                                     const float* unpool_src, float* unpool_dst, int Hu, int Wu, int B, int H,
                                                     int W, int K, int N, int accumulate, void* stream) {
-    if (!V || !U || (!y && !unpool_src) || !wino_shape_ok(B, H, W, K, N, 4) || !(K == 64 || K == 128) || N < 64 || (N % 64) ||
+    if (!V || !U || (!y && !unpool_src) || !wino_shape_ok(B, H, W, K, N, 4) || !(K == 64 || K == 128 || K == 256) || N < 64 || (N % 64) ||
         (((uintptr_t)V | (uintptr_t)U) & 15) || (plane_elems % 4))
         return WESUP_ERR_INVALID;
     const long T = wino_tiles(B, H, W, 4);
@@ -295,10 +299,13 @@ extern "C" int wesup_winograd_gemm_output_transform(const float* V, long plane_e
                                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         static const hipError_t attr2 = hipFuncSetAttribute(reinterpret_cast<const void*>(wino4_gemm_out_kernel<2>),
                                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (attr1 != hipSuccess || attr2 != hipSuccess) return WESUP_ERR_LAUNCH;
+        static const hipError_t attr4 = hipFuncSetAttribute(reinterpret_cast<const void*>(wino4_gemm_out_kernel<4>),
+                                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (attr1 != hipSuccess || attr2 != hipSuccess || attr4 != hipSuccess) return WESUP_ERR_LAUNCH;
     }
     if (K == 64) hipLaunchKernelGGL(wino4_gemm_out_kernel<1>, grid, dim3(256), lds, (hipStream_t)stream, p);
-    else hipLaunchKernelGGL(wino4_gemm_out_kernel<2>, grid, dim3(256), lds, (hipStream_t)stream, p);
+    else if (K == 128) hipLaunchKernelGGL(wino4_gemm_out_kernel<2>, grid, dim3(256), lds, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(wino4_gemm_out_kernel<4>, grid, dim3(256), lds, (hipStream_t)stream, p);
     WESUP_CHECK_LAUNCH();
     return WESUP_OK;
 }
