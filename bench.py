@@ -431,17 +431,18 @@ def worker(args):
             # effective rate of the whole op (the Winograd forms execute 4/9 resp. 1/4 of them; it can exceed the peak) and
             # carry no fraction of the peak.
             out['roofline'] = {'bound': 'mfma',
-                               'kernel': 'gemm_nt_kernel (conv3x3 fwd+dgrad GEMM launches: implicit GEMM for the 3/64-channel layers, '
-                                         'batched GEMMs over Winograd F(4x4,3x3)-domain operands for the layers with >= 128 input '
-                                         'channels; fp32 MFMA 32x32x2)',
+                               'kernel': 'the MFMA launches of conv3x3 fwd+dgrad: gemm_nt_kernel (implicit GEMM for the image layer; batched '
+                                         'GEMMs over Winograd F(4x4,3x3)-domain operands for the products with K = 512; fp32 MFMA '
+                                         '32x32x2) and wino4_gemm_out_kernel (products with K <= 256: the 36 products AND the output '
+                                         'transform in one kernel; fp32 MFMA 16x16x4)',
                                'achieved': round(ach_exec, 2), 'peak': PEAK_MFMA_F32_TFLOPS, 'unit': 'TFLOP/s',
                                'frac': round(ach_exec / PEAK_MFMA_F32_TFLOPS, 4),
                                'traffic': conv_in.get('hbm_bytes_per_launch'),
                                'avg_launch_us': round(ms_gemm / nl * 1e3, 2), 'launches_per_step': nl / n_ev,
                                'flop_per_step': fl_exec / n_ev, 'event_timed_steps': n_ev,
-                               'what': 'FLOPs the MFMA pipe executes in the conv forward + input-gradient GEMM launches (the kernel '
-                                       'rocprofv3 --stats lists as gemm_nt_kernel<..,1|2|3,..>) / their HIP-event time inside the '
-                                       'timed region',
+                               'what': 'FLOPs the MFMA pipe executes in the conv forward + input-gradient MFMA launches (rocprofv3 --stats: '
+                                       'gemm_nt_kernel<..,1|2|3,..> and wino4_gemm_out_kernel<..>, whose time includes the fused output '
+                                       'transform) / their HIP-event time inside the timed region',
                                'ms_per_step': {'gemm': round(ms_gemm / n_ev, 3), 'transforms': round((ms_all - ms_gemm) / n_ev, 3)},
                                'effective_direct_form': {'tflops': round(eff, 2), 'flop_per_step': fl_alg,
                                                          'what': 'SURVEY 8(d) algorithmic (direct-form 2*H*W*Cin*Cout*9) FLOPs of '

@@ -35,6 +35,8 @@ def read_pass(d):
 def klass(kernel):
     """conv3x3 fwd+dgrad GEMMs | conv3x3 wgrad GEMMs | scatter_mean | None.  gemm_nt_kernel MODE 1/2 = implicit-GEMM conv,
     MODE 3 = the batched Winograd-domain products (MODE 0: side convs / MLP, not counted here); gemm_tn_kernel likewise."""
+    if 'wino4_gemm_out_kernel' in kernel:      # the batched products + output transform of the short products in one kernel
+        return 'conv3x3_fwd_dgrad'
     m = re.search(r'gemm_nt_kernel<([^>]*)>', kernel)
     if m:
         mode = int(m.group(1).split(',')[5])
@@ -162,7 +164,9 @@ def conv_algorithmic_bytes(B, H, W, wino_min_ci=64, m=4):
     every result written once.  Direct layers (below wino_min_ci input channels) -- fwd: x, w, y; dgrad: dy, w, mask +
     old dx + new dx; wgrad: x, dy, dw.  Winograd-domain layers (F(m x m,3x3), P = (m+2)^2 positions) -- the GEMM launch
     reads the transformed input (P x tiles x Cin), the transformed filter (P x Cin x Cout) and writes the transformed
-    output (P x tiles x Cout); the wgrad launch reads both transformed tensors and writes P filter-gradient slabs."""
+    output (P x tiles x Cout), or, where the product is short (K <= 256: wino4_gemm_out_kernel, products + output transform
+    in one kernel), the output itself (forward: y; input gradient: mask + old + new dx); the wgrad launch reads both
+    transformed tensors and writes P filter-gradient slabs."""
     ch = [(3, 64), (64, 64), (64, 128), (128, 128), (128, 256), (256, 256), (256, 256), (256, 512), (512, 512), (512, 512),
           (512, 512), (512, 512), (512, 512)]
     pool = [False, True, False, True, False, False, True, False, False, True, False, False, False]
@@ -173,7 +177,11 @@ def conv_algorithmic_bytes(B, H, W, wino_min_ci=64, m=4):
         cin = 4 if l == 0 else ci
         if ci >= wino_min_ci:
             T, P = B * ((h + m - 1) // m) * ((w + m - 1) // m), (m + 2) ** 2
-            nt += 2 * 4.0 * P * (T * ci + ci * co + T * co)           # fwd and dgrad launches
+            for k, n, outs in ((ci, co, 1.0), (co, ci, 3.0)):         # fwd (K = ci: writes y), dgrad (K = co: mask + old + new dx)
+                if m == 4 and k <= 256 and n % 64 == 0:               # fused products + output transform
+                    nt += 4.0 * (P * T * k + P * k * n + outs * px * n)
+                else:
+                    nt += 4.0 * P * (T * k + k * n + T * n)
             n_nt += 2
             tn += 4.0 * P * (T * ci + T * co + ci * co)
             n_tn += 1
