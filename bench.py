@@ -61,6 +61,8 @@ def parse_args(argv=None):
                     help='A/B: m of the Winograd F(m x m, 3x3) domain for the wide layers (default: the engine\'s, 4; 2 = round 2)')
     ap.add_argument('--direct-wgrad', action='store_true', help='A/B: every conv weight gradient with the direct '
                                                                 'implicit-GEMM kernel (no Winograd-domain wgrad)')
+    ap.add_argument('--subbatch-mb', type=int, default=-1, help='A/B: fused Winograd layers whose transformed input exceeds this many '
+                                                                'MB run image group by image group (0: whole batch; default: ops.py)')
     ap.add_argument('--chain-priority', type=int, default=0, help='experiment: run the step on a stream of this priority '
                                                                   '(negative = higher than the side / wgrad streams)')
     ap.add_argument('--event-every', type=int, default=10, help='steps of the timed region that carry HIP events: every n-th')
@@ -254,6 +256,9 @@ def worker(args):
         type(trainer.model.engine).WINOGRAD_CONV_MIN_CI = args.winograd_min_ci
     if args.winograd_tile:
         type(trainer.model.engine).WINOGRAD_TILE = args.winograd_tile
+    if args.subbatch_mb >= 0:
+        from wesup_amd import ops as _ops3
+        _ops3.SUBBATCH_V_BYTES = args.subbatch_mb << 20
     if args.winograd_pipeline:
         from wesup_amd import ops as _ops2
         _ops2.PIPELINE_WINOGRAD = True

@@ -381,7 +381,7 @@ def test_conv3x3_dgrad_winograd(ops, B, H, W, Cin, Cout, m):
 
 
 @pytest.mark.parametrize('B,H,W,K,N', [(2, 24, 16, 64, 64), (1, 37, 41, 64, 128), (3, 9, 8, 128, 64), (1, 2, 2, 64, 64),
-                                       (1, 120, 120, 128, 128), (2, 30, 30, 128, 256)])
+                                       (1, 120, 120, 128, 128), (2, 30, 30, 128, 256), (1, 60, 60, 256, 128), (2, 15, 15, 256, 256)])
 def test_winograd_products_and_output_transform_in_one_kernel(ops, B, H, W, K, N):
     """wesup_winograd_gemm_output_transform (short products: the batched GEMM and the output transform in one kernel, the
     transformed output never written) against the two separate entries on the same transformed input, for every epilogue

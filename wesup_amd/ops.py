@@ -364,6 +364,10 @@ def winograd_filter_grad(slabs, dw=None, db=None, m=2):
     return dw, db
 
 
+# Fused short products: transformed inputs above this size are processed in image groups that fit the memory-side cache
+# (256 MB Infinity Cache on MI355X); 0 = always the whole batch.  bench.py --subbatch-mb for the A/B.
+SUBBATCH_V_BYTES = 0
+
 _aux_streams = {}
 # transforms of one half of the batch under the GEMM of the other half (helper stream): bit-identical and tested, OFF --
 # measured 13.74 -> 13.97 ms per step (the step is bound by the chip's total throughput, not by its chain)
@@ -433,14 +437,26 @@ def _winograd_conv(inp, u, bias, mask_src, out, out_relu, v_keep, relu_in, accum
 
     fused = 0 if out_relu is not None else lib.wesup_winograd_fused_supported(Cin, Cout, m)
     if fused == 2 or (fused == 1 and mask_src is None and not accumulate):
-        # short products (64 / 128 channels): the batched products and the output transform in one kernel
+        # short products (64 ... 256 channels): the batched products and the output transform in one kernel
         st = _stream()
-        t_in(0, B, st)
-        tok = timer.begin('winograd_gemm') if timer else None
-        _lib.call('wesup_winograd_gemm_output_transform', _p(V), T * Cin, _p(u), _p(bias), _p(mask_src), _p(out), _p(out_pool),
-                  int(pool_relu), None, None, 0, 0, B, H, W, Cin, Cout, int(accumulate), st)
-        if timer:
-            timer.end(tok, 2.0 * P * T * Cin * Cout)
+        # Sub-batches: a layer whose transformed input is larger than the memory-side cache goes image group by image
+        # group -- transform, then products, of one group before the next -- so that the products read V from the cache
+        # the transform just filled instead of from HBM (both passes are HBM-bound at these widths); the groups write their
+        # rows of the same planes, so the kept V and the result are those of the whole-batch call.
+        group = B
+        if SUBBATCH_V_BYTES and 4 * P * T * Cin > SUBBATCH_V_BYTES:
+            group = max(1, int(B * SUBBATCH_V_BYTES // (4 * P * T * Cin)))
+        for b0 in range(0, B, group):
+            nb_ = min(group, B - b0)
+            t_in(b0, nb_, st)
+            tok = timer.begin('winograd_gemm') if timer else None
+            t0, tn = winograd_tiles(b0, H, W, m), winograd_tiles(nb_, H, W, m)
+            sl = slice(b0, b0 + nb_)
+            _lib.call('wesup_winograd_gemm_output_transform', ctypes.c_void_p(V.data_ptr() + 4 * t0 * Cin), T * Cin, _p(u), _p(bias),
+                      _p(None if mask_src is None else mask_src[sl]), _p(out[sl]), _p(None if out_pool is None else out_pool[sl]),
+                      int(pool_relu), None, None, 0, 0, nb_, H, W, Cin, Cout, int(accumulate), st)
+            if timer:
+                timer.end(tok, 2.0 * P * tn * Cin * Cout)
         return out
     half_blocks = ((T // 2 + 127) // 128) * ((Cout + 127) // 128) * P
     if not (PIPELINE_WINOGRAD and B % 2 == 0 and half_blocks >= PIPELINE_MIN_BLOCKS):
