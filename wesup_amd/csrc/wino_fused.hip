@@ -31,7 +31,9 @@ struct FusedParams {
     int H, W, Th, Tw;
     long T;                  // tiles
     int N;
-    FastDiv dTw, dTh;
+    int n_fastest;           // block order: 1 = the channel blocks of one tile set run together on one XCD (see the kernel)
+    int tile_blocks, n_blocks;
+    FastDiv dTw, dTh, dNb;
 };
 
 // rows of A^T for the points 0, +-3/4, +-3/2, inf (oracle/winograd_oracle.py _AT[4])
@@ -65,7 +67,22 @@ __global__ __launch_bounds__(256, 2) void wino4_gemm_out_kernel(const FusedParam
     constexpr int ES = 8 * 64 + 4;                           // epilogue image: floats per tile (2 rows x 4 columns x 64 channels, padded)
     extern __shared__ __attribute__((aligned(16))) float smem[];      // ring of 3 stages (72 KB); the epilogue image reuses it
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int t0 = blockIdx.x * 32, n0 = blockIdx.y * 64;
+    // Block order.  The channel blocks of one tile set read the same rows of V, the tile sets of one channel block the
+    // same filter planes.  The grid is walked XCD by XCD with the channel block fastest: the N / 64 readers of a tile set sit
+    // behind one L2 at the same time and V comes from HBM once (tile-set fastest, the hardware order, re-read it N / 64
+    // times: fetch past L2 per launch 293 -> 215 MiB at K = 128, 296 -> 159 MiB at K = 256, although the filter planes of
+    // all channel blocks -- up to 9.4 MB -- then share that L2; the step time is the same within noise).
+    // WESUP_WINO_FUSED_NFAST_KB: filter sets above this size keep the tile set fastest (default: none do).
+    int tb, nb;
+    if (p.n_fastest) {
+        const int L = xcd_remap(blockIdx.x, p.tile_blocks * p.n_blocks);
+        tb = fast_div(L, p.dNb);
+        nb = L - tb * p.n_blocks;
+    } else {
+        nb = blockIdx.x / p.tile_blocks;
+        tb = blockIdx.x - nb * p.tile_blocks;
+    }
+    const int t0 = tb * 32, n0 = nb * 64;
     const int wa = wave & 1, wb = wave >> 1;                 // this wave: tiles 16 wa .. +15, channels 32 wb .. +31
     const int l15 = lane & 15, kq = lane >> 4;
 
@@ -292,7 +309,11 @@ extern "C" int wesup_winograd_gemm_output_transform(const float* V, long plane_e
     p.y_pool = y_pool; p.pool_relu = pool_relu; p.accum = accumulate; p.up_src = unpool_src; p.up_dst = unpool_dst;
     p.Hu = Hu; p.Wu = Wu; p.H = H; p.W = W; p.Th = (H + 3) / 4; p.Tw = (W + 3) / 4; p.T = T; p.N = N;
     p.dTw = make_fastdiv(p.Tw); p.dTh = make_fastdiv(p.Th);
-    const dim3 grid((unsigned)ceil_div(T, 32l), (unsigned)(N / 64));
+    p.tile_blocks = (int)ceil_div(T, 32l); p.n_blocks = N / 64; p.dNb = make_fastdiv(p.n_blocks);
+    static const long u_limit = [] { const char* e = getenv("WESUP_WINO_FUSED_NFAST_KB"); return (e ? atol(e) : 65536l) * 1024l; }();
+    p.n_fastest = (p.n_blocks > 1 && (long)36 * N * K * 4 <= u_limit) ? 1 : 0;
+    if ((long)p.tile_blocks * p.n_blocks >= (1l << 24)) return WESUP_ERR_INVALID;
+    const dim3 grid((unsigned)(p.tile_blocks * p.n_blocks));
     const size_t lds = (size_t)3 * (32 + 64) * 64 * sizeof(float);       // 72 KiB: above the default dynamic limit
     {
         static const hipError_t attr1 = hipFuncSetAttribute(reinterpret_cast<const void*>(wino4_gemm_out_kernel<1>),
