@@ -61,6 +61,8 @@ def parse_args(argv=None):
                     help='A/B: m of the Winograd F(m x m, 3x3) domain for the wide layers (default: the engine\'s, 4; 2 = round 2)')
     ap.add_argument('--direct-wgrad', action='store_true', help='A/B: every conv weight gradient with the direct '
                                                                 'implicit-GEMM kernel (no Winograd-domain wgrad)')
+    ap.add_argument('--side-wgrad-interleaved', action='store_true', help='A/B: side-conv weight gradients layer by layer between the '
+                                                                          'G_l GEMMs (round 2\'s order) instead of behind all of them')
     ap.add_argument('--subbatch-mb', type=int, default=-1, help='A/B: fused Winograd layers whose transformed input exceeds this many '
                                                                 'MB run image group by image group (0: whole batch; default: ops.py)')
     ap.add_argument('--chain-priority', type=int, default=0, help='experiment: run the step on a stream of this priority '
@@ -251,6 +253,7 @@ def worker(args):
     trainer.model.engine.fuse_pool_bwd = not args.unfused_pool_bwd
     trainer.model.engine.fuse_side_fwd = not args.no_side_fusion
     trainer.model.engine.wgrad_winograd = not args.direct_wgrad
+    trainer.model.engine.side_wgrad_last = not args.side_wgrad_interleaved
     trainer.model.engine.conv_winograd = not args.direct_conv
     if args.winograd_min_ci:
         type(trainer.model.engine).WINOGRAD_CONV_MIN_CI = args.winograd_min_ci

@@ -136,6 +136,8 @@ class WesupEngine:
         # the max-pool backward behind conv2_1 / conv3_1 / conv4_1 / conv5_1 as the epilogue of their F(4x4) input gradient:
         # no gradient tensor at pooled resolution, one position of each window updated instead of four re-written
         self.fuse_unpool = True
+        # side branch of backward: every G_l (what the dgrad chain waits for) before the side convs' own weight gradients
+        self.side_wgrad_last = True
         self.route_fn = default_route    # (ci, co, h, w, B) -> 0 | 2 | 4, consulted per layer and shape
         self._route = None               # the 13 tile sizes of the current / most recent shape
         self._side_stream = None
@@ -574,6 +576,21 @@ class WesupEngine:
                         T.end(tok, 4.0 * B * (h * w * (CONV_CH[l][1] // 2) + H * W + Kmax * (CONV_CH[l][1] // 2)))
                         ds_ready[l] = torch.cuda.Event()
                         ds_ready[l].record()
+        ds2ds = [None] * 13
+
+        def side_wgrad(l):
+            co = CONV_CH[l][1]
+            h, w = b.dims[l]
+            off = SIDE_OFF[l]
+            P = B * h * w
+            tok = T.begin('side_bwd')
+            ops.gemm_tn(ds2ds[l], b.y[l].view(P, co), out=g[f'side_conv{off}.weight'].view(co // 2, co), ws_tag='side',
+                        colsum=g[f'side_conv{off}.bias'])
+            T.end(tok, 2.0 * P * co * (co // 2))
+            # reported from the side stream, layer by layer (the reducer orders a bucket behind every stream that
+            # contributed to it): the side-conv gradients leave with the head's bucket instead of after the final join
+            ready([f'side_conv{off}.weight', f'side_conv{off}.bias'])
+
         with self._OnSide(self):
             for l in range(12, -1, -1):
                 ci, co = CONV_CH[l]
@@ -603,19 +620,21 @@ class WesupEngine:
                     ops.upsample_bwd(b.dfm, off, h, w, co // 2, out=b.ds[l])
                     ds2d = b.ds[l].view(P, co // 2)
                 T.end(tok, 4.0 * B * ((h * w * (co // 2) + H * W + Kmax * (co // 2)) if self.fuse_pool_bwd else H * W * (co // 2)))
-                tok = T.begin('side_bwd')
-                y2d = b.y[l].view(P, co)
+                ds2ds[l] = ds2d
                 if l >= lowest:              # G_l is only needed by backbone layers that train
+                    tok = T.begin('side_bwd')
                     ops.gemm_nt(ds2d, pk.sideT[l], None, out=b.G[l].view(P, co))
+                    T.end(tok, 2.0 * P * co * (co // 2))
                     if self.two_streams:
                         g_ready[l] = torch.cuda.Event()
                         g_ready[l].record()
-                ops.gemm_tn(ds2d, y2d, out=g[f'side_conv{off}.weight'].view(co // 2, co), ws_tag='side',
-                            colsum=g[f'side_conv{off}.bias'])
-                T.end(tok, (4.0 if l >= lowest else 2.0) * P * co * (co // 2))
-                # reported from the side stream, layer by layer (the reducer orders a bucket behind every stream that
-                # contributed to it): the side-conv gradients leave with the head's bucket instead of after the final join
-                ready([f'side_conv{off}.weight', f'side_conv{off}.bias'])
+                if not self.side_wgrad_last:
+                    side_wgrad(l)
+            # The side convs' own weight gradients are parameter gradients nobody waits for before the optimiser, while the
+            # dgrad chain waits for every G_l: all the G_l first (13 GEMMs), the weight gradients behind them.
+            if self.side_wgrad_last:
+                for l in range(12, -1, -1):
+                    side_wgrad(l)
         # ---- main path, conv5_3 down to conv1_1.  The dgrad chain stays on the caller's stream; each layer's wgrad
         # (which only produces parameter gradients) goes to a third stream so that it fills the tails of the dgrad
         # kernels instead of sitting on the critical path.
