@@ -138,6 +138,10 @@ class WesupEngine:
         self.fuse_unpool = True
         # side branch of backward: every G_l (what the dgrad chain waits for) before the side convs' own weight gradients
         self.side_wgrad_last = True
+        # stream-K tail for the MLP head's GEMMs (2304 rows at c2: 144 tiles on 512 block slots; nothing runs beside the head
+        # between forward and backward): measured, no difference in the step (10.08 / 10.12 / 10.15 vs 10.09 / 10.10 / 10.13 ms,
+        # bench.py --head-streamk), so plain tiling as everywhere else in the step
+        self.head_streamk = False
         self.route_fn = default_route    # (ci, co, h, w, B) -> 0 | 2 | 4, consulted per layer and shape
         self._route = None               # the 13 tile sizes of the current / most recent shape
         self._side_stream = None
@@ -467,9 +471,10 @@ class WesupEngine:
             T.end(tok, 4.0 * B * (FM_CHANNELS * H * W + H * W + Kmax * FM_CHANNELS))
         R = B * Kmax
         tok = T.begin('mlp_fwd')
-        ops.gemm_nt(b.sp_in.view(R, FM_CHANNELS), p['fc_layers.0.weight'], p['fc_layers.0.bias'], out=b.h1, flags=ops.RELU_OUT)
-        ops.gemm_nt(b.h1, p['fc_layers.2.weight'], p['fc_layers.2.bias'], out=b.h2, flags=ops.RELU_OUT)
-        ops.gemm_nt(b.h2, p['fc_layers.4.weight'], p['fc_layers.4.bias'], out=b.feats, flags=ops.RELU_OUT)
+        sk = self.head_streamk or None           # None: ops.STREAMK_GEMM decides
+        ops.gemm_nt(b.sp_in.view(R, FM_CHANNELS), p['fc_layers.0.weight'], p['fc_layers.0.bias'], out=b.h1, flags=ops.RELU_OUT, streamk=sk)
+        ops.gemm_nt(b.h1, p['fc_layers.2.weight'], p['fc_layers.2.bias'], out=b.h2, flags=ops.RELU_OUT, streamk=sk)
+        ops.gemm_nt(b.h2, p['fc_layers.4.weight'], p['fc_layers.4.bias'], out=b.feats, flags=ops.RELU_OUT, streamk=sk)
         T.end(tok, 2.0 * R * (FM_CHANNELS * 1024 + 1024 * 1024 + 1024 * self.D))
         ops.classifier_fwd(b.feats, p['classifier.0.weight'], p['classifier.0.bias'], b.sp_pred)
         sp_pred3 = b.sp_pred.view(B, Kmax, 2)
@@ -523,13 +528,14 @@ class WesupEngine:
         off_chain = self.two_streams and getattr(self, 'head_wgrad_off_chain', True)
         if not off_chain:
             ops.gemm_tn(b.dfeat, b.h2, out=g['fc_layers.4.weight'], colsum=g['fc_layers.4.bias'])
-        ops.gemm_nt(b.dfeat, pk.fcT[2], None, out=b.dh2, mask=b.h2)
+        sk = self.head_streamk or None
+        ops.gemm_nt(b.dfeat, pk.fcT[2], None, out=b.dh2, mask=b.h2, streamk=sk)
         if not off_chain:
             ops.gemm_tn(b.dh2, b.h1, out=g['fc_layers.2.weight'], colsum=g['fc_layers.2.bias'])
-        ops.gemm_nt(b.dh2, pk.fcT[1], None, out=b.dh1, mask=b.h1)
+        ops.gemm_nt(b.dh2, pk.fcT[1], None, out=b.dh1, mask=b.h1, streamk=sk)
         if not off_chain:
             ops.gemm_tn(b.dh1, b.sp_in.view(R, FM_CHANNELS), out=g['fc_layers.0.weight'], colsum=g['fc_layers.0.bias'])
-        ops.gemm_nt(b.dh1, pk.fcT[0], None, out=gsp2d)
+        ops.gemm_nt(b.dh1, pk.fcT[0], None, out=gsp2d, streamk=sk)
         T.end(tok, (4.0 if not off_chain else 2.0) * R * (FM_CHANNELS * 1024 + 1024 * 1024 + 1024 * D))
         if off_chain:
             wgs = self._wg()

@@ -594,8 +594,10 @@ def _ld(t):
     return t.stride(0)
 
 
-def gemm_nt(A, Bw, bias=None, out=None, mask=None, flags=0):
-    """out[M][N] = epi(A[M][K] @ Bw[N][K]^T + bias).  A/out/mask may be row-strided 2-D views."""
+def gemm_nt(A, Bw, bias=None, out=None, mask=None, flags=0, streamk=None):
+    """out[M][N] = epi(A[M][K] @ Bw[N][K]^T + bias).  A/out/mask may be row-strided 2-D views.
+    streamk: True / False overrides STREAMK_GEMM for this call (the stream-K tail pays where nothing else runs beside the
+    GEMM: the MLP head between the forward and the backward convolutions)."""
     for t, n in ((A, 'A'), (Bw, 'B')):
         if not t.is_cuda or t.dtype != torch.float32:
             raise _lib.WesupHipError(f'{n}: expected float32 CUDA/HIP tensor')
@@ -612,7 +614,7 @@ def gemm_nt(A, Bw, bias=None, out=None, mask=None, flags=0):
         flags |= MASK
     if bias is not None:
         _chk(bias, name='bias'); assert bias.numel() == N
-    nb = _lib.load().wesup_gemm_nt_workspace_bytes(M, N, K) if STREAMK_GEMM else 0
+    nb = _lib.load().wesup_gemm_nt_workspace_bytes(M, N, K) if (STREAMK_GEMM if streamk is None else streamk) else 0
     _lib.call('wesup_gemm_nt', _p(A), _ld(A), _p(Bw), _ld(Bw), _p(bias), _p(out), _ld(out), _p(mask), ldmask, M, N, K,
               flags, _p(_nt_workspace(nb, A.device)), nb, _stream())
     return out
