@@ -142,6 +142,7 @@ class WesupEngine:
         # between forward and backward): measured, no difference in the step (10.08 / 10.12 / 10.15 vs 10.09 / 10.10 / 10.13 ms,
         # bench.py --head-streamk), so plain tiling as everywhere else in the step
         self.head_streamk = False
+        self._diag_skip = set()          # TIMING-ONLY diagnostics (bench.py --diag-skip): classes of launches left out, results wrong
         self.route_fn = default_route    # (ci, co, h, w, B) -> 0 | 2 | 4, consulted per layer and shape
         self._route = None               # the 13 tile sizes of the current / most recent shape
         self._side_stream = None
@@ -585,6 +586,8 @@ class WesupEngine:
         ds2ds = [None] * 13
 
         def side_wgrad(l):
+            if 'side_wgrad' in self._diag_skip:
+                return
             co = CONV_CH[l][1]
             h, w = b.dims[l]
             off = SIDE_OFF[l]
@@ -669,7 +672,7 @@ class WesupEngine:
                     ops.conv3x3_wgrad(x_in, b.G[l], ci, relu_in=relu_x, dw=dw, db=db, ws_tag=ws_tag)
                     T.end(tok, 2.0 * B * h * w * ci * co * 9)
                 ready([f'backbone.{idx}.weight', f'backbone.{idx}.bias'])
-            if not trainable[l]:
+            if not trainable[l] or 'wgrad' in self._diag_skip:
                 pass
             elif wg is not None:
                 wg.wait_stream(main)                       # G_l is final here
