@@ -152,3 +152,18 @@ def test_record_dir_bookkeeping(tmp_path, monkeypatch):
     curves = record.plot_learning_curves(rd / 'history.csv')
     assert sorted(p.name for p in curves) == ['dice.png', 'loss.png'] and all(p.stat().st_size > 1000 for p in curves)
     assert 'dice' in t.report() and 'val_dice' in t.report() and 'loss' not in t.report().split('\n', 3)[-1]
+
+
+def test_default_route_of_the_conv_layers():
+    """wesup_amd.engine.default_route: the algorithm per 3x3 layer -- implicit GEMM for the image layer, Winograd F(4x4,3x3)
+    from 64 input channels up (measured per layer and pass at 480 / 800 / 1024: profiles/r03*_wino_table.txt); the class
+    attributes are what bench.py's A/B flags change."""
+    from wesup_amd.engine import CONV_CH, WesupEngine, default_route
+    assert [default_route(ci, co, 480, 480, 4) for ci, co in CONV_CH] == [0] + [4] * 12
+    assert WesupEngine.WINOGRAD_CONV_MIN_CI == 64 and WesupEngine.WINOGRAD_TILE == 4
+    old = WesupEngine.WINOGRAD_CONV_MIN_CI, WesupEngine.WINOGRAD_TILE
+    try:
+        WesupEngine.WINOGRAD_CONV_MIN_CI, WesupEngine.WINOGRAD_TILE = 128, 2          # round 2's routing
+        assert [default_route(ci, co, 60, 60, 4) for ci, co in CONV_CH] == [0, 0, 0] + [2] * 10
+    finally:
+        WesupEngine.WINOGRAD_CONV_MIN_CI, WesupEngine.WINOGRAD_TILE = old
