@@ -165,6 +165,12 @@ int wesup_winograd_input_transform(const float* x, float* V, long plane_elems, i
                                    int m, void* stream);
 int wesup_gemm_nt_batched(const float* A, int lda, long strideA, const float* B, int ldb, long strideB,
                           float* C, int ldc, long strideC, int nbatch, int M, int N, int K, void* stream);
+/* ... with a bias vector per product (strideBias elements apart; bias may be NULL): several 1x1 side convs of one shape
+ * (models/wesup.py:208-209,253: Conv2d(C, C/2, 1) on the hooked conv outputs of the layers that share a resolution) and their
+ * input gradients as one launch each */
+int wesup_gemm_nt_batched_bias(const float* A, int lda, long strideA, const float* B, int ldb, long strideB,
+                               const float* bias, long strideBias, float* C, int ldc, long strideC,
+                               int nbatch, int M, int N, int K, void* stream);
 int wesup_winograd_output_transform(const float* Mt, long plane_elems, const float* bias, const float* mask_src, float* y,
                                     float* y_relu, float* y_pool, int pool_relu, int B, int H, int W, int C,
                                     int accumulate, int m, void* stream);

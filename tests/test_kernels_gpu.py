@@ -572,6 +572,29 @@ def test_gemm_tn_batched(ops):
         assert rel_err(ops.gemm_tn(A[i], Bm[i]), ref[i]) < TOL
 
 
+def test_gemm_nt_group_one_launch_with_per_product_bias(ops):
+    """wesup_gemm_nt_batched_bias through ops.gemm_nt_group: three side convs of one resolution (weights and biases views of
+    one flat parameter buffer, outputs column slices of the side-feature matrix) in one launch -- the numbers of three
+    single launches, bit for bit; unequally spaced operands launch nothing and return False."""
+    d = dev()
+    P, co, cs = 900, 512, 256
+    y = rnd(3, P, co, seed=1).to(d)
+    flat = (rnd(3 * (cs * co + cs), seed=2) * 0.05).to(d)
+    step = cs * co + cs
+    ws = [flat[i * step:i * step + cs * co].view(cs, co) for i in range(3)]
+    bs = [flat[i * step + cs * co:(i + 1) * step] for i in range(3)]
+    s = torch.zeros(P, 3 * cs + 64, device=d)
+    outs = [s[:, cs * i:cs * (i + 1)] for i in range(3)]
+    assert ops.gemm_nt_group([y[i] for i in range(3)], ws, bs, outs) is True
+    assert float(s[:, 3 * cs:].abs().max()) == 0.0
+    for i in range(3):
+        ref = y[i].double().cpu() @ ws[i].double().cpu().t() + bs[i].double().cpu()
+        assert rel_err(outs[i], ref.float()) < TOL
+        assert torch.equal(ops.gemm_nt(y[i], ws[i], bs[i]), outs[i])
+    before = s.clone()
+    assert ops.gemm_nt_group([y[0], y[2], y[1]], ws, bs, outs) is False and torch.equal(before, s)
+
+
 # ---------------------------------------------------------------- maxpool / upsample
 @pytest.mark.parametrize('B,H,W,C', [(2, 8, 6, 64), (1, 30, 30, 512), (1, 10, 14, 128)])
 def test_maxpool(ops, B, H, W, C):

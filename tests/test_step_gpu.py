@@ -43,7 +43,7 @@ def make_trainer(weights, **kw):
 
 
 @pytest.mark.parametrize('name', CASES)
-@pytest.mark.parametrize('fused', [True, False, 'side_as_gemm', 'direct_convs'])
+@pytest.mark.parametrize('fused', [True, False, 'side_as_gemm', 'direct_convs', 'batched_side'])
 def test_step_matches_reference_golden(golden_dir, name, fused):
     from oracle import wesup_oracle as orc
     from wesup_amd.models.wesup import preprocess_label_maps, SuperpixelMaps
@@ -56,6 +56,8 @@ def test_step_matches_reference_golden(golden_dir, name, fused):
     model.engine.fuse_side_fwd = fused != 'side_as_gemm'     # default: the side convs of conv1_1..conv2_1 inside the conv epilogue
     if fused == 'direct_convs':       # every conv pass on the implicit-GEMM kernels (default: Winograd domain from 128 channels up)
         model.engine.conv_winograd = model.engine.wgrad_winograd = False
+    # the side convs (and the initial input gradients) of conv4_x / conv5_x as one batched launch per resolution
+    model.engine.batch_side_convs = fused == 'batched_side'
     fused = bool(fused)
     model.engine.fuse_pool_bwd = fused
     model.engine.fuse_pool_fwd = fused

@@ -51,6 +51,7 @@ _SIGS = {
     'wesup_winograd_gemm_output_transform': (c_int, 'plpppppippiiiiiiiip'),
     'wesup_winograd_input_transform': (c_int, 'ppliiiiiip'),
     'wesup_gemm_nt_batched': (c_int, 'pilpilpiliiiip'),
+    'wesup_gemm_nt_batched_bias': (c_int, 'pilpilplpiliiiip'),
     'wesup_winograd_output_transform': (c_int, 'plpppppiiiiiiip'),
     'wesup_winograd_outgrad_workspace_bytes': (c_size_t, 'iiiii'),
     'wesup_winograd_outgrad_transform': (c_int, 'pppiiiiipzp'),

@@ -59,6 +59,7 @@ struct NtParams {
     int nbatch;              // 0 / 1: a single product
     FastDiv dTiles;          // tiles per product
     long batchA, batchB, batchC;   // element strides between the products' operands
+    long batchBias;                // ... and between their bias vectors (0: one bias for all)
     // fused 1x1 side conv (SIDE instantiations, N == BN, no stream-K): side_out[m][0..N/2) = C[m][:] . side_w^T + side_bias
     const float* side_w;     // [N/2][N] row-major
     const float* side_bias;  // [N/2] or NULL
@@ -129,11 +130,11 @@ __global__ __launch_bounds__(NW * 64, MINB) void gemm_nt_kernel(const NtParams p
     }
     // n fastest: the N-tiles of one pixel tile run together and share the activation rows through their XCD's L2
     // (the m-fastest order, which keeps a weight slab in L2 instead, measured within 1 %)
-    long zA = 0, zB = 0, zC = 0;
+    long zA = 0, zB = 0, zC = 0, zBias = 0;
     if (MODE == 3) {      // batched plain GEMMs: an instantiation of its own (and a kernel name of its own in profiles)
         const int z = fast_div(lt, p.dTiles);
         lt -= z * p.tiles_m * p.tiles_n;
-        zA = z * p.batchA; zB = z * p.batchB; zC = z * p.batchC;
+        zA = z * p.batchA; zB = z * p.batchB; zC = z * p.batchC; zBias = z * p.batchBias;
     }
     const int tile_n = lt % p.tiles_n, tile_m = lt / p.tiles_n;
     const int m_blk = tile_m * BM, n_blk = tile_n * BN;
@@ -298,7 +299,7 @@ __global__ __launch_bounds__(NW * 64, MINB) void gemm_nt_kernel(const NtParams p
     const int n = n_blk + 4 * cq;
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
     float4 bv = zero4;
-    if (!SIDE && !sk && p.bias && n < p.N) bv = ld4(p.bias + n);
+    if (!SIDE && !sk && p.bias && n < p.N) bv = ld4(p.bias + zBias + n);
     float* raw = sk ? p.sk_ws + ((long)part * 2 + slot) * (BM * BN) : nullptr;
     // Fused side conv: the LDS image of the output rows (bias already added) is the A operand of a second, small GEMM
     // against the 1x1 side weights: wave (sr0, sc0) of an (HR/32) x (BN/64) grid computes 32 rows x 32 side channels
@@ -1409,6 +1410,27 @@ extern "C" int wesup_gemm_nt_batched(const float* A, int lda, long strideA, cons
     p.A = A; p.Bw = Bw; p.C = C;
     p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldmask = ldc;
     p.nbatch = nbatch; p.batchA = strideA; p.batchB = strideB; p.batchC = strideC;
+    hipStream_t st = (hipStream_t)stream;
+    if (N > 64 && t128 >= 384) return launch_nt<4, 128, 128, 2, 2, 3, 2, false>(p, st);
+    return launch_nt<4, 64, 64, 1, 1, 3, 2, false>(p, st);
+}
+
+// The same with a bias per product (element stride between the bias vectors; bias may be NULL): the 1x1 side convs of the
+// layers that share a resolution (models/wesup.py:208-209,253) as ONE launch -- three products of 14 400 (3 600) pixels each
+// fill 226 (58) of the 512 block slots one at a time.
+extern "C" int wesup_gemm_nt_batched_bias(const float* A, int lda, long strideA, const float* Bw, int ldb, long strideB,
+                                          const float* bias, long strideBias, float* C, int ldc, long strideC, int nbatch,
+                                          int M, int N, int K, void* stream) {
+    if (!A || !Bw || !C || nbatch <= 0 || M <= 0 || N <= 0 || K <= 0 || (K % BK) || (lda % 4) || (ldb % 4) || (N % 4) ||
+        (ldc % 4) || (strideA % 4) || (strideB % 4) || (strideC % 4) || (strideBias % 4) ||
+        (((uintptr_t)A | (uintptr_t)Bw | (uintptr_t)C | (uintptr_t)bias) & 15))
+        return WESUP_ERR_INVALID;
+    const long t128 = (long)ceil_div(M, 128) * ceil_div(N, 128) * nbatch, t64 = (long)ceil_div(M, 64) * ceil_div(N, 64) * nbatch;
+    if (t64 >= (1l << 31) / 2) return WESUP_ERR_INVALID;
+    NtParams p = {};
+    p.A = A; p.Bw = Bw; p.C = C; p.bias = bias;
+    p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldmask = ldc;
+    p.nbatch = nbatch; p.batchA = strideA; p.batchB = strideB; p.batchC = strideC; p.batchBias = strideBias;
     hipStream_t st = (hipStream_t)stream;
     if (N > 64 && t128 >= 384) return launch_nt<4, 128, 128, 2, 2, 3, 2, false>(p, st);
     return launch_nt<4, 64, 64, 1, 1, 3, 2, false>(p, st);

@@ -141,6 +141,7 @@ class WesupEngine:
         # stream-K tail for the MLP head's GEMMs (2304 rows at c2: 144 tiles on 512 block slots; nothing runs beside the head
         # between forward and backward): measured, no difference in the step (10.08 / 10.12 / 10.15 vs 10.09 / 10.10 / 10.13 ms,
         # bench.py --head-streamk), so plain tiling as everywhere else in the step
+        self.batch_side_convs = False    # A/B: side convs (and their input gradients) of the layers that share a deep resolution in one launch
         self.head_streamk = False
         self._diag_skip = set()          # TIMING-ONLY diagnostics (bench.py --diag-skip): classes of launches left out, results wrong
         self.route_fn = default_route    # (ci, co, h, w, B) -> 0 | 2 | 4, consulted per layer and shape
@@ -247,6 +248,12 @@ class WesupEngine:
                             c0 = SIDE_OFF[i] - g.off
                             b.s[i] = g.s[..., c0:c0 + CONV_CH[i][1] // 2]
                             b.group_of[i] = len(b.groups)
+                        # conv outputs of the group side by side (equal widths): their side convs are ONE batched launch
+                        g.same_co = len({CONV_CH[i][1] for i in g.layers}) == 1
+                        if g.same_co:
+                            g.y = torch.empty(len(g.layers), B, gh, gw, CONV_CH[l][1], **f32)
+                            for k, i in enumerate(g.layers):
+                                b.y[i] = g.y[k]
                         b.groups.append(g)
                     l = e + 1
             # the (B,HW,2112) feature map only exists on the unfused path (or when somebody asks for it)
@@ -265,6 +272,11 @@ class WesupEngine:
         if train and not b.train:
             R = B * Kmax
             b.G = [torch.empty_like(y) for y in b.y]
+            for g in b.groups:           # ... and their gradients, for the batched side-conv input gradient
+                if g.same_co:
+                    g.G = torch.empty_like(g.y)
+                    for k, i in enumerate(g.layers):
+                        b.G[i] = g.G[k]
             b.ds = [None if ((hh, ww) == (H, W) and not self.fuse_pool_bwd) else torch.empty(B, hh, ww, co // 2, **f32)
                     for (hh, ww), (ci, co) in zip(b.dims, CONV_CH)]
             for g in b.groups:
@@ -308,7 +320,12 @@ class WesupEngine:
             for l, (ci, co) in enumerate(CONV_CH):
                 pk.wf.append(torch.empty(co, ops.conv3x3_kpad(ci), dtype=torch.float32, device=self.device))
                 pk.wd.append(None if l == 0 else torch.empty(ci, 9 * co, dtype=torch.float32, device=self.device))
-            pk.sideT = [torch.empty(co, co // 2, dtype=torch.float32, device=self.device) for ci, co in CONV_CH]
+            # (one flat buffer: the transposed side weights of equally wide layers sit at a constant stride -- batched launches)
+            flatT = torch.empty(sum(co * (co // 2) for ci, co in CONV_CH), dtype=torch.float32, device=self.device)
+            pk.sideT, o = [], 0
+            for ci, co in CONV_CH:
+                pk.sideT.append(flatT[o:o + co * (co // 2)].view(co, co // 2))
+                o += co * (co // 2)
             pk.fcT = [torch.empty(FM_CHANNELS, 1024, dtype=torch.float32, device=self.device),
                       torch.empty(1024, 1024, dtype=torch.float32, device=self.device),
                       torch.empty(1024, self.D, dtype=torch.float32, device=self.device)]
@@ -438,7 +455,23 @@ class WesupEngine:
             # side branch of this layer: 1x1 conv on the pre-ReLU tap, then either the fused upsample+scatter-mean
             # straight into the superpixel feature slice, or upsample into fm's channel slice
             with self._OnSide(self):
-                if not side_in_conv:
+                grp = b.groups[b.group_of[l]] if b.group_of[l] is not None else None
+                batched = grp is not None and grp.same_co and self.batch_side_convs
+                if batched and l == grp.layers[-1]:
+                    # the side convs of the layers that share this resolution as one launch (each alone fills 226 / 58 of the
+                    # 512 block slots)
+                    tok = T.begin('side_fwd')
+                    ls = grp.layers
+                    done = ops.gemm_nt_group([b.y[i].view(B * h * w, co) for i in ls],
+                                             [p[f'side_conv{SIDE_OFF[i]}.weight'].view(co // 2, co) for i in ls],
+                                             [p[f'side_conv{SIDE_OFF[i]}.bias'] for i in ls],
+                                             [b.s[i].view(B * h * w, co // 2) for i in ls])
+                    if not done:
+                        for i in ls:
+                            ops.gemm_nt(b.y[i].view(B * h * w, co), p[f'side_conv{SIDE_OFF[i]}.weight'].view(co // 2, co),
+                                        p[f'side_conv{SIDE_OFF[i]}.bias'], out=b.s[i].view(B * h * w, co // 2))
+                    T.end(tok, 2.0 * len(ls) * B * h * w * co * (co // 2))
+                elif not side_in_conv and not batched:
                     tok = T.begin('side_fwd')
                     ops.gemm_nt(b.y[l].view(B * h * w, co), ws, p[f'side_conv{off}.bias'], out=s2d)
                     T.end(tok, 2.0 * B * h * w * co * (co // 2))
@@ -630,7 +663,23 @@ class WesupEngine:
                     ds2d = b.ds[l].view(P, co // 2)
                 T.end(tok, 4.0 * B * ((h * w * (co // 2) + H * W + Kmax * (co // 2)) if self.fuse_pool_bwd else H * W * (co // 2)))
                 ds2ds[l] = ds2d
-                if l >= lowest:              # G_l is only needed by backbone layers that train
+                grp = b.groups[b.group_of[l]] if b.group_of[l] is not None else None
+                if grp is not None and grp.same_co and self.batch_side_convs and grp.layers[0] >= lowest:
+                    if l == grp.layers[-1]:      # G of every layer of the resolution in one launch (their ds are all there)
+                        ls = grp.layers
+                        tok = T.begin('side_bwd')
+                        dss = [b.ds[i].view(P, co // 2) for i in ls]
+                        done = ops.gemm_nt_group(dss, [pk.sideT[i] for i in ls], None, [b.G[i].view(P, co) for i in ls])
+                        if not done:
+                            for i, d_ in zip(ls, dss):
+                                ops.gemm_nt(d_, pk.sideT[i], None, out=b.G[i].view(P, co))
+                        T.end(tok, 2.0 * len(ls) * P * co * (co // 2))
+                        if self.two_streams:
+                            ev = torch.cuda.Event()
+                            ev.record()
+                            for i in ls:
+                                g_ready[i] = ev
+                elif l >= lowest:            # G_l is only needed by backbone layers that train
                     tok = T.begin('side_bwd')
                     ops.gemm_nt(ds2d, pk.sideT[l], None, out=b.G[l].view(P, co))
                     T.end(tok, 2.0 * P * co * (co // 2))

@@ -348,6 +348,33 @@ def gemm_nt_batched(A, Bw, out=None):
     return out
 
 
+def gemm_nt_group(As, Bs, biases, outs):
+    """outs[i] = As[i] @ Bs[i]^T + biases[i] for equally shaped 2-D operands that sit at a constant element stride from
+    each other (row-strided views allowed: column slices of one buffer, parameters of one flat buffer): ONE launch.
+    Returns False -- and launches nothing -- when the operands are not equally spaced; the caller then loops."""
+    n = len(As)
+    M, K = As[0].shape
+    N = Bs[0].shape[0]
+
+    def stride(ts):
+        if any(t.shape != ts[0].shape or t.stride() != ts[0].stride() or t.dtype != torch.float32 or not t.is_cuda for t in ts):
+            return None
+        d = [(ts[i + 1].data_ptr() - ts[i].data_ptr()) for i in range(n - 1)]
+        if any(v != d[0] for v in d) or d[0] % 16:
+            return None
+        return d[0] // 4
+    sA, sB, sC = stride(As), stride(Bs), stride(outs)
+    sb = 0 if biases is None else stride(biases)
+    if n < 2 or None in (sA, sB, sC, sb) or K % 32 or min(sA, sB, sC) < 0:
+        return False
+    for t in (As[0], Bs[0], outs[0]):
+        assert t.dim() == 2 and t.stride(1) == 1
+    assert Bs[0].shape == (N, K) and outs[0].shape == (M, N)
+    _lib.call('wesup_gemm_nt_batched_bias', _p(As[0]), As[0].stride(0), sA, _p(Bs[0]), Bs[0].stride(0), sB,
+              _p(None if biases is None else biases[0]), sb, _p(outs[0]), outs[0].stride(0), sC, n, M, N, K, _stream())
+    return True
+
+
 def winograd_filter_grad(slabs, dw=None, db=None, m=2):
     """slabs (P, S, Cout*Cin + Cout): split-K partial products of the P transformed filter gradients, each followed by
     the column sums of its dM operand -> (dw (Cout,Cin,3,3) = G^T (sum over S) G, db (Cout) from position (1,1): m = 2
