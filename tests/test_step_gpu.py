@@ -43,7 +43,7 @@ def make_trainer(weights, **kw):
 
 
 @pytest.mark.parametrize('name', CASES)
-@pytest.mark.parametrize('fused', [True, False, 'side_as_gemm', 'direct_convs', 'batched_side'])
+@pytest.mark.parametrize('fused', [True, False, 'side_as_gemm', 'direct_convs', 'batched_side', 'side_before_pool'])
 def test_step_matches_reference_golden(golden_dir, name, fused):
     from oracle import wesup_oracle as orc
     from wesup_amd.models.wesup import preprocess_label_maps, SuperpixelMaps
@@ -58,6 +58,10 @@ def test_step_matches_reference_golden(golden_dir, name, fused):
         model.engine.conv_winograd = model.engine.wgrad_winograd = False
     # the side convs (and the initial input gradients) of conv4_x / conv5_x as one batched launch per resolution
     model.engine.batch_side_convs = fused == 'batched_side'
+    # default: the shallow layers' side convs BEHIND the upsample + superpixel mean (they commute); here in front, as written
+    # in the reference (models/wesup.py:246-261), with the side outputs and their gradients materialised
+    if fused in ('side_before_pool', 'side_as_gemm', 'batched_side'):
+        model.engine.commute_side = False
     fused = bool(fused)
     model.engine.fuse_pool_bwd = fused
     model.engine.fuse_pool_fwd = fused

@@ -141,6 +141,13 @@ class WesupEngine:
         # stream-K tail for the MLP head's GEMMs (2304 rows at c2: 144 tiles on 512 block slots; nothing runs beside the head
         # between forward and backward): measured, no difference in the step (10.08 / 10.12 / 10.15 vs 10.09 / 10.10 / 10.13 ms,
         # bench.py --head-streamk), so plain tiling as everywhere else in the step
+        # Shallow layers (native resolution above the matrix-pool limit: conv1_1 ... conv3_3 at 480^2): the 1x1 side conv, the
+        # bilinear upsample and the superpixel mean are all linear, and the first acts on channels while the other two act on
+        # pixels -- they commute.  mean_r(upsample(y W^T + b)) = mean_r(upsample(y)) W^T + b: the fused upsample+scatter-mean
+        # reads the conv output y itself and the side conv shrinks to a (B*Kmax x C) x (C x C/2) product; backward likewise
+        # (dYbar = g W, G_l = upsample-pool-backward of dYbar straight into the conv's gradient buffer, dW = g^T Ybar,
+        # db = column sums of g).  No side output, no gradient of it, no P x C side GEMMs at 480^2 / 240^2 / 120^2.
+        self.commute_side = True
         self.batch_side_convs = False    # A/B: side convs (and their input gradients) of the layers that share a deep resolution in one launch
         self.head_streamk = False
         self._diag_skip = set()          # TIMING-ONLY diagnostics (bench.py --diag-skip): classes of launches left out, results wrong
@@ -216,7 +223,7 @@ class WesupEngine:
                 b.dims.append((h, w))
                 b.y.append(torch.empty(B, h, w, co, **f32))
                 full = (h, w) == (H, W)
-                b.s.append(None if (full and not self.fuse_pool_fwd) else torch.empty(B, h, w, co // 2, **f32))
+                b.s.append(None)         # side outputs: views of the group buffers below, or allocated on first use (_side_out)
                 # the ReLU'd copy the next conv (forward and wgrad) reads: the pooled tensor where the layer is pooled
                 # (stored ReLU'd), a second output of the conv kernel elsewhere; the last layer has no reader
                 b.yr.append(torch.empty(B, h, w, co, **f32) if (self.relu_on_store and not POOL_AFTER[l] and l < 12) else None)
@@ -259,6 +266,8 @@ class WesupEngine:
             # the (B,HW,2112) feature map only exists on the unfused path (or when somebody asks for it)
             b.fm = None if self.fuse_pool_fwd else torch.empty(B, H, W, FM_CHANNELS, **f32)
             b.fm_valid = False
+            b.ybar, b.dybar = [None] * 13, [None] * 13       # commuted side branch: mean_r(upsample(y_l)) and its gradient
+            b.s_valid = [False] * 13
             b.shape = (B, H, W)
             R = B * Kmax
             b.sp_in = torch.empty(B, Kmax, FM_CHANNELS, **f32)
@@ -277,8 +286,7 @@ class WesupEngine:
                     g.G = torch.empty_like(g.y)
                     for k, i in enumerate(g.layers):
                         b.G[i] = g.G[k]
-            b.ds = [None if ((hh, ww) == (H, W) and not self.fuse_pool_bwd) else torch.empty(B, hh, ww, co // 2, **f32)
-                    for (hh, ww), (ci, co) in zip(b.dims, CONV_CH)]
+            b.ds = [None] * 13           # views of the group buffers, or allocated on first use (_side_grad)
             for g in b.groups:
                 g.ds = torch.empty(B, g.h, g.w, g.C, **f32)
                 for i in g.layers:
@@ -293,6 +301,25 @@ class WesupEngine:
             b.gsp = torch.empty(B, Kmax, FM_CHANNELS, **f32)
             b.train = True
         return b
+
+    def _side_out(self, b, l):
+        """Buffer of layer l's side output at native resolution (B,h,w,C/2); None where the unfused path writes the side
+        conv straight into the feature map (full-resolution layers)."""
+        if b.s[l] is None and not (b.dims[l] == b.shape[1:] and not self.fuse_pool_fwd):
+            h, w = b.dims[l]
+            b.s[l] = torch.empty(b.shape[0], h, w, CONV_CH[l][1] // 2, dtype=torch.float32, device=self.device)
+        return b.s[l]
+
+    def _side_grad(self, b, l):
+        if b.ds[l] is None and not (b.dims[l] == b.shape[1:] and not self.fuse_pool_bwd):
+            h, w = b.dims[l]
+            b.ds[l] = torch.empty(b.shape[0], h, w, CONV_CH[l][1] // 2, dtype=torch.float32, device=self.device)
+        return b.ds[l]
+
+    def _commuted(self, b, l):
+        """Layer l's side conv behind the pooling instead of in front of it (see commute_side)."""
+        return (self.commute_side and self.fuse_pool_fwd and self.fuse_pool_bwd and b.group_of[l] is None
+                and CONV_CH[l][1] <= 256)
 
     def release_buffers(self):
         self._bufs.clear()
@@ -424,11 +451,14 @@ class WesupEngine:
             if l == 1 and pk.ready is not None:
                 torch.cuda.current_stream().wait_event(pk.ready)
             ws = p[f'side_conv{off}.weight'].view(co // 2, co)
+            commute = self._commuted(b, l)
+            b.s_valid[l] = not commute
             # unfused, full resolution: the side conv writes its slice of fm directly
-            s2d = fm2d[:, off:off + co // 2] if b.s[l] is None else b.s[l].view(B * h * w, co // 2)
+            s_l = None if commute else self._side_out(b, l)
+            s2d = None if commute else (fm2d[:, off:off + co // 2] if s_l is None else s_l.view(B * h * w, co // 2))
             # optional: the side conv of the four widest layers (64 / 128 channels at 480^2 / 240^2: the y re-read is
             # 236 / 118 MB) in the conv's epilogue, where the output tile sits in LDS anyway
-            side_in_conv = self.fuse_side_fwd and co <= 128 and not self._wino(l)
+            side_in_conv = self.fuse_side_fwd and co <= 128 and not self._wino(l) and not commute
             b.x_in[l], b.x_relu[l] = cur, cur_relu
             # The ReLU'd copy of this layer's output exists for the next layer's 9-tap re-reads and its weight gradient.
             # A Winograd-domain consumer reads its input once (input transform) and its weight gradient reads the kept V:
@@ -457,7 +487,17 @@ class WesupEngine:
             with self._OnSide(self):
                 grp = b.groups[b.group_of[l]] if b.group_of[l] is not None else None
                 batched = grp is not None and grp.same_co and self.batch_side_convs
-                if batched and l == grp.layers[-1]:
+                if commute:
+                    if b.ybar[l] is None:
+                        b.ybar[l] = torch.empty(B, Kmax, co, dtype=torch.float32, device=self.device)
+                    tok = T.begin('sp_pool_up_fwd')
+                    ops.sp_pool_upsample_fwd(b.y[l], meta, b.ybar[l], 0)
+                    T.end(tok, 4.0 * B * (h * w * co + H * W + Kmax * co))
+                    tok = T.begin('side_fwd')
+                    ops.gemm_nt(b.ybar[l].view(B * Kmax, co), ws, p[f'side_conv{off}.bias'],
+                                out=b.sp_in.view(B * Kmax, FM_CHANNELS)[:, off:off + co // 2])
+                    T.end(tok, 2.0 * B * Kmax * co * (co // 2))
+                elif batched and l == grp.layers[-1]:
                     # the side convs of the layers that share this resolution as one launch (each alone fills 226 / 58 of the
                     # 512 block slots)
                     tok = T.begin('side_fwd')
@@ -475,7 +515,9 @@ class WesupEngine:
                     tok = T.begin('side_fwd')
                     ops.gemm_nt(b.y[l].view(B * h * w, co), ws, p[f'side_conv{off}.bias'], out=s2d)
                     T.end(tok, 2.0 * B * h * w * co * (co // 2))
-                if b.group_of[l] is not None:
+                if commute:
+                    pass
+                elif b.group_of[l] is not None:
                     g = b.groups[b.group_of[l]]
                     if l == g.layers[-1]:        # all side outputs of this resolution are in: sp_in slice = Wm . s
                         tok = T.begin('sp_pool_mat_fwd')
@@ -484,11 +526,11 @@ class WesupEngine:
                         T.end(tok, 2.0 * B * Kmax * g.h * g.w * g.C)
                 elif fused:
                     tok = T.begin('sp_pool_up_fwd')
-                    ops.sp_pool_upsample_fwd(b.s[l], meta, b.sp_in, off)
+                    ops.sp_pool_upsample_fwd(s_l, meta, b.sp_in, off)
                     T.end(tok, 4.0 * B * (h * w * (co // 2) + H * W + Kmax * (co // 2)))
-                elif b.s[l] is not None:
+                elif s_l is not None:
                     tok = T.begin('upsample_fwd')
-                    ops.upsample_fwd(b.s[l], b.fm, off)
+                    ops.upsample_fwd(s_l, b.fm, off)
                     T.end(tok, 4.0 * B * H * W * (co // 2))
             if POOL_AFTER[l]:
                 if not self._wino(l):
@@ -528,7 +570,14 @@ class WesupEngine:
             if b.fm is None:
                 b.fm = torch.empty(B, H, W, FM_CHANNELS, dtype=torch.float32, device=self.device)
             for l, off in enumerate(SIDE_OFF):
-                ops.upsample_fwd(b.s[l].contiguous(), b.fm, off)
+                s_l = self._side_out(b, l)
+                if not b.s_valid[l]:          # commuted side branch: the step never formed this side output
+                    h, w = b.dims[l]
+                    co = CONV_CH[l][1]
+                    ops.gemm_nt(b.y[l].view(B * h * w, co), self.p[f'side_conv{off}.weight'].view(co // 2, co),
+                                self.p[f'side_conv{off}.bias'], out=s_l.view(B * h * w, co // 2))
+                    b.s_valid[l] = True
+                ops.upsample_fwd(s_l.contiguous(), b.fm, off)
             b.fm_valid = True
         return b.fm
 
@@ -597,6 +646,22 @@ class WesupEngine:
         # stream it sat between the side GEMMs of layers 7..1 and the dgrad chain waited for it (~0.75 ms with no MFMA
         # kernel in flight); on a stream of its own it runs under the deep layers' GEMMs.
         ds_ready = [None] * 13
+
+        def commuted_G(l):
+            """Commuted side branch: dYbar = g_slice . W_side (B*Kmax rows), then G_l = the upsample + scatter-mean backward of
+            dYbar, written straight into the conv's gradient buffer (all C channels)."""
+            co = CONV_CH[l][1]
+            h, w = b.dims[l]
+            off = SIDE_OFF[l]
+            if b.dybar[l] is None:
+                b.dybar[l] = torch.empty(B, Kmax, co, dtype=torch.float32, device=self.device)
+            tok = T.begin('side_bwd')
+            ops.gemm_nt(gsp2d[:, off:off + co // 2], pk.sideT[l], None, out=b.dybar[l].view(R, co))
+            T.end(tok, 2.0 * R * co * (co // 2))
+            tok = T.begin('upsample_bwd')
+            ops.upsample_bwd_fused(b.dybar[l], meta.new_row, meta.area_new, H, W, 0, h, w, co, out=b.G[l])
+            T.end(tok, 4.0 * B * (h * w * co + H * W + Kmax * co))
+
         if self.two_streams and self.fuse_pool_bwd:
             # ... at the head of the wgrad stream, which has nothing to do until the first weight gradient is queued.
             # (A fourth stream of its own measured the same; with three engine streams + the RCCL stream the process
@@ -606,11 +671,16 @@ class WesupEngine:
             aux.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(aux):
                 for l in range(12, -1, -1):
-                    if b.group_of[l] is None:
+                    if b.group_of[l] is None and self._commuted(b, l):
+                        if l >= lowest:
+                            commuted_G(l)
+                            g_ready[l] = torch.cuda.Event()
+                            g_ready[l].record()
+                    elif b.group_of[l] is None:
                         h, w = b.dims[l]
                         tok = T.begin('upsample_bwd')
                         ops.upsample_bwd_fused(b.gsp, meta.new_row, meta.area_new, H, W, SIDE_OFF[l], h, w,
-                                               CONV_CH[l][1] // 2, out=b.ds[l])
+                                               CONV_CH[l][1] // 2, out=self._side_grad(b, l))
                         # own byte model (pool-backward fused in): the gradient at native resolution out, the pixel labels
                         # and one row of g per superpixel in -- not the (H, W, C/2) slice of a materialised gradient
                         T.end(tok, 4.0 * B * (h * w * (CONV_CH[l][1] // 2) + H * W + Kmax * (CONV_CH[l][1] // 2)))
@@ -626,9 +696,14 @@ class WesupEngine:
             off = SIDE_OFF[l]
             P = B * h * w
             tok = T.begin('side_bwd')
-            ops.gemm_tn(ds2ds[l], b.y[l].view(P, co), out=g[f'side_conv{off}.weight'].view(co // 2, co), ws_tag='side',
-                        colsum=g[f'side_conv{off}.bias'])
-            T.end(tok, 2.0 * P * co * (co // 2))
+            if self._commuted(b, l):         # dW = g_slice^T . Ybar, db = column sums of g_slice (the rows of upsample+mean sum to 1)
+                ops.gemm_tn(gsp2d[:, off:off + co // 2], b.ybar[l].view(R, co), out=g[f'side_conv{off}.weight'].view(co // 2, co),
+                            ws_tag='side', colsum=g[f'side_conv{off}.bias'])
+                T.end(tok, 2.0 * R * co * (co // 2))
+            else:
+                ops.gemm_tn(ds2ds[l], b.y[l].view(P, co), out=g[f'side_conv{off}.weight'].view(co // 2, co), ws_tag='side',
+                            colsum=g[f'side_conv{off}.bias'])
+                T.end(tok, 2.0 * P * co * (co // 2))
             # reported from the side stream, layer by layer (the reducer orders a bucket behind every stream that
             # contributed to it): the side-conv gradients leave with the head's bucket instead of after the final join
             ready([f'side_conv{off}.weight', f'side_conv{off}.bias'])
@@ -639,6 +714,12 @@ class WesupEngine:
                 h, w = b.dims[l]
                 off = SIDE_OFF[l]
                 P = B * h * w
+                if self._commuted(b, l):
+                    if g_ready[l] is None and l >= lowest:       # single-stream schedule: not queued above
+                        commuted_G(l)
+                    if not self.side_wgrad_last:
+                        side_wgrad(l)
+                    continue
                 if b.group_of[l] is not None:
                     grp = b.groups[b.group_of[l]]
                     if l == grp.layers[-1]:      # ds of every layer of this resolution at once: ds = Wm^T . gsp slice
@@ -654,9 +735,9 @@ class WesupEngine:
                     ds2d = b.ds[l].view(P, co // 2)
                 elif self.fuse_pool_bwd:
                     tok = T.begin('upsample_bwd')
-                    ops.upsample_bwd_fused(b.gsp, meta.new_row, meta.area_new, H, W, off, h, w, co // 2, out=b.ds[l])
+                    ops.upsample_bwd_fused(b.gsp, meta.new_row, meta.area_new, H, W, off, h, w, co // 2, out=self._side_grad(b, l))
                     ds2d = b.ds[l].view(P, co // 2)
-                elif b.s[l] is None:
+                elif self._side_grad(b, l) is None:
                     ds2d = dfm2d[:, off:off + co // 2]
                 else:
                     ops.upsample_bwd(b.dfm, off, h, w, co // 2, out=b.ds[l])
