@@ -64,6 +64,7 @@ def parse_args(argv=None):
     ap.add_argument('--side-wgrad-interleaved', action='store_true', help='A/B: side-conv weight gradients layer by layer between the '
                                                                           'G_l GEMMs (round 2\'s order) instead of behind all of them')
     ap.add_argument('--side-before-pool', action='store_true', help='A/B: the shallow side convs in front of the upsample + superpixel mean, side outputs materialised (round 2 / early round 3 schedule)')
+    ap.add_argument('--commute-deep', action='store_true', help='A/B: the deep layers (matrix pooling) commuted as well (measured, not kept)')
     ap.add_argument('--batched-side', action='store_true', help='A/B: the side convs of the layers that share a deep resolution in one batched launch (measured, not kept)')
     ap.add_argument('--diag-skip', default='', help="TIMING-ONLY diagnostic (results are wrong): comma list of launch classes left out "
                                                     "of the step -- 'wgrad' (conv weight gradients), 'side_wgrad' -- to see what they cost the step")
@@ -262,6 +263,7 @@ def worker(args):
     trainer.model.engine.head_streamk = args.head_streamk
     trainer.model.engine.batch_side_convs = args.batched_side
     trainer.model.engine.commute_side = not args.side_before_pool
+    trainer.model.engine.commute_side_deep = args.commute_deep
     trainer.model.engine._diag_skip = set(filter(None, args.diag_skip.split(',')))
     trainer.model.engine.conv_winograd = not args.direct_conv
     if args.winograd_min_ci:

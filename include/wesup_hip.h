@@ -241,6 +241,12 @@ int wesup_upsample_fwd(const float* s, float* fm, int B, int h, int w, int H, in
 int wesup_upsample_bwd(const float* dfm_or_g, const int32_t* new_row, const int32_t* area_new,
                        float* ds, int B, int h, int w, int H, int W, int C, int ldf, int coff,
                        int Kmax, void* stream);
+/* The fused form (new_row given) for n <= 3 layers that share one coarse resolution (h, w) != (H, W), one launch:
+ * ds_i [B][h][w][C_i] from g_i [B][Kmax][C_i] (dense rows, C_0 + .. + C_{n-1} <= 768); the scan of a cell's window of
+ * full-resolution pixels is shared by the layers.  Same values as n calls of wesup_upsample_bwd. */
+int wesup_upsample_bwd_group(const float* g0, const float* g1, const float* g2, float* ds0, float* ds1, float* ds2,
+                             int C0, int C1, int C2, int n, const int32_t* new_row, const int32_t* area_new, int B,
+                             int h, int w, int H, int W, int Kmax, void* stream);
 
 /* ------------------------------------------------------------------ superpixels (K6/K8/K9)
  * wesup_sp_preprocess replaces _preprocess_superpixels (models/wesup.py:18-63) without dense maps.

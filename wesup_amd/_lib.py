@@ -68,6 +68,7 @@ _SIGS = {
     'wesup_maxpool2_bwd': (c_int, 'pppiiiiip'),
     'wesup_upsample_fwd': (c_int, 'ppiiiiiiiip'),
     'wesup_upsample_bwd': (c_int, 'ppppiiiiiiiiip'),
+    'wesup_upsample_bwd_group': (c_int, 'ppppppiiiippiiiiiip'),
     'wesup_sp_preprocess_workspace_bytes': (c_size_t, 'iiii'),
     'wesup_sp_preprocess': (c_int, 'ppiiii' + 'pppppppppp' + 'pzp'),
     'wesup_spmaps_to_labels': (c_int, 'ppiip'),

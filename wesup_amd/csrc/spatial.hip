@@ -356,6 +356,143 @@ __global__ __launch_bounds__(256) void upsample_bwd_cell_kernel(const float* __r
     }
     if (lane < C4) st4(ds + (cellid * C4 + lane) * 4, acc);
 }
+// Fused backward at native resolution (h == H, w == W): the upsample is the identity, a pixel's gradient is its
+// superpixel's row of g over the area -- one gather per (pixel, channel quad), the value the window scan above produces
+// for its single candidate (weight 1).
+__global__ __launch_bounds__(256) void upsample_bwd_ident_kernel(const float* __restrict__ g, const int32_t* __restrict__ new_row,
+                                                                 const int32_t* __restrict__ area, float* __restrict__ ds,
+                                                                 long npix, int HW, int C4, int ldf, int coff, int Kmax) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= npix * C4) return;
+    const long p = idx / C4;
+    const int c = idx - p * C4;
+    const int b = p / HW;
+    const int r = new_row[p];
+    const float coef = 1.f * (1.f / (float)area[(long)b * Kmax + r]);
+    const float4 v = ld4(g + ((long)b * Kmax + r) * ldf + coff + 4 * c);
+    st4(ds + idx * 4, make_float4(coef * v.x, coef * v.y, coef * v.z, coef * v.w));
+}
+
+// The cell kernel for up to three layers that share a coarse resolution (commuted side branch: all their g's exist when
+// backward starts): the window scan and the peeling of distinct rows -- most of the work of a cell -- are done once, the
+// lanes then walk the layers' channel quads as one concatenated range, 64 quads per pass.
+struct UpGroup {
+    const float* g[3];
+    float* ds[3];
+    int c4[3];               // channel quads per layer (0: unused slot); rows of g[i] are c4[i]*4 floats apart
+};
+template <int NPASS>
+__global__ __launch_bounds__(256) void upsample_bwd_cell_group_kernel(UpGroup G, const int32_t* __restrict__ new_row,
+                                                                      const int32_t* __restrict__ area, int B, int h, int w,
+                                                                      int H, int W, int Kmax, float sh, float sw) {
+    const long cellid = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (cellid >= (long)B * h * w) return;          // wave-uniform
+    const int lane = threadIdx.x & 63;
+    long t = cellid;
+    const int qx = t % w;
+    t /= w;
+    const int qy = t % h;
+    const int b = t / h;
+    int Ylo = 0, Yhi = H - 1, Xlo = 0, Xhi = W - 1;
+    if (sh > 0.f) {
+        Ylo = max(0, (int)floorf((float)(qy - 1) / sh) - 1);
+        Yhi = min(H - 1, (int)ceilf((float)(qy + 1) / sh) + 1);
+    }
+    if (sw > 0.f) {
+        Xlo = max(0, (int)floorf((float)(qx - 1) / sw) - 1);
+        Xhi = min(W - 1, (int)ceilf((float)(qx + 1) / sw) + 1);
+    }
+    const int nwx = Xhi - Xlo + 1, ncand = nwx * (Yhi - Ylo + 1);
+    const int32_t* rows = new_row + (long)b * H * W;
+    // this lane's quad of pass k: layer, row stride and offset inside the row
+    const float* src[NPASS];
+    float* dst[NPASS];
+    int ld[NPASS];
+    float4 acc[NPASS];
+#pragma unroll
+    for (int k = 0; k < NPASS; ++k) {
+        int q = lane + 64 * k, i = 0;
+        while (i < 3 && q >= G.c4[i]) { q -= G.c4[i]; ++i; }
+        const bool on = i < 3;
+        const int c4 = on ? G.c4[i] : 0;
+        ld[k] = c4 * 4;
+        src[k] = on ? G.g[i] + (long)b * Kmax * c4 * 4 + 4 * q : nullptr;
+        dst[k] = on ? G.ds[i] + (cellid * c4 + q) * 4 : nullptr;
+        acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    for (int base = 0; base < ncand; base += 64) {
+        const int i = base + lane;
+        float wgt = 0.f;
+        int r = -1;
+        if (i < ncand) {
+            const int dy = i / nwx, Y = Ylo + dy, X = Xlo + i - dy * nwx;
+            const Lerp ly = lerp_of(Y, sh, h), lx = lerp_of(X, sw, w);
+            const float wy = (ly.i0 == qy ? ly.l0 : 0.f) + (ly.i1 == qy ? ly.l1 : 0.f);
+            const float wx = (lx.i0 == qx ? lx.l0 : 0.f) + (lx.i1 == qx ? lx.l1 : 0.f);
+            wgt = wy * wx;
+            if (wgt != 0.f) r = rows[(long)Y * W + X];
+        }
+        unsigned long long todo = __ballot(r >= 0);
+        while (todo) {
+            const int first = __builtin_ctzll(todo);
+            const int rr = __builtin_amdgcn_readlane(r, first);
+            const bool mine = (r == rr);
+            float wsum = mine ? wgt : 0.f;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) wsum += __shfl_xor(wsum, off);
+            todo &= ~__ballot(mine);
+            const float coef = wsum * (1.f / (float)area[(long)b * Kmax + rr]);
+#pragma unroll
+            for (int k = 0; k < NPASS; ++k)
+                if (src[k]) {
+                    const float4 v = ld4(src[k] + (long)rr * ld[k]);
+                    acc[k].x += coef * v.x;
+                    acc[k].y += coef * v.y;
+                    acc[k].z += coef * v.z;
+                    acc[k].w += coef * v.w;
+                }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < NPASS; ++k)
+        if (dst[k]) st4(dst[k], acc[k]);
+}
+/* Fused upsample + scatter-mean backward of up to three layers of one coarse resolution in one launch:
+   ds_i (B,h,w,C_i) from g_i (B,Kmax,C_i), i < n.  Same numbers as n calls of wesup_upsample_bwd (same order of additions). */
+extern "C" int wesup_upsample_bwd_group(const float* g0, const float* g1, const float* g2, float* ds0, float* ds1, float* ds2,
+                                        int C0, int C1, int C2, int n, const int32_t* new_row, const int32_t* area_new, int B,
+                                        int h, int w, int H, int W, int Kmax, void* stream) {
+    if (n < 1 || n > 3 || !new_row || !area_new || B <= 0 || h <= 0 || w <= 0 || H <= 0 || W <= 0 || Kmax <= 0 ||
+        (h == H && w == W))
+        return WESUP_ERR_INVALID;
+    const float* gs[3] = {g0, g1, g2};
+    float* dss[3] = {ds0, ds1, ds2};
+    const int cs[3] = {C0, C1, C2};
+    UpGroup G;
+    int quads = 0;
+    for (int i = 0; i < 3; ++i) {
+        const bool on = i < n;
+        if (on && (!gs[i] || !dss[i] || cs[i] <= 0 || (cs[i] % 4))) return WESUP_ERR_INVALID;
+        G.g[i] = on ? gs[i] : nullptr;
+        G.ds[i] = on ? dss[i] : nullptr;
+        G.c4[i] = on ? cs[i] / 4 : 0;
+        quads += G.c4[i];
+    }
+    const int npass = (quads + 63) / 64;
+    if (npass > 3) return WESUP_ERR_INVALID;
+    const dim3 grid((unsigned)(((long)B * h * w + 3) / 4));
+    const float sh = ac_scale(h, H), sw = ac_scale(w, W);
+    hipStream_t st = (hipStream_t)stream;
+    if (npass == 1)
+        hipLaunchKernelGGL(upsample_bwd_cell_group_kernel<1>, grid, dim3(256), 0, st, G, new_row, area_new, B, h, w, H, W, Kmax, sh, sw);
+    else if (npass == 2)
+        hipLaunchKernelGGL(upsample_bwd_cell_group_kernel<2>, grid, dim3(256), 0, st, G, new_row, area_new, B, h, w, H, W, Kmax, sh, sw);
+    else
+        hipLaunchKernelGGL(upsample_bwd_cell_group_kernel<3>, grid, dim3(256), 0, st, G, new_row, area_new, B, h, w, H, W, Kmax, sh, sw);
+    WESUP_CHECK_LAUNCH();
+    return WESUP_OK;
+}
+
 extern "C" int wesup_upsample_bwd(const float* dfm_or_g, const int32_t* new_row, const int32_t* area_new, float* ds,
                                   int B, int h, int w, int H, int W, int C, int ldf, int coff, int Kmax, void* stream) {
     if (!dfm_or_g || !ds || B <= 0 || h <= 0 || w <= 0 || H <= 0 || W <= 0 || (C % 4) || (ldf % 4) || (coff % 4))
@@ -363,7 +500,10 @@ extern "C" int wesup_upsample_bwd(const float* dfm_or_g, const int32_t* new_row,
     if (new_row && (!area_new || Kmax <= 0)) return WESUP_ERR_INVALID;
     const long tot = (long)B * h * w * (C / 4);
     const dim3 grid((unsigned)((tot + 255) / 256));
-    if (new_row && !(h == H && w == W) && C / 4 <= 64)
+    if (new_row && h == H && w == W)
+        hipLaunchKernelGGL(upsample_bwd_ident_kernel, grid, dim3(256), 0, (hipStream_t)stream, dfm_or_g, new_row, area_new, ds,
+                           (long)B * H * W, H * W, C / 4, ldf, coff, Kmax);
+    else if (new_row && C / 4 <= 64)
         hipLaunchKernelGGL(upsample_bwd_cell_kernel, dim3((unsigned)(((long)B * h * w + 3) / 4)), dim3(256), 0,
                            (hipStream_t)stream, dfm_or_g, new_row, area_new, ds, B, h, w, H, W, C / 4, ldf, coff, Kmax,
                            ac_scale(h, H), ac_scale(w, W));

@@ -419,6 +419,7 @@ __device__ __forceinline__ Lerp2 lerp2_of(int dst, float scale, int in) {
     r.l0 = 1.f - r.l1;
     return r;
 }
+#define SP_UP_UNROLL 4
 #define SP_CELL_CAP 1024          // cells of a segment's box of the coarse grid kept in LDS (8 KiB per wave)
 template <int LPP>
 __global__ __launch_bounds__(256) void sp_pool_up_fwd_kernel(const float* __restrict__ s, const int32_t* __restrict__ pix_sorted,
@@ -485,26 +486,62 @@ __global__ __launch_bounds__(256) void sp_pool_up_fwd_kernel(const float* __rest
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
             __builtin_amdgcn_wave_barrier();
             const float scale = inv * (1.f / FX);
-            for (int q = grp; q < ncell; q += PPW) {
-                const unsigned long long wq = cell[q];
-                if (wq == 0ull) continue;
-                const int cy = q / bw, cx = q - cy * bw;
-                const float wgt = (float)wq * scale;
-                const float4 v = ld4(base + ((long)(y0 + cy) * w + x0 + cx) * C);
-                acc.x = fmaf(v.x, wgt, acc.x);
-                acc.y = fmaf(v.y, wgt, acc.y);
-                acc.z = fmaf(v.z, wgt, acc.z);
-                acc.w = fmaf(v.w, wgt, acc.w);
+            // SP_UP_UNROLL cells in flight per lane group (same order of additions as one at a time: a cell nobody touched
+            // has weight 0 and its load is skipped)
+            for (int q0 = grp; q0 < ncell; q0 += PPW * SP_UP_UNROLL) {
+                float wgt[SP_UP_UNROLL];
+                float4 v[SP_UP_UNROLL];
+#pragma unroll
+                for (int u = 0; u < SP_UP_UNROLL; ++u) {
+                    const int q = q0 + u * PPW;
+                    const unsigned long long wq = (q < ncell) ? cell[q] : 0ull;
+                    wgt[u] = (float)wq * scale;
+                    v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (wq != 0ull) {
+                        const int cy = q / bw, cx = q - cy * bw;
+                        v[u] = ld4(base + ((long)(y0 + cy) * w + x0 + cx) * C);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < SP_UP_UNROLL; ++u) {       // (untouched cell: weight 0 times the 0 put in v)
+                    acc.x = fmaf(v[u].x, wgt[u], acc.x);
+                    acc.y = fmaf(v[u].y, wgt[u], acc.y);
+                    acc.z = fmaf(v[u].z, wgt[u], acc.z);
+                    acc.w = fmaf(v[u].w, wgt[u], acc.w);
+                }
             }
         }
     }
-    if (!by_cell)
+    if (ident) {
+        // native resolution: the pixel's own row of s, SP_UP_UNROLL pixels in flight per lane group, added in list order
+        int j = j0 + grp;
+        for (; j + (SP_UP_UNROLL - 1) * PPW < j1; j += PPW * SP_UP_UNROLL) {
+            int pix[SP_UP_UNROLL];
+#pragma unroll
+            for (int u = 0; u < SP_UP_UNROLL; ++u) pix[u] = list[j + u * PPW];
+            float4 v[SP_UP_UNROLL];
+#pragma unroll
+            for (int u = 0; u < SP_UP_UNROLL; ++u) v[u] = ld4(base + (long)pix[u] * C);
+#pragma unroll
+            for (int u = 0; u < SP_UP_UNROLL; ++u) {
+                acc.x = fmaf(v[u].x, inv, acc.x);
+                acc.y = fmaf(v[u].y, inv, acc.y);
+                acc.z = fmaf(v[u].z, inv, acc.z);
+                acc.w = fmaf(v[u].w, inv, acc.w);
+            }
+        }
+        for (; j < j1; j += PPW) {
+            const float4 v = ld4(base + (long)list[j] * C);
+            acc.x = fmaf(v.x, inv, acc.x);
+            acc.y = fmaf(v.y, inv, acc.y);
+            acc.z = fmaf(v.z, inv, acc.z);
+            acc.w = fmaf(v.w, inv, acc.w);
+        }
+    } else if (!by_cell)
     for (int j = j0 + grp; j < j1; j += PPW) {
         const int p = list[j];
         float4 v;
-        if (ident) {
-            v = ld4(base + (long)p * C);
-        } else {
+        {
             const int Y = fast_div(p, dW), X = p - Y * W;
             const Lerp2 ly = lerp2_of(Y, sh, h), lx = lerp2_of(X, sw, w);
             const float4 v00 = ld4(base + ((long)ly.i0 * w + lx.i0) * C);

@@ -148,6 +148,11 @@ class WesupEngine:
         # (dYbar = g W, G_l = upsample-pool-backward of dYbar straight into the conv's gradient buffer, dW = g^T Ybar,
         # db = column sums of g).  No side output, no gradient of it, no P x C side GEMMs at 480^2 / 240^2 / 120^2.
         self.commute_side = True
+        # ... and the same for the deep layers, whose pooling is a GEMM with the interpolation matrix Wm: Ybar = Wm . y and
+        # G = Wm^T . dYbar over all C channels instead of the C/2 of the side output.  The FLOPs saved on the side convs are
+        # spent there again and the products are less efficient (N = 512 per layer instead of 768 per resolution): alone on the
+        # GPU 1.04 -> 1.15 ms for the four classes involved, step 9.37 -> 9.41 ms.  Measured, off (bench.py --commute-deep).
+        self.commute_side_deep = False
         self.batch_side_convs = False    # A/B: side convs (and their input gradients) of the layers that share a deep resolution in one launch
         self.head_streamk = False
         self._diag_skip = set()          # TIMING-ONLY diagnostics (bench.py --diag-skip): classes of launches left out, results wrong
@@ -248,12 +253,10 @@ class WesupEngine:
                         g.layers, g.h, g.w = list(range(l, e + 1)), gh, gw
                         g.off = SIDE_OFF[l]
                         g.C = sum(CONV_CH[i][1] // 2 for i in g.layers)
-                        g.s = torch.empty(B, gh, gw, g.C, **f32)
+                        g.s = g.ds = None    # side outputs / their gradients side by side: allocated on first use
                         g.Wm = torch.empty(B, Kmax, gh * gw, **f32)
                         g.WmT = torch.empty(B, gh * gw, Kmax, **f32)
                         for i in g.layers:
-                            c0 = SIDE_OFF[i] - g.off
-                            b.s[i] = g.s[..., c0:c0 + CONV_CH[i][1] // 2]
                             b.group_of[i] = len(b.groups)
                         # conv outputs of the group side by side (equal widths): their side convs are ONE batched launch
                         g.same_co = len({CONV_CH[i][1] for i in g.layers}) == 1
@@ -287,11 +290,6 @@ class WesupEngine:
                     for k, i in enumerate(g.layers):
                         b.G[i] = g.G[k]
             b.ds = [None] * 13           # views of the group buffers, or allocated on first use (_side_grad)
-            for g in b.groups:
-                g.ds = torch.empty(B, g.h, g.w, g.C, **f32)
-                for i in g.layers:
-                    c0 = SIDE_OFF[i] - g.off
-                    b.ds[i] = g.ds[..., c0:c0 + CONV_CH[i][1] // 2]
             b.dxp = [None if yp is None else torch.empty(yp.shape[0], yp.shape[1], yp.shape[2], CONV_CH[l + 1][0], **f32)
                      for l, yp in enumerate(b.yp)]
             b.dfm = None if self.fuse_pool_bwd else torch.empty(B, H, W, FM_CHANNELS, **f32)
@@ -305,21 +303,33 @@ class WesupEngine:
     def _side_out(self, b, l):
         """Buffer of layer l's side output at native resolution (B,h,w,C/2); None where the unfused path writes the side
         conv straight into the feature map (full-resolution layers)."""
-        if b.s[l] is None and not (b.dims[l] == b.shape[1:] and not self.fuse_pool_fwd):
+        if b.s[l] is None and b.group_of[l] is not None:
+            g = b.groups[b.group_of[l]]
+            g.s = torch.empty(b.shape[0], g.h, g.w, g.C, dtype=torch.float32, device=self.device)
+            for i in g.layers:
+                c0 = SIDE_OFF[i] - g.off
+                b.s[i] = g.s[..., c0:c0 + CONV_CH[i][1] // 2]
+        elif b.s[l] is None and not (b.dims[l] == b.shape[1:] and not self.fuse_pool_fwd):
             h, w = b.dims[l]
             b.s[l] = torch.empty(b.shape[0], h, w, CONV_CH[l][1] // 2, dtype=torch.float32, device=self.device)
         return b.s[l]
 
     def _side_grad(self, b, l):
-        if b.ds[l] is None and not (b.dims[l] == b.shape[1:] and not self.fuse_pool_bwd):
+        if b.ds[l] is None and b.group_of[l] is not None:
+            g = b.groups[b.group_of[l]]
+            g.ds = torch.empty(b.shape[0], g.h, g.w, g.C, dtype=torch.float32, device=self.device)
+            for i in g.layers:
+                c0 = SIDE_OFF[i] - g.off
+                b.ds[i] = g.ds[..., c0:c0 + CONV_CH[i][1] // 2]
+        elif b.ds[l] is None and not (b.dims[l] == b.shape[1:] and not self.fuse_pool_bwd):
             h, w = b.dims[l]
             b.ds[l] = torch.empty(b.shape[0], h, w, CONV_CH[l][1] // 2, dtype=torch.float32, device=self.device)
         return b.ds[l]
 
     def _commuted(self, b, l):
         """Layer l's side conv behind the pooling instead of in front of it (see commute_side)."""
-        return (self.commute_side and self.fuse_pool_fwd and self.fuse_pool_bwd and b.group_of[l] is None
-                and CONV_CH[l][1] <= 256)
+        return (self.commute_side and self.fuse_pool_fwd and self.fuse_pool_bwd
+                and ((b.group_of[l] is not None and self.commute_side_deep) or (b.group_of[l] is None and CONV_CH[l][1] <= 256)))
 
     def release_buffers(self):
         self._bufs.clear()
@@ -490,9 +500,14 @@ class WesupEngine:
                 if commute:
                     if b.ybar[l] is None:
                         b.ybar[l] = torch.empty(B, Kmax, co, dtype=torch.float32, device=self.device)
-                    tok = T.begin('sp_pool_up_fwd')
-                    ops.sp_pool_upsample_fwd(b.y[l], meta, b.ybar[l], 0)
-                    T.end(tok, 4.0 * B * (h * w * co + H * W + Kmax * co))
+                    if grp is not None:      # coarse resolution: Ybar = Wm . y, one GEMM per image
+                        tok = T.begin('sp_pool_mat_fwd')
+                        ops.gemm_tn_batched(grp.WmT, b.y[l].view(B, h * w, co), b.ybar[l], ws_tag='side')
+                        T.end(tok, 2.0 * B * Kmax * h * w * co)
+                    else:
+                        tok = T.begin('sp_pool_up_fwd')
+                        ops.sp_pool_upsample_fwd(b.y[l], meta, b.ybar[l], 0)
+                        T.end(tok, 4.0 * B * (h * w * co + H * W + Kmax * co))
                     tok = T.begin('side_fwd')
                     ops.gemm_nt(b.ybar[l].view(B * Kmax, co), ws, p[f'side_conv{off}.bias'],
                                 out=b.sp_in.view(B * Kmax, FM_CHANNELS)[:, off:off + co // 2])
@@ -647,20 +662,45 @@ class WesupEngine:
         # kernel in flight); on a stream of its own it runs under the deep layers' GEMMs.
         ds_ready = [None] * 13
 
-        def commuted_G(l):
-            """Commuted side branch: dYbar = g_slice . W_side (B*Kmax rows), then G_l = the upsample + scatter-mean backward of
-            dYbar, written straight into the conv's gradient buffer (all C channels)."""
-            co = CONV_CH[l][1]
-            h, w = b.dims[l]
-            off = SIDE_OFF[l]
-            if b.dybar[l] is None:
-                b.dybar[l] = torch.empty(B, Kmax, co, dtype=torch.float32, device=self.device)
-            tok = T.begin('side_bwd')
-            ops.gemm_nt(gsp2d[:, off:off + co // 2], pk.sideT[l], None, out=b.dybar[l].view(R, co))
-            T.end(tok, 2.0 * R * co * (co // 2))
+        def commuted_G(ls):
+            """Commuted side branch of the layers ls (one resolution, deepest first): dYbar_l = g_slice . W_side (B*Kmax rows),
+            then G_l = the upsample + scatter-mean backward of dYbar_l, written straight into the conv's gradient buffer (all C
+            channels) -- the layers of a coarse resolution in one launch (the scan of a cell's pixel window is shared)."""
+            h, w = b.dims[ls[0]]
+            for l in ls:
+                co, off = CONV_CH[l][1], SIDE_OFF[l]
+                if b.dybar[l] is None:
+                    b.dybar[l] = torch.empty(B, Kmax, co, dtype=torch.float32, device=self.device)
+                tok = T.begin('side_bwd')
+                ops.gemm_nt(gsp2d[:, off:off + co // 2], pk.sideT[l], None, out=b.dybar[l].view(R, co))
+                T.end(tok, 2.0 * R * co * (co // 2))
+            if b.group_of[ls[0]] is not None:        # coarse resolution: G_l = Wm^T . dYbar_l, one GEMM per image
+                grp = b.groups[b.group_of[ls[0]]]
+                tok = T.begin('upsample_mat_bwd')
+                for l in ls:
+                    ops.gemm_tn_batched(grp.Wm, b.dybar[l], b.G[l].view(B, h * w, CONV_CH[l][1]), ws_tag='side')
+                T.end(tok, 2.0 * B * Kmax * h * w * sum(CONV_CH[l][1] for l in ls))
+                return
             tok = T.begin('upsample_bwd')
-            ops.upsample_bwd_fused(b.dybar[l], meta.new_row, meta.area_new, H, W, 0, h, w, co, out=b.G[l])
-            T.end(tok, 4.0 * B * (h * w * co + H * W + Kmax * co))
+            if (h, w) == (H, W) or sum(CONV_CH[l][1] for l in ls) > 768:
+                for l in ls:
+                    ops.upsample_bwd_fused(b.dybar[l], meta.new_row, meta.area_new, H, W, 0, h, w, CONV_CH[l][1], out=b.G[l])
+            else:
+                ops.upsample_bwd_fused_group([b.dybar[l] for l in ls], meta.new_row, meta.area_new, H, W, h, w,
+                                             [b.G[l] for l in ls])
+            T.end(tok, 4.0 * B * sum(h * w * CONV_CH[l][1] + H * W + Kmax * CONV_CH[l][1] for l in ls))
+
+        def commuted_runs():
+            """The commuted layers whose G the dgrad chain needs, deepest first, in runs of (at most three) layers that share a
+            resolution."""
+            runs = []
+            for l in range(12, -1, -1):
+                if b.group_of[l] is None and self._commuted(b, l) and l >= lowest:
+                    if runs and b.dims[runs[-1][0]] == b.dims[l] and len(runs[-1]) < 3:
+                        runs[-1].append(l)
+                    else:
+                        runs.append([l])
+            return runs
 
         if self.two_streams and self.fuse_pool_bwd:
             # ... at the head of the wgrad stream, which has nothing to do until the first weight gradient is queued.
@@ -670,12 +710,15 @@ class WesupEngine:
             aux = self._wg()
             aux.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(aux):
+                for ls in commuted_runs():
+                    commuted_G(ls)
+                    ev = torch.cuda.Event()
+                    ev.record()
+                    for l in ls:
+                        g_ready[l] = ev
                 for l in range(12, -1, -1):
                     if b.group_of[l] is None and self._commuted(b, l):
-                        if l >= lowest:
-                            commuted_G(l)
-                            g_ready[l] = torch.cuda.Event()
-                            g_ready[l].record()
+                        pass
                     elif b.group_of[l] is None:
                         h, w = b.dims[l]
                         tok = T.begin('upsample_bwd')
@@ -715,11 +758,20 @@ class WesupEngine:
                 off = SIDE_OFF[l]
                 P = B * h * w
                 if self._commuted(b, l):
-                    if g_ready[l] is None and l >= lowest:       # single-stream schedule: not queued above
-                        commuted_G(l)
+                    if b.group_of[l] is not None:
+                        if l >= lowest:      # layer by layer, deepest first: the dgrad chain starts with conv5_3
+                            commuted_G([l])
+                            if self.two_streams:
+                                g_ready[l] = torch.cuda.Event()
+                                g_ready[l].record()
+                    elif not self.two_streams and l >= lowest:   # single-stream schedule: not queued above
+                        for ls in commuted_runs():
+                            if ls[0] == l:
+                                commuted_G(ls)
                     if not self.side_wgrad_last:
                         side_wgrad(l)
                     continue
+                self._side_grad(b, l)            # (allocated on first use; a group's buffer serves all its layers)
                 if b.group_of[l] is not None:
                     grp = b.groups[b.group_of[l]]
                     if l == grp.layers[-1]:      # ds of every layer of this resolution at once: ds = Wm^T . gsp slice

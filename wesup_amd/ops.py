@@ -745,6 +745,25 @@ def upsample_bwd_fused(g, new_row, area_new, H, W, coff, h, w, C, out=None):
     return out
 
 
+def upsample_bwd_fused_group(gs, new_row, area_new, H, W, h, w, outs):
+    """upsample_bwd_fused for up to three layers of one coarse resolution in one launch: gs[i] (B,Kmax,C_i) dense ->
+    outs[i] (B,h,w,C_i).  The window scan per coarse cell is shared by the layers."""
+    n = len(gs)
+    assert 1 <= n <= 3 and len(outs) == n and (h, w) != (H, W)
+    B, Kmax = gs[0].shape[:2]
+    _chk(new_row, torch.int32, 'new_row'); _chk(area_new, torch.int32, 'area_new')
+    assert new_row.shape == (B, H * W) and area_new.shape == (B, Kmax)
+    for g, o in zip(gs, outs):
+        _chk(g, name='g'); _chk(o, name='out')
+        assert g.is_contiguous() and o.is_contiguous() and g.shape[:2] == (B, Kmax) and o.shape == (B, h, w, g.shape[2])
+    assert sum(g.shape[2] for g in gs) <= 768
+    pg = [_p(g) for g in gs] + [_p(None)] * (3 - n)
+    po = [_p(o) for o in outs] + [_p(None)] * (3 - n)
+    cs = [g.shape[2] for g in gs] + [0] * (3 - n)
+    _lib.call('wesup_upsample_bwd_group', *pg, *po, *cs, n, _p(new_row), _p(area_new), B, h, w, H, W, Kmax, _stream())
+    return outs
+
+
 # ---------------------------------------------------------------- superpixels
 class SuperpixelMeta:
     """Device-side result of wesup_sp_preprocess for a batch of label maps (padded to Kmax rows per image)."""
