@@ -64,6 +64,7 @@ def parse_args(argv=None):
     ap.add_argument('--side-wgrad-interleaved', action='store_true', help='A/B: side-conv weight gradients layer by layer between the '
                                                                           'G_l GEMMs (round 2\'s order) instead of behind all of them')
     ap.add_argument('--side-before-pool', action='store_true', help='A/B: the shallow side convs in front of the upsample + superpixel mean, side outputs materialised (round 2 / early round 3 schedule)')
+    ap.add_argument('--no-gather-epilogue', action='store_true', help='A/B: the side-branch gradient of conv1_1 / conv1_2 materialised (gather kernel) and accumulated into, instead of gathered by the dgrad epilogue')
     ap.add_argument('--commute-deep', action='store_true', help='A/B: the deep layers (matrix pooling) commuted as well (measured, not kept)')
     ap.add_argument('--batched-side', action='store_true', help='A/B: the side convs of the layers that share a deep resolution in one batched launch (measured, not kept)')
     ap.add_argument('--diag-skip', default='', help="TIMING-ONLY diagnostic (results are wrong): comma list of launch classes left out "
@@ -264,6 +265,7 @@ def worker(args):
     trainer.model.engine.batch_side_convs = args.batched_side
     trainer.model.engine.commute_side = not args.side_before_pool
     trainer.model.engine.commute_side_deep = args.commute_deep
+    trainer.model.engine.gather_side_grad = not args.no_gather_epilogue
     trainer.model.engine._diag_skip = set(filter(None, args.diag_skip.split(',')))
     trainer.model.engine.conv_winograd = not args.direct_conv
     if args.winograd_min_ci:
@@ -541,9 +543,12 @@ def worker(args):
                     if l in (1, 3, 6, 9):
                         hh, ww = hh // 2, ww // 2
                 own = 0.0
+                commuted = trainer.model.engine.commute_side
                 for (h_, w_, c_) in dims:
-                    own += 4.0 * h_ * w_ * c_                                    # the side output, read once
                     matrix = (h_, w_) != (H, W) and h_ * w_ <= 4096
+                    # read once: the side output -- or, for the gather layers with the side conv commuted behind the pooling,
+                    # the conv output itself (twice the channels; the side output is never formed)
+                    own += 4.0 * h_ * w_ * (c_ if (matrix or not commuted) else 2 * c_)
                     own += 0.0 if matrix else 4.0 * H * W                        # gather layers: the sorted pixel list
                 for (h_, w_) in sorted({(h_, w_) for (h_, w_, _) in dims if (h_, w_) != (H, W) and h_ * w_ <= 4096}):
                     own += 4 * 4.0 * g * g * h_ * w_                             # Wm and its transpose: written, then read
@@ -553,7 +558,9 @@ def worker(args):
                          'materialised_model': {'bytes': by, 'what': 'SURVEY 8(d): 2112*HW*4 + HW*4 + N*2112*4 per image -- the bytes of '
                                                                      'the scatter-mean over a materialised feature map, which these '
                                                                      'kernels never read: the fraction may exceed 1'},
-                         'own_model': {'bytes': own, 'what': 'side outputs at native resolution + pixel lists of the gather layers + '
+                         'own_model': {'bytes': own, 'what': 'what the pooling reads at native resolution (gather layers: the conv '
+                                                             'output, all C channels, the side conv being applied to the pooled rows; '
+                                                             'matrix layers: the side output) + pixel lists of the gather layers + '
                                                              'the interpolation-pooling matrices (written and read) + N*2112*4'}}
                 for key, bts in (('materialised_model', by), ('own_model', own)):
                     for nm, ms_ in (('in_step', f_in), ('alone', f_alone)):

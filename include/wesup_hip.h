@@ -190,6 +190,24 @@ int wesup_winograd_gemm_output_transform(const float* V, long plane_elems, const
                                          const float* mask_src, float* y, float* y_pool, int pool_relu,
                                          const float* unpool_src, float* unpool_dst, int Hu, int Wu,
                                          int B, int H, int W, int K, int N, int accumulate, void* stream);
+/* ... with the destination's OLD content replaced by a gather: with the side conv of a native-resolution layer applied
+ * behind the superpixel mean (the two commute, models/wesup.py:246-261,281-285), the side-branch gradient of that layer's
+ * conv output is constant over a superpixel: side [B][Kmax][N] one row per superpixel, new_row [B][pixels] the pixel's row,
+ * area_new [B][Kmax]; value(pixel) = side[new_row[pixel]] / area_new[new_row[pixel]] (what wesup_upsample_bwd would write).
+ * y form: y = value(pixel) + (mask_src > 0 ? result : 0).  unpool form (unpool_src (B,Hu,Wu,N) given, y is the (B,Hu,Wu,N)
+ * destination, Hu and Wu even): every position of a 2x2 window = its value, the first positive maximum of unpool_src gets
+ * the window's result on top.  The destination is written, never read. */
+int wesup_winograd_gemm_output_transform_gather(const float* V, long plane_elems, const float* U, const float* mask_src,
+                                                float* y, const float* unpool_src, int Hu, int Wu, const float* side,
+                                                const int32_t* new_row, const int32_t* area_new, int Kmax,
+                                                int B, int H, int W, int K, int N, void* stream);
+/* wesup_conv3x3_dgrad_winograd(accumulate = 1) resp. wesup_conv3x3_dgrad_winograd_unpool (unpool_src given; dx is then
+ * (B,Hu,Wu,Cin)) with that gather in the epilogue instead of a materialised side-branch gradient in dx.  m = 4; product shapes
+ * with wesup_winograd_fused_supported(Cout, Cin, 4) == 2, otherwise WESUP_ERR_INVALID (materialise, use the forms above). */
+int wesup_conv3x3_dgrad_winograd_gather(const float* dy, const float* u_dgrad, const float* mask_src,
+                                        const float* unpool_src, float* dx, const float* side, const int32_t* new_row,
+                                        const int32_t* area_new, int Kmax, int B, int H, int W, int Hu, int Wu,
+                                        int Cin, int Cout, void* ws, size_t ws_bytes, void* stream);
 /* The weight gradient's own transforms: dy (B,H,W,C) -> dM [P][tiles][C] = A dY A^T per m x m tile; and the way back from
  * the split-K slabs of the P transformed filter gradients ([P][S][Cout*Cin + Cout], each slab followed by the Cout
  * column sums of its dM operand) to dw (Cout,Cin,3,3) = G^T (sum over S) G.  The bias gradient db = sum over pixels of dy:

@@ -472,6 +472,44 @@ def test_conv3x3_dgrad_winograd_through_the_maxpool_backward(ops, B, Hu, Wu, Cin
     assert torch.equal(again, fused)
 
 
+@pytest.mark.parametrize('B,Hd,Wd,g,Cin,Cout,pooled', [(2, 32, 32, 4, 64, 64, False), (1, 44, 36, 5, 64, 128, True), (2, 24, 40, 4, 64, 64, True),
+                                                      (1, 30, 26, 3, 128, 64, False)])
+def test_conv3x3_dgrad_winograd_with_the_side_gradient_gathered_in_the_epilogue(ops, B, Hd, Wd, g, Cin, Cout, pooled):
+    """conv3x3_dgrad_winograd_gather: the destination's old content (the side-branch gradient of a native-resolution layer of
+    the commuted side branch: one row per superpixel over its area) is gathered by the epilogue instead of being materialised by
+    wesup_upsample_bwd and accumulated into.  Against exactly that pair of launches -- masked accumulate form and max-pool
+    backward form (destination (Hd, Wd), dy at half of it) -- to the rounding of one multiply-add."""
+    d = dev()
+    labs, masks = _sp_case(3, B, Hd, Wd, g)
+    Kmax = int(labs.max()) + 3
+    m = ops.sp_preprocess(torch.from_numpy(labs).to(d), torch.from_numpy(masks).to(d), Kmax)
+    side = rnd(B, Kmax, Cin, seed=7).to(d)
+    H, W = (Hd // 2, Wd // 2) if pooled else (Hd, Wd)
+    w = rnd(Cout, Cin, 3, 3, seed=2, scale=(2.0 / (9 * Cin)) ** 0.5)
+    _, ud = ops.winograd_pack_weight(w.to(d), need_fwd=False, m=4)
+    dy = nhwc(rnd(B, Cout, H, W, seed=4)).to(d)
+    ypre = rnd(B, Hd, Wd, Cin, seed=1).to(d)
+    want = ops.upsample_bwd_fused(side, m.new_row, m.area_new, Hd, Wd, 0, Hd, Wd, Cin)
+    base = want.clone()
+    if pooled:
+        ops.conv3x3_dgrad_winograd_unpool(dy, ud, ypre, want)
+    else:
+        ops.conv3x3_dgrad_winograd(dy, ud, mask_src=ypre, out=want, accumulate=True, m=4)
+    got = torch.full((B, Hd, Wd, Cin), float('nan'), device=d)
+    ops.conv3x3_dgrad_winograd_gather(dy, ud, side, m.new_row, m.area_new, out=got, mask_src=None if pooled else ypre,
+                                      unpool_src=ypre if pooled else None)
+    scale = float(want.abs().max())
+    assert float((got - want).abs().max()) <= 2e-7 * scale
+    assert float((want - base).abs().max()) > 0.05 * scale         # the conv part is not negligible beside the gathered part
+    class _T:
+        def begin(self, tag): return tag
+        def end(self, tok, work): pass
+    again = torch.empty_like(got)
+    ops.conv3x3_dgrad_winograd_gather(dy, ud, side, m.new_row, m.area_new, out=again, mask_src=None if pooled else ypre,
+                                      unpool_src=ypre if pooled else None, timer=_T())
+    assert torch.equal(again, got)
+
+
 @pytest.mark.parametrize('B,H,W,Cin,Cout', [c for c in CONV_CASES if c[3] != 3])
 def test_conv3x3_dgrad(ops, B, H, W, Cin, Cout):
     d = dev()

@@ -49,6 +49,8 @@ _SIGS = {
     'wesup_winograd_output_transform_unpool': (c_int, 'plppppiiiiiiip'),
     'wesup_winograd_fused_supported': (c_int, 'iii'),
     'wesup_winograd_gemm_output_transform': (c_int, 'plpppppippiiiiiiiip'),
+    'wesup_winograd_gemm_output_transform_gather': (c_int, 'plppppiipppiiiiiip'),
+    'wesup_conv3x3_dgrad_winograd_gather': (c_int, 'ppppppppiiiiiiiipzp'),
     'wesup_winograd_input_transform': (c_int, 'ppliiiiiip'),
     'wesup_gemm_nt_batched': (c_int, 'pilpilpiliiiip'),
     'wesup_gemm_nt_batched_bias': (c_int, 'pilpilplpiliiiip'),

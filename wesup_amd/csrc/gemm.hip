@@ -1479,6 +1479,26 @@ extern "C" int wesup_conv3x3_dgrad_winograd(const float* dy, const float* u_dgra
                      ws, ws_bytes, stream);
 }
 
+// wesup_conv3x3_dgrad_winograd (accumulate form) / _unpool for a destination whose old content is the side-branch gradient of
+// a native-resolution layer with the side conv commuted behind the superpixel mean: that gradient is a gather
+// (side[b][new_row[b][pixel]] / area), taken in the epilogue -- dx is written, never read, and nobody materialises the
+// gather.  m = 4, product shapes of the fused kernel only (wesup_winograd_fused_supported(Cout, Cin, 4) == 2).
+extern "C" int wesup_conv3x3_dgrad_winograd_gather(const float* dy, const float* u_dgrad, const float* mask_src,
+                                                   const float* unpool_src, float* dx, const float* side,
+                                                   const int32_t* new_row, const int32_t* area_new, int Kmax, int B, int H, int W,
+                                                   int Hu, int Wu, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream) {
+    if (!dy || !u_dgrad || !dx || !ws || !wino_shape_ok(B, H, W, Cout, Cin, 4) || wino_fused_supported(Cout, Cin, 4) != 2 ||
+        (((uintptr_t)u_dgrad | (uintptr_t)ws) & 15))
+        return WESUP_ERR_INVALID;
+    if (unpool_src && (Hu / 2 != H || Wu / 2 != W)) return WESUP_ERR_INVALID;
+    if (ws_bytes < wesup_conv3x3_winograd_workspace_bytes(B, H, W, Cout, Cin, 4)) return WESUP_ERR_WORKSPACE;
+    float* V = (float*)ws;
+    const int rc = wesup_winograd_input_transform(dy, V, 0, B, H, W, Cout, 0, 4, stream);
+    if (rc) return rc;
+    return wesup_winograd_gemm_output_transform_gather(V, 0, u_dgrad, mask_src, dx, unpool_src, Hu, Wu, side, new_row, area_new,
+                                                       Kmax, B, H, W, Cout, Cin, stream);
+}
+
 // The input gradient of a layer that follows a max-pool, taken straight through the pooling's backward (m = 4): nothing is
 // written at pooled resolution; every value is added to unpool_dst (B,Hu,Wu,Cin) -- the gradient w.r.t. the pre-pool
 // activations unpool_src, which already holds the side-branch gradient -- at the first positive maximum of its window.

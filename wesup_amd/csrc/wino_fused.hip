@@ -28,6 +28,7 @@ struct FusedParams {
     const float* up_src;     // unpool mode: pre-pool activations (B,Hu,Wu,N)
     float* up_dst;           // ... and the gradient they receive (accumulated into)
     int Hu, Wu;
+    WinoGather gat;          // side-branch gradient gathered per pixel in place of reading y / up_dst (src NULL: off)
     int H, W, Th, Tw;
     long T;                  // tiles
     int N;
@@ -236,10 +237,14 @@ __global__ __launch_bounds__(256, 2) void wino4_gemm_out_kernel(const FusedParam
                 v.z = mk.z > 0.f ? v.z : 0.f; v.w = mk.w > 0.f ? v.w : 0.f;
             }
             if (up.src) {            // input gradient at pooled resolution: straight through the max-pool backward
-                wino_unpool_add(up, b, h, w, p.N, n0 + 4 * q4, v);
+                if (p.gat.src) wino_unpool_gather(up, p.gat, b, h, w, p.N, n0 + 4 * q4, v);
+                else wino_unpool_add(up, b, h, w, p.N, n0 + 4 * q4, v);
                 continue;
             }
-            if (p.accum) {
+            if (p.gat.src) {
+                const float4 old = wino_gather(p.gat, b, (long)h * p.W + w, p.N, n0 + 4 * q4);
+                v = make_float4(v.x + old.x, v.y + old.y, v.z + old.z, v.w + old.w);
+            } else if (p.accum) {
                 const float4 old = ld4(p.y + off);
                 v = make_float4(v.x + old.x, v.y + old.y, v.z + old.z, v.w + old.w);
             }
@@ -293,10 +298,9 @@ extern "C" int wesup_winograd_fused_supported(int K, int N, int m) { return wino
 
 // V [36][tiles][K] (plane stride plane_elems, 0 = tiles * K) x U [36][N][K] -> y = A^T (V_p . U_p^T) A + the output
 // transform's epilogue (wesup_winograd_output_transform / _unpool), without the transformed output in between.
-extern "C" int wesup_winograd_gemm_output_transform(const float* V, long plane_elems, const float* U, const float* bias,
-                                                    const float* mask_src, float* y, float* y_pool, int pool_relu,
-                                                    const float* unpool_src, float* unpool_dst, int Hu, int Wu, int B, int H,
-                                                    int W, int K, int N, int accumulate, void* stream) {
+static int fused_launch(const float* V, long plane_elems, const float* U, const float* bias, const float* mask_src, float* y,
+                        float* y_pool, int pool_relu, const float* unpool_src, float* unpool_dst, int Hu, int Wu, int B, int H,
+                        int W, int K, int N, int accumulate, const WinoGather& gat, void* stream) {
     if (!V || !U || (!y && !unpool_src) || !wino_shape_ok(B, H, W, K, N, 4) || !(K == 64 || K == 128 || K == 256) || N < 64 || (N % 64) ||
         (((uintptr_t)V | (uintptr_t)U) & 15) || (plane_elems % 4))
         return WESUP_ERR_INVALID;
@@ -307,6 +311,7 @@ extern "C" int wesup_winograd_gemm_output_transform(const float* V, long plane_e
     FusedParams p = {};
     p.V = V; p.plane_v = plane_elems > 0 ? plane_elems : T * K; p.U = U; p.bias = bias; p.mask = mask_src; p.y = y;
     p.y_pool = y_pool; p.pool_relu = pool_relu; p.accum = accumulate; p.up_src = unpool_src; p.up_dst = unpool_dst;
+    p.gat = gat;
     p.Hu = Hu; p.Wu = Wu; p.H = H; p.W = W; p.Th = (H + 3) / 4; p.Tw = (W + 3) / 4; p.T = T; p.N = N;
     p.dTw = make_fastdiv(p.Tw); p.dTh = make_fastdiv(p.Th);
     p.tile_blocks = (int)ceil_div(T, 32l); p.n_blocks = N / 64; p.dNb = make_fastdiv(p.n_blocks);
@@ -329,4 +334,28 @@ extern "C" int wesup_winograd_gemm_output_transform(const float* V, long plane_e
     else hipLaunchKernelGGL(wino4_gemm_out_kernel<4>, grid, dim3(256), lds, (hipStream_t)stream, p);
     WESUP_CHECK_LAUNCH();
     return WESUP_OK;
+}
+
+extern "C" int wesup_winograd_gemm_output_transform(const float* V, long plane_elems, const float* U, const float* bias,
+                                                    const float* mask_src, float* y, float* y_pool, int pool_relu,
+                                                    const float* unpool_src, float* unpool_dst, int Hu, int Wu, int B, int H,
+                                                    int W, int K, int N, int accumulate, void* stream) {
+    return fused_launch(V, plane_elems, U, bias, mask_src, y, y_pool, pool_relu, unpool_src, unpool_dst, Hu, Wu, B, H, W, K, N,
+                        accumulate, WinoGather{nullptr, nullptr, nullptr, 0, 0}, stream);
+}
+
+// The same with the old content of the destination replaced by a per-pixel gather (WinoGather, winograd.hpp): the destination
+// is written, never read.  y form: y = gather(pixel) + masked result; unpool form (unpool_src given, Hu, Wu even): every
+// position of a window = its gather, the first positive maximum gets the window's result on top.
+extern "C" int wesup_winograd_gemm_output_transform_gather(const float* V, long plane_elems, const float* U, const float* mask_src,
+                                                           float* y, const float* unpool_src, int Hu, int Wu, const float* side,
+                                                           const int32_t* new_row, const int32_t* area_new, int Kmax, int B,
+                                                           int H, int W, int K, int N, void* stream) {
+    if (!side || !new_row || !area_new || Kmax <= 0 || !y || (((uintptr_t)side) & 15)) return WESUP_ERR_INVALID;
+    if (unpool_src && ((Hu & 1) || (Wu & 1))) return WESUP_ERR_INVALID;
+    const WinoGather gat = {side, new_row, area_new, Kmax, unpool_src ? (long)Hu * Wu : (long)H * W};
+    if (unpool_src)
+        return fused_launch(V, plane_elems, U, nullptr, mask_src, nullptr, nullptr, 0, unpool_src, y, Hu, Wu, B, H, W, K, N, 0, gat,
+                            stream);
+    return fused_launch(V, plane_elems, U, nullptr, mask_src, y, nullptr, 0, nullptr, nullptr, 0, 0, B, H, W, K, N, 0, gat, stream);
 }

@@ -48,6 +48,48 @@ __device__ __forceinline__ void wino_unpool_add(const WinoUnpool& u, int b, int 
     }
 }
 
+// The side-branch gradient of a native-resolution layer as a gather (commuted side branch, engine.py: the side conv sits
+// behind the superpixel mean, so that gradient is constant over a superpixel): side [B][Kmax][C] rows per superpixel,
+// row [B][H*W] the pixel's superpixel row, area [B][Kmax].  value(b, pix) = side[b][row[b][pix]][.] / area[b][row[b][pix]]
+// -- what wesup_upsample_bwd writes for such a layer, read here by the epilogue that would otherwise accumulate into it.
+struct WinoGather {
+    const float* src;    // NULL: no gather
+    const int32_t* row;
+    const int32_t* area;
+    int Kmax;
+    long HW;             // pixels per image at the resolution of the epilogue's destination
+};
+__device__ __forceinline__ float4 wino_gather(const WinoGather& g, int b, long pix, int C, int c0) {
+    const int r = g.row[(long)b * g.HW + pix];
+    const float coef = 1.f / (float)g.area[(long)b * g.Kmax + r];
+    const float4 t = ld4(g.src + ((long)b * g.Kmax + r) * C + c0);
+    return make_float4(coef * t.x, coef * t.y, coef * t.z, coef * t.w);
+}
+// wino_unpool_add with the destination's old content replaced by the gather: every position of the window is WRITTEN
+// (gathered side gradient, plus v at the first positive maximum); Hu, Wu even (every pre-pool pixel sits in a window).
+__device__ __forceinline__ void wino_unpool_gather(const WinoUnpool& u, const WinoGather& g, int b, int h, int w, int C, int c0,
+                                                   float4 v) {
+    const long rs = (long)u.Wu * C;
+    const long o00 = (((long)b * u.Hu + 2 * h) * u.Wu + 2 * w) * C + c0;
+    const float4 a0 = ld4(u.src + o00), a1 = ld4(u.src + o00 + C), a2 = ld4(u.src + o00 + rs), a3 = ld4(u.src + o00 + rs + C);
+    auto pick = [](float p0, float p1, float p2, float p3) {
+        int best = 0;
+        float m = p0;
+        if (p1 > m) { m = p1; best = 1; }
+        if (p2 > m) { m = p2; best = 2; }
+        if (p3 > m) { m = p3; best = 3; }
+        return m > 0.f ? best : -1;
+    };
+    const int kx = pick(a0.x, a1.x, a2.x, a3.x), ky = pick(a0.y, a1.y, a2.y, a3.y), kz = pick(a0.z, a1.z, a2.z, a3.z),
+              kw = pick(a0.w, a1.w, a2.w, a3.w);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        float4 o = wino_gather(g, b, (long)(2 * h + (k >> 1)) * u.Wu + 2 * w + (k & 1), C, c0);
+        o.x += kx == k ? v.x : 0.f; o.y += ky == k ? v.y : 0.f; o.z += kz == k ? v.z : 0.f; o.w += kw == k ? v.w : 0.f;
+        st4(u.dst + o00 + (k >> 1) * rs + (k & 1) * C, o);
+    }
+}
+
 #endif
 
 // internal entry points of winograd.hip used by the weight-gradient pass in gemm.hip (not part of the C ABI): the F(4x4)

@@ -153,6 +153,10 @@ class WesupEngine:
         # spent there again and the products are less efficient (N = 512 per layer instead of 768 per resolution): alone on the
         # GPU 1.04 -> 1.15 ms for the four classes involved, step 9.37 -> 9.41 ms.  Measured, off (bench.py --commute-deep).
         self.commute_side_deep = False
+        # native-resolution layers of the commuted side branch (conv1_1, conv1_2): their side-branch gradient is a gather of one
+        # row per superpixel; the dgrad epilogue that used to accumulate into the materialised gather takes it itself
+        # (conv3x3_dgrad_winograd_gather): G_l is written once, by that epilogue, and never read for accumulation
+        self.gather_side_grad = True
         self.batch_side_convs = False    # A/B: side convs (and their input gradients) of the layers that share a deep resolution in one launch
         self.head_streamk = False
         self._diag_skip = set()          # TIMING-ONLY diagnostics (bench.py --diag-skip): classes of launches left out, results wrong
@@ -684,11 +688,22 @@ class WesupEngine:
             tok = T.begin('upsample_bwd')
             if (h, w) == (H, W) or sum(CONV_CH[l][1] for l in ls) > 768:
                 for l in ls:
-                    ops.upsample_bwd_fused(b.dybar[l], meta.new_row, meta.area_new, H, W, 0, h, w, CONV_CH[l][1], out=b.G[l])
+                    if not gat[l]:           # (gat: the dgrad epilogue of layer l + 1 gathers from dYbar_l itself)
+                        ops.upsample_bwd_fused(b.dybar[l], meta.new_row, meta.area_new, H, W, 0, h, w, CONV_CH[l][1], out=b.G[l])
             else:
                 ops.upsample_bwd_fused_group([b.dybar[l] for l in ls], meta.new_row, meta.area_new, H, W, h, w,
                                              [b.G[l] for l in ls])
-            T.end(tok, 4.0 * B * sum(h * w * CONV_CH[l][1] + H * W + Kmax * CONV_CH[l][1] for l in ls))
+            T.end(tok, 4.0 * B * sum(h * w * CONV_CH[l][1] + H * W + Kmax * CONV_CH[l][1] for l in ls if not gat[l]))
+
+        # native-resolution commuted layers whose G is written by the dgrad epilogue of the layer above (gather form)
+        gat = [False] * 13
+        if self.gather_side_grad:
+            for l in range(0, 12):
+                ci1, co1 = CONV_CH[l + 1]
+                if (b.group_of[l] is None and self._commuted(b, l) and b.dims[l] == (H, W) and l >= lowest
+                        and b.wino_fwd[l + 1] == 4 and ops.winograd_fused_supported(co1, ci1, 4) == 2
+                        and (not POOL_AFTER[l] or (self.fuse_unpool and H % 2 == 0 and W % 2 == 0))):
+                    gat[l] = True
 
         def commuted_runs():
             """The commuted layers whose G the dgrad chain needs, deepest first, in runs of (at most three) layers that share a
@@ -866,7 +881,13 @@ class WesupEngine:
                 if g_ready[l - 1] is not None:
                     main.wait_event(g_ready[l - 1])
                 unpooled = False
-                if b.wino_fwd[l]:
+                if gat[l - 1]:
+                    pooled = POOL_AFTER[l - 1]
+                    ops.conv3x3_dgrad_winograd_gather(b.G[l], pk.ud[l], b.dybar[l - 1], meta.new_row, meta.area_new, out=b.G[l - 1],
+                                                      mask_src=None if pooled else b.y[l - 1],
+                                                      unpool_src=b.y[l - 1] if pooled else None, ws_tag='wino_main', timer=T)
+                    unpooled = True
+                elif b.wino_fwd[l]:
                     if POOL_AFTER[l - 1] and self.fuse_unpool and b.wino_fwd[l] == 4:
                         ops.conv3x3_dgrad_winograd_unpool(b.G[l], pk.ud[l], b.y[l - 1], b.G[l - 1], ws_tag='wino_main', timer=T)
                         unpooled = True

@@ -592,6 +592,55 @@ def conv3x3_dgrad_winograd_unpool(dy, u_dgrad, unpool_src, unpool_dst, ws_tag='d
     return unpool_dst
 
 
+def winograd_fused_supported(K, N, m=4):
+    """0: the products of this shape go through the batched GEMM + output transform; 1 / 2: through the one-kernel route in the
+    forward / in every pass (wesup_winograd_fused_supported)."""
+    return int(_lib.load().wesup_winograd_fused_supported(K, N, m))
+
+
+def conv3x3_dgrad_winograd_gather(dy, u_dgrad, side, new_row, area_new, out, mask_src=None, unpool_src=None,
+                                  ws_tag='default', timer=None):
+    """conv3x3_dgrad_winograd(accumulate=True) / conv3x3_dgrad_winograd_unpool (unpool_src given) with out's old content
+    replaced by the gather side[b][new_row[b][pixel]] / area_new[...] (side (B,Kmax,Cin): the commuted side-branch gradient of
+    a native-resolution layer): out is written, never read.  m = 4, shapes of the one-kernel product route only."""
+    for t, n in ((dy, 'dy'), (u_dgrad, 'u_dgrad'), (side, 'side'), (out, 'out')):
+        _chk(t, name=n)
+    _chk(new_row, torch.int32, 'new_row'); _chk(area_new, torch.int32, 'area_new')
+    B, H, W, Cout = dy.shape
+    Cin = u_dgrad.shape[1]
+    Kmax = side.shape[1]
+    assert u_dgrad.shape == (36, Cin, Cout) and side.shape == (B, Kmax, Cin) and area_new.shape == (B, Kmax)
+    Hu = Wu = 0
+    if unpool_src is not None:
+        _chk(unpool_src, name='unpool_src')
+        _, Hu, Wu, _ = unpool_src.shape
+        assert unpool_src.shape == (B, Hu, Wu, Cin) == out.shape and (Hu // 2, Wu // 2) == (H, W) and Hu % 2 == 0 and Wu % 2 == 0
+        assert mask_src is None and new_row.shape == (B, Hu * Wu)
+    else:
+        assert out.shape == (B, H, W, Cin) and new_row.shape == (B, H * W)
+        if mask_src is not None:
+            _chk(mask_src, name='mask_src'); assert mask_src.shape == out.shape
+    lib = _lib.load()
+    if lib.wesup_winograd_fused_supported(Cout, Cin, 4) != 2:
+        raise _lib.WesupHipError(f'conv3x3_dgrad_winograd_gather: product {Cout} -> {Cin} is not on the one-kernel route')
+    nb = lib.wesup_conv3x3_winograd_workspace_bytes(B, H, W, Cout, Cin, 4)
+    ws = workspace(nb, dy.device, ws_tag)
+    if timer is None:
+        _lib.call('wesup_conv3x3_dgrad_winograd_gather', _p(dy), _p(u_dgrad), _p(mask_src), _p(unpool_src), _p(out), _p(side),
+                  _p(new_row), _p(area_new), Kmax, B, H, W, Hu, Wu, Cin, Cout, _p(ws), nb, _stream())
+        return out
+    T, P = winograd_tiles(B, H, W, 4), 36
+    st = _stream()
+    tok = timer.begin('winograd_transform')
+    _lib.call('wesup_winograd_input_transform', _p(dy), _p(ws), 0, B, H, W, Cout, 0, 4, st)
+    timer.end(tok, 4.0 * (B * H * W + P * T) * Cout)
+    tok = timer.begin('winograd_gemm')
+    _lib.call('wesup_winograd_gemm_output_transform_gather', _p(ws), 0, _p(u_dgrad), _p(mask_src), _p(out), _p(unpool_src), Hu, Wu,
+              _p(side), _p(new_row), _p(area_new), Kmax, B, H, W, Cout, Cin, st)
+    timer.end(tok, 2.0 * P * T * Cin * Cout)
+    return out
+
+
 def conv3x3_wgrad_winograd(x, dy, relu_in, dw=None, db=None, ws_tag='default', v_pre=None, m=2):
     """The same (dw, db) as conv3x3_wgrad through the Winograd F(m x m, 3x3) domain: 2.25x (m = 2) / 4x (m = 4) fewer
     multiply-adds, 4x / 2.25x the operand bytes; for the wide layers (Ci, Cout >= 128)."""
