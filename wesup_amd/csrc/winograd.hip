@@ -135,26 +135,45 @@ __device__ __forceinline__ void wino_gt(const float (&u)[NP], float (&r)[3]) {  
 // Bias gradient, in the blocks behind the pair blocks: F(2x2) from the column sums stored behind each slab of position
 // (1,1); F(4x4) from the per-block rows wino4_outgrad_transform_kernel left (bias_part [bias_rows][Co]): a block takes 16
 // channels, 64 row groups of 4 lanes each walk the rows, LDS folds the groups in a fixed order.
-template <int NP>
+// PB pairs per block: 64, or 16 for the narrow layers (64 x 64 ... 128 x 128 filters: with 64 pairs a block the grid is 64 ..
+// 256 blocks and every thread walks 9 positions x S <= 28 slabs one load after the other; 16 pairs x 16 position groups
+// quarter that walk and fill the chip.  The sum over the slabs of one (position, pair) keeps its order: same bits.)
+template <int NP, int PB>
 __global__ __launch_bounds__(256) void wino_wgrad_reduce_kernel(const float* __restrict__ slab, long stride, long batch_slab,
                                                                 float* __restrict__ dw, int Co, int Ci, int S,
                                                                 float* __restrict__ db, int pair_blocks,
                                                                 const float* __restrict__ bias_part, int bias_rows) {
-    constexpr int P = NP * NP, PB = 64;
-    __shared__ __attribute__((aligned(16))) float us[P][PB + 1];
+    constexpr int P = NP * NP, PG = 256 / PB;            // PG position groups
+    __shared__ __attribute__((aligned(16))) float us[(P * (PB + 1) > 1024 ? P * (PB + 1) : 1024)];
     const int tid = threadIdx.x;
     if ((int)blockIdx.x >= pair_blocks) {                // bias gradient
         const int bb = blockIdx.x - pair_blocks;
         if (!db) return;
         if (bias_part) {
-            float4* sh = reinterpret_cast<float4*>(&us[0][0]);       // 256 float4 = 4 KiB <= sizeof(us)
+            float4* sh = reinterpret_cast<float4*>(us);              // 256 float4 = 4 KiB <= sizeof(us)
             const int cq = tid & 3, rg = tid >> 2, c = 16 * bb + 4 * cq;
             float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (c < Co)
-                for (int r = rg; r < bias_rows; r += 64) {
-                    const float4 v = ld4(bias_part + (long)r * Co + c);
-                    acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+            if (c < Co) {
+                // (57 600 rows for a 480^2 x 64 gradient, 4 blocks: eight rows in flight per thread, eight running sums
+                // folded in a fixed order)
+                float4 a8[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) a8[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                int r = rg;
+                for (; r + 7 * 64 < bias_rows; r += 8 * 64) {
+                    float4 v[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) v[u] = ld4(bias_part + (long)(r + 64 * u) * Co + c);
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) { a8[u].x += v[u].x; a8[u].y += v[u].y; a8[u].z += v[u].z; a8[u].w += v[u].w; }
                 }
+                for (; r < bias_rows; r += 64) {
+                    const float4 v = ld4(bias_part + (long)r * Co + c);
+                    a8[0].x += v.x; a8[0].y += v.y; a8[0].z += v.z; a8[0].w += v.w;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { acc.x += a8[u].x; acc.y += a8[u].y; acc.z += a8[u].z; acc.w += a8[u].w; }
+            }
             sh[tid] = acc;
             __syncthreads();
             if (tid < 4 && c < Co) {
@@ -177,7 +196,7 @@ __global__ __launch_bounds__(256) void wino_wgrad_reduce_kernel(const float* __r
     const int i = tid & (PB - 1);
     const long idx = (long)blockIdx.x * PB + i;
     const bool ok = idx < (long)Co * Ci;
-    for (int p = tid >> 6; p < P; p += 4) {
+    for (int p = tid / PB; p < P; p += PG) {
         float s0 = 0.f, s1 = 0.f;
         if (ok) {
             const float* src = slab + p * batch_slab + idx;
@@ -185,7 +204,7 @@ __global__ __launch_bounds__(256) void wino_wgrad_reduce_kernel(const float* __r
             for (; k + 1 < S; k += 2) { s0 += src[(long)k * stride]; s1 += src[(long)(k + 1) * stride]; }
             if (k < S) s0 += src[(long)k * stride];
         }
-        us[p][i] = s0 + s1;
+        us[p * (PB + 1) + i] = s0 + s1;
     }
     __syncthreads();
     if (tid >= PB || !ok) return;
@@ -194,7 +213,7 @@ __global__ __launch_bounds__(256) void wino_wgrad_reduce_kernel(const float* __r
     for (int c = 0; c < NP; ++c) {
         float col[NP], o[3];
 #pragma unroll
-        for (int a = 0; a < NP; ++a) col[a] = us[NP * a + c][i];
+        for (int a = 0; a < NP; ++a) col[a] = us[(NP * a + c) * (PB + 1) + i];
         wino_gt<NP>(col, o);
         r[0][c] = o[0]; r[1][c] = o[1]; r[2][c] = o[2];
     }
@@ -699,14 +718,18 @@ extern "C" int wesup_winograd_outgrad_transform(const float* dy, float* dM, floa
 int wino_filter_grad_launch(const float* slabs, long slab_stride, long batch_stride, int S, float* dw_kcrs, float* db, int Cout,
                             int Cin, int m, const float* bias_part, int bias_rows, void* stream) {
     const long tot = (long)Cout * Cin;
-    const int pair_blocks = (int)((tot + 63) / 64);
+    const bool narrow = m == 4 && tot / 64 < 512;        // few pairs: 16 per block
+    const int pair_blocks = (int)((tot + (narrow ? 15 : 63)) / (narrow ? 16 : 64));
     const int bias_blocks = !db ? 0 : bias_part ? (Cout + 15) / 16 : (Cout + 255) / 256;
     const dim3 grid((unsigned)(pair_blocks + bias_blocks));
     if (m == 2)
-        hipLaunchKernelGGL(wino_wgrad_reduce_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, slabs, slab_stride,
+        hipLaunchKernelGGL((wino_wgrad_reduce_kernel<4, 64>), grid, dim3(256), 0, (hipStream_t)stream, slabs, slab_stride,
                            batch_stride, dw_kcrs, Cout, Cin, S, db, pair_blocks, (const float*)nullptr, 0);
+    else if (narrow)
+        hipLaunchKernelGGL((wino_wgrad_reduce_kernel<6, 16>), grid, dim3(256), 0, (hipStream_t)stream, slabs, slab_stride,
+                           batch_stride, dw_kcrs, Cout, Cin, S, db, pair_blocks, bias_part, bias_rows);
     else
-        hipLaunchKernelGGL(wino_wgrad_reduce_kernel<6>, grid, dim3(256), 0, (hipStream_t)stream, slabs, slab_stride,
+        hipLaunchKernelGGL((wino_wgrad_reduce_kernel<6, 64>), grid, dim3(256), 0, (hipStream_t)stream, slabs, slab_stride,
                            batch_stride, dw_kcrs, Cout, Cin, S, db, pair_blocks, bias_part, bias_rows);
     WESUP_CHECK_LAUNCH();
     return WESUP_OK;
