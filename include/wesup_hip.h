@@ -201,6 +201,21 @@ int wesup_winograd_gemm_output_transform_gather(const float* V, long plane_elems
                                                 float* y, const float* unpool_src, int Hu, int Wu, const float* side,
                                                 const int32_t* new_row, const int32_t* area_new, int Kmax,
                                                 int B, int H, int W, int K, int N, void* stream);
+/* Compact forms of what the backward needs of the forward's activations (F(4x4) route; 16x resp. 32x smaller than the tensors
+ * they replace).  relu_bits [B][H][W][C/4] bytes: bit j of byte q = x[..., 4q + j] > 0 -- the ReLU decisions of the layer that
+ * produced x, written by the input transform of the layer that consumes it (it reads x anyway).  pool codes
+ * [B][H/2][W/2][C/4] uint16, 3 bits per channel of the quad: 0 = the window's maximum is not positive, k + 1 = first maximum at
+ * window position k (row-major: torch's scan order) -- the max-pool's decisions, written by the epilogue that pools.
+ * wesup_winograd_gemm_output_transform_ex: every option of the one-kernel route.  mask_bits instead of mask_src; pool_code
+ * OUT (needs y_pool); unpool_code IN instead of reading unpool_src (then optional); side != NULL selects the gather forms. */
+int wesup_winograd_input_transform_bits(const float* x, float* V, long plane_elems, unsigned char* relu_bits,
+                                        int B, int H, int W, int C, int relu_in, void* stream);
+int wesup_winograd_gemm_output_transform_ex(const float* V, long plane_elems, const float* U, const float* bias,
+                                            const float* mask_src, const unsigned char* mask_bits, float* y, float* y_pool,
+                                            int pool_relu, unsigned short* pool_code, const float* unpool_src,
+                                            const unsigned short* unpool_code, float* unpool_dst, int Hu, int Wu,
+                                            const float* side, const int32_t* new_row, const int32_t* area_new, int Kmax,
+                                            int B, int H, int W, int K, int N, int accumulate, void* stream);
 /* wesup_conv3x3_dgrad_winograd(accumulate = 1) resp. wesup_conv3x3_dgrad_winograd_unpool (unpool_src given; dx is then
  * (B,Hu,Wu,Cin)) with that gather in the epilogue instead of a materialised side-branch gradient in dx.  m = 4; product shapes
  * with wesup_winograd_fused_supported(Cout, Cin, 4) == 2, otherwise WESUP_ERR_INVALID (materialise, use the forms above). */

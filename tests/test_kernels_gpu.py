@@ -510,6 +510,77 @@ def test_conv3x3_dgrad_winograd_with_the_side_gradient_gathered_in_the_epilogue(
     assert torch.equal(again, got)
 
 
+def _pool_codes(y):
+    """(B,H,W,C) -> (B,H//2,W//2,C) codes of the 2x2 max-pool's decisions: 0 = the window's maximum is not positive, k + 1 =
+    first maximum at window position k (row-major)."""
+    B, H, W, C = y.shape
+    Hp, Wp = H // 2, W // 2
+    win = torch.stack([y[:, 0:2 * Hp:2, 0:2 * Wp:2], y[:, 0:2 * Hp:2, 1:2 * Wp:2], y[:, 1:2 * Hp:2, 0:2 * Wp:2], y[:, 1:2 * Hp:2, 1:2 * Wp:2]], 0)
+    mx, idx = win.max(0)                       # torch.max returns the first maximal index along the dim? not guaranteed: do it by hand
+    first = torch.full_like(idx, 3)
+    for k in (2, 1, 0):
+        first = torch.where(win[k] == mx, torch.full_like(idx, k), first)
+    return torch.where(mx > 0, first + 1, torch.zeros_like(first))
+
+
+@pytest.mark.parametrize('B,H,W,Cin,Cout', [(2, 24, 16, 64, 64), (1, 38, 42, 64, 128), (1, 17, 13, 128, 128), (2, 8, 8, 256, 256)])
+def test_winograd_compact_masks_and_pool_codes(ops, B, H, W, Cin, Cout):
+    """The compact forms the forward leaves for the backward (F(4x4), one-kernel route): sign bits of the input from the input
+    transform, pooling codes from the pooling epilogue -- checked against the tensors they stand for -- and the dgrad
+    epilogues that read them (masked accumulate, max-pool backward, both gather forms): the same bits as with the float
+    tensors."""
+    d = dev()
+    x = rnd(B, H, W, Cin, seed=1).to(d)
+    x[0, :2, :2, :8] = 0.0                                    # exact zeros: not positive
+    w = rnd(Cout, Cin, 3, 3, seed=2, scale=(2.0 / (9 * Cin)) ** 0.5)
+    uf, ud = ops.winograd_pack_weight(w.to(d), m=4)
+    bias = rnd(Cout, seed=3).to(d)
+    bits = torch.zeros(B, H, W, Cin // 4, dtype=torch.uint8, device=d)
+    codes = torch.full((B, H // 2, W // 2, Cout // 4), -1, dtype=torch.int16, device=d)
+    yp = torch.empty(B, H // 2, W // 2, Cout, device=d)
+    y = ops.conv3x3_fwd_winograd(x, uf, bias, relu_in=True, out_pool=yp, m=4, relu_bits_out=bits, pool_code_out=codes)
+    y_ref = ops.conv3x3_fwd_winograd(x, uf, bias, relu_in=True, out_pool=torch.empty_like(yp), m=4)
+    assert torch.equal(y, y_ref)
+    xb = (x > 0).view(B, H, W, Cin // 4, 4).to(torch.uint8)
+    assert torch.equal(bits, xb[..., 0] | (xb[..., 1] << 1) | (xb[..., 2] << 2) | (xb[..., 3] << 3))
+    c4 = _pool_codes(y).view(B, H // 2, W // 2, Cout // 4, 4).to(torch.int16)
+    assert torch.equal(codes, c4[..., 0] | (c4[..., 1] << 3) | (c4[..., 2] << 6) | (c4[..., 3] << 9))
+    assert torch.equal(yp, F.max_pool2d(nchw(y), 2).permute(0, 2, 3, 1))
+    # consumers.  dy of the layer (Cout channels) -> gradient w.r.t. x (pre-ReLU values: mask x > 0)
+    dy = rnd(B, H, W, Cout, seed=5).to(d)
+    base = rnd(B, H, W, Cin, seed=6).to(d)
+    a, b_ = base.clone(), base.clone()
+    ops.conv3x3_dgrad_winograd(dy, ud, mask_src=x, out=a, accumulate=True, m=4)
+    ops.conv3x3_dgrad_winograd(dy, ud, out=b_, accumulate=True, m=4, mask_bits=bits)
+    assert torch.equal(a, b_)
+    # ... and through a max-pool: x2 (B,2H,2W,Cin) pre-pool activations with their codes
+    x2 = rnd(B, 2 * H, 2 * W, Cin, seed=7).to(d)
+    c2 = _pool_codes(x2).view(B, H, W, Cin // 4, 4).to(torch.int16)
+    code2 = (c2[..., 0] | (c2[..., 1] << 3) | (c2[..., 2] << 6) | (c2[..., 3] << 9)).contiguous()
+    base2 = rnd(B, 2 * H, 2 * W, Cin, seed=8).to(d)
+    a, b_ = base2.clone(), base2.clone()
+    ops.conv3x3_dgrad_winograd_unpool(dy, ud, x2, a)
+    ops.conv3x3_dgrad_winograd_unpool(dy, ud, None, b_, unpool_code=code2)
+    assert torch.equal(a, b_)
+    # gather forms
+    labs, masks = _sp_case(3, B, 2 * H, 2 * W, 3)
+    Kmax = int(labs.max()) + 2
+    m2 = ops.sp_preprocess(torch.from_numpy(labs).to(d), torch.from_numpy(masks).to(d), Kmax)
+    side = rnd(B, Kmax, Cin, seed=9).to(d)
+    a, b_ = torch.empty_like(base2), torch.empty_like(base2)
+    ops.conv3x3_dgrad_winograd_gather(dy, ud, side, m2.new_row, m2.area_new, out=a, unpool_src=x2)
+    ops.conv3x3_dgrad_winograd_gather(dy, ud, side, m2.new_row, m2.area_new, out=b_, unpool_code=code2)
+    assert torch.equal(a, b_)
+    labs, masks = _sp_case(4, B, H, W, 3)
+    Kmax = int(labs.max()) + 2
+    m1 = ops.sp_preprocess(torch.from_numpy(labs).to(d), torch.from_numpy(masks).to(d), Kmax)
+    side = rnd(B, Kmax, Cin, seed=10).to(d)
+    a, b_ = torch.empty_like(base), torch.empty_like(base)
+    ops.conv3x3_dgrad_winograd_gather(dy, ud, side, m1.new_row, m1.area_new, out=a, mask_src=x)
+    ops.conv3x3_dgrad_winograd_gather(dy, ud, side, m1.new_row, m1.area_new, out=b_, mask_bits=bits)
+    assert torch.equal(a, b_)
+
+
 @pytest.mark.parametrize('B,H,W,Cin,Cout', [c for c in CONV_CASES if c[3] != 3])
 def test_conv3x3_dgrad(ops, B, H, W, Cin, Cout):
     d = dev()

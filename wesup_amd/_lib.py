@@ -50,6 +50,8 @@ _SIGS = {
     'wesup_winograd_fused_supported': (c_int, 'iii'),
     'wesup_winograd_gemm_output_transform': (c_int, 'plpppppippiiiiiiiip'),
     'wesup_winograd_gemm_output_transform_gather': (c_int, 'plppppiipppiiiiiip'),
+    'wesup_winograd_input_transform_bits': (c_int, 'pplpiiiiip'),
+    'wesup_winograd_gemm_output_transform_ex': (c_int, 'plpppppp' + 'i' + 'pppp' + 'ii' + 'ppp' + 'iiiiiii' + 'p'),
     'wesup_conv3x3_dgrad_winograd_gather': (c_int, 'ppppppppiiiiiiiipzp'),
     'wesup_winograd_input_transform': (c_int, 'ppliiiiiip'),
     'wesup_gemm_nt_batched': (c_int, 'pilpilpiliiiip'),

@@ -29,6 +29,9 @@ struct FusedParams {
     float* up_dst;           // ... and the gradient they receive (accumulated into)
     int Hu, Wu;
     WinoGather gat;          // side-branch gradient gathered per pixel in place of reading y / up_dst (src NULL: off)
+    const unsigned char* mask_bits;     // the mask as sign bits [B][H][W][N/4] (wesup_winograd_input_transform_bits) instead of mask
+    unsigned short* pool_code;          // forward: the max-pool's decisions out, [B][H/2][W/2][N/4] (winograd.hpp)
+    const unsigned short* up_code;      // unpool mode: ... and in, instead of reading up_src
     int H, W, Th, Tw;
     long T;                  // tiles
     int N;
@@ -231,14 +234,18 @@ __global__ __launch_bounds__(256, 2) void wino4_gemm_out_kernel(const FusedParam
             const float4 e = ld4(smem + tl * ES + slot * 64 + 4 * q4);
             float4 v = make_float4(e.x + bv.x, e.y + bv.y, e.z + bv.z, e.w + bv.w);
             const long off = (((long)b * p.H + h) * p.W + w) * p.N + n0 + 4 * q4;
-            if (p.mask) {
+            if (p.mask_bits) {
+                const unsigned mb = p.mask_bits[(((long)b * p.H + h) * p.W + w) * (p.N >> 2) + (n0 >> 2) + q4];
+                v.x = (mb & 1) ? v.x : 0.f; v.y = (mb & 2) ? v.y : 0.f;
+                v.z = (mb & 4) ? v.z : 0.f; v.w = (mb & 8) ? v.w : 0.f;
+            } else if (p.mask) {
                 const float4 mk = ld4(p.mask + off);
                 v.x = mk.x > 0.f ? v.x : 0.f; v.y = mk.y > 0.f ? v.y : 0.f;
                 v.z = mk.z > 0.f ? v.z : 0.f; v.w = mk.w > 0.f ? v.w : 0.f;
             }
-            if (up.src) {            // input gradient at pooled resolution: straight through the max-pool backward
-                if (p.gat.src) wino_unpool_gather(up, p.gat, b, h, w, p.N, n0 + 4 * q4, v);
-                else wino_unpool_add(up, b, h, w, p.N, n0 + 4 * q4, v);
+            if (up.dst) {            // input gradient at pooled resolution: straight through the max-pool backward
+                if (p.gat.src) wino_unpool_gather(up, p.up_code, p.gat, b, h, w, p.N, n0 + 4 * q4, v);
+                else wino_unpool_add(up, p.up_code, b, h, w, p.N, n0 + 4 * q4, v);
                 continue;
             }
             if (p.gat.src) {
@@ -267,6 +274,11 @@ __global__ __launch_bounds__(256, 2) void wino4_gemm_out_kernel(const FusedParam
                 const float* e = smem + tl * ES + 4 * q;
                 const float4 b4 = p.bias ? ld4(p.bias + n0 + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
                 const float4 e0 = ld4(e + (2 * k) * 64), e1 = ld4(e + (2 * k + 1) * 64), e2 = ld4(e + (4 + 2 * k) * 64), e3 = ld4(e + (5 + 2 * k) * 64);
+                if (p.pool_code) {       // the window's decisions on the stored values y = e + bias, for the backward
+                    auto plus = [&](float4 a) { return make_float4(a.x + b4.x, a.y + b4.y, a.z + b4.z, a.w + b4.w); };
+                    p.pool_code[(((long)b * Hp + ph) * Wp + pw) * (p.N >> 2) + (n0 >> 2) + q] =
+                        wino_picks_code(wino_picks(plus(e0), plus(e1), plus(e2), plus(e3)));
+                }
                 float4 m;
                 m.x = fmaxf(fmaxf(e0.x, e1.x), fmaxf(e2.x, e3.x)) + b4.x;
                 m.y = fmaxf(fmaxf(e0.y, e1.y), fmaxf(e2.y, e3.y)) + b4.y;
@@ -298,20 +310,28 @@ extern "C" int wesup_winograd_fused_supported(int K, int N, int m) { return wino
 
 // V [36][tiles][K] (plane stride plane_elems, 0 = tiles * K) x U [36][N][K] -> y = A^T (V_p . U_p^T) A + the output
 // transform's epilogue (wesup_winograd_output_transform / _unpool), without the transformed output in between.
+struct FusedBits {       // the compact forms of mask_src / unpool_src (in) and of the pooling decisions (out); all optional
+    const unsigned char* mask_bits;
+    unsigned short* pool_code;
+    const unsigned short* up_code;
+};
 static int fused_launch(const float* V, long plane_elems, const float* U, const float* bias, const float* mask_src, float* y,
                         float* y_pool, int pool_relu, const float* unpool_src, float* unpool_dst, int Hu, int Wu, int B, int H,
-                        int W, int K, int N, int accumulate, const WinoGather& gat, void* stream) {
-    if (!V || !U || (!y && !unpool_src) || !wino_shape_ok(B, H, W, K, N, 4) || !(K == 64 || K == 128 || K == 256) || N < 64 || (N % 64) ||
+                        int W, int K, int N, int accumulate, const WinoGather& gat, const FusedBits& bits, void* stream) {
+    if (bits.pool_code && !y_pool) return WESUP_ERR_INVALID;
+    const bool unpool = unpool_src || bits.up_code;
+    if (!V || !U || (!y && !unpool) || !wino_shape_ok(B, H, W, K, N, 4) || !(K == 64 || K == 128 || K == 256) || N < 64 || (N % 64) ||
         (((uintptr_t)V | (uintptr_t)U) & 15) || (plane_elems % 4))
         return WESUP_ERR_INVALID;
     const long T = wino_tiles(B, H, W, 4);
     if (plane_elems > 0 && plane_elems < T * K) return WESUP_ERR_INVALID;
-    if (unpool_src && (!unpool_dst || y_pool || accumulate || Hu / 2 != H || Wu / 2 != W)) return WESUP_ERR_INVALID;
+    if (unpool && (!unpool_dst || y_pool || accumulate || Hu / 2 != H || Wu / 2 != W)) return WESUP_ERR_INVALID;
     if (T > (1l << 31) / 64 || (long)32 * K * 4 >= (1l << 31)) return WESUP_ERR_INVALID;
     FusedParams p = {};
     p.V = V; p.plane_v = plane_elems > 0 ? plane_elems : T * K; p.U = U; p.bias = bias; p.mask = mask_src; p.y = y;
     p.y_pool = y_pool; p.pool_relu = pool_relu; p.accum = accumulate; p.up_src = unpool_src; p.up_dst = unpool_dst;
     p.gat = gat;
+    p.mask_bits = bits.mask_bits; p.pool_code = bits.pool_code; p.up_code = bits.up_code;
     p.Hu = Hu; p.Wu = Wu; p.H = H; p.W = W; p.Th = (H + 3) / 4; p.Tw = (W + 3) / 4; p.T = T; p.N = N;
     p.dTw = make_fastdiv(p.Tw); p.dTh = make_fastdiv(p.Th);
     p.tile_blocks = (int)ceil_div(T, 32l); p.n_blocks = N / 64; p.dNb = make_fastdiv(p.n_blocks);
@@ -341,7 +361,34 @@ extern "C" int wesup_winograd_gemm_output_transform(const float* V, long plane_e
                                                     const float* unpool_src, float* unpool_dst, int Hu, int Wu, int B, int H,
                                                     int W, int K, int N, int accumulate, void* stream) {
     return fused_launch(V, plane_elems, U, bias, mask_src, y, y_pool, pool_relu, unpool_src, unpool_dst, Hu, Wu, B, H, W, K, N,
-                        accumulate, WinoGather{nullptr, nullptr, nullptr, 0, 0}, stream);
+                        accumulate, WinoGather{nullptr, nullptr, nullptr, 0, 0}, FusedBits{nullptr, nullptr, nullptr}, stream);
+}
+
+// Every option of the one-kernel route in one entry.  Beyond wesup_winograd_gemm_output_transform[_gather]:
+//   mask_bits   the ReLU mask as sign bits [B][H][W][N/4] (wesup_winograd_input_transform_bits) instead of mask_src;
+//   pool_code   (with y_pool) OUT: the decisions of the 2x2 max-pool per window and channel, [B][H/2][W/2][N/4] uint16, 3 bits
+//               per channel of the quad: 0 = maximum not positive, k + 1 = first maximum at window position k (row-major);
+//   unpool_code the same codes IN, instead of reading unpool_src (which may then be NULL): [B][H][W][N/4] at the resolution
+//               of this product's output (the pooled resolution).
+// side != NULL selects the gather forms (y / unpool_dst written, never read).
+extern "C" int wesup_winograd_gemm_output_transform_ex(const float* V, long plane_elems, const float* U, const float* bias,
+                                                       const float* mask_src, const unsigned char* mask_bits, float* y,
+                                                       float* y_pool, int pool_relu, unsigned short* pool_code,
+                                                       const float* unpool_src, const unsigned short* unpool_code,
+                                                       float* unpool_dst, int Hu, int Wu, const float* side,
+                                                       const int32_t* new_row, const int32_t* area_new, int Kmax, int B, int H,
+                                                       int W, int K, int N, int accumulate, void* stream) {
+    const bool unpool = unpool_src || unpool_code;
+    if (unpool && (!unpool_dst || Hu / 2 != H || Wu / 2 != W)) return WESUP_ERR_INVALID;
+    WinoGather gat = {nullptr, nullptr, nullptr, 0, 0};
+    if (side) {
+        if (!new_row || !area_new || Kmax <= 0 || accumulate || bias || y_pool || (((uintptr_t)side) & 15)) return WESUP_ERR_INVALID;
+        if (unpool && ((Hu & 1) || (Wu & 1))) return WESUP_ERR_INVALID;
+        gat = WinoGather{side, new_row, area_new, Kmax, unpool ? (long)Hu * Wu : (long)H * W};
+    }
+    return fused_launch(V, plane_elems, U, bias, mask_src, unpool ? nullptr : y, y_pool, pool_relu, unpool_src,
+                        unpool ? unpool_dst : nullptr, Hu, Wu, B, H, W, K, N, accumulate, gat,
+                        FusedBits{mask_bits, pool_code, unpool_code}, stream);
 }
 
 // The same with the old content of the destination replaced by a per-pixel gather (WinoGather, winograd.hpp): the destination
@@ -354,8 +401,10 @@ extern "C" int wesup_winograd_gemm_output_transform_gather(const float* V, long 
     if (!side || !new_row || !area_new || Kmax <= 0 || !y || (((uintptr_t)side) & 15)) return WESUP_ERR_INVALID;
     if (unpool_src && ((Hu & 1) || (Wu & 1))) return WESUP_ERR_INVALID;
     const WinoGather gat = {side, new_row, area_new, Kmax, unpool_src ? (long)Hu * Wu : (long)H * W};
+    const FusedBits nobits = {nullptr, nullptr, nullptr};
     if (unpool_src)
         return fused_launch(V, plane_elems, U, nullptr, mask_src, nullptr, nullptr, 0, unpool_src, y, Hu, Wu, B, H, W, K, N, 0, gat,
-                            stream);
-    return fused_launch(V, plane_elems, U, nullptr, mask_src, y, nullptr, 0, nullptr, nullptr, 0, 0, B, H, W, K, N, 0, gat, stream);
+                            nobits, stream);
+    return fused_launch(V, plane_elems, U, nullptr, mask_src, y, nullptr, 0, nullptr, nullptr, 0, 0, B, H, W, K, N, 0, gat, nobits,
+                        stream);
 }

@@ -398,8 +398,10 @@ __device__ __forceinline__ bool wino4_decode(const WinoGeom& g, WinoTile& o) {
 }
 
 // thread = (tile, 4 channels): 36 float4 loads (patch rows 4i-1 .. 4i+4), B^T d B, 36 float4 stores
+// bits (optional, [B][H][W][C/4] bytes): bit j of a byte = x[..., 4 cq + j] > 0 for the 4x4 pixels the tile owns (its
+// patch without the halo) -- the ReLU decisions of the layer below, kept for its backward (16x smaller than the mask tensor).
 __global__ __launch_bounds__(256) void wino4_input_transform_kernel(const float* __restrict__ x, float* __restrict__ V,
-                                                                    const WinoGeom g, int relu) {
+                                                                    const WinoGeom g, int relu, unsigned char* __restrict__ bits) {
     WinoTile q;
     if (!wino4_decode(g, q)) return;
     const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -414,6 +416,9 @@ __global__ __launch_bounds__(256) void wino4_input_transform_kernel(const float*
             const bool in = (unsigned)h < (unsigned)g.H && (unsigned)w < (unsigned)g.W;
             const float4 v = in ? ld4(x + (((long)q.b * g.H + h) * g.W + w) * g.C + 4 * q.cq) : z;
             d[r] = relu ? relu4(v) : v;
+            if (bits && in && r >= 1 && r <= 4 && c >= 1 && c <= 4)
+                bits[(((long)q.b * g.H + h) * g.W + w) * (g.C >> 2) + q.cq] =
+                    (unsigned char)((v.x > 0.f ? 1 : 0) | (v.y > 0.f ? 2 : 0) | (v.z > 0.f ? 4 : 0) | (v.w > 0.f ? 8 : 0));
         }
         wino4_bt(d, t);
 #pragma unroll
@@ -524,7 +529,7 @@ __global__ __launch_bounds__(256) void wino4_output_transform_kernel(const float
                     v.z = mk.z > 0.f ? v.z : 0.f; v.w = mk.w > 0.f ? v.w : 0.f;
                 }
                 if (up.src) {        // input gradient at pooled resolution: straight through the max-pool backward
-                    wino_unpool_add(up, q.b, h, w, g.C, 4 * q.cq, v);
+                    wino_unpool_add(up, nullptr, q.b, h, w, g.C, 4 * q.cq, v);
                     continue;
                 }
                 if (accum) v = f4add(v, ld4(y + off));
@@ -620,17 +625,28 @@ static WinoGeom wino_geom(int B, int H, int W, int C, int m, long plane_elems = 
 }
 
 // x (B,H,W,C) -> V [P][tiles][C]
-extern "C" int wesup_winograd_input_transform(const float* x, float* V, long plane_elems, int B, int H, int W, int C,
-                                              int relu_in, int m, void* stream) {
-    if (!x || !V || !wino_shape_ok(B, H, W, C, C, m) || (((uintptr_t)x | (uintptr_t)V) & 15) || (plane_elems % 4) ||
+static int wino_input_launch(const float* x, float* V, long plane_elems, unsigned char* bits, int B, int H, int W, int C,
+                             int relu_in, int m, void* stream) {
+    if (!x || !V || (bits && m != 4) || !wino_shape_ok(B, H, W, C, C, m) || (((uintptr_t)x | (uintptr_t)V) & 15) || (plane_elems % 4) ||
         (plane_elems > 0 && plane_elems < wino_tiles(B, H, W, m) * C))
         return WESUP_ERR_INVALID;
     const WinoGeom g = wino_geom(B, H, W, C, m, plane_elems);
     const dim3 grid((unsigned)ceil_div(g.T * (C / 4), 256l));
     if (m == 2) hipLaunchKernelGGL(wino_input_transform_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, V, g, relu_in);
-    else hipLaunchKernelGGL(wino4_input_transform_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, V, g, relu_in);
+    else hipLaunchKernelGGL(wino4_input_transform_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, V, g, relu_in, bits);
     WESUP_CHECK_LAUNCH();
     return WESUP_OK;
+}
+extern "C" int wesup_winograd_input_transform(const float* x, float* V, long plane_elems, int B, int H, int W, int C,
+                                              int relu_in, int m, void* stream) {
+    return wino_input_launch(x, V, plane_elems, nullptr, B, H, W, C, relu_in, m, stream);
+}
+// ... F(4x4), also leaving the sign bits of x (one byte per pixel and channel quad: bit j = x[..., 4 q + j] > 0) in
+// relu_bits [B][H][W][C/4]: what the input gradient of the layer that produced x needs of it (its ReLU mask)
+extern "C" int wesup_winograd_input_transform_bits(const float* x, float* V, long plane_elems, unsigned char* relu_bits, int B,
+                                                   int H, int W, int C, int relu_in, void* stream) {
+    if (!relu_bits) return WESUP_ERR_INVALID;
+    return wino_input_launch(x, V, plane_elems, relu_bits, B, H, W, C, relu_in, 4, stream);
 }
 // Mt [P][tiles][C] -> y (B,H,W,C) = A^T M A + bias, masked by mask_src > 0, added to the old y if accumulate;
 // y_relu: optional second output max(y, 0);  y_pool: optional third output (B,H/2,W/2,C) = the 2x2 / stride-2 max-pool

@@ -24,20 +24,41 @@ struct WinoUnpool {
     float* dst;          // gradient w.r.t. them, same shape, accumulated into
     int Hu, Wu;
 };
-__device__ __forceinline__ void wino_unpool_add(const WinoUnpool& u, int b, int h, int w, int C, int c0, float4 v) {
+// The decisions of one window and channel quad: position 0..3 of the first positive maximum per channel, -1 if none.
+struct WinoPicks { int kx, ky, kz, kw; };
+__device__ __forceinline__ int wino_pick(float p0, float p1, float p2, float p3) {
+    int best = 0;
+    float m = p0;
+    if (p1 > m) { m = p1; best = 1; }
+    if (p2 > m) { m = p2; best = 2; }
+    if (p3 > m) { m = p3; best = 3; }
+    return m > 0.f ? best : -1;
+}
+__device__ __forceinline__ WinoPicks wino_picks(float4 a0, float4 a1, float4 a2, float4 a3) {
+    return WinoPicks{wino_pick(a0.x, a1.x, a2.x, a3.x), wino_pick(a0.y, a1.y, a2.y, a3.y), wino_pick(a0.z, a1.z, a2.z, a3.z),
+                     wino_pick(a0.w, a1.w, a2.w, a3.w)};
+}
+// ... as a 12-bit code (3 bits per channel: position + 1, 0 = none): what the forward's pooling epilogue leaves for the
+// backward instead of the four pre-pool values (pool_code [B][H/2][W/2][C/4] uint16)
+__device__ __forceinline__ unsigned short wino_picks_code(const WinoPicks& k) {
+    return (unsigned short)((k.kx + 1) | ((k.ky + 1) << 3) | ((k.kz + 1) << 6) | ((k.kw + 1) << 9));
+}
+__device__ __forceinline__ WinoPicks wino_code_picks(unsigned c) {
+    return WinoPicks{(int)(c & 7) - 1, (int)((c >> 3) & 7) - 1, (int)((c >> 6) & 7) - 1, (int)((c >> 9) & 7) - 1};
+}
+__device__ __forceinline__ WinoPicks wino_unpool_picks(const WinoUnpool& u, const unsigned short* code, int b, int h, int w, int C,
+                                                       int c0) {
+    if (code) return wino_code_picks(code[(((long)b * (u.Hu >> 1) + h) * (u.Wu >> 1) + w) * (C >> 2) + (c0 >> 2)]);
     const long rs = (long)u.Wu * C;
     const long o00 = (((long)b * u.Hu + 2 * h) * u.Wu + 2 * w) * C + c0;
-    const float4 a0 = ld4(u.src + o00), a1 = ld4(u.src + o00 + C), a2 = ld4(u.src + o00 + rs), a3 = ld4(u.src + o00 + rs + C);
-    auto pick = [](float p0, float p1, float p2, float p3) {
-        int best = 0;
-        float m = p0;
-        if (p1 > m) { m = p1; best = 1; }
-        if (p2 > m) { m = p2; best = 2; }
-        if (p3 > m) { m = p3; best = 3; }
-        return m > 0.f ? best : -1;
-    };
-    const int kx = pick(a0.x, a1.x, a2.x, a3.x), ky = pick(a0.y, a1.y, a2.y, a3.y), kz = pick(a0.z, a1.z, a2.z, a3.z),
-              kw = pick(a0.w, a1.w, a2.w, a3.w);
+    return wino_picks(ld4(u.src + o00), ld4(u.src + o00 + C), ld4(u.src + o00 + rs), ld4(u.src + o00 + rs + C));
+}
+__device__ __forceinline__ void wino_unpool_add(const WinoUnpool& u, const unsigned short* code, int b, int h, int w, int C, int c0,
+                                                float4 v) {
+    const long rs = (long)u.Wu * C;
+    const long o00 = (((long)b * u.Hu + 2 * h) * u.Wu + 2 * w) * C + c0;
+    const WinoPicks pk = wino_unpool_picks(u, code, b, h, w, C, c0);
+    const int kx = pk.kx, ky = pk.ky, kz = pk.kz, kw = pk.kw;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         if (kx != k && ky != k && kz != k && kw != k) continue;
@@ -67,21 +88,12 @@ __device__ __forceinline__ float4 wino_gather(const WinoGather& g, int b, long p
 }
 // wino_unpool_add with the destination's old content replaced by the gather: every position of the window is WRITTEN
 // (gathered side gradient, plus v at the first positive maximum); Hu, Wu even (every pre-pool pixel sits in a window).
-__device__ __forceinline__ void wino_unpool_gather(const WinoUnpool& u, const WinoGather& g, int b, int h, int w, int C, int c0,
-                                                   float4 v) {
+__device__ __forceinline__ void wino_unpool_gather(const WinoUnpool& u, const unsigned short* code, const WinoGather& g, int b,
+                                                   int h, int w, int C, int c0, float4 v) {
     const long rs = (long)u.Wu * C;
     const long o00 = (((long)b * u.Hu + 2 * h) * u.Wu + 2 * w) * C + c0;
-    const float4 a0 = ld4(u.src + o00), a1 = ld4(u.src + o00 + C), a2 = ld4(u.src + o00 + rs), a3 = ld4(u.src + o00 + rs + C);
-    auto pick = [](float p0, float p1, float p2, float p3) {
-        int best = 0;
-        float m = p0;
-        if (p1 > m) { m = p1; best = 1; }
-        if (p2 > m) { m = p2; best = 2; }
-        if (p3 > m) { m = p3; best = 3; }
-        return m > 0.f ? best : -1;
-    };
-    const int kx = pick(a0.x, a1.x, a2.x, a3.x), ky = pick(a0.y, a1.y, a2.y, a3.y), kz = pick(a0.z, a1.z, a2.z, a3.z),
-              kw = pick(a0.w, a1.w, a2.w, a3.w);
+    const WinoPicks pk = wino_unpool_picks(u, code, b, h, w, C, c0);
+    const int kx = pk.kx, ky = pk.ky, kz = pk.kz, kw = pk.kw;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         float4 o = wino_gather(g, b, (long)(2 * h + (k >> 1)) * u.Wu + 2 * w + (k & 1), C, c0);

@@ -157,6 +157,11 @@ class WesupEngine:
         # row per superpixel; the dgrad epilogue that used to accumulate into the materialised gather takes it itself
         # (conv3x3_dgrad_winograd_gather): G_l is written once, by that epilogue, and never read for accumulation
         self.gather_side_grad = True
+        # What the backward needs of the activations of the F(4x4) layers on the one-kernel product route, kept in compact form by
+        # the forward: the ReLU decisions of a conv output as sign bits (written by the input transform of the next layer, which
+        # reads the output anyway; 1/16 of the tensor) and the max-pool's decisions as 3-bit codes (written by the epilogue that
+        # pools; 1/32).  The dgrad epilogues read those instead of the pre-ReLU outputs: 0.9 GB less traffic per step at c2.
+        self.compact_masks = True
         self.batch_side_convs = False    # A/B: side convs (and their input gradients) of the layers that share a deep resolution in one launch
         self.head_streamk = False
         self._diag_skip = set()          # TIMING-ONLY diagnostics (bench.py --diag-skip): classes of launches left out, results wrong
@@ -274,6 +279,8 @@ class WesupEngine:
             b.fm = None if self.fuse_pool_fwd else torch.empty(B, H, W, FM_CHANNELS, **f32)
             b.fm_valid = False
             b.ybar, b.dybar = [None] * 13, [None] * 13       # commuted side branch: mean_r(upsample(y_l)) and its gradient
+            b.mbits, b.pcode = [None] * 13, [None] * 13      # compact_masks: sign bits / pooling codes of y_l (None: not kept)
+            b.mbits_ok, b.pcode_ok = [False] * 13, [False] * 13
             b.s_valid = [False] * 13
             b.shape = (B, H, W)
             R = B * Kmax
@@ -481,6 +488,27 @@ class WesupEngine:
             if yr is not None and l < 12 and self._wino(l + 1) and (self.wgrad_winograd or not train):
                 yr = None
             m = self._wino(l)
+            bits_out = code_out = None
+            if l >= 1:
+                b.mbits_ok[l - 1] = False
+            b.pcode_ok[l] = False
+            if train and self.compact_masks and m == 4:
+                # sign bits of y_{l-1}: this layer's input transform reads it (pre-ReLU, not pooled) and this layer's input
+                # gradient is the consumer (one-kernel route: product co -> ci)
+                if l >= 1 and cur is b.y[l - 1] and cur_relu and ops.winograd_fused_supported(co, ci, 4) == 2:
+                    if b.mbits[l - 1] is None:
+                        b.mbits[l - 1] = torch.empty(B, h, w, ci // 4, dtype=torch.uint8, device=self.device)
+                    bits_out = b.mbits[l - 1]
+                    b.mbits_ok[l - 1] = True
+                # pooling codes of y_l: this layer's pooling epilogue writes them, the input gradient of layer l + 1 (through
+                # the max-pool backward, one-kernel route) reads them
+                if (POOL_AFTER[l] and l < 12 and yr is None and self.fuse_unpool and self._wino(l + 1) == 4
+                        and ops.winograd_fused_supported(ci, co, 4) >= 1
+                        and ops.winograd_fused_supported(CONV_CH[l + 1][1], CONV_CH[l + 1][0], 4) == 2):
+                    if b.pcode[l] is None:
+                        b.pcode[l] = torch.empty(B, h // 2, w // 2, co // 4, dtype=torch.int16, device=self.device)
+                    code_out = b.pcode[l]
+                    b.pcode_ok[l] = True
             if m:
                 vshape = (ops.winograd_positions(m), ops.winograd_tiles(B, h, w, m), ci)
                 if train and (b.V[l] is None or b.V[l].shape != vshape):      # the transformed input, kept for the weight gradient
@@ -490,7 +518,8 @@ class WesupEngine:
                 # output transform writes the pooled tensor too and the max-pool launch below is skipped)
                 ops.conv3x3_fwd_winograd(cur, pk.uf[l], p[f'backbone.{idx}.bias'], relu_in=cur_relu, out=b.y[l],
                                          out_relu=yr, v_keep=b.V[l] if train else None, ws_tag='wino_main', timer=T,
-                                         out_pool=b.yp[l] if POOL_AFTER[l] else None, pool_relu=b.relu_stored, m=m)
+                                         out_pool=b.yp[l] if POOL_AFTER[l] else None, pool_relu=b.relu_stored, m=m,
+                                         relu_bits_out=bits_out, pool_code_out=code_out)
             else:
                 tok = T.begin('conv3x3_fwd')
                 ops.conv3x3_fwd(cur, pk.wf[l], p[f'backbone.{idx}.bias'], co, relu_in=cur_relu, out=b.y[l], out_relu=yr,
@@ -881,22 +910,26 @@ class WesupEngine:
                 if g_ready[l - 1] is not None:
                     main.wait_event(g_ready[l - 1])
                 unpooled = False
+                mbits = b.mbits[l - 1] if (self.compact_masks and b.mbits_ok[l - 1]) else None
+                pcode = b.pcode[l - 1] if (self.compact_masks and b.pcode_ok[l - 1]) else None
                 if gat[l - 1]:
                     pooled = POOL_AFTER[l - 1]
                     ops.conv3x3_dgrad_winograd_gather(b.G[l], pk.ud[l], b.dybar[l - 1], meta.new_row, meta.area_new, out=b.G[l - 1],
                                                       mask_src=None if pooled else b.y[l - 1],
-                                                      unpool_src=b.y[l - 1] if pooled else None, ws_tag='wino_main', timer=T)
+                                                      unpool_src=b.y[l - 1] if pooled else None, ws_tag='wino_main', timer=T,
+                                                      mask_bits=None if pooled else mbits, unpool_code=pcode if pooled else None)
                     unpooled = True
                 elif b.wino_fwd[l]:
                     if POOL_AFTER[l - 1] and self.fuse_unpool and b.wino_fwd[l] == 4:
-                        ops.conv3x3_dgrad_winograd_unpool(b.G[l], pk.ud[l], b.y[l - 1], b.G[l - 1], ws_tag='wino_main', timer=T)
+                        ops.conv3x3_dgrad_winograd_unpool(b.G[l], pk.ud[l], b.y[l - 1], b.G[l - 1], ws_tag='wino_main', timer=T,
+                                                          unpool_code=pcode)
                         unpooled = True
                     elif POOL_AFTER[l - 1]:
                         ops.conv3x3_dgrad_winograd(b.G[l], pk.ud[l], out=b.dxp[l - 1], ws_tag='wino_main', timer=T,
                                                    m=b.wino_fwd[l])
                     else:
-                        ops.conv3x3_dgrad_winograd(b.G[l], pk.ud[l], mask_src=b.y[l - 1], out=b.G[l - 1], accumulate=True,
-                                                   ws_tag='wino_main', timer=T, m=b.wino_fwd[l])
+                        ops.conv3x3_dgrad_winograd(b.G[l], pk.ud[l], mask_src=None if mbits is not None else b.y[l - 1], out=b.G[l - 1],
+                                                   accumulate=True, ws_tag='wino_main', timer=T, m=b.wino_fwd[l], mask_bits=mbits)
                 else:
                     tok = T.begin('conv3x3_dgrad')
                     if POOL_AFTER[l - 1]:

@@ -414,7 +414,7 @@ def _aux_stream(device):
 
 
 def _winograd_conv(inp, u, bias, mask_src, out, out_relu, v_keep, relu_in, accumulate, ws_tag, timer, out_pool=None,
-                   pool_relu=False, m=2):
+                   pool_relu=False, m=2, relu_bits_out=None, pool_code_out=None, mask_bits=None):
     """The three passes of a Winograd-domain conv (input transform, 16 batched NT GEMMs, output transform + epilogue).
     timer (optional, engine.KernelTimer-like): the GEMM and the two transforms are bracketed as classes of their own.
 
@@ -439,8 +439,12 @@ def _winograd_conv(inp, u, bias, mask_src, out, out_relu, v_keep, relu_in, accum
     def t_in(b0, nb_, st):
         tok = timer.begin('winograd_transform') if timer else None
         t0 = winograd_tiles(b0, H, W, m)
-        _lib.call('wesup_winograd_input_transform', _p(inp[b0:b0 + nb_]), ctypes.c_void_p(V.data_ptr() + 4 * t0 * Cin), T * Cin,
-                  nb_, H, W, Cin, int(relu_in), m, st)
+        if relu_bits_out is not None:      # the sign bits of the input ride along (the ReLU mask of the layer below, for its backward)
+            _lib.call('wesup_winograd_input_transform_bits', _p(inp[b0:b0 + nb_]), ctypes.c_void_p(V.data_ptr() + 4 * t0 * Cin),
+                      T * Cin, _p(relu_bits_out[b0:b0 + nb_]), nb_, H, W, Cin, int(relu_in), st)
+        else:
+            _lib.call('wesup_winograd_input_transform', _p(inp[b0:b0 + nb_]), ctypes.c_void_p(V.data_ptr() + 4 * t0 * Cin), T * Cin,
+                      nb_, H, W, Cin, int(relu_in), m, st)
         if timer:       # bytes: read x, write the P / m^2-fold expansion (4x for m = 2, 2.25x for m = 4)
             timer.end(tok, 4.0 * (nb_ * H * W + P * winograd_tiles(nb_, H, W, m)) * Cin)
 
@@ -463,7 +467,16 @@ def _winograd_conv(inp, u, bias, mask_src, out, out_relu, v_keep, relu_in, accum
             timer.end(tok, 4.0 * (P * winograd_tiles(nb_, H, W, m) + (n_io + (0.25 if out_pool is not None else 0)) * nb_ * H * W) * Cout)
 
     fused = 0 if out_relu is not None else lib.wesup_winograd_fused_supported(Cin, Cout, m)
-    if fused == 2 or (fused == 1 and mask_src is None and not accumulate):
+    masked = mask_src is not None or mask_bits is not None
+    if relu_bits_out is not None:
+        assert m == 4 and relu_bits_out.dtype == torch.uint8 and relu_bits_out.shape == (B, H, W, Cin // 4) and relu_bits_out.is_contiguous()
+    if mask_bits is not None or pool_code_out is not None:       # compact mask in / pooling decisions out: one-kernel route only
+        if not (fused == 2 or (fused == 1 and not masked and not accumulate)):
+            raise _lib.WesupHipError(f'winograd conv {Cin} -> {Cout}: mask_bits / pool_code_out need the one-kernel product route')
+        assert mask_bits is None or (mask_bits.dtype == torch.uint8 and mask_bits.shape == (B, H, W, Cout // 4) and mask_bits.is_contiguous())
+        assert pool_code_out is None or (out_pool is not None and pool_code_out.dtype == torch.int16
+                                         and pool_code_out.shape == (B, H // 2, W // 2, Cout // 4) and pool_code_out.is_contiguous())
+    if fused == 2 or (fused == 1 and not masked and not accumulate):
         # short products (64 ... 256 channels): the batched products and the output transform in one kernel
         st = _stream()
         # Sub-batches: a layer whose transformed input is larger than the memory-side cache goes image group by image
@@ -479,9 +492,16 @@ def _winograd_conv(inp, u, bias, mask_src, out, out_relu, v_keep, relu_in, accum
             tok = timer.begin('winograd_gemm') if timer else None
             t0, tn = winograd_tiles(b0, H, W, m), winograd_tiles(nb_, H, W, m)
             sl = slice(b0, b0 + nb_)
-            _lib.call('wesup_winograd_gemm_output_transform', ctypes.c_void_p(V.data_ptr() + 4 * t0 * Cin), T * Cin, _p(u), _p(bias),
-                      _p(None if mask_src is None else mask_src[sl]), _p(out[sl]), _p(None if out_pool is None else out_pool[sl]),
-                      int(pool_relu), None, None, 0, 0, nb_, H, W, Cin, Cout, int(accumulate), st)
+            if mask_bits is not None or pool_code_out is not None:
+                _lib.call('wesup_winograd_gemm_output_transform_ex', ctypes.c_void_p(V.data_ptr() + 4 * t0 * Cin), T * Cin, _p(u),
+                          _p(bias), _p(None if mask_src is None else mask_src[sl]), _p(None if mask_bits is None else mask_bits[sl]),
+                          _p(out[sl]), _p(None if out_pool is None else out_pool[sl]), int(pool_relu),
+                          _p(None if pool_code_out is None else pool_code_out[sl]), None, None, None, 0, 0, None, None, None, 0,
+                          nb_, H, W, Cin, Cout, int(accumulate), st)
+            else:
+                _lib.call('wesup_winograd_gemm_output_transform', ctypes.c_void_p(V.data_ptr() + 4 * t0 * Cin), T * Cin, _p(u), _p(bias),
+                          _p(None if mask_src is None else mask_src[sl]), _p(out[sl]), _p(None if out_pool is None else out_pool[sl]),
+                          int(pool_relu), None, None, 0, 0, nb_, H, W, Cin, Cout, int(accumulate), st)
             if timer:
                 timer.end(tok, 2.0 * P * tn * Cin * Cout)
         return out
@@ -512,7 +532,7 @@ def _winograd_conv(inp, u, bias, mask_src, out, out_relu, v_keep, relu_in, accum
 
 
 def conv3x3_fwd_winograd(x, u_fwd, bias, relu_in, out=None, out_relu=None, v_keep=None, ws_tag='default', timer=None,
-                         out_pool=None, pool_relu=False, m=2):
+                         out_pool=None, pool_relu=False, m=2, relu_bits_out=None, pool_code_out=None):
     """conv3x3_fwd through the Winograd F(m x m, 3x3) domain (deep layers); v_keep (P, tiles, Cin) receives the transformed
     input; out_pool (B, H//2, W//2, Cout) the 2x2 max-pool of the output (ReLU'd if pool_relu), written by the output
     transform."""
@@ -531,10 +551,14 @@ def conv3x3_fwd_winograd(x, u_fwd, bias, relu_in, out=None, out_relu=None, v_kee
         _chk(v_keep, name='v_keep'); assert v_keep.numel() == winograd_positions(m) * winograd_tiles(B, H, W, m) * Cin
     if out_pool is not None:
         _chk(out_pool, name='out_pool'); assert out_pool.shape == (B, H // 2, W // 2, Cout) and out_pool.is_contiguous()
-    return _winograd_conv(x, u_fwd, bias, None, out, out_relu, v_keep, relu_in, False, ws_tag, timer, out_pool, pool_relu, m)
+    # relu_bits_out (B,H,W,Cin/4) uint8: the sign bits of x; pool_code_out (B,H/2,W/2,Cout/4) int16: the pooling's decisions
+    # (include/wesup_hip.h: wesup_winograd_input_transform_bits, wesup_winograd_gemm_output_transform_ex)
+    return _winograd_conv(x, u_fwd, bias, None, out, out_relu, v_keep, relu_in, False, ws_tag, timer, out_pool, pool_relu, m,
+                          relu_bits_out=relu_bits_out, pool_code_out=pool_code_out)
 
 
-def conv3x3_dgrad_winograd(dy, u_dgrad, mask_src=None, out=None, accumulate=False, ws_tag='default', timer=None, m=2):
+def conv3x3_dgrad_winograd(dy, u_dgrad, mask_src=None, out=None, accumulate=False, ws_tag='default', timer=None, m=2,
+                           mask_bits=None):
     _chk(dy, name='dy'); _chk(u_dgrad, name='u_dgrad')
     B, H, W, Cout = dy.shape
     Cin = u_dgrad.shape[1]
@@ -545,20 +569,40 @@ def conv3x3_dgrad_winograd(dy, u_dgrad, mask_src=None, out=None, accumulate=Fals
         assert not accumulate
         out = torch.empty(B, H, W, Cin, dtype=torch.float32, device=dy.device)
     assert out.shape == (B, H, W, Cin) and out.is_contiguous()
-    return _winograd_conv(dy, u_dgrad, None, mask_src, out, None, None, False, accumulate, ws_tag, timer, m=m)
+    return _winograd_conv(dy, u_dgrad, None, mask_src, out, None, None, False, accumulate, ws_tag, timer, m=m, mask_bits=mask_bits)
 
 
-def conv3x3_dgrad_winograd_unpool(dy, u_dgrad, unpool_src, unpool_dst, ws_tag='default', timer=None, m=4):
+def conv3x3_dgrad_winograd_unpool(dy, u_dgrad, unpool_src, unpool_dst, ws_tag='default', timer=None, m=4, unpool_code=None):
     """Input gradient of a layer that follows a 2x2 max-pool, added straight into the gradient of the PRE-pool activations:
     dy (B,H,W,Cout) at pooled resolution, unpool_src / unpool_dst (B,Hu,Wu,Cin) with H == Hu // 2, W == Wu // 2.  Equals
     conv3x3_dgrad_winograd(out=dxp) followed by maxpool2_bwd(unpool_src, dxp, unpool_dst, accumulate=True)."""
-    _chk(dy, name='dy'); _chk(u_dgrad, name='u_dgrad'); _chk(unpool_src, name='unpool_src'); _chk(unpool_dst, name='unpool_dst')
+    _chk(dy, name='dy'); _chk(u_dgrad, name='u_dgrad'); _chk(unpool_dst, name='unpool_dst')
     B, H, W, Cout = dy.shape
     Cin = u_dgrad.shape[1]
     assert m == 4 and u_dgrad.shape == (winograd_positions(m), Cin, Cout)
-    _, Hu, Wu, _ = unpool_src.shape
-    assert unpool_src.shape == (B, Hu, Wu, Cin) == unpool_dst.shape and (Hu // 2, Wu // 2) == (H, W)
+    _, Hu, Wu, _ = unpool_dst.shape
+    assert unpool_dst.shape == (B, Hu, Wu, Cin) and (Hu // 2, Wu // 2) == (H, W)
     lib = _lib.load()
+    if unpool_code is not None:        # the pooling's decisions as codes (conv3x3_fwd_winograd(pool_code_out=...)): no read of unpool_src
+        assert unpool_code.dtype == torch.int16 and unpool_code.shape == (B, H, W, Cin // 4) and unpool_code.is_contiguous()
+        if lib.wesup_winograd_fused_supported(Cout, Cin, m) != 2:
+            raise _lib.WesupHipError(f'winograd dgrad {Cout} -> {Cin}: unpool_code needs the one-kernel product route')
+        nb = lib.wesup_conv3x3_winograd_workspace_bytes(B, H, W, Cout, Cin, m)
+        ws = workspace(nb, dy.device, ws_tag)
+        T, P = winograd_tiles(B, H, W, m), winograd_positions(m)
+        st = _stream()
+        tok = timer.begin('winograd_transform') if timer else None
+        _lib.call('wesup_winograd_input_transform', _p(dy), _p(ws), 0, B, H, W, Cout, 0, m, st)
+        if timer:
+            timer.end(tok, 4.0 * (B * H * W + P * T) * Cout)
+        tok = timer.begin('winograd_gemm') if timer else None
+        _lib.call('wesup_winograd_gemm_output_transform_ex', _p(ws), 0, _p(u_dgrad), None, None, None, None, None, 0, None, None,
+                  _p(unpool_code), _p(unpool_dst), Hu, Wu, None, None, None, 0, B, H, W, Cout, Cin, 0, st)
+        if timer:
+            timer.end(tok, 2.0 * P * T * Cin * Cout)
+        return unpool_dst
+    _chk(unpool_src, name='unpool_src')
+    assert unpool_src.shape == unpool_dst.shape
     nb = lib.wesup_conv3x3_winograd_workspace_bytes(B, H, W, Cout, Cin, m)
     if not nb:
         raise _lib.WesupHipError(f'winograd dgrad: unsupported shape {(B, H, W, Cout, Cin, m)}')
@@ -599,7 +643,7 @@ def winograd_fused_supported(K, N, m=4):
 
 
 def conv3x3_dgrad_winograd_gather(dy, u_dgrad, side, new_row, area_new, out, mask_src=None, unpool_src=None,
-                                  ws_tag='default', timer=None):
+                                  ws_tag='default', timer=None, mask_bits=None, unpool_code=None):
     """conv3x3_dgrad_winograd(accumulate=True) / conv3x3_dgrad_winograd_unpool (unpool_src given) with out's old content
     replaced by the gather side[b][new_row[b][pixel]] / area_new[...] (side (B,Kmax,Cin): the commuted side-branch gradient of
     a native-resolution layer): out is written, never read.  m = 4, shapes of the one-kernel product route only."""
@@ -611,33 +655,49 @@ def conv3x3_dgrad_winograd_gather(dy, u_dgrad, side, new_row, area_new, out, mas
     Kmax = side.shape[1]
     assert u_dgrad.shape == (36, Cin, Cout) and side.shape == (B, Kmax, Cin) and area_new.shape == (B, Kmax)
     Hu = Wu = 0
-    if unpool_src is not None:
-        _chk(unpool_src, name='unpool_src')
-        _, Hu, Wu, _ = unpool_src.shape
-        assert unpool_src.shape == (B, Hu, Wu, Cin) == out.shape and (Hu // 2, Wu // 2) == (H, W) and Hu % 2 == 0 and Wu % 2 == 0
-        assert mask_src is None and new_row.shape == (B, Hu * Wu)
+    if unpool_src is not None or unpool_code is not None:
+        _, Hu, Wu, _ = out.shape
+        assert out.shape == (B, Hu, Wu, Cin) and (Hu // 2, Wu // 2) == (H, W) and Hu % 2 == 0 and Wu % 2 == 0
+        assert mask_src is None and mask_bits is None and new_row.shape == (B, Hu * Wu)
+        if unpool_code is not None:
+            assert unpool_code.dtype == torch.int16 and unpool_code.shape == (B, H, W, Cin // 4) and unpool_code.is_contiguous()
+            unpool_src = None
+        else:
+            _chk(unpool_src, name='unpool_src'); assert unpool_src.shape == out.shape
     else:
         assert out.shape == (B, H, W, Cin) and new_row.shape == (B, H * W)
-        if mask_src is not None:
+        if mask_bits is not None:
+            assert mask_bits.dtype == torch.uint8 and mask_bits.shape == (B, H, W, Cin // 4) and mask_bits.is_contiguous()
+            mask_src = None
+        elif mask_src is not None:
             _chk(mask_src, name='mask_src'); assert mask_src.shape == out.shape
     lib = _lib.load()
     if lib.wesup_winograd_fused_supported(Cout, Cin, 4) != 2:
         raise _lib.WesupHipError(f'conv3x3_dgrad_winograd_gather: product {Cout} -> {Cin} is not on the one-kernel route')
     nb = lib.wesup_conv3x3_winograd_workspace_bytes(B, H, W, Cout, Cin, 4)
     ws = workspace(nb, dy.device, ws_tag)
-    if timer is None:
+    compact = mask_bits is not None or unpool_code is not None
+    if timer is None and not compact:
         _lib.call('wesup_conv3x3_dgrad_winograd_gather', _p(dy), _p(u_dgrad), _p(mask_src), _p(unpool_src), _p(out), _p(side),
                   _p(new_row), _p(area_new), Kmax, B, H, W, Hu, Wu, Cin, Cout, _p(ws), nb, _stream())
         return out
     T, P = winograd_tiles(B, H, W, 4), 36
     st = _stream()
-    tok = timer.begin('winograd_transform')
+    tok = timer.begin('winograd_transform') if timer else None
     _lib.call('wesup_winograd_input_transform', _p(dy), _p(ws), 0, B, H, W, Cout, 0, 4, st)
-    timer.end(tok, 4.0 * (B * H * W + P * T) * Cout)
-    tok = timer.begin('winograd_gemm')
-    _lib.call('wesup_winograd_gemm_output_transform_gather', _p(ws), 0, _p(u_dgrad), _p(mask_src), _p(out), _p(unpool_src), Hu, Wu,
-              _p(side), _p(new_row), _p(area_new), Kmax, B, H, W, Cout, Cin, st)
-    timer.end(tok, 2.0 * P * T * Cin * Cout)
+    if timer:
+        timer.end(tok, 4.0 * (B * H * W + P * T) * Cout)
+    tok = timer.begin('winograd_gemm') if timer else None
+    if compact:
+        pooled = Hu > 0
+        _lib.call('wesup_winograd_gemm_output_transform_ex', _p(ws), 0, _p(u_dgrad), None, _p(mask_src), _p(mask_bits),
+                  _p(None if pooled else out), None, 0, None, _p(unpool_src), _p(unpool_code), _p(out if pooled else None), Hu, Wu,
+                  _p(side), _p(new_row), _p(area_new), Kmax, B, H, W, Cout, Cin, 0, st)
+    else:
+        _lib.call('wesup_winograd_gemm_output_transform_gather', _p(ws), 0, _p(u_dgrad), _p(mask_src), _p(out), _p(unpool_src), Hu, Wu,
+                  _p(side), _p(new_row), _p(area_new), Kmax, B, H, W, Cout, Cin, st)
+    if timer:
+        timer.end(tok, 2.0 * P * T * Cin * Cout)
     return out
 
 
