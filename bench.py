@@ -66,6 +66,7 @@ def parse_args(argv=None):
     ap.add_argument('--side-before-pool', action='store_true', help='A/B: the shallow side convs in front of the upsample + superpixel mean, side outputs materialised (round 2 / early round 3 schedule)')
     ap.add_argument('--no-gather-epilogue', action='store_true', help='A/B: the side-branch gradient of conv1_1 / conv1_2 materialised (gather kernel) and accumulated into, instead of gathered by the dgrad epilogue')
     ap.add_argument('--float-masks', action='store_true', help='A/B: the dgrad epilogues read the pre-ReLU conv outputs for the ReLU mask / the max-pool decisions instead of the sign bits / codes the forward leaves')
+    ap.add_argument('--no-dual-transform', action='store_true', help='A/B: the input-gradient and weight-gradient transforms of a layer\'s output gradient as two launches on two streams (each reads the gradient)')
     ap.add_argument('--commute-deep', action='store_true', help='A/B: the deep layers (matrix pooling) commuted as well (measured, not kept)')
     ap.add_argument('--batched-side', action='store_true', help='A/B: the side convs of the layers that share a deep resolution in one batched launch (measured, not kept)')
     ap.add_argument('--diag-skip', default='', help="TIMING-ONLY diagnostic (results are wrong): comma list of launch classes left out "
@@ -268,6 +269,7 @@ def worker(args):
     trainer.model.engine.commute_side_deep = args.commute_deep
     trainer.model.engine.gather_side_grad = not args.no_gather_epilogue
     trainer.model.engine.compact_masks = not args.float_masks
+    trainer.model.engine.dual_transform = not args.no_dual_transform
     trainer.model.engine._diag_skip = set(filter(None, args.diag_skip.split(',')))
     trainer.model.engine.conv_winograd = not args.direct_conv
     if args.winograd_min_ci:

@@ -201,6 +201,17 @@ int wesup_winograd_gemm_output_transform_gather(const float* V, long plane_elems
                                                 float* y, const float* unpool_src, int Hu, int Wu, const float* side,
                                                 const int32_t* new_row, const int32_t* area_new, int Kmax,
                                                 int B, int H, int W, int K, int N, void* stream);
+/* One pass over a gradient tensor for both of its F(4x4) transforms: V = B^T dY B (6x6 patches; the input of the layer's input
+ * gradient) and dM = A dY A^T (4x4 cores; the second operand of its weight gradient), plus the per-block column sums of dy the
+ * bias gradient is folded from (bias_part, optional: [wesup_winograd_bias_rows(B,H,W,C)][C]; 0 rows = this C is not covered).
+ * wesup_conv3x3_wgrad_winograd_pre: the weight gradient from those operands and the forward's kept transformed input v_pre
+ * (wesup_conv3x3_fwd_winograd's v_keep): batched TN products + filter-gradient reduce, the transform passes already done. */
+long wesup_winograd_bias_rows(int B, int H, int W, int C);
+int wesup_winograd_dual_transform(const float* dy, float* V, float* dM, float* bias_part, int B, int H, int W, int C,
+                                  void* stream);
+int wesup_conv3x3_wgrad_winograd_pre(const float* v_pre, const float* dm_pre, const float* bias_part, int bias_rows,
+                                     float* dw_kcrs, float* db, int B, int H, int W, int Ci, int Cout,
+                                     void* ws, size_t ws_bytes, void* stream);
 /* Compact forms of what the backward needs of the forward's activations (F(4x4) route; 16x resp. 32x smaller than the tensors
  * they replace).  relu_bits [B][H][W][C/4] bytes: bit j of byte q = x[..., 4q + j] > 0 -- the ReLU decisions of the layer that
  * produced x, written by the input transform of the layer that consumes it (it reads x anyway).  pool codes

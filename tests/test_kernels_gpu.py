@@ -510,6 +510,35 @@ def test_conv3x3_dgrad_winograd_with_the_side_gradient_gathered_in_the_epilogue(
     assert torch.equal(again, got)
 
 
+@pytest.mark.parametrize('B,H,W,Cin,Cout', [(2, 24, 16, 64, 64), (1, 37, 41, 64, 128), (1, 13, 9, 256, 512), (3, 8, 8, 512, 512)])
+def test_winograd_dual_transform_and_weight_gradient_from_it(ops, B, H, W, Cin, Cout):
+    """winograd_dual_transform: one pass over a gradient tensor leaves exactly what the two separate F(4x4) transforms leave (input
+    transform for the input gradient, outgrad transform for the weight gradient), and conv3x3_wgrad_winograd_pre on those operands
+    gives the weight and bias gradient of conv3x3_wgrad_winograd bit for bit."""
+    d = dev()
+    x = torch.relu(rnd(B, H, W, Cin, seed=1)).to(d)
+    dy = rnd(B, H, W, Cout, seed=2).to(d)
+    T = ops.winograd_tiles(B, H, W, 4)
+    V = torch.full((36, T, Cout), float('nan'), device=d)
+    dM = torch.full((36, T, Cout), float('nan'), device=d)
+    rows = ops.winograd_bias_rows(B, H, W, Cout)
+    assert rows > 0
+    bp = torch.empty(rows, Cout, device=d)
+    ops.winograd_dual_transform(dy, V, dM, bp)
+    assert torch.equal(V, ops.winograd_input_transform(dy, m=4))
+    assert torch.equal(dM, ops.winograd_outgrad_transform(dy, m=4))
+    assert rel_err(bp.sum(0), dy.sum((0, 1, 2))) < 1e-5
+    Vx = ops.winograd_input_transform(x, m=4)
+    dw, db = ops.conv3x3_wgrad_winograd(x, dy, relu_in=False, v_pre=Vx, m=4)
+    dw2 = torch.empty_like(dw); db2 = torch.empty_like(db)
+    ops.conv3x3_wgrad_winograd_pre(Vx, dM, bp, B, H, W, dw2, db2)
+    assert torch.equal(dw, dw2) and torch.equal(db, db2)
+    # the input gradient from the transformed operand: same bits as from dy itself
+    w = rnd(Cout, Cin, 3, 3, seed=3, scale=(2.0 / (9 * Cin)) ** 0.5)
+    _, ud = ops.winograd_pack_weight(w.to(d), need_fwd=False, m=4)
+    assert torch.equal(ops.conv3x3_dgrad_winograd(dy, ud, m=4), ops.conv3x3_dgrad_winograd(dy, ud, m=4, v_pre=V))
+
+
 def _pool_codes(y):
     """(B,H,W,C) -> (B,H//2,W//2,C) codes of the 2x2 max-pool's decisions: 0 = the window's maximum is not positive, k + 1 =
     first maximum at window position k (row-major)."""

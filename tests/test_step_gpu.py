@@ -43,7 +43,7 @@ def make_trainer(weights, **kw):
 
 
 @pytest.mark.parametrize('name', CASES)
-@pytest.mark.parametrize('fused', [True, False, 'side_as_gemm', 'direct_convs', 'batched_side', 'side_before_pool', 'commute_deep', 'gather_kernel', 'float_masks'])
+@pytest.mark.parametrize('fused', [True, False, 'side_as_gemm', 'direct_convs', 'batched_side', 'side_before_pool', 'commute_deep', 'gather_kernel', 'float_masks', 'two_transforms'])
 def test_step_matches_reference_golden(golden_dir, name, fused):
     from oracle import wesup_oracle as orc
     from wesup_amd.models.wesup import preprocess_label_maps, SuperpixelMaps
@@ -65,6 +65,8 @@ def test_step_matches_reference_golden(golden_dir, name, fused):
     model.engine.commute_side_deep = fused == 'commute_deep'
     if fused == 'float_masks':        # the dgrad epilogues read the pre-ReLU outputs (default: sign bits / pooling codes left by the forward)
         model.engine.compact_masks = False
+    if fused == 'two_transforms':     # the output gradient's two F(4x4) transforms as separate launches (default: one pass)
+        model.engine.dual_transform = False
     if fused == 'gather_kernel':      # the native-resolution side-branch gradients materialised by the gather kernel (default: gathered in the dgrad epilogue)
         model.engine.gather_side_grad = False
     fused = bool(fused)

@@ -51,6 +51,9 @@ _SIGS = {
     'wesup_winograd_gemm_output_transform': (c_int, 'plpppppippiiiiiiiip'),
     'wesup_winograd_gemm_output_transform_gather': (c_int, 'plppppiipppiiiiiip'),
     'wesup_winograd_input_transform_bits': (c_int, 'pplpiiiiip'),
+    'wesup_winograd_bias_rows': (ctypes.c_long, 'iiii'),
+    'wesup_winograd_dual_transform': (c_int, 'ppppiiiip'),
+    'wesup_conv3x3_wgrad_winograd_pre': (c_int, 'pppipp' + 'iiiii' + 'pzp'),
     'wesup_winograd_gemm_output_transform_ex': (c_int, 'plpppppp' + 'i' + 'pppp' + 'ii' + 'ppp' + 'iiiiiii' + 'p'),
     'wesup_conv3x3_dgrad_winograd_gather': (c_int, 'ppppppppiiiiiiiipzp'),
     'wesup_winograd_input_transform': (c_int, 'ppliiiiiip'),

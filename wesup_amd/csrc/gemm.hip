@@ -1390,6 +1390,34 @@ extern "C" int wesup_conv3x3_wgrad_winograd(const float* x, const float* v_pre, 
                                    Ci, m, bias_rows ? ows : nullptr, bias_rows, stream);
 }
 
+// The F(4x4) weight gradient from operands that exist already: v_pre [36][tiles][Ci] (the forward's kept transformed input)
+// and dm_pre [36][tiles][Cout] with its bias rows (wesup_winograd_dual_transform, which the layer's input gradient shares):
+// the batched TN products and the filter-gradient reduce only.  db needs bias_part (bias_rows = wesup_winograd_bias_rows).
+// Workspace: wesup_conv3x3_wgrad_winograd_workspace_bytes (the slabs; its V / dM regions stay unused).
+extern "C" int wesup_conv3x3_wgrad_winograd_pre(const float* v_pre, const float* dm_pre, const float* bias_part, int bias_rows,
+                                                float* dw_kcrs, float* db, int B, int H, int W, int Ci, int Cout, void* ws,
+                                                size_t ws_bytes, void* stream) {
+    const int m = 4;
+    if (!v_pre || !dm_pre || !dw_kcrs || !ws || !wino_shape_ok(B, H, W, Ci, Cout, m) || (db && (!bias_part || bias_rows <= 0)) ||
+        (bias_part && bias_rows != (int)wino4_bias_rows(B, H, W, Cout)) ||
+        (((uintptr_t)v_pre | (uintptr_t)dm_pre | (uintptr_t)bias_part | (uintptr_t)ws) & 15))
+        return WESUP_ERR_INVALID;
+    if (ws_bytes < wesup_conv3x3_wgrad_winograd_workspace_bytes(B, H, W, Ci, Cout, m)) return WESUP_ERR_WORKSPACE;
+    const long T = wino_tiles(B, H, W, m);
+    const int P = wino_positions(m);
+    float* slab = (float*)((char*)ws + align_up((size_t)P * T * Ci * sizeof(float), 256) + align_up((size_t)P * T * Cout * sizeof(float), 256));
+    const TnPlan pl = plan_tn(Cout, Ci, (int)T, 1, P);
+    TnParams p = {};
+    p.A = dm_pre; p.Bx = v_pre; p.slab = slab; p.M = Cout; p.N = Ci; p.K = (int)T; p.lda = Cout; p.ldb = Ci;
+    p.relu_b = 0; p.H = 1; p.W = 1; p.dW = make_fastdiv(1); p.dH = make_fastdiv(1);
+    p.slab_stride = (long)tn_slab_stride(Cout, pl.Nslab); p.want_colsum = false; p.colsum_batch = 5;
+    p.batchA = T * Cout; p.batchB = T * Ci; p.batch_slab = (long)pl.S * p.slab_stride;
+    int rc;
+    if ((rc = launch_tn<3>(p, pl, (hipStream_t)stream, P))) return rc;
+    return wino_filter_grad_launch(slab, p.slab_stride, p.batch_slab, pl.S, dw_kcrs, db, Cout, Ci, m, db ? bias_part : nullptr,
+                                   db ? bias_rows : 0, stream);
+}
+
 // workspace of one forward / dgrad call: [V: P T Cin][M: P T Cout] (for dgrad ask with the channel counts swapped)
 extern "C" size_t wesup_conv3x3_winograd_workspace_bytes(int B, int H, int W, int Cin, int Cout, int m) {
     if (!wino_shape_ok(B, H, W, Cin, Cout, m) || (Cin % 32)) return 0;

@@ -400,10 +400,8 @@ __device__ __forceinline__ bool wino4_decode(const WinoGeom& g, WinoTile& o) {
 // thread = (tile, 4 channels): 36 float4 loads (patch rows 4i-1 .. 4i+4), B^T d B, 36 float4 stores
 // bits (optional, [B][H][W][C/4] bytes): bit j of a byte = x[..., 4 cq + j] > 0 for the 4x4 pixels the tile owns (its
 // patch without the halo) -- the ReLU decisions of the layer below, kept for its backward (16x smaller than the mask tensor).
-__global__ __launch_bounds__(256) void wino4_input_transform_kernel(const float* __restrict__ x, float* __restrict__ V,
-                                                                    const WinoGeom g, int relu, unsigned char* __restrict__ bits) {
-    WinoTile q;
-    if (!wino4_decode(g, q)) return;
+__device__ __forceinline__ void wino4_input_body(const float* __restrict__ x, float* __restrict__ V, const WinoGeom& g,
+                                                 const WinoTile& q, int relu, unsigned char* __restrict__ bits) {
     const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
     float4 m[6][6];      // B^T d
 #pragma unroll
@@ -434,20 +432,23 @@ __global__ __launch_bounds__(256) void wino4_input_transform_kernel(const float*
         for (int c = 0; c < 6; ++c) st4(out + (6 * r + c) * ps, o[c]);
     }
 }
+__global__ __launch_bounds__(256) void wino4_input_transform_kernel(const float* __restrict__ x, float* __restrict__ V,
+                                                                    const WinoGeom g, int relu, unsigned char* __restrict__ bits) {
+    WinoTile q;
+    if (!wino4_decode(g, q)) return;
+    wino4_input_body(x, V, g, q, relu, bits);
+}
 
 // thread = (tile, 4 channels): the tile's 4x4 gradients -> A dY A^T (6x6).
 // colsum_part (optional, [blocks][C]): the bias gradient rides along.  This point set has no point 1, so no single position
 // of dM is the plain sum of a tile's gradients (for F(2x2) position (1,1) is, and the TN GEMM sums its column); instead
 // every thread adds up the 16 gradients it has loaded anyway, the tiles of a block meet in LDS in a fixed order (needs
 // C/4 | 256), and wesup_colsum folds the per-block rows: dy is not read a second time, no float atomics.
-__global__ __launch_bounds__(256) void wino4_outgrad_transform_kernel(const float* __restrict__ dy, float* __restrict__ dM,
-                                                                      const WinoGeom g, float* __restrict__ colsum_part) {
-    __shared__ float4 sh[256];
-    WinoTile q;
-    const bool active = wino4_decode(g, q);
+__device__ __forceinline__ float4 wino4_outgrad_body(const float* __restrict__ dy, float* __restrict__ dM, const WinoGeom& g,
+                                                     const WinoTile& q) {
     const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
     float4 tot = z;
-    if (active) {
+    {
         float4 m[6][4];      // A dY
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
@@ -473,7 +474,10 @@ __global__ __launch_bounds__(256) void wino4_outgrad_transform_kernel(const floa
             for (int c = 0; c < 6; ++c) st4(out + (6 * r + c) * ps, o[c]);
         }
     }
-    if (!colsum_part) return;            // uniform
+    return tot;
+}
+// the per-block column sums of the gradients the block's threads loaded (tot), one row of colsum_part per block
+__device__ __forceinline__ void wino4_block_colsum(float4 tot, const WinoGeom& g, float* __restrict__ colsum_part, float4* sh) {
     const int Q = g.C >> 2, tid = threadIdx.x;
     sh[tid] = tot;
     __syncthreads();
@@ -482,6 +486,33 @@ __global__ __launch_bounds__(256) void wino4_outgrad_transform_kernel(const floa
         for (int k = tid + Q; k < 256; k += Q) s = f4add(s, sh[k]);
         st4(colsum_part + (long)xcd_remap(blockIdx.x, gridDim.x) * g.C + 4 * tid, s);
     }
+}
+__global__ __launch_bounds__(256) void wino4_outgrad_transform_kernel(const float* __restrict__ dy, float* __restrict__ dM,
+                                                                      const WinoGeom g, float* __restrict__ colsum_part) {
+    __shared__ float4 sh[256];
+    WinoTile q;
+    const bool active = wino4_decode(g, q);
+    const float4 tot = active ? wino4_outgrad_body(dy, dM, g, q) : make_float4(0.f, 0.f, 0.f, 0.f);
+    if (!colsum_part) return;            // uniform
+    wino4_block_colsum(tot, g, colsum_part, sh);
+}
+// Both transforms of one gradient tensor in one pass over it: V = B^T dY B of the 6x6 patches (the input of the layer's input
+// gradient) and dM = A dY A^T of their 4x4 cores (the second operand of its weight gradient).  A thread does the first, then the
+// second on the 16 core values it re-reads (cache hits: it loaded them a moment ago); dy comes from HBM once instead of once
+// per stream, and one launch replaces two.
+__global__ __launch_bounds__(256) void wino4_dual_transform_kernel(const float* __restrict__ dy, float* __restrict__ V,
+                                                                   float* __restrict__ dM, const WinoGeom g,
+                                                                   float* __restrict__ colsum_part) {
+    __shared__ float4 sh[256];
+    WinoTile q;
+    const bool active = wino4_decode(g, q);
+    float4 tot = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (active) {
+        wino4_input_body(dy, V, g, q, 0, nullptr);
+        tot = wino4_outgrad_body(dy, dM, g, q);
+    }
+    if (!colsum_part) return;            // uniform
+    wino4_block_colsum(tot, g, colsum_part, sh);
 }
 
 // thread = (tile, 4 channels): Y = A^T M A for the tile's 4x4 outputs, then the conv epilogue on the pixels inside the
@@ -710,6 +741,23 @@ int wino_outgrad_launch(const float* dy, float* dM, float* bias_part, int B, int
     const dim3 grid((unsigned)wino_transform_blocks(B, H, W, C, m));
     if (m == 2) hipLaunchKernelGGL(wino_outgrad_transform_kernel, grid, dim3(256), 0, (hipStream_t)stream, dy, dM, g);
     else hipLaunchKernelGGL(wino4_outgrad_transform_kernel, grid, dim3(256), 0, (hipStream_t)stream, dy, dM, g, bias_part);
+    WESUP_CHECK_LAUNCH();
+    return WESUP_OK;
+}
+// rows of per-block column sums the F(4x4) gradient transforms leave for the bias gradient (0: C / 4 does not divide 256)
+extern "C" long wesup_winograd_bias_rows(int B, int H, int W, int C) {
+    return wino_shape_ok(B, H, W, C, C, 4) ? wino4_bias_rows(B, H, W, C) : 0;
+}
+// dy (B,H,W,C) -> V [36][tiles][C] (input transform, no ReLU) AND dM [36][tiles][C] (outgrad transform) in one launch (m = 4);
+// bias_part (optional, [wesup_winograd_bias_rows][C]): the per-block column sums of dy for wesup_conv3x3_wgrad_winograd_pre.
+extern "C" int wesup_winograd_dual_transform(const float* dy, float* V, float* dM, float* bias_part, int B, int H, int W, int C,
+                                             void* stream) {
+    if (!dy || !V || !dM || !wino_shape_ok(B, H, W, C, C, 4) || (((uintptr_t)dy | (uintptr_t)V | (uintptr_t)dM | (uintptr_t)bias_part) & 15) ||
+        (bias_part && !wino4_block_colsum_ok(C)))
+        return WESUP_ERR_INVALID;
+    const WinoGeom g = wino_geom(B, H, W, C, 4);
+    const dim3 grid((unsigned)wino_transform_blocks(B, H, W, C, 4));
+    hipLaunchKernelGGL(wino4_dual_transform_kernel, grid, dim3(256), 0, (hipStream_t)stream, dy, V, dM, g, bias_part);
     WESUP_CHECK_LAUNCH();
     return WESUP_OK;
 }

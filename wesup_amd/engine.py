@@ -162,6 +162,10 @@ class WesupEngine:
         # reads the output anyway; 1/16 of the tensor) and the max-pool's decisions as 3-bit codes (written by the epilogue that
         # pools; 1/32).  The dgrad epilogues read those instead of the pre-ReLU outputs: 0.9 GB less traffic per step at c2.
         self.compact_masks = True
+        # Both F(4x4) transforms of a layer's output gradient -- the input of its input gradient and the operand of its weight
+        # gradient -- in one pass over it on the main stream (ops.winograd_dual_transform): the gradient is read once instead of
+        # once per stream and twelve launches go
+        self.dual_transform = True
         self.batch_side_convs = False    # A/B: side convs (and their input gradients) of the layers that share a deep resolution in one launch
         self.head_streamk = False
         self._diag_skip = set()          # TIMING-ONLY diagnostics (bench.py --diag-skip): classes of launches left out, results wrong
@@ -279,6 +283,7 @@ class WesupEngine:
             b.fm = None if self.fuse_pool_fwd else torch.empty(B, H, W, FM_CHANNELS, **f32)
             b.fm_valid = False
             b.ybar, b.dybar = [None] * 13, [None] * 13       # commuted side branch: mean_r(upsample(y_l)) and its gradient
+            b.dM, b.bpart, b.dV = [None] * 13, [None] * 13, None   # dual_transform: per layer dM + bias rows, one shared V'
             b.mbits, b.pcode = [None] * 13, [None] * 13      # compact_masks: sign bits / pooling codes of y_l (None: not kept)
             b.mbits_ok, b.pcode_ok = [False] * 13, [False] * 13
             b.s_valid = [False] * 13
@@ -882,11 +887,34 @@ class WesupEngine:
             if g_ready[l] is not None:
                 main.wait_event(g_ready[l])
             x_in, relu_x = b.x_in[l], b.x_relu[l]      # what the forward of this layer read
+            # one pass over G_l for both consumers (F(4x4) input gradient and weight gradient; the input gradient through a
+            # max-pool backward needs the one-kernel product route to take a transformed input)
+            dual = (self.dual_transform and b.wino_fwd[l] == 4 and l > lowest and trainable[l] and self.wgrad_winograd
+                    and b.V[l] is not None and 'wgrad' not in self._diag_skip and ops.winograd_bias_rows(B, h, w, co) > 0
+                    and not (POOL_AFTER[l - 1] and not (self.fuse_unpool and ops.winograd_fused_supported(co, ci, 4) == 2)))
+            v_dy = None
+            if dual:
+                Tl = ops.winograd_tiles(B, h, w, 4)
+                if b.dV is None:
+                    b.dV = torch.empty(max(36 * ops.winograd_tiles(B, *b.dims[i], 4) * CONV_CH[i][1] for i in range(1, 13)),
+                                       dtype=torch.float32, device=self.device)
+                if b.dM[l] is None:
+                    b.dM[l] = torch.empty(36, Tl, co, dtype=torch.float32, device=self.device)
+                    b.bpart[l] = torch.empty(ops.winograd_bias_rows(B, h, w, co), co, dtype=torch.float32, device=self.device)
+                v_dy = b.dV[:36 * Tl * co].view(36, Tl, co)
+                tok = T.begin('winograd_transform')
+                ops.winograd_dual_transform(b.G[l], v_dy, b.dM[l], b.bpart[l])
+                T.end(tok, 4.0 * (B * h * w + 2 * 36 * Tl) * co)
             def wgrad(ws_tag):
                 tok = T.begin('conv3x3_wgrad')
                 dw, db = g[f'backbone.{idx}.weight'], g[f'backbone.{idx}.bias']
                 mw = b.wino_fwd[l]                             # this forward went through the Winograd domain: its V was kept
                 v_pre = b.V[l] if mw else None
+                if dual:
+                    ops.conv3x3_wgrad_winograd_pre(v_pre, b.dM[l], b.bpart[l], B, h, w, dw, db, ws_tag=ws_tag)
+                    T.end(tok, 2.0 * 36 * ops.winograd_tiles(B, h, w, 4) * ci * co)
+                    ready([f'backbone.{idx}.weight', f'backbone.{idx}.bias'])
+                    return
                 # the forward's kept V decides; without one (direct forward) only the layers where a transform pass of
                 # its own still pays
                 if self.wgrad_winograd and (v_pre is not None or (ci >= self.WINOGRAD_MIN_CI and co >= self.WINOGRAD_MIN_CO)):
@@ -917,19 +945,21 @@ class WesupEngine:
                     ops.conv3x3_dgrad_winograd_gather(b.G[l], pk.ud[l], b.dybar[l - 1], meta.new_row, meta.area_new, out=b.G[l - 1],
                                                       mask_src=None if pooled else b.y[l - 1],
                                                       unpool_src=b.y[l - 1] if pooled else None, ws_tag='wino_main', timer=T,
-                                                      mask_bits=None if pooled else mbits, unpool_code=pcode if pooled else None)
+                                                      mask_bits=None if pooled else mbits, unpool_code=pcode if pooled else None,
+                                                      v_pre=v_dy)
                     unpooled = True
                 elif b.wino_fwd[l]:
                     if POOL_AFTER[l - 1] and self.fuse_unpool and b.wino_fwd[l] == 4:
                         ops.conv3x3_dgrad_winograd_unpool(b.G[l], pk.ud[l], b.y[l - 1], b.G[l - 1], ws_tag='wino_main', timer=T,
-                                                          unpool_code=pcode)
+                                                          unpool_code=pcode, v_pre=v_dy)
                         unpooled = True
                     elif POOL_AFTER[l - 1]:
                         ops.conv3x3_dgrad_winograd(b.G[l], pk.ud[l], out=b.dxp[l - 1], ws_tag='wino_main', timer=T,
-                                                   m=b.wino_fwd[l])
+                                                   m=b.wino_fwd[l], v_pre=v_dy)
                     else:
                         ops.conv3x3_dgrad_winograd(b.G[l], pk.ud[l], mask_src=None if mbits is not None else b.y[l - 1], out=b.G[l - 1],
-                                                   accumulate=True, ws_tag='wino_main', timer=T, m=b.wino_fwd[l], mask_bits=mbits)
+                                                   accumulate=True, ws_tag='wino_main', timer=T, m=b.wino_fwd[l], mask_bits=mbits,
+                                                   v_pre=v_dy)
                 else:
                     tok = T.begin('conv3x3_dgrad')
                     if POOL_AFTER[l - 1]:

@@ -414,7 +414,7 @@ def _aux_stream(device):
 
 
 def _winograd_conv(inp, u, bias, mask_src, out, out_relu, v_keep, relu_in, accumulate, ws_tag, timer, out_pool=None,
-                   pool_relu=False, m=2, relu_bits_out=None, pool_code_out=None, mask_bits=None):
+                   pool_relu=False, m=2, relu_bits_out=None, pool_code_out=None, mask_bits=None, v_ready=False):
     """The three passes of a Winograd-domain conv (input transform, 16 batched NT GEMMs, output transform + epilogue).
     timer (optional, engine.KernelTimer-like): the GEMM and the two transforms are bracketed as classes of their own.
 
@@ -437,6 +437,8 @@ def _winograd_conv(inp, u, bias, mask_src, out, out_relu, v_keep, relu_in, accum
     n_io = 1 + (out_relu is not None) + (mask_src is not None) + bool(accumulate)
 
     def t_in(b0, nb_, st):
+        if v_ready:        # v_keep holds the transformed input already (winograd_dual_transform)
+            return
         tok = timer.begin('winograd_transform') if timer else None
         t0 = winograd_tiles(b0, H, W, m)
         if relu_bits_out is not None:      # the sign bits of the input ride along (the ReLU mask of the layer below, for its backward)
@@ -558,7 +560,7 @@ def conv3x3_fwd_winograd(x, u_fwd, bias, relu_in, out=None, out_relu=None, v_kee
 
 
 def conv3x3_dgrad_winograd(dy, u_dgrad, mask_src=None, out=None, accumulate=False, ws_tag='default', timer=None, m=2,
-                           mask_bits=None):
+                           mask_bits=None, v_pre=None):
     _chk(dy, name='dy'); _chk(u_dgrad, name='u_dgrad')
     B, H, W, Cout = dy.shape
     Cin = u_dgrad.shape[1]
@@ -569,10 +571,15 @@ def conv3x3_dgrad_winograd(dy, u_dgrad, mask_src=None, out=None, accumulate=Fals
         assert not accumulate
         out = torch.empty(B, H, W, Cin, dtype=torch.float32, device=dy.device)
     assert out.shape == (B, H, W, Cin) and out.is_contiguous()
-    return _winograd_conv(dy, u_dgrad, None, mask_src, out, None, None, False, accumulate, ws_tag, timer, m=m, mask_bits=mask_bits)
+    # v_pre (P,tiles,Cout): dy's input transform, done already (winograd_dual_transform): only the products and the way back
+    if v_pre is not None:
+        _chk(v_pre, name='v_pre'); assert v_pre.shape == (winograd_positions(m), winograd_tiles(B, H, W, m), Cout)
+    return _winograd_conv(dy, u_dgrad, None, mask_src, out, None, v_pre, False, accumulate, ws_tag, timer, m=m, mask_bits=mask_bits,
+                          v_ready=v_pre is not None)
 
 
-def conv3x3_dgrad_winograd_unpool(dy, u_dgrad, unpool_src, unpool_dst, ws_tag='default', timer=None, m=4, unpool_code=None):
+def conv3x3_dgrad_winograd_unpool(dy, u_dgrad, unpool_src, unpool_dst, ws_tag='default', timer=None, m=4, unpool_code=None,
+                                  v_pre=None):
     """Input gradient of a layer that follows a 2x2 max-pool, added straight into the gradient of the PRE-pool activations:
     dy (B,H,W,Cout) at pooled resolution, unpool_src / unpool_dst (B,Hu,Wu,Cin) with H == Hu // 2, W == Wu // 2.  Equals
     conv3x3_dgrad_winograd(out=dxp) followed by maxpool2_bwd(unpool_src, dxp, unpool_dst, accumulate=True)."""
@@ -583,20 +590,30 @@ def conv3x3_dgrad_winograd_unpool(dy, u_dgrad, unpool_src, unpool_dst, ws_tag='d
     _, Hu, Wu, _ = unpool_dst.shape
     assert unpool_dst.shape == (B, Hu, Wu, Cin) and (Hu // 2, Wu // 2) == (H, W)
     lib = _lib.load()
-    if unpool_code is not None:        # the pooling's decisions as codes (conv3x3_fwd_winograd(pool_code_out=...)): no read of unpool_src
-        assert unpool_code.dtype == torch.int16 and unpool_code.shape == (B, H, W, Cin // 4) and unpool_code.is_contiguous()
+    if unpool_code is not None or v_pre is not None:
+        # the pooling's decisions as codes (conv3x3_fwd_winograd(pool_code_out=...)): no read of unpool_src; and / or the input
+        # transform of dy done already (winograd_dual_transform).  One-kernel product route only.
+        if unpool_code is not None:
+            assert unpool_code.dtype == torch.int16 and unpool_code.shape == (B, H, W, Cin // 4) and unpool_code.is_contiguous()
+        else:
+            _chk(unpool_src, name='unpool_src'); assert unpool_src.shape == unpool_dst.shape
         if lib.wesup_winograd_fused_supported(Cout, Cin, m) != 2:
-            raise _lib.WesupHipError(f'winograd dgrad {Cout} -> {Cin}: unpool_code needs the one-kernel product route')
-        nb = lib.wesup_conv3x3_winograd_workspace_bytes(B, H, W, Cout, Cin, m)
-        ws = workspace(nb, dy.device, ws_tag)
+            raise _lib.WesupHipError(f'winograd dgrad {Cout} -> {Cin}: unpool_code / v_pre need the one-kernel product route')
         T, P = winograd_tiles(B, H, W, m), winograd_positions(m)
         st = _stream()
-        tok = timer.begin('winograd_transform') if timer else None
-        _lib.call('wesup_winograd_input_transform', _p(dy), _p(ws), 0, B, H, W, Cout, 0, m, st)
-        if timer:
-            timer.end(tok, 4.0 * (B * H * W + P * T) * Cout)
+        if v_pre is None:
+            nb = lib.wesup_conv3x3_winograd_workspace_bytes(B, H, W, Cout, Cin, m)
+            ws = workspace(nb, dy.device, ws_tag)
+            tok = timer.begin('winograd_transform') if timer else None
+            _lib.call('wesup_winograd_input_transform', _p(dy), _p(ws), 0, B, H, W, Cout, 0, m, st)
+            if timer:
+                timer.end(tok, 4.0 * (B * H * W + P * T) * Cout)
+        else:
+            _chk(v_pre, name='v_pre'); assert v_pre.shape == (P, T, Cout)
+            ws = v_pre
         tok = timer.begin('winograd_gemm') if timer else None
-        _lib.call('wesup_winograd_gemm_output_transform_ex', _p(ws), 0, _p(u_dgrad), None, None, None, None, None, 0, None, None,
+        _lib.call('wesup_winograd_gemm_output_transform_ex', _p(ws), 0, _p(u_dgrad), None, None, None, None, None, 0, None,
+                  _p(None if unpool_code is not None else unpool_src),
                   _p(unpool_code), _p(unpool_dst), Hu, Wu, None, None, None, 0, B, H, W, Cout, Cin, 0, st)
         if timer:
             timer.end(tok, 2.0 * P * T * Cin * Cout)
@@ -643,7 +660,7 @@ def winograd_fused_supported(K, N, m=4):
 
 
 def conv3x3_dgrad_winograd_gather(dy, u_dgrad, side, new_row, area_new, out, mask_src=None, unpool_src=None,
-                                  ws_tag='default', timer=None, mask_bits=None, unpool_code=None):
+                                  ws_tag='default', timer=None, mask_bits=None, unpool_code=None, v_pre=None):
     """conv3x3_dgrad_winograd(accumulate=True) / conv3x3_dgrad_winograd_unpool (unpool_src given) with out's old content
     replaced by the gather side[b][new_row[b][pixel]] / area_new[...] (side (B,Kmax,Cin): the commuted side-branch gradient of
     a native-resolution layer): out is written, never read.  m = 4, shapes of the one-kernel product route only."""
@@ -677,16 +694,21 @@ def conv3x3_dgrad_winograd_gather(dy, u_dgrad, side, new_row, area_new, out, mas
     nb = lib.wesup_conv3x3_winograd_workspace_bytes(B, H, W, Cout, Cin, 4)
     ws = workspace(nb, dy.device, ws_tag)
     compact = mask_bits is not None or unpool_code is not None
-    if timer is None and not compact:
+    if v_pre is not None:      # dy's input transform, done already (winograd_dual_transform)
+        _chk(v_pre, name='v_pre'); assert v_pre.shape == (36, winograd_tiles(B, H, W, 4), Cout)
+    if timer is None and not compact and v_pre is None:
         _lib.call('wesup_conv3x3_dgrad_winograd_gather', _p(dy), _p(u_dgrad), _p(mask_src), _p(unpool_src), _p(out), _p(side),
                   _p(new_row), _p(area_new), Kmax, B, H, W, Hu, Wu, Cin, Cout, _p(ws), nb, _stream())
         return out
     T, P = winograd_tiles(B, H, W, 4), 36
     st = _stream()
-    tok = timer.begin('winograd_transform') if timer else None
-    _lib.call('wesup_winograd_input_transform', _p(dy), _p(ws), 0, B, H, W, Cout, 0, 4, st)
-    if timer:
-        timer.end(tok, 4.0 * (B * H * W + P * T) * Cout)
+    if v_pre is None:
+        tok = timer.begin('winograd_transform') if timer else None
+        _lib.call('wesup_winograd_input_transform', _p(dy), _p(ws), 0, B, H, W, Cout, 0, 4, st)
+        if timer:
+            timer.end(tok, 4.0 * (B * H * W + P * T) * Cout)
+    else:
+        ws = v_pre
     tok = timer.begin('winograd_gemm') if timer else None
     if compact:
         pooled = Hu > 0
@@ -699,6 +721,44 @@ def conv3x3_dgrad_winograd_gather(dy, u_dgrad, side, new_row, area_new, out, mas
     if timer:
         timer.end(tok, 2.0 * P * T * Cin * Cout)
     return out
+
+
+def winograd_bias_rows(B, H, W, C):
+    """Rows of per-block column sums the F(4x4) gradient transforms leave for the bias gradient (0: C is not covered)."""
+    return int(_lib.load().wesup_winograd_bias_rows(B, H, W, C))
+
+
+def winograd_dual_transform(dy, V, dM, bias_part=None):
+    """One pass over dy (B,H,W,C) for both of its F(4x4) transforms: V (36,tiles,C) = B^T dY B (input of the layer's input
+    gradient) and dM (36,tiles,C) = A dY A^T (operand of its weight gradient); bias_part (winograd_bias_rows, C): per-block
+    column sums of dy for conv3x3_wgrad_winograd_pre."""
+    _chk(dy, name='dy'); _chk(V, name='V'); _chk(dM, name='dM')
+    B, H, W, C = dy.shape
+    T = winograd_tiles(B, H, W, 4)
+    assert V.shape == (36, T, C) == dM.shape
+    if bias_part is not None:
+        _chk(bias_part, name='bias_part'); assert bias_part.shape == (winograd_bias_rows(B, H, W, C), C) and bias_part.shape[0] > 0
+    _lib.call('wesup_winograd_dual_transform', _p(dy), _p(V), _p(dM), _p(bias_part), B, H, W, C, _stream())
+    return V, dM
+
+
+def conv3x3_wgrad_winograd_pre(v_pre, dm_pre, bias_part, B, H, W, dw, db=None, ws_tag='default'):
+    """The F(4x4) weight gradient from operands that exist: v_pre (36,tiles,Ci) kept by the forward, dm_pre (36,tiles,Cout) and
+    bias_part from winograd_dual_transform.  dw (Cout,Ci,3,3); db (Cout) needs bias_part."""
+    _chk(v_pre, name='v_pre'); _chk(dm_pre, name='dm_pre'); _chk(dw, name='dw')
+    T = winograd_tiles(B, H, W, 4)
+    Ci, Cout = v_pre.shape[2], dm_pre.shape[2]
+    assert v_pre.shape == (36, T, Ci) and dm_pre.shape == (36, T, Cout) and dw.shape == (Cout, Ci, 3, 3)
+    rows = 0
+    if db is not None:
+        _chk(db, name='db'); _chk(bias_part, name='bias_part')
+        rows = bias_part.shape[0]
+        assert db.numel() == Cout and bias_part.shape == (winograd_bias_rows(B, H, W, Cout), Cout)
+    nb = _lib.load().wesup_conv3x3_wgrad_winograd_workspace_bytes(B, H, W, Ci, Cout, 4)
+    ws = workspace(nb, v_pre.device, ws_tag)
+    _lib.call('wesup_conv3x3_wgrad_winograd_pre', _p(v_pre), _p(dm_pre), _p(bias_part if db is not None else None), rows, _p(dw),
+              _p(db), B, H, W, Ci, Cout, _p(ws), nb, _stream())
+    return dw, db
 
 
 def conv3x3_wgrad_winograd(x, dy, relu_in, dw=None, db=None, ws_tag='default', v_pre=None, m=2):
