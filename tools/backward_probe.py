@@ -31,7 +31,7 @@ def wrap(obj, name, tag, first_only=True):
 wrap(ops, 'conv3x3_fwd', 'conv1_1')
 wrap(trainer, 'compute_loss', 'fwd_end')
 wrap(ops, 'classifier_bwd', 'bwd_begin')
-wrap(ops, 'conv3x3_dgrad_winograd', 'first_dgrad')
+wrap(ops, 'winograd_dual_transform', 'first_dgrad')
 wrap(ops, 'upsample_bwd_fused_group', 'x')          # (not on the main stream; ignored)
 wrap(trainer.optimizer, 'step', 'bwd_end')
 N = 12
