@@ -851,7 +851,7 @@ def test_sp_pool(ops, B, H, W, g, C):
     assert torch.equal(out, ops.sp_pool_fwd(fm.to(d), m))          # bitwise reproducible
     # fused upsample + scatter-mean forward == upsample_fwd followed by sp_pool_fwd
     for (h, w, Cs, coff) in [(H, W, 32, 0), (H, W, 64, 32), (H // 2, W // 2, 64, 64), (H // 2, W // 2, 128, 128), (H // 4, W // 4, 128, 128),
-                             (H // 4, W // 4, 256, 0), (max(1, H // 16), max(1, W // 16), 256, 512)]:
+                             (H // 4, W // 4, 256, 0), (max(1, H // 8), max(1, W // 8), 512, 256), (max(1, H // 16), max(1, W // 16), 256, 512)]:
         if coff + Cs > C:
             continue
         sl = rnd(B, h, w, Cs, seed=9).to(d)
@@ -866,19 +866,25 @@ def test_sp_pool(ops, B, H, W, g, C):
         ops.sp_pool_upsample_fwd(sl, m, got2, coff)
         assert torch.equal(got, got2)
     # fused pool-backward + upsample-backward == unfused
-    for (h, w, Cs, coff) in [(H, W, 32, 0), (H, W, 64, 32), (H // 2, W // 2, 64, 64), (H // 4, W // 4, 256, 0), (max(1, H // 16), max(1, W // 16), 64, 128)]:
+    for (h, w, Cs, coff) in [(H, W, 32, 0), (H, W, 64, 32), (H // 2, W // 2, 64, 64), (H // 4, W // 4, 256, 0), (max(1, H // 8), max(1, W // 8), 512, 0), (max(1, H // 16), max(1, W // 16), 64, 128)]:
         if coff + Cs > C:
             continue
         a = ops.upsample_bwd(dfm, coff, h, w, Cs)
         f = ops.upsample_bwd_fused(gup.to(d), m.new_row, m.area_new, H, W, coff, h, w, Cs)
         assert rel_err(f, a) < 1e-5
     # ... and the layers of one coarse resolution in one launch (shared window scan): the per-layer values, bit for bit
-    for (h, w, Cl) in [(H // 2, W // 2, (128, 128)), (H // 4, W // 4, (256, 256, 256)), (H // 2, W // 4, (64,)), (H // 4, W // 4, (32, 256))]:
+    for (h, w, Cl) in [(H // 2, W // 2, (128, 128)), (H // 4, W // 4, (256, 256, 256)), (H // 2, W // 4, (64,)), (H // 4, W // 4, (32, 256)), (H // 4, W // 4, (512,))]:
         gs = [rnd(B, Kmax, c, seed=20 + i).to(d) for i, c in enumerate(Cl)]
         outs = [torch.full((B, h, w, c), 7.0, device=d) for c in Cl]
         ops.upsample_bwd_fused_group(gs, m.new_row, m.area_new, H, W, h, w, outs)
         for gi, oi in zip(gs, outs):
-            assert torch.equal(oi, ops.upsample_bwd_fused(gi, m.new_row, m.area_new, H, W, 0, h, w, gi.shape[2]))
+            if gi.shape[2] <= 256:
+                assert torch.equal(oi, ops.upsample_bwd_fused(gi, m.new_row, m.area_new, H, W, 0, h, w, gi.shape[2]))
+            else:          # wide dense rows take the group kernel inside wesup_upsample_bwd too: compare with a strided call
+                wide = torch.zeros(B, Kmax, gi.shape[2] + 64, device=d)
+                wide[..., 32:32 + gi.shape[2]] = gi
+                assert rel_err(oi, ops.upsample_bwd_fused(wide, m.new_row, m.area_new, H, W, 32, h, w, gi.shape[2])) < 1e-6
+                assert torch.equal(oi, ops.upsample_bwd_fused(gi, m.new_row, m.area_new, H, W, 0, h, w, gi.shape[2]))
 
 
 def test_paint_and_dense_compat(ops):

@@ -503,6 +503,9 @@ extern "C" int wesup_upsample_bwd(const float* dfm_or_g, const int32_t* new_row,
     if (new_row && h == H && w == W)
         hipLaunchKernelGGL(upsample_bwd_ident_kernel, grid, dim3(256), 0, (hipStream_t)stream, dfm_or_g, new_row, area_new, ds,
                            (long)B * H * W, H * W, C / 4, ldf, coff, Kmax);
+    else if (new_row && C / 4 > 64 && C <= 768 && ldf == C && coff == 0)      // wide dense rows: the cell kernel in passes of 64 quads
+        return wesup_upsample_bwd_group(dfm_or_g, nullptr, nullptr, ds, nullptr, nullptr, C, 0, 0, 1, new_row, area_new, B, h, w, H,
+                                        W, Kmax, stream);
     else if (new_row && C / 4 <= 64)
         hipLaunchKernelGGL(upsample_bwd_cell_kernel, dim3((unsigned)(((long)B * h * w + 3) / 4)), dim3(256), 0,
                            (hipStream_t)stream, dfm_or_g, new_row, area_new, ds, B, h, w, H, W, C / 4, ldf, coff, Kmax,

@@ -427,8 +427,8 @@ __global__ __launch_bounds__(256) void sp_pool_up_fwd_kernel(const float* __rest
                                                              const int32_t* __restrict__ seg_start,
                                                              const int32_t* __restrict__ unit_row, float* __restrict__ part,
                                                              float* __restrict__ sp_feat, int h, int w, int H, int W,
-                                                             FastDiv dW, int ldo, int coff, int Kmax, int Umax, float sh,
-                                                             float sw) {
+                                                             FastDiv dW, int lds, int ldo, int coff, int Kmax, int Umax,
+                                                             float sh, float sw) {
     constexpr int PPW = 64 / LPP;
     constexpr int C = LPP * 4;
     const int b = blockIdx.y;
@@ -441,7 +441,7 @@ __global__ __launch_bounds__(256) void sp_pool_up_fwd_kernel(const float* __rest
     const int r = sg.r, j0 = sg.j0, j1 = sg.j1;
     const float inv = sg.inv;
     const int32_t* list = pix_sorted + (long)b * HW;
-    const float* base = s + (long)b * h * w * C + 4 * cl;
+    const float* base = s + (long)b * h * w * lds + 4 * cl;       // lds: floats between two cells of s (>= C)
     const bool ident = (h == H && w == W);
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     // Coarse maps: "sample 4 cells per pixel, then average" is regrouped by CELL.  The segment's pixels touch only the
@@ -499,7 +499,7 @@ __global__ __launch_bounds__(256) void sp_pool_up_fwd_kernel(const float* __rest
                     v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
                     if (wq != 0ull) {
                         const int cy = q / bw, cx = q - cy * bw;
-                        v[u] = ld4(base + ((long)(y0 + cy) * w + x0 + cx) * C);
+                        v[u] = ld4(base + ((long)(y0 + cy) * w + x0 + cx) * lds);
                     }
                 }
 #pragma unroll
@@ -521,7 +521,7 @@ __global__ __launch_bounds__(256) void sp_pool_up_fwd_kernel(const float* __rest
             for (int u = 0; u < SP_UP_UNROLL; ++u) pix[u] = list[j + u * PPW];
             float4 v[SP_UP_UNROLL];
 #pragma unroll
-            for (int u = 0; u < SP_UP_UNROLL; ++u) v[u] = ld4(base + (long)pix[u] * C);
+            for (int u = 0; u < SP_UP_UNROLL; ++u) v[u] = ld4(base + (long)pix[u] * lds);
 #pragma unroll
             for (int u = 0; u < SP_UP_UNROLL; ++u) {
                 acc.x = fmaf(v[u].x, inv, acc.x);
@@ -531,7 +531,7 @@ __global__ __launch_bounds__(256) void sp_pool_up_fwd_kernel(const float* __rest
             }
         }
         for (; j < j1; j += PPW) {
-            const float4 v = ld4(base + (long)list[j] * C);
+            const float4 v = ld4(base + (long)list[j] * lds);
             acc.x = fmaf(v.x, inv, acc.x);
             acc.y = fmaf(v.y, inv, acc.y);
             acc.z = fmaf(v.z, inv, acc.z);
@@ -544,10 +544,10 @@ __global__ __launch_bounds__(256) void sp_pool_up_fwd_kernel(const float* __rest
         {
             const int Y = fast_div(p, dW), X = p - Y * W;
             const Lerp2 ly = lerp2_of(Y, sh, h), lx = lerp2_of(X, sw, w);
-            const float4 v00 = ld4(base + ((long)ly.i0 * w + lx.i0) * C);
-            const float4 v01 = ld4(base + ((long)ly.i0 * w + lx.i1) * C);
-            const float4 v10 = ld4(base + ((long)ly.i1 * w + lx.i0) * C);
-            const float4 v11 = ld4(base + ((long)ly.i1 * w + lx.i1) * C);
+            const float4 v00 = ld4(base + ((long)ly.i0 * w + lx.i0) * lds);
+            const float4 v01 = ld4(base + ((long)ly.i0 * w + lx.i1) * lds);
+            const float4 v10 = ld4(base + ((long)ly.i1 * w + lx.i0) * lds);
+            const float4 v11 = ld4(base + ((long)ly.i1 * w + lx.i1) * lds);
             v.x = ly.l0 * (lx.l0 * v00.x + lx.l1 * v01.x) + ly.l1 * (lx.l0 * v10.x + lx.l1 * v11.x);
             v.y = ly.l0 * (lx.l0 * v00.y + lx.l1 * v01.y) + ly.l1 * (lx.l0 * v10.y + lx.l1 * v11.y);
             v.z = ly.l0 * (lx.l0 * v00.z + lx.l1 * v01.z) + ly.l1 * (lx.l0 * v10.z + lx.l1 * v11.z);
@@ -583,20 +583,25 @@ extern "C" int wesup_sp_pool_upsample_fwd(const float* s, const int32_t* pix_sor
     const FastDiv dW = make_fastdiv(W);
     hipStream_t st = (hipStream_t)stream;
     float* part = (float*)ws;
-#define WESUP_LAUNCH_PU(L)                                                                                              \
-    hipLaunchKernelGGL(sp_pool_up_fwd_kernel<L>, grid, dim3(256), 0, st, s, pix_sorted, row_start, seg_start, unit_row, \
-                       part, sp_feat, h, w, H, W, dW, ldo, coff, Kmax, Umax, sh, sw)
-    switch (C) {
-        case 32: WESUP_LAUNCH_PU(8); break;
-        case 64: WESUP_LAUNCH_PU(16); break;
-        case 128: WESUP_LAUNCH_PU(32); break;
-        case 256: WESUP_LAUNCH_PU(64); break;
-        default: return WESUP_ERR_INVALID;
+#define WESUP_LAUNCH_PU(L, c0)                                                                                             \
+    hipLaunchKernelGGL(sp_pool_up_fwd_kernel<L>, grid, dim3(256), 0, st, s + (c0), pix_sorted, row_start, seg_start, unit_row, \
+                       part, sp_feat, h, w, H, W, dW, C, ldo, coff + (c0), Kmax, Umax, sh, sw)
+    // a wave's 64 lanes cover 256 channels of a pixel: wider maps go in slabs of 256 channels (row stride C)
+    if (C > 256 && (C % 256)) return WESUP_ERR_INVALID;
+    for (int c0 = 0; c0 < C; c0 += 256) {
+        const int cw = C - c0 < 256 ? C - c0 : 256;
+        switch (cw) {
+            case 32: WESUP_LAUNCH_PU(8, c0); break;
+            case 64: WESUP_LAUNCH_PU(16, c0); break;
+            case 128: WESUP_LAUNCH_PU(32, c0); break;
+            case 256: WESUP_LAUNCH_PU(64, c0); break;
+            default: return WESUP_ERR_INVALID;
+        }
+        const long tot = (long)Kmax * (cw / 4);
+        hipLaunchKernelGGL(sp_pool_combine_kernel, dim3((unsigned)((tot + 255) / 256), B), dim3(256), 0, st, (const float*)ws,
+                           seg_start, sp_feat, Kmax, Umax, cw / 4, ldo, coff + c0);
     }
 #undef WESUP_LAUNCH_PU
-    const long tot = (long)Kmax * (C / 4);
-    hipLaunchKernelGGL(sp_pool_combine_kernel, dim3((unsigned)((tot + 255) / 256), B), dim3(256), 0, st, (const float*)ws,
-                       seg_start, sp_feat, Kmax, Umax, C / 4, ldo, coff);
     WESUP_CHECK_LAUNCH();
     return WESUP_OK;
 }

@@ -345,7 +345,7 @@ class WesupEngine:
     def _commuted(self, b, l):
         """Layer l's side conv behind the pooling instead of in front of it (see commute_side)."""
         return (self.commute_side and self.fuse_pool_fwd and self.fuse_pool_bwd
-                and ((b.group_of[l] is not None and self.commute_side_deep) or (b.group_of[l] is None and CONV_CH[l][1] <= 256)))
+                and ((b.group_of[l] is not None and self.commute_side_deep) or b.group_of[l] is None))
 
     def release_buffers(self):
         self._bufs.clear()
