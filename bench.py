@@ -219,6 +219,12 @@ def worker(args):
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: the launcher and the flag disagree')
     if args.stub_trainer:
         return stub_worker(args, rank, world)
+    # stdout carries ONE line, the JSON of rank 0: whatever a library prints there while the step runs (RCCL announces its
+    # version on stdout when the first communicator is created) goes to stderr instead -- at the descriptor level, native
+    # writers included -- and the line is written after the descriptor is back
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
 
     import numpy as np  # noqa: F401
     import torch
@@ -604,9 +610,13 @@ def worker(args):
                                            '(dense sp_maps, incremental cat, dense mm; models/wesup.py:18-63,246-304,492-531 '
                                            "+ backward); 'label_map' = the scatter-mean restatement of the same step",
                                    'variants': variants}
-        print(json.dumps(out), flush=True)
     if use_dist:
         dist.destroy_process_group()
+    sys.stdout.flush()
+    os.dup2(real_stdout, 1)
+    os.close(real_stdout)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
 
 
 def main(argv=None):
