@@ -537,6 +537,13 @@ def test_winograd_dual_transform_and_weight_gradient_from_it(ops, B, H, W, Cin, 
     w = rnd(Cout, Cin, 3, 3, seed=3, scale=(2.0 / (9 * Cin)) ** 0.5)
     _, ud = ops.winograd_pack_weight(w.to(d), need_fwd=False, m=4)
     assert torch.equal(ops.conv3x3_dgrad_winograd(dy, ud, m=4), ops.conv3x3_dgrad_winograd(dy, ud, m=4, v_pre=V))
+    # ... also through a max-pool backward (one-kernel route or batched products + unpooling output transform)
+    ypre = rnd(B, 2 * H, 2 * W, Cin, seed=4).to(d)
+    base = rnd(B, 2 * H, 2 * W, Cin, seed=5).to(d)
+    a, b_ = base.clone(), base.clone()
+    ops.conv3x3_dgrad_winograd_unpool(dy, ud, ypre, a)
+    ops.conv3x3_dgrad_winograd_unpool(dy, ud, ypre, b_, v_pre=V)
+    assert torch.equal(a, b_)
 
 
 def _pool_codes(y):

@@ -887,11 +887,10 @@ class WesupEngine:
             if g_ready[l] is not None:
                 main.wait_event(g_ready[l])
             x_in, relu_x = b.x_in[l], b.x_relu[l]      # what the forward of this layer read
-            # one pass over G_l for both consumers (F(4x4) input gradient and weight gradient; the input gradient through a
-            # max-pool backward needs the one-kernel product route to take a transformed input)
+            # one pass over G_l for both consumers (F(4x4) input gradient and weight gradient)
             dual = (self.dual_transform and b.wino_fwd[l] == 4 and l > lowest and trainable[l] and self.wgrad_winograd
                     and b.V[l] is not None and 'wgrad' not in self._diag_skip and ops.winograd_bias_rows(B, h, w, co) > 0
-                    and not (POOL_AFTER[l - 1] and not (self.fuse_unpool and ops.winograd_fused_supported(co, ci, 4) == 2)))
+                    and not (POOL_AFTER[l - 1] and not self.fuse_unpool))
             v_dy = None
             if dual:
                 Tl = ops.winograd_tiles(B, h, w, 4)

@@ -590,7 +590,7 @@ def conv3x3_dgrad_winograd_unpool(dy, u_dgrad, unpool_src, unpool_dst, ws_tag='d
     _, Hu, Wu, _ = unpool_dst.shape
     assert unpool_dst.shape == (B, Hu, Wu, Cin) and (Hu // 2, Wu // 2) == (H, W)
     lib = _lib.load()
-    if unpool_code is not None or v_pre is not None:
+    if unpool_code is not None or (v_pre is not None and lib.wesup_winograd_fused_supported(Cout, Cin, m) == 2):
         # the pooling's decisions as codes (conv3x3_fwd_winograd(pool_code_out=...)): no read of unpool_src; and / or the input
         # transform of dy done already (winograd_dual_transform).  One-kernel product route only.
         if unpool_code is not None:
@@ -624,18 +624,26 @@ def conv3x3_dgrad_winograd_unpool(dy, u_dgrad, unpool_src, unpool_dst, ws_tag='d
     if not nb:
         raise _lib.WesupHipError(f'winograd dgrad: unsupported shape {(B, H, W, Cout, Cin, m)}')
     ws = workspace(nb, dy.device, ws_tag)
-    if timer is None:
+    if timer is None and v_pre is None:
         _lib.call('wesup_conv3x3_dgrad_winograd_unpool', _p(dy), _p(u_dgrad), _p(unpool_src), _p(unpool_dst), B, H, W, Hu, Wu,
                   Cin, Cout, m, _p(ws), nb, _stream())
         return unpool_dst
     # the three passes bracketed as classes of their own, as in _winograd_conv
+    class _NoTimer:
+        def begin(self, tag): return None
+        def end(self, tok, work): pass
+    timer = timer or _NoTimer()
     T, P = winograd_tiles(B, H, W, m), winograd_positions(m)
     v_bytes = (P * T * Cout * 4 + 255) // 256 * 256
     V, Mt = ws[:v_bytes], ws[v_bytes:]
     st = _stream()
-    tok = timer.begin('winograd_transform')
-    _lib.call('wesup_winograd_input_transform', _p(dy), _p(V), 0, B, H, W, Cout, 0, m, st)
-    timer.end(tok, 4.0 * (B * H * W + P * T) * Cout)
+    if v_pre is not None:      # dy's input transform, done already (winograd_dual_transform)
+        _chk(v_pre, name='v_pre'); assert v_pre.shape == (P, T, Cout)
+        V = v_pre
+    else:
+        tok = timer.begin('winograd_transform')
+        _lib.call('wesup_winograd_input_transform', _p(dy), _p(V), 0, B, H, W, Cout, 0, m, st)
+        timer.end(tok, 4.0 * (B * H * W + P * T) * Cout)
     if lib.wesup_winograd_fused_supported(Cout, Cin, m) == 2:
         tok = timer.begin('winograd_gemm')
         _lib.call('wesup_winograd_gemm_output_transform', _p(V), 0, _p(u_dgrad), None, None, None, None, 0, _p(unpool_src),
