@@ -70,7 +70,8 @@ def parse_args(argv=None):
     ap.add_argument('--commute-deep', action='store_true', help='A/B: the deep layers (matrix pooling) commuted as well (measured, not kept)')
     ap.add_argument('--batched-side', action='store_true', help='A/B: the side convs of the layers that share a deep resolution in one batched launch (measured, not kept)')
     ap.add_argument('--diag-skip', default='', help="TIMING-ONLY diagnostic (results are wrong): comma list of launch classes left out "
-                                                    "of the step -- 'wgrad' (conv weight gradients), 'side_wgrad' -- to see what they cost the step")
+                                                    "of the step after the warm-up (learning rate 0 from there on) -- 'wgrad' (conv weight gradients), 'side_wgrad', "
+                                                    "'side_fwd_shallow' (pooling + side conv of conv1_1 .. conv3_3), 'side_fwd_deep' -- to see what they cost the step")
     ap.add_argument('--head-streamk', action='store_true', help='A/B: the MLP head GEMMs with the stream-K tail (default: plain tiling)')
     ap.add_argument('--subbatch-mb', type=int, default=-1, help='A/B: fused Winograd layers whose transformed input exceeds this many '
                                                                 'MB run image group by image group (0: whole batch; default: ops.py)')
@@ -276,7 +277,6 @@ def worker(args):
     trainer.model.engine.gather_side_grad = not args.no_gather_epilogue
     trainer.model.engine.compact_masks = not args.float_masks
     trainer.model.engine.dual_transform = not args.no_dual_transform
-    trainer.model.engine._diag_skip = set(filter(None, args.diag_skip.split(',')))
     trainer.model.engine.conv_winograd = not args.direct_conv
     if args.winograd_min_ci:
         type(trainer.model.engine).WINOGRAD_CONV_MIN_CI = args.winograd_min_ci
@@ -313,6 +313,10 @@ def worker(args):
 
     for i in range(args.warmup):
         step(i)
+    if args.diag_skip:            # TIMING-ONLY: classes of launches left out from here on (buffers keep the warm-up's values)
+        trainer.model.engine._diag_skip = set(filter(None, args.diag_skip.split(',')))
+        for gr in trainer.optimizer.param_groups:
+            gr['lr'] = 0.0
     timer = trainer.model.engine.timer
     from wesup_amd import ops as _ops_t
     _ops_t.set_timer(timer)                           # sp_preprocess / propagate / paint / sgd launch outside the engine

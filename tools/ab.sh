@@ -1,3 +1,4 @@
+# A/B of two bench.py flag sets in alternating runs on one box:  bash tools/ab.sh "" "--no-dual-transform"
 A="$1"; Bf="$2"
 for i in 1 2 3; do
 for f in "$A" "$Bf"; do

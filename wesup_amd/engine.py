@@ -535,7 +535,9 @@ class WesupEngine:
             with self._OnSide(self):
                 grp = b.groups[b.group_of[l]] if b.group_of[l] is not None else None
                 batched = grp is not None and grp.same_co and self.batch_side_convs
-                if commute:
+                if ('side_fwd_shallow' in self._diag_skip and grp is None) or ('side_fwd_deep' in self._diag_skip and grp is not None):
+                    pass                     # timing-only diagnostic: sp_in keeps an earlier step's slice
+                elif commute:
                     if b.ybar[l] is None:
                         b.ybar[l] = torch.empty(B, Kmax, co, dtype=torch.float32, device=self.device)
                     if grp is not None:      # coarse resolution: Ybar = Wm . y, one GEMM per image
@@ -568,7 +570,7 @@ class WesupEngine:
                     tok = T.begin('side_fwd')
                     ops.gemm_nt(b.y[l].view(B * h * w, co), ws, p[f'side_conv{off}.bias'], out=s2d)
                     T.end(tok, 2.0 * B * h * w * co * (co // 2))
-                if commute:
+                if commute or ('side_fwd_deep' in self._diag_skip and grp is not None):
                     pass
                 elif b.group_of[l] is not None:
                     g = b.groups[b.group_of[l]]
