@@ -166,6 +166,8 @@ class WesupEngine:
         # gradient -- in one pass over it on the main stream (ops.winograd_dual_transform): the gradient is read once instead of
         # once per stream and twelve launches go
         self.dual_transform = True
+        # forward: the side-branch work of layer l queued behind the input transform of layer l + 1 instead of beside it
+        self.defer_side_fwd = True
         self.batch_side_convs = False    # A/B: side convs (and their input gradients) of the layers that share a deep resolution in one launch
         self.head_streamk = False
         self._diag_skip = set()          # TIMING-ONLY diagnostics (bench.py --diag-skip): classes of launches left out, results wrong
@@ -462,6 +464,7 @@ class WesupEngine:
                     for i in range(B):
                         ops.transpose(g.Wm[i], g.WmT[i])
                 T.end(tok, 0.0)
+        pending_side = None              # the side-branch work of the previous layer, when it is queued behind this layer's transform
         cur, cur_relu = b.x0, False      # the layer's input tensor, and whether its ReLU is still to be applied on load
         b.x_in, b.x_relu = [None] * 13, [False] * 13
         b.wino_fwd = list(self._route)
@@ -521,18 +524,23 @@ class WesupEngine:
                 # timed as 'winograd_gemm' (executed MFMA FLOPs: 4/9 resp. 1/4 of the direct form's) + 'winograd_transform'
                 # (bytes).  (An m x m output tile holds whole windows of the max-pool behind conv2_2 / conv3_3 / conv4_3: the
                 # output transform writes the pooled tensor too and the max-pool launch below is skipped)
+                after, pending_side = pending_side, None
                 ops.conv3x3_fwd_winograd(cur, pk.uf[l], p[f'backbone.{idx}.bias'], relu_in=cur_relu, out=b.y[l],
                                          out_relu=yr, v_keep=b.V[l] if train else None, ws_tag='wino_main', timer=T,
                                          out_pool=b.yp[l] if POOL_AFTER[l] else None, pool_relu=b.relu_stored, m=m,
-                                         relu_bits_out=bits_out, pool_code_out=code_out)
+                                         relu_bits_out=bits_out, pool_code_out=code_out, after_transform=after)
             else:
+                if pending_side is not None:
+                    pending_side()
+                    pending_side = None
                 tok = T.begin('conv3x3_fwd')
                 ops.conv3x3_fwd(cur, pk.wf[l], p[f'backbone.{idx}.bias'], co, relu_in=cur_relu, out=b.y[l], out_relu=yr,
                                 side=(ws, p[f'side_conv{off}.bias'], s2d) if side_in_conv else None)
                 T.end(tok, 2.0 * B * h * w * co * ((3 if l == 0 else ci) * 9 + (co // 2 if side_in_conv else 0)))
             # side branch of this layer: 1x1 conv on the pre-ReLU tap, then either the fused upsample+scatter-mean
             # straight into the superpixel feature slice, or upsample into fm's channel slice
-            with self._OnSide(self):
+            def side_work(l=l, ci=ci, co=co, h=h, w=w, off=off, ws=ws, commute=commute, s_l=s_l, s2d=s2d, side_in_conv=side_in_conv):
+              with self._OnSide(self):
                 grp = b.groups[b.group_of[l]] if b.group_of[l] is not None else None
                 batched = grp is not None and grp.same_co and self.batch_side_convs
                 if ('side_fwd_shallow' in self._diag_skip and grp is None) or ('side_fwd_deep' in self._diag_skip and grp is not None):
@@ -587,6 +595,13 @@ class WesupEngine:
                     tok = T.begin('upsample_fwd')
                     ops.upsample_fwd(s_l, b.fm, off)
                     T.end(tok, 4.0 * B * H * W * (co // 2))
+            # Queued now, the memory-bound pooling of y_l would run beside the equally memory-bound input transform of layer
+            # l + 1 (both read y_l); deferred until that transform has been queued (ops: after_transform), it runs beside the
+            # layer's products instead -- a memory-bound kernel next to an MFMA-bound one.
+            if self.defer_side_fwd and self.two_streams and l < 12 and self._wino(l + 1):
+                pending_side = side_work
+            else:
+                side_work()
             if POOL_AFTER[l]:
                 if not self._wino(l):
                     ops.maxpool2_fwd(b.y[l], b.yp[l], relu=b.relu_stored)

@@ -414,7 +414,8 @@ def _aux_stream(device):
 
 
 def _winograd_conv(inp, u, bias, mask_src, out, out_relu, v_keep, relu_in, accumulate, ws_tag, timer, out_pool=None,
-                   pool_relu=False, m=2, relu_bits_out=None, pool_code_out=None, mask_bits=None, v_ready=False):
+                   pool_relu=False, m=2, relu_bits_out=None, pool_code_out=None, mask_bits=None, v_ready=False,
+                   after_transform=None):
     """The three passes of a Winograd-domain conv (input transform, 16 batched NT GEMMs, output transform + epilogue).
     timer (optional, engine.KernelTimer-like): the GEMM and the two transforms are bracketed as classes of their own.
 
@@ -436,9 +437,16 @@ def _winograd_conv(inp, u, bias, mask_src, out, out_relu, v_keep, relu_in, accum
     Mt = ws[v_bytes:]
     n_io = 1 + (out_relu is not None) + (mask_src is not None) + bool(accumulate)
 
+    hook = [after_transform]      # called once, when the (first) input transform has been queued
+
     def t_in(b0, nb_, st):
-        if v_ready:        # v_keep holds the transformed input already (winograd_dual_transform)
-            return
+        if not v_ready:
+            _t_in(b0, nb_, st)
+        if hook[0] is not None:
+            hook[0]()
+            hook[0] = None
+
+    def _t_in(b0, nb_, st):
         tok = timer.begin('winograd_transform') if timer else None
         t0 = winograd_tiles(b0, H, W, m)
         if relu_bits_out is not None:      # the sign bits of the input ride along (the ReLU mask of the layer below, for its backward)
@@ -534,7 +542,7 @@ def _winograd_conv(inp, u, bias, mask_src, out, out_relu, v_keep, relu_in, accum
 
 
 def conv3x3_fwd_winograd(x, u_fwd, bias, relu_in, out=None, out_relu=None, v_keep=None, ws_tag='default', timer=None,
-                         out_pool=None, pool_relu=False, m=2, relu_bits_out=None, pool_code_out=None):
+                         out_pool=None, pool_relu=False, m=2, relu_bits_out=None, pool_code_out=None, after_transform=None):
     """conv3x3_fwd through the Winograd F(m x m, 3x3) domain (deep layers); v_keep (P, tiles, Cin) receives the transformed
     input; out_pool (B, H//2, W//2, Cout) the 2x2 max-pool of the output (ReLU'd if pool_relu), written by the output
     transform."""
@@ -556,7 +564,7 @@ def conv3x3_fwd_winograd(x, u_fwd, bias, relu_in, out=None, out_relu=None, v_kee
     # relu_bits_out (B,H,W,Cin/4) uint8: the sign bits of x; pool_code_out (B,H/2,W/2,Cout/4) int16: the pooling's decisions
     # (include/wesup_hip.h: wesup_winograd_input_transform_bits, wesup_winograd_gemm_output_transform_ex)
     return _winograd_conv(x, u_fwd, bias, None, out, out_relu, v_keep, relu_in, False, ws_tag, timer, out_pool, pool_relu, m,
-                          relu_bits_out=relu_bits_out, pool_code_out=pool_code_out)
+                          relu_bits_out=relu_bits_out, pool_code_out=pool_code_out, after_transform=after_transform)
 
 
 def conv3x3_dgrad_winograd(dy, u_dgrad, mask_src=None, out=None, accumulate=False, ws_tag='default', timer=None, m=2,
