@@ -24,7 +24,6 @@ few large RCCL calls launched while the rest of backward still runs.
 """
 from collections import OrderedDict
 
-import os
 import torch
 
 from . import ops
