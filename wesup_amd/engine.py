@@ -169,6 +169,9 @@ class WesupEngine:
         # forward: the side-branch work of layer l queued behind the input transform of layer l + 1 instead of beside it
         self.defer_side_fwd = True
         self.wgrad_behind_dgrad = True   # backward: a layer's weight gradient queued behind its input gradient (see backward())
+        # ... except for this many layers above the lowest trainable one: nothing runs behind the last input gradient, so conv1_2's
+        # weight gradient goes in front of it again (9.11 -> 9.03 ms; two layers: the same)
+        self.wgrad_early_layers = 1
         self.batch_side_convs = False    # A/B: side convs (and their input gradients) of the layers that share a deep resolution in one launch
         self.head_streamk = False
         self._diag_skip = set()          # TIMING-ONLY diagnostics (bench.py --diag-skip): classes of launches left out, results wrong
@@ -947,7 +950,7 @@ class WesupEngine:
             # With its operands ready (dual transform) a weight gradient can start any time.  Queued behind the layer's input
             # gradient instead of in front of it, its TN products run beside the NEXT layer's (memory-bound) transform rather
             # than beside this layer's products: 9.35 -> 9.20 ms.
-            late_wgrad = self.wgrad_behind_dgrad and wg is not None and dual and l > lowest
+            late_wgrad = self.wgrad_behind_dgrad and wg is not None and dual and l > lowest + self.wgrad_early_layers
             if not trainable[l] or 'wgrad' in self._diag_skip:
                 pass
             elif late_wgrad:
