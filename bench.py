@@ -441,6 +441,7 @@ def worker(args):
                         kern[tag]['alone_ms_per_step'] = round(ms / 2, 4)
                         if 'gbs' in kern[tag] and work > 0:
                             kern[tag]['alone_gbs'] = round(work / (ms * 1e-3) / 1e9, 1)
+            kern['_event_pairs_replaced'] = timer.replaced      # KernelTimer.collect: impossible durations (timestamp glitches)
             kern['_note'] = ('propagate = wesup_propagate (label propagation); sp_preprocess = wesup_sp_preprocess + '
                              'wesup_sp_segments (histograms, reference ordering, counting sort, segment table); paint = '
                              'wesup_paint_fwd; sgd = wesup_sgd_step (20 B per parameter).  gbs = algorithmic bytes / event time')
