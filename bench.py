@@ -81,7 +81,7 @@ def parse_args(argv=None):
     ap.add_argument('--chain-priority', type=int, default=0, help='experiment: run the step on a stream of this priority '
                                                                   '(negative = higher than the side / wgrad streams)')
     ap.add_argument('--event-every', type=int, default=10, help='steps of the timed region that carry HIP events: every n-th')
-    ap.add_argument('--timed-classes', default='conv3x3_fwd,conv3x3_dgrad,winograd_gemm,winograd_transform',
+    ap.add_argument('--timed-classes', default='conv3x3_fwd,conv3x3_dgrad,winograd_gemm',
                     help="kernel classes that get HIP events inside the timed region ('all', 'none' or a comma list); an "
                          "event record fences its queue, so only the dominant kernel is timed there by default and the "
                          "other classes are timed in extra untimed steps")
@@ -350,7 +350,10 @@ def worker(args):
     barrier()
     elapsed = time.perf_counter() - t0
     timer.enabled = False
-    step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+    step_ms_raw = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]
+    if os.environ.get('WESUP_BENCH_STEPS'):
+        print('per-step ms:', ' '.join(f'{v:.2f}' for v in step_ms_raw), file=sys.stderr)
+    step_ms = sorted(step_ms_raw)
     median_ms = step_ms[len(step_ms) // 2] if len(step_ms) % 2 else 0.5 * (step_ms[len(step_ms) // 2 - 1] + step_ms[len(step_ms) // 2])
     ddp_stats = None
     if reducer is not None:
@@ -454,12 +457,18 @@ def worker(args):
             # executes (the Winograd form needs 4/9 of the direct form's) over their event time.
             gemm_tags = ('conv3x3_fwd', 'conv3x3_dgrad', 'winograd_gemm')
             conv_tags = gemm_tags + ('winograd_transform',)
-            if any(t in allk and t not in tot for t in conv_tags):          # a class was left out of --timed-classes
+            if any(t in allk and t not in tot for t in gemm_tags):          # a GEMM class was left out of --timed-classes
                 tot, n_ev = allk, n_extra
             ms_gemm = sum(tot[t][0] for t in gemm_tags if t in tot)
             fl_exec = sum(tot[t][2] for t in gemm_tags if t in tot)
             nl = sum(tot[t][1] for t in gemm_tags if t in tot)
-            ms_all = sum(tot[t][0] for t in conv_tags if t in tot)
+            # the transform launches (effective_direct_form only): from the timed region when --timed-classes names them, else
+            # from the extra steps (events around them as well cost the event-carrying steps another 0.5 ms each)
+            if 'winograd_transform' in tot:
+                ms_tr = tot['winograd_transform'][0]
+            else:
+                ms_tr = allk.get('winograd_transform', (0.0, 0, 0.0))[0] / n_extra * n_ev
+            ms_all = ms_gemm + ms_tr
             fl_alg, hh, ww = 0.0, H, W
             for l, (ci, co) in enumerate(((3, 64), (64, 64), (64, 128), (128, 128), (128, 256), (256, 256), (256, 256),
                                           (256, 512), (512, 512), (512, 512), (512, 512), (512, 512), (512, 512))):
