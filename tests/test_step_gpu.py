@@ -211,6 +211,39 @@ def test_batched_step_matches_oracle():
         assert torch.equal(results[0][1][k], results[1][1][k]), k
 
 
+@pytest.mark.parametrize('B,H,W,g', [(3, 52, 44, 4), (2, 70, 38, 5), (1, 129, 97, 6)])
+def test_round3_schedule_and_fusions_against_the_plain_order(B, H, W, g):
+    """One training step on an odd, batched shape with every round-3 switch at its default (side conv behind the pooling, gathered
+    side gradients, dual transform, compact masks, deferred side work, weight gradients behind the input gradients) against the
+    same step with all of them off (the reference's order of operations, one launch per pass): the loss to 1e-6, every parameter
+    gradient to 2e-5 of its tensor's maximum -- the switches reorder sums and launches, nothing else."""
+    from oracle import wesup_oracle as orc
+    from wesup_amd import synth
+    d = torch.device('cuda:0')
+    imgs, labs, pts, pix = synth.make_batch(31, B, H, W, g)
+    data = (torch.from_numpy(imgs).to(d), torch.from_numpy(pix).long().to(d), torch.from_numpy(pts).long().to(d),
+            torch.from_numpy(labs).to(d))
+    weights = orc.make_weights(3, feat_scale=0.03)
+    res = []
+    for plain in (False, True):
+        tr = make_trainer(weights)
+        tr.tracker.train()
+        tr.model._ensure_engine()
+        e = tr.model.engine
+        if plain:
+            e.commute_side = e.gather_side_grad = e.dual_transform = e.compact_masks = False
+            e.defer_side_fwd = e.wgrad_behind_dgrad = False
+        tr.train_one_iteration('train', *data)
+        torch.cuda.synchronize()
+        res.append((tr.tracker.history['loss'][0], {k: v.detach().clone() for k, v in tr.model._grad_views.items()},
+                    tr.model.sp_features if tr.model.sp_features is not None else None))
+    (l0, g0, _), (l1, g1, _) = res
+    assert abs(l0 - l1) <= 1e-6 * abs(l1)
+    for k in g1:
+        scale = float(g1[k].abs().max())
+        assert float((g0[k] - g1[k]).abs().max()) <= 2e-5 * scale + 1e-12, k
+
+
 def test_gradients_at_fp32_noise_level(golden_dir):
     """Every parameter gradient of the HIP step vs an fp64 evaluation of the oracle: within 1e-4 of the
     tensor's max magnitude, and no worse than a small multiple of the error torch's own fp32 CPU path makes."""
