@@ -324,12 +324,19 @@ class WESUP(nn.Module):
         r = super()._apply(fn, *a, **k)
         self._flat = None          # parameters were re-created: rebuild flat storage lazily
         self.engine = None
+        self._named = None
         return r
 
     def _ensure_engine(self):
+        # (the Parameter objects are fixed once they are views of the flat buffer: their (name, parameter) list is kept -- walking
+        # the module tree for it costs 0.1 ms, and the step asked for it five times)
+        named = getattr(self, '_named', None)
+        if named and self.engine is not None and self._flat is not None and self._flat.device == named[0][1].device:
+            return
         params = dict(self.named_parameters())
         dev = next(iter(params.values())).device
         if self.engine is not None and self._flat is not None and self._flat.device == dev:
+            self._named = list(params.items())
             return
         if dev.type != 'cuda':
             raise RuntimeError('WESUP runs on the HIP kernels only: move the model to a GPU (no CPU fallback)')
@@ -348,12 +355,13 @@ class WESUP(nn.Module):
                 pv[name] = p.data
                 gv[name] = gflat[o:o + n].view(p.shape)
         self._flat, self._flat_grad, self._offs = flat, gflat, offs
+        self._named = list(params.items())
         self._grad_views = gv
         self._anchor = torch.zeros(1, device=dev, requires_grad=True)
         self.engine = WesupEngine(pv, gv, D=self.D)
 
     def _publish_grads(self):
-        for name, p in self.named_parameters():
+        for name, p in self._named:
             if not p.requires_grad:
                 continue
             gv = self._grad_views[name]
@@ -394,7 +402,7 @@ class WESUP(nn.Module):
         self.fm_size = (img.size(2), img.size(3))
         # parameters with requires_grad=False (freeze_backbone, models/wesup.py:427-429): the engine skips the frozen
         # backbone layers' wgrad and every dgrad below the lowest trainable one
-        self.engine.frozen = {n for n, p in self.named_parameters() if not p.requires_grad}
+        self.engine.frozen = {n for n, p in self._named if not p.requires_grad}
         feats, sp_pred, pred = _WesupFn.apply(self._anchor, self, img, meta)
         self._last_meta = meta
         self._padded = (feats, sp_pred)        # (B,Kmax,D), (B,Kmax,2): what the batched loss consumes

@@ -40,7 +40,7 @@ class FusedSGD(torch.optim.SGD):
         step() called twice) is skipped, not updated with whatever the flat gradient buffer still holds."""
         m = self.model
         ranges = []
-        for (name, p), has in zip(m.named_parameters(), with_grad):
+        for (name, p), has in zip(m._named, with_grad):
             if not has:
                 continue
             lo, hi = m._offs[name], m._offs[name] + (p.numel() + 63) // 64 * 64
@@ -56,10 +56,11 @@ class FusedSGD(torch.optim.SGD):
         self._sync_state_in()
         g = self.param_groups[0]
         lr, mu, wd = g['lr'], g['momentum'], g['weight_decay']
-        for name, p in m.named_parameters():          # a gradient that is not the flat view (set by hand): adopt it
+        m._ensure_engine()
+        for name, p in m._named:                      # a gradient that is not the flat view (set by hand): adopt it
             if p.requires_grad and p.grad is not None and p.grad.data_ptr() != m._grad_views[name].data_ptr():
                 m._grad_views[name].copy_(p.grad)
-        sig = tuple(p.requires_grad and p.grad is not None for p in m.parameters())
+        sig = tuple(p.requires_grad and p.grad is not None for _, p in m._named)
         if getattr(self, '_ranges_sig', None) != sig:
             self._ranges, self._ranges_sig = self._trainable_ranges(sig), sig
         for lo, hi in self._ranges:                   # one launch per contiguous trainable range
