@@ -216,15 +216,31 @@ class WesupEngine:
             e = self.eng
             if not e.two_streams:
                 return None
+            self.prev = torch.cuda.current_stream()
             if self.wait_main:
-                e._side().wait_stream(torch.cuda.current_stream())
-            self.cm = torch.cuda.stream(e._side())
-            self.cm.__enter__()
+                e._side().wait_stream(self.prev)
+            torch.cuda.set_stream(e._side())      # (torch.cuda.stream() as a context costs 10 us a time: ~40 times per step)
             return None
 
         def __exit__(self, *a):
             if self.eng.two_streams:
-                self.cm.__exit__(*a)
+                torch.cuda.set_stream(self.prev)
+            return False
+
+    class _On:
+        """`with torch.cuda.stream(s)` without its device bookkeeping: s becomes torch's current stream, the previous one comes back."""
+        __slots__ = ('s', 'prev')
+
+        def __init__(self, s):
+            self.s = s
+
+        def __enter__(self):
+            self.prev = torch.cuda.current_stream()
+            torch.cuda.set_stream(self.s)
+            return self.s
+
+        def __exit__(self, *a):
+            torch.cuda.set_stream(self.prev)
             return False
 
     def _join_side(self):
@@ -711,7 +727,7 @@ class WesupEngine:
         if off_chain:
             wgs = self._wg()
             wgs.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(wgs):
+            with self._On(wgs):
                 tok = T.begin('mlp_wgrad')
                 ops.gemm_tn(b.dfeat, b.h2, out=g['fc_layers.4.weight'], colsum=g['fc_layers.4.bias'], ws_tag='wgrad')
                 ops.gemm_tn(b.dh2, b.h1, out=g['fc_layers.2.weight'], colsum=g['fc_layers.2.bias'], ws_tag='wgrad')
@@ -793,7 +809,7 @@ class WesupEngine:
             # them and costs 1.2 ms per step, which is what a live process group did to the 4-stream schedule.)
             aux = self._wg()
             aux.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(aux):
+            with self._On(aux):
                 for ls in commuted_runs():
                     commuted_G(ls)
                     ev = torch.cuda.Event()
@@ -970,7 +986,7 @@ class WesupEngine:
                 pass
             elif wg is not None:
                 wg.wait_stream(main)                       # G_l is final here
-                with torch.cuda.stream(wg):
+                with self._On(wg):
                     wgrad('wgrad')
             else:
                 wgrad('default')
@@ -1011,7 +1027,7 @@ class WesupEngine:
                     ops.maxpool2_bwd(b.y[l - 1], b.dxp[l - 1], b.G[l - 1], accumulate=True)
                 if late_wgrad and trainable[l] and 'wgrad' not in self._diag_skip:
                     wg.wait_stream(main)
-                    with torch.cuda.stream(wg):
+                    with self._On(wg):
                         wgrad('wgrad')
         if wg is not None:
             main.wait_stream(wg)
