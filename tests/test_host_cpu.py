@@ -167,3 +167,25 @@ def test_default_route_of_the_conv_layers():
         assert [default_route(ci, co, 60, 60, 4) for ci, co in CONV_CH] == [0, 0, 0] + [2] * 10
     finally:
         WesupEngine.WINOGRAD_CONV_MIN_CI, WesupEngine.WINOGRAD_TILE = old
+
+
+def test_kernel_timer_replaces_an_impossible_pair():
+    """engine.KernelTimer.collect: a pair whose duration is off by tens of milliseconds (a timestamp glitch seen about once per
+    thousand pairs on the GPU) is replaced by its class's median and counted; ordinary spread is left alone."""
+    from wesup_amd.engine import KernelTimer
+
+    class _Ev:
+        def __init__(self, t): self.t = t
+        def elapsed_time(self, other): return other.t - self.t
+
+    T = KernelTimer()
+    times = [0.010, 0.012, 0.011, 65.0, 0.013, 0.009]                 # ms; the fourth is the glitch
+    T.pending = [('side_bwd', _Ev(0.0), _Ev(t), 1.0) for t in times]
+    T.pending += [('winograd_gemm', _Ev(0.0), _Ev(t), 2.0) for t in (0.20, 0.25, 6.0)]       # 6 ms is 24x the median: kept
+    tot = T.collect()
+    assert T.replaced == 1
+    ms, n, work = tot['side_bwd']
+    assert n == 6 and work == 6.0 and abs(ms - (0.010 + 0.012 + 0.011 + 0.012 + 0.013 + 0.009)) < 1e-9      # (upper median of the six: 0.012)
+    ms, n, work = tot['winograd_gemm']
+    assert n == 3 and abs(ms - 6.45) < 1e-9
+    assert T.pending == [] and len(T._free) == 18
