@@ -5,6 +5,7 @@ kernel entry fails, this module raises.  ``build()`` compiles it with hipcc for
 gfx950 (cross-compiles without a GPU).
 """
 import ctypes
+import functools
 import os
 import subprocess
 
@@ -151,6 +152,13 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the symbol is missing: fail loudly
         fn.restype = res
         fn.argtypes = [_T[a] for a in args]
+    # pure size / shape queries (integers in, an integer out): answered from a cache after the first call -- a training step asks
+    # ~150 of them, the same ones every step
+    for name in _SIGS:
+        if name.endswith('_bytes') or name in ('wesup_winograd_tiles', 'wesup_winograd_fused_supported', 'wesup_winograd_bias_rows',
+                                               'wesup_conv3x3_kpad', 'wesup_sp_max_units'):
+            if all(a in 'il' for a in _SIGS[name][1]):
+                setattr(lib, name, functools.lru_cache(maxsize=4096)(getattr(lib, name)))
     if lib.wesup_abi_version() != ABI_VERSION:
         raise WesupHipError(f'{LIB_PATH} has ABI version {lib.wesup_abi_version()}, this package binds version '
                             f'{ABI_VERSION}: rebuild it (make -C wesup_amd/csrc)')
