@@ -456,7 +456,6 @@ def worker(args):
             # transforms).  `mfma_executed` is the matrix-core view of the GEMM launches alone: the FLOPs the MFMA pipe
             # executes (the Winograd form needs 4/9 of the direct form's) over their event time.
             gemm_tags = ('conv3x3_fwd', 'conv3x3_dgrad', 'winograd_gemm')
-            conv_tags = gemm_tags + ('winograd_transform',)
             if any(t in allk and t not in tot for t in gemm_tags):          # a GEMM class was left out of --timed-classes
                 tot, n_ev = allk, n_extra
             ms_gemm = sum(tot[t][0] for t in gemm_tags if t in tot)

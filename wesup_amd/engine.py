@@ -275,7 +275,6 @@ class WesupEngine:
             for l, (ci, co) in enumerate(CONV_CH):
                 b.dims.append((h, w))
                 b.y.append(torch.empty(B, h, w, co, **f32))
-                full = (h, w) == (H, W)
                 b.s.append(None)         # side outputs: views of the group buffers below, or allocated on first use (_side_out)
                 # the ReLU'd copy the next conv (forward and wgrad) reads: the pooled tensor where the layer is pooled
                 # (stored ReLU'd), a second output of the conv kernel elsewhere; the last layer has no reader
