@@ -269,7 +269,7 @@ class WesupEngine:
         if b is None:
             b = _Bufs()
             b.x0 = torch.empty(B, H, W, 4, **f32)
-            b.y, b.yp, b.s, b.dims, b.yr = [], [], [], [], []
+            b.y, b.yp, b.s, b.dims, b.yr, b.yr_wanted = [], [], [], [], [], []
             b.V = [None] * 13            # Winograd-transformed layer inputs (training forward), allocated on first use
             h, w = H, W
             for l, (ci, co) in enumerate(CONV_CH):
@@ -278,7 +278,8 @@ class WesupEngine:
                 b.s.append(None)         # side outputs: views of the group buffers below, or allocated on first use (_side_out)
                 # the ReLU'd copy the next conv (forward and wgrad) reads: the pooled tensor where the layer is pooled
                 # (stored ReLU'd), a second output of the conv kernel elsewhere; the last layer has no reader
-                b.yr.append(torch.empty(B, h, w, co, **f32) if (self.relu_on_store and not POOL_AFTER[l] and l < 12) else None)
+                b.yr.append(None)        # allocated on first use (forward): a Winograd-domain consumer never needs it
+                b.yr_wanted.append(bool(self.relu_on_store and not POOL_AFTER[l] and l < 12))
                 if POOL_AFTER[l]:
                     h, w = h // 2, w // 2
                     b.yp.append(torch.empty(B, h, w, co, **f32))
@@ -500,7 +501,7 @@ class WesupEngine:
         cur, cur_relu = b.x0, False      # the layer's input tensor, and whether its ReLU is still to be applied on load
         b.x_in, b.x_relu = [None] * 13, [False] * 13
         b.wino_fwd = list(self._route)
-        b.relu_stored = self.relu_on_store and all(b.yr[l] is not None for l in range(12) if not POOL_AFTER[l])
+        b.relu_stored = self.relu_on_store and all(b.yr_wanted[l] for l in range(12) if not POOL_AFTER[l])
         fused = self.fuse_pool_fwd
         b.fm_valid = not fused
         fm2d = None if fused else b.fm.view(B * H * W, FM_CHANNELS)
@@ -524,9 +525,11 @@ class WesupEngine:
             # The ReLU'd copy of this layer's output exists for the next layer's 9-tap re-reads and its weight gradient.
             # A Winograd-domain consumer reads its input once (input transform) and its weight gradient reads the kept V:
             # then the copy is not written at all and the transform applies the ReLU while loading y.
-            yr = b.yr[l]
-            if yr is not None and l < 12 and self._wino(l + 1) and (self.wgrad_winograd or not train):
-                yr = None
+            yr = None
+            if b.yr_wanted[l] and not (l < 12 and self._wino(l + 1) and (self.wgrad_winograd or not train)):
+                if b.yr[l] is None:
+                    b.yr[l] = torch.empty(B, h, w, co, dtype=torch.float32, device=self.device)
+                yr = b.yr[l]
             m = self._wino(l)
             bits_out = code_out = None
             if l >= 1:
