@@ -10,7 +10,8 @@
 # 4. (480 shape only) the same two MFMA counters over tools/layer_pmc.py -> 13 layers x {fwd, dgrad, wgrad} table, and
 #    tools/layer_table.py (HIP-event times per layer and pass, direct kernels alone);
 # 5. tools/wino_table.py at the shape (direct vs Winograd F(2x2) vs F(4x4) per layer and pass);
-# 6. tools/roofline_inputs.py turns 3+4 into profiles/<tag>_roofline_inputs.json (read by bench.py) and <tag>_layer_mfma.csv.
+# 6. tools/roofline_inputs.py turns 3+4 into profiles/<tag>_roofline_inputs.json (read by bench.py) and <tag>_layer_mfma.csv;
+# 7. tools/step_traffic.py: bytes past L2 per kernel and step from the two traffic passes of 3.
 set -o pipefail
 R=${1:-r03}
 BATCH=${2:-4}; SIZE=${3:-480}; GRID=${4:-24}
@@ -46,6 +47,8 @@ cp profiles/${R}_roofline_inputs.json profiles/${R}_layer_mfma.csv $OUT/ 2>/dev/
 # the bench line itself, last: the counter inputs of this shape and round exist now (its roofline.traffic reads them)
 timeout -k 10 500 python3 bench.py $SHAPE $CPUB > $OUT/bench_line.json 2> $OUT/bench_line.err || { tail -5 $OUT/bench_line.err; exit 1; }
 echo "bench done"
+# traffic past L2 per kernel over a whole step (the same two counter passes, all kernels): profiles/<tag>_step_traffic.txt
+python3 tools/step_traffic.py $OUT/pmc_bench_fetch $OUT/pmc_bench_write 3 > $OUT/step_traffic.txt 2>/dev/null
 # keep the merge-back small: drop the raw counter files
 rm -rf $OUT/pmc_*/
 ls -la $OUT
