@@ -48,7 +48,7 @@ cp profiles/${R}_roofline_inputs.json profiles/${R}_layer_mfma.csv $OUT/ 2>/dev/
 timeout -k 10 500 python3 bench.py $SHAPE $CPUB > $OUT/bench_line.json 2> $OUT/bench_line.err || { tail -5 $OUT/bench_line.err; exit 1; }
 echo "bench done"
 # traffic past L2 per kernel over a whole step (the same two counter passes, all kernels): profiles/<tag>_step_traffic.txt
-python3 tools/step_traffic.py $OUT/pmc_bench_fetch $OUT/pmc_bench_write 3 > $OUT/step_traffic.txt 2>/dev/null
+python3 tools/step_traffic.py $OUT/pmc_bench_fetch $OUT/pmc_bench_write auto > $OUT/step_traffic.txt 2>/dev/null
 # keep the merge-back small: drop the raw counter files
 rm -rf $OUT/pmc_*/
 ls -la $OUT

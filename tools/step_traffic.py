@@ -1,7 +1,7 @@
 """Traffic past L2 of one whole training step, per kernel, from rocprofv3 --pmc passes over bench.py:
   rocprofv3 --pmc FETCH_SIZE --output-format csv -d OUT/f -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing
   rocprofv3 --pmc WRITE_SIZE ... -d OUT/w ...
-  python tools/step_traffic.py OUT/f OUT/w STEPS(=3)
+  python tools/step_traffic.py OUT/f OUT/w STEPS|auto
 bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 (MI355X_MICROARCH.md: gfx950 FETCH_SIZE under-reports wide streaming reads 2x)."""
 import collections, csv, glob, os, re, sys
 
@@ -24,9 +24,15 @@ def read(d, ctr):
 
 f, nf = read(sys.argv[1], 'FETCH_SIZE')
 w, _ = read(sys.argv[2], 'WRITE_SIZE')
-steps = int(sys.argv[3]) if len(sys.argv) > 3 else 3
+# steps: given, or 'auto' = the number of sgd_kernel launches in the run (one per training step)
+steps = int(sys.argv[3]) if len(sys.argv) > 3 and sys.argv[3] != 'auto' else (int(nf.get('sgd_kernel', 0)) or 3)
 rows = sorted(((2 * f[k] + w[k]) * 1024 / steps, k) for k in set(f) | set(w))
+# kernels that are not part of the step (bench.py's roofline leg materialises the feature map once and pools it)
+extra = [r for r in rows if r[1].startswith(('sp_pool_fwd_kernel', 'upsample_fwd_kernel'))]
+rows = [r for r in rows if r not in extra]
 tot = sum(r[0] for r in rows)
-print(f'total {(tot) / 1e9:.2f} GB per step (fetch x2 {sum(f.values()) * 2048 / steps / 1e9:.2f}, write {sum(w.values()) * 1024 / steps / 1e9:.2f})')
+keep = {k for _, k in rows}
+print(f'total {(tot) / 1e9:.2f} GB per step over {steps} steps (fetch x2 {sum(f[k] for k in keep) * 2048 / steps / 1e9:.2f}, '
+      f'write {sum(w[k] for k in keep) * 1024 / steps / 1e9:.2f}); not counted: {", ".join(sorted(k for _, k in extra)) or "-"}')
 for b, k in reversed(rows[-28:]):
     print(f'{b / 1e6:10.1f} MB/step  {nf[k] / steps:6.1f} launches  {k[:110]}')
