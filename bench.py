@@ -70,6 +70,7 @@ def parse_args(argv=None):
     ap.add_argument('--no-defer-side', action='store_true', help='A/B: forward side-branch work of layer l queued as soon as y_l is (beside the input transform of layer l + 1) instead of behind that transform')
     ap.add_argument('--wgrad-first', action='store_true', help='A/B: a layer\'s weight gradient queued in front of its input gradient (as before round 3\'s last day) instead of behind it')
     ap.add_argument('--wgrad-early-layers', type=int, default=-1, help='A/B: the number of lowest layers whose weight gradient stays in front of the input gradient (default: the engine\'s, 1)')
+    ap.add_argument('--deep-side-wgrad-at', type=int, default=-2, help='A/B: conv layer index at which the deep layers\' side-conv weight gradients are queued (-1: at the start of backward; default: the engine\'s, 2)')
     ap.add_argument('--commute-deep', action='store_true', help='A/B: the deep layers (matrix pooling) commuted as well (measured, not kept)')
     ap.add_argument('--batched-side', action='store_true', help='A/B: the side convs of the layers that share a deep resolution in one batched launch (measured, not kept)')
     ap.add_argument('--diag-skip', default='', help="TIMING-ONLY diagnostic (results are wrong): comma list of launch classes left out "
@@ -282,6 +283,8 @@ def worker(args):
     trainer.model.engine.dual_transform = not args.no_dual_transform
     trainer.model.engine.defer_side_fwd = not args.no_defer_side
     trainer.model.engine.wgrad_behind_dgrad = not args.wgrad_first
+    if args.deep_side_wgrad_at >= -1:
+        trainer.model.engine.deep_side_wgrad_at = args.deep_side_wgrad_at if args.deep_side_wgrad_at >= 0 else None
     if args.wgrad_early_layers >= 0:
         trainer.model.engine.wgrad_early_layers = args.wgrad_early_layers
     trainer.model.engine.conv_winograd = not args.direct_conv

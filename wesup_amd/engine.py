@@ -181,6 +181,9 @@ class WesupEngine:
         self.dual_transform = True
         # forward: the side-branch work of layer l queued behind the input transform of layer l + 1 instead of beside it
         self.defer_side_fwd = True
+        # the conv layer at which the deep layers' side-conv weight gradients are queued (None: with the others at the start of
+        # backward): 7 pairs at conv2_1, 9.05 vs 9.14 ms, each pair in its favour; at conv1_2 or conv3_3 it is slower than at the start
+        self.deep_side_wgrad_at = 2
         self.wgrad_behind_dgrad = True   # backward: a layer's weight gradient queued behind its input gradient (see backward())
         # ... except for this many layers above the lowest trainable one: nothing runs behind the last input gradient, so conv1_2's
         # weight gradient goes in front of it again (9.11 -> 9.03 ms; two layers: the same)
@@ -925,9 +928,12 @@ class WesupEngine:
                     side_wgrad(l)
             # The side convs' own weight gradients are parameter gradients nobody waits for before the optimiser, while the
             # dgrad chain waits for every G_l: all the G_l first (13 GEMMs), the weight gradients behind them.
+            late_at = self.deep_side_wgrad_at if (self.two_streams and self.side_wgrad_last) else None
+            late_side = [l for l in range(12, -1, -1) if late_at is not None and b.group_of[l] is not None and late_at > lowest]
             if self.side_wgrad_last:
                 for l in range(12, -1, -1):
-                    side_wgrad(l)
+                    if l not in late_side:
+                        side_wgrad(l)
         # ---- main path, conv5_3 down to conv1_1.  The dgrad chain stays on the caller's stream; each layer's wgrad
         # (which only produces parameter gradients) goes to a third stream so that it fills the tails of the dgrad
         # kernels instead of sitting on the critical path.
@@ -939,6 +945,13 @@ class WesupEngine:
             idx = CONV_IDX[l]
             if g_ready[l] is not None:
                 main.wait_event(g_ready[l])
+            if late_side and l == late_at:
+                # the deep layers' side-conv weight gradients (TN products with K = pixels: MFMA-bound) only now, beside the
+                # memory-bound transforms and 64-channel products of the last layers instead of beside conv5 / conv4
+                with self._OnSide(self):
+                    for ls_ in late_side:
+                        side_wgrad(ls_)
+                late_side = []
             x_in, relu_x = b.x_in[l], b.x_relu[l]      # what the forward of this layer read
             # one pass over G_l for both consumers (F(4x4) input gradient and weight gradient)
             dual = (self.dual_transform and b.wino_fwd[l] == 4 and l > lowest and trainable[l] and self.wgrad_winograd
