@@ -14,6 +14,7 @@
 #include "winograd.hpp"
 #include "ldsdma.hpp"
 #include <cstdlib>
+#include <cstdio>
 #include <type_traits>
 
 struct FusedParams {
@@ -61,15 +62,22 @@ __device__ __forceinline__ f32x4 fma4(float s, f32x4 a, f32x4 b) {
     return r;
 }
 
-__device__ __forceinline__ void glds_wait6() { asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); }
+template <int N>
+__device__ __forceinline__ void glds_wait_n() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <int KC>      // K = 64 * KC channels of the product
-__global__ __launch_bounds__(256, 2) void wino4_gemm_out_kernel(const FusedParams p) {
+// KC: K = 64 * KC channels of the product.  TW: 16-tile groups per block -- 2 (32 tiles, 4 waves, two blocks per CU) or 4 (64 tiles,
+// 8 waves, one block per CU: a filter plane is staged once per 64 tiles instead of once per 32, a third less staging traffic
+// per CU).  RING: stages in the LDS ring (RING - 1 in flight while one is read).
+template <int KC, int TW, int RING>
+__global__ __launch_bounds__(128 * TW, 2) void wino4_gemm_out_kernel(const FusedParams p) {
     constexpr int K = 64 * KC;
     constexpr int S = 36 * KC;                               // stages: (position, 64-channel chunk)
-    constexpr int STG = (32 + 64) * 64;                      // floats per stage: A [32 tiles][64], B [64 channels][64]
+    constexpr int NW = 2 * TW, NT = 64 * NW, TILES = 16 * TW;
+    constexpr int STG = (TILES + 64) * 64;                   // floats per stage: A [TILES tiles][64], B [64 channels][64]
+    constexpr int AQ = 2, BQ = 16 / NW;                      // DMA instructions (1 KiB each) per wave and stage
+    constexpr int INFL = (RING - 2) * (AQ + BQ);             // instructions of the stages behind the one awaited
     constexpr int ES = 8 * 64 + 4;                           // epilogue image: floats per tile (2 rows x 4 columns x 64 channels, padded)
-    extern __shared__ __attribute__((aligned(16))) float smem[];      // ring of 3 stages (72 KB); the epilogue image reuses it
+    extern __shared__ __attribute__((aligned(16))) float smem[];      // ring of RING stages; the epilogue image reuses it
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // Block order.  The channel blocks of one tile set read the same rows of V, the tile sets of one channel block the
     // same filter planes.  The grid is walked XCD by XCD with the channel block fastest: the N / 64 readers of a tile set sit
@@ -86,37 +94,37 @@ __global__ __launch_bounds__(256, 2) void wino4_gemm_out_kernel(const FusedParam
         nb = blockIdx.x / p.tile_blocks;
         tb = blockIdx.x - nb * p.tile_blocks;
     }
-    const int t0 = tb * 32, n0 = nb * 64;
-    const int wa = wave & 1, wb = wave >> 1;                 // this wave: tiles 16 wa .. +15, channels 32 wb .. +31
+    const int t0 = tb * TILES, n0 = nb * 64;
+    const int wa = wave % TW, wb = wave / TW;                // this wave: tiles 16 wa .. +15, channels 32 wb .. +31
     const int l15 = lane & 15, kq = lane >> 4;
 
     // ---- staging roles.  A wave-instruction fills 1 KiB = 4 rows of 64 floats; lane i supplies chunk position i & 15 of
     // row i >> 4 and fetches the logical chunk position ^ (row & 15) (the same involution on the read side).  A stage is
-    // 6 DMA instructions per wave; the ring is three stages deep (a position's 32 MFMAs last ~0.5 us, less than the
-    // latency of a DMA under load: with one stage in flight the kernel waited on every position).
-    const int rows_valid = (int)min((long)32, p.T - t0);
-    unsigned a_vo[2], b_vo[4];
+    // AQ + BQ DMA instructions per wave; the ring is at least three stages deep (a position's 32 MFMAs last ~0.5 us, less
+    // than the latency of a DMA under load: with one stage in flight the kernel waited on every position).
+    const int rows_valid = (int)min((long)TILES, p.T - t0);
+    unsigned a_vo[AQ], b_vo[BQ];
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        const int row = 4 * (2 * wave + q) + (lane >> 4);
+    for (int q = 0; q < AQ; ++q) {
+        const int row = 4 * (AQ * wave + q) + (lane >> 4);
         a_vo[q] = (unsigned)((row * K + 4 * ((lane & 15) ^ (row & 15))) * 4);      // rows >= rows_valid fall behind num_records
     }
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int row = 4 * (4 * wave + q) + (lane >> 4);
+    for (int q = 0; q < BQ; ++q) {
+        const int row = 4 * (BQ * wave + q) + (lane >> 4);
         b_vo[q] = (unsigned)((row * K + 4 * ((lane & 15) ^ (row & 15))) * 4);
     }
     auto stage = [&](int s, int buf) {
         const int pos = s / KC, c = s - pos * KC;
         const i32x4 srdA = make_srd(p.V + (long)pos * p.plane_v + (long)t0 * K, (unsigned)rows_valid * (unsigned)K * 4u);
         const i32x4 srdB = make_srd(p.U + ((long)pos * p.N + n0) * K, 64u * (unsigned)K * 4u);
-        // wave-uniform LDS byte addresses (the DMA takes them through M0): this wave's 2 resp. 4 KiB of the stage
-        const unsigned adst = __builtin_amdgcn_readfirstlane(lds_addr(smem + buf * STG + wave * 2 * 256));
-        const unsigned bdst = __builtin_amdgcn_readfirstlane(lds_addr(smem + buf * STG + 32 * 64 + wave * 4 * 256));
+        // wave-uniform LDS byte addresses (the DMA takes them through M0): this wave's AQ resp. BQ KiB of the stage
+        const unsigned adst = __builtin_amdgcn_readfirstlane(lds_addr(smem + buf * STG + wave * AQ * 256));
+        const unsigned bdst = __builtin_amdgcn_readfirstlane(lds_addr(smem + buf * STG + TILES * 64 + wave * BQ * 256));
 #pragma unroll
-        for (int q = 0; q < 2; ++q) bglds16(a_vo[q], srdA, (unsigned)(c * 256), adst + q * 1024);
+        for (int q = 0; q < AQ; ++q) bglds16(a_vo[q], srdA, (unsigned)(c * 256), adst + q * 1024);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) bglds16(b_vo[q], srdB, (unsigned)(c * 256), bdst + q * 1024);
+        for (int q = 0; q < BQ; ++q) bglds16(b_vo[q], srdB, (unsigned)(c * 256), bdst + q * 1024);
     };
 
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
@@ -126,12 +134,12 @@ __global__ __launch_bounds__(256, 2) void wino4_gemm_out_kernel(const FusedParam
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) Y[i][jj][0] = Y[i][jj][1] = zero4;
 
-    stage(0, 0);
-    stage(1, 1);
-    glds_wait6();               // stage 0 has landed (stage 1: six instructions in flight)
+#pragma unroll
+    for (int i = 0; i < RING - 1; ++i) stage(i, i);
+    glds_wait_n<INFL>();        // stage 0 has landed (stages 1 .. RING - 2 in flight)
     __syncthreads();
     int cur = 0, s = 0;
-    const int arow = (16 * wa + l15) * 64, brow = 32 * 64 + (32 * wb + l15) * 64;
+    const int arow = (16 * wa + l15) * 64, brow = TILES * 64 + (32 * wb + l15) * 64;
     for (int xi = 0; xi < 6; ++xi) {
         f32x4 Z[4][2];
 #pragma unroll
@@ -152,8 +160,8 @@ __global__ __launch_bounds__(256, 2) void wino4_gemm_out_kernel(const FusedParam
                     fb1[sl] = ld4(bs + 16 * 64 + ch);
                 };
                 load_frag(0, 0);
-                const int nxt = cur == 0 ? 2 : cur - 1;      // (cur + 2) % 3: everybody left that buffer before the last barrier
-                if (s + 2 < S) stage(s + 2, nxt);
+                const int nxt = cur == 0 ? RING - 1 : cur - 1;      // (cur + RING - 1) % RING: everybody left that buffer before the last barrier
+                if (s + RING - 1 < S) stage(s + RING - 1, nxt);
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const int sl = g & 1;
@@ -167,10 +175,10 @@ __global__ __launch_bounds__(256, 2) void wino4_gemm_out_kernel(const FusedParam
                     acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[sl].w, fb0[sl].w, acc0, 0, 0, 0);
                     acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[sl].w, fb1[sl].w, acc1, 0, 0, 0);
                 }
-                if (s + 2 < S) glds_wait6();    // stage s + 1 has landed, stage s + 2 may still fly
+                if (s + RING - 1 < S) glds_wait_n<INFL>();      // stage s + 1 has landed, the stages behind it may still fly
                 else glds_wait();
                 __syncthreads();                // ... for everybody; every wave is done reading buf[cur]
-                cur = cur == 2 ? 0 : cur + 1;
+                cur = cur == RING - 1 ? 0 : cur + 1;
             }
             // (.) A over the row of positions: Z[jj] += A^T[jj][nu] M_(xi, nu)
             if constexpr (WinoAT<0, nu>::v != 0.f) { Z[0][0] = fma4(WinoAT<0, nu>::v, acc0, Z[0][0]); Z[0][1] = fma4(WinoAT<0, nu>::v, acc1, Z[0][1]); }
@@ -203,7 +211,7 @@ __global__ __launch_bounds__(256, 2) void wino4_gemm_out_kernel(const FusedParam
     // the stores move 16 B per lane on 256-byte channel segments -- the output transform's own epilogue.
     const int Hp = p.H >> 1, Wp = p.W >> 1;
     const WinoUnpool up = {p.up_src, p.up_dst, p.Hu, p.Wu};
-    const int q4 = tid & 15, slot = (tid >> 4) & 7, tsel = tid >> 7;          // reader: channel quad, (row & 1, column), tile parity
+    const int q4 = tid & 15, slot = (tid >> 4) & 7, tsel = tid >> 7;          // reader: channel quad, (row & 1, column), tile index mod NW / 2
     float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
     if (p.bias) bv = ld4(p.bias + n0 + 4 * q4);
 #pragma unroll
@@ -222,7 +230,7 @@ __global__ __launch_bounds__(256, 2) void wino4_gemm_out_kernel(const FusedParam
         const int i = 2 * ip + (slot >> 2), jj = slot & 3;
 #pragma unroll 4
         for (int it = 0; it < 16; ++it) {
-            const int tl = 2 * it + tsel;
+            const int tl = (NW / 2) * it + tsel;
             const long tile = (long)t0 + tl;
             if (tile >= p.T) break;
             const int bi = fast_div((int)tile, p.dTw);
@@ -258,10 +266,10 @@ __global__ __launch_bounds__(256, 2) void wino4_gemm_out_kernel(const FusedParam
             st4(p.y + off, v);
         }
         if (p.y_pool) {              // forward only (v = Y + bias): the two pooled rows 2 ti + ip of every tile
-            // thread = (tile, window column k, quad): 32 x 2 x 16 = 1024 items
+            // thread = (tile, window column k, quad): TILES x 2 x 16 = 4 NT items
 #pragma unroll
             for (int it = 0; it < 4; ++it) {
-                const int item = it * 256 + tid;
+                const int item = it * NT + tid;
                 const int q = item & 15, k = (item >> 4) & 1, tl = item >> 5;
                 const long tile = (long)t0 + tl;
                 if (tile >= p.T) continue;
@@ -315,6 +323,35 @@ struct FusedBits {       // the compact forms of mask_src / unpool_src (in) and 
     unsigned short* pool_code;
     const unsigned short* up_code;
 };
+// Block shape of the one-kernel route: tile groups per block (2: 4 waves, two blocks per CU; 4: 8 waves, one block per CU) and
+// ring depth.  WESUP_WINO_FUSED_SHAPE="tw,ring" overrides the default for every K (A/B measurements in one process sequence).
+struct FusedShape { int tw, ring; };
+static FusedShape fused_shape(long T, int N) {
+    // -1: "auto" = 64-tile blocks where they still fill the chip (>= 200 blocks of 8 waves on 256 CUs), else 32-tile blocks
+    static const FusedShape env = [] {
+        FusedShape f = {0, 0};
+        const char* e = getenv("WESUP_WINO_FUSED_SHAPE");
+        if (e && e[0] == 'a') return FusedShape{-1, 3};
+        if (e && sscanf(e, "%d,%d", &f.tw, &f.ring) == 2 &&
+            ((f.tw == 2 && f.ring == 3) || (f.tw == 4 && f.ring >= 3 && f.ring <= 5)))
+            return f;
+        return FusedShape{0, 0};
+    }();
+    if (env.tw > 0) return env;
+    if (env.tw < 0 && ((T + 63) / 64) * (N / 64) >= 200) return FusedShape{4, 3};
+    return FusedShape{2, 3};
+}
+template <int KC, int TW, int RING>
+static int fused_go(const FusedParams& p, dim3 grid, void* stream) {
+    constexpr size_t ring = (size_t)RING * (16 * TW + 64) * 64 * sizeof(float);
+    constexpr size_t image = (size_t)16 * TW * (8 * 64 + 4) * sizeof(float);      // the epilogue's [tile][2 rows x 4 columns x 64] image
+    constexpr size_t lds = ring > image ? ring : image;      // 72 KiB (TW 2, RING 3) ... 160 KiB: above the default dynamic limit
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(wino4_gemm_out_kernel<KC, TW, RING>),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (attr != hipSuccess) return WESUP_ERR_LAUNCH;
+    hipLaunchKernelGGL((wino4_gemm_out_kernel<KC, TW, RING>), grid, dim3(128 * TW), lds, (hipStream_t)stream, p);
+    return WESUP_OK;
+}
 static int fused_launch(const float* V, long plane_elems, const float* U, const float* bias, const float* mask_src, float* y,
                         float* y_pool, int pool_relu, const float* unpool_src, float* unpool_dst, int Hu, int Wu, int B, int H,
                         int W, int K, int N, int accumulate, const WinoGather& gat, const FusedBits& bits, void* stream) {
@@ -334,24 +371,20 @@ static int fused_launch(const float* V, long plane_elems, const float* U, const 
     p.mask_bits = bits.mask_bits; p.pool_code = bits.pool_code; p.up_code = bits.up_code;
     p.Hu = Hu; p.Wu = Wu; p.H = H; p.W = W; p.Th = (H + 3) / 4; p.Tw = (W + 3) / 4; p.T = T; p.N = N;
     p.dTw = make_fastdiv(p.Tw); p.dTh = make_fastdiv(p.Th);
-    p.tile_blocks = (int)ceil_div(T, 32l); p.n_blocks = N / 64; p.dNb = make_fastdiv(p.n_blocks);
+    const FusedShape fs = fused_shape(T, N);
+    p.tile_blocks = (int)((T + 16 * fs.tw - 1) / (16 * fs.tw)); p.n_blocks = N / 64; p.dNb = make_fastdiv(p.n_blocks);
     static const long u_limit = [] { const char* e = getenv("WESUP_WINO_FUSED_NFAST_KB"); return (e ? atol(e) : 65536l) * 1024l; }();
     p.n_fastest = (p.n_blocks > 1 && (long)36 * N * K * 4 <= u_limit) ? 1 : 0;
     if ((long)p.tile_blocks * p.n_blocks >= (1l << 24)) return WESUP_ERR_INVALID;
     const dim3 grid((unsigned)(p.tile_blocks * p.n_blocks));
-    const size_t lds = (size_t)3 * (32 + 64) * 64 * sizeof(float);       // 72 KiB: above the default dynamic limit
-    {
-        static const hipError_t attr1 = hipFuncSetAttribute(reinterpret_cast<const void*>(wino4_gemm_out_kernel<1>),
-                                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        static const hipError_t attr2 = hipFuncSetAttribute(reinterpret_cast<const void*>(wino4_gemm_out_kernel<2>),
-                                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        static const hipError_t attr4 = hipFuncSetAttribute(reinterpret_cast<const void*>(wino4_gemm_out_kernel<4>),
-                                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (attr1 != hipSuccess || attr2 != hipSuccess || attr4 != hipSuccess) return WESUP_ERR_LAUNCH;
-    }
-    if (K == 64) hipLaunchKernelGGL(wino4_gemm_out_kernel<1>, grid, dim3(256), lds, (hipStream_t)stream, p);
-    else if (K == 128) hipLaunchKernelGGL(wino4_gemm_out_kernel<2>, grid, dim3(256), lds, (hipStream_t)stream, p);
-    else hipLaunchKernelGGL(wino4_gemm_out_kernel<4>, grid, dim3(256), lds, (hipStream_t)stream, p);
+    int rc = WESUP_ERR_INVALID;
+#define FUSED_CASE(TW_, RING_)                                                                        \
+    if (fs.tw == TW_ && fs.ring == RING_)                                                             \
+        rc = K == 64 ? fused_go<1, TW_, RING_>(p, grid, stream)                                       \
+           : K == 128 ? fused_go<2, TW_, RING_>(p, grid, stream) : fused_go<4, TW_, RING_>(p, grid, stream);
+    FUSED_CASE(2, 3) FUSED_CASE(4, 3) FUSED_CASE(4, 4) FUSED_CASE(4, 5)
+#undef FUSED_CASE
+    if (rc != WESUP_OK) return rc;
     WESUP_CHECK_LAUNCH();
     return WESUP_OK;
 }
