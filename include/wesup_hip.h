@@ -57,6 +57,10 @@ int wesup_pack_input(const float* img_nchw, float* out_nhwc4, int B, int H, int 
 int wesup_conv3x3_kpad(int Ci);
 int wesup_pack_conv3x3_weight(const float* w_kcrs, float* w_fwd, float* w_dgrad, int Co, int Ci, void* stream);
 int wesup_transpose(const float* in, float* out, int rows, int cols, void* stream);
+/* n <= 40 transposes in one launch (the weight panels the input-gradient GEMMs of the side convs / fc layers read,
+ * models/wesup.py:213-232; the interpolation-pooling matrices of a batch); items is a HOST array */
+typedef struct WesupTransposeItem { const float* in; float* out; int rows, cols; } WesupTransposeItem;
+int wesup_transpose_batched(const WesupTransposeItem* items /* host */, int n, void* stream);
 
 /* ------------------------------------------------------------------ input pipeline
  * replaces the per-item CPU augmentation (albumentations) of utils/data.py:116-133,302-327 for a batch of decoded,
@@ -138,6 +142,10 @@ int wesup_conv3x3_wgrad_winograd(const float* x, const float* v_pre, const float
 size_t wesup_winograd_weight_floats(int Cin, int Cout, int m);
 long wesup_winograd_tiles(int B, int H, int W, int m);
 int wesup_winograd_pack_weight(const float* w_kcrs, float* u_fwd, float* u_dgrad, int Cout, int Cin, int m, void* stream);
+/* the F(4x4,3x3) filters of several layers in ONE launch (what n calls of wesup_winograd_pack_weight(..., m = 4) write; the
+ * step re-derives 12 + 12 filter sets per iteration); layers is a HOST array, at most 32 non-NULL panels in all */
+typedef struct WesupWinoFilter { const float* w; float* u_fwd; float* u_dgrad; int Cout, Cin; } WesupWinoFilter;
+int wesup_winograd_pack_weights(const WesupWinoFilter* layers /* host */, int n, void* stream);
 size_t wesup_conv3x3_winograd_workspace_bytes(int B, int H, int W, int Cin, int Cout, int m);
 int wesup_conv3x3_fwd_winograd(const float* x, const float* u_fwd, const float* bias, float* y, float* y_relu,
                                float* y_pool, int pool_relu, float* v_keep,
@@ -304,7 +312,11 @@ size_t wesup_sp_preprocess_workspace_bytes(int B, int HW, int C, int Kmax);
 int wesup_sp_preprocess(const int32_t* labels, const uint8_t* mask, int B, int HW, int C, int Kmax,
                         int32_t* n_sp, int32_t* n_l, int32_t* perm, int32_t* inv_perm, int32_t* area_new,
                         float* sp_labels, int32_t* new_row, int32_t* row_start, int32_t* pix_sorted,
-                        int32_t* status, void* ws, size_t ws_bytes, void* stream);
+                        int32_t* status, int32_t* seg_start /* or NULL */, int32_t* unit_row /* or NULL */, int Umax,
+                        void* ws, size_t ws_bytes, void* stream);
+/* (ABI 4: two launches -- per-chunk counts in LDS, the image's last chunk block does the ordering, then the placement -- and
+ *  the segment table of wesup_sp_segments written on the way when seg_start / unit_row [B][Kmax+1] / [B][Umax] are given;
+ *  B <= 256 per call) */
 /* dense compat: labels[p] = argmax_n sp_maps[n][p] (first max), as models/wesup.py:295 does */
 int wesup_spmaps_to_labels(const float* sp_maps, int32_t* labels, int N, int HW, void* stream);
 /* scatter-mean: sp_feat[b][r][c] = (1/area_r) sum_{p in row r} fm[b][p][c]   (torch.mm, models/wesup.py:283-285) */
@@ -418,6 +430,39 @@ int wesup_softmax_ce_fwd(const float* logits, const float* y_true, const float* 
                          float* out2, int n, int C, void* stream);
 int wesup_softmax_ce_bwd(const float* probs, const float* y_true, const float* class_weights, const float* out2,
                          const float* dloss, float eps, float* dlogits, int n, int C, void* stream);
+
+/* ------------------------------------------------------------------ step plans (ABI 4)
+ * The reference walks one training iteration in Python every step (models/base.py:184-211); so does the engine above this
+ * library, ~330 launches on three streams.  A plan records that walk ONCE -- every launch this thread issues through the
+ * library between wesup_plan_begin and wesup_plan_end is executed as usual and appended with its kernel, grid, stream and a
+ * byte copy of its arguments; ordering edges and copies likewise -- and wesup_plan_replay re-issues the recording from C.
+ * Nothing is re-derived at replay: the caller replays a plan only while every buffer the recorded step touched is alive at
+ * the same address and the shapes / hyper-parameters are those of the recording (inputs go into buffers the plan knows). */
+typedef struct WesupPlan WesupPlan;
+int wesup_plan_create(WesupPlan** out /* host */);
+int wesup_plan_destroy(WesupPlan* plan);
+int wesup_plan_begin(WesupPlan* plan);            /* this thread records into plan (one at a time per thread) */
+int wesup_plan_end(WesupPlan* plan);
+int wesup_plan_size(const WesupPlan* plan);       /* nodes so far: a position to split a replay at */
+int wesup_plan_kernels(const WesupPlan* plan);    /* kernel launches among them */
+int wesup_plan_replay(const WesupPlan* plan, int first, int last);      /* nodes [first, last) in recorded order */
+/* 0 = the two recordings are identical (kernels, geometry, streams, argument bytes, edges, copies); k > 0 = they first
+ * differ at node k - 1: something the walk produces moved between the two steps and the older plan must not be replayed */
+int wesup_plan_diff(const WesupPlan* a, const WesupPlan* b);
+const char* wesup_plan_node_name(const WesupPlan* plan, int node);
+/* Ordering edges between streams on a fixed pool of events addressed by slot (0 .. wesup_sync_slots() - 1): record marks
+ * the work queued so far on `stream`, wait makes `stream` wait for the slot's latest mark.  Both act at once and, while the
+ * thread records a plan, become nodes of it.  wesup_sync_synchronize blocks the HOST until the mark is reached (the one
+ * wait of an iteration: the loss read-back). */
+int wesup_sync_slots(void);
+int wesup_sync_record(int slot, void* stream);
+int wesup_sync_wait(int slot, void* stream);
+int wesup_sync_synchronize(int slot);
+int wesup_sync_query(int slot);                   /* 1 reached, 0 not yet */
+/* recordable copies and fills: device -> pinned host, device -> device, 32-bit words */
+int wesup_copy_to_host(void* dst_host_pinned, const void* src, size_t bytes, void* stream);
+int wesup_copy(void* dst, const void* src, size_t bytes, void* stream);
+int wesup_fill_words(void* ptr, uint32_t value, size_t words, void* stream);
 
 #ifdef __cplusplus
 }

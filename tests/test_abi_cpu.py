@@ -45,7 +45,7 @@ def test_ctypes_signatures_match_header(lib):
 
 def test_host_side_queries(lib):
     h = lib.load()
-    assert h.wesup_abi_version() == lib.ABI_VERSION == 3
+    assert h.wesup_abi_version() == lib.ABI_VERSION == 4
     assert h.wesup_conv3x3_kpad(3) == 64 and h.wesup_conv3x3_kpad(64) == 576 and h.wesup_conv3x3_kpad(512) == 4608
     assert h.wesup_strerror(0) == b'ok' and b'workspace' in h.wesup_strerror(-3)
     assert h.wesup_conv3x3_wgrad_workspace_bytes(4, 480, 480, 64, 64) > 0
@@ -102,3 +102,23 @@ def test_winograd_host_side_queries_and_argument_checks(lib):
     import ctypes
     assert h.wesup_debug_clock(ctypes.byref(ctypes.c_double())) == -1 and h.wesup_debug_set_trace(None) == -1
     assert h.wesup_conv3x3_fwd_side(None, None, None, None, None, None, None, None, 32, 1, 8, 8, 64, 64, 0, None) == -1
+
+
+def test_step_plan_object_without_a_gpu(lib):
+    """The plan object itself is host code: create, record nothing, seal, compare, replay an empty range, destroy."""
+    import ctypes
+    h = lib.load()
+    a, b = ctypes.c_void_p(), ctypes.c_void_p()
+    assert h.wesup_plan_create(ctypes.byref(a)) == 0 and h.wesup_plan_create(ctypes.byref(b)) == 0
+    assert h.wesup_plan_replay(a, 0, 0) == -1                  # not sealed yet
+    assert h.wesup_plan_begin(a) == 0
+    assert h.wesup_plan_begin(b) == -1                         # one recording per thread at a time
+    assert h.wesup_plan_end(b) == -1
+    assert h.wesup_plan_size(a) == 0 and h.wesup_plan_end(a) == 0
+    assert h.wesup_plan_begin(b) == 0 and h.wesup_plan_end(b) == 0
+    assert h.wesup_plan_diff(a, b) == 0
+    assert h.wesup_plan_replay(a, 0, 0) == 0 and h.wesup_plan_replay(a, 0, 1) == -1
+    assert h.wesup_plan_kernels(a) == 0 and h.wesup_plan_node_name(a, 0) == b''
+    assert h.wesup_sync_slots() >= 64
+    assert h.wesup_plan_destroy(a) == 0 and h.wesup_plan_destroy(b) == 0
+    assert h.wesup_winograd_pack_weights(None, 0, None) == -1 and h.wesup_transpose_batched(None, 3, None) == -1

@@ -67,3 +67,14 @@ def test_launcher_and_flag_must_agree():
     r = subprocess.run([sys.executable, BENCH, '--gpus', '4', '--stub-trainer'], env=env, capture_output=True, text=True,
                        timeout=120)
     assert r.returncode != 0 and 'WORLD_SIZE=2' in r.stderr
+
+
+def test_self_launch_eight_ranks():
+    """The N = 8 line of the driver's scaling run, rehearsed on CPU ranks: eight children, one JSON line, the slowest rank's time."""
+    r = subprocess.run([sys.executable, BENCH, '--gpus', '8', '--steps', '4', '--warmup', '1', '--stub-trainer'],
+                       env=_env(), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = _one_json_line(r.stdout)
+    assert out['n_gpus'] == 8 and out['config']['parallelism'] == 'dp8'
+    assert out['collective'] == {'backend': 'gloo', 'ranks': 8, 'allreduce_sum': 8.0 ** 4}
+    assert out['rank_time']['max_s'] >= 4 * 0.002 * 8 > out['rank_time']['min_s'] * 0 

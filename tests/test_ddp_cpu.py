@@ -125,3 +125,100 @@ def test_weight_bias_pairs_merge_into_one_range():
         assert red.launched == []                    # nothing flushed: one growing contiguous range
     done = red.finish()
     assert done == [(0, total)]
+
+
+# ------------------------------------------------------------------ world size 8 on the model's real parameter layout
+def _model_layout():
+    """Names, 64-element-aligned offsets and padded sizes of the 18 868 194 parameters, as WESUP._ensure_engine lays them
+    out, and the order in which the engine's backward reports them (engine.py: head, side convs deepest first, backbone
+    from conv5_3 down, (weight, bias) per call)."""
+    from wesup_amd.engine import CONV_IDX, SIDE_OFF
+    from wesup_amd.models.wesup import WESUP
+    params = list(WESUP().named_parameters())
+    assert sum(p.numel() for _, p in params) == 18868194
+    offs, sizes, total = {}, {}, 0
+    for n, p in params:
+        offs[n] = total
+        sizes[n] = (p.numel() + 63) // 64 * 64
+        total += sizes[n]
+    order = [['classifier.0.weight', 'classifier.0.bias'] + [f'fc_layers.{k}.{t}' for k in (0, 2, 4) for t in ('weight', 'bias')]]
+    order += [[f'side_conv{off}.weight', f'side_conv{off}.bias'] for off in reversed(SIDE_OFF)]
+    order += [[f'backbone.{i}.weight', f'backbone.{i}.bias'] for i in reversed(CONV_IDX)]
+    assert sorted(n for call in order for n in call) == sorted(offs)
+    return offs, sizes, total, order
+
+
+def _worker8(rank, world, port, out):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        torch.set_num_threads(1)
+        offs, sizes, total, order = _model_layout()
+        flat = torch.full((total,), float(rank + 1))
+        red = ddp.GradAllReducer(flat, offs, sizes, bucket_bytes=16 << 20)
+        for call in order:
+            red.ready(call)
+        launched = red.finish()
+        expect = float(world * (world + 1) // 2)
+        ok = bool((flat == expect).all())
+        cov = sorted(launched)
+        tiles = cov[0][0] == 0 and cov[-1][1] == total and all(a[1] == b[0] for a, b in zip(cov, cov[1:]))
+        # every rank must have cut the same buckets in the same order (or the collectives would pair up wrongly)
+        mine = torch.tensor([v for ab in launched for v in ab], dtype=torch.int64)
+        theirs = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(theirs, mine)
+        same = all(torch.equal(t, mine) for t in theirs)
+        if rank == 0:
+            out.put((ok, tiles, same, [(b - a) * 4 for a, b in launched], total))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bucketed_allreduce_world8_on_the_model_layout():
+    ctx = mp.get_context('spawn')
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker8, args=(r, 8, port, out)) for r in range(8)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    ok, tiles, same, bucket_bytes, total = out.get(timeout=10)
+    assert ok, 'all-reduced flat gradient != sum over the 8 ranks'
+    assert tiles, 'buckets do not tile the flat buffer exactly once'
+    assert same, 'ranks cut different buckets'
+    assert total * 4 >= 18868194 * 4 and sum(bucket_bytes) == total * 4
+    # On the GPU a bucket never mixes streams (head / side convs / backbone: 13.0 + 3.6 + 3 x 18.9 + 2.2 MB, DESIGN.md 7);
+    # without streams the same reports coalesce across those borders: every bucket but the last reaches the 16 MB bar
+    assert 4 <= len(bucket_bytes) <= 6 and all(b >= 16 << 20 for b in bucket_bytes[:-1]) and max(bucket_bytes) < 32 << 20
+
+
+def test_non_adjacent_range_keeps_the_stream_of_its_call():
+    """after an in-loop flush the new pending range must still remember the stream it was reported on (CPU:
+    the bookkeeping only -- no stream exists -- but the range logic is the same)."""
+    names, offs, sizes, total = _layout()
+    flat = torch.zeros(total)
+    red = ddp.GradAllReducer(flat, offs, sizes, bucket_bytes=1 << 30)
+    red.ready(['fc.weight', 'backbone.0.weight'])          # not adjacent: the first is flushed, the second is pending
+    assert red.launched == [(offs['fc.weight'], offs['fc.weight'] + sizes['fc.weight'])]
+    assert (red.lo, red.hi) == (0, sizes['backbone.0.weight'])
+    red.finish()
+
+
+def test_shard_sampler_world8_epochs():
+    n = 165                                                 # GlaS has 85 training images, CRAG 173; any odd count
+    per_epoch = []
+    for epoch in range(3):
+        seen = []
+        for r in range(8):
+            s = ddp.ShardSampler(n, r, 8, seed=11)
+            s.set_epoch(epoch)
+            idx = list(s)
+            assert len(idx) == len(s) == (n + 7) // 8
+            seen.append(idx)
+        flat = [i for idx in seen for i in idx]
+        assert set(flat) == set(range(n)) and len(flat) == (n + 7) // 8 * 8
+        per_epoch.append(seen)
+    assert per_epoch[0] != per_epoch[1] != per_epoch[2]

@@ -1,0 +1,141 @@
+"""The recordable walk of the training iteration (wesup_amd/runner.py) and its replay from a step plan (csrc/plan.hip).
+
+Bar: the runner's walk equals the trainer's general path (preprocess -> forward -> compute_loss -> loss.backward() -> step)
+BIT FOR BIT -- the same kernels on the same operands in the same stream order --, and a replayed plan equals the walk bit
+for bit: loss, metrics, every parameter after every step."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _trainer(weights, **kw):
+    from wesup_amd.models import initialize_trainer
+    from wesup_amd.utils.metrics import accuracy, dice
+    t = initialize_trainer('wesup', device='cuda:0', **kw)
+    t.model.load_state_dict({k: torch.from_numpy(v) for k, v in weights.items()})
+    t.optimizer, t.scheduler = t.get_default_optimizer()
+    t.metric_funcs = [accuracy, dice]
+    t.model.train()
+    t.tracker.train()
+    return t
+
+
+def _batches(n, B, H, W, g, dev):
+    from wesup_amd import synth
+    out = []
+    for i in range(n):
+        imgs, labs, pts, pix = synth.make_batch(100 + i, B, H, W, g)
+        out.append(tuple(torch.from_numpy(a).to(dev) for a in (imgs, pix, pts, labs)))
+    return out
+
+
+def _flat(t):
+    return t.model._flat.detach().clone()
+
+
+@pytest.mark.parametrize('B,H,W,g', [(2, 96, 96, 6), (1, 80, 112, 5)])
+def test_runner_walk_equals_the_general_path_bit_for_bit(B, H, W, g):
+    from oracle import wesup_oracle as orc
+    dev = torch.device('cuda:0')
+    weights = orc.make_weights(3, feat_scale=0.05)
+    data = _batches(2, B, H, W, g, dev)
+    a = _trainer(weights, max_superpixels=g * g, native_step=False)          # the trainer's general path
+    b = _trainer(weights, max_superpixels=g * g, step_plan=False)            # the runner, never recording
+    for i in range(4):
+        a.train_one_iteration('train', *data[i % 2])
+        b.train_one_iteration('train', *data[i % 2])
+        assert b.step_runner().stats['eager'] == i + 1
+        for k in ('loss', 'labeled_sp_ratio', 'propagated_labels', 'propagate_loss', 'accuracy', 'dice'):
+            assert a.tracker.history[k][-1] == b.tracker.history[k][-1], (i, k)
+        assert torch.equal(_flat(a), _flat(b)), f'parameters differ after step {i}'
+        assert torch.equal(a.model._flat_grad, b.model._flat_grad)
+    assert a.step_runner() is None
+
+
+@pytest.mark.parametrize('B,H,W,g', [(2, 96, 96, 6), (4, 64, 64, 4)])
+def test_replayed_plan_equals_the_walk_bit_for_bit(B, H, W, g):
+    from oracle import wesup_oracle as orc
+    dev = torch.device('cuda:0')
+    weights = orc.make_weights(5, feat_scale=0.05)
+    data = _batches(3, B, H, W, g, dev)
+    a = _trainer(weights, max_superpixels=g * g, step_plan=False)
+    b = _trainer(weights, max_superpixels=g * g)
+    n = 10
+    for i in range(n):
+        a.train_one_iteration('train', *data[i % 3])
+        b.train_one_iteration('train', *data[i % 3])
+        assert a.tracker.history['loss'][-1] == b.tracker.history['loss'][-1], i
+        for k in ('labeled_sp_ratio', 'propagated_labels', 'propagate_loss', 'accuracy', 'dice'):
+            assert a.tracker.history[k][-1] == b.tracker.history[k][-1], (i, k)
+        assert torch.equal(_flat(a), _flat(b)), f'parameters differ after step {i}'
+    st = b.step_runner().stats
+    assert st['recorded'] == 2 and st['replayed'] == n - 4 and st['dropped'] == 0, st
+    # what the module carries after an iteration (models/wesup.py:287-292, :529)
+    assert b.model.sp_pred is None and b.model.sp_features.shape[0] == B
+    # the plan is a few hundred launches and a handful of cuts
+    plan = next(iter(b.step_runner().states.values())).plan
+    from wesup_amd import _lib
+    assert 150 < _lib.load().wesup_plan_kernels(plan.h) < 600 and len(plan.cuts) == 1
+
+
+def test_plan_is_dropped_when_the_walk_changes_and_nan_raises_before_the_update():
+    from oracle import wesup_oracle as orc
+    dev = torch.device('cuda:0')
+    B, H, W, g = 2, 64, 64, 4
+    weights = orc.make_weights(7, feat_scale=0.05)
+    data = _batches(2, B, H, W, g, dev)
+    a = _trainer(weights, max_superpixels=g * g, step_plan=False)
+    b = _trainer(weights, max_superpixels=g * g)
+    for i in range(6):
+        a.train_one_iteration('train', *data[i % 2])
+        b.train_one_iteration('train', *data[i % 2])
+    assert b.step_runner().stats['replayed'] == 2
+    for t in (a, b):                                  # a new learning rate: the recorded SGD launch is stale
+        t.optimizer.param_groups[0]['lr'] = 1e-4
+    for i in range(6):
+        a.train_one_iteration('train', *data[i % 2])
+        b.train_one_iteration('train', *data[i % 2])
+        assert torch.equal(_flat(a), _flat(b)), i
+    st = b.step_runner().stats
+    assert st['dropped'] == 1 and st['replayed'] == 4, st
+    # an engine switch changes the launch list
+    b.model.engine.dual_transform = a.model.engine.dual_transform = False
+    for i in range(2):
+        a.train_one_iteration('train', *data[i % 2])
+        b.train_one_iteration('train', *data[i % 2])
+        assert torch.equal(_flat(a), _flat(b)), i
+    assert b.step_runner().stats['dropped'] == 2
+    # NaN in the input while a plan is being replayed: ValueError before the optimiser, weights untouched
+    b.model.engine.dual_transform = a.model.engine.dual_transform = True
+    for i in range(5):
+        b.train_one_iteration('train', *data[i % 2])
+    assert b.step_runner().stats['replayed'] >= 5
+    before = _flat(b)
+    bad = list(data[0])
+    bad[0] = bad[0].clone()
+    bad[0][0, 0, 3, 3] = float('nan')
+    with pytest.raises(ValueError, match='Loss is nan'):
+        b.train_one_iteration('train', *bad)
+    torch.cuda.synchronize()
+    assert torch.equal(before, _flat(b))
+    b.train_one_iteration('train', *data[1])                 # and the next clean iteration goes through
+    assert np.isfinite(b.tracker.history['loss'][-1])
+
+
+def test_general_path_still_serves_what_the_runner_does_not_cover():
+    from oracle import wesup_oracle as orc
+    dev = torch.device('cuda:0')
+    B, H, W, g = 1, 64, 64, 4
+    weights = orc.make_weights(9, feat_scale=0.05)
+    (img, pix, pts, labs), = _batches(1, B, H, W, g, dev)
+    t = _trainer(weights, max_superpixels=g * g)
+    t.train_one_iteration('train', img, pix, pts)             # no label maps: SLIC inside preprocess, general path
+    assert t.step_runner().stats['eager'] == 0
+    t.model.eval(); t.tracker.eval()
+    t.train_one_iteration('val', img, pix, pts, labs)         # validation: general path
+    assert t.step_runner().stats['eager'] == 0
+    t.model.train(); t.tracker.train()
+    t.train_one_iteration('train', img, pix, pts, labs)
+    assert t.step_runner().stats['eager'] == 1

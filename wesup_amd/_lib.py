@@ -32,6 +32,7 @@ _SIGS = {
     'wesup_conv3x3_kpad': (c_int, 'i'),
     'wesup_pack_conv3x3_weight': (c_int, 'pppiip'),
     'wesup_transpose': (c_int, 'ppiip'),
+    'wesup_transpose_batched': (c_int, 'pip'),
     'wesup_conv3x3_workspace_bytes': (c_size_t, 'iiiii'),
     'wesup_conv3x3_fwd': (c_int, 'pppppiiiiiipzp'),
     'wesup_conv3x3_fwd_side': (c_int, 'ppppppppiiiiiiip'),
@@ -43,6 +44,7 @@ _SIGS = {
     'wesup_winograd_weight_floats': (c_size_t, 'iii'),
     'wesup_winograd_tiles': (ctypes.c_long, 'iiii'),
     'wesup_winograd_pack_weight': (c_int, 'pppiiip'),
+    'wesup_winograd_pack_weights': (c_int, 'pip'),
     'wesup_conv3x3_winograd_workspace_bytes': (c_size_t, 'iiiiii'),
     'wesup_conv3x3_fwd_winograd': (c_int, 'ppppppipiiiiiiipzp'),
     'wesup_conv3x3_dgrad_winograd': (c_int, 'ppppiiiiiiipzp'),
@@ -78,7 +80,7 @@ _SIGS = {
     'wesup_upsample_bwd': (c_int, 'ppppiiiiiiiiip'),
     'wesup_upsample_bwd_group': (c_int, 'ppppppiiiippiiiiiip'),
     'wesup_sp_preprocess_workspace_bytes': (c_size_t, 'iiii'),
-    'wesup_sp_preprocess': (c_int, 'ppiiii' + 'pppppppppp' + 'pzp'),
+    'wesup_sp_preprocess': (c_int, 'ppiiii' + 'pppppppppp' + 'ppi' + 'pzp'),
     'wesup_spmaps_to_labels': (c_int, 'ppiip'),
     'wesup_sp_max_units': (c_int, 'ii'),
     'wesup_sp_segments': (c_int, 'piiippp'),
@@ -115,17 +117,43 @@ _SIGS = {
     'wesup_upsample_bilinear_ac_bwd': (c_int, 'ppiiiiiiiip'),
     'wesup_softmax_ce_fwd': (c_int, 'pppfppiip'),
     'wesup_softmax_ce_bwd': (c_int, 'pppppfpiip'),
+    # step plans (csrc/plan.hip)
+    'wesup_plan_create': (c_int, 'p'),
+    'wesup_plan_destroy': (c_int, 'p'),
+    'wesup_plan_begin': (c_int, 'p'),
+    'wesup_plan_end': (c_int, 'p'),
+    'wesup_plan_size': (c_int, 'p'),
+    'wesup_plan_kernels': (c_int, 'p'),
+    'wesup_plan_replay': (c_int, 'pii'),
+    'wesup_plan_diff': (c_int, 'pp'),
+    'wesup_plan_node_name': (ctypes.c_char_p, 'pi'),
+    'wesup_sync_slots': (c_int, ''),
+    'wesup_sync_record': (c_int, 'ip'),
+    'wesup_sync_wait': (c_int, 'ip'),
+    'wesup_sync_synchronize': (c_int, 'i'),
+    'wesup_sync_query': (c_int, 'i'),
+    'wesup_copy_to_host': (c_int, 'ppzp'),
+    'wesup_copy': (c_int, 'ppzp'),
+    'wesup_fill_words': (c_int, 'pizp'),
 }
 _T = {'p': c_void_p, 'i': c_int, 'f': c_float, 'z': c_size_t, 'l': ctypes.c_long}
 
 EXPORTS = sorted(_SIGS)
-ABI_VERSION = 3          # include/wesup_hip.h; a stale libwesup_hip.so with other signatures must not be called
+ABI_VERSION = 4          # include/wesup_hip.h; a stale libwesup_hip.so with other signatures must not be called
 
 _lib = None
 
 
 class WesupHipError(RuntimeError):
     pass
+
+
+class WinoFilter(ctypes.Structure):            # WesupWinoFilter (include/wesup_hip.h)
+    _fields_ = [('w', c_void_p), ('u_fwd', c_void_p), ('u_dgrad', c_void_p), ('Cout', c_int), ('Cin', c_int)]
+
+
+class TransposeItem(ctypes.Structure):         # WesupTransposeItem
+    _fields_ = [('src', c_void_p), ('dst', c_void_p), ('rows', c_int), ('cols', c_int)]
 
 
 def build(verbose=False):

@@ -157,7 +157,7 @@ extern "C" int wesup_augment(const uint8_t* img_hwc, const uint8_t* mask_hw, con
     if (elastic_field && (!elastic_params || hc <= 0 || wc <= 0 || cell <= 0)) return WESUP_ERR_INVALID;
     const long HW = (long)H * W;
     const ElasticField el = {elastic_field, reinterpret_cast<const ElasticParams*>(elastic_params), hc, wc, cell};
-    hipLaunchKernelGGL(augment_kernel, dim3((unsigned)((HW + 255) / 256), B), dim3(256), 0, (hipStream_t)stream, img_hwc,
+    WESUP_LAUNCH(augment_kernel, dim3((unsigned)((HW + 255) / 256), B), dim3(256), 0, (hipStream_t)stream, img_hwc,
                        mask_hw, reinterpret_cast<const AugParams*>(params), out_img_nchw, out_mask_chw, H, W, C, el);
     WESUP_CHECK_LAUNCH();
     return WESUP_OK;
@@ -363,10 +363,10 @@ extern "C" int wesup_appearance(const uint8_t* img_hwc, const float* params, uin
     uint8_t* tmp = (uint8_t*)ws;
     uint8_t* lut = tmp + align_up((size_t)B * HW * 3, 256);
     const dim3 grid((unsigned)((HW + 255) / 256), B);
-    hipLaunchKernelGGL(app_color_kernel, grid, dim3(256), 0, st, img_hwc, pr, out_hwc, HW);              // src -> out
-    hipLaunchKernelGGL(clahe_lut_kernel, dim3(CLAHE_TILES * CLAHE_TILES, B), dim3(256), 0, st, out_hwc, pr, lut, H, W);
-    hipLaunchKernelGGL(clahe_apply_kernel, grid, dim3(256), 0, st, out_hwc, pr, lut, tmp, H, W);         // out -> tmp
-    hipLaunchKernelGGL(blur3_kernel, grid, dim3(256), 0, st, tmp, pr, out_hwc, H, W);                    // tmp -> out
+    WESUP_LAUNCH(app_color_kernel, grid, dim3(256), 0, st, img_hwc, pr, out_hwc, HW);              // src -> out
+    WESUP_LAUNCH(clahe_lut_kernel, dim3(CLAHE_TILES * CLAHE_TILES, B), dim3(256), 0, st, out_hwc, pr, lut, H, W);
+    WESUP_LAUNCH(clahe_apply_kernel, grid, dim3(256), 0, st, out_hwc, pr, lut, tmp, H, W);         // out -> tmp
+    WESUP_LAUNCH(blur3_kernel, grid, dim3(256), 0, st, tmp, pr, out_hwc, H, W);                    // tmp -> out
     WESUP_CHECK_LAUNCH();
     return WESUP_OK;
 }

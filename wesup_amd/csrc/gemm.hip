@@ -535,11 +535,11 @@ static int launch_nt(NtParams p, hipStream_t st, const SkPlan* sk = nullptr, voi
                                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (attr != hipSuccess) return WESUP_ERR_LAUNCH;
     }
-    hipLaunchKernelGGL(kern, dim3(p.full_tiles + p.sk_parts), dim3(NW * 64), lds, st, p);
+    WESUP_LAUNCH(kern, dim3(p.full_tiles + p.sk_parts), dim3(NW * 64), lds, st, p);
     WESUP_CHECK_LAUNCH();
     if (p.sk_parts > 0) {
         const int rem_tiles = p.tiles_m * p.tiles_n - p.full_tiles;
-        hipLaunchKernelGGL((nt_fixup_kernel<BM, BN>), dim3(rem_tiles * (BM * BN / 1024)), dim3(256), 0, st, p);
+        WESUP_LAUNCH((nt_fixup_kernel<BM, BN>), dim3(rem_tiles * (BM * BN / 1024)), dim3(256), 0, st, p);
         WESUP_CHECK_LAUNCH();
     }
     return WESUP_OK;
@@ -1065,7 +1065,7 @@ static const float* slab_fold(const float* slab, int& S, long slab_elems, float*
     const int chunks = slab_fold_chunks(S);
     if (!chunks) return slab;
     const int rows_per = ceil_div(S, chunks);
-    hipLaunchKernelGGL(colsum_stage1, dim3((unsigned)ceil_div(slab_elems, 64l), chunks), dim3(256), 0, st, slab,
+    WESUP_LAUNCH(colsum_stage1, dim3((unsigned)ceil_div(slab_elems, 64l), chunks), dim3(256), 0, st, slab,
                        (int)slab_elems, part, S, (int)slab_elems, rows_per);
     S = ceil_div(S, rows_per);
     return part;
@@ -1140,7 +1140,7 @@ static int launch_tn(TnParams p, const TnPlan& pl, hipStream_t st, int nbatch = 
     dim3 grid(pl.tiles_m * pl.tiles_n * pl.taps, pl.S, nbatch);
     const bool tiny = (MODE == 1 || MODE == 2) && (p.W < 16 || p.H < 2);
 #define WESUP_TN_LAUNCH(BM_, WM_, RELU_, TINY_)                                                                        \
-    hipLaunchKernelGGL((gemm_tn_kernel<BM_, BM_, WM_, WM_, MODE, RELU_, TINY_>), grid, dim3(256),                     \
+    WESUP_LAUNCH((gemm_tn_kernel<BM_, BM_, WM_, WM_, MODE, RELU_, TINY_>), grid, dim3(256),                     \
                        (size_t)2 * BK * (BM_ + BM_) * sizeof(float), st, p)
 #define WESUP_TN_PICK(BM_, WM_)                                                                                        \
     do {                                                                                                               \
@@ -1182,7 +1182,7 @@ extern "C" int wesup_gemm_tn(const float* A, int lda, const float* B, int ldb, f
     int S = pl.S;
     float* part = (float*)((char*)ws + align_up((size_t)pl.S * p.slab_stride * sizeof(float), 256));
     const float* src = slab_fold((const float*)ws, S, p.slab_stride, part, st);
-    hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)((tot + M + 255) / 256)), dim3(256), 0, st, src, p.slab_stride, C,
+    WESUP_LAUNCH(tn_reduce_kernel, dim3((unsigned)((tot + M + 255) / 256)), dim3(256), 0, st, src, p.slab_stride, C,
                        ldc, M, N, pl.Nslab, S, colsum_a, 0l, 0l);
     WESUP_CHECK_LAUNCH();
     return WESUP_OK;
@@ -1212,7 +1212,7 @@ extern "C" int wesup_gemm_tn_batched(const float* A, int lda, long strideA, cons
     int rc = launch_tn<0>(p, pl, st, nbatch);
     if (rc) return rc;
     const long tot = (long)M * N;
-    hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)((tot + 255) / 256), nbatch), dim3(256), 0, st, (const float*)ws,
+    WESUP_LAUNCH(tn_reduce_kernel, dim3((unsigned)((tot + 255) / 256), nbatch), dim3(256), 0, st, (const float*)ws,
                        p.slab_stride, C, ldc, M, N, pl.Nslab, pl.S, (float*)nullptr, p.batch_slab, strideC);
     WESUP_CHECK_LAUNCH();
     return WESUP_OK;
@@ -1264,9 +1264,9 @@ extern "C" int wesup_colsum(const float* A, int lda, float* out, int M, int N, v
     const int chunks = colsum_chunks(M, N);
     const int rows_per = ceil_div(M, chunks);
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(colsum_stage1, dim3(ceil_div(N, 64), chunks), dim3(256), 0, st, A, lda, (float*)ws, M, N,
+    WESUP_LAUNCH(colsum_stage1, dim3(ceil_div(N, 64), chunks), dim3(256), 0, st, A, lda, (float*)ws, M, N,
                        rows_per);
-    hipLaunchKernelGGL(colsum_stage1, dim3(ceil_div(N, 64), 1), dim3(256), 0, st, (const float*)ws, N, out, chunks, N,
+    WESUP_LAUNCH(colsum_stage1, dim3(ceil_div(N, 64), 1), dim3(256), 0, st, (const float*)ws, N, out, chunks, N,
                        chunks);
     WESUP_CHECK_LAUNCH();
     return WESUP_OK;
@@ -1315,7 +1315,7 @@ extern "C" int wesup_conv3x3_wgrad(const float* x, const float* dy, float* dw_kc
     const size_t slab_b = align_up((size_t)pl.S * p.slab_stride * sizeof(float), 256);
     int S = pl.S;
     const float* src = slab_fold((const float*)ws, S, p.slab_stride, (float*)((char*)ws + slab_b), st);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((tot + Cout + 255) / 256)), dim3(256), 0, st, src,
+    WESUP_LAUNCH(wgrad_reduce_kernel, dim3((unsigned)((tot + Cout + 255) / 256)), dim3(256), 0, st, src,
                        p.slab_stride, dw_kcrs, Cout, Ci, small ? 4 : Ci, pl.Nslab, S, db);
     WESUP_CHECK_LAUNCH();
     return WESUP_OK;

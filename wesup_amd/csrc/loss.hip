@@ -39,7 +39,7 @@ __global__ void classifier_fwd_kernel(const float* __restrict__ feat, const floa
 extern "C" int wesup_classifier_fwd(const float* feat, const float* Wc, const float* bc, float* pred, int R, int D,
                                     void* stream) {
     if (!feat || !Wc || !bc || !pred || R <= 0 || D <= 0) return WESUP_ERR_INVALID;
-    hipLaunchKernelGGL(classifier_fwd_kernel, dim3(ceil_div(R, 256)), dim3(256), 0, (hipStream_t)stream, feat, Wc, bc, pred,
+    WESUP_LAUNCH(classifier_fwd_kernel, dim3(ceil_div(R, 256)), dim3(256), 0, (hipStream_t)stream, feat, Wc, bc, pred,
                        R, D);
     WESUP_CHECK_LAUNCH();
     return WESUP_OK;
@@ -115,9 +115,9 @@ extern "C" int wesup_classifier_bwd(const float* feat, const float* Wc, const fl
     if (ws_bytes < wesup_classifier_bwd_workspace_bytes(R, D)) return WESUP_ERR_WORKSPACE;
     const int nblk = ceil_div(R, CLS_ROWS);
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(classifier_bwd_kernel, dim3(nblk), dim3(256), 0, st, feat, Wc, pred, dpred, dfeat_extra, dfeat,
+    WESUP_LAUNCH(classifier_bwd_kernel, dim3(nblk), dim3(256), 0, st, feat, Wc, pred, dpred, dfeat_extra, dfeat,
                        (float*)ws, R, D);
-    hipLaunchKernelGGL(classifier_bwd_reduce, dim3(ceil_div(2 * D + 2, 64)), dim3(64), 0, st, (const float*)ws, dWc, dbc,
+    WESUP_LAUNCH(classifier_bwd_reduce, dim3(ceil_div(2 * D + 2, 64)), dim3(64), 0, st, (const float*)ws, dWc, dbc,
                        nblk, D);
     WESUP_CHECK_LAUNCH();
     return WESUP_OK;
@@ -224,11 +224,11 @@ extern "C" int wesup_propagate(const float* feat, const float* sp_labels, const 
         return WESUP_ERR_INVALID;
     hipStream_t st = (hipStream_t)stream;
     const long total = (long)B * Kmax * C;
-    hipLaunchKernelGGL(prop_init_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, sp_labels, n_l, y_all,
+    WESUP_LAUNCH(prop_init_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, sp_labels, n_l, y_all,
                        src_idx, max_sim, Kmax, C, total);
     if (enable) {
         const size_t lds = ((size_t)PROP_TILE * (D + 1) + (size_t)PROP_ROWS * D) * sizeof(float);
-        hipLaunchKernelGGL(prop_kernel, dim3(ceil_div(Kmax, PROP_ROWS), B), dim3(256), lds, st, feat, sp_labels, n_sp, n_l,
+        WESUP_LAUNCH(prop_kernel, dim3(ceil_div(Kmax, PROP_ROWS), B), dim3(256), lds, st, feat, sp_labels, n_sp, n_l,
                            threshold, y_all, src_idx, max_sim, Kmax, D, C);
     }
     WESUP_CHECK_LAUNCH();
@@ -294,8 +294,8 @@ extern "C" int wesup_loss_fwd(const float* pred, const float* y_all, const int32
                               float prop_weight, float* terms, float* loss, int B, int Kmax, int C, void* stream) {
     if (!pred || !y_all || !n_sp || !n_l || !terms || !loss || B <= 0 || Kmax <= 0 || C <= 0) return WESUP_ERR_INVALID;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(loss_fwd_kernel, dim3(B), dim3(256), 0, st, pred, y_all, n_sp, n_l, eps, prop_weight, terms, Kmax, C);
-    hipLaunchKernelGGL(loss_mean_kernel, dim3(1), dim3(64), 0, st, (const float*)terms, loss, B);
+    WESUP_LAUNCH(loss_fwd_kernel, dim3(B), dim3(256), 0, st, pred, y_all, n_sp, n_l, eps, prop_weight, terms, Kmax, C);
+    WESUP_LAUNCH(loss_mean_kernel, dim3(1), dim3(64), 0, st, (const float*)terms, loss, B);
     WESUP_CHECK_LAUNCH();
     return WESUP_OK;
 }
@@ -326,7 +326,7 @@ extern "C" int wesup_loss_bwd(const float* pred, const float* y_all, const int32
     if (!pred || !y_all || !n_sp || !n_l || !terms || !dloss || !dpred || B <= 0 || Kmax <= 0 || C <= 0)
         return WESUP_ERR_INVALID;
     const long total = (long)B * Kmax * C;
-    hipLaunchKernelGGL(loss_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, pred,
+    WESUP_LAUNCH(loss_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, pred,
                        y_all, n_sp, n_l, terms, dloss, eps, prop_weight, dpred, B, Kmax, C, total);
     WESUP_CHECK_LAUNCH();
     return WESUP_OK;
@@ -367,7 +367,7 @@ __global__ void ce_bwd_kernel(const float* __restrict__ y_hat, const float* __re
 extern "C" int wesup_cross_entropy_fwd(const float* y_hat, const float* y_true, const float* class_weights, float eps,
                                        float* out2, int n, int C, void* stream) {
     if (!y_hat || !y_true || !out2 || n < 0 || C <= 0) return WESUP_ERR_INVALID;
-    hipLaunchKernelGGL(ce_fwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, y_hat, y_true, class_weights, eps, out2,
+    WESUP_LAUNCH(ce_fwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, y_hat, y_true, class_weights, eps, out2,
                        n, C);
     WESUP_CHECK_LAUNCH();
     return WESUP_OK;
@@ -377,7 +377,7 @@ extern "C" int wesup_cross_entropy_bwd(const float* y_hat, const float* y_true, 
                                        void* stream) {
     if (!y_hat || !y_true || !out2 || !dloss || !dy_hat || n <= 0 || C <= 0) return WESUP_ERR_INVALID;
     const long total = (long)n * C;
-    hipLaunchKernelGGL(ce_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, y_hat,
+    WESUP_LAUNCH(ce_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, y_hat,
                        y_true, class_weights, out2, dloss, eps, dy_hat, total, C);
     WESUP_CHECK_LAUNCH();
     return WESUP_OK;
@@ -421,7 +421,7 @@ extern "C" int wesup_sgd_step(float* p, const float* g, float* v, size_t n, floa
     size_t blocks = (n4 + 255) / 256;
     if (blocks > 2048) blocks = 2048;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(sgd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, v, n, lr, momentum,
+    WESUP_LAUNCH(sgd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, v, n, lr, momentum,
                        weight_decay, grad_scale, first_step);
     WESUP_CHECK_LAUNCH();
     return WESUP_OK;
@@ -472,14 +472,14 @@ extern "C" int wesup_seg_metrics(const float* pred, const uint8_t* mask, float* 
     if (!pred || !mask || !out4 || !ws || B <= 0 || HW <= 0 || C <= 0) return WESUP_ERR_INVALID;
     if (ws_bytes < (size_t)B * SEG_BLOCKS * 4 * sizeof(float)) return WESUP_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(seg_metrics_kernel, dim3(SEG_BLOCKS, B), dim3(256), 0, st, pred, mask, (float*)ws, HW, C);
-    hipLaunchKernelGGL(seg_metrics_reduce, dim3(ceil_div(B * 4, 64)), dim3(64), 0, st, (const float*)ws, out4, B);
+    WESUP_LAUNCH(seg_metrics_kernel, dim3(SEG_BLOCKS, B), dim3(256), 0, st, pred, mask, (float*)ws, HW, C);
+    WESUP_LAUNCH(seg_metrics_reduce, dim3(ceil_div(B * 4, 64)), dim3(64), 0, st, (const float*)ws, out4, B);
     WESUP_CHECK_LAUNCH();
     return WESUP_OK;
 }
 
 // ------------------------------------------------------------------ misc
-extern "C" int wesup_abi_version(void) { return 3; }
+extern "C" int wesup_abi_version(void) { return 4; }
 extern "C" const char* wesup_strerror(int code) {
     switch (code) {
         case WESUP_OK: return "ok";

@@ -25,10 +25,10 @@ extern "C" int wesup_sp_stats(const int32_t* labels, const uint8_t* mask, int B,
     if (!labels || !area || !status || B <= 0 || HW <= 0 || Kmax <= 0 || C <= 0 || B > 65535) return WESUP_ERR_INVALID;
     if (mask && !counts) return WESUP_ERR_INVALID;
     hipStream_t st = (hipStream_t)stream;
-    if (hipMemsetAsync(area, 0, sizeof(int32_t) * (size_t)B * Kmax, st) != hipSuccess) return WESUP_ERR_LAUNCH;
-    if (hipMemsetAsync(status, 0, sizeof(int32_t) * (size_t)B, st) != hipSuccess) return WESUP_ERR_LAUNCH;
-    if (counts && hipMemsetAsync(counts, 0, sizeof(int32_t) * (size_t)B * Kmax * C, st) != hipSuccess) return WESUP_ERR_LAUNCH;
-    hipLaunchKernelGGL(sp_stats_kernel, dim3((unsigned)((HW + 255) / 256), B), dim3(256), 0, st, labels, mask, area, counts,
+    if (wesup_fill_words_(area, 0u, (sizeof(int32_t) * (size_t)B * Kmax) / 4, st) != WESUP_OK) return WESUP_ERR_LAUNCH;
+    if (wesup_fill_words_(status, 0u, (sizeof(int32_t) * (size_t)B) / 4, st) != WESUP_OK) return WESUP_ERR_LAUNCH;
+    if (counts && wesup_fill_words_(counts, 0u, (sizeof(int32_t) * (size_t)B * Kmax * C) / 4, st) != WESUP_OK) return WESUP_ERR_LAUNCH;
+    WESUP_LAUNCH(sp_stats_kernel, dim3((unsigned)((HW + 255) / 256), B), dim3(256), 0, st, labels, mask, area, counts,
                        status, HW, C, Kmax);
     WESUP_CHECK_LAUNCH();
     return WESUP_OK;
@@ -150,7 +150,7 @@ __global__ void softmax_ce_bwd_kernel(const float* __restrict__ probs, const flo
 extern "C" int wesup_softmax_ce_fwd(const float* logits, const float* y_true, const float* class_weights, float eps,
                                     float* probs, float* out2, int n, int C, void* stream) {
     if (!logits || !y_true || !probs || !out2 || n < 0 || C <= 0) return WESUP_ERR_INVALID;
-    hipLaunchKernelGGL(softmax_ce_fwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, logits, y_true, class_weights, eps,
+    WESUP_LAUNCH(softmax_ce_fwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, logits, y_true, class_weights, eps,
                        probs, out2, n, C);
     WESUP_CHECK_LAUNCH();
     return WESUP_OK;
@@ -158,7 +158,7 @@ extern "C" int wesup_softmax_ce_fwd(const float* logits, const float* y_true, co
 extern "C" int wesup_softmax_ce_bwd(const float* probs, const float* y_true, const float* class_weights, const float* out2,
                                     const float* dloss, float eps, float* dlogits, int n, int C, void* stream) {
     if (!probs || !y_true || !out2 || !dloss || !dlogits || n <= 0 || C <= 0) return WESUP_ERR_INVALID;
-    hipLaunchKernelGGL(softmax_ce_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, probs,
+    WESUP_LAUNCH(softmax_ce_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, probs,
                        y_true, class_weights, out2, dloss, eps, dlogits, n, C);
     WESUP_CHECK_LAUNCH();
     return WESUP_OK;

@@ -312,12 +312,12 @@ extern "C" int wesup_slic(const float* img_nchw, int32_t* labels, int32_t* n_lab
 
     const long tot = (long)B * HW;
     const unsigned pb = (unsigned)((tot + 255) / 256);
-    hipLaunchKernelGGL(slic_lab_kernel, dim3(pb), dim3(256), 0, st, img_nchw, lab, B, HW, 1.f / compactness);
-    hipLaunchKernelGGL(slic_init_kernel, dim3(ceil_div(B * Kc, 256)), dim3(256), 0, st, lab, cen, g, B);
-    if (hipMemsetAsync(sums, 0, (size_t)B * Kc * 6 * 8, st) != hipSuccess) return WESUP_ERR_LAUNCH;
+    WESUP_LAUNCH(slic_lab_kernel, dim3(pb), dim3(256), 0, st, img_nchw, lab, B, HW, 1.f / compactness);
+    WESUP_LAUNCH(slic_init_kernel, dim3(ceil_div(B * Kc, 256)), dim3(256), 0, st, lab, cen, g, B);
+    if (wesup_fill_words_(sums, 0u, ((size_t)B * Kc * 6 * 8) / 4, st) != WESUP_OK) return WESUP_ERR_LAUNCH;
     for (int it = 0; it < max_iter; ++it) {
-        hipLaunchKernelGGL(slic_assign_kernel, dim3(pb), dim3(256), 0, st, lab, cen, clabel, sums, g, B, 1);
-        hipLaunchKernelGGL(slic_update_kernel, dim3(ceil_div(B * Kc, 256)), dim3(256), 0, st, cen, sums, B * Kc);
+        WESUP_LAUNCH(slic_assign_kernel, dim3(pb), dim3(256), 0, st, lab, cen, clabel, sums, g, B, 1);
+        WESUP_LAUNCH(slic_update_kernel, dim3(ceil_div(B * Kc, 256)), dim3(256), 0, st, cen, sums, B * Kc);
     }
     if (!enforce_connectivity) {
         // raw k-means labels: ids are centre indices (not necessarily all used)
@@ -326,16 +326,16 @@ extern "C" int wesup_slic(const float* img_nchw, int32_t* labels, int32_t* n_lab
         return WESUP_OK;
     }
     const int min_size = (int)(min_size_factor * (float)HW / (float)n_segments);
-    hipLaunchKernelGGL(ccl_init_kernel, dim3(pb), dim3(256), 0, st, parent, tot, HW);
-    if (hipMemsetAsync(size, 0, (size_t)tot * 4, st) != hipSuccess) return WESUP_ERR_LAUNCH;
-    hipLaunchKernelGGL(ccl_merge_kernel, dim3(pb), dim3(256), 0, st, clabel, parent, H, W, B);
-    hipLaunchKernelGGL(ccl_flatten_kernel, dim3(pb), dim3(256), 0, st, parent, size, HW, B);
-    hipLaunchKernelGGL(ccl_absorb_kernel, dim3(pb), dim3(256), 0, st, parent, size, target, W, HW, B, min_size);
-    hipLaunchKernelGGL(ccl_resolve_kernel, dim3(pb), dim3(256), 0, st, parent, target, final_root, is_root, HW, B);
-    hipLaunchKernelGGL(scan_block_sums, dim3(nblk, B), dim3(SCAN_BLOCK), 0, st, is_root, bsum, HW, nblk);
-    hipLaunchKernelGGL(scan_of_block_sums, dim3(B), dim3(64), 0, st, bsum, n_labels, nblk);
-    hipLaunchKernelGGL(scan_apply, dim3(nblk, B), dim3(SCAN_BLOCK), 0, st, is_root, bsum, newid, HW, nblk);
-    hipLaunchKernelGGL(relabel_kernel, dim3(pb), dim3(256), 0, st, final_root, newid, labels, HW, B);
+    WESUP_LAUNCH(ccl_init_kernel, dim3(pb), dim3(256), 0, st, parent, tot, HW);
+    if (wesup_fill_words_(size, 0u, ((size_t)tot * 4) / 4, st) != WESUP_OK) return WESUP_ERR_LAUNCH;
+    WESUP_LAUNCH(ccl_merge_kernel, dim3(pb), dim3(256), 0, st, clabel, parent, H, W, B);
+    WESUP_LAUNCH(ccl_flatten_kernel, dim3(pb), dim3(256), 0, st, parent, size, HW, B);
+    WESUP_LAUNCH(ccl_absorb_kernel, dim3(pb), dim3(256), 0, st, parent, size, target, W, HW, B, min_size);
+    WESUP_LAUNCH(ccl_resolve_kernel, dim3(pb), dim3(256), 0, st, parent, target, final_root, is_root, HW, B);
+    WESUP_LAUNCH(scan_block_sums, dim3(nblk, B), dim3(SCAN_BLOCK), 0, st, is_root, bsum, HW, nblk);
+    WESUP_LAUNCH(scan_of_block_sums, dim3(B), dim3(64), 0, st, bsum, n_labels, nblk);
+    WESUP_LAUNCH(scan_apply, dim3(nblk, B), dim3(SCAN_BLOCK), 0, st, is_root, bsum, newid, HW, nblk);
+    WESUP_LAUNCH(relabel_kernel, dim3(pb), dim3(256), 0, st, final_root, newid, labels, HW, B);
     WESUP_CHECK_LAUNCH();
     return WESUP_OK;
 }

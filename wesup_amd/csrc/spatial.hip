@@ -14,7 +14,7 @@ __global__ void pack_input_kernel(const float* __restrict__ img, float* __restri
 extern "C" int wesup_pack_input(const float* img, float* out, int B, int H, int W, void* stream) {
     if (!img || !out || B <= 0 || H <= 0 || W <= 0) return WESUP_ERR_INVALID;
     const long tot = (long)B * H * W;
-    hipLaunchKernelGGL(pack_input_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, img,
+    WESUP_LAUNCH(pack_input_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, img,
                        out, B, (long)H * W);
     WESUP_CHECK_LAUNCH();
     return WESUP_OK;
@@ -59,10 +59,10 @@ extern "C" int wesup_pack_conv3x3_weight(const float* w, float* w_fwd, float* w_
     hipStream_t st = (hipStream_t)stream;
     long tot = (long)Co * Cip;
     if (w_fwd)
-        hipLaunchKernelGGL(pack_w_fwd_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, w, w_fwd, Co, Ci, Cip, Kf);
+        WESUP_LAUNCH(pack_w_fwd_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, w, w_fwd, Co, Ci, Cip, Kf);
     if (w_dgrad) {
         tot = (long)Co * Ci;
-        hipLaunchKernelGGL(pack_w_dgrad_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, w, w_dgrad, Co, Ci);
+        WESUP_LAUNCH(pack_w_dgrad_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, w, w_dgrad, Co, Ci);
     }
     WESUP_CHECK_LAUNCH();
     return WESUP_OK;
@@ -85,8 +85,56 @@ __global__ void transpose_kernel(const float* __restrict__ in, float* __restrict
 }
 extern "C" int wesup_transpose(const float* in, float* out, int rows, int cols, void* stream) {
     if (!in || !out || rows <= 0 || cols <= 0) return WESUP_ERR_INVALID;
-    hipLaunchKernelGGL(transpose_kernel, dim3(ceil_div(cols, 32), ceil_div(rows, 32)), dim3(256), 0,
+    WESUP_LAUNCH(transpose_kernel, dim3(ceil_div(cols, 32), ceil_div(rows, 32)), dim3(256), 0,
                        (hipStream_t)stream, in, out, rows, cols);
+    WESUP_CHECK_LAUNCH();
+    return WESUP_OK;
+}
+
+// Several transposes in one launch (the step's 13 side-conv and 3 fc weight panels for the input-gradient GEMMs, the
+// interpolation-pooling matrices of a batch): a block finds its item by a scan of the tile ranges.
+#define TRANSPOSE_MAX 40
+struct TransposeBatch {
+    const float* in[TRANSPOSE_MAX];
+    float* out[TRANSPOSE_MAX];
+    int rows[TRANSPOSE_MAX], cols[TRANSPOSE_MAX];
+    int first[TRANSPOSE_MAX + 1];
+    int n;
+};
+__global__ void transpose_batched_kernel(const TransposeBatch p) {
+    __shared__ float t[32][33];
+    int j = 0;
+    while (j + 1 < p.n && (int)blockIdx.x >= p.first[j + 1]) ++j;
+    const int rows = p.rows[j], cols = p.cols[j];
+    const int tcols = (cols + 31) / 32, tile = blockIdx.x - p.first[j];
+    const int c0 = (tile % tcols) * 32, r0 = (tile / tcols) * 32;
+    const float* __restrict__ in = p.in[j];
+    float* __restrict__ out = p.out[j];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int k = ty; k < 32; k += 8) {
+        const int r = r0 + k, c = c0 + tx;
+        t[k][tx] = (r < rows && c < cols) ? in[(long)r * cols + c] : 0.f;
+    }
+    __syncthreads();
+    for (int k = ty; k < 32; k += 8) {
+        const int c = c0 + k, r = r0 + tx;
+        if (r < rows && c < cols) out[(long)c * rows + r] = t[tx][k];
+    }
+}
+extern "C" int wesup_transpose_batched(const WesupTransposeItem* items /* host */, int n, void* stream) {
+    if (!items || n <= 0 || n > TRANSPOSE_MAX) return WESUP_ERR_INVALID;
+    TransposeBatch p = {};
+    long blocks = 0;
+    for (int i = 0; i < n; ++i) {
+        if (!items[i].in || !items[i].out || items[i].rows <= 0 || items[i].cols <= 0) return WESUP_ERR_INVALID;
+        p.in[i] = items[i].in; p.out[i] = items[i].out; p.rows[i] = items[i].rows; p.cols[i] = items[i].cols;
+        p.first[i] = (int)blocks;
+        blocks += (long)ceil_div(items[i].rows, 32) * ceil_div(items[i].cols, 32);
+        if (blocks >= (1l << 30)) return WESUP_ERR_INVALID;
+    }
+    p.first[n] = (int)blocks;
+    p.n = n;
+    WESUP_LAUNCH(transpose_batched_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
     WESUP_CHECK_LAUNCH();
     return WESUP_OK;
 }
@@ -115,7 +163,7 @@ __global__ void maxpool_fwd_kernel(const float* __restrict__ y, float* __restric
 extern "C" int wesup_maxpool2_fwd(const float* y, float* yp, int B, int H, int W, int C, int relu_out, void* stream) {
     if (!y || !yp || B <= 0 || H < 2 || W < 2 || (C % 4)) return WESUP_ERR_INVALID;
     const long tot = (long)B * (H / 2) * (W / 2) * (C / 4);
-    hipLaunchKernelGGL(maxpool_fwd_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, y, yp,
+    WESUP_LAUNCH(maxpool_fwd_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, y, yp,
                        B, H, W, C / 4, relu_out);
     WESUP_CHECK_LAUNCH();
     return WESUP_OK;
@@ -166,7 +214,7 @@ extern "C" int wesup_maxpool2_bwd(const float* y, const float* dyp, float* dy, i
                                   int accumulate, void* stream) {
     if (!y || !dyp || !dy || B <= 0 || H < 2 || W < 2 || (C % 4)) return WESUP_ERR_INVALID;
     const long tot = (long)B * H * W * (C / 4);
-    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, y, dyp,
+    WESUP_LAUNCH(maxpool_bwd_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, y, dyp,
                        dy, B, H, W, C / 4, accumulate);
     WESUP_CHECK_LAUNCH();
     return WESUP_OK;
@@ -218,7 +266,7 @@ extern "C" int wesup_upsample_fwd(const float* s, float* fm, int B, int h, int w
     if (!s || !fm || B <= 0 || h <= 0 || w <= 0 || H <= 0 || W <= 0 || (C % 4) || (ldf % 4) || (coff % 4))
         return WESUP_ERR_INVALID;
     const long tot = (long)B * H * W * (C / 4);
-    hipLaunchKernelGGL(upsample_fwd_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, s, fm,
+    WESUP_LAUNCH(upsample_fwd_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, s, fm,
                        B, h, w, H, W, C / 4, ldf, coff, ac_scale(h, H), ac_scale(w, W));
     WESUP_CHECK_LAUNCH();
     return WESUP_OK;
@@ -484,11 +532,11 @@ extern "C" int wesup_upsample_bwd_group(const float* g0, const float* g1, const 
     const float sh = ac_scale(h, H), sw = ac_scale(w, W);
     hipStream_t st = (hipStream_t)stream;
     if (npass == 1)
-        hipLaunchKernelGGL(upsample_bwd_cell_group_kernel<1>, grid, dim3(256), 0, st, G, new_row, area_new, B, h, w, H, W, Kmax, sh, sw);
+        WESUP_LAUNCH(upsample_bwd_cell_group_kernel<1>, grid, dim3(256), 0, st, G, new_row, area_new, B, h, w, H, W, Kmax, sh, sw);
     else if (npass == 2)
-        hipLaunchKernelGGL(upsample_bwd_cell_group_kernel<2>, grid, dim3(256), 0, st, G, new_row, area_new, B, h, w, H, W, Kmax, sh, sw);
+        WESUP_LAUNCH(upsample_bwd_cell_group_kernel<2>, grid, dim3(256), 0, st, G, new_row, area_new, B, h, w, H, W, Kmax, sh, sw);
     else
-        hipLaunchKernelGGL(upsample_bwd_cell_group_kernel<3>, grid, dim3(256), 0, st, G, new_row, area_new, B, h, w, H, W, Kmax, sh, sw);
+        WESUP_LAUNCH(upsample_bwd_cell_group_kernel<3>, grid, dim3(256), 0, st, G, new_row, area_new, B, h, w, H, W, Kmax, sh, sw);
     WESUP_CHECK_LAUNCH();
     return WESUP_OK;
 }
@@ -501,20 +549,20 @@ extern "C" int wesup_upsample_bwd(const float* dfm_or_g, const int32_t* new_row,
     const long tot = (long)B * h * w * (C / 4);
     const dim3 grid((unsigned)((tot + 255) / 256));
     if (new_row && h == H && w == W)
-        hipLaunchKernelGGL(upsample_bwd_ident_kernel, grid, dim3(256), 0, (hipStream_t)stream, dfm_or_g, new_row, area_new, ds,
+        WESUP_LAUNCH(upsample_bwd_ident_kernel, grid, dim3(256), 0, (hipStream_t)stream, dfm_or_g, new_row, area_new, ds,
                            (long)B * H * W, H * W, C / 4, ldf, coff, Kmax);
     else if (new_row && C / 4 > 64 && C <= 768 && ldf == C && coff == 0)      // wide dense rows: the cell kernel in passes of 64 quads
         return wesup_upsample_bwd_group(dfm_or_g, nullptr, nullptr, ds, nullptr, nullptr, C, 0, 0, 1, new_row, area_new, B, h, w, H,
                                         W, Kmax, stream);
     else if (new_row && C / 4 <= 64)
-        hipLaunchKernelGGL(upsample_bwd_cell_kernel, dim3((unsigned)(((long)B * h * w + 3) / 4)), dim3(256), 0,
+        WESUP_LAUNCH(upsample_bwd_cell_kernel, dim3((unsigned)(((long)B * h * w + 3) / 4)), dim3(256), 0,
                            (hipStream_t)stream, dfm_or_g, new_row, area_new, ds, B, h, w, H, W, C / 4, ldf, coff, Kmax,
                            ac_scale(h, H), ac_scale(w, W));
     else if (new_row)
-        hipLaunchKernelGGL(upsample_bwd_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, dfm_or_g, new_row, area_new,
+        WESUP_LAUNCH(upsample_bwd_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, dfm_or_g, new_row, area_new,
                            ds, B, h, w, H, W, C / 4, ldf, coff, Kmax, ac_scale(h, H), ac_scale(w, W));
     else
-        hipLaunchKernelGGL(upsample_bwd_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, dfm_or_g, new_row, area_new,
+        WESUP_LAUNCH(upsample_bwd_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, dfm_or_g, new_row, area_new,
                            ds, B, h, w, H, W, C / 4, ldf, coff, Kmax, ac_scale(h, H), ac_scale(w, W));
     WESUP_CHECK_LAUNCH();
     return WESUP_OK;

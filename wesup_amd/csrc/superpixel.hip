@@ -7,38 +7,28 @@
 // load instruction of a wave is 1 KiB contiguous, there are no atomics, and the summation order is fixed
 // (ascending pixel index), so results are bitwise reproducible.
 #include "common.hpp"
+#include <mutex>
 
 #define SP_CHUNK 2048            // pixels per counting-sort chunk
 #define SP_MAX_K 16384           // LDS histogram capacity (ids per image)
+#define SP_SEG 512               // pixels per pooling segment (see the scatter-mean kernels)
 
-// ------------------------------------------------------------------ 1. per-chunk histograms (+ class counts)
-__global__ void sp_hist_kernel(const int32_t* __restrict__ labels, const uint8_t* __restrict__ mask, int HW, int C,
-                               int Kmax, int nchunk, int32_t* __restrict__ chunk_hist, int32_t* __restrict__ cnt,
-                               int32_t* __restrict__ nmax, int32_t* __restrict__ status) {
-    extern __shared__ int32_t hist[];
-    const int b = blockIdx.y, g = blockIdx.x;
-    for (int i = threadIdx.x; i < Kmax; i += blockDim.x) hist[i] = 0;
-    __syncthreads();
-    const int p0 = g * SP_CHUNK, p1 = min(HW, p0 + SP_CHUNK);
-    int lmax = 0;
-    for (int p = p0 + threadIdx.x; p < p1; p += blockDim.x) {
-        const int l = labels[(long)b * HW + p];
-        if (l < 0 || l >= Kmax) {
-            atomicOr(&status[b], 1);
-            continue;
-        }
-        atomicAdd(&hist[l], 1);
-        lmax = max(lmax, l + 1);
-        if (mask) {
-            for (int c = 0; c < C; ++c)
-                if (mask[((long)b * C + c) * HW + p]) atomicAdd(&cnt[((long)b * Kmax + l) * C + c], 1);
-        }
-    }
-    if (lmax) atomicMax(&nmax[b], lmax);
-    __syncthreads();
-    int32_t* out = chunk_hist + ((long)b * nchunk + g) * Kmax;
-    for (int i = threadIdx.x; i < Kmax; i += blockDim.x) out[i] = hist[i];
-}
+// ------------------------------------------------------------------ preprocessing in two launches
+// Launch 1, sp_count_order_kernel: one block per 2048-pixel chunk builds the chunk's histogram and class counts in LDS (no
+// global atomics, nothing to zero beforehand) and stores them; the LAST block of an image to finish -- told by an arrival
+// ticket -- then does the per-image part alone: areas, the reference ordering, row starts, the chunk bases of the stable
+// counting sort and the segment table.  Launch 2, sp_place_kernel: one wave per chunk places the pixels.
+// (Round 3 ran this as three memsets and five launches, 0.31 ms inside the step for 0.16 ms of work.)
+//
+// The hand-off inside launch 1 is the split-K "last arriver" recipe of cdna_hip_programming.md 5 (item 2): every wave drains
+// its stores, the block meets, lane 0 releases at agent scope, waits, and draws a ticket; the block that draws the last one
+// acquires at agent scope before anybody in it reads the other blocks' chunk rows.  Correct for any placement of the blocks.
+// The tickets live in a zero-initialised __device__ array of the library (a workspace handed in by the caller has unknown
+// content) and the last arriver puts its ticket back to zero; calls that may overlap on different streams use different
+// rows of it (one row per stream).
+#define SP_TICKET_ROWS 64
+#define SP_TICKET_B 256
+__device__ int32_t g_sp_ticket[SP_TICKET_ROWS][SP_TICKET_B];
 
 // block-wide exclusive scan of one int per thread (1024 threads); returns the exclusive prefix, total in *total
 __device__ int block_excl_scan(int v, int* total, int* sh /*[1024]*/) {
@@ -57,38 +47,81 @@ __device__ int block_excl_scan(int v, int* total, int* sh /*[1024]*/) {
     return incl - v;
 }
 
-// ------------------------------------------------------------------ 2. ordering (one block per image)
-// rows: labelled ids ascending, then unlabelled ids ascending (models/wesup.py:45-47); label = multi-hot
-// of the classes whose pixel count equals the row maximum (models/wesup.py:50-52, integer form).
-__global__ __launch_bounds__(1024) void sp_order_kernel(const int32_t* __restrict__ chunk_hist,
-                                                        const int32_t* __restrict__ cnt, const int32_t* __restrict__ nmax,
-                                                        int nchunk, int C, int Kmax, int HW, int has_mask,
-                                                        int32_t* __restrict__ n_sp, int32_t* __restrict__ n_l,
-                                                        int32_t* __restrict__ perm, int32_t* __restrict__ inv_perm,
-                                                        int32_t* __restrict__ area_new, float* __restrict__ sp_labels,
-                                                        int32_t* __restrict__ row_start, int32_t* __restrict__ area_old,
-                                                        int32_t* __restrict__ status) {
-    __shared__ int sh[1024];
-    const int b = blockIdx.x, tid = threadIdx.x;
-    const int n = min(nmax[b], Kmax);
+struct SpPre {
+    const int32_t* labels;
+    const uint8_t* mask;
+    int HW, C, Kmax, nchunk, Umax;
+    int32_t* chunk_hist;     // [B][nchunk][Kmax]: histogram, later the chunk's base inside each row
+    int32_t* chunk_cnt;      // [B][nchunk][Kmax * C] class counts per chunk (mask given)
+    int32_t* chunk_info;     // [B][nchunk][2] {largest id + 1, status bits}
+    int32_t* cnt;            // [B][Kmax * C] summed over the chunks
+    int32_t* area_old;       // [B][Kmax]
+    int32_t *n_sp, *n_l, *perm, *inv_perm, *area_new, *row_start, *status, *seg_start, *unit_row;
+    float* sp_labels;
+    int32_t* ticket;         // [B]
+};
+
+// rows: labelled ids ascending, then unlabelled ids ascending (models/wesup.py:45-47); label = multi-hot of the classes whose
+// pixel count equals the row maximum (models/wesup.py:50-52, integer form).  One block of 1024 threads per image.
+__device__ void sp_order_image(const SpPre& p, int b, int* sh /*[1024]*/) {
+    const int tid = threadIdx.x, Kmax = p.Kmax, C = p.C, nchunk = p.nchunk;
+    const bool has_mask = p.mask != nullptr;
+    const int32_t* hist = p.chunk_hist + (long)b * nchunk * Kmax;
+    const int32_t* ccnt = p.chunk_cnt + (long)b * nchunk * Kmax * C;
+    int32_t* cnt = p.cnt + (long)b * Kmax * C;
+    int32_t* area_old = p.area_old + (long)b * Kmax;
+    // largest id and status over the chunks
+    int lm = 0, stat = 0;
+    for (int g = tid; g < nchunk; g += 1024) {
+        lm = max(lm, p.chunk_info[((long)b * nchunk + g) * 2]);
+        stat |= p.chunk_info[((long)b * nchunk + g) * 2 + 1];
+    }
+    sh[tid] = lm;
+    __syncthreads();
+    for (int off = 512; off > 0; off >>= 1) {
+        if (tid < off) sh[tid] = max(sh[tid], sh[tid + off]);
+        __syncthreads();
+    }
+    const int n = min(sh[0], Kmax);
+    __syncthreads();
+    sh[tid] = stat;
+    __syncthreads();
+    for (int off = 512; off > 0; off >>= 1) {
+        if (tid < off) sh[tid] |= sh[tid + off];
+        __syncthreads();
+    }
+    stat = sh[0];
+    __syncthreads();
     const int per = (Kmax + 1023) / 1024;
-    const int i0 = tid * per, i1 = min(Kmax, i0 + per);
-    // areas by old id (sum of chunk histograms)
+    const int i0 = min(Kmax, tid * per), i1 = min(Kmax, i0 + per);
+    // areas and class counts by old id (sums over the chunks)
     int nlab = 0;
     bool empty = false;
     for (int i = i0; i < i1; ++i) {
         int a = 0;
-        for (int g = 0; g < nchunk; ++g) a += chunk_hist[((long)b * nchunk + g) * Kmax + i];
-        area_old[(long)b * Kmax + i] = a;
+        for (int g = 0; g < nchunk; ++g) a += hist[(long)g * Kmax + i];
+        area_old[i] = a;
+        int s = 0;
+        if (has_mask)
+            for (int c = 0; c < C; ++c) {
+                int v = 0;
+                for (int g = 0; g < nchunk; ++g) v += ccnt[((long)g * Kmax + i) * C + c];
+                cnt[i * C + c] = v;
+                s += v;
+            }
         if (i < n) {
             if (a == 0) empty = true;
-            int s = 0;
-            if (has_mask)
-                for (int c = 0; c < C; ++c) s += cnt[((long)b * Kmax + i) * C + c];
             if (s > 0) ++nlab;
         }
     }
-    if (empty) atomicOr(&status[b], 2);
+    sh[tid] = empty ? 1 : 0;
+    __syncthreads();
+    for (int off = 512; off > 0; off >>= 1) {
+        if (tid < off) sh[tid] |= sh[tid + off];
+        __syncthreads();
+    }
+    if (tid == 0) p.status[b] = stat | (sh[0] ? 2 : 0);
+    __syncthreads();
     int total_l;
     const int pre_l = block_excl_scan(nlab, &total_l, sh);
     // second pass: assign rows
@@ -99,59 +132,141 @@ __global__ __launch_bounds__(1024) void sp_order_kernel(const int32_t* __restric
             int s = 0, mx = 0;
             if (has_mask)
                 for (int c = 0; c < C; ++c) {
-                    const int v = cnt[((long)b * Kmax + i) * C + c];
+                    const int v = cnt[i * C + c];
                     s += v;
                     mx = max(mx, v);
                 }
             if (s > 0) {
                 row = rl++;
-                for (int c = 0; c < C; ++c)
-                    sp_labels[((long)b * Kmax + row) * C + c] = (cnt[((long)b * Kmax + i) * C + c] == mx) ? 1.f : 0.f;
+                for (int c = 0; c < C; ++c) p.sp_labels[((long)b * Kmax + row) * C + c] = (cnt[i * C + c] == mx) ? 1.f : 0.f;
             } else {
                 row = ru++;
-                for (int c = 0; c < C; ++c) sp_labels[((long)b * Kmax + row) * C + c] = 0.f;
+                for (int c = 0; c < C; ++c) p.sp_labels[((long)b * Kmax + row) * C + c] = 0.f;
             }
         } else {
             row = i;      // padding rows keep their place, area 0
-            for (int c = 0; c < C; ++c) sp_labels[((long)b * Kmax + row) * C + c] = 0.f;
+            for (int c = 0; c < C; ++c) p.sp_labels[((long)b * Kmax + row) * C + c] = 0.f;
         }
-        perm[(long)b * Kmax + row] = i;
-        inv_perm[(long)b * Kmax + i] = row;
-        area_new[(long)b * Kmax + row] = area_old[(long)b * Kmax + i];
+        p.perm[(long)b * Kmax + row] = i;
+        p.inv_perm[(long)b * Kmax + i] = row;
+        p.area_new[(long)b * Kmax + row] = area_old[i];
     }
     if (tid == 0) {
-        n_sp[b] = n;
-        n_l[b] = total_l;
+        p.n_sp[b] = n;
+        p.n_l[b] = total_l;
     }
-    __syncthreads();
+    __syncthreads();      // (area_new of this image: written and read by this block)
     // row_start = exclusive scan of area_new over rows
+    int32_t* rs = p.row_start + (long)b * (Kmax + 1);
     int asum = 0;
-    for (int r = i0; r < i1; ++r) asum += area_new[(long)b * Kmax + r];
+    for (int r = i0; r < i1; ++r) asum += p.area_new[(long)b * Kmax + r];
     int tot;
     int pre = block_excl_scan(asum, &tot, sh);
     for (int r = i0; r < i1; ++r) {
-        row_start[(long)b * (Kmax + 1) + r] = pre;
-        pre += area_new[(long)b * Kmax + r];
+        rs[r] = pre;
+        pre += p.area_new[(long)b * Kmax + r];
     }
-    if (tid == 1023) row_start[(long)b * (Kmax + 1) + Kmax] = tot;
+    if (tid == 1023) rs[Kmax] = tot;
+    __syncthreads();
+    // chunk bases: where chunk g starts inside the row of old id i (in place of the histogram)
+    for (int i = i0; i < i1; ++i) {
+        int run = rs[p.inv_perm[(long)b * Kmax + i]];
+        for (int g = 0; g < nchunk; ++g) {
+            int32_t* h = p.chunk_hist + ((long)b * nchunk + g) * Kmax + i;
+            const int v = *h;
+            *h = run;
+            run += v;
+        }
+    }
+    // segment table (rows cut into <= SP_SEG-pixel segments) for the load-balanced pooling kernels
+    if (p.seg_start) {
+        int c = 0;
+        for (int r = i0; r < i1; ++r) c += max(1, (rs[r + 1] - rs[r] + SP_SEG - 1) / SP_SEG);
+        int total;
+        int ps = block_excl_scan(c, &total, sh);
+        for (int r = i0; r < i1; ++r) {
+            const int k = max(1, (rs[r + 1] - rs[r] + SP_SEG - 1) / SP_SEG);
+            p.seg_start[(long)b * (Kmax + 1) + r] = ps;
+            for (int j = 0; j < k && ps + j < p.Umax; ++j) p.unit_row[(long)b * p.Umax + ps + j] = r;
+            ps += k;
+        }
+        if (tid == 1023) p.seg_start[(long)b * (Kmax + 1) + Kmax] = min(total, p.Umax);
+    }
 }
 
-// ------------------------------------------------------------------ 3. chunk bases: where chunk g starts inside each row
-__global__ void sp_chunk_base_kernel(int32_t* __restrict__ chunk_hist, const int32_t* __restrict__ inv_perm,
-                                     const int32_t* __restrict__ row_start, int nchunk, int Kmax) {
-    const int b = blockIdx.y;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= Kmax) return;
-    int run = row_start[(long)b * (Kmax + 1) + inv_perm[(long)b * Kmax + i]];
-    for (int g = 0; g < nchunk; ++g) {
-        int32_t* h = chunk_hist + ((long)b * nchunk + g) * Kmax + i;
-        const int v = *h;
-        *h = run;
-        run += v;
+__global__ __launch_bounds__(1024) void sp_count_order_kernel(const SpPre p) {
+    extern __shared__ int32_t lds[];      // [1024] scan / flags, [Kmax] histogram, [Kmax * C] class counts
+    int32_t* sh = lds;
+    int32_t* hist = lds + 1024;
+    int32_t* lcnt = hist + p.Kmax;
+    const int b = blockIdx.y, g = blockIdx.x, tid = threadIdx.x;
+    const int Kmax = p.Kmax, C = p.C, HW = p.HW;
+    const bool has_mask = p.mask != nullptr;
+    for (int i = tid; i < Kmax * (has_mask ? 1 + C : 1); i += 1024) hist[i] = 0;
+    __syncthreads();
+    const int p0 = g * SP_CHUNK, p1 = min(HW, p0 + SP_CHUNK);
+    int lmax = 0, bad = 0;
+    for (int q = p0 + tid; q < p1; q += 1024) {
+        const int l = p.labels[(long)b * HW + q];
+        if (l < 0 || l >= Kmax) {
+            bad = 1;
+            continue;
+        }
+        atomicAdd(&hist[l], 1);
+        lmax = max(lmax, l + 1);
+        if (has_mask)
+            for (int c = 0; c < C; ++c)
+                if (p.mask[((long)b * C + c) * HW + q]) atomicAdd(&lcnt[l * C + c], 1);
     }
+    sh[tid] = lmax;
+    __syncthreads();
+    for (int off = 512; off > 0; off >>= 1) {
+        if (tid < off) sh[tid] = max(sh[tid], sh[tid + off]);
+        __syncthreads();
+    }
+    lmax = sh[0];
+    __syncthreads();
+    sh[tid] = bad;
+    __syncthreads();
+    for (int off = 512; off > 0; off >>= 1) {
+        if (tid < off) sh[tid] |= sh[tid + off];
+        __syncthreads();
+    }
+    bad = sh[0];
+    __syncthreads();
+    int32_t* oh = p.chunk_hist + ((long)b * p.nchunk + g) * Kmax;
+    for (int i = tid; i < Kmax; i += 1024) oh[i] = hist[i];
+    if (has_mask) {
+        int32_t* oc = p.chunk_cnt + ((long)b * p.nchunk + g) * Kmax * C;
+        for (int i = tid; i < Kmax * C; i += 1024) oc[i] = lcnt[i];
+    }
+    if (tid == 0) {
+        p.chunk_info[((long)b * p.nchunk + g) * 2] = lmax;
+        p.chunk_info[((long)b * p.nchunk + g) * 2 + 1] = bad;
+    }
+    // ---- arrival: the image's last chunk block does the per-image part
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const int old = __hip_atomic_fetch_add(&p.ticket[b], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = old == p.nchunk - 1;
+        if (last) {
+            __hip_atomic_store(&p.ticket[b], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next call
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        sh[0] = last;
+    }
+    __syncthreads();
+    const int last = sh[0];
+    __syncthreads();
+    if (!last) return;
+    sp_order_image(p, b, sh);
 }
 
-// ------------------------------------------------------------------ 4. stable placement: one wave per chunk
+// ------------------------------------------------------------------ stable placement: one wave per chunk
 __global__ __launch_bounds__(64) void sp_place_kernel(const int32_t* __restrict__ labels,
                                                       const int32_t* __restrict__ chunk_base,
                                                       const int32_t* __restrict__ inv_perm, int HW, int Kmax, int nchunk,
@@ -190,44 +305,73 @@ __global__ __launch_bounds__(64) void sp_place_kernel(const int32_t* __restrict_
 extern "C" size_t wesup_sp_preprocess_workspace_bytes(int B, int HW, int C, int Kmax) {
     if (B <= 0 || HW <= 0 || Kmax <= 0) return 0;
     const size_t nchunk = (HW + SP_CHUNK - 1) / SP_CHUNK;
+    const size_t Cc = C > 0 ? C : 1;
     size_t bytes = align_up((size_t)B * nchunk * Kmax * 4, 256);     // chunk_hist / chunk_base
-    bytes += align_up((size_t)B * Kmax * (C > 0 ? C : 1) * 4, 256);  // cnt
+    bytes += align_up((size_t)B * nchunk * Kmax * Cc * 4, 256);      // class counts per chunk
+    bytes += align_up((size_t)B * nchunk * 2 * 4, 256);               // {largest id + 1, status} per chunk
+    bytes += align_up((size_t)B * Kmax * Cc * 4, 256);                // cnt
     bytes += align_up((size_t)B * Kmax * 4, 256);                     // area by old id
-    bytes += align_up((size_t)B * 4, 256);                            // nmax
     return bytes;
 }
+
+extern "C" int wesup_sp_max_units(int HW, int Kmax) { return (HW > 0 && Kmax > 0) ? Kmax + HW / SP_SEG : 0; }
 
 extern "C" int wesup_sp_preprocess(const int32_t* labels, const uint8_t* mask, int B, int HW, int C, int Kmax,
                                    int32_t* n_sp, int32_t* n_l, int32_t* perm, int32_t* inv_perm, int32_t* area_new,
                                    float* sp_labels, int32_t* new_row, int32_t* row_start, int32_t* pix_sorted,
-                                   int32_t* status, void* ws, size_t ws_bytes, void* stream) {
+                                   int32_t* status, int32_t* seg_start, int32_t* unit_row, int Umax, void* ws, size_t ws_bytes,
+                                   void* stream) {
     if (!labels || !n_sp || !n_l || !perm || !inv_perm || !area_new || !sp_labels || !new_row || !row_start ||
         !pix_sorted || !status || !ws)
         return WESUP_ERR_INVALID;
-    if (B <= 0 || HW <= 0 || C <= 0 || Kmax <= 0 || Kmax > SP_MAX_K) return WESUP_ERR_INVALID;
+    if (B <= 0 || B > SP_TICKET_B || HW <= 0 || C <= 0 || Kmax <= 0 || Kmax > SP_MAX_K) return WESUP_ERR_INVALID;
+    if ((seg_start || unit_row) && (!seg_start || !unit_row || Umax < Kmax)) return WESUP_ERR_INVALID;
+    const size_t lds = ((size_t)1024 + (size_t)Kmax * (mask ? 1 + C : 1)) * 4;
+    if (lds > 160 * 1024) return WESUP_ERR_INVALID;       // (Kmax <= 13 312 with a 2-class mask)
     if (ws_bytes < wesup_sp_preprocess_workspace_bytes(B, HW, C, Kmax)) return WESUP_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     const int nchunk = (HW + SP_CHUNK - 1) / SP_CHUNK;
+    SpPre p = {};
     char* w = (char*)ws;
-    int32_t* chunk_hist = (int32_t*)w;
-    w += align_up((size_t)B * nchunk * Kmax * 4, 256);
-    int32_t* cnt = (int32_t*)w;
-    const size_t cnt_bytes = align_up((size_t)B * Kmax * C * 4, 256);
-    w += cnt_bytes;
-    int32_t* area_old = (int32_t*)w;
-    w += align_up((size_t)B * Kmax * 4, 256);
-    int32_t* nmax = (int32_t*)w;
-    if (hipMemsetAsync(cnt, 0, cnt_bytes, st) != hipSuccess) return WESUP_ERR_LAUNCH;
-    if (hipMemsetAsync(nmax, 0, align_up((size_t)B * 4, 256), st) != hipSuccess) return WESUP_ERR_LAUNCH;
-    if (hipMemsetAsync(status, 0, (size_t)B * 4, st) != hipSuccess) return WESUP_ERR_LAUNCH;
-    hipLaunchKernelGGL(sp_hist_kernel, dim3(nchunk, B), dim3(256), (size_t)Kmax * 4, st, labels, mask, HW, C, Kmax, nchunk,
-                       chunk_hist, cnt, nmax, status);
-    hipLaunchKernelGGL(sp_order_kernel, dim3(B), dim3(1024), 0, st, chunk_hist, cnt, nmax, nchunk, C, Kmax, HW,
-                       mask ? 1 : 0, n_sp, n_l, perm, inv_perm, area_new, sp_labels, row_start, area_old, status);
-    hipLaunchKernelGGL(sp_chunk_base_kernel, dim3(ceil_div(Kmax, 256), B), dim3(256), 0, st, chunk_hist, inv_perm,
-                       row_start, nchunk, Kmax);
-    hipLaunchKernelGGL(sp_place_kernel, dim3(nchunk, B), dim3(64), (size_t)Kmax * 4, st, labels, chunk_hist, inv_perm, HW,
-                       Kmax, nchunk, pix_sorted, new_row);
+    p.chunk_hist = (int32_t*)w; w += align_up((size_t)B * nchunk * Kmax * 4, 256);
+    p.chunk_cnt = (int32_t*)w;  w += align_up((size_t)B * nchunk * Kmax * C * 4, 256);
+    p.chunk_info = (int32_t*)w; w += align_up((size_t)B * nchunk * 2 * 4, 256);
+    p.cnt = (int32_t*)w;        w += align_up((size_t)B * Kmax * C * 4, 256);
+    p.area_old = (int32_t*)w;
+    p.labels = labels; p.mask = mask; p.HW = HW; p.C = C; p.Kmax = Kmax; p.nchunk = nchunk; p.Umax = Umax;
+    p.n_sp = n_sp; p.n_l = n_l; p.perm = perm; p.inv_perm = inv_perm; p.area_new = area_new; p.row_start = row_start;
+    p.status = status; p.seg_start = seg_start; p.unit_row = unit_row; p.sp_labels = sp_labels;
+    // the ticket row of this call: one row per STREAM (calls on one stream run one after the other; calls in flight on
+    // different streams must not share a row), first come first served -- the same stream always gets the same row, so a
+    // recorded step plan and a later walk of the same step agree
+    static std::mutex mu;
+    static hipStream_t row_stream[SP_TICKET_ROWS];
+    static int rows_used = 0;
+    int row = -1;
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        for (int i = 0; i < rows_used; ++i)
+            if (row_stream[i] == st) row = i;
+        if (row < 0 && rows_used < SP_TICKET_ROWS) {
+            row = rows_used++;
+            row_stream[row] = st;
+        }
+    }
+    if (row < 0) return WESUP_ERR_INVALID;             // more than 64 streams have called this entry
+    static int32_t* const tickets = [] {
+        int32_t* t = nullptr;
+        return hipGetSymbolAddress((void**)&t, HIP_SYMBOL(g_sp_ticket)) == hipSuccess ? t : nullptr;
+    }();
+    if (!tickets) return WESUP_ERR_LAUNCH;
+    p.ticket = tickets + (size_t)row * SP_TICKET_B;
+    {
+        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(sp_count_order_kernel),
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (attr != hipSuccess) return WESUP_ERR_LAUNCH;
+    }
+    WESUP_LAUNCH(sp_count_order_kernel, dim3(nchunk, B), dim3(1024), lds, st, p);
+    WESUP_LAUNCH(sp_place_kernel, dim3(nchunk, B), dim3(64), (size_t)Kmax * 4, st, labels, p.chunk_hist, inv_perm, HW,
+                 Kmax, nchunk, pix_sorted, new_row);
     WESUP_CHECK_LAUNCH();
     return WESUP_OK;
 }
@@ -246,7 +390,7 @@ __global__ void spmaps_argmax_kernel(const float* __restrict__ maps, int32_t* __
 }
 extern "C" int wesup_spmaps_to_labels(const float* sp_maps, int32_t* labels, int N, int HW, void* stream) {
     if (!sp_maps || !labels || N <= 0 || HW <= 0) return WESUP_ERR_INVALID;
-    hipLaunchKernelGGL(spmaps_argmax_kernel, dim3((HW + 255) / 256), dim3(256), 0, (hipStream_t)stream, sp_maps, labels, N,
+    WESUP_LAUNCH(spmaps_argmax_kernel, dim3((HW + 255) / 256), dim3(256), 0, (hipStream_t)stream, sp_maps, labels, N,
                        (long)HW);
     WESUP_CHECK_LAUNCH();
     return WESUP_OK;
@@ -263,7 +407,6 @@ extern "C" int wesup_spmaps_to_labels(const float* sp_maps, int32_t* labels, int
 // sp_pool_combine_kernel adds them in segment order -- still a fixed summation order, and a superpixel 50x the
 // median no longer serialises on one wave.
 #define POOL_UNROLL 8
-#define SP_SEG 512
 struct SegInfo {
     int r, j0, j1, nseg, u;
     float inv;
@@ -304,12 +447,12 @@ __global__ __launch_bounds__(1024) void sp_segments_kernel(const int32_t* __rest
     }
     if (tid == 1023) seg_start[(long)b * (Kmax + 1) + Kmax] = min(total, Umax);
 }
-extern "C" int wesup_sp_max_units(int HW, int Kmax) { return (HW > 0 && Kmax > 0) ? Kmax + HW / SP_SEG : 0; }
+// (the same table from a row_start of the caller's own; wesup_sp_preprocess writes it itself when seg_start is given)
 extern "C" int wesup_sp_segments(const int32_t* row_start, int B, int Kmax, int Umax, int32_t* seg_start,
                                  int32_t* unit_row, void* stream) {
     if (!row_start || !seg_start || !unit_row || B <= 0 || Kmax <= 0 || Umax < Kmax) return WESUP_ERR_INVALID;
-    hipLaunchKernelGGL(sp_segments_kernel, dim3(B), dim3(1024), 0, (hipStream_t)stream, row_start, Kmax, Umax, seg_start,
-                       unit_row);
+    WESUP_LAUNCH(sp_segments_kernel, dim3(B), dim3(1024), 0, (hipStream_t)stream, row_start, Kmax, Umax, seg_start,
+                 unit_row);
     WESUP_CHECK_LAUNCH();
     return WESUP_OK;
 }
@@ -391,10 +534,10 @@ extern "C" int wesup_sp_pool_fwd(const float* fm, const int32_t* pix_sorted, con
     const int nslab = ceil_div(C, 256);
     const int units = Umax * nslab;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(sp_pool_fwd_kernel, dim3(ceil_div(units, 4), B), dim3(256), 0, st, fm, pix_sorted, row_start,
+    WESUP_LAUNCH(sp_pool_fwd_kernel, dim3(ceil_div(units, 4), B), dim3(256), 0, st, fm, pix_sorted, row_start,
                        seg_start, unit_row, (float*)ws, sp_feat, HW, ldf, C, Kmax, Umax, nslab, units);
     const long tot = (long)Kmax * (C / 4);
-    hipLaunchKernelGGL(sp_pool_combine_kernel, dim3((unsigned)((tot + 255) / 256), B), dim3(256), 0, st, (const float*)ws,
+    WESUP_LAUNCH(sp_pool_combine_kernel, dim3((unsigned)((tot + 255) / 256), B), dim3(256), 0, st, (const float*)ws,
                        seg_start, sp_feat, Kmax, Umax, C / 4, C, 0);
     WESUP_CHECK_LAUNCH();
     return WESUP_OK;
@@ -584,7 +727,7 @@ extern "C" int wesup_sp_pool_upsample_fwd(const float* s, const int32_t* pix_sor
     hipStream_t st = (hipStream_t)stream;
     float* part = (float*)ws;
 #define WESUP_LAUNCH_PU(L, c0)                                                                                             \
-    hipLaunchKernelGGL(sp_pool_up_fwd_kernel<L>, grid, dim3(256), 0, st, s + (c0), pix_sorted, row_start, seg_start, unit_row, \
+    WESUP_LAUNCH(sp_pool_up_fwd_kernel<L>, grid, dim3(256), 0, st, s + (c0), pix_sorted, row_start, seg_start, unit_row, \
                        part, sp_feat, h, w, H, W, dW, C, ldo, coff + (c0), Kmax, Umax, sh, sw)
     // a wave's 64 lanes cover 256 channels of a pixel: wider maps go in slabs of 256 channels (row stride C)
     if (C > 256 && (C % 256)) return WESUP_ERR_INVALID;
@@ -598,7 +741,7 @@ extern "C" int wesup_sp_pool_upsample_fwd(const float* s, const int32_t* pix_sor
             default: return WESUP_ERR_INVALID;
         }
         const long tot = (long)Kmax * (cw / 4);
-        hipLaunchKernelGGL(sp_pool_combine_kernel, dim3((unsigned)((tot + 255) / 256), B), dim3(256), 0, st, (const float*)ws,
+        WESUP_LAUNCH(sp_pool_combine_kernel, dim3((unsigned)((tot + 255) / 256), B), dim3(256), 0, st, (const float*)ws,
                            seg_start, sp_feat, Kmax, Umax, cw / 4, ldo, coff + c0);
     }
 #undef WESUP_LAUNCH_PU
@@ -648,7 +791,7 @@ extern "C" int wesup_sp_interp_matrix(const int32_t* pix_sorted, const int32_t* 
         Kmax <= 0 || (long)h * w > 8192)
         return WESUP_ERR_INVALID;
     const float sh = H > 1 ? (float)(h - 1) / (float)(H - 1) : 0.f, sw = W > 1 ? (float)(w - 1) / (float)(W - 1) : 0.f;
-    hipLaunchKernelGGL(sp_interp_matrix_kernel, dim3(Kmax, B), dim3(256), (size_t)h * w * sizeof(unsigned long long),
+    WESUP_LAUNCH(sp_interp_matrix_kernel, dim3(Kmax, B), dim3(256), (size_t)h * w * sizeof(unsigned long long),
                        (hipStream_t)stream, pix_sorted, row_start, Wm, H, W, h, w, Kmax, make_fastdiv(W), sh, sw);
     WESUP_CHECK_LAUNCH();
     return WESUP_OK;
@@ -674,7 +817,7 @@ extern "C" int wesup_sp_pool_bwd(const float* g, const int32_t* new_row, const i
         return WESUP_ERR_INVALID;
     const long total = (long)B * HW * (C / 4);
     const long blocks = (total + 255) / 256;
-    hipLaunchKernelGGL(sp_pool_bwd_kernel, dim3((unsigned)(blocks < 16384 ? blocks : 16384)), dim3(256), 0,
+    WESUP_LAUNCH(sp_pool_bwd_kernel, dim3((unsigned)(blocks < 16384 ? blocks : 16384)), dim3(256), 0,
                        (hipStream_t)stream, g, new_row, area_new, dfm, (long)HW, ldf, C / 4, Kmax, total);
     WESUP_CHECK_LAUNCH();
     return WESUP_OK;
@@ -692,7 +835,7 @@ extern "C" int wesup_paint_fwd(const float* sp_pred, const int32_t* new_row, flo
                                int cls, void* stream) {
     if (!sp_pred || !new_row || !pred || B <= 0 || HW <= 0 || Kmax <= 0 || cls < 0 || cls >= C) return WESUP_ERR_INVALID;
     const long total = (long)B * HW;
-    hipLaunchKernelGGL(paint_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, sp_pred,
+    WESUP_LAUNCH(paint_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, sp_pred,
                        new_row, pred, (long)HW, Kmax, C, cls, total);
     WESUP_CHECK_LAUNCH();
     return WESUP_OK;

@@ -324,7 +324,11 @@ struct FusedBits {       // the compact forms of mask_src / unpool_src (in) and 
     const unsigned short* up_code;
 };
 // Block shape of the one-kernel route: tile groups per block (2: 4 waves, two blocks per CU; 4: 8 waves, one block per CU) and
-// ring depth.  WESUP_WINO_FUSED_SHAPE="tw,ring" overrides the default for every K (A/B measurements in one process sequence).
+// ring depth.  WESUP_WINO_FUSED_SHAPE="tw,3" overrides the default for every K (A/B measurements in one process sequence).
+// Round 4, measured alone on the step's product shapes (tools/fused_micro.py): 64-tile blocks -3 ... -5 % where the grid still
+// fills the chip (conv1_2, conv2_2, conv3_2), +50 % where it does not (conv3_1 dgrad, conv4_1: ~115 blocks); rings of 4 and 5
+// stages (possible at one block per CU) change nothing -- the kernel does not wait for the latency of its staging DMA.  In the
+// step "auto" gains 0.03 ms of 9.2 (three alternating pairs); the default stays 32 tiles.
 struct FusedShape { int tw, ring; };
 static FusedShape fused_shape(long T, int N) {
     // -1: "auto" = 64-tile blocks where they still fill the chip (>= 200 blocks of 8 waves on 256 CUs), else 32-tile blocks
@@ -333,7 +337,7 @@ static FusedShape fused_shape(long T, int N) {
         const char* e = getenv("WESUP_WINO_FUSED_SHAPE");
         if (e && e[0] == 'a') return FusedShape{-1, 3};
         if (e && sscanf(e, "%d,%d", &f.tw, &f.ring) == 2 &&
-            ((f.tw == 2 && f.ring == 3) || (f.tw == 4 && f.ring >= 3 && f.ring <= 5)))
+            (f.tw == 2 || f.tw == 4) && f.ring == 3)
             return f;
         return FusedShape{0, 0};
     }();
@@ -349,7 +353,7 @@ static int fused_go(const FusedParams& p, dim3 grid, void* stream) {
     static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(wino4_gemm_out_kernel<KC, TW, RING>),
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (attr != hipSuccess) return WESUP_ERR_LAUNCH;
-    hipLaunchKernelGGL((wino4_gemm_out_kernel<KC, TW, RING>), grid, dim3(128 * TW), lds, (hipStream_t)stream, p);
+    WESUP_LAUNCH((wino4_gemm_out_kernel<KC, TW, RING>), grid, dim3(128 * TW), lds, (hipStream_t)stream, p);
     return WESUP_OK;
 }
 static int fused_launch(const float* V, long plane_elems, const float* U, const float* bias, const float* mask_src, float* y,
@@ -382,7 +386,7 @@ static int fused_launch(const float* V, long plane_elems, const float* U, const 
     if (fs.tw == TW_ && fs.ring == RING_)                                                             \
         rc = K == 64 ? fused_go<1, TW_, RING_>(p, grid, stream)                                       \
            : K == 128 ? fused_go<2, TW_, RING_>(p, grid, stream) : fused_go<4, TW_, RING_>(p, grid, stream);
-    FUSED_CASE(2, 3) FUSED_CASE(4, 3) FUSED_CASE(4, 4) FUSED_CASE(4, 5)
+    FUSED_CASE(2, 3) FUSED_CASE(4, 3)
 #undef FUSED_CASE
     if (rc != WESUP_OK) return rc;
     WESUP_CHECK_LAUNCH();

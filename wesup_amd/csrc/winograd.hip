@@ -639,10 +639,82 @@ extern "C" int wesup_winograd_pack_weight(const float* w, float* u_fwd, float* u
     for (int mode = 0; mode < 2; ++mode) {
         float* u = mode == 0 ? u_fwd : u_dgrad;
         if (!u) continue;
-        if (m == 2) hipLaunchKernelGGL(wino_weight_transform_kernel, grid, dim3(256), 0, st, w, u, Cout, Cin, mode);
-        else hipLaunchKernelGGL(wino4_weight_transform_kernel, grid, dim3(256), 0, st, w, u, Cout, Cin, mode);
+        if (m == 2) WESUP_LAUNCH(wino_weight_transform_kernel, grid, dim3(256), 0, st, w, u, Cout, Cin, mode);
+        else WESUP_LAUNCH(wino4_weight_transform_kernel, grid, dim3(256), 0, st, w, u, Cout, Cin, mode);
         WESUP_CHECK_LAUNCH();
     }
+    return WESUP_OK;
+}
+
+// The filters of SEVERAL layers in one launch (F(4x4,3x3)): the step re-derives 12 forward and 12 rotated filter sets from the
+// updated weights, 24 launches of 4-16 us that sat at the head of every iteration.  A block finds its job by a scan of the
+// (at most 32) block ranges, then works as wino4_weight_transform_kernel does.
+#define WINO_WB_MAX 32
+struct WinoWBatch {
+    const float* w[WINO_WB_MAX];
+    float* u[WINO_WB_MAX];
+    int co[WINO_WB_MAX], ci[WINO_WB_MAX], mode[WINO_WB_MAX];
+    int first[WINO_WB_MAX + 1];      // first block of job j; first[n] = grid size
+    int n;
+};
+__device__ __forceinline__ void wino4_weight_transform_one(const float* __restrict__ w, float* __restrict__ U, int Co, int Ci,
+                                                           int mode, long idx) {
+    int co, ci;
+    if (mode == 0) { co = idx / Ci; ci = idx - (long)co * Ci; }
+    else { ci = idx / Co; co = idx - (long)ci * Co; }
+    const float* gsrc = w + ((long)co * Ci + ci) * 9;
+    float g[3][3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) g[a][b] = mode == 0 ? gsrc[3 * a + b] : gsrc[8 - (3 * a + b)];
+    float r[6][3];       // G g
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+        float u[6];
+        wino4_g(g[0][b], g[1][b], g[2][b], u);
+#pragma unroll
+        for (int a = 0; a < 6; ++a) r[a][b] = u[a];
+    }
+    const long ps = (long)Co * Ci;
+    float* out = U + idx;
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {   // (.) G^T
+        float u[6];
+        wino4_g(r[a][0], r[a][1], r[a][2], u);
+#pragma unroll
+        for (int b = 0; b < 6; ++b) out[(6 * a + b) * ps] = u[b];
+    }
+}
+__global__ void wino4_weight_transform_batched_kernel(const WinoWBatch p) {
+    int j = 0;
+    while (j + 1 < p.n && (int)blockIdx.x >= p.first[j + 1]) ++j;
+    const long idx = (long)(blockIdx.x - p.first[j]) * blockDim.x + threadIdx.x;
+    if (idx >= (long)p.co[j] * p.ci[j]) return;
+    wino4_weight_transform_one(p.w[j], p.u[j], p.co[j], p.ci[j], p.mode[j], idx);
+}
+// layers[i] = {w (Cout,Cin,3,3), u_fwd or NULL, u_dgrad or NULL, Cout, Cin}: the same results as n calls of
+// wesup_winograd_pack_weight(..., m = 4), in one launch; at most 32 filter sets (a NULL panel does not count)
+extern "C" int wesup_winograd_pack_weights(const WesupWinoFilter* layers /* host */, int n, void* stream) {
+    if (!layers || n <= 0) return WESUP_ERR_INVALID;
+    WinoWBatch p = {};
+    int blocks = 0;
+    for (int i = 0; i < n; ++i) {
+        const WesupWinoFilter& L = layers[i];
+        if (!L.w || L.Cout <= 0 || L.Cin <= 0 || (!L.u_fwd && !L.u_dgrad)) return WESUP_ERR_INVALID;
+        for (int mode = 0; mode < 2; ++mode) {
+            float* u = mode == 0 ? L.u_fwd : L.u_dgrad;
+            if (!u) continue;
+            if (p.n >= WINO_WB_MAX) return WESUP_ERR_INVALID;
+            p.w[p.n] = L.w; p.u[p.n] = u; p.co[p.n] = L.Cout; p.ci[p.n] = L.Cin; p.mode[p.n] = mode;
+            p.first[p.n] = blocks;
+            blocks += (int)(((long)L.Cout * L.Cin + 255) / 256);
+            ++p.n;
+        }
+    }
+    p.first[p.n] = blocks;
+    WESUP_LAUNCH(wino4_weight_transform_batched_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
+    WESUP_CHECK_LAUNCH();
     return WESUP_OK;
 }
 
@@ -663,8 +735,8 @@ static int wino_input_launch(const float* x, float* V, long plane_elems, unsigne
         return WESUP_ERR_INVALID;
     const WinoGeom g = wino_geom(B, H, W, C, m, plane_elems);
     const dim3 grid((unsigned)ceil_div(g.T * (C / 4), 256l));
-    if (m == 2) hipLaunchKernelGGL(wino_input_transform_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, V, g, relu_in);
-    else hipLaunchKernelGGL(wino4_input_transform_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, V, g, relu_in, bits);
+    if (m == 2) WESUP_LAUNCH(wino_input_transform_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, V, g, relu_in);
+    else WESUP_LAUNCH(wino4_input_transform_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, V, g, relu_in, bits);
     WESUP_CHECK_LAUNCH();
     return WESUP_OK;
 }
@@ -696,10 +768,10 @@ static int wino_output_launch(const float* Mt, long plane_elems, const float* bi
     const WinoGeom g = wino_geom(B, H, W, C, m, plane_elems);
     const dim3 grid((unsigned)ceil_div(g.T * (C / 4), 256l));
     if (m == 2)
-        hipLaunchKernelGGL(wino_output_transform_kernel, grid, dim3(256), 0, (hipStream_t)stream, Mt, bias, mask_src, y, y_relu,
+        WESUP_LAUNCH(wino_output_transform_kernel, grid, dim3(256), 0, (hipStream_t)stream, Mt, bias, mask_src, y, y_relu,
                            y_pool, pool_relu, g, accumulate);
     else
-        hipLaunchKernelGGL(wino4_output_transform_kernel, grid, dim3(256), 0, (hipStream_t)stream, Mt, bias, mask_src, y, y_relu,
+        WESUP_LAUNCH(wino4_output_transform_kernel, grid, dim3(256), 0, (hipStream_t)stream, Mt, bias, mask_src, y, y_relu,
                            y_pool, pool_relu, g, accumulate, up);
     WESUP_CHECK_LAUNCH();
     return WESUP_OK;
@@ -739,8 +811,8 @@ extern "C" size_t wesup_winograd_outgrad_workspace_bytes(int B, int H, int W, in
 int wino_outgrad_launch(const float* dy, float* dM, float* bias_part, int B, int H, int W, int C, int m, void* stream) {
     const WinoGeom g = wino_geom(B, H, W, C, m);
     const dim3 grid((unsigned)wino_transform_blocks(B, H, W, C, m));
-    if (m == 2) hipLaunchKernelGGL(wino_outgrad_transform_kernel, grid, dim3(256), 0, (hipStream_t)stream, dy, dM, g);
-    else hipLaunchKernelGGL(wino4_outgrad_transform_kernel, grid, dim3(256), 0, (hipStream_t)stream, dy, dM, g, bias_part);
+    if (m == 2) WESUP_LAUNCH(wino_outgrad_transform_kernel, grid, dim3(256), 0, (hipStream_t)stream, dy, dM, g);
+    else WESUP_LAUNCH(wino4_outgrad_transform_kernel, grid, dim3(256), 0, (hipStream_t)stream, dy, dM, g, bias_part);
     WESUP_CHECK_LAUNCH();
     return WESUP_OK;
 }
@@ -757,7 +829,7 @@ extern "C" int wesup_winograd_dual_transform(const float* dy, float* V, float* d
         return WESUP_ERR_INVALID;
     const WinoGeom g = wino_geom(B, H, W, C, 4);
     const dim3 grid((unsigned)wino_transform_blocks(B, H, W, C, 4));
-    hipLaunchKernelGGL(wino4_dual_transform_kernel, grid, dim3(256), 0, (hipStream_t)stream, dy, V, dM, g, bias_part);
+    WESUP_LAUNCH(wino4_dual_transform_kernel, grid, dim3(256), 0, (hipStream_t)stream, dy, V, dM, g, bias_part);
     WESUP_CHECK_LAUNCH();
     return WESUP_OK;
 }
@@ -787,13 +859,13 @@ int wino_filter_grad_launch(const float* slabs, long slab_stride, long batch_str
     const int bias_blocks = !db ? 0 : bias_part ? (Cout + 15) / 16 : (Cout + 255) / 256;
     const dim3 grid((unsigned)(pair_blocks + bias_blocks));
     if (m == 2)
-        hipLaunchKernelGGL((wino_wgrad_reduce_kernel<4, 64>), grid, dim3(256), 0, (hipStream_t)stream, slabs, slab_stride,
+        WESUP_LAUNCH((wino_wgrad_reduce_kernel<4, 64>), grid, dim3(256), 0, (hipStream_t)stream, slabs, slab_stride,
                            batch_stride, dw_kcrs, Cout, Cin, S, db, pair_blocks, (const float*)nullptr, 0);
     else if (narrow)
-        hipLaunchKernelGGL((wino_wgrad_reduce_kernel<6, 16>), grid, dim3(256), 0, (hipStream_t)stream, slabs, slab_stride,
+        WESUP_LAUNCH((wino_wgrad_reduce_kernel<6, 16>), grid, dim3(256), 0, (hipStream_t)stream, slabs, slab_stride,
                            batch_stride, dw_kcrs, Cout, Cin, S, db, pair_blocks, bias_part, bias_rows);
     else
-        hipLaunchKernelGGL((wino_wgrad_reduce_kernel<6, 64>), grid, dim3(256), 0, (hipStream_t)stream, slabs, slab_stride,
+        WESUP_LAUNCH((wino_wgrad_reduce_kernel<6, 64>), grid, dim3(256), 0, (hipStream_t)stream, slabs, slab_stride,
                            batch_stride, dw_kcrs, Cout, Cin, S, db, pair_blocks, bias_part, bias_rows);
     WESUP_CHECK_LAUNCH();
     return WESUP_OK;

@@ -74,9 +74,11 @@ class GradAllReducer:
                 self.lo = lo
             elif lo == self.hi:
                 self.hi = hi
-            else:                    # not adjacent: flush what we have, start a new range
+            else:                    # not adjacent: flush what we have, start a new range (produced on this call's stream)
                 self._flush()
                 self.lo, self.hi = lo, hi
+                if self.flat.is_cuda:
+                    self._pending_stream = cur
         if self.lo is not None and self.hi - self.lo >= self.bucket_elems:
             self._flush()
 

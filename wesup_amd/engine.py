@@ -197,8 +197,22 @@ class WesupEngine:
         self._wgrad_stream = None
         self.timer = KernelTimer()
         self.on_grads_ready = None       # callback(names) for the data-parallel layer
+        self._rot = 0
+        self.buf_generation = 0          # bumped when a buffer set is created or evicted (a recorded step plan holds addresses)
 
     # ------------------------------------------------------------------ streams
+    # Ordering edges between the three streams go through the library's event pool (ops.sync_record / sync_wait: slots of a
+    # fixed pool, so that a recorded step plan replays the same edges, csrc/plan.hip): fixed slots for marks that are waited
+    # for later, a rotating range for "stream b goes on behind what stream a holds now".
+    SLOT_W0, SLOT_W, SLOT_G, SLOT_DS, SLOT_ROT0, SLOT_ROT_N = 0, 1, 2, 15, 64, 192       # G_l: 2 .. 14, ds_l: 15 .. 27
+
+    def _edge(self, src, dst):
+        """dst (torch stream) waits for everything queued so far on src."""
+        k = self._rot
+        self._rot = k + 1 if k + 1 < self.SLOT_ROT_N else 0
+        ops.sync_record(self.SLOT_ROT0 + k, src.cuda_stream)
+        ops.sync_wait(self.SLOT_ROT0 + k, dst.cuda_stream)
+
     def _side(self):
         if self._side_stream is None:
             self._side_stream = torch.cuda.Stream(device=self.device)
@@ -221,7 +235,7 @@ class WesupEngine:
                 return None
             self.prev = torch.cuda.current_stream()
             if self.wait_main:
-                e._side().wait_stream(self.prev)
+                e._edge(self.prev, e._side())
             torch.cuda.set_stream(e._side())      # (torch.cuda.stream() as a context costs 10 us a time: ~40 times per step)
             return None
 
@@ -248,7 +262,7 @@ class WesupEngine:
 
     def _join_side(self):
         if self.two_streams:
-            torch.cuda.current_stream().wait_stream(self._side())
+            self._edge(self._side(), torch.cuda.current_stream())
 
     # ------------------------------------------------------------------ buffers
     def _get_bufs(self, B, H, W, Kmax, train):
@@ -261,6 +275,7 @@ class WesupEngine:
             # images of varying size meets a new shape almost every call; every entry is a full set of activation and
             # gradient buffers (~0.6 GB per 480x480 image in training), so only the most recent shapes are kept and the
             # evicted buffers go back to torch's caching allocator, which hands their blocks to the next shape.
+            self.buf_generation += 1
             while len(self._bufs) >= max(1, self.max_cached_shapes):
                 _, old = self._bufs.popitem(last=False)
                 if old is self._last:
@@ -386,6 +401,7 @@ class WesupEngine:
                 and ((b.group_of[l] is not None and self.commute_side_deep) or b.group_of[l] is None))
 
     def release_buffers(self):
+        self.buf_generation += 1
         self._bufs.clear()
         self._last = None
         self.ctx = None
@@ -430,35 +446,47 @@ class WesupEngine:
         # ~40 launch-latency-bound repack kernels go to the side stream (idle at this point) and are joined in front of
         # the first convolution; the trainer queues them before the superpixel preprocessing (prefetch_weights)
         with self._OnSide(self):
-            pk.ready0 = pk.ready = None
+            pk.ready0 = pk.ready = False
+            fwd4, dg4 = [], []                     # F(4x4) layers: one launch for the forward filters, one for the rotated ones
             for l, idx in enumerate(CONV_IDX):     # forward panels first: conv1_1 only waits for its own
                 m = wino[l]
+                w = self.p[f'backbone.{idx}.weight']
                 if m:
                     P = ops.winograd_positions(m)
                     if pk.uf[l] is None or pk.uf[l].shape[0] != P:
                         ci, co = CONV_CH[l]
                         pk.uf[l] = torch.empty(P, co, ci, dtype=torch.float32, device=self.device)
                         pk.ud[l] = torch.empty(P, ci, co, dtype=torch.float32, device=self.device)
-                    ops.winograd_pack_weight(self.p[f'backbone.{idx}.weight'], need_dgrad=False, u_fwd=pk.uf[l], m=m)
+                    if m == 4:
+                        fwd4.append((w, pk.uf[l], None))
+                        dg4.append((w, None, pk.ud[l]))
+                    else:
+                        ops.winograd_pack_weight(w, need_dgrad=False, u_fwd=pk.uf[l], m=m)
                     continue
-                ops.pack_conv3x3_weight(self.p[f'backbone.{idx}.weight'], pk.wf[l], None, need_dgrad=False)
+                ops.pack_conv3x3_weight(w, pk.wf[l], None, need_dgrad=False)
                 if l == 0 and self.two_streams:
-                    pk.ready0 = torch.cuda.Event()
-                    pk.ready0.record()
+                    ops.sync_record(self.SLOT_W0)
+                    pk.ready0 = True
+            if fwd4:
+                ops.winograd_pack_weights(fwd4)
             if self.two_streams:
-                pk.ready = torch.cuda.Event()
-                pk.ready.record()
+                ops.sync_record(self.SLOT_W)
+                pk.ready = True
             if train:
+                if dg4:
+                    ops.winograd_pack_weights(dg4)
                 for l, idx in enumerate(CONV_IDX):
+                    if wino[l] == 4:
+                        continue
                     if wino[l]:
                         ops.winograd_pack_weight(self.p[f'backbone.{idx}.weight'], need_fwd=False, u_dgrad=pk.ud[l], m=wino[l])
                     elif l > 0:
                         ops.pack_conv3x3_weight(self.p[f'backbone.{idx}.weight'], None, pk.wd[l], need_fwd=False)
-                for l, off in enumerate(SIDE_OFF):
-                    co = CONV_CH[l][1]
-                    ops.transpose(self.p[f'side_conv{off}.weight'].view(co // 2, co), pk.sideT[l])
-                for i, k in enumerate((0, 2, 4)):
-                    ops.transpose(self.p[f'fc_layers.{k}.weight'], pk.fcT[i])
+                # the panels the input-gradient GEMMs of the side convs / fc layers read: 16 transposes, one launch
+                tr = [(self.p[f'side_conv{off}.weight'].view(CONV_CH[l][1] // 2, CONV_CH[l][1]), pk.sideT[l])
+                      for l, off in enumerate(SIDE_OFF)]
+                tr += [(self.p[f'fc_layers.{k}.weight'], pk.fcT[i]) for i, k in enumerate((0, 2, 4))]
+                ops.transpose_batched(tr)
         return pk
 
     def _wino(self, l):
@@ -497,8 +525,7 @@ class WesupEngine:
                 tok = T.begin('interp_matrix')
                 for g in b.groups:
                     ops.sp_interp_matrix(meta, g.h, g.w, out=g.Wm)
-                    for i in range(B):
-                        ops.transpose(g.Wm[i], g.WmT[i])
+                ops.transpose_batched([(g.Wm[i], g.WmT[i]) for g in b.groups for i in range(B)])
                 T.end(tok, 0.0)
         pending_side = None              # the side-branch work of the previous layer, when it is queued behind this layer's transform
         cur, cur_relu = b.x0, False      # the layer's input tensor, and whether its ReLU is still to be applied on load
@@ -511,10 +538,10 @@ class WesupEngine:
         for l, (ci, co) in enumerate(CONV_CH):
             h, w = b.dims[l]
             idx, off = CONV_IDX[l], SIDE_OFF[l]
-            if l == 0 and pk.ready0 is not None:
-                torch.cuda.current_stream().wait_event(pk.ready0)
-            if l == 1 and pk.ready is not None:
-                torch.cuda.current_stream().wait_event(pk.ready)
+            if l == 0 and pk.ready0:
+                ops.sync_wait(self.SLOT_W0)
+            if l == 1 and pk.ready:
+                ops.sync_wait(self.SLOT_W)
             ws = p[f'side_conv{off}.weight'].view(co // 2, co)
             commute = self._commuted(b, l)
             b.s_valid[l] = not commute
@@ -731,7 +758,7 @@ class WesupEngine:
         T.end(tok, (4.0 if not off_chain else 2.0) * R * (FM_CHANNELS * 1024 + 1024 * 1024 + 1024 * D))
         if off_chain:
             wgs = self._wg()
-            wgs.wait_stream(torch.cuda.current_stream())
+            self._edge(torch.cuda.current_stream(), wgs)
             with self._On(wgs):
                 tok = T.begin('mlp_wgrad')
                 ops.gemm_tn(b.dfeat, b.h2, out=g['fc_layers.4.weight'], colsum=g['fc_layers.4.bias'], ws_tag='wgrad')
@@ -813,14 +840,13 @@ class WesupEngine:
             # stays within the 4 hardware queues HIP maps streams onto by default -- a fifth stream aliases two of
             # them and costs 1.2 ms per step, which is what a live process group did to the 4-stream schedule.)
             aux = self._wg()
-            aux.wait_stream(torch.cuda.current_stream())
+            self._edge(torch.cuda.current_stream(), aux)
             with self._On(aux):
                 for ls in commuted_runs():
                     commuted_G(ls)
-                    ev = torch.cuda.Event()
-                    ev.record()
+                    ops.sync_record(self.SLOT_G + ls[0])
                     for l in ls:
-                        g_ready[l] = ev
+                        g_ready[l] = self.SLOT_G + ls[0]
                 for l in range(12, -1, -1):
                     if b.group_of[l] is None and self._commuted(b, l):
                         pass
@@ -832,8 +858,8 @@ class WesupEngine:
                         # own byte model (pool-backward fused in): the gradient at native resolution out, the pixel labels
                         # and one row of g per superpixel in -- not the (H, W, C/2) slice of a materialised gradient
                         T.end(tok, 4.0 * B * (h * w * (CONV_CH[l][1] // 2) + H * W + Kmax * (CONV_CH[l][1] // 2)))
-                        ds_ready[l] = torch.cuda.Event()
-                        ds_ready[l].record()
+                        ds_ready[l] = self.SLOT_DS + l
+                        ops.sync_record(ds_ready[l])
         ds2ds = [None] * 13
 
         def side_wgrad(l):
@@ -867,8 +893,8 @@ class WesupEngine:
                         if l >= lowest:      # layer by layer, deepest first: the dgrad chain starts with conv5_3
                             commuted_G([l])
                             if self.two_streams:
-                                g_ready[l] = torch.cuda.Event()
-                                g_ready[l].record()
+                                g_ready[l] = self.SLOT_G + l
+                                ops.sync_record(g_ready[l])
                     elif not self.two_streams and l >= lowest:   # single-stream schedule: not queued above
                         for ls in commuted_runs():
                             if ls[0] == l:
@@ -887,7 +913,7 @@ class WesupEngine:
                     tok = None
                     ds2d = b.ds[l].view(P, co // 2)
                 elif ds_ready[l] is not None:
-                    torch.cuda.current_stream().wait_event(ds_ready[l])
+                    ops.sync_wait(ds_ready[l])
                     tok = None
                     ds2d = b.ds[l].view(P, co // 2)
                 elif self.fuse_pool_bwd:
@@ -913,23 +939,24 @@ class WesupEngine:
                                 ops.gemm_nt(d_, pk.sideT[i], None, out=b.G[i].view(P, co))
                         T.end(tok, 2.0 * len(ls) * P * co * (co // 2))
                         if self.two_streams:
-                            ev = torch.cuda.Event()
-                            ev.record()
+                            ops.sync_record(self.SLOT_G + ls[0])
                             for i in ls:
-                                g_ready[i] = ev
+                                g_ready[i] = self.SLOT_G + ls[0]
                 elif l >= lowest:            # G_l is only needed by backbone layers that train
                     tok = T.begin('side_bwd')
                     ops.gemm_nt(ds2d, pk.sideT[l], None, out=b.G[l].view(P, co))
                     T.end(tok, 2.0 * P * co * (co // 2))
                     if self.two_streams:
-                        g_ready[l] = torch.cuda.Event()
-                        g_ready[l].record()
+                        g_ready[l] = self.SLOT_G + l
+                        ops.sync_record(g_ready[l])
                 if not self.side_wgrad_last:
                     side_wgrad(l)
             # The side convs' own weight gradients are parameter gradients nobody waits for before the optimiser, while the
             # dgrad chain waits for every G_l: all the G_l first (13 GEMMs), the weight gradients behind them.
             late_at = self.deep_side_wgrad_at if (self.two_streams and self.side_wgrad_last) else None
-            late_side = [l for l in range(12, -1, -1) if late_at is not None and b.group_of[l] is not None and late_at > lowest]
+            if late_at is not None and not (lowest < late_at <= 12):      # the main loop below never reaches such a layer
+                late_at = None
+            late_side = [l for l in range(12, -1, -1) if late_at is not None and b.group_of[l] is not None]
             if self.side_wgrad_last:
                 for l in range(12, -1, -1):
                     if l not in late_side:
@@ -944,7 +971,7 @@ class WesupEngine:
             h, w = b.dims[l]
             idx = CONV_IDX[l]
             if g_ready[l] is not None:
-                main.wait_event(g_ready[l])
+                ops.sync_wait(g_ready[l], main.cuda_stream)
             if late_side and l == late_at:
                 # the deep layers' side-conv weight gradients (TN products with K = pixels: MFMA-bound) only now, beside the
                 # memory-bound transforms and 64-channel products of the last layers instead of beside conv5 / conv4
@@ -1000,14 +1027,14 @@ class WesupEngine:
             elif late_wgrad:
                 pass
             elif wg is not None:
-                wg.wait_stream(main)                       # G_l is final here
+                self._edge(main, wg)                       # G_l is final here
                 with self._On(wg):
                     wgrad('wgrad')
             else:
                 wgrad('default')
             if l > lowest:
                 if g_ready[l - 1] is not None:
-                    main.wait_event(g_ready[l - 1])
+                    ops.sync_wait(g_ready[l - 1], main.cuda_stream)
                 unpooled = False
                 mbits = b.mbits[l - 1] if (self.compact_masks and b.mbits_ok[l - 1]) else None
                 pcode = b.pcode[l - 1] if (self.compact_masks and b.pcode_ok[l - 1]) else None
@@ -1041,10 +1068,10 @@ class WesupEngine:
                 if POOL_AFTER[l - 1] and not unpooled:
                     ops.maxpool2_bwd(b.y[l - 1], b.dxp[l - 1], b.G[l - 1], accumulate=True)
                 if late_wgrad and trainable[l] and 'wgrad' not in self._diag_skip:
-                    wg.wait_stream(main)
+                    self._edge(main, wg)
                     with self._On(wg):
                         wgrad('wgrad')
         if wg is not None:
-            main.wait_stream(wg)
+            self._edge(wg, main)
         self._join_side()
         self.ctx = None

@@ -57,6 +57,7 @@ class BaseTrainer(ABC):
         self.metric_funcs = []
         self.reducer = None
         self._host_buf = None            # pinned staging buffer of the per-step read-back
+        self._runner = None
         self.world_size = 1
         self.rank = 0
 
@@ -157,8 +158,21 @@ class BaseTrainer(ABC):
         flag.record_stream(aux)
         return flag, aux
 
+    def step_runner(self):
+        """The recordable walk of the standard training iteration (wesup_amd/runner.py), or None when it is switched off
+        (``native_step=False``) or the model has no engine."""
+        if self._runner is None and self.kwargs.get('native_step', True) and hasattr(self.model, 'prefetch_weights'):
+            from ..runner import StepRunner
+            self._runner = StepRunner(self)
+        return self._runner
+
     def train_one_iteration(self, phase, *data):
         from .. import ops
+        runner = self.step_runner()
+        if runner is not None:
+            parsed = runner.parse(phase, data)
+            if parsed is not None:
+                return runner.run(parsed)
         if self.reducer is not None:
             self.reducer.reset()             # nothing may be left over from an iteration that raised
         if hasattr(self.model, 'prefetch_weights'):      # weight repacking and superpixel preprocessing go to the side
@@ -269,18 +283,22 @@ class BaseTrainer(ABC):
             out['loss'] = float(out['loss'][0])
         if 'nan_anywhere' in out:
             out['nan_anywhere'] = float(out['nan_anywhere'][0])
+        self._metrics_from_terms(out, metrics)
+        if 'seg' in out:
+            out['seg'] = out['seg'].reshape(-1, 4)
+        return out
+
+    def _metrics_from_terms(self, out, metrics):
+        """labeled_sp_ratio / propagated_labels / propagate_loss (models/wesup.py:520-524) from the per-image loss terms."""
         if 'terms' in out:
             t = out['terms'].reshape(-1, 8)
             n_sp, n_l = out['n_sp'], out['n_l']
             weak = n_l < n_sp
-            if weak.any():                                           # models/wesup.py:520-524
+            if weak.any():
                 metrics['labeled_sp_ratio'] = float(np.mean(n_l[weak] / n_sp[weak]))
                 if self.kwargs.get('enable_propagation'):
                     metrics['propagated_labels'] = float(np.mean(t[weak, 4]))
                     metrics['propagate_loss'] = float(np.mean(np.where(t[weak, 3] > 0, t[weak, 2] / np.maximum(t[weak, 3], 1), 0.0)))
-        if 'seg' in out:
-            out['seg'] = out['seg'].reshape(-1, 4)
-        return out
 
     def train_one_epoch(self, no_val=False):
         phases = ['train'] if no_val else ['train', 'val']

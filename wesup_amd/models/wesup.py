@@ -512,6 +512,15 @@ class WESUPTrainer(BaseTrainer):
         # the safe bound 2 * n_segments (no host sync)
         return int(2 * int(H * W / self.kwargs.get('sp_area'))) + 8
 
+    def _kmax(self, n_sp_host, kmax_bound, H, W):
+        """Rows per image of the padded superpixel tables: the largest count when the counts are on the host, else a bound."""
+        Kmax = max(n_sp_host) if n_sp_host is not None else (
+            kmax_bound or self.kwargs.get('max_superpixels') or self._slic_bound(H, W))
+        # padded rows are inert: rounding up keeps the set of buffer shapes small when the superpixel count changes
+        # from batch to batch (every new (B,H,W,Kmax) is a new set of engine buffers) and keeps Kmax % 4 == 0, which
+        # the matrix form of the deep layers' pooling needs
+        return (int(Kmax) + 63) // 64 * 64
+
     def prefetch_segment_fn(self):
         """GPU SLIC of the next batch on the input pipeline's copy stream, beside the current training step
         (``slic_ahead``, default on; a CPU ``slic_fn`` stays inside preprocess)."""
@@ -564,12 +573,7 @@ class WESUPTrainer(BaseTrainer):
         # label maps already on the GPU: an upper bound on the ids avoids a host sync (padded rows are inert)
         # (label maps that arrive on the GPU without counts -- the pipeline's SLIC-ahead -- get the SLIC bound unless
         #  max_superpixels says otherwise)
-        Kmax = max(n_sp_host) if n_sp_host is not None else (
-            kmax_bound or self.kwargs.get('max_superpixels') or self._slic_bound(img.size(-2), img.size(-1)))
-        # padded rows are inert: rounding up keeps the set of buffer shapes small when the superpixel count changes
-        # from batch to batch (every new (B,H,W,Kmax) is a new set of engine buffers) and keeps Kmax % 4 == 0, which
-        # the matrix form of the deep layers' pooling needs
-        Kmax = (int(Kmax) + 63) // 64 * 64
+        Kmax = self._kmax(n_sp_host, kmax_bound, img.size(-2), img.size(-1))
         meta = preprocess_label_maps(segments, mask, Kmax=Kmax, n_sp_host=n_sp_host)
         if self.kwargs.get('check_label_maps', False):
             meta.check()

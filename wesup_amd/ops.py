@@ -77,15 +77,18 @@ def _p(t):
 
 
 _ws_cache = {}
+ws_generation = 0      # bumped whenever a workspace is (re)allocated: a recorded step plan holds the old addresses
 
 
 def workspace(nbytes, device, tag='default'):
     """Grow-only byte workspace per (device, tag)."""
+    global ws_generation
     key = (str(device), tag)
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
         _ws_cache[key] = buf
+        ws_generation += 1
     return buf
 
 
@@ -169,6 +172,29 @@ def transpose(a, out=None):
         out = torch.empty(c, r, dtype=torch.float32, device=a.device)
     _lib.call('wesup_transpose', _p(a), _p(out), r, c, _stream())
     return out
+
+
+def transpose_batched(pairs):
+    """[(a (r, c), out (c, r)), ...]: every out = a^T in one launch (at most 40 pairs)."""
+    n = len(pairs)
+    arr = (_lib.TransposeItem * n)()
+    for i, (a, out) in enumerate(pairs):
+        _chk(a, name='a'); _chk(out, name='out')
+        r, c = a.shape
+        assert out.shape == (c, r)
+        arr[i].src, arr[i].dst, arr[i].rows, arr[i].cols = a.data_ptr(), out.data_ptr(), r, c
+    _lib.call('wesup_transpose_batched', ctypes.cast(arr, ctypes.c_void_p), n, _stream())
+
+
+# ---------------------------------------------------------------- sync edges / step plans (csrc/plan.hip)
+def sync_record(slot, stream=None):
+    """Mark the work queued so far on ``stream`` (raw handle; None: torch's current stream) in event slot ``slot``."""
+    _lib.call('wesup_sync_record', int(slot), _stream() if stream is None else ctypes.c_void_p(stream))
+
+
+def sync_wait(slot, stream=None):
+    """``stream`` waits for the latest mark of ``slot``."""
+    _lib.call('wesup_sync_wait', int(slot), _stream() if stream is None else ctypes.c_void_p(stream))
 
 
 # ---------------------------------------------------------------- conv 3x3
@@ -255,6 +281,22 @@ def winograd_pack_weight(w, need_fwd=True, need_dgrad=True, u_fwd=None, u_dgrad=
     _lib.call('wesup_winograd_pack_weight', _p(w), _p(u_fwd if need_fwd else None),
               _p(u_dgrad if need_dgrad else None), Cout, Cin, m, _stream())
     return u_fwd if need_fwd else None, u_dgrad if need_dgrad else None
+
+
+def winograd_pack_weights(items):
+    """[(w (Cout,Cin,3,3), u_fwd (36,Cout,Cin) or None, u_dgrad (36,Cin,Cout) or None), ...]: the F(4x4,3x3) filters of
+    several layers in one launch (at most 32 panels)."""
+    n = len(items)
+    arr = (_lib.WinoFilter * n)()
+    for i, (w, uf, ud) in enumerate(items):
+        _chk(w, name='w')
+        Cout, Cin = w.shape[:2]
+        for u, shape in ((uf, (36, Cout, Cin)), (ud, (36, Cin, Cout))):
+            if u is not None:
+                _chk(u, name='u'); assert u.shape == shape, (u.shape, shape)
+        arr[i].w, arr[i].u_fwd, arr[i].u_dgrad = w.data_ptr(), (uf.data_ptr() if uf is not None else None), (ud.data_ptr() if ud is not None else None)
+        arr[i].Cout, arr[i].Cin = Cout, Cin
+    _lib.call('wesup_winograd_pack_weights', ctypes.cast(arr, ctypes.c_void_p), n, _stream())
 
 
 def winograd_tiles(B, H, W, m=2):
@@ -956,7 +998,7 @@ class SuperpixelMeta:
     """Device-side result of wesup_sp_preprocess for a batch of label maps (padded to Kmax rows per image)."""
     __slots__ = ('B', 'H', 'W', 'C', 'Kmax', 'labels', 'mask', 'n_sp', 'n_l', 'perm', 'inv_perm', 'area_new',
                  'sp_labels', 'new_row', 'row_start', 'pix_sorted', 'status', 'n_sp_host', 'seg_start', 'unit_row',
-                 'Umax')
+                 'Umax', 'counts')
 
     def check(self):
         """Host sync: raise on label-map errors the reference would turn into NaNs (models/wesup.py:57-61)."""
@@ -967,37 +1009,45 @@ class SuperpixelMeta:
                              'maximum id (ids must be contiguous 0..K-1)')
 
 
-def sp_preprocess(labels, mask, Kmax, n_classes=2, n_sp_host=None):
-    """labels (B,H,W) int32; mask (B,C,H,W) uint8 or None."""
+def sp_preprocess(labels, mask, Kmax, n_classes=2, n_sp_host=None, into=None, counts=None):
+    """labels (B,H,W) int32; mask (B,C,H,W) uint8 or None.  ``into``: a SuperpixelMeta of the same (B,H,W,C,Kmax) whose
+    buffers are written again (a recorded step plan needs every buffer at a fixed address); ``counts``: an int32 (3,B) tensor
+    that receives n_sp | n_l | status (the runner's read-back block)."""
     _chk(labels, torch.int32, 'labels')
     B, H, W = labels.shape
     HW = H * W
     dev = labels.device
     C = n_classes
+    Kmax = int(Kmax)
     if mask is not None:
         _chk(mask, torch.uint8, 'mask')
         assert mask.shape == (B, C, H, W)
-    m = SuperpixelMeta()
-    m.B, m.H, m.W, m.C, m.Kmax = B, H, W, C, int(Kmax)
+    m = into
+    if m is None or (m.B, m.H, m.W, m.C, m.Kmax) != (B, H, W, C, Kmax) or m.n_sp.device != dev:
+        m = SuperpixelMeta()
+        m.B, m.H, m.W, m.C, m.Kmax = B, H, W, C, Kmax
+        i32 = dict(dtype=torch.int32, device=dev)
+        # n_sp | n_l | status side by side: the trainer reads the three back with one copy
+        if counts is not None:
+            assert counts.shape == (3, B) and counts.dtype == torch.int32 and counts.is_contiguous()
+        m.counts = counts if counts is not None else torch.empty(3, B, **i32)
+        m.n_sp, m.n_l, m.status = m.counts[0], m.counts[1], m.counts[2]
+        m.perm = torch.empty(B, Kmax, **i32); m.inv_perm = torch.empty(B, Kmax, **i32)
+        m.area_new = torch.empty(B, Kmax, **i32)
+        m.sp_labels = torch.empty(B, Kmax, C, dtype=torch.float32, device=dev)
+        m.new_row = torch.empty(B, HW, **i32); m.row_start = torch.empty(B, Kmax + 1, **i32)
+        m.pix_sorted = torch.empty(B, HW, **i32)
+        # segment table (rows cut into <= 512-pixel segments) for the load-balanced pooling kernels
+        m.Umax = _lib.load().wesup_sp_max_units(HW, Kmax)
+        m.seg_start = torch.empty(B, Kmax + 1, **i32)
+        m.unit_row = torch.empty(B, m.Umax, **i32)
     m.labels, m.mask, m.n_sp_host = labels, mask, n_sp_host
-    i32 = dict(dtype=torch.int32, device=dev)
-    m.n_sp = torch.empty(B, **i32); m.n_l = torch.empty(B, **i32)
-    m.perm = torch.empty(B, Kmax, **i32); m.inv_perm = torch.empty(B, Kmax, **i32)
-    m.area_new = torch.empty(B, Kmax, **i32)
-    m.sp_labels = torch.empty(B, Kmax, C, dtype=torch.float32, device=dev)
-    m.new_row = torch.empty(B, HW, **i32); m.row_start = torch.empty(B, Kmax + 1, **i32)
-    m.pix_sorted = torch.empty(B, HW, **i32); m.status = torch.empty(B, **i32)
     nb = _lib.load().wesup_sp_preprocess_workspace_bytes(B, HW, C, Kmax)
     ws = workspace(nb, dev, 'sp')
     tok = _tbegin('sp_preprocess')
     _lib.call('wesup_sp_preprocess', _p(labels), _p(mask), B, HW, C, Kmax, _p(m.n_sp), _p(m.n_l), _p(m.perm),
               _p(m.inv_perm), _p(m.area_new), _p(m.sp_labels), _p(m.new_row), _p(m.row_start), _p(m.pix_sorted),
-              _p(m.status), _p(ws), nb, _stream())
-    # segment table (rows cut into <= 512-pixel segments) for the load-balanced pooling kernels
-    m.Umax = _lib.load().wesup_sp_max_units(HW, int(Kmax))
-    m.seg_start = torch.empty(B, Kmax + 1, **i32)
-    m.unit_row = torch.empty(B, m.Umax, **i32)
-    _lib.call('wesup_sp_segments', _p(m.row_start), B, int(Kmax), m.Umax, _p(m.seg_start), _p(m.unit_row), _stream())
+              _p(m.status), _p(m.seg_start), _p(m.unit_row), m.Umax, _p(ws), nb, _stream())
     # algorithmic bytes: the label map and the mask in, the row of every pixel and the row-sorted pixel list out
     _tend(tok, float(B) * HW * (4 + (C if mask is not None else 0) + 4 + 4))
     return m
@@ -1119,15 +1169,19 @@ def classifier_bwd(feat, Wc, pred, dpred, dfeat_extra=None, dfeat=None, dWc=None
     return dfeat, dWc, dbc
 
 
-def propagate(feat, meta, threshold, enable=True):
-    """feat (B,Kmax,D).  Returns y_all (B,Kmax,C), src_idx (B,Kmax) int32, max_sim (B,Kmax)."""
+def propagate(feat, meta, threshold, enable=True, out=None):
+    """feat (B,Kmax,D).  Returns y_all (B,Kmax,C), src_idx (B,Kmax) int32, max_sim (B,Kmax) (``out``: the three, reused)."""
     _chk(feat, name='feat')
     B, Kmax, D = feat.shape
     assert B == meta.B and Kmax == meta.Kmax
     dev = feat.device
-    y_all = torch.empty(B, Kmax, meta.C, dtype=torch.float32, device=dev)
-    src = torch.empty(B, Kmax, dtype=torch.int32, device=dev)
-    sim = torch.empty(B, Kmax, dtype=torch.float32, device=dev)
+    if out is not None:
+        y_all, src, sim = out
+        assert y_all.shape == (B, Kmax, meta.C) and src.shape == (B, Kmax) == sim.shape and src.dtype == torch.int32
+    else:
+        y_all = torch.empty(B, Kmax, meta.C, dtype=torch.float32, device=dev)
+        src = torch.empty(B, Kmax, dtype=torch.int32, device=dev)
+        sim = torch.empty(B, Kmax, dtype=torch.float32, device=dev)
     tok = _tbegin('propagate')
     _lib.call('wesup_propagate', _p(feat), _p(meta.sp_labels), _p(meta.n_sp), _p(meta.n_l), float(threshold), int(enable),
               _p(y_all), _p(src), _p(sim), B, Kmax, D, meta.C, _stream())
@@ -1135,12 +1189,16 @@ def propagate(feat, meta, threshold, enable=True):
     return y_all, src, sim
 
 
-def loss_fwd(pred, y_all, meta, eps, prop_weight):
+def loss_fwd(pred, y_all, meta, eps, prop_weight, out=None):
     _chk(pred, name='pred'); _chk(y_all, name='y_all')
     B, Kmax, C = pred.shape
     assert y_all.shape == (B, Kmax, C) and B == meta.B and Kmax == meta.Kmax
-    terms = torch.empty(B, 8, dtype=torch.float32, device=pred.device)
-    loss = torch.empty(1, dtype=torch.float32, device=pred.device)
+    if out is not None:
+        loss, terms = out
+        assert loss.numel() == 1 and terms.shape == (B, 8) and terms.is_contiguous()
+    else:
+        terms = torch.empty(B, 8, dtype=torch.float32, device=pred.device)
+        loss = torch.empty(1, dtype=torch.float32, device=pred.device)
     _lib.call('wesup_loss_fwd', _p(pred), _p(y_all), _p(meta.n_sp), _p(meta.n_l), float(eps), float(prop_weight),
               _p(terms), _p(loss), B, Kmax, C, _stream())
     return loss, terms
@@ -1186,12 +1244,14 @@ def sgd_step(p, g, v, lr, momentum, weight_decay, grad_scale, first_step):
     _tend(tok, 20.0 * p.numel())                     # read p, g, v; write p, v
 
 
-def seg_metrics(pred, mask):
+def seg_metrics(pred, mask, out=None):
     """pred (B,H,W) f32, mask (B,C,H,W) uint8 -> (B,4) sums {#(P==G), sum(P*G), sum(P), sum(G)}."""
     _chk(pred, name='pred'); _chk(mask, torch.uint8, 'mask')
     B, H, W = pred.shape
     C = mask.shape[1]
-    out = torch.empty(B, 4, dtype=torch.float32, device=pred.device)
+    if out is None:
+        out = torch.empty(B, 4, dtype=torch.float32, device=pred.device)
+    assert out.shape == (B, 4) and out.is_contiguous()
     nb = _lib.load().wesup_seg_metrics_workspace_bytes(B)
     ws = workspace(nb, pred.device, 'seg')
     _lib.call('wesup_seg_metrics', _p(pred), _p(mask), _p(out), B, H * W, C, _p(ws), nb, _stream())

@@ -1,0 +1,331 @@
+"""The training iteration of the standard case as ONE walk over the C ABI -- recordable and replayable.
+
+``BaseTrainer.train_one_iteration`` (models/base.py:184-211 of the reference: preprocess -> zero_grad -> forward -> loss ->
+NaN check -> backward -> step -> evaluate -> tracker) keeps its interface; for the case every benchmark configuration and
+the GlaS / CRAG training loops are in -- train phase, label maps given with the batch (tensor or ``LabelMaps``), point /
+pixel masks as (B,C,H,W) tensors, accuracy / dice as metrics, the fused SGD -- it hands the iteration to this runner:
+
+* every buffer the iteration touches lives in a per-shape state (inputs are COPIED into it), nothing is allocated per step and
+  nothing goes through autograd: the loss gradient is ``wesup_loss_bwd`` with an upstream gradient of one, the engine's
+  backward is called directly;
+* loss, per-image loss terms, segmentation sums and the superpixel counts sit in one device buffer that ONE copy brings to
+  pinned host memory; the host waits for it behind the queued backward, checks for NaN, and only then queues the optimiser
+  (``ValueError('Loss is nan!')`` with the weights untouched, models/base.py:202-203);
+* the third occurrence of a shape records the walk into a step plan (csrc/plan.hip), the fourth records it again and the
+  two recordings are compared node by node; when they are identical, later iterations of that shape REPLAY the plan from C
+  (``wesup_plan_replay``): ~330 launches without Python or ctypes in between.  Host work inside the iteration (the NaN check, a
+  gradient bucket handed to RCCL) splits the replay into segments.  Anything that moves a buffer (a workspace that grew, the
+  engine's buffer cache evicting the shape) or changes the walk (an engine switch, the learning rate, frozen parameters)
+  drops the plan; the Python walk is always there and computes the same thing.
+
+Results are bit-identical to the trainer's general path (tests/test_runner_gpu.py): the same kernels on the same operands in
+the same stream order.
+"""
+import ctypes
+import math
+import os
+
+import numpy as np
+import torch
+
+from . import _lib, ops
+from .utils import is_empty_tensor
+from .utils import metrics as M
+
+RB_SLOT = 40          # event slot of the read-back copy (the engine uses 0 .. 27 and 64 ..)
+RECORD_AT = 2         # eager iterations of a shape before the first recording
+MAX_RECORD_TRIES = 4
+MAX_STATES = 4
+
+
+class _Plan:
+    def __init__(self):
+        self.h = ctypes.c_void_p()
+        _lib.call('wesup_plan_create', ctypes.byref(self.h))
+        self.cuts = []        # (node index, callback) in walk order
+
+    def size(self):
+        return _lib.load().wesup_plan_size(self.h)
+
+    def __del__(self):
+        try:
+            if self.h:
+                _lib.load().wesup_plan_destroy(self.h)
+        except Exception:
+            pass
+
+
+class _State:
+    """Everything one shape's iteration reads or writes outside the engine's own buffers."""
+
+    def __init__(self, B, H, W, C, Kmax, dev, has_mask, has_gt):
+        f32 = dict(dtype=torch.float32, device=dev)
+        self.img = torch.empty(B, 3, H, W, **f32)
+        self.labels = torch.empty(B, H, W, dtype=torch.int32, device=dev)
+        self.mask = torch.empty(B, C, H, W, dtype=torch.uint8, device=dev) if has_mask else None
+        self.gt = torch.empty(B, C, H, W, dtype=torch.uint8, device=dev) if has_gt else None
+        self.meta = None
+        # read-back block: loss | terms (B,8) | seg (B,4) | NaN flag of the other ranks as floats, then n_sp | n_l | status as
+        # int32 (the superpixel preprocessing writes them there): ONE copy brings the block to the host
+        self.n_f = 1 + 8 * B + 4 * B + 1
+        self.rb = torch.zeros(self.n_f + 3 * B, **f32)
+        self.loss = self.rb[0:1]
+        self.terms = self.rb[1:1 + 8 * B].view(B, 8)
+        self.seg = self.rb[1 + 8 * B:1 + 12 * B].view(B, 4)
+        self.rb_flag = self.rb[self.n_f - 1:self.n_f]
+        self.rb_counts = self.rb[self.n_f:].view(torch.int32).view(3, B)
+        self.host = torch.empty(self.n_f + 3 * B, dtype=torch.float32).pin_memory()
+        self.rb_event = None      # data parallel: the copy runs on the NaN flag's stream, marked by a torch event
+        self.y_all = torch.empty(B, Kmax, C, **f32)
+        self.src = torch.empty(B, Kmax, dtype=torch.int32, device=dev)
+        self.sim = torch.empty(B, Kmax, **f32)
+        self.dpred = torch.empty(B, Kmax, C, **f32)
+        self.one = torch.ones(1, **f32)
+        self.count = 0
+        self.plan = None          # the plan being replayed
+        self.cand = None          # first recording, waiting for its twin
+        self.tries = 0
+        self.sig = None
+
+
+class StepRunner:
+    def __init__(self, trainer):
+        self.t = trainer
+        self.states = {}
+        self.replay = os.environ.get('WESUP_STEP_PLAN', '1') != '0' and trainer.kwargs.get('step_plan', True)
+        self.stats = {'eager': 0, 'recorded': 0, 'replayed': 0, 'dropped': 0}
+        self._cuts = None
+
+    # ------------------------------------------------------------------ which iterations take this path
+    def parse(self, phase, data):
+        """The data tuple of an iteration this runner covers as (img, pixel_mask, point_mask, labels, counts), else None."""
+        t = self.t
+        if phase != 'train' or len(data) != 4 or t.kwargs.get('check_label_maps', False):
+            return None
+        from .optim import FusedSGD
+        if not isinstance(t.optimizer, FusedSGD) or type(t.model).__name__ != 'WESUP':
+            return None
+        names = [f.__name__ for f in (t.metric_funcs or [])]
+        if not all(n in ('accuracy', 'dice') for n in names):
+            return None
+        img, pixel_mask, point_mask, seg = data
+        counts = None
+        if hasattr(seg, 'labels') and hasattr(seg, 'counts'):
+            counts, seg = list(seg.counts), seg.labels
+        if not (torch.is_tensor(img) and torch.is_tensor(seg) and img.dim() == 4 and seg.dim() == 3):
+            return None
+        B, _, H, W = img.shape
+        if seg.shape != (B, H, W) or B > 256:
+            return None
+        for m in (pixel_mask, point_mask):
+            if not torch.is_tensor(m) or not (is_empty_tensor(m) or (m.dim() == 4 and m.shape[0] == B and m.shape[2:] == (H, W))):
+                return None
+        if counts is None and not seg.is_cuda:
+            counts = [int(seg[b].max()) + 1 for b in range(B)]
+        return img, pixel_mask, point_mask, seg, counts
+
+    def _signature(self, eng):
+        t, o = self.t, self.t.optimizer
+        g = o.param_groups[0]
+        sw = tuple(sorted((k, v) for k, v in vars(eng).items() if isinstance(v, (bool, int, type(None))) and not k.startswith('_')))
+        red = t.reducer
+        return (sw, eng.route_fn, type(eng).WINOGRAD_CONV_MIN_CI, type(eng).WINOGRAD_TILE, tuple(sorted(eng._diag_skip)),
+                ops.STREAMK_FWD, ops.STREAMK_DGRAD, ops.STREAMK_GEMM, ops.STREAMK,
+                g['lr'], g['momentum'], g['weight_decay'], o.grad_scale, o._first,
+                tuple(p.requires_grad for _, p in t.model._named),
+                float(t.kwargs.get('propagate_threshold')), float(t.kwargs.get('propagate_weight')),
+                bool(t.kwargs.get('enable_propagation')), float(t.kwargs.get('epsilon')),
+                None if red is None else (id(red), t.world_size, red.bucket_elems, red.force),
+                torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice()))
+
+    # ------------------------------------------------------------------ the iteration
+    def run(self, parsed):
+        t = self.t
+        img, pixel_mask, point_mask, seg, counts = parsed
+        model = t.model
+        model._ensure_engine()
+        eng = model.engine
+        dev = eng.device
+        B, _, H, W = img.shape
+        mask = point_mask if not is_empty_tensor(point_mask) else (pixel_mask if not is_empty_tensor(pixel_mask) else None)
+        has_gt = not is_empty_tensor(pixel_mask)
+        names = [f.__name__ for f in (t.metric_funcs or [])]
+        want_seg = has_gt and bool(names)
+        C = mask.shape[1] if mask is not None else (pixel_mask.shape[1] if has_gt else 2)
+        Kmax = t._kmax(counts, None, H, W)
+        key = (B, H, W, C, Kmax, mask is not None, want_seg)
+        st = self.states.pop(key, None)
+        if st is None:
+            while len(self.states) >= MAX_STATES:
+                self.states.pop(next(iter(self.states)))
+            st = _State(B, H, W, C, Kmax, dev, mask is not None, want_seg)
+        self.states[key] = st                         # (most recently used last)
+        if t.reducer is not None:
+            t.reducer.reset()                         # nothing may be left over from an iteration that raised
+        # ---- inputs into the state's buffers (dtype conversions ride in the copies)
+        st.img.copy_(img, non_blocking=True)
+        st.labels.copy_(seg, non_blocking=True)
+        if mask is not None:
+            st.mask.copy_(mask, non_blocking=True)
+        if want_seg:
+            st.gt.copy_(pixel_mask, non_blocking=True)
+        st.n_sp_host = counts
+
+        timing = eng.timer.enabled or (t.reducer is not None and t.reducer.profile)
+        sig = self._signature(eng) if self.replay else None
+        gens = (ops.ws_generation, eng.buf_generation)
+        if st.plan is not None and (st.sig != sig or st.gens != gens):
+            st.plan = st.cand = None
+            st.count = 0
+            self.stats['dropped'] += 1
+        metrics = {}
+        if st.plan is not None and not timing:
+            host = self._replay(st, metrics)
+            self.stats['replayed'] += 1
+        else:
+            record = (self.replay and not timing and st.count >= RECORD_AT and st.tries < MAX_RECORD_TRIES
+                      and (st.cand is None or (st.sig == sig)))
+            plan = _Plan() if record else None
+            host = self._walk(st, metrics, want_seg, plan)
+            st.count += 1
+            if plan is not None:
+                self.stats['recorded'] += 1
+                gens = (ops.ws_generation, eng.buf_generation)
+                if st.cand is not None and st.gens == gens and _lib.load().wesup_plan_diff(st.cand.h, plan.h) == 0:
+                    st.plan, st.cand = plan, None
+                else:
+                    if st.cand is not None:
+                        st.tries += 1
+                        if os.environ.get('WESUP_PLAN_DEBUG'):
+                            k = _lib.load().wesup_plan_diff(st.cand.h, plan.h)
+                            print(f'[step plan] recordings differ at node {k - 1}: '
+                                  f'{_lib.load().wesup_plan_node_name(plan.h, k - 1)} (sizes {st.cand.size()} / {plan.size()})')
+                    st.cand = plan
+                st.sig, st.gens = sig, gens
+            else:
+                self.stats['eager'] += 1
+        return self._finish(st, host, metrics, want_seg, names, H, W)
+
+    def _cut(self, plan, fn):
+        """Host work inside the iteration: run it now, and when recording, remember where the replay has to stop for it."""
+        if plan is not None:
+            plan.cuts.append((plan.size(), fn))
+        return fn()
+
+    def _walk(self, st, metrics, want_seg, plan):
+        t = self.t
+        model, eng = t.model, t.model.engine
+        red = t.reducer
+        kw = t.kwargs
+        eng._rot = 0
+        if plan is not None:
+            _lib.call('wesup_plan_begin', plan.h)
+        saved_ready = eng.on_grads_ready
+        try:
+            if red is not None:
+                # a gradient range handed to the reducer is host work on the stream that produced it
+                def ready(names, _red=red):
+                    cur = torch.cuda.current_stream()
+                    def go(names=list(names), cur=cur):
+                        with eng._On(cur):
+                            _red.ready(names)
+                    self._cut(plan, go)
+                eng.on_grads_ready = ready
+            model.prefetch_weights(train=True)                # side stream: conv1_1 only waits for its own panel
+            with eng.side_stream():
+                st.meta = ops.sp_preprocess(st.labels, st.mask, st.y_all.shape[1], n_classes=st.y_all.shape[2],
+                                            n_sp_host=st.n_sp_host, into=st.meta, counts=st.rb_counts)
+            eng.frozen = {n for n, p in model._named if not p.requires_grad}
+            feats, sp_pred, pred = eng.forward(st.img, st.meta, train=True)
+            if want_seg:
+                ops.seg_metrics(pred, st.gt, out=st.seg)
+            ops.propagate(feats, st.meta, float(kw.get('propagate_threshold')), enable=bool(kw.get('enable_propagation')),
+                          out=(st.y_all, st.src, st.sim))
+            ops.loss_fwd(sp_pred, st.y_all, st.meta, float(kw.get('epsilon')), float(kw.get('propagate_weight')),
+                         out=(st.loss, st.terms))
+            if red is not None and t.world_size > 1:
+                # A NaN loss on one rank must stop every rank (models/base.py _loss_flag): a MAX all-reduce of a flag on a
+                # stream of its own, the read-back copy behind it.  Host work (torch collectives), i.e. a cut of the plan.
+                def nan_flag():
+                    f, aux = t._loss_flag(st.loss)
+                    with torch.cuda.stream(aux):
+                        st.rb_flag.copy_(f)
+                        st.host.copy_(st.rb, non_blocking=True)
+                        st.rb_event = torch.cuda.Event()
+                        st.rb_event.record()
+                self._cut(plan, nan_flag)
+            else:
+                st.rb_event = None
+                _lib.call('wesup_copy_to_host', ctypes.c_void_p(st.host.data_ptr()), ops._p(st.rb), st.rb.numel() * 4, ops._stream())
+                ops.sync_record(RB_SLOT)
+            if red is not None and red.profile:
+                red.t_backward = torch.cuda.Event(enable_timing=True)
+                red.t_backward.record()
+            ops.loss_bwd(sp_pred, st.y_all, st.meta, st.terms, st.one, float(kw.get('epsilon')),
+                         float(kw.get('propagate_weight')), out=st.dpred)
+            eng.backward(None, st.dpred)
+            if red is not None:
+                self._cut(plan, red.finish)
+            host = self._cut(plan, lambda: self._wait_and_check(st))
+            t.optimizer.step()
+        finally:
+            eng.on_grads_ready = saved_ready
+            if plan is not None:
+                _lib.load().wesup_plan_end(plan.h)
+        model._publish_grads()
+        st.feats, st.sp_pred = feats, sp_pred
+        self._publish(st)
+        return host
+
+    def _replay(self, st, metrics):
+        plan = st.plan
+        lib = _lib.load()
+        pos, host = 0, None
+        for node, fn in plan.cuts:
+            if node > pos:
+                _lib.check(lib.wesup_plan_replay(plan.h, pos, node), 'wesup_plan_replay')
+            pos = node
+            r = fn()
+            if isinstance(r, dict):
+                host = r
+        _lib.check(lib.wesup_plan_replay(plan.h, pos, plan.size()), 'wesup_plan_replay')
+        self.t.model._publish_grads()
+        self._publish(st)
+        return host
+
+    def _wait_and_check(self, st):
+        if st.rb_event is not None:
+            st.rb_event.synchronize()
+        else:
+            _lib.call('wesup_sync_synchronize', RB_SLOT)             # <- the host sync of the iteration
+        B = st.terms.shape[0]
+        raw = st.host.numpy()
+        f = raw[:st.n_f].astype(np.float64)
+        cnt = raw[st.n_f:].view(np.int32).reshape(3, B)
+        host = {'loss': float(f[0]), 'terms': f[1:1 + 8 * B].reshape(B, 8), 'seg': f[1 + 8 * B:1 + 12 * B].reshape(B, 4),
+                'n_sp': cnt[0].astype(np.float64), 'n_l': cnt[1].astype(np.float64)}
+        nan_anywhere = f[st.n_f - 1] if st.rb_event is not None else 0.0
+        if math.isnan(host['loss']) or nan_anywhere > 0:
+            raise ValueError('Loss is nan!')
+        return host
+
+    def _publish(self, st):
+        """The attributes the reference's forward leaves on the module (models/wesup.py:287-292); compute_loss clears sp_pred."""
+        m = self.t.model
+        m.fm_size = (st.img.shape[2], st.img.shape[3])
+        m._last_meta = st.meta
+        m._padded = (st.feats, st.sp_pred)
+        m.sp_features = st.feats
+        m.sp_pred = None
+
+    def _finish(self, st, host, metrics, want_seg, names, H, W):
+        t = self.t
+        t._metrics_from_terms(host, metrics)
+        metrics['loss'] = host['loss']
+        ev = {}
+        if want_seg:
+            if 'accuracy' in names:
+                ev['accuracy'] = M.accuracy_from_sums(host['seg'], H * W)
+            if 'dice' in names:
+                ev['dice'] = M.dice_from_sums(host['seg'])
+        t.tracker.step({**metrics, **ev})
