@@ -80,6 +80,7 @@ struct ElasticField {
     const float* field;          // [B][2][hc][wc] (dx plane, dy plane), or NULL
     const ElasticParams* par;    // [B]
     int hc, wc, cell;
+    int pad_;                    // (explicit padding, zero: launch.hpp)
 };
 __device__ __forceinline__ float elastic_sample(const float* f, int hc, int wc, float u, float v) {
     u = fminf(fmaxf(u, 0.f), (float)(wc - 1));
@@ -156,7 +157,7 @@ extern "C" int wesup_augment(const uint8_t* img_hwc, const uint8_t* mask_hw, con
     if (mask_hw && !out_mask_chw) return WESUP_ERR_INVALID;
     if (elastic_field && (!elastic_params || hc <= 0 || wc <= 0 || cell <= 0)) return WESUP_ERR_INVALID;
     const long HW = (long)H * W;
-    const ElasticField el = {elastic_field, reinterpret_cast<const ElasticParams*>(elastic_params), hc, wc, cell};
+    const ElasticField el = {elastic_field, reinterpret_cast<const ElasticParams*>(elastic_params), hc, wc, cell, 0};
     WESUP_LAUNCH(augment_kernel, dim3((unsigned)((HW + 255) / 256), B), dim3(256), 0, (hipStream_t)stream, img_hwc,
                        mask_hw, reinterpret_cast<const AugParams*>(params), out_img_nchw, out_mask_chw, H, W, C, el);
     WESUP_CHECK_LAUNCH();

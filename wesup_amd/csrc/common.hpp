@@ -21,9 +21,11 @@ static inline size_t align_up(size_t a, size_t b) { return (a + b - 1) / b * b; 
 struct FastDiv {
     unsigned long long m;
     int d;
+    int pad_;            // (explicit: by-value kernel parameters carry no indeterminate bytes, launch.hpp)
 };
 static inline FastDiv make_fastdiv(int d) {
     FastDiv f;
+    f.pad_ = 0;
     f.d = d;
     f.m = ((1ull << 40) + (unsigned long long)d - 1) / (unsigned long long)d;
     return f;

@@ -48,6 +48,7 @@ struct NtParams {
     int M, N, K;
     int lda, ldb, ldc, ldmask;
     int H, W, Cin, cin_shift;
+    int pad0_;           // (explicit padding, zero: by-value kernel parameters carry no indeterminate bytes, launch.hpp)
     FastDiv dW, dH;      // pixel index -> (image, row, column) without integer division (conv modes)
     int flags;
     int tiles_m, tiles_n;
@@ -57,6 +58,7 @@ struct NtParams {
     float* sk_ws;        // [sk_parts][2][BM*BN] partial tiles
     // batched plain GEMMs (MODE 0, no stream-K): nbatch products of one shape in one launch; tile ids run batch-major
     int nbatch;              // 0 / 1: a single product
+    int pad1_;
     FastDiv dTiles;          // tiles per product
     long batchA, batchB, batchC;   // element strides between the products' operands
     long batchBias;                // ... and between their bias vectors (0: one bias for all)
@@ -65,6 +67,7 @@ struct NtParams {
     const float* side_bias;  // [N/2] or NULL
     float* side_out;
     int ld_side;
+    int pad2_;
 };
 
 // ---------------------------------------------------------------------------------------------

@@ -14,25 +14,39 @@
 struct WesupPlan;
 // plan.hip: the plan this thread is recording into (NULL: none), and the appenders
 WesupPlan* wesup_plan_recording_();
-void wesup_plan_add_kernel_(WesupPlan* plan, const void* fn, dim3 grid, dim3 block, size_t lds, hipStream_t st, const void* blob,
-                            size_t blob_bytes, const unsigned* offs, int nargs);
+void wesup_plan_add_kernel_(WesupPlan* plan, const void* fn, dim3 grid, dim3 block, size_t lds, hipStream_t st,
+                            const void* const* args, const unsigned* sizes, int nargs);
 
 template <typename Tuple, size_t... I>
-static inline void wesup_arg_offsets_(const Tuple& t, unsigned* offs, std::index_sequence<I...>) {
-    ((offs[I] = (unsigned)((const char*)&std::get<I>(t) - (const char*)&t)), ...);
+static inline void wesup_arg_pointers_(const Tuple& t, const void** ptrs, std::index_sequence<I...>) {
+    ((ptrs[I] = &std::get<I>(t)), ...);
 }
+
+// A plan is compared with a second recording of the same step byte by byte (wesup_plan_diff), so an argument copy must not
+// carry indeterminate bytes: every by-value kernel parameter is a scalar, a pointer, or a struct WITHOUT padding (explicit
+// `pad_` members where the layout has holes).  Structs with float members cannot be checked by the compiler
+// (has_unique_object_representations is false for floating point): they opt in with WESUP_NO_PADDING(T, bytes-of-members).
+template <typename T>
+struct wesup_no_padding : std::integral_constant<bool, std::is_scalar<T>::value || std::has_unique_object_representations<T>::value> {};
+#define WESUP_NO_PADDING(T, member_bytes)                                                         \
+    static_assert(sizeof(T) == (member_bytes), #T " has padding: add explicit pad_ members");    \
+    template <>                                                                                   \
+    struct wesup_no_padding<T> : std::true_type {}
 
 template <typename... KA, typename... A>
 static inline void wesup_launch(void (*kern)(KA...), dim3 grid, dim3 block, size_t lds, hipStream_t st, A&&... a) {
     static_assert(sizeof...(KA) == sizeof...(A), "argument count differs from the kernel's parameter list");
     static_assert((std::is_trivially_copyable<std::decay_t<KA>>::value && ...), "kernel parameters are copied byte-wise into a plan");
+    static_assert((wesup_no_padding<std::decay_t<KA>>::value && ...), "a by-value kernel parameter has padding bytes (launch.hpp)");
     WesupPlan* rec = wesup_plan_recording_();
     if (rec) {
+        // the arguments as the kernel receives them (converted to its parameter types), copied one by one: the plan lays them
+        // out itself, so no byte between two arguments is left to chance either
         const std::tuple<std::decay_t<KA>...> args(static_cast<std::decay_t<KA>>(a)...);
-        unsigned offs[sizeof...(KA) > 0 ? sizeof...(KA) : 1];
-        wesup_arg_offsets_(args, offs, std::index_sequence_for<KA...>{});
-        wesup_plan_add_kernel_(rec, reinterpret_cast<const void*>(kern), grid, block, lds, st, &args, sizeof(args), offs,
-                               (int)sizeof...(KA));
+        const void* ptrs[sizeof...(KA) > 0 ? sizeof...(KA) : 1];
+        const unsigned sizes[sizeof...(KA) > 0 ? sizeof...(KA) : 1] = {(unsigned)sizeof(std::decay_t<KA>)...};
+        wesup_arg_pointers_(args, ptrs, std::index_sequence_for<KA...>{});
+        wesup_plan_add_kernel_(rec, reinterpret_cast<const void*>(kern), grid, block, lds, st, ptrs, sizes, (int)sizeof...(KA));
     }
     hipLaunchKernelGGL(kern, grid, block, lds, st, static_cast<std::decay_t<KA>>(a)...);
 }

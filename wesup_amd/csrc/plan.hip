@@ -41,15 +41,21 @@ static thread_local WesupPlan* t_rec = nullptr;
 
 WesupPlan* wesup_plan_recording_() { return t_rec; }
 
-void wesup_plan_add_kernel_(WesupPlan* plan, const void* fn, dim3 grid, dim3 block, size_t lds, hipStream_t st, const void* blob,
-                            size_t blob_bytes, const unsigned* offs, int nargs) {
+void wesup_plan_add_kernel_(WesupPlan* plan, const void* fn, dim3 grid, dim3 block, size_t lds, hipStream_t st,
+                            const void* const* args, const unsigned* sizes, int nargs) {
     PlanNode n = {};
     n.kind = NODE_KERNEL; n.fn = fn; n.grid = grid; n.block = block; n.lds = (unsigned)lds; n.st = st; n.nargs = nargs;
     n.blob = align_up(plan->blob.size(), 16);
-    plan->blob.resize(n.blob + blob_bytes);
-    memcpy(plan->blob.data() + n.blob, blob, blob_bytes);
     n.offs = plan->offs.size();
-    plan->offs.insert(plan->offs.end(), offs, offs + nargs);
+    size_t end = n.blob;
+    for (int k = 0; k < nargs; ++k) {              // every argument on a 16-byte boundary of a zero-filled blob
+        const size_t at = align_up(end, 16);
+        plan->offs.push_back((unsigned)(at - n.blob));
+        end = at + sizes[k];
+    }
+    plan->blob.resize(align_up(end, 16), 0);
+    for (int k = 0; k < nargs; ++k) memcpy(plan->blob.data() + n.blob + plan->offs[n.offs + k], args[k], sizes[k]);
+    n.bytes = plan->blob.size() - n.blob;
     plan->nodes.push_back(n);
 }
 
@@ -221,20 +227,7 @@ extern "C" int wesup_plan_diff(const WesupPlan* a, const WesupPlan* b) {
         if (same && x.kind == NODE_KERNEL) {
             same = x.fn == y.fn && x.grid.x == y.grid.x && x.grid.y == y.grid.y && x.grid.z == y.grid.z && x.block.x == y.block.x &&
                    x.lds == y.lds && x.nargs == y.nargs;
-            for (int k = 0; same && k < x.nargs; ++k) {
-                const size_t ox = a->offs[x.offs + k], oy = b->offs[y.offs + k];
-                // argument k spans up to the next argument's offset; compare the bytes both plans hold for it
-                same = ox == oy;
-            }
-            if (same && x.nargs) {
-                const size_t bx = (i + 1 < a->nodes.size() ? 0 : 0);
-                (void)bx;
-                // byte size of the argument copy = distance to the next 16-aligned blob or the end
-                size_t ex = a->blob.size(), ey = b->blob.size();
-                for (size_t j = i + 1; j < a->nodes.size(); ++j) if (a->nodes[j].kind == NODE_KERNEL) { ex = a->nodes[j].blob; break; }
-                for (size_t j = i + 1; j < b->nodes.size(); ++j) if (b->nodes[j].kind == NODE_KERNEL) { ey = b->nodes[j].blob; break; }
-                same = (ex - x.blob) == (ey - y.blob) && memcmp(a->blob.data() + x.blob, b->blob.data() + y.blob, ex - x.blob) == 0;
-            }
+            same = same && x.bytes == y.bytes && memcmp(a->blob.data() + x.blob, b->blob.data() + y.blob, x.bytes) == 0;
         } else if (same && (x.kind == NODE_RECORD || x.kind == NODE_WAIT)) {
             same = x.slot == y.slot;
         } else if (same && x.kind == NODE_COPY) {

@@ -428,6 +428,7 @@ struct UpGroup {
     const float* g[3];
     float* ds[3];
     int c4[3];               // channel quads per layer (0: unused slot); rows of g[i] are c4[i]*4 floats apart
+    int pad_;                // (explicit padding, zero: launch.hpp)
 };
 template <int NPASS>
 __global__ __launch_bounds__(256) void upsample_bwd_cell_group_kernel(UpGroup G, const int32_t* __restrict__ new_row,
@@ -516,7 +517,7 @@ extern "C" int wesup_upsample_bwd_group(const float* g0, const float* g1, const 
     const float* gs[3] = {g0, g1, g2};
     float* dss[3] = {ds0, ds1, ds2};
     const int cs[3] = {C0, C1, C2};
-    UpGroup G;
+    UpGroup G = {};
     int quads = 0;
     for (int i = 0; i < 3; ++i) {
         const bool on = i < n;

@@ -51,6 +51,7 @@ struct SpPre {
     const int32_t* labels;
     const uint8_t* mask;
     int HW, C, Kmax, nchunk, Umax;
+    int pad_;                // (explicit padding, zero: launch.hpp)
     int32_t* chunk_hist;     // [B][nchunk][Kmax]: histogram, later the chunk's base inside each row
     int32_t* chunk_cnt;      // [B][nchunk][Kmax * C] class counts per chunk (mask given)
     int32_t* chunk_info;     // [B][nchunk][2] {largest id + 1, status bits}

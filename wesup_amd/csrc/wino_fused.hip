@@ -398,7 +398,7 @@ extern "C" int wesup_winograd_gemm_output_transform(const float* V, long plane_e
                                                     const float* unpool_src, float* unpool_dst, int Hu, int Wu, int B, int H,
                                                     int W, int K, int N, int accumulate, void* stream) {
     return fused_launch(V, plane_elems, U, bias, mask_src, y, y_pool, pool_relu, unpool_src, unpool_dst, Hu, Wu, B, H, W, K, N,
-                        accumulate, WinoGather{nullptr, nullptr, nullptr, 0, 0}, FusedBits{nullptr, nullptr, nullptr}, stream);
+                        accumulate, WinoGather{nullptr, nullptr, nullptr, 0, 0, 0}, FusedBits{nullptr, nullptr, nullptr}, stream);
 }
 
 // Every option of the one-kernel route in one entry.  Beyond wesup_winograd_gemm_output_transform[_gather]:
@@ -417,11 +417,11 @@ extern "C" int wesup_winograd_gemm_output_transform_ex(const float* V, long plan
                                                        int W, int K, int N, int accumulate, void* stream) {
     const bool unpool = unpool_src || unpool_code;
     if (unpool && (!unpool_dst || Hu / 2 != H || Wu / 2 != W)) return WESUP_ERR_INVALID;
-    WinoGather gat = {nullptr, nullptr, nullptr, 0, 0};
+    WinoGather gat = {nullptr, nullptr, nullptr, 0, 0, 0};
     if (side) {
         if (!new_row || !area_new || Kmax <= 0 || accumulate || bias || y_pool || (((uintptr_t)side) & 15)) return WESUP_ERR_INVALID;
         if (unpool && ((Hu & 1) || (Wu & 1))) return WESUP_ERR_INVALID;
-        gat = WinoGather{side, new_row, area_new, Kmax, unpool ? (long)Hu * Wu : (long)H * W};
+        gat = WinoGather{side, new_row, area_new, Kmax, 0, unpool ? (long)Hu * Wu : (long)H * W};
     }
     return fused_launch(V, plane_elems, U, bias, mask_src, unpool ? nullptr : y, y_pool, pool_relu, unpool_src,
                         unpool ? unpool_dst : nullptr, Hu, Wu, B, H, W, K, N, accumulate, gat,
@@ -437,7 +437,7 @@ extern "C" int wesup_winograd_gemm_output_transform_gather(const float* V, long 
                                                            int H, int W, int K, int N, void* stream) {
     if (!side || !new_row || !area_new || Kmax <= 0 || !y || (((uintptr_t)side) & 15)) return WESUP_ERR_INVALID;
     if (unpool_src && ((Hu & 1) || (Wu & 1))) return WESUP_ERR_INVALID;
-    const WinoGather gat = {side, new_row, area_new, Kmax, unpool_src ? (long)Hu * Wu : (long)H * W};
+    const WinoGather gat = {side, new_row, area_new, Kmax, 0, unpool_src ? (long)Hu * Wu : (long)H * W};
     const FusedBits nobits = {nullptr, nullptr, nullptr};
     if (unpool_src)
         return fused_launch(V, plane_elems, U, nullptr, mask_src, nullptr, nullptr, 0, unpool_src, y, Hu, Wu, B, H, W, K, N, 0, gat,

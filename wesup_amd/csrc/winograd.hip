@@ -19,6 +19,7 @@
 
 struct WinoGeom {
     int H, W, C, Th, Tw;
+    int pad_;            // (explicit padding, zero: launch.hpp)
     long ps;             // elements between two position planes of the transformed tensor (>= T * C: a sub-batch may
                          // write its rows into the planes of the whole batch)
     long T;              // tiles = B * Th * Tw
@@ -719,7 +720,7 @@ extern "C" int wesup_winograd_pack_weights(const WesupWinoFilter* layers /* host
 }
 
 static WinoGeom wino_geom(int B, int H, int W, int C, int m, long plane_elems = 0) {
-    WinoGeom g;
+    WinoGeom g = {};
     g.H = H; g.W = W; g.Th = (H + m - 1) / m; g.Tw = (W + m - 1) / m; g.T = wino_tiles(B, H, W, m);
     g.ps = plane_elems > 0 ? plane_elems : g.T * C;
     g.dTw = make_fastdiv(g.Tw); g.dTh = make_fastdiv(g.Th);

@@ -78,6 +78,7 @@ struct WinoGather {
     const int32_t* row;
     const int32_t* area;
     int Kmax;
+    int pad_;            // (explicit padding, zero: by-value kernel parameters carry no indeterminate bytes, launch.hpp)
     long HW;             // pixels per image at the resolution of the epilogue's destination
 };
 __device__ __forceinline__ float4 wino_gather(const WinoGather& g, int b, long pix, int C, int c0) {

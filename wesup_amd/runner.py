@@ -267,12 +267,12 @@ class StepRunner:
             if red is not None:
                 self._cut(plan, red.finish)
             host = self._cut(plan, lambda: self._wait_and_check(st))
+            model._publish_grads()                            # p.grad = views of the flat gradient buffer (what step() looks at)
             t.optimizer.step()
         finally:
             eng.on_grads_ready = saved_ready
             if plan is not None:
                 _lib.load().wesup_plan_end(plan.h)
-        model._publish_grads()
         st.feats, st.sp_pred = feats, sp_pred
         self._publish(st)
         return host
