@@ -93,6 +93,12 @@ def parse_args(argv=None):
                     help='multi-rank rehearsal on a one-GPU box: every rank uses cuda:0 and gloo carries the exchange '
                          '(RCCL refuses two ranks on one device); exercises the launch contract, not performance')
     ap.add_argument('--ddp-probe', default='', help="diagnostics with one rank: 'pg' = process group only, 'reducer' = reducer without the collective")
+    ap.add_argument('--end-to-end', action='store_true', help='second bench line (never the headline): decoded uint8 batch -> wesup_augment -> '
+                    'GPU SLIC at sp_area 200, one batch ahead on a second stream -> training step; same JSON schema')
+    ap.add_argument('--multiscale', type=int, default=0, help='second bench line: the reference\'s own operating point (models/wesup.py:178, '
+                    'utils/data.py:98-101): batch 1, a new (H, W) every step drawn from 0.3-0.4 x 775x522, this many distinct shapes in rotation')
+    ap.add_argument('--no-step-plan', action='store_true', help='A/B: every iteration walks the launch list in Python (no replay of a recorded step plan, wesup_amd/runner.py)')
+    ap.add_argument('--general-path', action='store_true', help='A/B: the trainer\'s general path (preprocess / forward / compute_loss / autograd backward) instead of the step runner')
     ap.add_argument('--stub-trainer', action='store_true',
                     help='launch-contract rehearsal WITHOUT a GPU: every rank runs a trivial CPU step under gloo; only '
                          'the launcher, the rendezvous, the barrier/max-over-ranks timing and the one JSON line are real '
@@ -224,6 +230,8 @@ def worker(args):
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: the launcher and the flag disagree')
     if args.stub_trainer:
         return stub_worker(args, rank, world)
+    if args.multiscale or args.end_to_end:            # second lines: throughput only (the roofline objects belong to the headline)
+        args.no_kernel_timing = args.no_cpu_baseline = True
     # stdout carries ONE line, the JSON of rank 0: whatever a library prints there while the step runs (RCCL announces its
     # version on stdout when the first communicator is created) goes to stderr instead -- at the descriptor level, native
     # writers included -- and the line is written after the descriptor is back
@@ -264,7 +272,8 @@ def worker(args):
         _ops.set_streamk(fwd='fwd' in keep or 'all' in keep, dgrad='dgrad' in keep or 'all' in keep,
                          gemm='gemm' in keep or 'all' in keep)
     weights = orc.make_weights(0, feat_scale=0.05)
-    trainer = initialize_trainer('wesup', device=str(dev), max_superpixels=g * g, force_allreduce=args.force_ddp)
+    trainer = initialize_trainer('wesup', device=str(dev), max_superpixels=g * g, force_allreduce=args.force_ddp,
+                                 step_plan=not args.no_step_plan, native_step=not args.general_path)
     trainer.model.load_state_dict({k: torch.from_numpy(v) for k, v in weights.items()})
     trainer.optimizer, trainer.scheduler = trainer.get_default_optimizer()
     trainer.metric_funcs = [accuracy, dice]
@@ -303,14 +312,71 @@ def worker(args):
 
     # two different synthetic batches per rank, resident in HBM before the timed region
     pool = []
-    for i in range(2):
-        imgs, labs, pts, pix = synth.make_batch(1000 * rank + i + 1, B, H, W, g)
-        pool.append((torch.from_numpy(imgs).to(dev), torch.from_numpy(pix).to(dev), torch.from_numpy(pts).to(dev),
-                     torch.from_numpy(labs).to(dev)))
+    e2e = None
+    if args.multiscale:
+        # the reference trains at batch 1 on GlaS images (775 x 522) rescaled by U(0.3, 0.4) per item: a new shape almost every step
+        rs = np.random.RandomState(7 + rank)
+        B = 1
+        for i in range(args.multiscale):
+            f = rs.uniform(0.3, 0.4)
+            h, w = int(522 * f), int(775 * f)
+            gi = max(2, int(round((h * w / 200.0) ** 0.5)))           # sp_area 200 (models/wesup.py:158)
+            imgs, labs, pts, pix = synth.make_batch(1000 * rank + i + 1, 1, h, w, gi)
+            pool.append((torch.from_numpy(imgs).to(dev), torch.from_numpy(pix).to(dev), torch.from_numpy(pts).to(dev),
+                         torch.from_numpy(labs).to(dev)))
+        trainer.kwargs['max_superpixels'] = None                      # rows = the label map's own count (known on the host)
+        from wesup_amd.utils.data import LabelMaps as _LM
+        pool = [(a, b_, c, _LM(d, [int(d.max()) + 1])) for a, b_, c, d in pool]
+    elif args.end_to_end:
+        from wesup_amd import ops as _ops_e
+        from wesup_amd.utils import data as _D
+        rs = np.random.RandomState(11 + rank)
+        trainer.kwargs['max_superpixels'] = None
+        seg_fn = trainer.prefetch_segment_fn()
+        side = torch.cuda.Stream(device=dev)
+        raw = []
+        for i in range(2):
+            u8 = np.ascontiguousarray((np.stack([synth.synth_image(1000 * rank + 10 * i + b_, H, W) for b_ in range(B)])
+                                       .transpose(0, 2, 3, 1) * 255).astype(np.uint8))
+            msk = (rs.random_sample((B, H, W)) > 0.5).astype(np.uint8)
+            par = np.stack([_D.sample_params(rs, H, W, True)[0] for _ in range(B)])
+            pts = torch.zeros(B, 2, H, W, dtype=torch.uint8, device=dev)
+            idx = rs.randint(0, min(H, W), (B, 120, 2))
+            for b_ in range(B):
+                pts[b_, rs.randint(0, 2, 120), idx[b_, :, 0], idx[b_, :, 1]] = 1
+            raw.append((torch.from_numpy(u8).to(dev), torch.from_numpy(msk).to(dev), torch.from_numpy(par).to(dev), pts))
+        e2e = {'i': 0}
+
+        def stage(i):
+            d_img, d_mask, params, pts = raw[i % 2]
+            with torch.cuda.stream(side):
+                img, pm = _ops_e.augment(d_img, d_mask, params)
+                seg, n_dev = seg_fn(img)
+                counts = torch.empty(n_dev.shape, dtype=n_dev.dtype).pin_memory()
+                counts.copy_(n_dev, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record()
+            return img, pm, pts, seg, counts, ev
+        e2e['nxt'] = stage(0)
+    else:
+        for i in range(2):
+            imgs, labs, pts, pix = synth.make_batch(1000 * rank + i + 1, B, H, W, g)
+            pool.append((torch.from_numpy(imgs).to(dev), torch.from_numpy(pix).to(dev), torch.from_numpy(pts).to(dev),
+                         torch.from_numpy(labs).to(dev)))
 
     chain = torch.cuda.Stream(device=dev, priority=args.chain_priority) if args.chain_priority else None
 
     def step(i):
+        if e2e is not None:
+            # augmentation + SLIC of the NEXT batch run on a second stream beside this step; its superpixel counts reached
+            # pinned host memory meanwhile (utils/data.py DevicePrefetcher does the same from a DataLoader)
+            img, pm, pts, seg, counts, ev = e2e['nxt']
+            e2e['nxt'] = stage(i + 1)
+            torch.cuda.current_stream().wait_event(ev)
+            ev.synchronize()
+            for t_ in (img, pm, seg):
+                t_.record_stream(torch.cuda.current_stream())
+            return trainer.train_one_iteration('train', img, pm, pts, _D.LabelMaps(seg, [int(v) for v in counts]))
         if chain is None:
             return trainer.train_one_iteration('train', *pool[i % len(pool)])
         with torch.cuda.stream(chain):
@@ -369,6 +435,8 @@ def worker(args):
         rank_time = {'min_s': round(-float(t[1].item()), 4), 'max_s': round(float(t[0].item()), 4)}
         elapsed = float(t[0].item())                      # the slowest rank's wall time of the timed region
     loss_last = trainer.tracker.history['loss'][-1]
+    runner = trainer.step_runner()
+    plan_stats = dict(runner.stats) if runner is not None else None      # iterations of warm-up + timed region by how they ran
 
     # ---- untimed extras for the roofline report (every rank runs them so that collectives stay matched)
     iso, pool_ms = None, None
@@ -425,7 +493,21 @@ def worker(args):
             'config': {'workload': workload_label(B, H, W, g),
                        'global_batch': world * B, 'image': [H, W], 'superpixels': g * g,
                        'parallelism': f'dp{world}', 'last_loss': loss_last},
+            # how the warm-up + timed iterations were issued (wesup_amd/runner.py): walked in Python ('eager'; the first two of a
+            # shape and every event-carrying one), walked and recorded, or replayed from the recorded step plan
+            'step_plan': plan_stats,
         }
+        if args.end_to_end:
+            out['config']['workload'] = ('END-TO-END (second line, not the headline): decoded uint8 batch resident in HBM -> wesup_augment '
+                                         '(flips, shift-scale-rotate, HSV, brightness/contrast, ToTensor, one-hot) -> GPU SLIC at sp_area 200 '
+                                         '(wesup_slic, one batch ahead on a second stream, counts through pinned memory) -> ' + out['config']['workload'])
+            out['config']['superpixels'] = 'SLIC, sp_area 200'
+        if args.multiscale:
+            shapes = sorted({tuple(p_[0].shape[2:]) for p_ in pool})
+            out['config']['workload'] = (f'MULTI-SCALE (second line, not the headline): the reference\'s own operating point -- batch 1, GlaS 775x522 '
+                                         f'rescaled by U(0.3, 0.4) per item, {len(shapes)} distinct shapes in rotation ({shapes[0]} ... {shapes[-1]}), '
+                                         'sp_area 200 Voronoi label maps, 20% point-labelled, full train step, SLIC excluded')
+            out['config']['image'], out['config']['superpixels'] = 'varies', 'varies'
         rin = roofline_inputs(B, H, W, g)
         if not args.no_kernel_timing:
             tot = timer.collect()

@@ -144,6 +144,10 @@ def test_buffer_cache_is_bounded_over_changing_shapes():
     from oracle import wesup_oracle as orc
     from wesup_amd import synth
     trainer = make_trainer(orc.make_weights(2, feat_scale=0.05))
+    trainer.model._ensure_engine()
+    eng = trainer.model.engine
+    assert eng.max_cached_shapes >= 2 and eng.max_cached_pixels >= 2 * 4 * 480 * 480      # training + validation shape of configs[1]
+    eng.max_cached_shapes = 2                # (default 16: small crops that come back find their buffers and their step plan)
     rs = np.random.RandomState(0)
     peak = []
     shapes = set()

@@ -13,7 +13,7 @@ if sys.argv[1] == 'run':
     from wesup_amd.models import initialize_trainer
     from wesup_amd.utils.metrics import accuracy, dice
     dev = torch.device('cuda:0')
-    B, H, W, g = 4, 480, 480, 24
+    B, H, W, g = int(os.environ.get('WESUP_TRACE_BATCH', '4')), 480, 480, 24
     trainer = initialize_trainer('wesup', device='cuda:0', max_superpixels=g * g)
     trainer.model.load_state_dict({k: torch.from_numpy(v) for k, v in orc.make_weights(0, feat_scale=0.05).items()})
     trainer.optimizer, _ = trainer.get_default_optimizer()
@@ -22,7 +22,7 @@ if sys.argv[1] == 'run':
     trainer.model.engine.two_streams = len(sys.argv) > 2 and sys.argv[2] == 'multi'
     imgs, labs, pts, pix = synth.make_batch(1, B, H, W, g)
     data = (torch.from_numpy(imgs).to(dev), torch.from_numpy(pix).to(dev), torch.from_numpy(pts).to(dev), torch.from_numpy(labs).to(dev))
-    for _ in range(4):
+    for _ in range(8):          # (the last iterations replay the recorded step plan: the host is out of the picture)
         trainer.train_one_iteration('train', *data)
     torch.cuda.synchronize()
 else:

@@ -124,8 +124,13 @@ class WesupEngine:
         self.g = grads
         self.D = D
         self.device = next(iter(params.values())).device
-        self._bufs = OrderedDict()       # (B,H,W,Kmax) -> _Bufs, least recently used first, at most max_cached_shapes
-        self.max_cached_shapes = 2       # e.g. the training shape and the validation shape
+        self._bufs = OrderedDict()       # (B,H,W,Kmax) -> _Bufs, least recently used first
+        # Bounds of that cache: shapes, and pixels (B*H*W summed over the cached shapes; a training buffer set is ~3-9 KB per
+        # pixel).  Large shapes: the training and the validation shape (two 4 x 480^2 sets are 1.8 M pixels, two 8 x 1024^2
+        # sets 16.8 M: the second evicts the first).  Small multi-scale crops (batch 1 at 0.3-0.4 x 775x522: ~50 K pixels each)
+        # stay until the shape bound, so a shape that comes back finds its buffers -- and its recorded step plan -- again.
+        self.max_cached_shapes = 16
+        self.max_cached_pixels = 10 * 1024 * 1024
         self._last = None                # buffers of the most recent forward (feature_maps() reads these)
         self.frozen = set()              # names of parameters with requires_grad=False (set by WESUP.forward)
         self._packed = None
@@ -276,7 +281,9 @@ class WesupEngine:
             # gradient buffers (~0.6 GB per 480x480 image in training), so only the most recent shapes are kept and the
             # evicted buffers go back to torch's caching allocator, which hands their blocks to the next shape.
             self.buf_generation += 1
-            while len(self._bufs) >= max(1, self.max_cached_shapes):
+            px = lambda k: k[0] * k[1] * k[2]
+            while self._bufs and (len(self._bufs) >= max(1, self.max_cached_shapes)
+                                  or sum(px(k) for k in self._bufs) + px(key) > self.max_cached_pixels):
                 _, old = self._bufs.popitem(last=False)
                 if old is self._last:
                     self._last = None

@@ -35,7 +35,7 @@ from .utils import metrics as M
 RB_SLOT = 40          # event slot of the read-back copy (the engine uses 0 .. 27 and 64 ..)
 RECORD_AT = 2         # eager iterations of a shape before the first recording
 MAX_RECORD_TRIES = 4
-MAX_STATES = 4
+MAX_STATES = 16       # shapes with a state (inputs, read-back block, plan) of their own, least recently used first out
 
 
 class _Plan:
