@@ -449,7 +449,10 @@ int wesup_plan_replay(const WesupPlan* plan, int first, int last);      /* nodes
 /* 0 = the two recordings are identical (kernels, geometry, streams, argument bytes, edges, copies); k > 0 = they first
  * differ at node k - 1: something the walk produces moved between the two steps and the older plan must not be replayed */
 int wesup_plan_diff(const WesupPlan* a, const WesupPlan* b);
-const char* wesup_plan_node_name(const WesupPlan* plan, int node);
+const char* wesup_plan_node_name(const WesupPlan* plan, int node);   /* kernel name, "<record s>", "<wait s>", "<copy n>" */
+void* wesup_plan_node_stream(const WesupPlan* plan, int node);
+/* diagnostics (environment WESUP_PLAN_TIMING=1): host nanoseconds the latest replay spent issuing the node, and when */
+int wesup_plan_node_host_ns(const WesupPlan* plan, int node, long long* out2 /* host */);
 /* Ordering edges between streams on a fixed pool of events addressed by slot (0 .. wesup_sync_slots() - 1): record marks
  * the work queued so far on `stream`, wait makes `stream` wait for the slot's latest mark.  Both act at once and, while the
  * thread records a plan, become nodes of it.  wesup_sync_synchronize blocks the HOST until the mark is reached (the one

@@ -127,6 +127,8 @@ _SIGS = {
     'wesup_plan_replay': (c_int, 'pii'),
     'wesup_plan_diff': (c_int, 'pp'),
     'wesup_plan_node_name': (ctypes.c_char_p, 'pi'),
+    'wesup_plan_node_stream': (c_void_p, 'pi'),
+    'wesup_plan_node_host_ns': (c_int, 'pip'),
     'wesup_sync_slots': (c_int, ''),
     'wesup_sync_record': (c_int, 'ip'),
     'wesup_sync_wait': (c_int, 'ip'),

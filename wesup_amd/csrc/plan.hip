@@ -10,7 +10,10 @@
 // its buffers per shape; inputs are copied into buffers the plan knows).
 #include "common.hpp"
 #include "launch.hpp"
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <vector>
 
 enum { NODE_KERNEL = 0, NODE_RECORD = 1, NODE_WAIT = 2, NODE_COPY = 3 };
@@ -35,9 +38,16 @@ struct WesupPlan {
     std::vector<char> blob;
     std::vector<unsigned> offs;
     std::vector<void*> argv;
+    mutable std::vector<long long> host_ns;      // WESUP_PLAN_TIMING: host time of each node's issue in the latest replay
+    mutable std::vector<long long> host_at;      // ... and when it was issued (ns since the replay began)
     bool sealed = false;
 };
 static thread_local WesupPlan* t_rec = nullptr;
+static inline long long now_ns() {
+    timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (long long)ts.tv_sec * 1000000000ll + ts.tv_nsec;
+}
 
 WesupPlan* wesup_plan_recording_() { return t_rec; }
 
@@ -68,6 +78,7 @@ static bool g_event_made[SYNC_SLOTS];
 static hipEvent_t* sync_event(int slot) {
     if (slot < 0 || slot >= SYNC_SLOTS) return nullptr;
     if (!g_event_made[slot]) {
+        // (hipEventReleaseToDevice instead of the default system-scope fence of a record: measured, no difference -- DESIGN.md 6)
         if (hipEventCreateWithFlags(&g_events[slot], hipEventDisableTiming) != hipSuccess) return nullptr;
         g_event_made[slot] = true;
     }
@@ -194,9 +205,17 @@ extern "C" int wesup_plan_kernels(const WesupPlan* plan) {
 extern "C" int wesup_plan_replay(const WesupPlan* plan, int first, int last) {
     if (!plan || !plan->sealed || first < 0 || last < first || (size_t)last > plan->nodes.size()) return WESUP_ERR_INVALID;
     void* const* argv = plan->argv.data();
+    static const bool timing = getenv("WESUP_PLAN_TIMING") != nullptr;
+    static thread_local long long t_origin = 0;
+    if (timing) {
+        plan->host_ns.resize(plan->nodes.size(), 0);
+        plan->host_at.resize(plan->nodes.size(), 0);
+        if (first == 0) t_origin = now_ns();
+    }
     for (int i = first; i < last; ++i) {
         const PlanNode& n = plan->nodes[i];
         hipError_t e = hipSuccess;
+        const long long t0 = timing ? now_ns() : 0;
         switch (n.kind) {
         case NODE_KERNEL:
             e = hipLaunchKernel(n.fn, n.grid, n.block, const_cast<void**>(argv + n.argv), n.lds, n.st);
@@ -211,8 +230,15 @@ extern "C" int wesup_plan_replay(const WesupPlan* plan, int first, int last) {
             e = hipMemcpyAsync(n.dst, n.src, n.bytes, (hipMemcpyKind)n.copy_kind, n.st);
             break;
         }
+        if (timing) { plan->host_at[i] = t0 - t_origin; plan->host_ns[i] = now_ns() - t0; }
         if (e != hipSuccess) return WESUP_ERR_LAUNCH;
     }
+    return WESUP_OK;
+}
+// WESUP_PLAN_TIMING=1: host nanoseconds the latest replay spent issuing node i (out[0]) and when, since the replay began (out[1])
+extern "C" int wesup_plan_node_host_ns(const WesupPlan* plan, int i, long long* out /* host [2] */) {
+    if (!plan || !out || i < 0 || (size_t)i >= plan->host_ns.size()) return WESUP_ERR_INVALID;
+    out[0] = plan->host_ns[i]; out[1] = plan->host_at[i];
     return WESUP_OK;
 }
 // Compares two plans node by node (kernel, geometry, stream, argument bytes; edges; copies): 0 = identical, k > 0 = the first
@@ -237,13 +263,18 @@ extern "C" int wesup_plan_diff(const WesupPlan* a, const WesupPlan* b) {
     }
     return a->nodes.size() == b->nodes.size() ? 0 : (int)n + 1;
 }
-// name of the kernel behind node i ("" for edges and copies) -- diagnostics of a plan_diff mismatch
+// what node i is, for diagnostics (a plan_diff mismatch, a dump of the recorded schedule): the kernel's name, or
+// "<record slot>" / "<wait slot>" / "<copy bytes>"; *stream_out (optional) receives the node's stream handle
 extern "C" const char* wesup_plan_node_name(const WesupPlan* plan, int i) {
+    static thread_local char buf[64];
     if (!plan || i < 0 || (size_t)i >= plan->nodes.size()) return "";
     const PlanNode& n = plan->nodes[i];
-    if (n.kind == NODE_RECORD) return "<record>";
-    if (n.kind == NODE_WAIT) return "<wait>";
-    if (n.kind == NODE_COPY) return "<copy>";
+    if (n.kind == NODE_RECORD) { snprintf(buf, sizeof buf, "<record %d>", n.slot); return buf; }
+    if (n.kind == NODE_WAIT) { snprintf(buf, sizeof buf, "<wait %d>", n.slot); return buf; }
+    if (n.kind == NODE_COPY) { snprintf(buf, sizeof buf, "<copy %zu>", n.bytes); return buf; }
     const char* s = hipKernelNameRefByPtr(n.fn, n.st);
     return s ? s : "<kernel>";
+}
+extern "C" void* wesup_plan_node_stream(const WesupPlan* plan, int i) {
+    return (!plan || i < 0 || (size_t)i >= plan->nodes.size()) ? nullptr : (void*)plan->nodes[i].st;
 }

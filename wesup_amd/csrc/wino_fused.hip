@@ -328,21 +328,18 @@ struct FusedBits {       // the compact forms of mask_src / unpool_src (in) and 
 // Round 4, measured alone on the step's product shapes (tools/fused_micro.py): 64-tile blocks -3 ... -5 % where the grid still
 // fills the chip (conv1_2, conv2_2, conv3_2), +50 % where it does not (conv3_1 dgrad, conv4_1: ~115 blocks); rings of 4 and 5
 // stages (possible at one block per CU) change nothing -- the kernel does not wait for the latency of its staging DMA.  In the
-// step "auto" gains 0.03 ms of 9.2 (three alternating pairs); the default stays 32 tiles.
+// step that rule gains 0.03 ms of 9.2 (three alternating pairs, each in its favour); it is the default.
 struct FusedShape { int tw, ring; };
 static FusedShape fused_shape(long T, int N) {
-    // -1: "auto" = 64-tile blocks where they still fill the chip (>= 200 blocks of 8 waves on 256 CUs), else 32-tile blocks
+    // default: 64-tile blocks where they still fill the chip (>= 200 blocks of 8 waves on 256 CUs), else 32-tile blocks
     static const FusedShape env = [] {
         FusedShape f = {0, 0};
         const char* e = getenv("WESUP_WINO_FUSED_SHAPE");
-        if (e && e[0] == 'a') return FusedShape{-1, 3};
-        if (e && sscanf(e, "%d,%d", &f.tw, &f.ring) == 2 &&
-            (f.tw == 2 || f.tw == 4) && f.ring == 3)
-            return f;
+        if (e && sscanf(e, "%d,%d", &f.tw, &f.ring) == 2 && (f.tw == 2 || f.tw == 4) && f.ring == 3) return f;
         return FusedShape{0, 0};
     }();
     if (env.tw > 0) return env;
-    if (env.tw < 0 && ((T + 63) / 64) * (N / 64) >= 200) return FusedShape{4, 3};
+    if (((T + 63) / 64) * (N / 64) >= 200) return FusedShape{4, 3};
     return FusedShape{2, 3};
 }
 template <int KC, int TW, int RING>
