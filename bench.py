@@ -47,40 +47,19 @@ def parse_args(argv=None):
     ap.add_argument('--grid', type=int, default=24, help='superpixel grid side: g*g superpixels per image')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true')
-    ap.add_argument('--streamk', default='', help="A/B: comma list of the uses that get a stream-K tail ('fwd', 'dgrad', "
-                                                  "'gemm', or 'all'); default: none (the step runs plain tiling, ops.py)")
     ap.add_argument('--no-side-fusion', action='store_true', help='A/B: side convs of conv1_1..conv2_1 as GEMMs on the side '
                                                                   'stream instead of in the conv epilogue')
     ap.add_argument('--direct-conv', action='store_true', help='A/B: forward and input gradient of every conv layer with '
                                                                'the direct implicit-GEMM kernel (no Winograd-domain conv)')
-    ap.add_argument('--winograd-pipeline', action='store_true', help='A/B: Winograd-domain convs with the half-batch '
-                                                                      'pipeline over a helper stream')
-    ap.add_argument('--winograd-min-ci', type=int, default=0, help='A/B: input-channel count from which forward / input '
-                                                                    'gradient go through the Winograd domain (default: 64)')
-    ap.add_argument('--winograd-tile', type=int, default=0, choices=(0, 2, 4),
-                    help='A/B: m of the Winograd F(m x m, 3x3) domain for the wide layers (default: the engine\'s, 4; 2 = round 2)')
     ap.add_argument('--direct-wgrad', action='store_true', help='A/B: every conv weight gradient with the direct '
                                                                 'implicit-GEMM kernel (no Winograd-domain wgrad)')
-    ap.add_argument('--side-wgrad-interleaved', action='store_true', help='A/B: side-conv weight gradients layer by layer between the '
-                                                                          'G_l GEMMs (round 2\'s order) instead of behind all of them')
     ap.add_argument('--side-before-pool', action='store_true', help='A/B: the shallow side convs in front of the upsample + superpixel mean, side outputs materialised (round 2 / early round 3 schedule)')
     ap.add_argument('--no-gather-epilogue', action='store_true', help='A/B: the side-branch gradient of conv1_1 / conv1_2 materialised (gather kernel) and accumulated into, instead of gathered by the dgrad epilogue')
     ap.add_argument('--float-masks', action='store_true', help='A/B: the dgrad epilogues read the pre-ReLU conv outputs for the ReLU mask / the max-pool decisions instead of the sign bits / codes the forward leaves')
     ap.add_argument('--no-dual-transform', action='store_true', help='A/B: the input-gradient and weight-gradient transforms of a layer\'s output gradient as two launches on two streams (each reads the gradient)')
-    ap.add_argument('--no-defer-side', action='store_true', help='A/B: forward side-branch work of layer l queued as soon as y_l is (beside the input transform of layer l + 1) instead of behind that transform')
-    ap.add_argument('--wgrad-first', action='store_true', help='A/B: a layer\'s weight gradient queued in front of its input gradient (as before round 3\'s last day) instead of behind it')
-    ap.add_argument('--wgrad-early-layers', type=int, default=-1, help='A/B: the number of lowest layers whose weight gradient stays in front of the input gradient (default: the engine\'s, 1)')
-    ap.add_argument('--deep-side-wgrad-at', type=int, default=-2, help='A/B: conv layer index at which the deep layers\' side-conv weight gradients are queued (-1: at the start of backward; default: the engine\'s, 2)')
-    ap.add_argument('--commute-deep', action='store_true', help='A/B: the deep layers (matrix pooling) commuted as well (measured, not kept)')
-    ap.add_argument('--batched-side', action='store_true', help='A/B: the side convs of the layers that share a deep resolution in one batched launch (measured, not kept)')
     ap.add_argument('--diag-skip', default='', help="TIMING-ONLY diagnostic (results are wrong): comma list of launch classes left out "
                                                     "of the step after the warm-up (learning rate 0 from there on) -- 'wgrad' (conv weight gradients), 'side_wgrad', "
                                                     "'side_fwd_shallow' (pooling + side conv of conv1_1 .. conv3_3), 'side_fwd_deep' -- to see what they cost the step")
-    ap.add_argument('--head-streamk', action='store_true', help='A/B: the MLP head GEMMs with the stream-K tail (default: plain tiling)')
-    ap.add_argument('--subbatch-mb', type=int, default=-1, help='A/B: fused Winograd layers whose transformed input exceeds this many '
-                                                                'MB run image group by image group (0: whole batch; default: ops.py)')
-    ap.add_argument('--chain-priority', type=int, default=0, help='experiment: run the step on a stream of this priority '
-                                                                  '(negative = higher than the side / wgrad streams)')
     ap.add_argument('--event-every', type=int, default=10, help='steps of the timed region that carry HIP events: every n-th')
     ap.add_argument('--timed-classes', default='conv3x3_fwd,conv3x3_dgrad,winograd_gemm',
                     help="kernel classes that get HIP events inside the timed region ('all', 'none' or a comma list); an "
@@ -266,11 +245,6 @@ def worker(args):
     from wesup_amd.utils.metrics import accuracy, dice
 
     B, H, W, g = args.batch, args.size, args.size, args.grid
-    if args.streamk:
-        from wesup_amd import ops as _ops
-        keep = set(args.streamk.split(','))
-        _ops.set_streamk(fwd='fwd' in keep or 'all' in keep, dgrad='dgrad' in keep or 'all' in keep,
-                         gemm='gemm' in keep or 'all' in keep)
     weights = orc.make_weights(0, feat_scale=0.05)
     trainer = initialize_trainer('wesup', device=str(dev), max_superpixels=g * g, force_allreduce=args.force_ddp,
                                  step_plan=not args.no_step_plan, native_step=not args.general_path)
@@ -279,34 +253,15 @@ def worker(args):
     trainer.metric_funcs = [accuracy, dice]
     trainer.model.train()
     trainer.tracker.train()
-    trainer.model.engine.fuse_pool_bwd = not args.unfused_pool_bwd
-    trainer.model.engine.fuse_side_fwd = not args.no_side_fusion
-    trainer.model.engine.wgrad_winograd = not args.direct_wgrad
-    trainer.model.engine.side_wgrad_last = not args.side_wgrad_interleaved
-    trainer.model.engine.head_streamk = args.head_streamk
-    trainer.model.engine.batch_side_convs = args.batched_side
-    trainer.model.engine.commute_side = not args.side_before_pool
-    trainer.model.engine.commute_side_deep = args.commute_deep
-    trainer.model.engine.gather_side_grad = not args.no_gather_epilogue
-    trainer.model.engine.compact_masks = not args.float_masks
-    trainer.model.engine.dual_transform = not args.no_dual_transform
-    trainer.model.engine.defer_side_fwd = not args.no_defer_side
-    trainer.model.engine.wgrad_behind_dgrad = not args.wgrad_first
-    if args.deep_side_wgrad_at >= -1:
-        trainer.model.engine.deep_side_wgrad_at = args.deep_side_wgrad_at if args.deep_side_wgrad_at >= 0 else None
-    if args.wgrad_early_layers >= 0:
-        trainer.model.engine.wgrad_early_layers = args.wgrad_early_layers
-    trainer.model.engine.conv_winograd = not args.direct_conv
-    if args.winograd_min_ci:
-        type(trainer.model.engine).WINOGRAD_CONV_MIN_CI = args.winograd_min_ci
-    if args.winograd_tile:
-        type(trainer.model.engine).WINOGRAD_TILE = args.winograd_tile
-    if args.subbatch_mb >= 0:
-        from wesup_amd import ops as _ops3
-        _ops3.SUBBATCH_V_BYTES = args.subbatch_mb << 20
-    if args.winograd_pipeline:
-        from wesup_amd import ops as _ops2
-        _ops2.PIPELINE_WINOGRAD = True
+    eng = trainer.model.engine
+    eng.fuse_pool_bwd = not args.unfused_pool_bwd
+    eng.fuse_side_fwd = not args.no_side_fusion
+    eng.conv_winograd = not args.direct_conv
+    eng.wgrad_winograd = not args.direct_wgrad
+    eng.commute_side = not args.side_before_pool
+    eng.gather_side_grad = not args.no_gather_epilogue
+    eng.compact_masks = not args.float_masks
+    eng.dual_transform = not args.no_dual_transform
     if use_dist and args.ddp_probe != 'pg':
         trainer.enable_data_parallel(bucket_bytes=args.bucket_mb << 20)
 
@@ -364,7 +319,6 @@ def worker(args):
             pool.append((torch.from_numpy(imgs).to(dev), torch.from_numpy(pix).to(dev), torch.from_numpy(pts).to(dev),
                          torch.from_numpy(labs).to(dev)))
 
-    chain = torch.cuda.Stream(device=dev, priority=args.chain_priority) if args.chain_priority else None
 
     def step(i):
         if e2e is not None:
@@ -377,10 +331,7 @@ def worker(args):
             for t_ in (img, pm, seg):
                 t_.record_stream(torch.cuda.current_stream())
             return trainer.train_one_iteration('train', img, pm, pts, _D.LabelMaps(seg, [int(v) for v in counts]))
-        if chain is None:
-            return trainer.train_one_iteration('train', *pool[i % len(pool)])
-        with torch.cuda.stream(chain):
-            trainer.train_one_iteration('train', *pool[i % len(pool)])
+        return trainer.train_one_iteration('train', *pool[i % len(pool)])
 
     def barrier():
         if use_dist:
@@ -404,9 +355,7 @@ def worker(args):
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]      # one record per step: its end
     barrier()
     t0 = time.perf_counter()
-    if chain is not None:
-        chain.wait_stream(torch.cuda.current_stream())
-    marks[0].record(chain)
+    marks[0].record()
     for i in range(args.steps):
         # an event record fences its queue (events on the 25 conv launches of every step cost 3 % of the step, on every
         # kernel class 16 %): inside the timed region only every --event-every'th step carries events
@@ -415,7 +364,7 @@ def worker(args):
         if reducer is not None:                       # bucket launch offsets + exposed all-reduce tail of the same steps
             reducer.profile = (i % args.event_every == 0)
         step(i)
-        marks[i + 1].record(chain)
+        marks[i + 1].record()
     barrier()
     elapsed = time.perf_counter() - t0
     timer.enabled = False
@@ -529,7 +478,8 @@ def worker(args):
                         kern[tag]['alone_ms_per_step'] = round(ms / 2, 4)
                         if 'gbs' in kern[tag] and work > 0:
                             kern[tag]['alone_gbs'] = round(work / (ms * 1e-3) / 1e9, 1)
-            kern['_event_pairs_replaced'] = timer.replaced      # KernelTimer.collect: impossible durations (timestamp glitches)
+            kern['_event_pairs_replaced'] = timer.replaced      # KernelTimer.collect: impossible durations (timestamp glitches) ...
+            kern['_event_pairs_replaced_list'] = [list(x) for x in timer.replaced_pairs]      # ... (class, measured ms, substituted median ms)
             kern['_note'] = ('propagate = wesup_propagate (label propagation); sp_preprocess = wesup_sp_preprocess + '
                              'wesup_sp_segments (histograms, reference ordering, counting sort, segment table); paint = '
                              'wesup_paint_fwd; sgd = wesup_sgd_step (20 B per parameter).  gbs = algorithmic bytes / event time')

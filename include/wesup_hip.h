@@ -192,7 +192,10 @@ int wesup_winograd_output_transform_unpool(const float* Mt, long plane_elems, co
  * transformed output [36][tiles][N] is never written.  At these widths the separate passes are HBM-bound on exactly that
  * tensor; wesup_conv3x3_fwd/dgrad_winograd[_unpool] take this route by themselves (WESUP_WINO_FUSED=0: never, 1: forward only).
  * Results equal the two-kernel route's up to fp32 summation order. */
-int wesup_winograd_fused_supported(int K, int N, int m);      /* 0: no; 1: the conv entries take the one-kernel route for this
+int wesup_winograd_fused_supported(int K, int N, int m);
+/* ... and whether a problem of `tiles` tiles takes it (0: the grid of the one-kernel route would be too small, < 200 blocks) */
+int wesup_winograd_fused_route(int K, int N, int m, long tiles);
+int wesup_winograd_set_fused_min_blocks(int blocks);   /* tuning knob of that rule (default 200); returns the previous value */      /* 0: no; 1: the conv entries take the one-kernel route for this
                                                                  product in the forward; 2: in the input gradient as well */
 int wesup_winograd_gemm_output_transform(const float* V, long plane_elems, const float* U, const float* bias,
                                          const float* mask_src, float* y, float* y_pool, int pool_relu,

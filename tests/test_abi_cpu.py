@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _header_decls():
     hdr = open(os.path.join(ROOT, 'include', 'wesup_hip.h')).read()
     hdr = re.sub(r'/\*.*?\*/', '', hdr, flags=re.S)
-    return re.findall(r'\n\s*(?:int|long|size_t|const char\*)\s+(wesup_\w+)\s*\(([^;]*?)\)\s*;', hdr, flags=re.S)
+    return re.findall(r'\n\s*(?:int|long|size_t|const char\*|void\*)\s+(wesup_\w+)\s*\(([^;]*?)\)\s*;', hdr, flags=re.S)
 
 
 @pytest.fixture(scope='module')

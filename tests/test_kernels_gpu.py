@@ -323,37 +323,6 @@ def test_winograd_building_blocks_match_the_numpy_oracle(ops, B, H, W, Ci, Co, m
         assert np.abs(db.cpu().numpy() - db_o).max() < 1e-4 * np.abs(db_o).max()
 
 
-@pytest.mark.parametrize('B,H,W,Cin,Cout', [(2, 13, 11, 64, 128), (4, 30, 30, 256, 256), (6, 9, 9, 128, 64)])
-@pytest.mark.parametrize('m', [2, 4])
-def test_winograd_conv_pipelined_halves_are_bit_identical(ops, B, H, W, Cin, Cout, m):
-    """The two halves of the batch pipelined over the helper stream (transforms of one half under the GEMM of the other)
-    give bit for bit the outputs, the kept V and the accumulate/mask epilogue of the unsplit call."""
-    d = dev()
-    x = nhwc(rnd(B, Cin, H, W, seed=1)).to(d)
-    w = rnd(Cout, Cin, 3, 3, seed=2, scale=(2.0 / (9 * Cin)) ** 0.5).to(d)
-    b = rnd(Cout, seed=3, scale=0.1).to(d)
-    dy = nhwc(rnd(B, Cout, H, W, seed=4)).to(d)
-    base = rnd(B, H, W, Cin, seed=5).to(d)
-    uf, ud = ops.winograd_pack_weight(w, m=m)
-    T = ops.winograd_tiles(B, H, W, m)
-    res = []
-    was = ops.PIPELINE_WINOGRAD, ops.PIPELINE_MIN_BLOCKS
-    try:
-        for pipelined in (False, True):
-            ops.PIPELINE_WINOGRAD, ops.PIPELINE_MIN_BLOCKS = pipelined, 0
-            v = torch.zeros((m + 2) ** 2, T, Cin, device=d)
-            y, yr = torch.empty(B, H, W, Cout, device=d), torch.empty(B, H, W, Cout, device=d)
-            ops.conv3x3_fwd_winograd(x, uf, b, True, out=y, out_relu=yr, v_keep=v, m=m)
-            dx = base.clone()
-            ops.conv3x3_dgrad_winograd(dy, ud, mask_src=x, out=dx, accumulate=True, m=m)
-            torch.cuda.synchronize()
-            res.append((y, yr, v, dx))
-    finally:
-        ops.PIPELINE_WINOGRAD, ops.PIPELINE_MIN_BLOCKS = was
-    for a, bb in zip(*res):
-        assert torch.equal(a, bb)
-
-
 @pytest.mark.parametrize('B,H,W,Cin,Cout', WINO_CASES)
 @pytest.mark.parametrize('m', [2, 4])
 def test_conv3x3_dgrad_winograd(ops, B, H, W, Cin, Cout, m):
@@ -499,7 +468,10 @@ def test_conv3x3_dgrad_winograd_with_the_side_gradient_gathered_in_the_epilogue(
     ops.conv3x3_dgrad_winograd_gather(dy, ud, side, m.new_row, m.area_new, out=got, mask_src=None if pooled else ypre,
                                       unpool_src=ypre if pooled else None)
     scale = float(want.abs().max())
-    assert float((got - want).abs().max()) <= 2e-7 * scale
+    # (a grid this small sends the plain entries through the batched GEMM + output transform -- other summation order -- while
+    # the gather form always is the one-kernel route: then to the rounding of the products instead of one multiply-add)
+    same_route = ops.winograd_fused_supported(Cout, Cin, 4, ops.winograd_tiles(B, H, W, 4)) == 2
+    assert float((got - want).abs().max()) <= (2e-7 if same_route else 4e-6) * scale
     assert float((want - base).abs().max()) > 0.05 * scale         # the conv part is not negligible beside the gathered part
     class _T:
         def begin(self, tag): return tag
@@ -566,6 +538,16 @@ def test_winograd_compact_masks_and_pool_codes(ops, B, H, W, Cin, Cout):
     epilogues that read them (masked accumulate, max-pool backward, both gather forms): the same bits as with the float
     tensors."""
     d = dev()
+    # (grids this small take the two-kernel route by default; the float-tensor twins of this test must run the same product
+    # kernel as the compact forms, which only exist on the one-kernel route)
+    was = _lib_mod().load().wesup_winograd_set_fused_min_blocks(0)
+    try:
+        _compact_masks_body(ops, d, B, H, W, Cin, Cout)
+    finally:
+        _lib_mod().load().wesup_winograd_set_fused_min_blocks(was)
+
+
+def _compact_masks_body(ops, d, B, H, W, Cin, Cout):
     x = rnd(B, H, W, Cin, seed=1).to(d)
     x[0, :2, :2, :8] = 0.0                                    # exact zeros: not positive
     w = rnd(Cout, Cin, 3, 3, seed=2, scale=(2.0 / (9 * Cin)) ** 0.5)

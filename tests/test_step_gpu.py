@@ -43,7 +43,7 @@ def make_trainer(weights, **kw):
 
 
 @pytest.mark.parametrize('name', CASES)
-@pytest.mark.parametrize('fused', [True, False, 'side_as_gemm', 'direct_convs', 'batched_side', 'side_before_pool', 'commute_deep', 'gather_kernel', 'float_masks', 'two_transforms'])
+@pytest.mark.parametrize('fused', [True, False, 'side_as_gemm', 'direct_convs', 'side_before_pool', 'gather_kernel', 'float_masks', 'two_transforms'])
 def test_step_matches_reference_golden(golden_dir, name, fused):
     from oracle import wesup_oracle as orc
     from wesup_amd.models.wesup import preprocess_label_maps, SuperpixelMaps
@@ -56,13 +56,10 @@ def test_step_matches_reference_golden(golden_dir, name, fused):
     model.engine.fuse_side_fwd = fused != 'side_as_gemm'     # default: the side convs of conv1_1..conv2_1 inside the conv epilogue
     if fused == 'direct_convs':       # every conv pass on the implicit-GEMM kernels (default: Winograd domain from 128 channels up)
         model.engine.conv_winograd = model.engine.wgrad_winograd = False
-    # the side convs (and the initial input gradients) of conv4_x / conv5_x as one batched launch per resolution
-    model.engine.batch_side_convs = fused == 'batched_side'
     # default: the shallow layers' side convs BEHIND the upsample + superpixel mean (they commute); here in front, as written
     # in the reference (models/wesup.py:246-261), with the side outputs and their gradients materialised
-    if fused in ('side_before_pool', 'side_as_gemm', 'batched_side'):
+    if fused in ('side_before_pool', 'side_as_gemm'):
         model.engine.commute_side = False
-    model.engine.commute_side_deep = fused == 'commute_deep'
     if fused == 'float_masks':        # the dgrad epilogues read the pre-ReLU outputs (default: sign bits / pooling codes left by the forward)
         model.engine.compact_masks = False
     if fused == 'two_transforms':     # the output gradient's two F(4x4) transforms as separate launches (default: one pass)
@@ -214,7 +211,7 @@ def test_batched_step_matches_oracle():
 @pytest.mark.parametrize('B,H,W,g', [(3, 52, 44, 4), (2, 70, 38, 5), (1, 129, 97, 6)])
 def test_round3_schedule_and_fusions_against_the_plain_order(B, H, W, g):
     """One training step on an odd, batched shape with every round-3 switch at its default (side conv behind the pooling, gathered
-    side gradients, dual transform, compact masks, deferred side work, weight gradients behind the input gradients) against the
+    side gradients, dual transform, compact masks) against the
     same step with all of them off (the reference's order of operations, one launch per pass): the loss to 1e-6, every parameter
     gradient to 2e-5 of its tensor's maximum -- the switches reorder sums and launches, nothing else."""
     from oracle import wesup_oracle as orc
@@ -232,7 +229,6 @@ def test_round3_schedule_and_fusions_against_the_plain_order(B, H, W, g):
         e = tr.model.engine
         if plain:
             e.commute_side = e.gather_side_grad = e.dual_transform = e.compact_masks = False
-            e.defer_side_fwd = e.wgrad_behind_dgrad = False
         tr.train_one_iteration('train', *data)
         torch.cuda.synchronize()
         res.append((tr.tracker.history['loss'][0], {k: v.detach().clone() for k, v in tr.model._grad_views.items()},

@@ -18,6 +18,7 @@ ap.add_argument('--size', type=int, default=480)
 ap.add_argument('--batch', type=int, default=4)
 ap.add_argument('--reps', type=int, default=10)
 ap.add_argument('--check', action='store_true', help='compare with the batched GEMM + output transform')
+ap.add_argument('--unfused', action='store_true', help='also time the two-kernel route (batched GEMM + output transform) on the same operands')
 ap.add_argument('--only', default='', help='substring of the shape names to run (counter passes)')
 args = ap.parse_args()
 d = torch.device('cuda:0')
@@ -67,6 +68,13 @@ for name, K, N, div in SHAPES:
         y2 = ops.winograd_gemm_output_transform(V2, U, 1, h2, w2, bias=bias)
         ref2 = ops.winograd_output_transform(ops.gemm_nt_batched(V2, U), 1, h2, w2, bias=bias, m=4)
         err += f' / {float((y2 - ref2).abs().max() / ref2.abs().max()):.1e}'
+    if args.unfused:
+        Mt = torch.empty(36, T, N, device=d)
+        def two():
+            ops.gemm_nt_batched(V, U, out=Mt)
+            ops.winograd_output_transform(Mt, B, h, w, bias=bias, out=y, m=4)
+        us2 = timeit(two, args.reps)
+        err += f'   two-kernel route {us2:7.1f} us  ({((T + 31) // 32) * (N // 64)} blocks of the one-kernel route)'
     total += us * COUNT[name]
     print(f'{name:18s} K={K:3d} N={N:3d} {h:3d}x{w:<3d} tiles {T:6d}: {us:7.1f} us  {gf / us * 1e3:6.1f} TF  {mb / us:5.2f} TB/s{err}')
 print(f'sum over the 13 launches of a step: {total * 1e-3:.3f} ms')

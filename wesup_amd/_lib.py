@@ -51,6 +51,8 @@ _SIGS = {
     'wesup_conv3x3_dgrad_winograd_unpool': (c_int, 'ppppiiiiiiiipzp'),
     'wesup_winograd_output_transform_unpool': (c_int, 'plppppiiiiiiip'),
     'wesup_winograd_fused_supported': (c_int, 'iii'),
+    'wesup_winograd_fused_route': (c_int, 'iiil'),
+    'wesup_winograd_set_fused_min_blocks': (c_int, 'i'),
     'wesup_winograd_gemm_output_transform': (c_int, 'plpppppippiiiiiiiip'),
     'wesup_winograd_gemm_output_transform_gather': (c_int, 'plppppiipppiiiiiip'),
     'wesup_winograd_input_transform_bits': (c_int, 'pplpiiiiip'),

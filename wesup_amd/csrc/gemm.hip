@@ -1484,7 +1484,7 @@ static int wino_conv(const float* in, const float* u, const float* bias, const f
     int rc = wesup_winograd_input_transform(in, V, 0, B, H, W, Cin, relu_in, m, st);
     if (rc) return rc;
     // short products (64 / 128 channels): products + output transform in one kernel, no transformed output in between
-    const int fused = out_relu ? 0 : wino_fused_supported(Cin, Cout, m);
+    const int fused = out_relu ? 0 : wino_fused_route(Cin, Cout, m, T);
     if (fused == 2 || (fused == 1 && !mask && !accum && !unpool_src))
         return wesup_winograd_gemm_output_transform(V, 0, u, bias, mask, out, out_pool, pool_relu, unpool_src, unpool_dst, Hu, Wu,
                                                     B, H, W, Cin, Cout, accum, st);

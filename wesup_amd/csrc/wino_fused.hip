@@ -315,6 +315,23 @@ int wino_fused_supported(int K, int N, int m) {
 }
 
 extern "C" int wesup_winograd_fused_supported(int K, int N, int m) { return wino_fused_supported(K, N, m); }
+// ... and whether a problem of `tiles` tiles should take it: the one-kernel route walks 36 K/64 stages per block whatever the
+// grid, so below ~200 blocks (32 tiles x 64 channels each: conv3_x / conv4_1 at batch 1, 480 x 480) the batched GEMM + output
+// transform -- 36 x more blocks -- is faster (tools/fused_micro.py --unfused: 103 -> 72 us at 116 blocks, 100 -> 39 us at 64;
+// 106 vs 113 us at 228 blocks).  0 = two kernels; else wesup_winograd_fused_supported's answer.
+static int g_fused_min_blocks = 200;
+int wino_fused_route(int K, int N, int m, long tiles) {
+    const int cap = wino_fused_supported(K, N, m);
+    if (!cap || tiles <= 0) return cap;
+    return ((tiles + 31) / 32) * (N / 64) >= g_fused_min_blocks ? cap : 0;
+}
+// tuning knob of that rule (process-wide; returns the previous value): 0 = every supported shape takes the one-kernel route
+extern "C" int wesup_winograd_set_fused_min_blocks(int blocks) {
+    const int was = g_fused_min_blocks;
+    if (blocks >= 0) g_fused_min_blocks = blocks;
+    return was;
+}
+extern "C" int wesup_winograd_fused_route(int K, int N, int m, long tiles) { return wino_fused_route(K, N, m, tiles); }
 
 // V [36][tiles][K] (plane stride plane_elems, 0 = tiles * K) x U [36][N][K] -> y = A^T (V_p . U_p^T) A + the output
 // transform's epilogue (wesup_winograd_output_transform / _unpool), without the transformed output in between.

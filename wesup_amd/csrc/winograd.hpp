@@ -113,3 +113,4 @@ int wino_filter_grad_launch(const float* slabs, long slab_stride, long batch_str
                             int Cin, int m, const float* bias_part, int bias_rows, void* stream);
 // wino_fused.hip: the batched products and the output transform in one kernel (K = 64 / 128, N % 64 == 0, m = 4)
 int wino_fused_supported(int K, int N, int m);      // 0 no, 1 forward epilogue only, 2 every epilogue
+int wino_fused_route(int K, int N, int m, long tiles);      // the same, 0 when the grid of the one-kernel route would be too small

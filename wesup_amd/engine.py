@@ -47,6 +47,7 @@ class KernelTimer:
         self.totals = {}
         self._free = []            # recycled events (an event record is not free: it fences the queue it is put on)
         self.replaced = 0          # event pairs with an impossible duration (see collect)
+        self.replaced_pairs = []   # ... each of them as (tag, measured ms, median ms of its class): what was substituted, auditable
 
     def _event(self):
         return self._free.pop() if self._free else torch.cuda.Event(enable_timing=True)
@@ -69,7 +70,8 @@ class KernelTimer:
         """Call after a device sync.  Returns {tag: (ms_total, launches, work_total)}.
         A pair whose end timestamp is off by tens of milliseconds turns up about once per thousand pairs on this stack (the
         next event on the same stream carries the same offset; the step itself has no such gap): a value above 5 ms AND above
-        100 x the median of its class is replaced by that median and counted in self.replaced."""
+        100 x the median of its class is replaced by that median, counted in self.replaced and listed in self.replaced_pairs (the
+        bench line carries the list, so the substitution can be audited)."""
         by_tag = {}
         for tag, s, e, work in self.pending:
             by_tag.setdefault(tag, []).append((s.elapsed_time(e), work))
@@ -81,6 +83,7 @@ class KernelTimer:
             for v, work in vals:
                 if v > 5.0 and v > 100.0 * med:
                     self.replaced += 1
+                    self.replaced_pairs.append((tag, round(v, 3), round(med, 4)))
                     v = med
                 ms, n, wk = ms + v, n + 1, wk + work
             self.totals[tag] = (ms, n, wk)
@@ -117,6 +120,8 @@ class WesupEngine:
     # bench.py --winograd-min-ci / --winograd-tile for the A/B.
     WINOGRAD_CONV_MIN_CI = 64
     WINOGRAD_TILE = 4                    # m of F(m x m, 3x3) for those layers: 4 (default) or 2 (round 2's routing)
+    DEEP_SIDE_WGRAD_AT = 2               # conv layer at which the deep layers' side-conv weight gradients are queued (conv2_1)
+    WGRAD_EARLY_LAYERS = 1               # layers above the lowest trainable one whose weight gradient stays in front of the input gradient
 
     def __init__(self, params, grads, D=32):
         """params/grads: dict name -> tensor (views of the flat parameter / gradient buffers)."""
@@ -150,15 +155,9 @@ class WesupEngine:
         # epilogue work sat on the chain, the GEMMs it removed had run beside it); with the wide layers in the Winograd
         # domain the step is the sum of its kernels' times and the fusion wins a little (13.77 -> 13.70 ms, 3 A/B pairs)
         self.fuse_side_fwd = True
-        self.relu_on_store = True        # ReLU'd copies written by the producing kernel instead of ReLU on every load
         # the max-pool backward behind conv2_1 / conv3_1 / conv4_1 / conv5_1 as the epilogue of their F(4x4) input gradient:
         # no gradient tensor at pooled resolution, one position of each window updated instead of four re-written
         self.fuse_unpool = True
-        # side branch of backward: every G_l (what the dgrad chain waits for) before the side convs' own weight gradients
-        self.side_wgrad_last = True
-        # stream-K tail for the MLP head's GEMMs (2304 rows at c2: 144 tiles on 512 block slots; nothing runs beside the head
-        # between forward and backward): measured, no difference in the step (10.08 / 10.12 / 10.15 vs 10.09 / 10.10 / 10.13 ms,
-        # bench.py --head-streamk), so plain tiling as everywhere else in the step
         # Shallow layers (native resolution above the matrix-pool limit: conv1_1 ... conv3_3 at 480^2): the 1x1 side conv, the
         # bilinear upsample and the superpixel mean are all linear, and the first acts on channels while the other two act on
         # pixels -- they commute.  mean_r(upsample(y W^T + b)) = mean_r(upsample(y)) W^T + b: the fused upsample+scatter-mean
@@ -166,11 +165,6 @@ class WesupEngine:
         # (dYbar = g W, G_l = upsample-pool-backward of dYbar straight into the conv's gradient buffer, dW = g^T Ybar,
         # db = column sums of g).  No side output, no gradient of it, no P x C side GEMMs at 480^2 / 240^2 / 120^2.
         self.commute_side = True
-        # ... and the same for the deep layers, whose pooling is a GEMM with the interpolation matrix Wm: Ybar = Wm . y and
-        # G = Wm^T . dYbar over all C channels instead of the C/2 of the side output.  The FLOPs saved on the side convs are
-        # spent there again and the products are less efficient (N = 512 per layer instead of 768 per resolution): alone on the
-        # GPU 1.04 -> 1.15 ms for the four classes involved, step 9.37 -> 9.41 ms.  Measured, off (bench.py --commute-deep).
-        self.commute_side_deep = False
         # native-resolution layers of the commuted side branch (conv1_1, conv1_2): their side-branch gradient is a gather of one
         # row per superpixel; the dgrad epilogue that used to accumulate into the materialised gather takes it itself
         # (conv3x3_dgrad_winograd_gather): G_l is written once, by that epilogue, and never read for accumulation
@@ -184,17 +178,10 @@ class WesupEngine:
         # gradient -- in one pass over it on the main stream (ops.winograd_dual_transform): the gradient is read once instead of
         # once per stream and twelve launches go
         self.dual_transform = True
-        # forward: the side-branch work of layer l queued behind the input transform of layer l + 1 instead of beside it
-        self.defer_side_fwd = True
-        # the conv layer at which the deep layers' side-conv weight gradients are queued (None: with the others at the start of
-        # backward): 7 pairs at conv2_1, 9.05 vs 9.14 ms, each pair in its favour; at conv1_2 or conv3_3 it is slower than at the start
-        self.deep_side_wgrad_at = 2
-        self.wgrad_behind_dgrad = True   # backward: a layer's weight gradient queued behind its input gradient (see backward())
-        # ... except for this many layers above the lowest trainable one: nothing runs behind the last input gradient, so conv1_2's
-        # weight gradient goes in front of it again (9.11 -> 9.03 ms; two layers: the same)
-        self.wgrad_early_layers = 1
-        self.batch_side_convs = False    # A/B: side convs (and their input gradients) of the layers that share a deep resolution in one launch
-        self.head_streamk = False
+        # Orderings of the schedule that were measured once and are fixed (each is bit-neutral): the side-branch
+        # work of layer l behind the input transform of layer l + 1; a layer's weight gradient behind its input gradient except
+        # for the lowest trainable layer's neighbour; every G_l before the side convs' own weight gradients, those of the deep
+        # layers queued when the chain reaches conv2_1 (DEEP_SIDE_WGRAD_AT).
         self._diag_skip = set()          # TIMING-ONLY diagnostics (bench.py --diag-skip): classes of launches left out, results wrong
         self.route_fn = default_route    # (ci, co, h, w, B) -> 0 | 2 | 4, consulted per layer and shape
         self._route = None               # the 13 tile sizes of the current / most recent shape
@@ -304,7 +291,7 @@ class WesupEngine:
                 # the ReLU'd copy the next conv (forward and wgrad) reads: the pooled tensor where the layer is pooled
                 # (stored ReLU'd), a second output of the conv kernel elsewhere; the last layer has no reader
                 b.yr.append(None)        # allocated on first use (forward): a Winograd-domain consumer never needs it
-                b.yr_wanted.append(bool(self.relu_on_store and not POOL_AFTER[l] and l < 12))
+                b.yr_wanted.append(bool(not POOL_AFTER[l] and l < 12))
                 if POOL_AFTER[l]:
                     h, w = h // 2, w // 2
                     b.yp.append(torch.empty(B, h, w, co, **f32))
@@ -331,12 +318,6 @@ class WesupEngine:
                         g.WmT = torch.empty(B, gh * gw, Kmax, **f32)
                         for i in g.layers:
                             b.group_of[i] = len(b.groups)
-                        # conv outputs of the group side by side (equal widths): their side convs are ONE batched launch
-                        g.same_co = len({CONV_CH[i][1] for i in g.layers}) == 1
-                        if g.same_co:
-                            g.y = torch.empty(len(g.layers), B, gh, gw, CONV_CH[l][1], **f32)
-                            for k, i in enumerate(g.layers):
-                                b.y[i] = g.y[k]
                         b.groups.append(g)
                     l = e + 1
             # the (B,HW,2112) feature map only exists on the unfused path (or when somebody asks for it)
@@ -360,11 +341,6 @@ class WesupEngine:
         if train and not b.train:
             R = B * Kmax
             b.G = [torch.empty_like(y) for y in b.y]
-            for g in b.groups:           # ... and their gradients, for the batched side-conv input gradient
-                if g.same_co:
-                    g.G = torch.empty_like(g.y)
-                    for k, i in enumerate(g.layers):
-                        b.G[i] = g.G[k]
             b.ds = [None] * 13           # views of the group buffers, or allocated on first use (_side_grad)
             b.dxp = [None if yp is None else torch.empty(yp.shape[0], yp.shape[1], yp.shape[2], CONV_CH[l + 1][0], **f32)
                      for l, yp in enumerate(b.yp)]
@@ -405,7 +381,7 @@ class WesupEngine:
     def _commuted(self, b, l):
         """Layer l's side conv behind the pooling instead of in front of it (see commute_side)."""
         return (self.commute_side and self.fuse_pool_fwd and self.fuse_pool_bwd
-                and ((b.group_of[l] is not None and self.commute_side_deep) or b.group_of[l] is None))
+                and b.group_of[l] is None)
 
     def release_buffers(self):
         self.buf_generation += 1
@@ -520,6 +496,9 @@ class WesupEngine:
         B, _, H, W = img.shape
         Kmax = meta.Kmax
         assert (meta.B, meta.H, meta.W) == (B, H, W)
+        if torch.cuda.current_device() != self.device.index:     # every launch goes to the CURRENT device's current stream
+            raise RuntimeError(f'the model lives on {self.device} but the current device is cuda:{torch.cuda.current_device()}: '
+                               'one process per GPU (torch.cuda.set_device) -- launches would go to the wrong device')
         b = self._get_bufs(B, H, W, Kmax, train)
         self._last = b
         self._route = self.route(B, H, W)
@@ -538,7 +517,7 @@ class WesupEngine:
         cur, cur_relu = b.x0, False      # the layer's input tensor, and whether its ReLU is still to be applied on load
         b.x_in, b.x_relu = [None] * 13, [False] * 13
         b.wino_fwd = list(self._route)
-        b.relu_stored = self.relu_on_store and all(b.yr_wanted[l] for l in range(12) if not POOL_AFTER[l])
+        b.relu_stored = all(b.yr_wanted[l] for l in range(12) if not POOL_AFTER[l])
         fused = self.fuse_pool_fwd
         b.fm_valid = not fused
         fm2d = None if fused else b.fm.view(B * H * W, FM_CHANNELS)
@@ -575,7 +554,8 @@ class WesupEngine:
             if train and self.compact_masks and m == 4:
                 # sign bits of y_{l-1}: this layer's input transform reads it (pre-ReLU, not pooled) and this layer's input
                 # gradient is the consumer (one-kernel route: product co -> ci)
-                if l >= 1 and cur is b.y[l - 1] and cur_relu and ops.winograd_fused_supported(co, ci, 4) == 2:
+                tiles = ops.winograd_tiles(B, h, w, 4)
+                if l >= 1 and cur is b.y[l - 1] and cur_relu and ops.winograd_fused_supported(co, ci, 4, tiles) == 2:
                     if b.mbits[l - 1] is None:
                         b.mbits[l - 1] = torch.empty(B, h, w, ci // 4, dtype=torch.uint8, device=self.device)
                     bits_out = b.mbits[l - 1]
@@ -583,8 +563,9 @@ class WesupEngine:
                 # pooling codes of y_l: this layer's pooling epilogue writes them, the input gradient of layer l + 1 (through
                 # the max-pool backward, one-kernel route) reads them
                 if (POOL_AFTER[l] and l < 12 and yr is None and self.fuse_unpool and self._wino(l + 1) == 4
-                        and ops.winograd_fused_supported(ci, co, 4) >= 1
-                        and ops.winograd_fused_supported(CONV_CH[l + 1][1], CONV_CH[l + 1][0], 4) == 2):
+                        and ops.winograd_fused_supported(ci, co, 4, tiles) >= 1
+                        and ops.winograd_fused_supported(CONV_CH[l + 1][1], CONV_CH[l + 1][0], 4,
+                                                         ops.winograd_tiles(B, h // 2, w // 2, 4)) == 2):
                     if b.pcode[l] is None:
                         b.pcode[l] = torch.empty(B, h // 2, w // 2, co // 4, dtype=torch.int16, device=self.device)
                     code_out = b.pcode[l]
@@ -614,39 +595,19 @@ class WesupEngine:
             def side_work(l=l, ci=ci, co=co, h=h, w=w, off=off, ws=ws, commute=commute, s_l=s_l, s2d=s2d, side_in_conv=side_in_conv):
               with self._OnSide(self):
                 grp = b.groups[b.group_of[l]] if b.group_of[l] is not None else None
-                batched = grp is not None and grp.same_co and self.batch_side_convs
                 if ('side_fwd_shallow' in self._diag_skip and grp is None) or ('side_fwd_deep' in self._diag_skip and grp is not None):
                     pass                     # timing-only diagnostic: sp_in keeps an earlier step's slice
                 elif commute:
                     if b.ybar[l] is None:
                         b.ybar[l] = torch.empty(B, Kmax, co, dtype=torch.float32, device=self.device)
-                    if grp is not None:      # coarse resolution: Ybar = Wm . y, one GEMM per image
-                        tok = T.begin('sp_pool_mat_fwd')
-                        ops.gemm_tn_batched(grp.WmT, b.y[l].view(B, h * w, co), b.ybar[l], ws_tag='side')
-                        T.end(tok, 2.0 * B * Kmax * h * w * co)
-                    else:
-                        tok = T.begin('sp_pool_up_fwd')
-                        ops.sp_pool_upsample_fwd(b.y[l], meta, b.ybar[l], 0)
-                        T.end(tok, 4.0 * B * (h * w * co + H * W + Kmax * co))
+                    tok = T.begin('sp_pool_up_fwd')          # (commuted layers are the gather layers: no interpolation matrix)
+                    ops.sp_pool_upsample_fwd(b.y[l], meta, b.ybar[l], 0)
+                    T.end(tok, 4.0 * B * (h * w * co + H * W + Kmax * co))
                     tok = T.begin('side_fwd')
                     ops.gemm_nt(b.ybar[l].view(B * Kmax, co), ws, p[f'side_conv{off}.bias'],
                                 out=b.sp_in.view(B * Kmax, FM_CHANNELS)[:, off:off + co // 2])
                     T.end(tok, 2.0 * B * Kmax * co * (co // 2))
-                elif batched and l == grp.layers[-1]:
-                    # the side convs of the layers that share this resolution as one launch (each alone fills 226 / 58 of the
-                    # 512 block slots)
-                    tok = T.begin('side_fwd')
-                    ls = grp.layers
-                    done = ops.gemm_nt_group([b.y[i].view(B * h * w, co) for i in ls],
-                                             [p[f'side_conv{SIDE_OFF[i]}.weight'].view(co // 2, co) for i in ls],
-                                             [p[f'side_conv{SIDE_OFF[i]}.bias'] for i in ls],
-                                             [b.s[i].view(B * h * w, co // 2) for i in ls])
-                    if not done:
-                        for i in ls:
-                            ops.gemm_nt(b.y[i].view(B * h * w, co), p[f'side_conv{SIDE_OFF[i]}.weight'].view(co // 2, co),
-                                        p[f'side_conv{SIDE_OFF[i]}.bias'], out=b.s[i].view(B * h * w, co // 2))
-                    T.end(tok, 2.0 * len(ls) * B * h * w * co * (co // 2))
-                elif not side_in_conv and not batched:
+                elif not side_in_conv:
                     tok = T.begin('side_fwd')
                     ops.gemm_nt(b.y[l].view(B * h * w, co), ws, p[f'side_conv{off}.bias'], out=s2d)
                     T.end(tok, 2.0 * B * h * w * co * (co // 2))
@@ -671,7 +632,7 @@ class WesupEngine:
             # l + 1 (both read y_l); deferred until that transform has been queued (ops: after_transform), it runs beside the
             # layer's products instead -- a memory-bound kernel next to an MFMA-bound one.
             # (the deep layers too: deferring only the memory-bound shallow ones measured 0.03 ms worse)
-            if self.defer_side_fwd and self.two_streams and l < 12 and self._wino(l + 1):
+            if self.two_streams and l < 12 and self._wino(l + 1):
                 pending_side = side_work
             else:
                 side_work()
@@ -690,10 +651,9 @@ class WesupEngine:
             T.end(tok, 4.0 * B * (FM_CHANNELS * H * W + H * W + Kmax * FM_CHANNELS))
         R = B * Kmax
         tok = T.begin('mlp_fwd')
-        sk = self.head_streamk or None           # None: ops.STREAMK_GEMM decides
-        ops.gemm_nt(b.sp_in.view(R, FM_CHANNELS), p['fc_layers.0.weight'], p['fc_layers.0.bias'], out=b.h1, flags=ops.RELU_OUT, streamk=sk)
-        ops.gemm_nt(b.h1, p['fc_layers.2.weight'], p['fc_layers.2.bias'], out=b.h2, flags=ops.RELU_OUT, streamk=sk)
-        ops.gemm_nt(b.h2, p['fc_layers.4.weight'], p['fc_layers.4.bias'], out=b.feats, flags=ops.RELU_OUT, streamk=sk)
+        ops.gemm_nt(b.sp_in.view(R, FM_CHANNELS), p['fc_layers.0.weight'], p['fc_layers.0.bias'], out=b.h1, flags=ops.RELU_OUT)
+        ops.gemm_nt(b.h1, p['fc_layers.2.weight'], p['fc_layers.2.bias'], out=b.h2, flags=ops.RELU_OUT)
+        ops.gemm_nt(b.h2, p['fc_layers.4.weight'], p['fc_layers.4.bias'], out=b.feats, flags=ops.RELU_OUT)
         T.end(tok, 2.0 * R * (FM_CHANNELS * 1024 + 1024 * 1024 + 1024 * self.D))
         ops.classifier_fwd(b.feats, p['classifier.0.weight'], p['classifier.0.bias'], b.sp_pred)
         sp_pred3 = b.sp_pred.view(B, Kmax, 2)
@@ -751,17 +711,16 @@ class WesupEngine:
                            None if dfeat_extra is None else dfeat_extra.reshape(R, D),
                            b.dfeat, g['classifier.0.weight'], g['classifier.0.bias'])
         gsp2d = b.gsp.view(R, FM_CHANNELS)
-        off_chain = self.two_streams and getattr(self, 'head_wgrad_off_chain', True)
+        off_chain = self.two_streams
         if not off_chain:
             ops.gemm_tn(b.dfeat, b.h2, out=g['fc_layers.4.weight'], colsum=g['fc_layers.4.bias'])
-        sk = self.head_streamk or None
-        ops.gemm_nt(b.dfeat, pk.fcT[2], None, out=b.dh2, mask=b.h2, streamk=sk)
+        ops.gemm_nt(b.dfeat, pk.fcT[2], None, out=b.dh2, mask=b.h2)
         if not off_chain:
             ops.gemm_tn(b.dh2, b.h1, out=g['fc_layers.2.weight'], colsum=g['fc_layers.2.bias'])
-        ops.gemm_nt(b.dh2, pk.fcT[1], None, out=b.dh1, mask=b.h1, streamk=sk)
+        ops.gemm_nt(b.dh2, pk.fcT[1], None, out=b.dh1, mask=b.h1)
         if not off_chain:
             ops.gemm_tn(b.dh1, b.sp_in.view(R, FM_CHANNELS), out=g['fc_layers.0.weight'], colsum=g['fc_layers.0.bias'])
-        ops.gemm_nt(b.dh1, pk.fcT[0], None, out=gsp2d, streamk=sk)
+        ops.gemm_nt(b.dh1, pk.fcT[0], None, out=gsp2d)
         T.end(tok, (4.0 if not off_chain else 2.0) * R * (FM_CHANNELS * 1024 + 1024 * 1024 + 1024 * D))
         if off_chain:
             wgs = self._wg()
@@ -802,13 +761,6 @@ class WesupEngine:
                 tok = T.begin('side_bwd')
                 ops.gemm_nt(gsp2d[:, off:off + co // 2], pk.sideT[l], None, out=b.dybar[l].view(R, co))
                 T.end(tok, 2.0 * R * co * (co // 2))
-            if b.group_of[ls[0]] is not None:        # coarse resolution: G_l = Wm^T . dYbar_l, one GEMM per image
-                grp = b.groups[b.group_of[ls[0]]]
-                tok = T.begin('upsample_mat_bwd')
-                for l in ls:
-                    ops.gemm_tn_batched(grp.Wm, b.dybar[l], b.G[l].view(B, h * w, CONV_CH[l][1]), ws_tag='side')
-                T.end(tok, 2.0 * B * Kmax * h * w * sum(CONV_CH[l][1] for l in ls))
-                return
             tok = T.begin('upsample_bwd')
             if (h, w) == (H, W) or sum(CONV_CH[l][1] for l in ls) > 768:
                 for l in ls:
@@ -825,7 +777,8 @@ class WesupEngine:
             for l in range(0, 12):
                 ci1, co1 = CONV_CH[l + 1]
                 if (b.group_of[l] is None and self._commuted(b, l) and b.dims[l] == (H, W) and l >= lowest
-                        and b.wino_fwd[l + 1] == 4 and ops.winograd_fused_supported(co1, ci1, 4) == 2
+                        and b.wino_fwd[l + 1] == 4
+                        and ops.winograd_fused_supported(co1, ci1, 4, ops.winograd_tiles(B, *b.dims[l + 1], 4)) == 2
                         and (not POOL_AFTER[l] or (self.fuse_unpool and H % 2 == 0 and W % 2 == 0))):
                     gat[l] = True
 
@@ -896,18 +849,10 @@ class WesupEngine:
                 off = SIDE_OFF[l]
                 P = B * h * w
                 if self._commuted(b, l):
-                    if b.group_of[l] is not None:
-                        if l >= lowest:      # layer by layer, deepest first: the dgrad chain starts with conv5_3
-                            commuted_G([l])
-                            if self.two_streams:
-                                g_ready[l] = self.SLOT_G + l
-                                ops.sync_record(g_ready[l])
-                    elif not self.two_streams and l >= lowest:   # single-stream schedule: not queued above
+                    if not self.two_streams and l >= lowest:     # single-stream schedule: not queued above
                         for ls in commuted_runs():
                             if ls[0] == l:
                                 commuted_G(ls)
-                    if not self.side_wgrad_last:
-                        side_wgrad(l)
                     continue
                 self._side_grad(b, l)            # (allocated on first use; a group's buffer serves all its layers)
                 if b.group_of[l] is not None:
@@ -935,39 +880,22 @@ class WesupEngine:
                 T.end(tok, 4.0 * B * ((h * w * (co // 2) + H * W + Kmax * (co // 2)) if self.fuse_pool_bwd else H * W * (co // 2)))
                 ds2ds[l] = ds2d
                 grp = b.groups[b.group_of[l]] if b.group_of[l] is not None else None
-                if grp is not None and grp.same_co and self.batch_side_convs and grp.layers[0] >= lowest:
-                    if l == grp.layers[-1]:      # G of every layer of the resolution in one launch (their ds are all there)
-                        ls = grp.layers
-                        tok = T.begin('side_bwd')
-                        dss = [b.ds[i].view(P, co // 2) for i in ls]
-                        done = ops.gemm_nt_group(dss, [pk.sideT[i] for i in ls], None, [b.G[i].view(P, co) for i in ls])
-                        if not done:
-                            for i, d_ in zip(ls, dss):
-                                ops.gemm_nt(d_, pk.sideT[i], None, out=b.G[i].view(P, co))
-                        T.end(tok, 2.0 * len(ls) * P * co * (co // 2))
-                        if self.two_streams:
-                            ops.sync_record(self.SLOT_G + ls[0])
-                            for i in ls:
-                                g_ready[i] = self.SLOT_G + ls[0]
-                elif l >= lowest:            # G_l is only needed by backbone layers that train
+                if l >= lowest:              # G_l is only needed by backbone layers that train
                     tok = T.begin('side_bwd')
                     ops.gemm_nt(ds2d, pk.sideT[l], None, out=b.G[l].view(P, co))
                     T.end(tok, 2.0 * P * co * (co // 2))
                     if self.two_streams:
                         g_ready[l] = self.SLOT_G + l
                         ops.sync_record(g_ready[l])
-                if not self.side_wgrad_last:
-                    side_wgrad(l)
             # The side convs' own weight gradients are parameter gradients nobody waits for before the optimiser, while the
             # dgrad chain waits for every G_l: all the G_l first (13 GEMMs), the weight gradients behind them.
-            late_at = self.deep_side_wgrad_at if (self.two_streams and self.side_wgrad_last) else None
+            late_at = self.DEEP_SIDE_WGRAD_AT if self.two_streams else None
             if late_at is not None and not (lowest < late_at <= 12):      # the main loop below never reaches such a layer
                 late_at = None
             late_side = [l for l in range(12, -1, -1) if late_at is not None and b.group_of[l] is not None]
-            if self.side_wgrad_last:
-                for l in range(12, -1, -1):
-                    if l not in late_side:
-                        side_wgrad(l)
+            for l in range(12, -1, -1):
+                if l not in late_side:
+                    side_wgrad(l)
         # ---- main path, conv5_3 down to conv1_1.  The dgrad chain stays on the caller's stream; each layer's wgrad
         # (which only produces parameter gradients) goes to a third stream so that it fills the tails of the dgrad
         # kernels instead of sitting on the critical path.
@@ -1028,7 +956,7 @@ class WesupEngine:
             # With its operands ready (dual transform) a weight gradient can start any time.  Queued behind the layer's input
             # gradient instead of in front of it, its TN products run beside the NEXT layer's (memory-bound) transform rather
             # than beside this layer's products: 9.35 -> 9.20 ms.
-            late_wgrad = self.wgrad_behind_dgrad and wg is not None and dual and l > lowest + self.wgrad_early_layers
+            late_wgrad = wg is not None and dual and l > lowest + self.WGRAD_EARLY_LAYERS
             if not trainable[l] or 'wgrad' in self._diag_skip:
                 pass
             elif late_wgrad:

@@ -37,10 +37,15 @@ def set_streamk(fwd=None, dgrad=None, gemm=None, everything=None):
         STREAMK_GEMM = bool(gemm)
 
 
-def _stream():
-    # the raw handle of torch's current stream on the current device (torch.cuda.current_stream().cuda_stream builds a Stream
-    # object per call: 2.5 us, ~500 times per training step -- a quarter of the host time of a step at batch 1)
-    return ctypes.c_void_p(torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice()))
+if hasattr(torch._C, '_cuda_getCurrentRawStream') and hasattr(torch._C, '_cuda_getDevice'):
+    def _stream():
+        # the raw handle of torch's current stream on the current device (torch.cuda.current_stream().cuda_stream builds a Stream
+        # object per call: 2.5 us, ~500 times per training step -- a quarter of the host time of a step at batch 1).  The engine
+        # checks once per forward that the current device is the model's.
+        return ctypes.c_void_p(torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice()))
+else:                                                  # a torch build without the private accessors
+    def _stream():
+        return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
 # Optional HIP-event timing of the kernel classes that are launched outside the engine's schedule (superpixel
@@ -435,39 +440,14 @@ def winograd_filter_grad(slabs, dw=None, db=None, m=2):
     return dw, db
 
 
-# Fused short products: transformed inputs above this size are processed in image groups that fit the memory-side cache
-# (256 MB Infinity Cache on MI355X); 0 = always the whole batch.  bench.py --subbatch-mb for the A/B.
-SUBBATCH_V_BYTES = 0
-
-_aux_streams = {}
-# transforms of one half of the batch under the GEMM of the other half (helper stream): bit-identical and tested, OFF --
-# measured 13.74 -> 13.97 ms per step (the step is bound by the chip's total throughput, not by its chain)
-PIPELINE_WINOGRAD = False
-PIPELINE_MIN_BLOCKS = 768         # ... when each half's GEMM still fills the chip (512 block slots) more than once
-
-
-def _aux_stream(device):
-    """One helper stream per caller stream: the engine's chain stays on the caller's stream, the helper only ever runs
-    transform passes between events of that chain."""
-    main = torch.cuda.current_stream(device)
-    key = (str(device), main.cuda_stream)
-    st = _aux_streams.get(key)
-    if st is None:
-        st = _aux_streams[key] = torch.cuda.Stream(device=device)
-    return main, st
-
-
 def _winograd_conv(inp, u, bias, mask_src, out, out_relu, v_keep, relu_in, accumulate, ws_tag, timer, out_pool=None,
                    pool_relu=False, m=2, relu_bits_out=None, pool_code_out=None, mask_bits=None, v_ready=False,
                    after_transform=None):
-    """The three passes of a Winograd-domain conv (input transform, 16 batched NT GEMMs, output transform + epilogue).
-    timer (optional, engine.KernelTimer-like): the GEMM and the two transforms are bracketed as classes of their own.
-
-    The transforms are memory-bound and the GEMM MFMA-bound.  With an even batch that is large enough, the two halves
-    of the batch (independent images) are pipelined: the caller's stream runs  Tin(A), GEMM(A), GEMM(B), Tout(B)  and a
-    helper stream  Tin(B) under GEMM(A)  and  Tout(A) under GEMM(B);  both halves write their rows of the same
-    [16][tiles][C] planes, so the kept V and the result are exactly those of the unsplit call.  The caller's stream has
-    waited for everything when this returns."""
+    """The three passes of a Winograd-domain conv (input transform, P batched NT GEMMs, output transform + epilogue) -- or, for
+    the short products (K <= 256 channels), the input transform and ONE kernel for products + output transform.
+    timer (optional, engine.KernelTimer-like): the GEMM and the transforms are bracketed as classes of their own.
+    after_transform: called once, when the input transform has been queued (the engine queues the previous layer's side
+    branch there)."""
     B, H, W, Cin = inp.shape
     Cout = u.shape[1]
     lib = _lib.load()
@@ -520,7 +500,11 @@ def _winograd_conv(inp, u, bias, mask_src, out, out_relu, v_keep, relu_in, accum
         if timer:
             timer.end(tok, 4.0 * (P * winograd_tiles(nb_, H, W, m) + (n_io + (0.25 if out_pool is not None else 0)) * nb_ * H * W) * Cout)
 
-    fused = 0 if out_relu is not None else lib.wesup_winograd_fused_supported(Cin, Cout, m)
+    # (the compact forms -- sign bits in, pooling codes out -- exist on the one-kernel route only: a caller that hands them over
+    #  has chosen it; otherwise the size of the grid decides, wesup_winograd_fused_route)
+    compact = mask_bits is not None or pool_code_out is not None
+    fused = 0 if out_relu is not None else (lib.wesup_winograd_fused_supported(Cin, Cout, m) if compact
+                                            else lib.wesup_winograd_fused_route(Cin, Cout, m, T))
     masked = mask_src is not None or mask_bits is not None
     if relu_bits_out is not None:
         assert m == 4 and relu_bits_out.dtype == torch.uint8 and relu_bits_out.shape == (B, H, W, Cin // 4) and relu_bits_out.is_contiguous()
@@ -533,15 +517,7 @@ def _winograd_conv(inp, u, bias, mask_src, out, out_relu, v_keep, relu_in, accum
     if fused == 2 or (fused == 1 and not masked and not accumulate):
         # short products (64 ... 256 channels): the batched products and the output transform in one kernel
         st = _stream()
-        # Sub-batches: a layer whose transformed input is larger than the memory-side cache goes image group by image
-        # group -- transform, then products, of one group before the next -- so that the products read V from the cache
-        # the transform just filled instead of from HBM (both passes are HBM-bound at these widths); the groups write their
-        # rows of the same planes, so the kept V and the result are those of the whole-batch call.
-        group = B
-        if SUBBATCH_V_BYTES and 4 * P * T * Cin > SUBBATCH_V_BYTES:
-            group = max(1, int(B * SUBBATCH_V_BYTES // (4 * P * T * Cin)))
-        for b0 in range(0, B, group):
-            nb_ = min(group, B - b0)
+        for b0, nb_ in ((0, B),):
             t_in(b0, nb_, st)
             tok = timer.begin('winograd_gemm') if timer else None
             t0, tn = winograd_tiles(b0, H, W, m), winograd_tiles(nb_, H, W, m)
@@ -559,29 +535,8 @@ def _winograd_conv(inp, u, bias, mask_src, out, out_relu, v_keep, relu_in, accum
             if timer:
                 timer.end(tok, 2.0 * P * tn * Cin * Cout)
         return out
-    half_blocks = ((T // 2 + 127) // 128) * ((Cout + 127) // 128) * P
-    if not (PIPELINE_WINOGRAD and B % 2 == 0 and half_blocks >= PIPELINE_MIN_BLOCKS):
-        st = _stream()
-        t_in(0, B, st); gemm(0, B, st); t_out(0, B, st)
-        return out
-    hb = B // 2
-    main, aux = _aux_stream(inp.device)
-    ms, xs = ctypes.c_void_p(main.cuda_stream), ctypes.c_void_p(aux.cuda_stream)
-    aux.wait_stream(main)                      # the inputs are ready where the caller's stream stands
-    t_in(0, hb, ms)
-    with torch.cuda.stream(aux):
-        t_in(hb, hb, xs)
-        e_in_b = torch.cuda.Event(); e_in_b.record()
-    gemm(0, hb, ms)
-    e_gemm_a = torch.cuda.Event(); e_gemm_a.record()
-    with torch.cuda.stream(aux):
-        aux.wait_event(e_gemm_a)
-        t_out(0, hb, xs)
-        e_out_a = torch.cuda.Event(); e_out_a.record()
-    main.wait_event(e_in_b)
-    gemm(hb, hb, ms)
-    t_out(hb, hb, ms)
-    main.wait_event(e_out_a)
+    st = _stream()
+    t_in(0, B, st); gemm(0, B, st); t_out(0, B, st)
     return out
 
 
@@ -642,7 +597,8 @@ def conv3x3_dgrad_winograd_unpool(dy, u_dgrad, unpool_src, unpool_dst, ws_tag='d
     _, Hu, Wu, _ = unpool_dst.shape
     assert unpool_dst.shape == (B, Hu, Wu, Cin) and (Hu // 2, Wu // 2) == (H, W)
     lib = _lib.load()
-    if unpool_code is not None or (v_pre is not None and lib.wesup_winograd_fused_supported(Cout, Cin, m) == 2):
+    route = lib.wesup_winograd_fused_route(Cout, Cin, m, winograd_tiles(B, H, W, m))
+    if unpool_code is not None or (v_pre is not None and route == 2):
         # the pooling's decisions as codes (conv3x3_fwd_winograd(pool_code_out=...)): no read of unpool_src; and / or the input
         # transform of dy done already (winograd_dual_transform).  One-kernel product route only.
         if unpool_code is not None:
@@ -650,7 +606,7 @@ def conv3x3_dgrad_winograd_unpool(dy, u_dgrad, unpool_src, unpool_dst, ws_tag='d
         else:
             _chk(unpool_src, name='unpool_src'); assert unpool_src.shape == unpool_dst.shape
         if lib.wesup_winograd_fused_supported(Cout, Cin, m) != 2:
-            raise _lib.WesupHipError(f'winograd dgrad {Cout} -> {Cin}: unpool_code / v_pre need the one-kernel product route')
+            raise _lib.WesupHipError(f'winograd dgrad {Cout} -> {Cin}: unpool_code needs the one-kernel product route')
         T, P = winograd_tiles(B, H, W, m), winograd_positions(m)
         st = _stream()
         if v_pre is None:
@@ -696,7 +652,7 @@ def conv3x3_dgrad_winograd_unpool(dy, u_dgrad, unpool_src, unpool_dst, ws_tag='d
         tok = timer.begin('winograd_transform')
         _lib.call('wesup_winograd_input_transform', _p(dy), _p(V), 0, B, H, W, Cout, 0, m, st)
         timer.end(tok, 4.0 * (B * H * W + P * T) * Cout)
-    if lib.wesup_winograd_fused_supported(Cout, Cin, m) == 2:
+    if route == 2:
         tok = timer.begin('winograd_gemm')
         _lib.call('wesup_winograd_gemm_output_transform', _p(V), 0, _p(u_dgrad), None, None, None, None, 0, _p(unpool_src),
                   _p(unpool_dst), Hu, Wu, B, H, W, Cout, Cin, 0, st)
@@ -713,10 +669,11 @@ def conv3x3_dgrad_winograd_unpool(dy, u_dgrad, unpool_src, unpool_dst, ws_tag='d
     return unpool_dst
 
 
-def winograd_fused_supported(K, N, m=4):
+def winograd_fused_supported(K, N, m=4, tiles=0):
     """0: the products of this shape go through the batched GEMM + output transform; 1 / 2: through the one-kernel route in the
-    forward / in every pass (wesup_winograd_fused_supported)."""
-    return int(_lib.load().wesup_winograd_fused_supported(K, N, m))
+    forward / in every pass (wesup_winograd_fused_supported).  tiles > 0: ... of a problem of that many tiles (0 when the
+    one-kernel route's grid would be too small, wesup_winograd_fused_route)."""
+    return int(_lib.load().wesup_winograd_fused_route(K, N, m, int(tiles)))
 
 
 def conv3x3_dgrad_winograd_gather(dy, u_dgrad, side, new_row, area_new, out, mask_src=None, unpool_src=None,

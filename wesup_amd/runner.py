@@ -136,7 +136,7 @@ class StepRunner:
                 float(t.kwargs.get('propagate_threshold')), float(t.kwargs.get('propagate_weight')),
                 bool(t.kwargs.get('enable_propagation')), float(t.kwargs.get('epsilon')),
                 None if red is None else (id(red), t.world_size, red.bucket_elems, red.force),
-                torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice()))
+                ops._stream().value)
 
     # ------------------------------------------------------------------ the iteration
     def run(self, parsed):
