@@ -131,10 +131,10 @@ def main():
 MEM_KERNELS = {      # kernel-name prefix -> class of the memory-bound report (per-launch counter traffic next to the event times)
     'sgd_kernel': 'sgd', 'prop_kernel': 'propagate', 'paint_kernel': 'paint', 'sp_hist_kernel': 'sp_preprocess',
     'sp_order_kernel': 'sp_preprocess', 'sp_chunk_base_kernel': 'sp_preprocess', 'sp_place_kernel': 'sp_preprocess',
-    'sp_segments_kernel': 'sp_preprocess', 'sp_pool_up_fwd_kernel': 'sp_pool_up_fwd', 'sp_interp_matrix_kernel': 'interp_matrix',
+    'sp_segments_kernel': 'sp_preprocess', 'sp_count_order_kernel': 'sp_preprocess', 'sp_pool_up_fwd_kernel': 'sp_pool_up_fwd', 'sp_interp_matrix_kernel': 'interp_matrix',
     'wino4_input_transform_kernel': 'winograd_transform', 'wino4_output_transform_kernel': 'winograd_transform',
     'wino_input_transform_kernel': 'winograd_transform', 'wino_output_transform_kernel': 'winograd_transform',
-    'wino4_outgrad_transform_kernel': 'winograd_outgrad_transform', 'upsample_bwd_cell_kernel': 'upsample_bwd',
+    'wino4_dual_transform_kernel': 'winograd_transform', 'wino4_outgrad_transform_kernel': 'winograd_outgrad_transform', 'upsample_bwd_cell_kernel': 'upsample_bwd',
     'maxpool_bwd_kernel': 'maxpool_bwd'}
 
 
