@@ -16,6 +16,7 @@
 // lanes, 16-byte loads and stores of contiguous channel rows; tiles that hang over a ragged border read zeros and skip
 // the stores.
 #include "winograd.hpp"
+#include <cstdlib>
 
 struct WinoGeom {
     int H, W, C, Th, Tw;
@@ -423,8 +424,9 @@ __device__ __forceinline__ void wino4_input_body(const float* __restrict__ x, fl
 #pragma unroll
         for (int r = 0; r < 6; ++r) m[r][c] = t[r];
     }
-    float* out = V + (long)q.t * g.C + 4 * q.cq;
-    const long ps = g.ps;
+    // EXPERIMENT (g.pad_ = 1): tile-blocked layout [tile / 32][36][32][C] instead of [36][T][C]
+    float* out = g.pad_ ? V + (((long)(q.t >> 5) * 36 * 32) + (q.t & 31)) * g.C + 4 * q.cq : V + (long)q.t * g.C + 4 * q.cq;
+    const long ps = g.pad_ ? 32l * g.C : g.ps;
 #pragma unroll
     for (int r = 0; r < 6; ++r) {   // (.) B
         float4 o[6];
@@ -737,7 +739,12 @@ static int wino_input_launch(const float* x, float* V, long plane_elems, unsigne
     const WinoGeom g = wino_geom(B, H, W, C, m, plane_elems);
     const dim3 grid((unsigned)ceil_div(g.T * (C / 4), 256l));
     if (m == 2) WESUP_LAUNCH(wino_input_transform_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, V, g, relu_in);
-    else WESUP_LAUNCH(wino4_input_transform_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, V, g, relu_in, bits);
+    else {
+        static const bool blocked = getenv("WESUP_VBLOCKED") != nullptr;      // EXPERIMENT
+        WinoGeom g2 = g;
+        g2.pad_ = blocked ? 1 : 0;
+        WESUP_LAUNCH(wino4_input_transform_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, V, g2, relu_in, bits);
+    }
     WESUP_CHECK_LAUNCH();
     return WESUP_OK;
 }
