@@ -67,3 +67,22 @@ __device__ __forceinline__ float vmax1(float x) {
 // so that the loss is NaN and the trainer raises before the weights are touched (models/base.py:202-203).
 __device__ __forceinline__ float relu1(float x) { return x < 0.f ? 0.f : x; }
 __device__ __forceinline__ float4 relu4(float4 v) { return make_float4(relu1(v.x), relu1(v.y), relu1(v.z), relu1(v.w)); }
+
+#include <cstdlib>
+// Streaming stores.  A transformed tensor of the big layers is 2.25 x its activation (conv1_2 at B = 4, 480 x 480: 531 MB) --
+// larger than the 256 MB memory-side cache -- and is read once, by a later kernel: written with ordinary stores it only evicts
+// what the next kernels would have found there, and the write stream itself runs at half the copy rate (input transform of
+// conv1_2 alone 231 us = 3.3 TB/s; with non-temporal stores 144 us = 5.3 TB/s; 240^2 x 128: 112 -> 79 us).  A tensor that
+// is small (<= WESUP_NT_MB per launch, default 16 MB) keeps ordinary stores: its consumer finds it in L2.  Alone on the GPU a
+// 133 MB tensor is better off with ordinary stores (42 vs 47 us: it fits the memory-side cache); inside the step, where
+// three streams stream through that cache, the low bar wins (threshold 100000 / 160 / 64 / 16 MB: 9.03 / 8.97 / 8.97 / 8.93 ms).
+__device__ __forceinline__ void st4s(float* p, float4 v, int nt) {
+    if (nt) {
+        f32x4 t = {v.x, v.y, v.z, v.w};
+        __builtin_nontemporal_store(t, reinterpret_cast<f32x4*>(p));
+    } else st4(p, v);
+}
+static inline int wino_nt_stores(double bytes_written) {
+    static const double limit = [] { const char* e = getenv("WESUP_NT_MB"); return (e ? atof(e) : 16.0) * 1048576.0; }();
+    return bytes_written > limit ? 1 : 0;
+}

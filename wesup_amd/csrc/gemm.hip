@@ -38,6 +38,7 @@ __device__ unsigned long long* g_trace = nullptr;
 #define WESUP_DBG(...)
 #endif
 
+#define NT_FLAG_STREAM 0x100      // internal bit of NtParams::flags: the output is large and read once later -> streaming stores
 struct NtParams {
     const float* A;
     const float* Bw;
@@ -296,6 +297,7 @@ __global__ __launch_bounds__(NW * 64, MINB) void gemm_nt_kernel(const NtParams p
     // stores the raw tile to its workspace slot instead.
     float* Cs = smem;
     const bool relu_out = p.flags & WESUP_RELU_OUT, accum = p.flags & WESUP_ACCUM, use_mask = p.flags & WESUP_MASK;
+    const int nt = (p.flags & NT_FLAG_STREAM) ? 1 : 0;      // outputs written with streaming stores (common.hpp)
     constexpr int QN = BN / 4;                 // float4 pieces per row
     constexpr int ROWS_PER_PASS = NT / QN;
     const int cq = tid % QN, r0 = tid / QN;
@@ -380,8 +382,8 @@ __global__ __launch_bounds__(NW * 64, MINB) void gemm_nt_kernel(const NtParams p
                     const float4 o = ld4(c);
                     v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
                 }
-                st4(c, v);
-                if (p.C2) st4(p.C2 + (long)m * p.ldc + n, relu4(v));
+                st4s(c, v, nt);
+                if (p.C2) st4s(p.C2 + (long)m * p.ldc + n, relu4(v), nt);
             }
         }
     }
@@ -656,7 +658,7 @@ static int conv_common(const float* x, const float* w, const float* bias, float*
     p.lda = Cin; p.ldb = p.K; p.ldc = Cout; p.ldmask = Cout;
     p.H = H; p.W = W; p.Cin = Cin; p.cin_shift = ilog2(Cin);
     p.dW = make_fastdiv(W); p.dH = make_fastdiv(H);
-    p.flags = flags;
+    p.flags = flags | ((!(flags & WESUP_ACCUM) && wino_nt_stores(4.0 * p.M * Cout * (y_relu ? 2 : 1))) ? NT_FLAG_STREAM : 0);
     if (side) {
         if (!side->w || !side->out || (Cout != 64 && Cout != 128) || side->ld < Cout / 2 ||
             (((uintptr_t)side->w | (uintptr_t)side->out | (uintptr_t)side->bias) & 15))

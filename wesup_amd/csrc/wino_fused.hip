@@ -29,6 +29,7 @@ struct FusedParams {
     const float* up_src;     // unpool mode: pre-pool activations (B,Hu,Wu,N)
     float* up_dst;           // ... and the gradient they receive (accumulated into)
     int Hu, Wu;
+    int nt, pad_;            // nt: y / the unpooled gradient written with streaming stores (common.hpp: wino_nt_stores)
     WinoGather gat;          // side-branch gradient gathered per pixel in place of reading y / up_dst (src NULL: off)
     const unsigned char* mask_bits;     // the mask as sign bits [B][H][W][N/4] (wesup_winograd_input_transform_bits) instead of mask
     unsigned short* pool_code;          // forward: the max-pool's decisions out, [B][H/2][W/2][N/4] (winograd.hpp)
@@ -252,7 +253,7 @@ __global__ __launch_bounds__(128 * TW, 2) void wino4_gemm_out_kernel(const Fused
                 v.z = mk.z > 0.f ? v.z : 0.f; v.w = mk.w > 0.f ? v.w : 0.f;
             }
             if (up.dst) {            // input gradient at pooled resolution: straight through the max-pool backward
-                if (p.gat.src) wino_unpool_gather(up, p.up_code, p.gat, b, h, w, p.N, n0 + 4 * q4, v);
+                if (p.gat.src) wino_unpool_gather(up, p.up_code, p.gat, b, h, w, p.N, n0 + 4 * q4, v, p.nt);
                 else wino_unpool_add(up, p.up_code, b, h, w, p.N, n0 + 4 * q4, v);
                 continue;
             }
@@ -263,7 +264,7 @@ __global__ __launch_bounds__(128 * TW, 2) void wino4_gemm_out_kernel(const Fused
                 const float4 old = ld4(p.y + off);
                 v = make_float4(v.x + old.x, v.y + old.y, v.z + old.z, v.w + old.w);
             }
-            st4(p.y + off, v);
+            st4s(p.y + off, v, p.nt);
         }
         if (p.y_pool) {              // forward only (v = Y + bias): the two pooled rows 2 ti + ip of every tile
             // thread = (tile, window column k, quad): TILES x 2 x 16 = 4 NT items
@@ -387,6 +388,7 @@ static int fused_launch(const float* V, long plane_elems, const float* U, const 
     p.y_pool = y_pool; p.pool_relu = pool_relu; p.accum = accumulate; p.up_src = unpool_src; p.up_dst = unpool_dst;
     p.gat = gat;
     p.mask_bits = bits.mask_bits; p.pool_code = bits.pool_code; p.up_code = bits.up_code;
+    p.nt = wino_nt_stores(4.0 * B * (unpool ? 4.0 : 1.0) * H * W * N);
     p.Hu = Hu; p.Wu = Wu; p.H = H; p.W = W; p.Th = (H + 3) / 4; p.Tw = (W + 3) / 4; p.T = T; p.N = N;
     p.dTw = make_fastdiv(p.Tw); p.dTh = make_fastdiv(p.Th);
     const FusedShape fs = fused_shape(T, N);

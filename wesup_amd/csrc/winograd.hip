@@ -20,7 +20,7 @@
 
 struct WinoGeom {
     int H, W, C, Th, Tw;
-    int pad_;            // (explicit padding, zero: launch.hpp)
+    int nt;              // 1: the transformed tensor is written with non-temporal (streaming) stores, see wino_nt_stores()
     long ps;             // elements between two position planes of the transformed tensor (>= T * C: a sub-batch may
                          // write its rows into the planes of the whole batch)
     long T;              // tiles = B * Th * Tw
@@ -424,15 +424,14 @@ __device__ __forceinline__ void wino4_input_body(const float* __restrict__ x, fl
 #pragma unroll
         for (int r = 0; r < 6; ++r) m[r][c] = t[r];
     }
-    // EXPERIMENT (g.pad_ = 1): tile-blocked layout [tile / 32][36][32][C] instead of [36][T][C]
-    float* out = g.pad_ ? V + (((long)(q.t >> 5) * 36 * 32) + (q.t & 31)) * g.C + 4 * q.cq : V + (long)q.t * g.C + 4 * q.cq;
-    const long ps = g.pad_ ? 32l * g.C : g.ps;
+    float* out = V + (long)q.t * g.C + 4 * q.cq;
+    const long ps = g.ps;
 #pragma unroll
     for (int r = 0; r < 6; ++r) {   // (.) B
         float4 o[6];
         wino4_bt(m[r], o);
 #pragma unroll
-        for (int c = 0; c < 6; ++c) st4(out + (6 * r + c) * ps, o[c]);
+        for (int c = 0; c < 6; ++c) st4s(out + (6 * r + c) * ps, o[c], g.nt);
     }
 }
 __global__ __launch_bounds__(256) void wino4_input_transform_kernel(const float* __restrict__ x, float* __restrict__ V,
@@ -474,7 +473,7 @@ __device__ __forceinline__ float4 wino4_outgrad_body(const float* __restrict__ d
             float4 o[6];
             wino4_a(m[r], o);
 #pragma unroll
-            for (int c = 0; c < 6; ++c) st4(out + (6 * r + c) * ps, o[c]);
+            for (int c = 0; c < 6; ++c) st4s(out + (6 * r + c) * ps, o[c], g.nt);
         }
     }
     return tot;
@@ -740,9 +739,8 @@ static int wino_input_launch(const float* x, float* V, long plane_elems, unsigne
     const dim3 grid((unsigned)ceil_div(g.T * (C / 4), 256l));
     if (m == 2) WESUP_LAUNCH(wino_input_transform_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, V, g, relu_in);
     else {
-        static const bool blocked = getenv("WESUP_VBLOCKED") != nullptr;      // EXPERIMENT
         WinoGeom g2 = g;
-        g2.pad_ = blocked ? 1 : 0;
+        g2.nt = wino_nt_stores(4.0 * 36 * g.T * C);
         WESUP_LAUNCH(wino4_input_transform_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, V, g2, relu_in, bits);
     }
     WESUP_CHECK_LAUNCH();
@@ -817,7 +815,8 @@ extern "C" size_t wesup_winograd_outgrad_workspace_bytes(int B, int H, int W, in
 }
 // internal (winograd.hpp): the transform with the per-block sums written to bias_part ([wino4_bias_rows][C], m = 4) or not
 int wino_outgrad_launch(const float* dy, float* dM, float* bias_part, int B, int H, int W, int C, int m, void* stream) {
-    const WinoGeom g = wino_geom(B, H, W, C, m);
+    WinoGeom g = wino_geom(B, H, W, C, m);
+    g.nt = m == 4 ? wino_nt_stores(4.0 * 36 * g.T * C) : 0;
     const dim3 grid((unsigned)wino_transform_blocks(B, H, W, C, m));
     if (m == 2) WESUP_LAUNCH(wino_outgrad_transform_kernel, grid, dim3(256), 0, (hipStream_t)stream, dy, dM, g);
     else WESUP_LAUNCH(wino4_outgrad_transform_kernel, grid, dim3(256), 0, (hipStream_t)stream, dy, dM, g, bias_part);
@@ -835,7 +834,8 @@ extern "C" int wesup_winograd_dual_transform(const float* dy, float* V, float* d
     if (!dy || !V || !dM || !wino_shape_ok(B, H, W, C, C, 4) || (((uintptr_t)dy | (uintptr_t)V | (uintptr_t)dM | (uintptr_t)bias_part) & 15) ||
         (bias_part && !wino4_block_colsum_ok(C)))
         return WESUP_ERR_INVALID;
-    const WinoGeom g = wino_geom(B, H, W, C, 4);
+    WinoGeom g = wino_geom(B, H, W, C, 4);
+    g.nt = wino_nt_stores(2 * 4.0 * 36 * g.T * C);      // (two transformed tensors per launch)
     const dim3 grid((unsigned)wino_transform_blocks(B, H, W, C, 4));
     WESUP_LAUNCH(wino4_dual_transform_kernel, grid, dim3(256), 0, (hipStream_t)stream, dy, V, dM, g, bias_part);
     WESUP_CHECK_LAUNCH();

@@ -90,7 +90,7 @@ __device__ __forceinline__ float4 wino_gather(const WinoGather& g, int b, long p
 // wino_unpool_add with the destination's old content replaced by the gather: every position of the window is WRITTEN
 // (gathered side gradient, plus v at the first positive maximum); Hu, Wu even (every pre-pool pixel sits in a window).
 __device__ __forceinline__ void wino_unpool_gather(const WinoUnpool& u, const unsigned short* code, const WinoGather& g, int b,
-                                                   int h, int w, int C, int c0, float4 v) {
+                                                   int h, int w, int C, int c0, float4 v, int nt = 0) {
     const long rs = (long)u.Wu * C;
     const long o00 = (((long)b * u.Hu + 2 * h) * u.Wu + 2 * w) * C + c0;
     const WinoPicks pk = wino_unpool_picks(u, code, b, h, w, C, c0);
@@ -99,7 +99,7 @@ __device__ __forceinline__ void wino_unpool_gather(const WinoUnpool& u, const un
     for (int k = 0; k < 4; ++k) {
         float4 o = wino_gather(g, b, (long)(2 * h + (k >> 1)) * u.Wu + 2 * w + (k & 1), C, c0);
         o.x += kx == k ? v.x : 0.f; o.y += ky == k ? v.y : 0.f; o.z += kz == k ? v.z : 0.f; o.w += kw == k ? v.w : 0.f;
-        st4(u.dst + o00 + (k >> 1) * rs + (k & 1) * C, o);
+        st4s(u.dst + o00 + (k >> 1) * rs + (k & 1) * C, o, nt);
     }
 }
 
