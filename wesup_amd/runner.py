@@ -237,13 +237,14 @@ class StepRunner:
                                             n_sp_host=st.n_sp_host, into=st.meta, counts=st.rb_counts)
             eng.frozen = {n for n, p in model._named if not p.requires_grad}
             feats, sp_pred, pred = eng.forward(st.img, st.meta, train=True)
-            if want_seg:
+            multi = red is not None and t.world_size > 1
+            if want_seg and multi:
                 ops.seg_metrics(pred, st.gt, out=st.seg)
             ops.propagate(feats, st.meta, float(kw.get('propagate_threshold')), enable=bool(kw.get('enable_propagation')),
                           out=(st.y_all, st.src, st.sim))
             ops.loss_fwd(sp_pred, st.y_all, st.meta, float(kw.get('epsilon')), float(kw.get('propagate_weight')),
                          out=(st.loss, st.terms))
-            if red is not None and t.world_size > 1:
+            if multi:
                 # A NaN loss on one rank must stop every rank (models/base.py _loss_flag): a MAX all-reduce of a flag on a
                 # stream of its own, the read-back copy behind it.  Host work (torch collectives), i.e. a cut of the plan.
                 def nan_flag():
@@ -255,9 +256,14 @@ class StepRunner:
                         st.rb_event.record()
                 self._cut(plan, nan_flag)
             else:
+                # The segmentation metrics and the read-back are not on the way to the loss gradient: on the side stream (idle
+                # between the last pooling of the forward and the first side-branch gradient), behind the loss.
                 st.rb_event = None
-                _lib.call('wesup_copy_to_host', ctypes.c_void_p(st.host.data_ptr()), ops._p(st.rb), st.rb.numel() * 4, ops._stream())
-                ops.sync_record(RB_SLOT)
+                with eng.side_stream():
+                    if want_seg:
+                        ops.seg_metrics(pred, st.gt, out=st.seg)
+                    _lib.call('wesup_copy_to_host', ctypes.c_void_p(st.host.data_ptr()), ops._p(st.rb), st.rb.numel() * 4, ops._stream())
+                    ops.sync_record(RB_SLOT)
             if red is not None and red.profile:
                 red.t_backward = torch.cuda.Event(enable_timing=True)
                 red.t_backward.record()
