@@ -236,8 +236,8 @@ class StepRunner:
                 st.meta = ops.sp_preprocess(st.labels, st.mask, st.y_all.shape[1], n_classes=st.y_all.shape[2],
                                             n_sp_host=st.n_sp_host, into=st.meta, counts=st.rb_counts)
             eng.frozen = {n for n, p in model._named if not p.requires_grad}
-            feats, sp_pred, pred = eng.forward(st.img, st.meta, train=True)
             multi = red is not None and t.world_size > 1
+            feats, sp_pred, pred = eng.forward(st.img, st.meta, train=True, need_paint=multi)
             if want_seg and multi:
                 ops.seg_metrics(pred, st.gt, out=st.seg)
             ops.propagate(feats, st.meta, float(kw.get('propagate_threshold')), enable=bool(kw.get('enable_propagation')),
@@ -260,6 +260,7 @@ class StepRunner:
                 # between the last pooling of the forward and the first side-branch gradient), behind the loss.
                 st.rb_event = None
                 with eng.side_stream():
+                    ops.paint_fwd(sp_pred, st.meta, 1, out=pred)          # (the pixel-wise prediction: metrics and callers only)
                     if want_seg:
                         ops.seg_metrics(pred, st.gt, out=st.seg)
                     _lib.call('wesup_copy_to_host', ctypes.c_void_p(st.host.data_ptr()), ops._p(st.rb), st.rb.numel() * 4, ops._stream())
