@@ -1,9 +1,7 @@
 """The one-kernel Winograd product route (csrc/wino_fused.hip) alone on the GPU, on the product shapes of the training step:
 microseconds per launch, executed TFLOP/s, bytes past the kernel's own model, and the distance from the two-kernel route.
 
-  WESUP_WINO_FUSED_SHAPE=4,4 python tools/fused_micro.py [--size 480] [--batch 4] [--reps 10]
-
-The block shape is read once per process (environment), so variants are compared by running this script once per shape.
+  python tools/fused_micro.py [--size 480] [--batch 4] [--reps 10]
 """
 import argparse
 import os
@@ -42,7 +40,7 @@ def timeit(fn, reps):
     return e0.elapsed_time(e1) / reps * 1e3
 
 
-print(f'# shape {os.environ.get("WESUP_WINO_FUSED_SHAPE", "default")}  B={B} {S}x{S}')
+print(f'# B={B} {S}x{S}')
 total = 0.0
 for name, K, N, div in SHAPES:
     if args.only and args.only not in name:

@@ -341,25 +341,14 @@ struct FusedBits {       // the compact forms of mask_src / unpool_src (in) and 
     unsigned short* pool_code;
     const unsigned short* up_code;
 };
-// Block shape of the one-kernel route: tile groups per block (2: 4 waves, two blocks per CU; 4: 8 waves, one block per CU) and
-// ring depth.  WESUP_WINO_FUSED_SHAPE="tw,3" overrides the default for every K (A/B measurements in one process sequence).
-// Round 4, measured alone on the step's product shapes (tools/fused_micro.py): 64-tile blocks -3 ... -5 % where the grid still
-// fills the chip (conv1_2, conv2_2, conv3_2), +50 % where it does not (conv3_1 dgrad, conv4_1: ~115 blocks); rings of 4 and 5
-// stages (possible at one block per CU) change nothing -- the kernel does not wait for the latency of its staging DMA.  In the
-// step that rule gains 0.03 ms of 9.2 (three alternating pairs, each in its favour); it is the default.
+// Block shape of the one-kernel route: TW = 2 tile groups (32 tiles, 4 waves, two blocks per CU), a ring of 3 stages.
+// Round 4 measured the alternatives (profiles/r04_fused_shapes.txt, tools/fused_micro.py): 64-tile blocks of 8 waves (TW = 4, one
+// block per CU) are 3 ... 5 % faster alone where the grid still fills the chip (conv1_2, conv2_2, conv3_2 at 480 x 480) and 50 %
+// slower where it does not; as a rule ("64-tile blocks from 200 blocks up") neutral in the 480 x 480 step (9.10 vs 9.10 ms) and
+// at 1024 x 1024, 2.5 % slower at 800 x 800 (21.7 vs 21.1 ms) -- not kept.  Rings of 4 and 5 stages (possible at one block per
+// CU) change nothing: the kernel does not wait for the latency of its staging DMA.
 struct FusedShape { int tw, ring; };
-static FusedShape fused_shape(long T, int N) {
-    // default: 64-tile blocks where they still fill the chip (>= 200 blocks of 8 waves on 256 CUs), else 32-tile blocks
-    static const FusedShape env = [] {
-        FusedShape f = {0, 0};
-        const char* e = getenv("WESUP_WINO_FUSED_SHAPE");
-        if (e && sscanf(e, "%d,%d", &f.tw, &f.ring) == 2 && (f.tw == 2 || f.tw == 4) && f.ring == 3) return f;
-        return FusedShape{0, 0};
-    }();
-    if (env.tw > 0) return env;
-    if (((T + 63) / 64) * (N / 64) >= 200) return FusedShape{4, 3};
-    return FusedShape{2, 3};
-}
+static FusedShape fused_shape(long, int) { return FusedShape{2, 3}; }
 template <int KC, int TW, int RING>
 static int fused_go(const FusedParams& p, dim3 grid, void* stream) {
     constexpr size_t ring = (size_t)RING * (16 * TW + 64) * 64 * sizeof(float);
@@ -402,7 +391,7 @@ static int fused_launch(const float* V, long plane_elems, const float* U, const 
     if (fs.tw == TW_ && fs.ring == RING_)                                                             \
         rc = K == 64 ? fused_go<1, TW_, RING_>(p, grid, stream)                                       \
            : K == 128 ? fused_go<2, TW_, RING_>(p, grid, stream) : fused_go<4, TW_, RING_>(p, grid, stream);
-    FUSED_CASE(2, 3) FUSED_CASE(4, 3)
+    FUSED_CASE(2, 3)
 #undef FUSED_CASE
     if (rc != WESUP_OK) return rc;
     WESUP_CHECK_LAUNCH();
