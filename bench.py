@@ -68,6 +68,8 @@ def parse_args(argv=None):
     ap.add_argument('--unfused-pool-bwd', action='store_true')
     ap.add_argument('--force-ddp', action='store_true', help='run the RCCL gradient all-reduce path even with one rank')
     ap.add_argument('--bucket-mb', type=int, default=16, help='gradient all-reduce bucket size')
+    ap.add_argument('--rccl-channels', type=int, default=0, help='A/B on a multi-GPU box: NCCL_MIN_NCHANNELS = NCCL_MAX_NCHANNELS = this '
+                    '(RCCL kernels occupy one workgroup per channel: the CUs they take from the step); 0 = RCCL\'s own choice')
     ap.add_argument('--rehearse-on-one-gpu', action='store_true',
                     help='multi-rank rehearsal on a one-GPU box: every rank uses cuda:0 and gloo carries the exchange '
                          '(RCCL refuses two ranks on one device); exercises the launch contract, not performance')
@@ -201,6 +203,15 @@ def stub_worker(args, rank, world):
 
 
 # --------------------------------------------------------------------------------------------- one rank
+def rccl_version():
+    try:
+        import torch
+        v = torch.cuda.nccl.version()
+        return '.'.join(str(x) for x in v) if isinstance(v, (tuple, list)) else str(v)
+    except Exception as e:       # a CPU rehearsal (gloo): no RCCL in the process
+        return f'unavailable ({type(e).__name__})'
+
+
 def worker(args):
     rank = int(os.environ.get('RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -228,6 +239,8 @@ def worker(args):
         os.environ.setdefault('MASTER_PORT', '29511')
         os.environ.setdefault('RANK', '0')
         os.environ.setdefault('WORLD_SIZE', '1')
+        if args.rccl_channels > 0:                    # read by RCCL when the communicator is created
+            os.environ['NCCL_MIN_NCHANNELS'] = os.environ['NCCL_MAX_NCHANNELS'] = str(args.rccl_channels)
         if args.rehearse_on_one_gpu:
             local_rank = 0
             torch.cuda.set_device(0)
@@ -638,7 +651,13 @@ def worker(args):
             out['rank_time'] = rank_time              # spread of the per-rank wall time of the timed region
             out['collective'] = {'backend': backend, 'ranks': dist.get_world_size(),
                                  'what': 'bucketed all-reduce(sum) of the flat fp32 gradient buffer, 1/world folded into SGD',
-                                 'bucket_mb': args.bucket_mb, 'exposed_ms': None, 'buckets': None}
+                                 'bucket_mb': args.bucket_mb, 'exposed_ms': None, 'buckets': None,
+                                 # what the first multi-GPU run has to be read against
+                                 'env': {k: os.environ.get(k) for k in ('GPU_MAX_HW_QUEUES', 'NCCL_MIN_NCHANNELS', 'NCCL_MAX_NCHANNELS',
+                                                                        'NCCL_ALGO', 'NCCL_PROTO', 'HSA_ENABLE_IPC_MODE_LEGACY')},
+                                 'rccl_version': rccl_version(),
+                                 'rank_ms_per_step': {'min': round(rank_time['min_s'] / args.steps * 1e3, 3),
+                                                      'max': round(rank_time['max_s'] / args.steps * 1e3, 3)}}
             if ddp_stats:
                 ex = sorted(st['exposed_ms'] for st in ddp_stats if 'exposed_ms' in st)
                 last = ddp_stats[-1]
