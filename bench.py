@@ -399,6 +399,9 @@ def worker(args):
     loss_last = trainer.tracker.history['loss'][-1]
     runner = trainer.step_runner()
     plan_stats = dict(runner.stats) if runner is not None else None      # iterations of warm-up + timed region by how they ran
+    if runner is not None and os.environ.get('WESUP_PLAN_DEBUG'):
+        import collections
+        print('[step plan] states', len(runner.states), collections.Counter((st.plan is not None, st.cand is not None, st.count, st.tries) for st in runner.states.values()), file=sys.stderr)
 
     # ---- untimed extras for the roofline report (every rank runs them so that collectives stay matched)
     iso, pool_ms = None, None
@@ -458,6 +461,9 @@ def worker(args):
             # how the warm-up + timed iterations were issued (wesup_amd/runner.py): walked in Python ('eager'; the first two of a
             # shape and every event-carrying one), walked and recorded, or replayed from the recorded step plan
             'step_plan': plan_stats,
+            'memory': {'peak_allocated_gib': round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 2),
+                       'reserved_gib': round(torch.cuda.memory_reserved(dev) / 2 ** 30, 2),
+                       'cached_buffer_sets': len(trainer.model.engine._bufs)},
         }
         if args.end_to_end:
             out['config']['workload'] = ('END-TO-END (second line, not the headline): decoded uint8 batch resident in HBM -> wesup_augment '

@@ -139,3 +139,32 @@ def test_general_path_still_serves_what_the_runner_does_not_cover():
     t.model.train(); t.tracker.train()
     t.train_one_iteration('train', img, pix, pts, labs)
     assert t.step_runner().stats['eager'] == 1
+
+
+def test_interleaved_shapes_each_get_a_plan_and_keep_it():
+    """Multi-scale training (models/wesup.py:178, utils/data.py:98-101): shapes come interleaved.  A shape's plan depends on ITS
+    buffer set and on the shared workspaces only -- other shapes' buffers being created while it waits for the twin of its first
+    recording must neither block the second recording nor drop a sealed plan; a workspace that grew (a larger shape arrived)
+    drops the plans, and they come back.  Results stay bit-identical to a trainer that never replays."""
+    from oracle import wesup_oracle as orc
+    dev = torch.device('cuda:0')
+    weights = orc.make_weights(11, feat_scale=0.05)
+    shapes = [(1, 48, 64, 4), (1, 64, 48, 4), (1, 40, 56, 3)]
+    data = [_batches(1, *s, dev)[0] for s in shapes]
+    a = _trainer(weights, max_superpixels=16, step_plan=False)
+    b = _trainer(weights, max_superpixels=16)
+    order = [0, 1, 0, 1, 0, 2, 1, 0, 2, 1, 0, 2, 1, 2, 0, 1, 2, 0, 1, 2, 0, 1, 2]
+    for k, i in enumerate(order):
+        a.train_one_iteration('train', *data[i])
+        b.train_one_iteration('train', *data[i])
+        assert torch.equal(_flat(a), _flat(b)), k
+    r = b.step_runner()
+    assert len(r.states) == 3 and all(st.plan is not None for st in r.states.values()), r.stats
+    from wesup_amd import ops
+    ops.ws_generation += 1                   # what a workspace that had to grow does (ops.workspace): every recorded address is stale
+    for k, i in enumerate([0, 1, 2] * 5):
+        a.train_one_iteration('train', *data[i])
+        b.train_one_iteration('train', *data[i])
+        assert torch.equal(_flat(a), _flat(b)), k
+    assert all(st.plan is not None for st in r.states.values()), r.stats
+    assert r.stats['dropped'] >= 3

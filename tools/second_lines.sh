@@ -1,5 +1,5 @@
 # The second bench lines of a round (never the headline), one gpurun call:  bash tools/second_lines.sh r04
-#   end-to-end (+ its rocprofv3 --stats), multi-scale rotation (replay / Python walk / more shapes than plan states),
+#   end-to-end (+ its rocprofv3 --stats), multi-scale rotations (12 shapes replayed / walked; 200 draws steady state / cold),
 #   batch 1 (+ stats) and batch 2, walk vs replay at batch 4, wesup_slic alone.  Results under gpurun_out/lines/.
 set -o pipefail
 R=${1:-r04}
@@ -10,7 +10,8 @@ b() { local out=$1; shift; timeout -k 10 300 python3 bench.py --no-cpu-baseline 
 b ${R}_e2e_bench_line --end-to-end --steps 40 --warmup 10
 b ${R}_multiscale_bench_line --multiscale 12 --no-kernel-timing --steps 120 --warmup 60
 b ${R}_multiscale_walk_bench_line --multiscale 12 --no-kernel-timing --steps 120 --warmup 60 --no-step-plan
-b ${R}_multiscale64_bench_line --multiscale 64 --no-kernel-timing --steps 128 --warmup 64
+b ${R}_multiscale200_bench_line --multiscale 200 --no-kernel-timing --steps 200 --warmup 1000     # ~94 distinct shapes, steady state
+b ${R}_multiscale200_cold_bench_line --multiscale 200 --no-kernel-timing --steps 200 --warmup 0   # every shape for the first time
 b ${R}_b1_bench_line --batch 1 --steps 60 --warmup 10
 b ${R}_b1_walk_bench_line --batch 1 --no-kernel-timing --steps 60 --warmup 10 --no-step-plan
 b ${R}_b2_bench_line --batch 2 --steps 60 --warmup 10

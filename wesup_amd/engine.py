@@ -134,7 +134,7 @@ class WesupEngine:
         # pixel).  Large shapes: the training and the validation shape (two 4 x 480^2 sets are 1.8 M pixels, two 8 x 1024^2
         # sets 16.8 M: the second evicts the first).  Small multi-scale crops (batch 1 at 0.3-0.4 x 775x522: ~50 K pixels each)
         # stay until the shape bound, so a shape that comes back finds its buffers -- and its recorded step plan -- again.
-        self.max_cached_shapes = 16
+        self.max_cached_shapes = 256
         self.max_cached_pixels = 10 * 1024 * 1024
         self._last = None                # buffers of the most recent forward (feature_maps() reads these)
         self.frozen = set()              # names of parameters with requires_grad=False (set by WESUP.forward)
@@ -190,7 +190,7 @@ class WesupEngine:
         self.timer = KernelTimer()
         self.on_grads_ready = None       # callback(names) for the data-parallel layer
         self._rot = 0
-        self.buf_generation = 0          # bumped when a buffer set is created or evicted (a recorded step plan holds addresses)
+        self.buf_generation = 0          # counts buffer sets ever created: a set's `gen` (a recorded step plan holds ITS addresses)
 
     # ------------------------------------------------------------------ streams
     # Ordering edges between the three streams go through the library's event pool (ops.sync_record / sync_wait: slots of a
@@ -267,7 +267,6 @@ class WesupEngine:
             # images of varying size meets a new shape almost every call; every entry is a full set of activation and
             # gradient buffers (~0.6 GB per 480x480 image in training), so only the most recent shapes are kept and the
             # evicted buffers go back to torch's caching allocator, which hands their blocks to the next shape.
-            self.buf_generation += 1
             px = lambda k: k[0] * k[1] * k[2]
             while self._bufs and (len(self._bufs) >= max(1, self.max_cached_shapes)
                                   or sum(px(k) for k in self._bufs) + px(key) > self.max_cached_pixels):
@@ -280,6 +279,8 @@ class WesupEngine:
         f32 = dict(dtype=torch.float32, device=dev)
         if b is None:
             b = _Bufs()
+            self.buf_generation += 1
+            b.gen = self.buf_generation
             b.x0 = torch.empty(B, H, W, 4, **f32)
             b.y, b.yp, b.s, b.dims, b.yr, b.yr_wanted = [], [], [], [], [], []
             b.V = [None] * 13            # Winograd-transformed layer inputs (training forward), allocated on first use
@@ -383,8 +384,16 @@ class WesupEngine:
         return (self.commute_side and self.fuse_pool_fwd and self.fuse_pool_bwd
                 and b.group_of[l] is None)
 
+    def bufs_gen(self, B, H, W, Kmax):
+        """The identity of the cached buffer set of a shape (None: not cached), marking it most recently used: what a
+        recorded step plan of that shape depends on -- other shapes' sets coming and going do not move its addresses."""
+        b = self._bufs.get((B, H, W, Kmax))
+        if b is None:
+            return None
+        self._bufs.move_to_end((B, H, W, Kmax))
+        return b.gen
+
     def release_buffers(self):
-        self.buf_generation += 1
         self._bufs.clear()
         self._last = None
         self.ctx = None

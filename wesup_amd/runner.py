@@ -35,7 +35,7 @@ from .utils import metrics as M
 RB_SLOT = 40          # event slot of the read-back copy (the engine uses 0 .. 27 and 64 ..)
 RECORD_AT = 2         # eager iterations of a shape before the first recording
 MAX_RECORD_TRIES = 4
-MAX_STATES = 16       # shapes with a state (inputs, read-back block, plan) of their own, least recently used first out
+MAX_STATES = 256      # shapes with a state (inputs, read-back block, plan) of their own, least recently used first out
 
 
 class _Plan:
@@ -127,7 +127,8 @@ class StepRunner:
     def _signature(self, eng):
         t, o = self.t, self.t.optimizer
         g = o.param_groups[0]
-        sw = tuple(sorted((k, v) for k, v in vars(eng).items() if isinstance(v, (bool, int, type(None))) and not k.startswith('_')))
+        sw = tuple(sorted((k, v) for k, v in vars(eng).items() if isinstance(v, (bool, int, type(None))) and not k.startswith('_')
+                          and k not in ('buf_generation', 'max_cached_shapes', 'max_cached_pixels')))
         red = t.reducer
         return (sw, eng.route_fn, type(eng).WINOGRAD_CONV_MIN_CI, type(eng).WINOGRAD_TILE, tuple(sorted(eng._diag_skip)),
                 ops.STREAMK_FWD, ops.STREAMK_DGRAD, ops.STREAMK_GEMM, ops.STREAMK,
@@ -173,7 +174,7 @@ class StepRunner:
 
         timing = eng.timer.enabled or (t.reducer is not None and t.reducer.profile)
         sig = self._signature(eng) if self.replay else None
-        gens = (ops.ws_generation, eng.buf_generation)
+        gens = (ops.ws_generation, eng.bufs_gen(B, H, W, st.y_all.shape[1]))
         if st.plan is not None and (st.sig != sig or st.gens != gens):
             st.plan = st.cand = None
             st.count = 0
@@ -183,18 +184,19 @@ class StepRunner:
             host = self._replay(st, metrics)
             self.stats['replayed'] += 1
         else:
-            record = (self.replay and not timing and st.count >= RECORD_AT and st.tries < MAX_RECORD_TRIES
-                      and (st.cand is None or (st.sig == sig)))
+            if st.cand is not None and st.sig != sig:       # settings changed since the first recording: it has no twin to wait for
+                st.cand = None
+            record = self.replay and not timing and st.count >= RECORD_AT and st.tries < MAX_RECORD_TRIES
             plan = _Plan() if record else None
             host = self._walk(st, metrics, want_seg, plan)
             st.count += 1
             if plan is not None:
                 self.stats['recorded'] += 1
-                gens = (ops.ws_generation, eng.buf_generation)
+                gens = (ops.ws_generation, eng.bufs_gen(B, H, W, st.y_all.shape[1]))
                 if st.cand is not None and st.gens == gens and _lib.load().wesup_plan_diff(st.cand.h, plan.h) == 0:
                     st.plan, st.cand = plan, None
                 else:
-                    if st.cand is not None:
+                    if st.cand is not None and st.gens == gens:      # (a workspace that grew in between is nobody's failure)
                         st.tries += 1
                         if os.environ.get('WESUP_PLAN_DEBUG'):
                             k = _lib.load().wesup_plan_diff(st.cand.h, plan.h)
