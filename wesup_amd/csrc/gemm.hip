@@ -7,7 +7,7 @@
 //
 // Operand staging is LDS-DMA (buffer_load_dwordx4 ... lds; global_load_lds_dwordx4 for the image layer): a
 // wave-instruction copies 64 x 16 B from per-lane addresses straight into 1 KiB of LDS, no staging registers and
-// no ds_write.  tools/mfma_ingredients.hip
+// no ds_write.  round-2 probe mfma_ingredients.hip, tools/README.md
 // measured why: with register staging hipcc either waits for the loads in front of the MFMA phase or sinks them
 // behind it (100-124 TFLOP/s for the bare loop); with LDS-DMA the only wait is the vmcnt(0) that __syncthreads()
 // emits, exactly at the end of the K-step (128-137 TFLOP/s).
@@ -17,7 +17,7 @@
 //   * a lane whose element is outside the image / matrix is given an out-of-range buffer offset and the DMA writes
 //     zeros for it (implicit zero padding; the 64-bit global form of the image layer reads a zeroed page instead);
 //   * ReLU of the previous layer is applied to the fragments after the ds_read (compile-time kernel variant).
-// What the loops cost and why they look the way they do: DESIGN.md 3.1 and 6 (tools/gemm_lab.hip).
+// What the loops cost and why they look the way they do: DESIGN.md 3.1 and 6 (round-2 probe gemm_lab.hip, tools/README.md).
 #include "common.hpp"
 #include "ldsdma.hpp"
 #include <cstdlib>
@@ -245,7 +245,7 @@ __global__ __launch_bounds__(NW * 64, MINB) void gemm_nt_kernel(const NtParams p
             for (int j = 0; j < WN; ++j) fb[sl][j] = ld4(bs + 32 * j * BK + cb);
         };
         load_frag(0, 0);
-        // (issuing one staging part per MFMA group instead was measured 3-4 % slower: tools/gemm_trace.py)
+        // (issuing one staging part per MFMA group instead was measured 3-4 % slower: round-2 probe gemm_trace.py, tools/README.md)
         if (kk + 1 < ke) stage(kk + 1, cur ^ 1);
 #pragma unroll
         for (int g = 0; g < BK / 8; ++g) {
@@ -455,7 +455,7 @@ __global__ __launch_bounds__(256) void nt_fixup_kernel(const NtParams p) {
 // run in lock step behind one barrier, so every tile of a round ends at the same time and the stream-K tail starts
 // level on all CUs (with two independent 128x128 blocks per CU the older block of a pair wins the MFMA arbitration and
 // finishes a 72-step tile ~100 us before its partner, which leaves the end of the launch ragged); a quarter less
-// operand traffic per FLOP comes with it.  tools/gemm_lab.hip: +2-4 % over the 2-blocks-per-CU form on whole rounds.
+// operand traffic per FLOP comes with it.  round-2 probe gemm_lab.hip, tools/README.md: +2-4 % over the 2-blocks-per-CU form on whole rounds.
 // STD: 128x128, 4 waves, two blocks per CU.
 enum NtShape { NT_BIG = 0, NT_STD = 1, NT_N64 = 2, NT_SMALL = 3 };
 
@@ -765,7 +765,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnParams p) {
     const int m_blk = tile_m * BM, n_blk = tile_n * BN;
     // K range of this split.  A grid of at most 512 blocks is dispatched as "blocks 0..255 one per CU, blocks 256.. into
     // the second slot of each CU", and of the two blocks that share a CU the one that arrived first wins the MFMA
-    // arbitration (tools/tn_trace.py: with equal ranges the first blocks end at 500 us, their partners at 657 us, the
+    // arbitration (round-2 probe tn_trace.py, tools/README.md: with equal ranges the first blocks end at 500 us, their partners at 657 us, the
     // last quarter of the launch running one block per CU at two thirds of the pipe).  So the ranges are weighted:
     // a block of the first 256 gets w_old K-steps for every w_young of a later one, every tile's splits still
     // partition [0, K) exactly, and the pairs end together.  Static, so the summation order stays fixed.

@@ -22,8 +22,8 @@ __device__ __forceinline__ void glds16(const float* src, unsigned lds_byte_addr_
 // supplies one 32-bit byte offset and the K-step adds a scalar offset, so a staging instruction needs no vector
 // address arithmetic at all (the 64-bit global form needed an add-with-carry and two selects per instruction), and
 // a lane whose offset is >= num_records gets ZEROS written to LDS -- implicit zero padding without a zero page
-// (tools/bufdma_probe.hip: out-of-range lanes store 0, the scalar offset takes part in the range check).
-// tools/gemm_lab.hip: +2.4 % on the 128x128 two-blocks-per-CU loop.
+// (round-2 probe bufdma_probe.hip, tools/README.md: out-of-range lanes store 0, the scalar offset takes part in the range check).
+// round-2 probe gemm_lab.hip, tools/README.md: +2.4 % on the 128x128 two-blocks-per-CU loop.
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 #define WESUP_OOB 0x80000000u            // per-lane offset of a masked lane; every descriptor has num_records <= 2 GiB
 __device__ __forceinline__ i32x4 make_srd(const float* base, unsigned num_records = WESUP_OOB) {
