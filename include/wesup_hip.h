@@ -240,7 +240,11 @@ int wesup_winograd_gemm_output_transform_ex(const float* V, long plane_elems, co
                                             int B, int H, int W, int K, int N, int accumulate, void* stream);
 /* wesup_conv3x3_dgrad_winograd(accumulate = 1) resp. wesup_conv3x3_dgrad_winograd_unpool (unpool_src given; dx is then
  * (B,Hu,Wu,Cin)) with that gather in the epilogue instead of a materialised side-branch gradient in dx.  m = 4; product shapes
- * with wesup_winograd_fused_supported(Cout, Cin, 4) == 2, otherwise WESUP_ERR_INVALID (materialise, use the forms above). */
+ * with wesup_winograd_fused_supported(Cout, Cin, 4) == 2, otherwise WESUP_ERR_INVALID (materialise, use the forms above).
+ * area_new == NULL (here and in the two gather entries above): the rows of `side` are divided by their areas already --
+ * wesup_scale_rows_by_area(side, area_new, B * Kmax, Cin): x[row][:] *= 1 / area[row] (0 where area is 0) -- so the epilogue
+ * gathers one row per pixel and nothing else (conv1_2's input gradient alone 387 -> 349 us at configs[1]). */
+int wesup_scale_rows_by_area(float* x, const int32_t* area, long rows, int C, void* stream);
 int wesup_conv3x3_dgrad_winograd_gather(const float* dy, const float* u_dgrad, const float* mask_src,
                                         const float* unpool_src, float* dx, const float* side, const int32_t* new_row,
                                         const int32_t* area_new, int Kmax, int B, int H, int W, int Hu, int Wu,

@@ -94,6 +94,7 @@ def test_winograd_host_side_queries_and_argument_checks(lib):
         assert h.wesup_winograd_filter_grad(None, 0, 0, 1, None, None, 64, 64, m, None) == -1
         assert h.wesup_winograd_pack_weight(None, None, None, 64, 64, m, None) == -1
     assert h.wesup_gemm_nt_batched(None, 0, 0, None, 0, 0, None, 0, 0, 16, 128, 128, 32, None) == -1
+    assert h.wesup_scale_rows_by_area(None, None, 4, 64, None) == -1
     # the bias gradient of the F(4x4) weight gradient is summed inside the outgrad transform: per-block rows + colsum workspace
     assert h.wesup_winograd_outgrad_workspace_bytes(4, 60, 60, 512, 2) == 0
     blocks = -(-4 * 15 * 15 * 128 // 256)

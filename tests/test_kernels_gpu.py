@@ -480,6 +480,17 @@ def test_conv3x3_dgrad_winograd_with_the_side_gradient_gathered_in_the_epilogue(
     ops.conv3x3_dgrad_winograd_gather(dy, ud, side, m.new_row, m.area_new, out=again, mask_src=None if pooled else ypre,
                                       unpool_src=ypre if pooled else None, timer=_T())
     assert torch.equal(again, got)
+    # the side rows divided by their areas beforehand (scale_rows_by_area; area_new = None): the same coefficient applied once
+    # per row instead of once per pixel -- one rounding more per element (the product is no longer fused into the sum)
+    scaled = ops.scale_rows_by_area(side.clone(), m.area_new)
+    ref_rows = side / m.area_new.clamp(min=1).unsqueeze(-1).float()
+    live = (m.area_new > 0).unsqueeze(-1)
+    assert torch.equal(scaled[live.expand_as(scaled)], (side * (1.0 / m.area_new.clamp(min=1).float()).unsqueeze(-1))[live.expand_as(scaled)])
+    assert float((scaled - torch.where(live, ref_rows, torch.zeros_like(ref_rows))).abs().max()) <= 1e-6 * float(ref_rows.abs().max())
+    pre = torch.full_like(got, float('nan'))
+    ops.conv3x3_dgrad_winograd_gather(dy, ud, scaled, m.new_row, None, out=pre, mask_src=None if pooled else ypre,
+                                      unpool_src=ypre if pooled else None)
+    assert float((pre - got).abs().max()) <= 2e-6 * float(got.abs().max())
 
 
 @pytest.mark.parametrize('B,H,W,Cin,Cout', [(2, 24, 16, 64, 64), (1, 37, 41, 64, 128), (1, 13, 9, 256, 512), (3, 8, 8, 512, 512)])

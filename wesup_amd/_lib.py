@@ -33,6 +33,7 @@ _SIGS = {
     'wesup_pack_conv3x3_weight': (c_int, 'pppiip'),
     'wesup_transpose': (c_int, 'ppiip'),
     'wesup_transpose_batched': (c_int, 'pip'),
+    'wesup_scale_rows_by_area': (c_int, 'pplip'),
     'wesup_conv3x3_workspace_bytes': (c_size_t, 'iiiii'),
     'wesup_conv3x3_fwd': (c_int, 'pppppiiiiiipzp'),
     'wesup_conv3x3_fwd_side': (c_int, 'ppppppppiiiiiiip'),

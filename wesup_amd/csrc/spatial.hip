@@ -568,3 +568,23 @@ extern "C" int wesup_upsample_bwd(const float* dfm_or_g, const int32_t* new_row,
     WESUP_CHECK_LAUNCH();
     return WESUP_OK;
 }
+
+// x [rows][C] *= 1 / area[row] (0 for a row of area 0: padded superpixel rows, which no pixel refers to).  The side-branch
+// gradient rows a gather epilogue reads (wesup_conv3x3_dgrad_winograd_gather with area_new == NULL) are scaled here once per
+// row instead of once per pixel and channel quad there -- with the same coefficient, 1.f / (float)area.
+__global__ __launch_bounds__(256) void scale_rows_kernel(float* __restrict__ x, const int32_t* __restrict__ area, long total, int Q) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int a = area[i / Q];
+    const float coef = a > 0 ? 1.f / (float)a : 0.f;
+    float4 v = ld4(x + 4 * i);
+    v.x *= coef; v.y *= coef; v.z *= coef; v.w *= coef;
+    st4(x + 4 * i, v);
+}
+extern "C" int wesup_scale_rows_by_area(float* x, const int32_t* area, long rows, int C, void* stream) {
+    if (!x || !area || rows <= 0 || C <= 0 || (C % 4) || (((uintptr_t)x) & 15)) return WESUP_ERR_INVALID;
+    const long total = rows * (C / 4);
+    WESUP_LAUNCH(scale_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, area, total, C / 4);
+    WESUP_CHECK_LAUNCH();
+    return WESUP_OK;
+}

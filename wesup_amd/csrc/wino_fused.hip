@@ -424,7 +424,7 @@ extern "C" int wesup_winograd_gemm_output_transform_ex(const float* V, long plan
     if (unpool && (!unpool_dst || Hu / 2 != H || Wu / 2 != W)) return WESUP_ERR_INVALID;
     WinoGather gat = {nullptr, nullptr, nullptr, 0, 0, 0};
     if (side) {
-        if (!new_row || !area_new || Kmax <= 0 || accumulate || bias || y_pool || (((uintptr_t)side) & 15)) return WESUP_ERR_INVALID;
+        if (!new_row || Kmax <= 0 || accumulate || bias || y_pool || (((uintptr_t)side) & 15)) return WESUP_ERR_INVALID;
         if (unpool && ((Hu & 1) || (Wu & 1))) return WESUP_ERR_INVALID;
         gat = WinoGather{side, new_row, area_new, Kmax, 0, unpool ? (long)Hu * Wu : (long)H * W};
     }
@@ -440,7 +440,7 @@ extern "C" int wesup_winograd_gemm_output_transform_gather(const float* V, long 
                                                            float* y, const float* unpool_src, int Hu, int Wu, const float* side,
                                                            const int32_t* new_row, const int32_t* area_new, int Kmax, int B,
                                                            int H, int W, int K, int N, void* stream) {
-    if (!side || !new_row || !area_new || Kmax <= 0 || !y || (((uintptr_t)side) & 15)) return WESUP_ERR_INVALID;
+    if (!side || !new_row || Kmax <= 0 || !y || (((uintptr_t)side) & 15)) return WESUP_ERR_INVALID;      // (area_new NULL: rows pre-scaled)
     if (unpool_src && ((Hu & 1) || (Wu & 1))) return WESUP_ERR_INVALID;
     const WinoGather gat = {side, new_row, area_new, Kmax, 0, unpool_src ? (long)Hu * Wu : (long)H * W};
     const FusedBits nobits = {nullptr, nullptr, nullptr};

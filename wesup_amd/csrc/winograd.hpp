@@ -71,7 +71,8 @@ __device__ __forceinline__ void wino_unpool_add(const WinoUnpool& u, const unsig
 
 // The side-branch gradient of a native-resolution layer as a gather (commuted side branch, engine.py: the side conv sits
 // behind the superpixel mean, so that gradient is constant over a superpixel): side [B][Kmax][C] rows per superpixel,
-// row [B][H*W] the pixel's superpixel row, area [B][Kmax].  value(b, pix) = side[b][row[b][pix]][.] / area[b][row[b][pix]]
+// row [B][H*W] the pixel's superpixel row, area [B][Kmax].  value(b, pix) = side[b][row[b][pix]][.] / area[b][row[b][pix]];
+// area == NULL: the rows of side are divided already (wesup_scale_rows_by_area) -- one dependent load and a reciprocal less per pixel
 // -- what wesup_upsample_bwd writes for such a layer, read here by the epilogue that would otherwise accumulate into it.
 struct WinoGather {
     const float* src;    // NULL: no gather
@@ -83,7 +84,7 @@ struct WinoGather {
 };
 __device__ __forceinline__ float4 wino_gather(const WinoGather& g, int b, long pix, int C, int c0) {
     const int r = g.row[(long)b * g.HW + pix];
-    const float coef = 1.f / (float)g.area[(long)b * g.Kmax + r];
+    const float coef = g.area ? 1.f / (float)g.area[(long)b * g.Kmax + r] : 1.f;
     const float4 t = ld4(g.src + ((long)b * g.Kmax + r) * C + c0);
     return make_float4(coef * t.x, coef * t.y, coef * t.z, coef * t.w);
 }

@@ -769,6 +769,8 @@ class WesupEngine:
                     b.dybar[l] = torch.empty(B, Kmax, co, dtype=torch.float32, device=self.device)
                 tok = T.begin('side_bwd')
                 ops.gemm_nt(gsp2d[:, off:off + co // 2], pk.sideT[l], None, out=b.dybar[l].view(R, co))
+                if gat[l]:      # gathered per pixel by the epilogue of layer l + 1's input gradient: rows divided by their areas here, once
+                    ops.scale_rows_by_area(b.dybar[l], meta.area_new)
                 T.end(tok, 2.0 * R * co * (co // 2))
             tok = T.begin('upsample_bwd')
             if (h, w) == (H, W) or sum(CONV_CH[l][1] for l in ls) > 768:
@@ -984,7 +986,7 @@ class WesupEngine:
                 pcode = b.pcode[l - 1] if (self.compact_masks and b.pcode_ok[l - 1]) else None
                 if gat[l - 1]:
                     pooled = POOL_AFTER[l - 1]
-                    ops.conv3x3_dgrad_winograd_gather(b.G[l], pk.ud[l], b.dybar[l - 1], meta.new_row, meta.area_new, out=b.G[l - 1],
+                    ops.conv3x3_dgrad_winograd_gather(b.G[l], pk.ud[l], b.dybar[l - 1], meta.new_row, None, out=b.G[l - 1],
                                                       mask_src=None if pooled else b.y[l - 1],
                                                       unpool_src=b.y[l - 1] if pooled else None, ws_tag='wino_main', timer=T,
                                                       mask_bits=None if pooled else mbits, unpool_code=pcode if pooled else None,

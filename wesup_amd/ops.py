@@ -192,6 +192,15 @@ def transpose_batched(pairs):
 
 
 # ---------------------------------------------------------------- sync edges / step plans (csrc/plan.hip)
+def scale_rows_by_area(x, area):
+    """x (B,Kmax,C) *= 1 / area (B,Kmax) per row, in place (0 for rows of area 0): the pre-scaled form of the side-branch gradient
+    rows that conv3x3_dgrad_winograd_gather(area_new=None) gathers."""
+    _chk(x, name='x'); _chk(area, torch.int32, 'area')
+    assert x.dim() == 3 and area.shape == x.shape[:2]
+    _lib.call('wesup_scale_rows_by_area', _p(x), _p(area), x.shape[0] * x.shape[1], x.shape[2], _stream())
+    return x
+
+
 def sync_record(slot, stream=None):
     """Mark the work queued so far on ``stream`` (raw handle; None: torch's current stream) in event slot ``slot``."""
     _lib.call('wesup_sync_record', int(slot), _stream() if stream is None else ctypes.c_void_p(stream))
@@ -683,11 +692,13 @@ def conv3x3_dgrad_winograd_gather(dy, u_dgrad, side, new_row, area_new, out, mas
     a native-resolution layer): out is written, never read.  m = 4, shapes of the one-kernel product route only."""
     for t, n in ((dy, 'dy'), (u_dgrad, 'u_dgrad'), (side, 'side'), (out, 'out')):
         _chk(t, name=n)
-    _chk(new_row, torch.int32, 'new_row'); _chk(area_new, torch.int32, 'area_new')
+    _chk(new_row, torch.int32, 'new_row')
+    if area_new is not None:       # None: the rows of side are divided by their areas already (scale_rows_by_area)
+        _chk(area_new, torch.int32, 'area_new')
     B, H, W, Cout = dy.shape
     Cin = u_dgrad.shape[1]
     Kmax = side.shape[1]
-    assert u_dgrad.shape == (36, Cin, Cout) and side.shape == (B, Kmax, Cin) and area_new.shape == (B, Kmax)
+    assert u_dgrad.shape == (36, Cin, Cout) and side.shape == (B, Kmax, Cin) and (area_new is None or area_new.shape == (B, Kmax))
     Hu = Wu = 0
     if unpool_src is not None or unpool_code is not None:
         _, Hu, Wu, _ = out.shape
