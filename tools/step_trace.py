@@ -1,7 +1,13 @@
 """Kernel-by-kernel durations of ONE training step (single-stream schedule) from a rocprofv3 kernel trace.
 
-  rocprofv3 --kernel-trace --output-format csv -d gpurun_out/trace -- python3 tools/step_trace.py run
+  rocprofv3 --kernel-trace --output-format csv -d gpurun_out/trace -- python3 tools/step_trace.py run [multi]
   python3 tools/step_trace.py report gpurun_out/trace > gpurun_out/step_trace.txt
+On the GPU box (one gpurun call; `multi` = the three-stream schedule, WESUP_TRACE_BATCH = images per step, WESUP_TRACE_SKIP =
+launch classes left out, timing only):
+  cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" && export GPU_MAX_HW_QUEUES=6 WESUP_TRACE_BATCH=1 &&
+  rocprofv3 --kernel-trace --output-format csv -d gpurun_out/trace -- python3 tools/step_trace.py run multi > gpurun_out/trace.log 2>&1 &&
+  python3 tools/step_trace.py report gpurun_out/trace > gpurun_out/step_trace_b1.txt
+(A caution, DESIGN.md 6 round 4: the tracer stretches cross-queue waits of short kernels; compare gaps with untraced A/B runs.)
 """
 import sys, os, glob, csv, re
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
