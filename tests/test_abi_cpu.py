@@ -123,3 +123,16 @@ def test_step_plan_object_without_a_gpu(lib):
     assert h.wesup_sync_slots() >= 64
     assert h.wesup_plan_destroy(a) == 0 and h.wesup_plan_destroy(b) == 0
     assert h.wesup_winograd_pack_weights(None, 0, None) == -1 and h.wesup_transpose_batched(None, 3, None) == -1
+
+
+def test_driver_build_entry_runs():
+    """__graft_entry__.build() is what the driver calls on the CPU box every round: it must compile, load the library and agree
+    with it about the ABI version (it asserted a stale version for most of round 4 while every other test was green)."""
+    import importlib
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    g = importlib.import_module('__graft_entry__')
+    g.build()
