@@ -191,7 +191,6 @@ def transpose_batched(pairs):
     _lib.call('wesup_transpose_batched', ctypes.cast(arr, ctypes.c_void_p), n, _stream())
 
 
-# ---------------------------------------------------------------- sync edges / step plans (csrc/plan.hip)
 def scale_rows_by_area(x, area):
     """x (B,Kmax,C) *= 1 / area (B,Kmax) per row, in place (0 for rows of area 0): the pre-scaled form of the side-branch gradient
     rows that conv3x3_dgrad_winograd_gather(area_new=None) gathers."""
@@ -201,6 +200,7 @@ def scale_rows_by_area(x, area):
     return x
 
 
+# ---------------------------------------------------------------- sync edges / step plans (csrc/plan.hip)
 def sync_record(slot, stream=None):
     """Mark the work queued so far on ``stream`` (raw handle; None: torch's current stream) in event slot ``slot``."""
     _lib.call('wesup_sync_record', int(slot), _stream() if stream is None else ctypes.c_void_p(stream))
