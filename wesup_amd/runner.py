@@ -164,12 +164,15 @@ class StepRunner:
         if t.reducer is not None:
             t.reducer.reset()                         # nothing may be left over from an iteration that raised
         # ---- inputs into the state's buffers (dtype conversions ride in the copies)
+        # The conv chain needs the image only; label map and masks are read by the side stream (superpixel preprocessing, metrics):
+        # their copies go there, behind whatever the caller's stream has queued so far (it may have produced them).
         st.img.copy_(img, non_blocking=True)
-        st.labels.copy_(seg, non_blocking=True)
-        if mask is not None:
-            st.mask.copy_(mask, non_blocking=True)
-        if want_seg:
-            st.gt.copy_(pixel_mask, non_blocking=True)
+        with eng.side_stream():
+            st.labels.copy_(seg, non_blocking=True)
+            if mask is not None:
+                st.mask.copy_(mask, non_blocking=True)
+            if want_seg:
+                st.gt.copy_(pixel_mask, non_blocking=True)
         st.n_sp_host = counts
 
         timing = eng.timer.enabled or (t.reducer is not None and t.reducer.profile)
