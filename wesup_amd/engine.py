@@ -437,10 +437,17 @@ class WesupEngine:
         pk.wino = wino
         # ~40 launch-latency-bound repack kernels go to the side stream (idle at this point) and are joined in front of
         # the first convolution; the trainer queues them before the superpixel preprocessing (prefetch_weights)
+        # conv1_1's own panel (a 5 us kernel) on the caller's stream, in front of the first convolution: the side stream starts
+        # the step with the label / mask copies of the step runner, and the chain would wait for them with it
+        first_here = not wino[0]
+        if first_here:
+            ops.pack_conv3x3_weight(self.p[f'backbone.{CONV_IDX[0]}.weight'], pk.wf[0], None, need_dgrad=False)
         with self._OnSide(self):
             pk.ready0 = pk.ready = False
             fwd4, dg4 = [], []                     # F(4x4) layers: one launch for the forward filters, one for the rotated ones
-            for l, idx in enumerate(CONV_IDX):     # forward panels first: conv1_1 only waits for its own
+            for l, idx in enumerate(CONV_IDX):
+                if l == 0 and first_here:
+                    continue
                 m = wino[l]
                 w = self.p[f'backbone.{idx}.weight']
                 if m:
