@@ -57,7 +57,7 @@ else:
     ev = []
     for r in step:
         n = r['Kernel_Name']
-        mf = ('gemm_nt_kernel' in n) or ('gemm_tn_kernel' in n)
+        mf = ('gemm_nt_kernel' in n) or ('gemm_tn_kernel' in n) or ('wino4_gemm_out_kernel' in n)
         ev.append((int(r['Start_Timestamp']), 1, mf))
         ev.append((int(r['End_Timestamp']), -1, mf))
     ev.sort()
