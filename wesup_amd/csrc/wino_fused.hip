@@ -229,8 +229,53 @@ __global__ __launch_bounds__(128 * TW, 2) void wino4_gemm_out_kernel(const Fused
                         smem[(16 * wa + 4 * kq + r) * ES + (4 * i2 + jj) * 64 + 32 * wb + 16 * j + l15] = Y[2 * ip + i2][jj][j][r];
         __syncthreads();
         const int i = 2 * ip + (slot >> 2), jj = slot & 3;
+        // The y forms that READ something per pixel (sign bits, the old gradient, a gathered side-gradient row): four pixels at a
+        // time, every load of a level issued before the first use -- out-of-image pixels are clamped and predicated instead of
+        // skipped, so that nothing divergent stands between the loads.
+        const bool batched = !up.dst && !p.mask && !(p.gat.src && p.gat.area) && (p.mask_bits || p.accum || p.gat.src);
+        if (batched) {
+#pragma unroll 1
+            for (int it0 = 0; it0 < 16; it0 += 4) {
+                long off[4]; bool ok[4]; unsigned mb[4]; float4 old[4]; int row[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int tl = (NW / 2) * (it0 + k) + tsel;
+                    long tile = (long)t0 + tl;
+                    ok[k] = tile < p.T;
+                    tile = ok[k] ? tile : p.T - 1;
+                    const int bi = fast_div((int)tile, p.dTw);
+                    const int tj = (int)tile - bi * p.Tw;
+                    const int b = fast_div(bi, p.dTh);
+                    const int ti = bi - b * p.Th;
+                    int h = 4 * ti + i, w = 4 * tj + jj;
+                    ok[k] = ok[k] && h < p.H && w < p.W;
+                    h = min(h, p.H - 1); w = min(w, p.W - 1);
+                    const long pix = ((long)b * p.H + h) * p.W + w;
+                    off[k] = pix * p.N + n0 + 4 * q4;
+                    mb[k] = p.mask_bits ? p.mask_bits[pix * (p.N >> 2) + (n0 >> 2) + q4] : 15u;
+                    old[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    row[k] = 0;
+                    if (p.gat.src) row[k] = p.gat.row[pix] + b * p.gat.Kmax;       // (pix = b * HW + the pixel of image b)
+                    else if (p.accum) old[k] = ld4(p.y + off[k]);
+                }
+                if (p.gat.src) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) old[k] = ld4(p.gat.src + (long)row[k] * p.N + n0 + 4 * q4);
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int tl = (NW / 2) * (it0 + k) + tsel;
+                    const float4 e = ld4(smem + tl * ES + slot * 64 + 4 * q4);
+                    float4 v = make_float4(e.x + bv.x, e.y + bv.y, e.z + bv.z, e.w + bv.w);
+                    v.x = (mb[k] & 1) ? v.x : 0.f; v.y = (mb[k] & 2) ? v.y : 0.f;
+                    v.z = (mb[k] & 4) ? v.z : 0.f; v.w = (mb[k] & 8) ? v.w : 0.f;
+                    v = make_float4(v.x + old[k].x, v.y + old[k].y, v.z + old[k].z, v.w + old[k].w);
+                    if (ok[k]) st4s(p.y + off[k], v, p.nt);
+                }
+            }
+        }
 #pragma unroll 4
-        for (int it = 0; it < 16; ++it) {
+        for (int it = batched ? 16 : 0; it < 16; ++it) {
             const int tl = (NW / 2) * it + tsel;
             const long tile = (long)t0 + tl;
             if (tile >= p.T) break;
