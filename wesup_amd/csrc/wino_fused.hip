@@ -274,8 +274,66 @@ __global__ __launch_bounds__(128 * TW, 2) void wino4_gemm_out_kernel(const Fused
                 }
             }
         }
+        // The unpooling forms with the pooling's decisions as codes, two windows at a time in the same manner: codes (and the
+        // four row indices of a gathered window) first, then the destination's old values at the chosen positions resp. the
+        // gathered rows, then the stores.
+        const bool ubatched = up.dst && p.up_code && !p.mask && !p.mask_bits && !(p.gat.src && p.gat.area);
+        if (ubatched) {
+            const long rs = (long)p.Wu * p.N;
+#pragma unroll 1
+            for (int it0 = 0; it0 < 16; it0 += 2) {
+                long o00[2]; bool ok[2]; unsigned code[2]; int row[2][4]; float4 val[2][4];
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const int tl = (NW / 2) * (it0 + k) + tsel;
+                    long tile = (long)t0 + tl;
+                    ok[k] = tile < p.T;
+                    tile = ok[k] ? tile : p.T - 1;
+                    const int bi = fast_div((int)tile, p.dTw);
+                    const int tj = (int)tile - bi * p.Tw;
+                    const int b = fast_div(bi, p.dTh);
+                    const int ti = bi - b * p.Th;
+                    int h = 4 * ti + i, w = 4 * tj + jj;
+                    ok[k] = ok[k] && h < p.H && w < p.W;
+                    h = min(h, p.H - 1); w = min(w, p.W - 1);
+                    code[k] = p.up_code[(((long)b * p.H + h) * p.W + w) * (p.N >> 2) + (n0 >> 2) + q4];
+                    const long pix00 = ((long)b * p.Hu + 2 * h) * p.Wu + 2 * w;          // window's first pixel, batch-wide index
+                    o00[k] = pix00 * p.N + n0 + 4 * q4;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        row[k][q] = p.gat.src ? p.gat.row[pix00 + (q >> 1) * p.Wu + (q & 1)] + b * p.gat.Kmax : 0;
+                }
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const WinoPicks pk = wino_code_picks(code[k]);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        val[k][q] = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (p.gat.src) val[k][q] = ld4(p.gat.src + (long)row[k][q] * p.N + n0 + 4 * q4);
+                        else if (ok[k] && (pk.kx == q || pk.ky == q || pk.kz == q || pk.kw == q))
+                            val[k][q] = ld4(up.dst + o00[k] + (q >> 1) * rs + (q & 1) * p.N);
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const int tl = (NW / 2) * (it0 + k) + tsel;
+                    const float4 e = ld4(smem + tl * ES + slot * 64 + 4 * q4);
+                    const float4 v = make_float4(e.x + bv.x, e.y + bv.y, e.z + bv.z, e.w + bv.w);
+                    const WinoPicks pk = wino_code_picks(code[k]);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const bool hit = pk.kx == q || pk.ky == q || pk.kz == q || pk.kw == q;
+                        if (!ok[k] || (!p.gat.src && !hit)) continue;
+                        float4 o = val[k][q];
+                        o.x += pk.kx == q ? v.x : 0.f; o.y += pk.ky == q ? v.y : 0.f; o.z += pk.kz == q ? v.z : 0.f; o.w += pk.kw == q ? v.w : 0.f;
+                        float* dptr = up.dst + o00[k] + (q >> 1) * rs + (q & 1) * p.N;
+                        if (p.gat.src) st4s(dptr, o, p.nt); else st4(dptr, o);
+                    }
+                }
+            }
+        }
 #pragma unroll 4
-        for (int it = batched ? 16 : 0; it < 16; ++it) {
+        for (int it = (batched || ubatched) ? 16 : 0; it < 16; ++it) {
             const int tl = (NW / 2) * it + tsel;
             const long tile = (long)t0 + tl;
             if (tile >= p.T) break;
