@@ -547,7 +547,34 @@ __global__ __launch_bounds__(256) void wino4_output_transform_kernel(const float
     for (int r = 0; r < 4; ++r) {
         const int h = 4 * q.i + r;
         if ((r & 1) == 0) pm[0] = pm[1] = make_float4(ninf, ninf, ninf, ninf);
-        if (h < g.H) {
+        if (h < g.H && !up.src) {
+            // the four pixels of a tile row together: what the epilogue reads per pixel (ReLU mask, the old gradient) is loaded for
+            // all of them before the first use; columns outside the image are clamped and predicated
+            float4 o[4], mk[4], old[4];
+            long offc[4];
+            wino4_at(s[r], o);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int w = min(4 * q.j + c, g.W - 1);
+                offc[c] = (((long)q.b * g.H + h) * g.W + w) * g.C + 4 * q.cq;
+                if (mask) mk[c] = ld4(mask + offc[c]);
+                if (accum) old[c] = ld4(y + offc[c]);
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                if (4 * q.j + c >= g.W) break;
+                float4 v = f4add(o[c], bv);
+                if (mask) {
+                    v.x = mk[c].x > 0.f ? v.x : 0.f; v.y = mk[c].y > 0.f ? v.y : 0.f;
+                    v.z = mk[c].z > 0.f ? v.z : 0.f; v.w = mk[c].w > 0.f ? v.w : 0.f;
+                }
+                if (accum) v = f4add(v, old[c]);
+                st4(y + offc[c], v);
+                if (y_relu) st4(y_relu + offc[c], relu4(v));
+                float4& p = pm[c >> 1];
+                p.x = fmaxf(p.x, v.x); p.y = fmaxf(p.y, v.y); p.z = fmaxf(p.z, v.z); p.w = fmaxf(p.w, v.w);
+            }
+        } else if (h < g.H) {
             float4 o[4];
             wino4_at(s[r], o);
 #pragma unroll
