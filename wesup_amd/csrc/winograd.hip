@@ -140,13 +140,18 @@ __device__ __forceinline__ void wino_gt(const float (&u)[NP], float (&r)[3]) {  
 // PB pairs per block: 64, or 16 for the narrow layers (64 x 64 ... 128 x 128 filters: with 64 pairs a block the grid is 64 ..
 // 256 blocks and every thread walks 9 positions x S <= 28 slabs one load after the other; 16 pairs x 16 position groups
 // quarter that walk and fill the chip.  The sum over the slabs of one (position, pair) keeps its order: same bits.)
-template <int NP, int PB>
+__device__ __forceinline__ float4 wr_add4(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+// VEC: four consecutive pairs per thread (16-byte loads; strides and the pair count divisible by 4), every load of a thread's
+// positions in flight before the first sum -- beside the conv chain's kernels a load takes several times as long as alone, and
+// with two scalar loads in flight per thread this kernel ran 70 us there against 15 us alone.  Same sums in the same order.
+template <int NP, int PB, bool VEC = false>
 __global__ __launch_bounds__(256) void wino_wgrad_reduce_kernel(const float* __restrict__ slab, long stride, long batch_slab,
                                                                 float* __restrict__ dw, int Co, int Ci, int S,
                                                                 float* __restrict__ db, int pair_blocks,
                                                                 const float* __restrict__ bias_part, int bias_rows) {
     constexpr int P = NP * NP, PG = 256 / PB;            // PG position groups
-    __shared__ __attribute__((aligned(16))) float us[(P * (PB + 1) > 1024 ? P * (PB + 1) : 1024)];
+    constexpr int QB = VEC ? 4 * PB : PB;                // pairs per block
+    __shared__ __attribute__((aligned(16))) float us[(P * (QB + 1) > 1024 ? P * (QB + 1) : 1024)];
     const int tid = threadIdx.x;
     if ((int)blockIdx.x >= pair_blocks) {                // bias gradient
         const int bb = blockIdx.x - pair_blocks;
@@ -195,9 +200,43 @@ __global__ __launch_bounds__(256) void wino_wgrad_reduce_kernel(const float* __r
         }
         return;
     }
-    const int i = tid & (PB - 1);
-    const long idx = (long)blockIdx.x * PB + i;
-    const bool ok = idx < (long)Co * Ci;
+    int i = tid & (PB - 1);
+    long idx = (long)blockIdx.x * PB + i;
+    bool ok = idx < (long)Co * Ci;
+    if constexpr (VEC) {
+        const long idx4 = ((long)blockIdx.x * PB + i) * 4;
+        const bool ok4 = idx4 < (long)Co * Ci;          // (the pair count is a multiple of 4)
+        constexpr int NPOS = (P + PG - 1) / PG;
+        const int pg = tid / PB;
+#pragma unroll
+        for (int n = 0; n < NPOS; ++n) {
+            const int p = pg + n * PG;
+            if (p >= P) break;
+            float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
+            if (ok4) {
+                const float* src = slab + p * batch_slab + idx4;
+                int k = 0;
+                for (; k + 3 < S; k += 4) {
+                    const float4 v0 = ld4(src + (long)k * stride), v1 = ld4(src + (long)(k + 1) * stride);
+                    const float4 v2 = ld4(src + (long)(k + 2) * stride), v3 = ld4(src + (long)(k + 3) * stride);
+                    s0 = wr_add4(s0, v0); s1 = wr_add4(s1, v1); s0 = wr_add4(s0, v2); s1 = wr_add4(s1, v3);
+                }
+                for (; k + 1 < S; k += 2) {
+                    const float4 v0 = ld4(src + (long)k * stride), v1 = ld4(src + (long)(k + 1) * stride);
+                    s0 = wr_add4(s0, v0); s1 = wr_add4(s1, v1);
+                }
+                if (k < S) s0 = wr_add4(s0, ld4(src + (long)k * stride));
+            }
+            float* u = us + p * (QB + 1) + 4 * i;
+            u[0] = s0.x + s1.x; u[1] = s0.y + s1.y; u[2] = s0.z + s1.z; u[3] = s0.w + s1.w;
+        }
+        __syncthreads();
+        if (tid >= QB) return;
+        i = tid;
+        idx = (long)blockIdx.x * QB + i;
+        ok = idx < (long)Co * Ci;
+        if (!ok) return;
+    } else {
     for (int p = tid / PB; p < P; p += PG) {
         float s0 = 0.f, s1 = 0.f;
         if (ok) {
@@ -210,12 +249,13 @@ __global__ __launch_bounds__(256) void wino_wgrad_reduce_kernel(const float* __r
     }
     __syncthreads();
     if (tid >= PB || !ok) return;
+    }
     float r[3][NP];      // G^T u
 #pragma unroll
     for (int c = 0; c < NP; ++c) {
         float col[NP], o[3];
 #pragma unroll
-        for (int a = 0; a < NP; ++a) col[a] = us[(NP * a + c) * (PB + 1) + i];
+        for (int a = 0; a < NP; ++a) col[a] = us[(NP * a + c) * (QB + 1) + i];
         wino_gt<NP>(col, o);
         r[0][c] = o[0]; r[1][c] = o[1]; r[2][c] = o[2];
     }
@@ -890,10 +930,18 @@ int wino_filter_grad_launch(const float* slabs, long slab_stride, long batch_str
                             int Cin, int m, const float* bias_part, int bias_rows, void* stream) {
     const long tot = (long)Cout * Cin;
     const bool narrow = m == 4 && tot / 64 < 512;        // few pairs: 16 per block
-    const int pair_blocks = (int)((tot + (narrow ? 15 : 63)) / (narrow ? 16 : 64));
+    const bool vec = m == 4 && tot % 4 == 0 && slab_stride % 4 == 0 && batch_stride % 4 == 0 && !((uintptr_t)slabs & 15);
+    const int per_block = (narrow ? 16 : 64) * (vec ? 4 : 1);
+    const int pair_blocks = (int)((tot + per_block - 1) / per_block);
     const int bias_blocks = !db ? 0 : bias_part ? (Cout + 15) / 16 : (Cout + 255) / 256;
     const dim3 grid((unsigned)(pair_blocks + bias_blocks));
-    if (m == 2)
+    if (vec && narrow)
+        WESUP_LAUNCH((wino_wgrad_reduce_kernel<6, 16, true>), grid, dim3(256), 0, (hipStream_t)stream, slabs, slab_stride,
+                           batch_stride, dw_kcrs, Cout, Cin, S, db, pair_blocks, bias_part, bias_rows);
+    else if (vec)
+        WESUP_LAUNCH((wino_wgrad_reduce_kernel<6, 64, true>), grid, dim3(256), 0, (hipStream_t)stream, slabs, slab_stride,
+                           batch_stride, dw_kcrs, Cout, Cin, S, db, pair_blocks, bias_part, bias_rows);
+    else if (m == 2)
         WESUP_LAUNCH((wino_wgrad_reduce_kernel<4, 64>), grid, dim3(256), 0, (hipStream_t)stream, slabs, slab_stride,
                            batch_stride, dw_kcrs, Cout, Cin, S, db, pair_blocks, (const float*)nullptr, 0);
     else if (narrow)
