@@ -445,22 +445,51 @@ __device__ __forceinline__ bool wino4_decode(const WinoGeom& g, WinoTile& o) {
 __device__ __forceinline__ void wino4_input_body(const float* __restrict__ x, float* __restrict__ V, const WinoGeom& g,
                                                  const WinoTile& q, int relu, unsigned char* __restrict__ bits) {
     const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-    float4 m[6][6];      // B^T d
+    // All 36 loads first, nothing between them: with the sign-bit stores in the same loop every load was followed by its own
+    // s_waitcnt (36 serial round trips per thread -- unnoticed alone, where other waves cover them, and the reason this kernel
+    // doubled its time beside the other streams' kernels).
+    float4 d[6][6];
 #pragma unroll
     for (int c = 0; c < 6; ++c) {
         const int w = 4 * q.j - 1 + c;
-        float4 d[6], t[6];
 #pragma unroll
         for (int r = 0; r < 6; ++r) {
             const int h = 4 * q.i - 1 + r;
             const bool in = (unsigned)h < (unsigned)g.H && (unsigned)w < (unsigned)g.W;
-            const float4 v = in ? ld4(x + (((long)q.b * g.H + h) * g.W + w) * g.C + 4 * q.cq) : z;
-            d[r] = relu ? relu4(v) : v;
-            if (bits && in && r >= 1 && r <= 4 && c >= 1 && c <= 4)
-                bits[(((long)q.b * g.H + h) * g.W + w) * (g.C >> 2) + q.cq] =
-                    (unsigned char)((v.x > 0.f ? 1 : 0) | (v.y > 0.f ? 2 : 0) | (v.z > 0.f ? 4 : 0) | (v.w > 0.f ? 8 : 0));
+            d[r][c] = in ? ld4(x + (((long)q.b * g.H + h) * g.W + w) * g.C + 4 * q.cq) : z;
         }
-        wino4_bt(d, t);
+    }
+    if (bits) {
+        unsigned bt[4][4];       // (all sixteen values first: a store whose source register is reused waits for the one before)
+#pragma unroll
+        for (int c = 1; c <= 4; ++c)
+#pragma unroll
+            for (int r = 1; r <= 4; ++r) {
+                const float4 v = d[r][c];
+                bt[r - 1][c - 1] = (v.x > 0.f ? 1u : 0u) | (v.y > 0.f ? 2u : 0u) | (v.z > 0.f ? 4u : 0u) | (v.w > 0.f ? 8u : 0u);
+            }
+        unsigned char* b0 = bits + (((long)q.b * g.H + 4 * q.i) * g.W + 4 * q.j) * (g.C >> 2) + q.cq;
+        const long qs = g.C >> 2, rsb = (long)g.W * qs;
+        if (4 * q.i + 4 <= g.H && 4 * q.j + 4 <= g.W) {      // the tile lies inside the image (all but the last row / column of
+#pragma unroll                                              // tiles): sixteen stores in one block, none waiting for another
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) b0[r * rsb + c * qs] = (unsigned char)bt[r][c];
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    if (4 * q.i + r < g.H && 4 * q.j + c < g.W) b0[r * rsb + c * qs] = (unsigned char)bt[r][c];
+        }
+    }
+    float4 m[6][6];      // B^T d
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+        float4 col[6], t[6];
+#pragma unroll
+        for (int r = 0; r < 6; ++r) col[r] = relu ? relu4(d[r][c]) : d[r][c];
+        wino4_bt(col, t);
 #pragma unroll
         for (int r = 0; r < 6; ++r) m[r][c] = t[r];
     }
