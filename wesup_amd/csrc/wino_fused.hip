@@ -384,7 +384,7 @@ __global__ __launch_bounds__(128 * TW, 2) void wino4_gemm_out_kernel(const Fused
                 const int ph = 2 * ti + ip, pw = 2 * tj + k;
                 if (ph >= Hp || pw >= Wp) continue;
                 const float* e = smem + tl * ES + 4 * q;
-                const float4 b4 = p.bias ? ld4(p.bias + n0 + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+                const float4 b4 = bv;      // (q == q4: NT is a multiple of 16 -- the bias quad this thread loaded once)
                 const float4 e0 = ld4(e + (2 * k) * 64), e1 = ld4(e + (2 * k + 1) * 64), e2 = ld4(e + (4 + 2 * k) * 64), e3 = ld4(e + (5 + 2 * k) * 64);
                 if (p.pool_code) {       // the window's decisions on the stored values y = e + bias, for the backward
                     auto plus = [&](float4 a) { return make_float4(a.x + b4.x, a.y + b4.y, a.z + b4.z, a.w + b4.w); };

@@ -442,8 +442,10 @@ __device__ __forceinline__ bool wino4_decode(const WinoGeom& g, WinoTile& o) {
 // thread = (tile, 4 channels): 36 float4 loads (patch rows 4i-1 .. 4i+4), B^T d B, 36 float4 stores
 // bits (optional, [B][H][W][C/4] bytes): bit j of a byte = x[..., 4 cq + j] > 0 for the 4x4 pixels the tile owns (its
 // patch without the halo) -- the ReLU decisions of the layer below, kept for its backward (16x smaller than the mask tensor).
+template <bool KEEP_CORE = false>
 __device__ __forceinline__ void wino4_input_body(const float* __restrict__ x, float* __restrict__ V, const WinoGeom& g,
-                                                 const WinoTile& q, int relu, unsigned char* __restrict__ bits) {
+                                                 const WinoTile& q, int relu, unsigned char* __restrict__ bits,
+                                                 float4 (*core)[4] = nullptr) {
     const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
     // All 36 loads first, nothing between them: with the sign-bit stores in the same loop every load was followed by its own
     // s_waitcnt (36 serial round trips per thread -- unnoticed alone, where other waves cover them, and the reason this kernel
@@ -458,6 +460,12 @@ __device__ __forceinline__ void wino4_input_body(const float* __restrict__ x, fl
             const bool in = (unsigned)h < (unsigned)g.H && (unsigned)w < (unsigned)g.W;
             d[r][c] = in ? ld4(x + (((long)q.b * g.H + h) * g.W + w) * g.C + 4 * q.cq) : z;
         }
+    }
+    if constexpr (KEEP_CORE) {           // the tile's own 4x4 values for the caller (the dual transform's second half)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) core[r][c] = d[r + 1][c + 1];
     }
     if (bits) {
         unsigned bt[4][4];       // (all sixteen values first: a store whose source register is reused waits for the one before)
@@ -515,8 +523,9 @@ __global__ __launch_bounds__(256) void wino4_input_transform_kernel(const float*
 // of dM is the plain sum of a tile's gradients (for F(2x2) position (1,1) is, and the TN GEMM sums its column); instead
 // every thread adds up the 16 gradients it has loaded anyway, the tiles of a block meet in LDS in a fixed order (needs
 // C/4 | 256), and wesup_colsum folds the per-block rows: dy is not read a second time, no float atomics.
+template <bool HAVE_CORE = false>
 __device__ __forceinline__ float4 wino4_outgrad_body(const float* __restrict__ dy, float* __restrict__ dM, const WinoGeom& g,
-                                                     const WinoTile& q) {
+                                                     const WinoTile& q, const float4 (*core)[4] = nullptr) {
     const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
     float4 tot = z;
     {
@@ -528,7 +537,8 @@ __device__ __forceinline__ float4 wino4_outgrad_body(const float* __restrict__ d
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int h = 4 * q.i + r;
-                y[r] = (h < g.H && w < g.W) ? ld4(dy + (((long)q.b * g.H + h) * g.W + w) * g.C + 4 * q.cq) : z;
+                if constexpr (HAVE_CORE) y[r] = core[r][c];      // (out-of-image positions were loaded as zeros)
+                else y[r] = (h < g.H && w < g.W) ? ld4(dy + (((long)q.b * g.H + h) * g.W + w) * g.C + 4 * q.cq) : z;
             }
             tot = f4add(tot, f4add(f4add(y[0], y[1]), f4add(y[2], y[3])));
             wino4_a(y, t);
@@ -579,8 +589,9 @@ __global__ __launch_bounds__(256) void wino4_dual_transform_kernel(const float* 
     const bool active = wino4_decode(g, q);
     float4 tot = make_float4(0.f, 0.f, 0.f, 0.f);
     if (active) {
-        wino4_input_body(dy, V, g, q, 0, nullptr);
-        tot = wino4_outgrad_body(dy, dM, g, q);
+        float4 core[4][4];           // dy is read once: the 16 values both transforms share stay in registers
+        wino4_input_body<true>(dy, V, g, q, 0, nullptr, core);
+        tot = wino4_outgrad_body<true>(dy, dM, g, q, core);
     }
     if (!colsum_part) return;            // uniform
     wino4_block_colsum(tot, g, colsum_part, sh);
