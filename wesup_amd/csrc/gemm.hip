@@ -79,6 +79,8 @@ struct NtParams {
 // A lane's fragments for 4 consecutive MFMA k-steps are ONE ds_read_b128; MFMA t of a group uses element t of the
 // A and the B fragment: lanes 0-31 then carry k = 8g+t, lanes 32-63 k = 8g+4+t (any consistent k order is fine).
 // ---------------------------------------------------------------------------------------------
+template <int N>
+__device__ __forceinline__ void nt_wait_newest() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }      // all but the newest stage
 template <int NW, int BM, int BN, int WM, int WN, int MODE, int MINB, bool RELU, bool SIDE = false>
 __global__ __launch_bounds__(NW * 64, MINB) void gemm_nt_kernel(const NtParams p) {
     constexpr int NT = NW * 64;                        // threads per block
@@ -88,13 +90,16 @@ __global__ __launch_bounds__(NW * 64, MINB) void gemm_nt_kernel(const NtParams p
     constexpr int LDC = BN + 4;
     static_assert((BM / (32 * WM)) * WAVES_N == NW, "wave grid covers the tile");
     static_assert(BM % PR == 0 && BN % PR == 0, "whole staging passes");
-    constexpr int LDS_FLOATS = 2 * (BM + BN) * BK;
+    // The 64 x 64 tile with MINB = 3 is the three-stage form: a K-step of this tile is 0.4 us of MFMA time, and beside the other
+    // streams' kernels a staging DMA takes several times that -- two K-steps of lead instead of one (48 KiB: three blocks per CU).
+    constexpr int STAGES = (BM == 64 && BN == 64 && MINB == 3) ? 3 : 2;
+    constexpr int LDS_FLOATS = STAGES * (BM + BN) * BK;
     constexpr int EP = (BM * LDC + LDS_FLOATS - 1) / LDS_FLOATS;     // epilogue passes (C tile staged in row slabs)
     constexpr int HR = BM / EP;
     static_assert(HR % (32 * WM) == 0 && HR * LDC <= LDS_FLOATS, "epilogue slab fits in the staging buffers");
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* As = smem;                       // [2][BM][BK]
-    float* Bs = smem + 2 * BM * BK;         // [2][BN][BK]
+    float* As = smem;                       // [STAGES][BM][BK]
+    float* Bs = smem + STAGES * BM * BK;    // [STAGES][BN][BK]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     WESUP_DBG(const unsigned long long tr0 = __builtin_amdgcn_s_memrealtime();)
@@ -224,7 +229,11 @@ __global__ __launch_bounds__(NW * 64, MINB) void gemm_nt_kernel(const NtParams p
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     stage(ks, 0);
-    glds_wait();
+    if constexpr (STAGES == 3) {
+        if (ks + 1 < ke) { stage(ks + 1, 1); nt_wait_newest<RA + RB>(); } else glds_wait();
+    } else {
+        glds_wait();
+    }
     __syncthreads();
     WESUP_DBG(if (slot == 0) { clk0 = __builtin_amdgcn_s_memtime(); rt0 = __builtin_amdgcn_s_memrealtime(); })
     // (staggering every second resident block by 0.5-4 K-steps; s_setprio around either phase, alternating between the two
@@ -246,7 +255,11 @@ __global__ __launch_bounds__(NW * 64, MINB) void gemm_nt_kernel(const NtParams p
         };
         load_frag(0, 0);
         // (issuing one staging part per MFMA group instead was measured 3-4 % slower: round-2 probe gemm_trace.py, tools/README.md)
-        if (kk + 1 < ke) stage(kk + 1, cur ^ 1);
+        if constexpr (STAGES == 3) {
+            if (kk + 2 < ke) stage(kk + 2, cur >= 1 ? cur - 1 : 2);       // (cur + 2) % 3: the buffer of step kk - 1, free since its barrier
+        } else {
+            if (kk + 1 < ke) stage(kk + 1, cur ^ 1);
+        }
 #pragma unroll
         for (int g = 0; g < BK / 8; ++g) {
             const int sl = g & 1;
@@ -276,10 +289,16 @@ __global__ __launch_bounds__(NW * 64, MINB) void gemm_nt_kernel(const NtParams p
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][j], 0, 0, 0);
                     }
         }
+        if constexpr (STAGES == 3) {
+            if (kk + 2 < ke) nt_wait_newest<RA + RB>(); else glds_wait();     // step kk + 1's tile has landed, kk + 2's may still fly
+            __syncthreads();
+            cur = cur == 2 ? 0 : cur + 1;
+        } else {
         glds_wait();                // this wave's DMA for the next tile has landed ...
         __syncthreads();            // ... and so has everybody's; every wave is done reading buf[cur]
         // (timing-only diagnostic without this barrier: main loop only 5 % shorter -- barrier coupling is not the limiter)
         cur ^= 1;
+        }
     }
 
 #ifdef WESUP_GEMM_DEBUG
@@ -523,6 +542,11 @@ static NtChoice choose_nt(int M, int N, int K, bool with_ws) {
     return c;
 }
 
+// 64 x 64 tiles: a grid that is resident all at once (<= 512 blocks: three per CU leave room) takes the three-stage form -- it
+// has no second round of blocks to cover a late DMA with, and beside the other streams' kernels DMAs are late (batch 1 at 480^2:
+// 3.56 -> 3.50 ms; nothing at batch 4, whose small grids are the side GEMMs off the chain; larger grids lose occupancy: 8.28 ->
+// 8.34 ms with every 64 x 64 launch on three stages).
+static bool nt_three_stages(long blocks) { return blocks <= 512; }
 template <int NW, int BM, int BN, int WM, int WN, int MODE, int MINB, bool RELU, bool SIDE = false>
 static int launch_nt(NtParams p, hipStream_t st, const SkPlan* sk = nullptr, void* ws = nullptr) {
     p.tiles_m = ceil_div(p.M, BM);
@@ -533,7 +557,7 @@ static int launch_nt(NtParams p, hipStream_t st, const SkPlan* sk = nullptr, voi
     if (sk && sk->parts > 0) {
         p.full_tiles = sk->full; p.sk_parts = sk->parts; p.sk_steps = sk->steps; p.sk_ws = (float*)ws;
     }
-    const size_t lds = (size_t)2 * (BM + BN) * BK * sizeof(float);
+    const size_t lds = (size_t)((BM == 64 && BN == 64 && MINB == 3) ? 3 : 2) * (BM + BN) * BK * sizeof(float);
     auto kern = gemm_nt_kernel<NW, BM, BN, WM, WN, MODE, MINB, RELU, SIDE>;
     if (lds > 64 * 1024) {           // more than the default dynamic LDS limit: raise it once per instantiation
         static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -560,7 +584,9 @@ static int dispatch_nt_r(NtParams p, hipStream_t st, void* ws, size_t ws_bytes) 
         case NT_BIG: return launch_nt<8, 256, 128, 2, 2, MODE, 1, RELU>(p, st, sk, ws);
         case NT_STD: return launch_nt<4, 128, 128, 2, 2, MODE, 2, RELU>(p, st, sk, ws);
         case NT_N64: return launch_nt<4, 128, 64, 2, 1, MODE, 2, RELU>(p, st);
-        default: return launch_nt<4, 64, 64, 1, 1, MODE, 2, RELU>(p, st);
+        default:
+            if (nt_three_stages((long)ceil_div(p.M, 64) * ceil_div(p.N, 64) * (p.nbatch > 1 ? p.nbatch : 1)) && (MODE == 0 || MODE == 3)) return launch_nt<4, 64, 64, 1, 1, MODE, 3, RELU>(p, st);
+            return launch_nt<4, 64, 64, 1, 1, MODE, 2, RELU>(p, st);
     }
 }
 // conv forward with the layer's 1x1 side conv fused into the epilogue: one N-tile holds all output channels
@@ -1445,6 +1471,7 @@ extern "C" int wesup_gemm_nt_batched(const float* A, int lda, long strideA, cons
     p.nbatch = nbatch; p.batchA = strideA; p.batchB = strideB; p.batchC = strideC;
     hipStream_t st = (hipStream_t)stream;
     if (N > 64 && t128 >= 384) return launch_nt<4, 128, 128, 2, 2, 3, 2, false>(p, st);
+    if (nt_three_stages(t64)) return launch_nt<4, 64, 64, 1, 1, 3, 3, false>(p, st);
     return launch_nt<4, 64, 64, 1, 1, 3, 2, false>(p, st);
 }
 
@@ -1466,6 +1493,7 @@ extern "C" int wesup_gemm_nt_batched_bias(const float* A, int lda, long strideA,
     p.nbatch = nbatch; p.batchA = strideA; p.batchB = strideB; p.batchC = strideC; p.batchBias = strideBias;
     hipStream_t st = (hipStream_t)stream;
     if (N > 64 && t128 >= 384) return launch_nt<4, 128, 128, 2, 2, 3, 2, false>(p, st);
+    if (nt_three_stages(t64)) return launch_nt<4, 64, 64, 1, 1, 3, 3, false>(p, st);
     return launch_nt<4, 64, 64, 1, 1, 3, 2, false>(p, st);
 }
 
