@@ -10,8 +10,10 @@ two questions are separated and both are answered tightly:
 
   1. every decision on which the GPU and the fp64 evaluation disagree is NAMED and must be a genuine near-tie
      (|pre-activation| resp. the gap between the two window candidates within ``tie_tol`` x the layer's max);
-  2. GIVEN the same decisions, every parameter gradient must agree with fp64 to 1e-4 of the tensor's max (or be no worse
-     than twice the error of torch's CPU fp32 evaluation under the same decisions).
+  2. GIVEN the same decisions, every parameter gradient must agree with fp64 to 1e-4 of the tensor's max -- a fixed bar
+     (round 4 also accepted "no worse than twice the error of torch's CPU fp32 evaluation under the same decisions", which
+     reached 2.9e-3 on one tensor while the worst GPU error ever observed is 1.7e-6: a bar that pinned nothing; the torch
+     fp32 evaluation is now an optional yardstick that is recorded, never a bar).
 """
 import numpy as np
 import torch
@@ -162,7 +164,7 @@ def gpu_mlp_outputs(engine):
     return [t.detach().float().cpu().view(B, -1, t.shape[-1]) for t in (b.h1, b.h2, b.feats)]
 
 
-def check_gradients(model, weights, imgs, segs, masks, names=None, tol=1e-4, tie_tol=2e-5, case=None, **loss_kw):
+def check_gradients(model, weights, imgs, segs, masks, names=None, tol=1e-4, tie_tol=2e-5, case=None, yardstick=False, **loss_kw):
     """Assert points 1 and 2 of the module docstring for the gradients the model holds after a backward pass.
     Returns (worst relative error, number of named disagreements)."""
     ys = gpu_preactivations(model.engine)
@@ -182,7 +184,9 @@ def check_gradients(model, weights, imgs, segs, masks, names=None, tol=1e-4, tie
     # regression hiding behind the tie tolerance
     n_units = sum(int(y.numel()) for y in ys)
     assert named.total <= max(64, n_units // 20000), (named.total, n_units)
-    _, g32, _ = forced_step(weights, imgs, segs, masks, ys, torch.float32, tie_tol, mlp_gpu=hs, pseudo_gpu=pseudo, **loss_kw)
+    g32 = None
+    if yardstick:
+        _, g32, _ = forced_step(weights, imgs, segs, masks, ys, torch.float32, tie_tol, mlp_gpu=hs, pseudo_gpu=pseudo, **loss_kw)
     worst = 0.0
     for k in (names or list(g64)):
         ref = g64[k]
@@ -192,13 +196,13 @@ def check_gradients(model, weights, imgs, segs, masks, names=None, tol=1e-4, tie
             assert float(got.abs().max()) == 0.0, k
             continue
         e_gpu = float((got - ref).abs().max()) / scale
-        e_cpu = float((g32[k].double() - ref).abs().max()) / scale
-        assert e_gpu < max(tol, 2 * e_cpu), (k, e_gpu, e_cpu, [(n['kind'], n['layer']) for n in named][:8])
+        assert e_gpu < tol, (k, e_gpu, [(n['kind'], n['layer']) for n in named][:8])
         worst = max(worst, e_gpu)
         if case is not None:
             import _tol
-            _tol.within(case, 'gradients vs fp64 (GPU decisions)', e_gpu, max(tol, 2 * e_cpu),
-                        'max |g - g64| / max |g64| per parameter tensor; bar 1e-4, or 2x the error of torch CPU fp32 under the same decisions')
-            _tol.within(case, 'torch CPU fp32 gradients vs fp64 (yardstick, no bar)', e_cpu, 1.0, 'the same measure for torch\'s own fp32 path')
+            _tol.within(case, 'gradients vs fp64 (GPU decisions)', e_gpu, tol, 'max |g - g64| / max |g64| per parameter tensor; fixed bar 1e-4')
+            if g32 is not None:
+                e_cpu = float((g32[k].double() - ref).abs().max()) / scale
+                _tol.within(case, 'torch CPU fp32 gradients vs fp64 (yardstick, no bar)', e_cpu, 1.0, 'the same measure for torch\'s own fp32 path')
     check_gradients.last_named = named
     return worst, named.total

@@ -3,6 +3,7 @@ wesup_winograd_pack_weights, wesup_transpose_batched, wesup_winograd_fused_route
 hand through the C ABI (wesup_plan_* / wesup_sync_* / wesup_copy / wesup_fill_words) across two streams."""
 import ctypes
 
+import numpy as np
 import pytest
 import torch
 
@@ -45,6 +46,50 @@ def test_transposes_of_several_matrices_in_one_launch():
     ops.transpose_batched(pairs)
     for a, out in pairs:
         assert torch.equal(out, a.t().contiguous())
+
+
+def test_more_transposes_than_one_launch_takes():
+    """ops.transpose_batched cuts its list into launches of TRANSPOSE_MAX items (the C entry takes at most 40)."""
+    from wesup_amd import ops
+    d = _dev()
+    g = torch.Generator().manual_seed(6)
+    n = 2 * ops.TRANSPOSE_MAX + 7
+    pairs = [(torch.randn(5 + i % 11, 3 + i % 7, generator=g).to(d), None) for i in range(n)]
+    pairs = [(a, torch.full((a.shape[1], a.shape[0]), float('nan'), device=d)) for a, _ in pairs]
+    ops.transpose_batched(pairs)
+    for a, out in pairs:
+        assert torch.equal(out, a.t().contiguous())
+
+
+@pytest.mark.parametrize('B,H,W,g', [(16, 256, 256, 12), (32, 480, 480, 24)])
+def test_large_batches_step_through_the_matrix_pooling(B, H, W, g):
+    """The forward hands B x (matrix-pooling groups) interpolation-matrix transposes to ops.transpose_batched: 48 at B = 16,
+    256 x 256 (three groups), 64 at B = 32, 480 x 480 (two) -- more than one launch holds.  One training iteration; the superpixel
+    features of the first four images against the same images as a batch of four (1e-4 of the tensor's max: the product kernels'
+    tilings depend on the batch)."""
+    from oracle import wesup_oracle as orc
+    from wesup_amd import synth
+    from wesup_amd.models import initialize_trainer
+    d = _dev()
+    weights = orc.make_weights(2, feat_scale=0.05)
+    imgs, labs, pts, pix = synth.make_batch(21, B, H, W, g)
+
+    def run(n):
+        t = initialize_trainer('wesup', device='cuda:0', max_superpixels=g * g)
+        t.model.load_state_dict({k: torch.from_numpy(v) for k, v in weights.items()})
+        t.optimizer, t.scheduler = t.get_default_optimizer()
+        t.model.train(); t.tracker.train()
+        t.train_one_iteration('train', *(torch.from_numpy(a[:n]).to(d) for a in (imgs, pix, pts, labs)))
+        torch.cuda.synchronize()
+        feats = t.model._padded[0].detach().clone()
+        loss = t.tracker.history['loss'][-1]
+        t.model.engine.release_buffers()
+        return feats, loss
+    full, loss = run(B)
+    part, _ = run(4)
+    assert np.isfinite(loss) and full.shape[0] == B
+    assert float((full[:4] - part).abs().max()) <= 1e-4 * float(part.abs().max())
+    torch.cuda.empty_cache()
 
 
 def test_one_kernel_route_needs_a_grid_that_fills_the_chip():

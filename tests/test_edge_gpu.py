@@ -47,7 +47,7 @@ def run_both(imgs, segs, masks, pix, seed=7, feat_scale=0.03, check_grads=('back
     assert abs(loss - ref_loss) <= TOL * max(abs(ref_loss), 1e-3), (loss, ref_loss)
     # Gradients against an fp64 evaluation that takes the GPU's ReLU signs and pooling arg-maxes (tests/_gradcheck.py):
     # decisions that differ from fp64's own must be genuine near-ties (they are named in the failure message), and
-    # under equal decisions every checked gradient is within 1e-4 of its tensor's max (or <= 2x torch's CPU fp32 error).
+    # under equal decisions every checked gradient is within 1e-4 of its tensor's max.
     import _gradcheck
     ys = _gradcheck.gpu_preactivations(trainer.model.engine)
     import torch.nn.functional as F

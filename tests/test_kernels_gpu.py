@@ -1050,6 +1050,123 @@ def test_sp_pool_skewed_maps_multi_segment_rows(ops, H, W, g):
         assert rel_err(got[..., coff:coff + Cs], ref2[..., coff:coff + Cs]) < 1e-5
 
 
+# ---------------------------------------------------------------- fused upsample + scatter-mean, tile by tile (round 5)
+def _tile_pool_cases(H, W):
+    return [(H, W, 32, 0), (H, W, 64, 32), (H // 2, W // 2, 64, 64), (H // 2, W // 2, 128, 128), (H // 4, W // 4, 128, 128),
+            (H // 4, W // 4, 256, 0), (max(1, H // 8), max(1, W // 8), 512, 256)]
+
+
+@pytest.mark.parametrize('B,H,W,g', [(2, 32, 32, 4), (1, 96, 80, 7), (2, 120, 136, 9), (1, 53, 47, 5)])
+def test_sp_pool_tiles_equals_the_pixel_list_form(ops, B, H, W, g):
+    """wesup_sp_tiles + wesup_sp_pool_tiles_fwd against wesup_sp_pool_upsample_fwd (itself pinned to upsample_fwd + sp_pool_fwd and,
+    through them, to the oracle) and against the materialised form directly; tables checked against numpy; bitwise reproducible."""
+    d = dev()
+    labs, masks = _sp_case(17, B, H, W, g)
+    Kmax = g * g + 3
+    m = ops.sp_preprocess(torch.from_numpy(labs).to(d), torch.from_numpy(masks).to(d), Kmax)
+    t = ops.sp_tiles(m)
+    nty, ntx = (H + 15) // 16, (W + 15) // 16
+    new_row = m.new_row.cpu().numpy().reshape(B, H, W)
+    ns, rows, slot = t.tile_ns.cpu().numpy(), t.tile_rows.cpu().numpy(), t.slot.cpu().numpy().reshape(B, H, W)
+    base, bbox = t.tile_base.cpu().numpy(), t.bbox.cpu().numpy()
+    for b in range(B):
+        want_box = {}
+        for ty in range(nty):
+            for tx in range(ntx):
+                blk = new_row[b, ty * 16:(ty + 1) * 16, tx * 16:(tx + 1) * 16]
+                u = np.unique(blk)
+                ti = ty * ntx + tx
+                assert ns[b, ti] == len(u) and np.array_equal(rows[b, ti, :len(u)], u)
+                assert np.array_equal(u[slot[b, ty * 16:(ty + 1) * 16, tx * 16:(tx + 1) * 16]], blk)
+                for r in u:
+                    y0, y1, x0, x1 = want_box.get(r, (ty, ty, tx, tx))
+                    want_box[r] = (min(y0, ty), max(y1, ty), min(x0, tx), max(x1, tx))
+        for r, box in want_box.items():
+            assert tuple(bbox[b, r]) == box
+        # part rows handed out: every tile its own range, all inside the capacity
+        order = np.argsort(base[b])
+        assert base[b].min() == 0 and np.array_equal(base[b][order][1:], np.cumsum(ns[b][order])[:-1])
+        assert int(t.alloc[b]) == ns[b].sum() <= ops._lib.load().wesup_sp_tiles_part_rows(H, W, Kmax)
+    assert int(t.row_flag.abs().max()) == 0
+    C = 768
+    for (h, w, Cs, coff) in _tile_pool_cases(H, W):
+        if not ops.sp_pool_tiles_supported(h, w, H, W, Cs):
+            assert (h, w) != (H, W) and h * 1.6 > H                     # only upsampling factors below 1.67 are left to the other form
+            continue
+        sl = rnd(B, h, w, Cs, seed=9).to(d)
+        want = torch.zeros(B, Kmax, C, device=d)
+        ops.sp_pool_upsample_fwd(sl, m, want, coff)
+        got = torch.full((B, Kmax, C), 7.0, device=d)
+        ops.sp_pool_tiles_fwd(sl, m, got, coff)
+        assert rel_err(got[..., coff:coff + Cs], want[..., coff:coff + Cs]) < 1e-5
+        assert float((got[..., :coff] - 7).abs().max() if coff else 0.0) == 0.0 and float((got[..., coff + Cs:] - 7).abs().max()) == 0.0
+        got2 = torch.zeros(B, Kmax, C, device=d)
+        ops.sp_pool_tiles_fwd(sl, m, got2, coff)
+        assert torch.equal(got[..., coff:coff + Cs], got2[..., coff:coff + Cs])
+        fm2 = torch.zeros(B, H, W, C, device=d)
+        ops.upsample_fwd(sl, fm2, coff)
+        ref2 = ops.sp_pool_fwd(fm2, m)
+        assert rel_err(got[..., coff:coff + Cs], ref2[..., coff:coff + Cs]) < 1e-5
+        n_sp = m.n_sp.cpu().tolist()
+        for b in range(B):
+            assert float(got[b, n_sp[b]:, coff:coff + Cs].abs().max()) == 0.0          # padded rows: zeros
+
+
+def test_sp_pool_tiles_rows_that_do_not_fit_take_the_pixel_lists(ops):
+    """One-pixel-high stripes across the image: every tile holds 16 rows, more than the part buffer has room for (6 per tile +
+    Kmax): the tiles that did not fit mark their rows, and the combine kernel sums those from the pixel lists -- same values."""
+    d = dev()
+    B, H, W = 2, 64, 80
+    labs = np.broadcast_to(np.arange(H, dtype=np.int32)[None, :, None], (B, H, W)).copy()
+    labs[1] = labs[1][::-1]                       # (any ids: rows are the reference's order of them)
+    m = ops.sp_preprocess(torch.from_numpy(labs).to(d), None, H)
+    t = ops.sp_tiles(m)
+    assert int(t.alloc.min()) > ops._lib.load().wesup_sp_tiles_part_rows(H, W, H)       # more rows asked for than there are
+    flagged = int(t.row_flag.sum())
+    assert 0 < flagged <= B * H and int((t.tile_base < 0).sum()) > 0
+    for (h, w, Cs) in [(H, W, 64), (H // 2, W // 2, 128), (H // 4, W // 4, 256)]:
+        sl = rnd(B, h, w, Cs, seed=4).to(d)
+        want = torch.zeros(B, H, Cs, device=d)
+        ops.sp_pool_upsample_fwd(sl, m, want, 0)
+        got = torch.zeros(B, H, Cs, device=d)
+        ops.sp_pool_tiles_fwd(sl, m, got, 0)
+        assert rel_err(got, want) < 1e-5
+
+
+@pytest.mark.parametrize('Kmax,C,ok', [(16384, 2, True), (16384, 3, True), (16384, 4, False), (13312, 4, True), (20000, 2, False)])
+def test_sp_preprocess_limits(ops, Kmax, C, ok):
+    """The limits wesup_hip.h states: Kmax <= 16384 and Kmax * (2 + C) <= 81920 (round 4's form refused Kmax > 13312 with a 2-class
+    mask); a map with ids up to Kmax - 1 goes through and counts right."""
+    d = dev()
+    H = W = 128
+    rs = np.random.RandomState(3)
+    labs = rs.randint(0, min(Kmax, 16384), (1, H, W)).astype(np.int32)
+    labs[0, 0, 0] = min(Kmax, 16384) - 1
+    mask = (rs.random_sample((1, C, H, W)) > 0.7).astype(np.uint8)
+    if not ok:
+        with pytest.raises(Exception):
+            ops.sp_preprocess(torch.from_numpy(labs).to(d), torch.from_numpy(mask).to(d), Kmax, n_classes=C)
+        return
+    m = ops.sp_preprocess(torch.from_numpy(labs).to(d), torch.from_numpy(mask).to(d), Kmax, n_classes=C)
+    assert int(m.n_sp[0]) == Kmax
+    area = np.bincount(labs.reshape(-1), minlength=Kmax)
+    perm = m.perm[0].cpu().numpy()
+    assert np.array_equal(m.area_new[0].cpu().numpy(), area[perm]) and int(m.area_new.sum()) == H * W
+    cnt = np.stack([np.bincount(labs.reshape(-1), weights=mask[0, c].reshape(-1), minlength=Kmax) for c in range(C)], 1)
+    lab_rows = cnt.sum(1) > 0
+    assert int(m.n_l[0]) == int((lab_rows & (area > 0)).sum())
+    n_l = int(m.n_l[0])
+    assert np.array_equal(perm[:n_l], np.nonzero(lab_rows)[0])                       # labelled ids ascending first
+    want_lab = (cnt[perm[:n_l]] == cnt[perm[:n_l]].max(1, keepdims=True)).astype(np.float32)
+    assert np.array_equal(m.sp_labels[0, :n_l].cpu().numpy(), want_lab)
+    # the stable counting sort: pixels of a row in ascending order, rows in the reference's order
+    ps, rs_ = m.pix_sorted[0].cpu().numpy(), m.row_start[0].cpu().numpy()
+    flat = labs.reshape(-1)
+    for r in (0, n_l, Kmax - 1):
+        seg = ps[rs_[r]:rs_[r + 1]]
+        assert np.array_equal(seg, np.nonzero(flat == perm[r])[0])
+
+
 # ---------------------------------------------------------------- interpolation-pooling matrix (deep layers)
 @pytest.mark.parametrize('B,H,W,g,h,w', [(2, 64, 64, 6, 8, 8), (1, 96, 80, 7, 12, 10), (1, 120, 120, 12, 30, 30),
                                          (1, 96, 96, 5, 96, 96 // 2)])

@@ -71,7 +71,9 @@ def test_replayed_plan_equals_the_walk_bit_for_bit(B, H, W, g):
             assert a.tracker.history[k][-1] == b.tracker.history[k][-1], (i, k)
         assert torch.equal(_flat(a), _flat(b)), f'parameters differ after step {i}'
     st = b.step_runner().stats
-    assert st['recorded'] == 2 and st['replayed'] == n - 4 and st['dropped'] == 0, st
+    # the first iteration of a run is walked only (the optimiser's first step is its own launch), the second and third record the
+    # plan and its twin, the fourth replays
+    assert st['eager'] == 1 and st['recorded'] == 2 and st['replayed'] == n - 3 and st['dropped'] == 0, st
     # what the module carries after an iteration (models/wesup.py:287-292, :529)
     assert b.model.sp_pred is None and b.model.sp_features.shape[0] == B
     # the plan is a few hundred launches and a handful of cuts
@@ -91,7 +93,7 @@ def test_plan_is_dropped_when_the_walk_changes_and_nan_raises_before_the_update(
     for i in range(6):
         a.train_one_iteration('train', *data[i % 2])
         b.train_one_iteration('train', *data[i % 2])
-    assert b.step_runner().stats['replayed'] == 2
+    assert b.step_runner().stats['replayed'] == 3
     for t in (a, b):                                  # a new learning rate: the recorded SGD launch is stale
         t.optimizer.param_groups[0]['lr'] = 1e-4
     for i in range(6):
@@ -99,7 +101,7 @@ def test_plan_is_dropped_when_the_walk_changes_and_nan_raises_before_the_update(
         b.train_one_iteration('train', *data[i % 2])
         assert torch.equal(_flat(a), _flat(b)), i
     st = b.step_runner().stats
-    assert st['dropped'] == 1 and st['replayed'] == 4, st
+    assert st['dropped'] == 1 and st['replayed'] == 7, st          # (a dropped plan is recorded again at once: twin, then 4 replays)
     # an engine switch changes the launch list
     b.model.engine.dual_transform = a.model.engine.dual_transform = False
     for i in range(2):
@@ -160,6 +162,9 @@ def test_interleaved_shapes_each_get_a_plan_and_keep_it():
         assert torch.equal(_flat(a), _flat(b)), k
     r = b.step_runner()
     assert len(r.states) == 3 and all(st.plan is not None for st in r.states.values()), r.stats
+    # a shape is recorded on its first occurrence, confirmed on its second and replayed from its third: only the run's very first
+    # iteration (the optimiser's first step) is walked without a recording
+    assert r.stats['eager'] == 1 and r.stats['replayed'] >= len(order) - 1 - 2 * 3 - 2, r.stats
     from wesup_amd import ops
     ops.ws_generation += 1                   # what a workspace that had to grow does (ops.workspace): every recorded address is stale
     for k, i in enumerate([0, 1, 2] * 5):
@@ -168,3 +173,66 @@ def test_interleaved_shapes_each_get_a_plan_and_keep_it():
         assert torch.equal(_flat(a), _flat(b)), k
     assert all(st.plan is not None for st in r.states.values()), r.stats
     assert r.stats['dropped'] >= 3
+
+
+def test_end_to_end_staging_feeds_the_same_step_as_the_general_path():
+    """bench.py --end-to-end (and utils/data.py DevicePrefetcher): uint8 batch -> wesup_augment -> wesup_slic on a second stream,
+    counts to pinned host memory, LabelMaps as the fourth element of the data tuple, the step through the runner (walked, recorded,
+    replayed).  Against the trainer's general path (preprocess -> forward -> compute_loss -> backward -> step) on copies of the
+    SAME augmented images, masks and label maps: loss, metrics and every parameter bit for bit, every iteration."""
+    from oracle import wesup_oracle as orc
+    from wesup_amd import ops, synth
+    from wesup_amd.utils import data as D
+    dev = torch.device('cuda:0')
+    B, H, W = 2, 96, 112
+    weights = orc.make_weights(13, feat_scale=0.05)
+    a = _trainer(weights, native_step=False)          # the general path
+    b = _trainer(weights)                              # the runner
+    for t in (a, b):
+        t.kwargs['max_superpixels'] = None             # rows = the label maps' own counts (known on the host)
+    seg_fn = b.prefetch_segment_fn()
+    side = torch.cuda.Stream(device=dev)
+    rs = np.random.RandomState(3)
+    raw = []
+    for i in range(2):
+        u8 = np.ascontiguousarray((np.stack([synth.synth_image(50 + 10 * i + k, H, W) for k in range(B)]).transpose(0, 2, 3, 1) * 255)
+                                  .astype(np.uint8))
+        msk = (rs.random_sample((B, H, W)) > 0.5).astype(np.uint8)
+        par = np.stack([D.sample_params(rs, H, W, True)[0] for _ in range(B)])
+        pts = torch.zeros(B, 2, H, W, dtype=torch.uint8, device=dev)
+        idx = rs.randint(0, min(H, W), (B, 30, 2))
+        for k in range(B):
+            pts[k, rs.randint(0, 2, 30), idx[k, :, 0], idx[k, :, 1]] = 1
+        raw.append((torch.from_numpy(u8).to(dev), torch.from_numpy(msk).to(dev), torch.from_numpy(par).to(dev), pts))
+
+    def stage(i):
+        d_img, d_mask, params, pts = raw[i % 2]
+        with torch.cuda.stream(side):
+            img, pm = ops.augment(d_img, d_mask, params)
+            seg, n_dev = seg_fn(img)
+            counts = torch.empty(n_dev.shape, dtype=n_dev.dtype).pin_memory()
+            counts.copy_(n_dev, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+        return img, pm, pts, seg, counts, ev
+
+    nxt = stage(0)
+    n = 7
+    for i in range(n):
+        img, pm, pts, seg, counts, ev = nxt
+        nxt = stage(i + 1)                             # the next batch is staged beside this step, as in the bench
+        torch.cuda.current_stream().wait_event(ev)
+        ev.synchronize()
+        cnt = [int(v) for v in counts]
+        twin = (img.clone(), pm.clone(), pts.clone(), D.LabelMaps(seg.clone(), list(cnt)))
+        b.train_one_iteration('train', img, pm, pts, D.LabelMaps(seg, cnt))
+        a.train_one_iteration('train', *twin)
+        for k in ('loss', 'labeled_sp_ratio', 'propagated_labels', 'propagate_loss', 'accuracy', 'dice'):
+            assert a.tracker.history[k][-1] == b.tracker.history[k][-1], (i, k)
+        assert torch.equal(_flat(a), _flat(b)), f'parameters differ after step {i}'
+        assert torch.equal(a.model._flat_grad, b.model._flat_grad), i
+    st = b.step_runner().stats
+    # SLIC's superpixel count of an image is the same every time it comes round: two batches, at most two shapes (Kmax), each
+    # replayed from its third occurrence
+    assert st['eager'] + st['recorded'] + st['replayed'] == n and st['replayed'] >= 1, st
+    assert a.step_runner() is None

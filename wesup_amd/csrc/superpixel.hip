@@ -7,28 +7,27 @@
 // load instruction of a wave is 1 KiB contiguous, there are no atomics, and the summation order is fixed
 // (ascending pixel index), so results are bitwise reproducible.
 #include "common.hpp"
-#include <mutex>
 
 #define SP_CHUNK 2048            // pixels per counting-sort chunk
 #define SP_MAX_K 16384           // LDS histogram capacity (ids per image)
 #define SP_SEG 512               // pixels per pooling segment (see the scatter-mean kernels)
 
-// ------------------------------------------------------------------ preprocessing in two launches
-// Launch 1, sp_count_order_kernel: one block per 2048-pixel chunk builds the chunk's histogram and class counts in LDS (no
-// global atomics, nothing to zero beforehand) and stores them; the LAST block of an image to finish -- told by an arrival
-// ticket -- then does the per-image part alone: areas, the reference ordering, row starts, the chunk bases of the stable
-// counting sort and the segment table.  Launch 2, sp_place_kernel: one wave per chunk places the pixels.
-// (Round 3 ran this as three memsets and five launches, 0.31 ms inside the step for 0.16 ms of work.)
-//
-// The hand-off inside launch 1 is the split-K "last arriver" recipe of cdna_hip_programming.md 5 (item 2): every wave drains
-// its stores, the block meets, lane 0 releases at agent scope, waits, and draws a ticket; the block that draws the last one
-// acquires at agent scope before anybody in it reads the other blocks' chunk rows.  Correct for any placement of the blocks.
-// The tickets live in a zero-initialised __device__ array of the library (a workspace handed in by the caller has unknown
-// content) and the last arriver puts its ticket back to zero; calls that may overlap on different streams use different
-// rows of it (one row per stream).
-#define SP_TICKET_ROWS 64
-#define SP_TICKET_B 256
-__device__ int32_t g_sp_ticket[SP_TICKET_ROWS][SP_TICKET_B];
+// ------------------------------------------------------------------ preprocessing: four launches, every phase parallel
+// (Round 4 ran this as two launches whose first ended in ONE block per image summing nchunk x Kmax x (1 + C) strided words and
+// re-walking them for the sort bases: 0.23 ms in the configs[1] step, 4.4 ms at the 1024 x 1024 shard, on the stream the first
+// pooling waits for -- and the class counts in LDS capped Kmax at 13 312.  Now:)
+//   0. sp_zero: the per-image sums (area and class counts by id, largest id, status) are zeroed;
+//   1. sp_hist_kernel, one block per 2048-pixel chunk: histogram and class counts of the chunk in LDS (class counts as 16-bit
+//      halves: a chunk has 2048 pixels), the histogram row stored for the counting sort, every non-zero entry ADDED to the
+//      image's sums with integer atomics (exact in any order: the result does not depend on the arrival order);
+//   2. sp_scan_order_kernel, two kinds of block in one launch, independent of each other: (a) blocks of 64 ids x 16 chunk ranges
+//      turn the histogram columns into exclusive prefixes over the chunks (where chunk g starts inside the pixel list of id i),
+//      all loads of a thread in flight at once; (b) one block per image does what needs all ids: the reference ordering, labels,
+//      row starts, segment table -- O(Kmax / 1024) per thread, from the sums;
+//   3. sp_place_kernel, one wave per chunk: places the pixels (stable: ascending pixel index inside a row).
+// No hand-off between blocks inside a launch, no library-side state: any B, any number of streams.
+#define SP_SCAN_COLS 64
+#define SP_SCAN_SEGS 16
 
 // block-wide exclusive scan of one int per thread (1024 threads); returns the exclusive prefix, total in *total
 __device__ int block_excl_scan(int v, int* total, int* sh /*[1024]*/) {
@@ -51,69 +50,89 @@ struct SpPre {
     const int32_t* labels;
     const uint8_t* mask;
     int HW, C, Kmax, nchunk, Umax;
-    int pad_;                // (explicit padding, zero: launch.hpp)
-    int32_t* chunk_hist;     // [B][nchunk][Kmax]: histogram, later the chunk's base inside each row
-    int32_t* chunk_cnt;      // [B][nchunk][Kmax * C] class counts per chunk (mask given)
-    int32_t* chunk_info;     // [B][nchunk][2] {largest id + 1, status bits}
-    int32_t* cnt;            // [B][Kmax * C] summed over the chunks
-    int32_t* area_old;       // [B][Kmax]
+    int nslice;              // blocks of SP_SCAN_COLS ids per image in launch 2
+    int32_t* chunk_hist;     // [B][nchunk][Kmax]: histogram, then the chunk's start inside the pixel list of each id
+    int32_t* img_info;       // [B][2] {largest id + 1, status bits}     | zeroed by launch 0, summed by launch 1
+    int32_t* cnt;            // [B][Kmax * C] class counts by id         |
+    int32_t* area_old;       // [B][Kmax] pixels by id                   |
     int32_t *n_sp, *n_l, *perm, *inv_perm, *area_new, *row_start, *status, *seg_start, *unit_row;
     float* sp_labels;
-    int32_t* ticket;         // [B]
 };
+
+__global__ __launch_bounds__(1024) void sp_hist_kernel(const SpPre p) {
+    extern __shared__ int32_t lds[];      // [Kmax] histogram, [(Kmax * C + 1) / 2] class counts (two 16-bit counts per word)
+    int32_t* hist = lds;
+    int32_t* lcnt = lds + p.Kmax;
+    const int b = blockIdx.y, g = blockIdx.x, tid = threadIdx.x;
+    const int Kmax = p.Kmax, C = p.C, HW = p.HW;
+    const bool has_mask = p.mask != nullptr;
+    const int words = Kmax + (has_mask ? (Kmax * C + 1) / 2 : 0);
+    for (int i = tid; i < words; i += 1024) lds[i] = 0;
+    __syncthreads();
+    const int p0 = g * SP_CHUNK, p1 = min(HW, p0 + SP_CHUNK);
+    int lmax = 0, bad = 0;
+    for (int q = p0 + tid; q < p1; q += 1024) {
+        const int l = p.labels[(long)b * HW + q];
+        if (l < 0 || l >= Kmax) {
+            bad = 1;
+            continue;
+        }
+        atomicAdd(&hist[l], 1);
+        lmax = max(lmax, l + 1);
+        if (has_mask)
+            for (int c = 0; c < C; ++c)
+                if (p.mask[((long)b * C + c) * HW + q]) {
+                    const int e = l * C + c;
+                    atomicAdd(&lcnt[e >> 1], 1 << (16 * (e & 1)));          // (a chunk has 2048 pixels: no carry into the other half)
+                }
+    }
+    // wave-level reduction of the two scalars, one atomic per wave
+    for (int off = 32; off > 0; off >>= 1) {
+        lmax = max(lmax, __shfl_xor(lmax, off));
+        bad |= __shfl_xor(bad, off);
+    }
+    if ((tid & 63) == 0) {
+        if (lmax) atomicMax(&p.img_info[2 * b], lmax);
+        if (bad) atomicOr(&p.img_info[2 * b + 1], 1);
+    }
+    __syncthreads();
+    int32_t* oh = p.chunk_hist + ((long)b * p.nchunk + g) * Kmax;
+    int32_t* area = p.area_old + (long)b * Kmax;
+    int32_t* cnt = p.cnt + (long)b * Kmax * C;
+    for (int i = tid; i < Kmax; i += 1024) {
+        const int h = hist[i];
+        oh[i] = h;
+        if (h) {
+            atomicAdd(&area[i], h);
+            if (has_mask)
+                for (int c = 0; c < C; ++c) {
+                    const int e = i * C + c;
+                    const int v = (lcnt[e >> 1] >> (16 * (e & 1))) & 0xffff;
+                    if (v) atomicAdd(&cnt[e], v);
+                }
+        }
+    }
+}
 
 // rows: labelled ids ascending, then unlabelled ids ascending (models/wesup.py:45-47); label = multi-hot of the classes whose
 // pixel count equals the row maximum (models/wesup.py:50-52, integer form).  One block of 1024 threads per image.
 __device__ void sp_order_image(const SpPre& p, int b, int* sh /*[1024]*/) {
-    const int tid = threadIdx.x, Kmax = p.Kmax, C = p.C, nchunk = p.nchunk;
+    const int tid = threadIdx.x, Kmax = p.Kmax, C = p.C;
     const bool has_mask = p.mask != nullptr;
-    const int32_t* hist = p.chunk_hist + (long)b * nchunk * Kmax;
-    const int32_t* ccnt = p.chunk_cnt + (long)b * nchunk * Kmax * C;
-    int32_t* cnt = p.cnt + (long)b * Kmax * C;
-    int32_t* area_old = p.area_old + (long)b * Kmax;
-    // largest id and status over the chunks
-    int lm = 0, stat = 0;
-    for (int g = tid; g < nchunk; g += 1024) {
-        lm = max(lm, p.chunk_info[((long)b * nchunk + g) * 2]);
-        stat |= p.chunk_info[((long)b * nchunk + g) * 2 + 1];
-    }
-    sh[tid] = lm;
-    __syncthreads();
-    for (int off = 512; off > 0; off >>= 1) {
-        if (tid < off) sh[tid] = max(sh[tid], sh[tid + off]);
-        __syncthreads();
-    }
-    const int n = min(sh[0], Kmax);
-    __syncthreads();
-    sh[tid] = stat;
-    __syncthreads();
-    for (int off = 512; off > 0; off >>= 1) {
-        if (tid < off) sh[tid] |= sh[tid + off];
-        __syncthreads();
-    }
-    stat = sh[0];
-    __syncthreads();
+    const int32_t* cnt = p.cnt + (long)b * Kmax * C;
+    const int32_t* area_old = p.area_old + (long)b * Kmax;
+    const int n = min(p.img_info[2 * b], Kmax);
+    const int stat = p.img_info[2 * b + 1];
     const int per = (Kmax + 1023) / 1024;
     const int i0 = min(Kmax, tid * per), i1 = min(Kmax, i0 + per);
-    // areas and class counts by old id (sums over the chunks)
     int nlab = 0;
     bool empty = false;
-    for (int i = i0; i < i1; ++i) {
-        int a = 0;
-        for (int g = 0; g < nchunk; ++g) a += hist[(long)g * Kmax + i];
-        area_old[i] = a;
+    for (int i = i0; i < min(i1, n); ++i) {
         int s = 0;
         if (has_mask)
-            for (int c = 0; c < C; ++c) {
-                int v = 0;
-                for (int g = 0; g < nchunk; ++g) v += ccnt[((long)g * Kmax + i) * C + c];
-                cnt[i * C + c] = v;
-                s += v;
-            }
-        if (i < n) {
-            if (a == 0) empty = true;
-            if (s > 0) ++nlab;
-        }
+            for (int c = 0; c < C; ++c) s += cnt[i * C + c];
+        if (area_old[i] == 0) empty = true;
+        if (s > 0) ++nlab;
     }
     sh[tid] = empty ? 1 : 0;
     __syncthreads();
@@ -127,6 +146,7 @@ __device__ void sp_order_image(const SpPre& p, int b, int* sh /*[1024]*/) {
     const int pre_l = block_excl_scan(nlab, &total_l, sh);
     // second pass: assign rows
     int rl = pre_l, ru = total_l + (min(i0, n) - pre_l);
+    int asum = 0;
     for (int i = i0; i < i1; ++i) {
         int row;
         if (i < n) {
@@ -159,7 +179,6 @@ __device__ void sp_order_image(const SpPre& p, int b, int* sh /*[1024]*/) {
     __syncthreads();      // (area_new of this image: written and read by this block)
     // row_start = exclusive scan of area_new over rows
     int32_t* rs = p.row_start + (long)b * (Kmax + 1);
-    int asum = 0;
     for (int r = i0; r < i1; ++r) asum += p.area_new[(long)b * Kmax + r];
     int tot;
     int pre = block_excl_scan(asum, &tot, sh);
@@ -169,16 +188,6 @@ __device__ void sp_order_image(const SpPre& p, int b, int* sh /*[1024]*/) {
     }
     if (tid == 1023) rs[Kmax] = tot;
     __syncthreads();
-    // chunk bases: where chunk g starts inside the row of old id i (in place of the histogram)
-    for (int i = i0; i < i1; ++i) {
-        int run = rs[p.inv_perm[(long)b * Kmax + i]];
-        for (int g = 0; g < nchunk; ++g) {
-            int32_t* h = p.chunk_hist + ((long)b * nchunk + g) * Kmax + i;
-            const int v = *h;
-            *h = run;
-            run += v;
-        }
-    }
     // segment table (rows cut into <= SP_SEG-pixel segments) for the load-balanced pooling kernels
     if (p.seg_start) {
         int c = 0;
@@ -195,112 +204,110 @@ __device__ void sp_order_image(const SpPre& p, int b, int* sh /*[1024]*/) {
     }
 }
 
-__global__ __launch_bounds__(1024) void sp_count_order_kernel(const SpPre p) {
-    extern __shared__ int32_t lds[];      // [1024] scan / flags, [Kmax] histogram, [Kmax * C] class counts
-    int32_t* sh = lds;
-    int32_t* hist = lds + 1024;
-    int32_t* lcnt = hist + p.Kmax;
-    const int b = blockIdx.y, g = blockIdx.x, tid = threadIdx.x;
-    const int Kmax = p.Kmax, C = p.C, HW = p.HW;
-    const bool has_mask = p.mask != nullptr;
-    for (int i = tid; i < Kmax * (has_mask ? 1 + C : 1); i += 1024) hist[i] = 0;
-    __syncthreads();
-    const int p0 = g * SP_CHUNK, p1 = min(HW, p0 + SP_CHUNK);
-    int lmax = 0, bad = 0;
-    for (int q = p0 + tid; q < p1; q += 1024) {
-        const int l = p.labels[(long)b * HW + q];
-        if (l < 0 || l >= Kmax) {
-            bad = 1;
-            continue;
+__global__ __launch_bounds__(1024) void sp_scan_order_kernel(const SpPre p) {
+    __shared__ int32_t sh[1024];
+    const int b = blockIdx.y, tid = threadIdx.x;
+    if ((int)blockIdx.x == p.nslice) {
+        sp_order_image(p, b, sh);
+        return;
+    }
+    // chunk_hist[b][g][i] -> sum over g' < g of chunk_hist[b][g'][i]: thread (i, seg) owns the chunks [seg L, (seg + 1) L) of id i
+    const int Kmax = p.Kmax, nchunk = p.nchunk;
+    const int col = tid & (SP_SCAN_COLS - 1), seg = tid / SP_SCAN_COLS;
+    const int i = blockIdx.x * SP_SCAN_COLS + col;
+    const int L = (nchunk + SP_SCAN_SEGS - 1) / SP_SCAN_SEGS;
+    const int g0 = min(nchunk, seg * L), g1 = min(nchunk, g0 + L);
+    int32_t* h = p.chunk_hist + (long)b * nchunk * Kmax + i;
+    int sum = 0;
+    if (i < Kmax) {
+        int g = g0;
+        for (; g + 8 <= g1; g += 8) {
+            int v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = h[(long)(g + k) * Kmax];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) sum += v[k];
         }
-        atomicAdd(&hist[l], 1);
-        lmax = max(lmax, l + 1);
-        if (has_mask)
-            for (int c = 0; c < C; ++c)
-                if (p.mask[((long)b * C + c) * HW + q]) atomicAdd(&lcnt[l * C + c], 1);
+        for (; g < g1; ++g) sum += h[(long)g * Kmax];
     }
-    sh[tid] = lmax;
+    sh[tid] = sum;
     __syncthreads();
-    for (int off = 512; off > 0; off >>= 1) {
-        if (tid < off) sh[tid] = max(sh[tid], sh[tid + off]);
-        __syncthreads();
-    }
-    lmax = sh[0];
-    __syncthreads();
-    sh[tid] = bad;
-    __syncthreads();
-    for (int off = 512; off > 0; off >>= 1) {
-        if (tid < off) sh[tid] |= sh[tid + off];
-        __syncthreads();
-    }
-    bad = sh[0];
-    __syncthreads();
-    int32_t* oh = p.chunk_hist + ((long)b * p.nchunk + g) * Kmax;
-    for (int i = tid; i < Kmax; i += 1024) oh[i] = hist[i];
-    if (has_mask) {
-        int32_t* oc = p.chunk_cnt + ((long)b * p.nchunk + g) * Kmax * C;
-        for (int i = tid; i < Kmax * C; i += 1024) oc[i] = lcnt[i];
-    }
-    if (tid == 0) {
-        p.chunk_info[((long)b * p.nchunk + g) * 2] = lmax;
-        p.chunk_info[((long)b * p.nchunk + g) * 2 + 1] = bad;
-    }
-    // ---- arrival: the image's last chunk block does the per-image part
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (tid == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const int old = __hip_atomic_fetch_add(&p.ticket[b], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const int last = old == p.nchunk - 1;
-        if (last) {
-            __hip_atomic_store(&p.ticket[b], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next call
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    int run = 0;
+    for (int s2 = 0; s2 < seg; ++s2) run += sh[s2 * SP_SCAN_COLS + col];
+    if (i < Kmax) {
+        int g = g0;
+        for (; g + 8 <= g1; g += 8) {
+            int v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = h[(long)(g + k) * Kmax];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                h[(long)(g + k) * Kmax] = run;
+                run += v[k];
+            }
         }
-        sh[0] = last;
+        for (; g < g1; ++g) {
+            const int v = h[(long)g * Kmax];
+            h[(long)g * Kmax] = run;
+            run += v;
+        }
     }
-    __syncthreads();
-    const int last = sh[0];
-    __syncthreads();
-    if (!last) return;
-    sp_order_image(p, b, sh);
 }
 
 // ------------------------------------------------------------------ stable placement: one wave per chunk
+// The wave keeps a cursor per id in LDS, started at row_start[row of the id] + the chunk's prefix (three coalesced / gathered loads
+// per id, all independent), so that the pixel loop holds no dependent global load: per 64 pixels the labels (and the rows they map
+// to) are loaded one iteration ahead, the lanes of equal label rank themselves with ballots.
 __global__ __launch_bounds__(64) void sp_place_kernel(const int32_t* __restrict__ labels,
                                                       const int32_t* __restrict__ chunk_base,
-                                                      const int32_t* __restrict__ inv_perm, int HW, int Kmax, int nchunk,
+                                                      const int32_t* __restrict__ inv_perm,
+                                                      const int32_t* __restrict__ row_start, int HW, int Kmax, int nchunk,
                                                       int32_t* __restrict__ pix_sorted, int32_t* __restrict__ new_row) {
-    extern __shared__ int32_t cntl[];
+    extern __shared__ int32_t cur[];
     const int b = blockIdx.y, g = blockIdx.x, lane = threadIdx.x;
-    for (int i = lane; i < Kmax; i += 64) cntl[i] = 0;
-    __syncthreads();
     const int32_t* base = chunk_base + ((long)b * nchunk + g) * Kmax;
+    const int32_t* ip = inv_perm + (long)b * Kmax;
+    const int32_t* rs = row_start + (long)b * (Kmax + 1);
+    for (int i = lane; i < Kmax; i += 64) cur[i] = rs[ip[i]] + base[i];
+    __syncthreads();
     const int p0 = g * SP_CHUNK, p1 = min(HW, p0 + SP_CHUNK);
+    int l_nxt = (p0 + lane < p1) ? labels[(long)b * HW + p0 + lane] : -1;
+    if (l_nxt >= Kmax) l_nxt = -1;
+    int r_nxt = l_nxt >= 0 ? ip[l_nxt] : 0;
     for (int s = p0; s < p1; s += 64) {
         const int p = s + lane;
-        int l = (p < p1) ? labels[(long)b * HW + p] : -1;
-        if (l >= Kmax) l = -1;
+        const int l = l_nxt, row = r_nxt;
+        if (s + 64 < p1) {
+            const int pn = p + 64;
+            l_nxt = (pn < p1) ? labels[(long)b * HW + pn] : -1;
+            if (l_nxt >= Kmax) l_nxt = -1;
+            r_nxt = l_nxt >= 0 ? ip[l_nxt] : 0;
+        }
         unsigned long long rem = __ballot(l >= 0);
         int pos = -1;
         while (rem) {
             const int leader = __ffsll((long long)rem) - 1;
             const int ll = __shfl(l, leader);
             const unsigned long long m = __ballot(l == ll);
-            if (l == ll) pos = base[ll] + cntl[ll] + __popcll(m & ((1ull << lane) - 1ull));
+            const int c0 = cur[ll];                     // (every lane reads the same word: a broadcast)
+            if (l == ll) pos = c0 + __popcll(m & ((1ull << lane) - 1ull));
             __syncthreads();
-            if (lane == leader) cntl[ll] += __popcll(m);
+            if (lane == leader) cur[ll] = c0 + __popcll(m);
             __syncthreads();
             rem &= ~m;
         }
         if (l >= 0) {
             pix_sorted[(long)b * HW + pos] = p;
-            new_row[(long)b * HW + p] = inv_perm[(long)b * Kmax + l];
+            new_row[(long)b * HW + p] = row;
         } else if (p < p1) {
             new_row[(long)b * HW + p] = 0;
         }
     }
+}
+
+__global__ void sp_zero_kernel(int32_t* __restrict__ w, long n) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) w[i] = 0;
 }
 
 extern "C" size_t wesup_sp_preprocess_workspace_bytes(int B, int HW, int C, int Kmax) {
@@ -308,10 +315,7 @@ extern "C" size_t wesup_sp_preprocess_workspace_bytes(int B, int HW, int C, int 
     const size_t nchunk = (HW + SP_CHUNK - 1) / SP_CHUNK;
     const size_t Cc = C > 0 ? C : 1;
     size_t bytes = align_up((size_t)B * nchunk * Kmax * 4, 256);     // chunk_hist / chunk_base
-    bytes += align_up((size_t)B * nchunk * Kmax * Cc * 4, 256);      // class counts per chunk
-    bytes += align_up((size_t)B * nchunk * 2 * 4, 256);               // {largest id + 1, status} per chunk
-    bytes += align_up((size_t)B * Kmax * Cc * 4, 256);                // cnt
-    bytes += align_up((size_t)B * Kmax * 4, 256);                     // area by old id
+    bytes += align_up((size_t)B * (2 + Kmax * (1 + Cc)) * 4, 256);    // {largest id + 1, status}, class counts, areas by id
     return bytes;
 }
 
@@ -325,53 +329,36 @@ extern "C" int wesup_sp_preprocess(const int32_t* labels, const uint8_t* mask, i
     if (!labels || !n_sp || !n_l || !perm || !inv_perm || !area_new || !sp_labels || !new_row || !row_start ||
         !pix_sorted || !status || !ws)
         return WESUP_ERR_INVALID;
-    if (B <= 0 || B > SP_TICKET_B || HW <= 0 || C <= 0 || Kmax <= 0 || Kmax > SP_MAX_K) return WESUP_ERR_INVALID;
+    if (B <= 0 || B > 65535 || HW <= 0 || C <= 0 || Kmax <= 0 || Kmax > SP_MAX_K) return WESUP_ERR_INVALID;
     if ((seg_start || unit_row) && (!seg_start || !unit_row || Umax < Kmax)) return WESUP_ERR_INVALID;
-    const size_t lds = ((size_t)1024 + (size_t)Kmax * (mask ? 1 + C : 1)) * 4;
-    if (lds > 160 * 1024) return WESUP_ERR_INVALID;       // (Kmax <= 13 312 with a 2-class mask)
+    const size_t lds = ((size_t)Kmax + (mask ? ((size_t)Kmax * C + 1) / 2 : 0)) * 4;
+    if (lds > 160 * 1024) return WESUP_ERR_INVALID;       // (a mask of up to 3 classes at Kmax = 16 384; Kmax * (2 + C) <= 81 920)
     if (ws_bytes < wesup_sp_preprocess_workspace_bytes(B, HW, C, Kmax)) return WESUP_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     const int nchunk = (HW + SP_CHUNK - 1) / SP_CHUNK;
     SpPre p = {};
     char* w = (char*)ws;
     p.chunk_hist = (int32_t*)w; w += align_up((size_t)B * nchunk * Kmax * 4, 256);
-    p.chunk_cnt = (int32_t*)w;  w += align_up((size_t)B * nchunk * Kmax * C * 4, 256);
-    p.chunk_info = (int32_t*)w; w += align_up((size_t)B * nchunk * 2 * 4, 256);
-    p.cnt = (int32_t*)w;        w += align_up((size_t)B * Kmax * C * 4, 256);
-    p.area_old = (int32_t*)w;
+    p.img_info = (int32_t*)w;
+    p.cnt = p.img_info + (size_t)2 * B;
+    p.area_old = p.cnt + (size_t)B * Kmax * C;
+    const long sums = (long)B * (2 + (long)Kmax * (1 + C));
     p.labels = labels; p.mask = mask; p.HW = HW; p.C = C; p.Kmax = Kmax; p.nchunk = nchunk; p.Umax = Umax;
+    p.nslice = (Kmax + SP_SCAN_COLS - 1) / SP_SCAN_COLS;
     p.n_sp = n_sp; p.n_l = n_l; p.perm = perm; p.inv_perm = inv_perm; p.area_new = area_new; p.row_start = row_start;
     p.status = status; p.seg_start = seg_start; p.unit_row = unit_row; p.sp_labels = sp_labels;
-    // the ticket row of this call: one row per STREAM (calls on one stream run one after the other; calls in flight on
-    // different streams must not share a row), first come first served -- the same stream always gets the same row, so a
-    // recorded step plan and a later walk of the same step agree
-    static std::mutex mu;
-    static hipStream_t row_stream[SP_TICKET_ROWS];
-    static int rows_used = 0;
-    int row = -1;
     {
-        std::lock_guard<std::mutex> lock(mu);
-        for (int i = 0; i < rows_used; ++i)
-            if (row_stream[i] == st) row = i;
-        if (row < 0 && rows_used < SP_TICKET_ROWS) {
-            row = rows_used++;
-            row_stream[row] = st;
-        }
-    }
-    if (row < 0) return WESUP_ERR_INVALID;             // more than 64 streams have called this entry
-    static int32_t* const tickets = [] {
-        int32_t* t = nullptr;
-        return hipGetSymbolAddress((void**)&t, HIP_SYMBOL(g_sp_ticket)) == hipSuccess ? t : nullptr;
-    }();
-    if (!tickets) return WESUP_ERR_LAUNCH;
-    p.ticket = tickets + (size_t)row * SP_TICKET_B;
-    {
-        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(sp_count_order_kernel),
+        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(sp_hist_kernel),
                                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (attr != hipSuccess) return WESUP_ERR_LAUNCH;
+        static const hipError_t attr2 = hipFuncSetAttribute(reinterpret_cast<const void*>(sp_place_kernel),
+                                                            hipFuncAttributeMaxDynamicSharedMemorySize, SP_MAX_K * 4);
+        if (attr2 != hipSuccess) return WESUP_ERR_LAUNCH;
     }
-    WESUP_LAUNCH(sp_count_order_kernel, dim3(nchunk, B), dim3(1024), lds, st, p);
-    WESUP_LAUNCH(sp_place_kernel, dim3(nchunk, B), dim3(64), (size_t)Kmax * 4, st, labels, p.chunk_hist, inv_perm, HW,
+    WESUP_LAUNCH(sp_zero_kernel, dim3((unsigned)((sums + 255) / 256)), dim3(256), 0, st, p.img_info, sums);
+    WESUP_LAUNCH(sp_hist_kernel, dim3(nchunk, B), dim3(1024), lds, st, p);
+    WESUP_LAUNCH(sp_scan_order_kernel, dim3(p.nslice + 1, B), dim3(1024), 0, st, p);
+    WESUP_LAUNCH(sp_place_kernel, dim3(nchunk, B), dim3(64), (size_t)Kmax * 4, st, labels, p.chunk_hist, inv_perm, row_start, HW,
                  Kmax, nchunk, pix_sorted, new_row);
     WESUP_CHECK_LAUNCH();
     return WESUP_OK;
@@ -746,6 +733,383 @@ extern "C" int wesup_sp_pool_upsample_fwd(const float* s, const int32_t* pix_sor
                            seg_start, sp_feat, Kmax, Umax, cw / 4, ldo, coff + c0);
     }
 #undef WESUP_LAUNCH_PU
+    WESUP_CHECK_LAUNCH();
+    return WESUP_OK;
+}
+
+// ------------------------------------------------------------------ the same scatter-mean, tile by tile (round 5)
+// The segment form above walks a superpixel's pixel list: list -> pixel -> (four cells of) s, a chain of dependent loads per lane
+// group, and for a coarse s it rebuilds the per-cell weights of every segment in every layer.  Alone that reads at 2.5 TB/s; beside
+// the other streams of the training step, where a load takes several times as long, it fell to 0.9 TB/s (configs[1]) and 0.5 TB/s
+// (the 120 x 120 layers).  Here the image is cut into 16 x 16-pixel tiles and a block streams ITS part of s in raster order --
+// every load address is known up front, a thread's loads are all issued before the first use --:
+//   * wesup_sp_tiles (once per step): per tile the rows (superpixels) present, ascending, and each pixel's slot in that list;
+//     a first part row per tile (bump allocation per image: the ORDER of the tiles in the part buffer is arbitrary, its content
+//     is not), and per row the box of tiles it touches;
+//   * sp_pool_tile_kernel (per layer): the tile's cells of s -- its own pixels at native resolution, the <= 12 x 12 cells under
+//     it for a coarse s, whose bilinear weights are summed per (cell, slot) in LDS as 2^-40 fixed point (integer atomics: exact in
+//     any order) -- are loaded once, coalesced, and accumulated per slot in a fixed order: one partial sum per (tile, slot);
+//   * sp_pool_tile_combine_kernel (per layer): one wave per row adds the row's partial sums over its box of tiles in raster order
+//     and scales by 1 / area.
+// Bitwise reproducible (every order is fixed), no float atomics.  A label map whose tiles hold more rows than the part buffer
+// has room for (6 per tile + Kmax per image: superpixels far smaller than a tile) marks the rows of the tiles that did not fit;
+// the combine kernel sums such a row from its pixel list instead (the slow, general form) -- no host decision anywhere.
+#define SPT 16                 // tile edge, full-resolution pixels
+#define SPT_SLOTS 16           // slots accumulated per pass over the tile's cells
+#define SPT_CB 8               // cells in flight per thread
+#define SPT_CMAX 12            // coarse cells per dimension under one tile (upsampling factor >= 1.5)
+struct SpTiles {
+    const int32_t* new_row;    // [B][HW]
+    int H, W, Kmax, nty, ntx, cap;      // cap: part rows per image
+    uint8_t* slot;             // [B][HW] the pixel's slot in its tile's row list
+    int32_t* tile_ns;          // [B][ntile] rows present
+    int32_t* tile_base;        // [B][ntile] first part row, -1: did not fit
+    int32_t* tile_rows;        // [B][ntile][256] the rows, ascending
+    int32_t* alloc;            // [B] part rows handed out            | initialised by sp_tiles_init_kernel
+    int32_t* row_flag;         // [B][Kmax] 1: a tile of the row did not fit |
+    int32_t* bbox;             // [B][Kmax][4] ty0, ty1, tx0, tx1     |
+};
+__global__ void sp_tiles_init_kernel(const SpTiles p, int B) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)B * p.Kmax) return;
+    if (i < B) p.alloc[i] = 0;
+    p.row_flag[i] = 0;
+    p.bbox[4 * i + 0] = 0x7fffffff; p.bbox[4 * i + 1] = -1; p.bbox[4 * i + 2] = 0x7fffffff; p.bbox[4 * i + 3] = -1;
+}
+__global__ __launch_bounds__(256) void sp_tiles_kernel(const SpTiles p) {
+    __shared__ uint32_t bits[SP_MAX_K / 32];
+    __shared__ int wpre[SP_MAX_K / 32];
+    __shared__ int scan[256];
+    __shared__ int srows[256];
+    __shared__ int sbase;
+    const int b = blockIdx.z, ty = blockIdx.y, tx = blockIdx.x, tid = threadIdx.x;
+    const int tile = ty * p.ntx + tx, ntile = p.nty * p.ntx;
+    const int words = (p.Kmax + 31) >> 5;
+    for (int i = tid; i < words; i += 256) bits[i] = 0u;
+    __syncthreads();
+    const int y = ty * SPT + (tid >> 4), x = tx * SPT + (tid & 15);
+    const bool inside = y < p.H && x < p.W;
+    const long pix = (long)b * p.H * p.W + (long)y * p.W + x;
+    int r = inside ? p.new_row[pix] : -1;
+    if (r >= p.Kmax) r = -1;
+    if (r >= 0) atomicOr(&bits[r >> 5], 1u << (r & 31));
+    __syncthreads();
+    // exclusive prefix of the popcounts over the words: thread t owns the words [t per, (t + 1) per)
+    const int per = (words + 255) / 256;
+    int cnt = 0;
+    for (int i = tid * per; i < min(words, (tid + 1) * per); ++i) cnt += __popc(bits[i]);
+    scan[tid] = cnt;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {
+        const int t = (tid >= off) ? scan[tid - off] : 0;
+        __syncthreads();
+        scan[tid] += t;
+        __syncthreads();
+    }
+    const int ns = scan[255];
+    int run = scan[tid] - cnt;
+    for (int i = tid * per; i < min(words, (tid + 1) * per); ++i) {
+        wpre[i] = run;
+        uint32_t m = bits[i];
+        while (m) {
+            const int bit = __ffs(m) - 1;
+            m &= m - 1;
+            srows[run++] = i * 32 + bit;          // (ns <= 256: a tile has 256 pixels)
+        }
+    }
+    if (tid == 0) {
+        const int base = atomicAdd(&p.alloc[b], ns);
+        sbase = (base + ns <= p.cap) ? base : -1;
+        p.tile_ns[(long)b * ntile + tile] = ns;
+        p.tile_base[(long)b * ntile + tile] = sbase;
+    }
+    __syncthreads();
+    if (inside) p.slot[pix] = r >= 0 ? (uint8_t)(wpre[r >> 5] + __popc(bits[r >> 5] & ((1u << (r & 31)) - 1u))) : (uint8_t)255;
+    if (tid < ns) {
+        const int rr = srows[tid];
+        p.tile_rows[((long)b * ntile + tile) * 256 + tid] = rr;
+        int32_t* bb = p.bbox + ((long)b * p.Kmax + rr) * 4;
+        atomicMin(&bb[0], ty); atomicMax(&bb[1], ty); atomicMin(&bb[2], tx); atomicMax(&bb[3], tx);
+        if (sbase < 0) p.row_flag[(long)b * p.Kmax + rr] = 1;
+    }
+}
+extern "C" int wesup_sp_tiles_part_rows(int H, int W, int Kmax) {
+    return (H > 0 && W > 0 && Kmax > 0) ? 6 * ceil_div(H, SPT) * ceil_div(W, SPT) + Kmax : 0;
+}
+extern "C" int wesup_sp_tiles(const int32_t* new_row, int B, int H, int W, int Kmax, uint8_t* slot, int32_t* tile_ns,
+                              int32_t* tile_base, int32_t* tile_rows, int32_t* alloc, int32_t* row_flag, int32_t* bbox,
+                              void* stream) {
+    if (!new_row || !slot || !tile_ns || !tile_base || !tile_rows || !alloc || !row_flag || !bbox || B <= 0 || B > 65535 || H <= 0 ||
+        W <= 0 || Kmax <= 0 || Kmax > SP_MAX_K)
+        return WESUP_ERR_INVALID;
+    SpTiles p = {};
+    p.new_row = new_row; p.H = H; p.W = W; p.Kmax = Kmax; p.nty = ceil_div(H, SPT); p.ntx = ceil_div(W, SPT);
+    p.cap = wesup_sp_tiles_part_rows(H, W, Kmax);
+    p.slot = slot; p.tile_ns = tile_ns; p.tile_base = tile_base; p.tile_rows = tile_rows; p.alloc = alloc; p.row_flag = row_flag;
+    p.bbox = bbox;
+    if (p.nty > 65535) return WESUP_ERR_INVALID;
+    hipStream_t st = (hipStream_t)stream;
+    WESUP_LAUNCH(sp_tiles_init_kernel, dim3((unsigned)(((long)B * Kmax + 255) / 256)), dim3(256), 0, st, p, B);
+    WESUP_LAUNCH(sp_tiles_kernel, dim3(p.ntx, p.nty, B), dim3(256), 0, st, p);
+    WESUP_CHECK_LAUNCH();
+    return WESUP_OK;
+}
+
+struct SpPoolTile {
+    const float* s;            // (B, h, w, lds) the side output / conv output at its own resolution, channel offset applied
+    float* part;               // [B][cap][C]
+    float* out;                // (B, Kmax, ldo), channel offset applied
+    const uint8_t* slot;
+    const int32_t *tile_ns, *tile_base, *tile_rows, *row_flag, *bbox;
+    const int32_t *pix_sorted, *row_start;
+    int h, w, H, W, lds, ldo, Kmax, nty, ntx, cap;
+    float sh, sw;
+    FastDiv dW;
+};
+WESUP_NO_PADDING(SpPoolTile, 11 * 8 + 10 * 4 + 2 * 4 + 16);
+// NQ = C / 4 lanes cover the channels of one cell; G = 256 / NQ lane groups walk the tile's cells g, g + G, ...
+template <int NQ, bool IDENT>
+__global__ __launch_bounds__(256) void sp_pool_tile_kernel(const SpPoolTile p) {
+    constexpr int G = 256 / NQ, C = 4 * NQ;
+    constexpr int WPW = NQ >= 64 ? 1 : 64 / NQ;       // lane groups per wave
+    __shared__ short sslot[256];
+    __shared__ unsigned long long wq[IDENT ? 1 : SPT_CMAX * SPT_CMAX * SPT_SLOTS];
+    __shared__ __attribute__((aligned(16))) float wf[IDENT ? 4 : SPT_CMAX * SPT_CMAX * SPT_SLOTS];
+    __shared__ __attribute__((aligned(16))) float red[4][4][NQ * 4];          // [slot of the quartet][wave][channel]
+    const int b = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x;
+    const int ntile = p.nty * p.ntx;
+    const int ns = p.tile_ns[(long)b * ntile + tile], base = p.tile_base[(long)b * ntile + tile];
+    if (ns == 0 || base < 0) return;                  // (block-uniform)
+    const int ty = tile / p.ntx, tx = tile - ty * p.ntx;
+    const int Y0 = ty * SPT, X0 = tx * SPT;
+    const int Y1 = min(p.H - 1, Y0 + SPT - 1), X1 = min(p.W - 1, X0 + SPT - 1);
+    const int py = Y0 + (tid >> 4), px = X0 + (tid & 15);
+    const bool inside = py <= Y1 && px <= X1;
+    const int myslot = inside ? (int)p.slot[(long)b * p.H * p.W + (long)py * p.W + px] : -1;
+    sslot[tid] = (short)myslot;
+    int cy0, cx0, ncy, ncx;
+    Lerp2 ly = {0, 0, 1.f, 0.f}, lx = {0, 0, 1.f, 0.f};
+    if (IDENT) {
+        cy0 = Y0; cx0 = X0; ncy = Y1 - Y0 + 1; ncx = X1 - X0 + 1;
+    } else {
+        cy0 = lerp2_of(Y0, p.sh, p.h).i0; cx0 = lerp2_of(X0, p.sw, p.w).i0;
+        ncy = lerp2_of(Y1, p.sh, p.h).i1 - cy0 + 1; ncx = lerp2_of(X1, p.sw, p.w).i1 - cx0 + 1;
+        if (inside) { ly = lerp2_of(py, p.sh, p.h); lx = lerp2_of(px, p.sw, p.w); }
+    }
+    const int ncell = ncy * ncx;
+    const int q = tid % NQ, g = tid / NQ, wave = tid >> 6, lane = tid & 63;
+    const float* sb = p.s + (long)b * p.h * p.w * p.lds + 4 * q;
+    __syncthreads();
+    for (int s0 = 0; s0 < ns; s0 += SPT_SLOTS) {
+        const int nsc = min(SPT_SLOTS, ns - s0);
+        if (!IDENT) {
+            // per (cell, slot) the sum of the bilinear weights of the tile's pixels of that slot
+            for (int i = tid; i < ncell * SPT_SLOTS; i += 256) wq[i] = 0ull;
+            __syncthreads();
+            const int sl = myslot - s0;
+            if (inside && sl >= 0 && sl < nsc) {
+                const float FX = 1099511627776.f;      // 2^40
+                const int a0 = ((ly.i0 - cy0) * ncx - cx0) * SPT_SLOTS + sl, a1 = ((ly.i1 - cy0) * ncx - cx0) * SPT_SLOTS + sl;
+                atomicAdd(&wq[a0 + lx.i0 * SPT_SLOTS], (unsigned long long)(ly.l0 * lx.l0 * FX + 0.5f));
+                atomicAdd(&wq[a0 + lx.i1 * SPT_SLOTS], (unsigned long long)(ly.l0 * lx.l1 * FX + 0.5f));
+                atomicAdd(&wq[a1 + lx.i0 * SPT_SLOTS], (unsigned long long)(ly.l1 * lx.l0 * FX + 0.5f));
+                atomicAdd(&wq[a1 + lx.i1 * SPT_SLOTS], (unsigned long long)(ly.l1 * lx.l1 * FX + 0.5f));
+            }
+            __syncthreads();
+            for (int i = tid; i < ncell * SPT_SLOTS; i += 256) wf[i] = (float)wq[i] * (1.f / 1099511627776.f);
+            __syncthreads();
+        }
+        float4 acc[SPT_SLOTS];
+#pragma unroll
+        for (int k = 0; k < SPT_SLOTS; ++k) acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int c0 = g; c0 < ncell; c0 += G * SPT_CB) {
+            float4 v[SPT_CB];
+            int cc[SPT_CB];
+#pragma unroll
+            for (int k = 0; k < SPT_CB; ++k) {
+                const int c = c0 + k * G;
+                const int cy = c / ncx, cx = c - cy * ncx;
+                cc[k] = c < ncell ? (IDENT ? cy * SPT + cx : c) : -1;
+                v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (c < ncell) v[k] = ld4(sb + ((long)(cy0 + cy) * p.w + cx0 + cx) * p.lds);
+            }
+#pragma unroll
+            for (int k = 0; k < SPT_CB; ++k) {
+                if (cc[k] < 0) continue;
+                if (IDENT) {
+                    const int sl = (int)sslot[cc[k]] - s0;
+#pragma unroll
+                    for (int j = 0; j < SPT_SLOTS; ++j)
+                        if (j < nsc) {
+                            const float m = sl == j ? 1.f : 0.f;
+                            acc[j].x = fmaf(m, v[k].x, acc[j].x); acc[j].y = fmaf(m, v[k].y, acc[j].y);
+                            acc[j].z = fmaf(m, v[k].z, acc[j].z); acc[j].w = fmaf(m, v[k].w, acc[j].w);
+                        }
+                } else {
+                    const float* wr = wf + cc[k] * SPT_SLOTS;
+#pragma unroll
+                    for (int j4 = 0; j4 < SPT_SLOTS; j4 += 4)
+                        if (j4 < nsc) {
+                            const float4 w4 = ld4(wr + j4);
+                            const float ww[4] = {w4.x, w4.y, w4.z, w4.w};
+#pragma unroll
+                            for (int jj = 0; jj < 4; ++jj) {
+                                acc[j4 + jj].x = fmaf(ww[jj], v[k].x, acc[j4 + jj].x); acc[j4 + jj].y = fmaf(ww[jj], v[k].y, acc[j4 + jj].y);
+                                acc[j4 + jj].z = fmaf(ww[jj], v[k].z, acc[j4 + jj].z); acc[j4 + jj].w = fmaf(ww[jj], v[k].w, acc[j4 + jj].w);
+                            }
+                        }
+                }
+            }
+        }
+        // the lane groups of a wave by a fixed xor tree, the four waves through LDS in wave order, four slots at a time
+#pragma unroll
+        for (int j = 0; j < SPT_SLOTS; ++j)
+            if (j < nsc) {
+#pragma unroll
+                for (int off = NQ; off < 64; off <<= 1) {
+                    acc[j].x += __shfl_xor(acc[j].x, off); acc[j].y += __shfl_xor(acc[j].y, off);
+                    acc[j].z += __shfl_xor(acc[j].z, off); acc[j].w += __shfl_xor(acc[j].w, off);
+                }
+            }
+#pragma unroll
+        for (int j4 = 0; j4 < SPT_SLOTS; j4 += 4) {
+            if (j4 >= nsc) break;
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj)
+                if (j4 + jj < nsc && lane < NQ) st4(&red[jj][wave][4 * lane], acc[j4 + jj]);
+            __syncthreads();
+            for (int i = tid; i < 4 * NQ; i += 256) {
+                const int jj = i / NQ, qq = i - jj * NQ;
+                if (j4 + jj < nsc) {
+                    float4 t = ld4(&red[jj][0][4 * qq]);
+                    if (NQ < 64 || true) {
+#pragma unroll
+                        for (int wv = 1; wv < 4; ++wv) {
+                            const float4 u = ld4(&red[jj][wv][4 * qq]);
+                            t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
+                        }
+                    }
+                    st4(p.part + ((long)b * p.cap + base + s0 + j4 + jj) * C + 4 * qq, t);
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+// one wave per row: the partial sums of the row's tiles in raster order (or, for a row some tile of which did not fit, the row's
+// pixel list sampled directly), times 1 / area
+template <int NQ>
+__global__ __launch_bounds__(256) void sp_pool_tile_combine_kernel(const SpPoolTile p) {
+    constexpr int C = 4 * NQ, PPW = 64 / NQ;
+    const int b = blockIdx.y, lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (r >= p.Kmax) return;
+    const int j0 = p.row_start[(long)b * (p.Kmax + 1) + r], j1 = p.row_start[(long)b * (p.Kmax + 1) + r + 1];
+    const float inv = j1 > j0 ? 1.f / (float)(j1 - j0) : 0.f;
+    const int ntile = p.nty * p.ntx;
+    const int grp = lane / NQ, cl = lane % NQ;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (j1 > j0 && !p.row_flag[(long)b * p.Kmax + r]) {
+        const int32_t* bb = p.bbox + ((long)b * p.Kmax + r) * 4;
+        const int ty0 = bb[0], ty1 = bb[1], tx0 = bb[2], tx1 = bb[3];
+        const int bw = tx1 - tx0 + 1, nt = (ty1 - ty0 + 1) * bw;
+        // 64 tiles of the box at a time: a lane looks its tile's row list up (lists are a few entries long), then the wave adds the
+        // hits in tile order
+        for (int t0 = 0; t0 < nt; t0 += 64) {
+            const int t = t0 + lane;
+            int row_of_part = -1;
+            if (t < nt) {
+                const int tyy = ty0 + t / bw, txx = tx0 + t % bw;
+                const long ti = (long)b * ntile + (long)tyy * p.ntx + txx;
+                const int ns = p.tile_ns[ti], base = p.tile_base[ti];
+                const int32_t* rows = p.tile_rows + ti * 256;
+                int lo = 0, hi = ns;                         // ascending: binary search
+                while (lo < hi) {
+                    const int mid = (lo + hi) >> 1;
+                    if (rows[mid] < r) lo = mid + 1; else hi = mid;
+                }
+                if (lo < ns && rows[lo] == r) row_of_part = base + lo;
+            }
+            unsigned long long hit = __ballot(row_of_part >= 0);
+            while (hit) {
+                const int l = __ffsll((long long)hit) - 1;
+                hit &= hit - 1;
+                const int pr = __shfl(row_of_part, l);
+                if (grp == 0) {
+                    const float4 v = ld4(p.part + ((long)b * p.cap + pr) * C + 4 * cl);
+                    acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+                }
+            }
+        }
+    } else if (j1 > j0) {
+        const int32_t* list = p.pix_sorted + (long)b * p.H * p.W;
+        const float* base = p.s + (long)b * p.h * p.w * p.lds + 4 * cl;
+        for (int j = j0 + grp; j < j1; j += PPW) {
+            const int pp = list[j];
+            const int Y = fast_div(pp, p.dW), X = pp - Y * p.W;
+            const Lerp2 ly = lerp2_of(Y, p.sh, p.h), lx = lerp2_of(X, p.sw, p.w);
+            const float4 v00 = ld4(base + ((long)ly.i0 * p.w + lx.i0) * p.lds), v01 = ld4(base + ((long)ly.i0 * p.w + lx.i1) * p.lds);
+            const float4 v10 = ld4(base + ((long)ly.i1 * p.w + lx.i0) * p.lds), v11 = ld4(base + ((long)ly.i1 * p.w + lx.i1) * p.lds);
+            acc.x += ly.l0 * (lx.l0 * v00.x + lx.l1 * v01.x) + ly.l1 * (lx.l0 * v10.x + lx.l1 * v11.x);
+            acc.y += ly.l0 * (lx.l0 * v00.y + lx.l1 * v01.y) + ly.l1 * (lx.l0 * v10.y + lx.l1 * v11.y);
+            acc.z += ly.l0 * (lx.l0 * v00.z + lx.l1 * v01.z) + ly.l1 * (lx.l0 * v10.z + lx.l1 * v11.z);
+            acc.w += ly.l0 * (lx.l0 * v00.w + lx.l1 * v01.w) + ly.l1 * (lx.l0 * v10.w + lx.l1 * v11.w);
+        }
+#pragma unroll
+        for (int off = NQ; off < 64; off <<= 1) {
+            acc.x += __shfl_xor(acc.x, off); acc.y += __shfl_xor(acc.y, off);
+            acc.z += __shfl_xor(acc.z, off); acc.w += __shfl_xor(acc.w, off);
+        }
+    }
+    if (grp == 0) st4(p.out + ((long)b * p.Kmax + r) * p.ldo + 4 * cl, make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv));
+}
+extern "C" size_t wesup_sp_pool_tiles_workspace_bytes(int B, int H, int W, int C, int Kmax) {
+    return (B > 0 && C > 0) ? (size_t)B * wesup_sp_tiles_part_rows(H, W, Kmax) * (C < 256 ? C : 256) * sizeof(float) : 0;
+}
+// 1 = wesup_sp_pool_tiles_fwd covers this level: the tile's cells of a coarse s must fit SPT_CMAX per dimension
+extern "C" int wesup_sp_pool_tiles_supported(int h, int w, int H, int W, int C) {
+    if (h <= 0 || w <= 0 || H < h || W < w || (C != 32 && C != 64 && C != 128 && (C % 256))) return 0;
+    if (h == H && w == W) return 1;
+    const double shd = H > 1 ? (double)(h - 1) / (H - 1) : 0.0, swd = W > 1 ? (double)(w - 1) / (W - 1) : 0.0;
+    return ((SPT - 1) * shd + 3.0 <= SPT_CMAX && (SPT - 1) * swd + 3.0 <= SPT_CMAX) ? 1 : 0;
+}
+extern "C" int wesup_sp_pool_tiles_fwd(const float* s, const uint8_t* slot, const int32_t* tile_ns, const int32_t* tile_base,
+                                       const int32_t* tile_rows, const int32_t* row_flag, const int32_t* bbox,
+                                       const int32_t* pix_sorted, const int32_t* row_start, float* sp_feat, int B, int h, int w,
+                                       int H, int W, int C, int ldo, int coff, int Kmax, void* ws, size_t ws_bytes, void* stream) {
+    if (!s || !slot || !tile_ns || !tile_base || !tile_rows || !row_flag || !bbox || !pix_sorted || !row_start || !sp_feat || !ws ||
+        B <= 0 || B > 65535 || Kmax <= 0 || (ldo % 4) || (coff % 4) || coff + C > ldo || !wesup_sp_pool_tiles_supported(h, w, H, W, C))
+        return WESUP_ERR_INVALID;
+    if (ws_bytes < wesup_sp_pool_tiles_workspace_bytes(B, H, W, C, Kmax)) return WESUP_ERR_WORKSPACE;
+    SpPoolTile p = {};
+    p.part = (float*)ws; p.slot = slot; p.tile_ns = tile_ns; p.tile_base = tile_base; p.tile_rows = tile_rows; p.row_flag = row_flag;
+    p.bbox = bbox; p.pix_sorted = pix_sorted; p.row_start = row_start;
+    p.h = h; p.w = w; p.H = H; p.W = W; p.lds = C; p.ldo = ldo; p.Kmax = Kmax; p.nty = ceil_div(H, SPT); p.ntx = ceil_div(W, SPT);
+    p.cap = wesup_sp_tiles_part_rows(H, W, Kmax);
+    p.sh = H > 1 ? (float)(h - 1) / (float)(H - 1) : 0.f; p.sw = W > 1 ? (float)(w - 1) / (float)(W - 1) : 0.f;
+    p.dW = make_fastdiv(W);
+    const bool ident = h == H && w == W;
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 gt((unsigned)(p.nty * p.ntx), B), gc(ceil_div(Kmax, 4), B);
+    // a wave's 64 lanes cover 256 channels of a cell: wider maps go in slabs of 256 channels (cell stride C)
+    for (int c0 = 0; c0 < C; c0 += 256) {
+        const int cw = C - c0 < 256 ? C - c0 : 256;
+        p.s = s + c0; p.out = sp_feat + coff + c0;
+#define WESUP_LAUNCH_PT(NQ_)                                                                                   \
+        do {                                                                                                   \
+            if (ident) WESUP_LAUNCH((sp_pool_tile_kernel<NQ_, true>), gt, dim3(256), 0, st, p);                \
+            else WESUP_LAUNCH((sp_pool_tile_kernel<NQ_, false>), gt, dim3(256), 0, st, p);                     \
+            WESUP_LAUNCH(sp_pool_tile_combine_kernel<NQ_>, gc, dim3(256), 0, st, p);                           \
+        } while (0)
+        switch (cw) {
+            case 32: WESUP_LAUNCH_PT(8); break;
+            case 64: WESUP_LAUNCH_PT(16); break;
+            case 128: WESUP_LAUNCH_PT(32); break;
+            case 256: WESUP_LAUNCH_PT(64); break;
+            default: return WESUP_ERR_INVALID;
+        }
+#undef WESUP_LAUNCH_PT
+    }
     WESUP_CHECK_LAUNCH();
     return WESUP_OK;
 }

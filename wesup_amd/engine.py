@@ -178,6 +178,10 @@ class WesupEngine:
         # gradient -- in one pass over it on the main stream (ops.winograd_dual_transform): the gradient is read once instead of
         # once per stream and twelve launches go
         self.dual_transform = True
+        # The fused upsample + scatter-mean of the shallow layers tile by tile (ops.sp_pool_tiles_fwd: every tile of the image
+        # streams its cells of the layer's output once, in raster order) instead of superpixel by superpixel through the pixel
+        # lists (ops.sp_pool_upsample_fwd: chains of dependent loads, three to five times slower beside the other streams)
+        self.pool_tiles = True
         # Orderings of the schedule that were measured once and are fixed (each is bit-neutral): the side-branch
         # work of layer l behind the input transform of layer l + 1; a layer's weight gradient behind its input gradient except
         # for the lowest trainable layer's neighbour; every G_l before the side convs' own weight gradients, those of the deep
@@ -529,12 +533,16 @@ class WesupEngine:
                     ops.sp_interp_matrix(meta, g.h, g.w, out=g.Wm)
                 ops.transpose_batched([(g.Wm[i], g.WmT[i]) for g in b.groups for i in range(B)])
                 T.end(tok, 0.0)
+        fused = self.fuse_pool_fwd
+        tiles = fused and self.pool_tiles and any(b.group_of[l] is None for l in range(13))
+        if tiles:
+            with self._OnSide(self):     # (the label maps' tile tables: once per step, for every shallow layer)
+                ops.sp_tiles(meta)
         pending_side = None              # the side-branch work of the previous layer, when it is queued behind this layer's transform
         cur, cur_relu = b.x0, False      # the layer's input tensor, and whether its ReLU is still to be applied on load
         b.x_in, b.x_relu = [None] * 13, [False] * 13
         b.wino_fwd = list(self._route)
         b.relu_stored = all(b.yr_wanted[l] for l in range(12) if not POOL_AFTER[l])
-        fused = self.fuse_pool_fwd
         b.fm_valid = not fused
         fm2d = None if fused else b.fm.view(B * H * W, FM_CHANNELS)
         for l, (ci, co) in enumerate(CONV_CH):
@@ -608,7 +616,7 @@ class WesupEngine:
                 T.end(tok, 2.0 * B * h * w * co * ((3 if l == 0 else ci) * 9 + (co // 2 if side_in_conv else 0)))
             # side branch of this layer: 1x1 conv on the pre-ReLU tap, then either the fused upsample+scatter-mean
             # straight into the superpixel feature slice, or upsample into fm's channel slice
-            def side_work(l=l, ci=ci, co=co, h=h, w=w, off=off, ws=ws, commute=commute, s_l=s_l, s2d=s2d, side_in_conv=side_in_conv):
+            def side_work(l=l, ci=ci, co=co, h=h, w=w, off=off, ws=ws, commute=commute, s_l=s_l, s2d=s2d, side_in_conv=side_in_conv, tiles=tiles):
               with self._OnSide(self):
                 grp = b.groups[b.group_of[l]] if b.group_of[l] is not None else None
                 if ('side_fwd_shallow' in self._diag_skip and grp is None) or ('side_fwd_deep' in self._diag_skip and grp is not None):
@@ -617,7 +625,10 @@ class WesupEngine:
                     if b.ybar[l] is None:
                         b.ybar[l] = torch.empty(B, Kmax, co, dtype=torch.float32, device=self.device)
                     tok = T.begin('sp_pool_up_fwd')          # (commuted layers are the gather layers: no interpolation matrix)
-                    ops.sp_pool_upsample_fwd(b.y[l], meta, b.ybar[l], 0)
+                    if tiles and ops.sp_pool_tiles_supported(h, w, H, W, co):
+                        ops.sp_pool_tiles_fwd(b.y[l], meta, b.ybar[l], 0)
+                    else:
+                        ops.sp_pool_upsample_fwd(b.y[l], meta, b.ybar[l], 0)
                     T.end(tok, 4.0 * B * (h * w * co + H * W + Kmax * co))
                     tok = T.begin('side_fwd')
                     ops.gemm_nt(b.ybar[l].view(B * Kmax, co), ws, p[f'side_conv{off}.bias'],
@@ -638,7 +649,10 @@ class WesupEngine:
                         T.end(tok, 2.0 * B * Kmax * g.h * g.w * g.C)
                 elif fused:
                     tok = T.begin('sp_pool_up_fwd')
-                    ops.sp_pool_upsample_fwd(s_l, meta, b.sp_in, off)
+                    if tiles and ops.sp_pool_tiles_supported(h, w, H, W, co // 2):
+                        ops.sp_pool_tiles_fwd(s_l, meta, b.sp_in, off)
+                    else:
+                        ops.sp_pool_upsample_fwd(s_l, meta, b.sp_in, off)
                     T.end(tok, 4.0 * B * (h * w * (co // 2) + H * W + Kmax * (co // 2)))
                 elif s_l is not None:
                     tok = T.begin('upsample_fwd')

@@ -179,16 +179,22 @@ def transpose(a, out=None):
     return out
 
 
+TRANSPOSE_MAX = 40      # items per wesup_transpose_batched launch (csrc/spatial.hip)
+
+
 def transpose_batched(pairs):
-    """[(a (r, c), out (c, r)), ...]: every out = a^T in one launch (at most 40 pairs)."""
-    n = len(pairs)
-    arr = (_lib.TransposeItem * n)()
-    for i, (a, out) in enumerate(pairs):
+    """[(a (r, c), out (c, r)), ...]: every out = a^T, TRANSPOSE_MAX pairs per launch (a batch of 32 images at 480 x 480 hands over
+    64 interpolation-pooling matrices: two launches)."""
+    for a, out in pairs:
         _chk(a, name='a'); _chk(out, name='out')
-        r, c = a.shape
-        assert out.shape == (c, r)
-        arr[i].src, arr[i].dst, arr[i].rows, arr[i].cols = a.data_ptr(), out.data_ptr(), r, c
-    _lib.call('wesup_transpose_batched', ctypes.cast(arr, ctypes.c_void_p), n, _stream())
+        assert out.shape == (a.shape[1], a.shape[0])
+    for i0 in range(0, len(pairs), TRANSPOSE_MAX):
+        part = pairs[i0:i0 + TRANSPOSE_MAX]
+        n = len(part)
+        arr = (_lib.TransposeItem * n)()
+        for i, (a, out) in enumerate(part):
+            arr[i].src, arr[i].dst, arr[i].rows, arr[i].cols = a.data_ptr(), out.data_ptr(), a.shape[0], a.shape[1]
+        _lib.call('wesup_transpose_batched', ctypes.cast(arr, ctypes.c_void_p), n, _stream())
 
 
 def scale_rows_by_area(x, area):
@@ -198,6 +204,11 @@ def scale_rows_by_area(x, area):
     assert x.dim() == 3 and area.shape == x.shape[:2]
     _lib.call('wesup_scale_rows_by_area', _p(x), _p(area), x.shape[0] * x.shape[1], x.shape[2], _stream())
     return x
+
+
+def winograd_fused_min_blocks():
+    """The process-wide rule behind wesup_winograd_fused_route: grids below this many blocks take the two-kernel route."""
+    return int(_lib.load().wesup_winograd_set_fused_min_blocks(-1))
 
 
 # ---------------------------------------------------------------- sync edges / step plans (csrc/plan.hip)
@@ -966,7 +977,7 @@ class SuperpixelMeta:
     """Device-side result of wesup_sp_preprocess for a batch of label maps (padded to Kmax rows per image)."""
     __slots__ = ('B', 'H', 'W', 'C', 'Kmax', 'labels', 'mask', 'n_sp', 'n_l', 'perm', 'inv_perm', 'area_new',
                  'sp_labels', 'new_row', 'row_start', 'pix_sorted', 'status', 'n_sp_host', 'seg_start', 'unit_row',
-                 'Umax', 'counts')
+                 'Umax', 'counts', 'tiles')
 
     def check(self):
         """Host sync: raise on label-map errors the reference would turn into NaNs (models/wesup.py:57-61)."""
@@ -1009,6 +1020,7 @@ def sp_preprocess(labels, mask, Kmax, n_classes=2, n_sp_host=None, into=None, co
         m.Umax = _lib.load().wesup_sp_max_units(HW, Kmax)
         m.seg_start = torch.empty(B, Kmax + 1, **i32)
         m.unit_row = torch.empty(B, m.Umax, **i32)
+        m.tiles = None
     m.labels, m.mask, m.n_sp_host = labels, mask, n_sp_host
     nb = _lib.load().wesup_sp_preprocess_workspace_bytes(B, HW, C, Kmax)
     ws = workspace(nb, dev, 'sp')
@@ -1054,6 +1066,49 @@ def sp_pool_upsample_fwd(s, meta, out, coff):
     _lib.call('wesup_sp_pool_upsample_fwd', _p(s), _p(meta.pix_sorted), _p(meta.row_start), _p(meta.seg_start),
               _p(meta.unit_row), _p(out), B, h, w, meta.H, meta.W, C, out.shape[2], coff, meta.Kmax, meta.Umax, _p(ws), nb,
               _stream())
+    return out
+
+
+class _SpTiles:
+    __slots__ = ('slot', 'tile_ns', 'tile_base', 'tile_rows', 'alloc', 'row_flag', 'bbox', 'ntile')
+
+
+def sp_tiles(meta):
+    """The tile tables of the label maps of ``meta`` (wesup_sp_tiles): once per step, behind sp_preprocess on the same stream; the
+    buffers live with the meta (a recorded step plan holds their addresses)."""
+    B, H, W, Kmax = meta.B, meta.H, meta.W, meta.Kmax
+    t = meta.tiles
+    if t is None:
+        dev = meta.new_row.device
+        i32 = dict(dtype=torch.int32, device=dev)
+        t = _SpTiles()
+        t.ntile = ((H + 15) // 16) * ((W + 15) // 16)
+        t.slot = torch.empty(B, H * W, dtype=torch.uint8, device=dev)
+        t.tile_ns = torch.empty(B, t.ntile, **i32); t.tile_base = torch.empty(B, t.ntile, **i32)
+        t.tile_rows = torch.empty(B, t.ntile, 256, **i32)
+        t.alloc = torch.empty(B, **i32); t.row_flag = torch.empty(B, Kmax, **i32); t.bbox = torch.empty(B, Kmax, 4, **i32)
+        meta.tiles = t
+    _lib.call('wesup_sp_tiles', _p(meta.new_row), B, H, W, Kmax, _p(t.slot), _p(t.tile_ns), _p(t.tile_base), _p(t.tile_rows),
+              _p(t.alloc), _p(t.row_flag), _p(t.bbox), _stream())
+    return t
+
+
+def sp_pool_tiles_supported(h, w, H, W, C):
+    return bool(_lib.load().wesup_sp_pool_tiles_supported(h, w, H, W, C))
+
+
+def sp_pool_tiles_fwd(s, meta, out, coff):
+    """sp_pool_upsample_fwd tile by tile (wesup_sp_pool_tiles_fwd; needs sp_tiles(meta) of this step's label maps)."""
+    _chk(s, name='s'); _chk(out, name='out')
+    B, h, w, C = s.shape
+    t = meta.tiles
+    assert t is not None, 'sp_tiles(meta) first'
+    assert out.shape[:2] == (B, meta.Kmax) and B == meta.B and coff + C <= out.shape[2]
+    nb = _lib.load().wesup_sp_pool_tiles_workspace_bytes(B, meta.H, meta.W, C, meta.Kmax)
+    ws = workspace(nb, s.device, 'pool_up')
+    _lib.call('wesup_sp_pool_tiles_fwd', _p(s), _p(t.slot), _p(t.tile_ns), _p(t.tile_base), _p(t.tile_rows), _p(t.row_flag),
+              _p(t.bbox), _p(meta.pix_sorted), _p(meta.row_start), _p(out), B, h, w, meta.H, meta.W, C, out.shape[2], coff,
+              meta.Kmax, _p(ws), nb, _stream())
     return out
 
 

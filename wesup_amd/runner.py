@@ -11,8 +11,11 @@ pixel masks as (B,C,H,W) tensors, accuracy / dice as metrics, the fused SGD -- i
 * loss, per-image loss terms, segmentation sums and the superpixel counts sit in one device buffer that ONE copy brings to
   pinned host memory; the host waits for it behind the queued backward, checks for NaN, and only then queues the optimiser
   (``ValueError('Loss is nan!')`` with the weights untouched, models/base.py:202-203);
-* the third occurrence of a shape records the walk into a step plan (csrc/plan.hip), the fourth records it again and the
-  two recordings are compared node by node; when they are identical, later iterations of that shape REPLAY the plan from C
+* the FIRST occurrence of a shape records the walk into a step plan (csrc/plan.hip), the second records it again and the
+  two recordings are compared node by node; when they are identical, the third and later iterations of that shape REPLAY the
+  plan from C (round 4 walked twice before the first recording: with the reference's ~100 shapes x 85 images per epoch,
+  utils/data.py:98-101, the first epochs hardly replayed.  A first walk that allocates -- the shape's buffer set, a workspace
+  that grows -- records addresses that are final when the walk ends; the twin either confirms them or replaces the candidate)
   (``wesup_plan_replay``): ~330 launches without Python or ctypes in between.  Host work inside the iteration (the NaN check, a
   gradient bucket handed to RCCL) splits the replay into segments.  Anything that moves a buffer (a workspace that grew, the
   engine's buffer cache evicting the shape) or changes the walk (an engine switch, the learning rate, frozen parameters)
@@ -33,7 +36,7 @@ from .utils import is_empty_tensor
 from .utils import metrics as M
 
 RB_SLOT = 40          # event slot of the read-back copy (the engine uses 0 .. 27 and 64 ..)
-RECORD_AT = 2         # eager iterations of a shape before the first recording
+RECORD_AT = 0         # eager iterations of a shape before the first recording
 MAX_RECORD_TRIES = 4
 MAX_STATES = 256      # shapes with a state (inputs, read-back block, plan) of their own, least recently used first out
 
@@ -124,12 +127,18 @@ class StepRunner:
             counts = [int(seg[b].max()) + 1 for b in range(B)]
         return img, pixel_mask, point_mask, seg, counts
 
-    def _signature(self, eng):
+    def _signature(self, eng, B, H, W):
+        """Everything a recorded plan depends on besides its own buffer set (bufs_gen) and the shared workspaces (ws_generation):
+        the settings that shape the launch list AND the identity of every long-lived allocation whose address the launches carry
+        (a plan holds raw device addresses: replaying it over a freed or re-made buffer corrupts silently)."""
         t, o = self.t, self.t.optimizer
         g = o.param_groups[0]
         sw = tuple(sorted((k, v) for k, v in vars(eng).items() if isinstance(v, (bool, int, type(None))) and not k.startswith('_')
                           and k not in ('buf_generation', 'max_cached_shapes', 'max_cached_pixels')))
         red = t.reducer
+        m = t.model
+        pk = eng._packed
+        panels = None if pk is None else tuple(0 if u is None else u.data_ptr() for u in list(pk.uf) + list(pk.ud))
         return (sw, eng.route_fn, type(eng).WINOGRAD_CONV_MIN_CI, type(eng).WINOGRAD_TILE, tuple(sorted(eng._diag_skip)),
                 ops.STREAMK_FWD, ops.STREAMK_DGRAD, ops.STREAMK_GEMM, ops.STREAMK,
                 g['lr'], g['momentum'], g['weight_decay'], o.grad_scale, o._first,
@@ -137,7 +146,11 @@ class StepRunner:
                 float(t.kwargs.get('propagate_threshold')), float(t.kwargs.get('propagate_weight')),
                 bool(t.kwargs.get('enable_propagation')), float(t.kwargs.get('epsilon')),
                 None if red is None else (id(red), t.world_size, red.bucket_elems, red.force),
-                ops._stream().value)
+                ops._stream().value,
+                # the engine object itself (model.to(device) re-makes it and restarts buf_generation), the per-shape routing result
+                # and the process-wide rule behind it, the flat parameter / gradient / momentum buffers, the Winograd filter panels
+                id(eng), tuple(eng.route(B, H, W)), ops.winograd_fused_min_blocks(),
+                m._flat.data_ptr(), m._flat_grad.data_ptr(), o._vflat.data_ptr(), panels)
 
     # ------------------------------------------------------------------ the iteration
     def run(self, parsed):
@@ -176,7 +189,7 @@ class StepRunner:
         st.n_sp_host = counts
 
         timing = eng.timer.enabled or (t.reducer is not None and t.reducer.profile)
-        sig = self._signature(eng) if self.replay else None
+        sig = self._signature(eng, B, H, W) if self.replay else None
         gens = (ops.ws_generation, eng.bufs_gen(B, H, W, st.y_all.shape[1]))
         if st.plan is not None and (st.sig != sig or st.gens != gens):
             st.plan = st.cand = None
@@ -184,18 +197,23 @@ class StepRunner:
             self.stats['dropped'] += 1
         metrics = {}
         if st.plan is not None and not timing:
+            if st.meta is not None:                   # the replay does not re-enter sp_preprocess: this batch's host-side counts
+                st.meta.n_sp_host = counts
             host = self._replay(st, metrics)
             self.stats['replayed'] += 1
         else:
             if st.cand is not None and st.sig != sig:       # settings changed since the first recording: it has no twin to wait for
                 st.cand = None
-            record = self.replay and not timing and st.count >= RECORD_AT and st.tries < MAX_RECORD_TRIES
+            # (the very first optimiser step of a run differs from every later one -- buf = g --: not worth recording)
+            record = self.replay and not timing and st.count >= RECORD_AT and st.tries < MAX_RECORD_TRIES and not t.optimizer._first
             plan = _Plan() if record else None
             host = self._walk(st, metrics, want_seg, plan)
             st.count += 1
             if plan is not None:
                 self.stats['recorded'] += 1
                 gens = (ops.ws_generation, eng.bufs_gen(B, H, W, st.y_all.shape[1]))
+                sig = self._signature(eng, B, H, W)           # the state the recording ENDED in (a first walk allocates the filter
+                                                              # panels and clears the optimiser's first-step flag: the twin decides)
                 if st.cand is not None and st.gens == gens and _lib.load().wesup_plan_diff(st.cand.h, plan.h) == 0:
                     st.plan, st.cand = plan, None
                 else:
@@ -327,7 +345,8 @@ class StepRunner:
         m.fm_size = (st.img.shape[2], st.img.shape[3])
         m._last_meta = st.meta
         m._padded = (st.feats, st.sp_pred)
-        m.sp_features = st.feats
+        # (models/wesup.py:287-292: one image -> (n_sp, D), as the general path publishes it)
+        m.sp_features = st.feats[0, :int(st.n_sp_host[0])] if st.feats.shape[0] == 1 and st.n_sp_host is not None else st.feats
         m.sp_pred = None
 
     def _finish(self, st, host, metrics, want_seg, names, H, W):
