@@ -607,18 +607,11 @@ def worker(args):
                 by = 4.0 * B * (2112 * H * W + H * W + g * g * 2112)
                 a = by / (pool_ms * 1e-3) / 1e9
                 sm_in = (rin or {}).get('scatter_mean', {})
-                out['roofline_scatter_mean'] = {
-                    'bound': 'hbm', 'kernel': 'sp_pool_fwd_kernel (superpixel scatter-mean over the materialised '
-                                              '(HW x 2112) feature map; the step itself uses the fused upsample+scatter-mean)',
-                    'achieved': round(a, 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': round(a / PEAK_HBM_GBS, 4),
-                    'frac_of_measured_copy_6290': round(a / 6290.0, 4),
-                    'traffic': sm_in.get('hbm_bytes_per_launch'),
-                    'traffic_how': (f"{rin['file']}: FETCH_SIZE x2 + WRITE_SIZE of sp_pool_fwd_kernel in the PMC passes over "
-                                    'this command') if sm_in else None,
-                    'avg_launch_us': round(pool_ms * 1e3, 2), 'algorithmic_bytes': by}
-                # the scatter-mean the STEP runs: fused upsample + pooling of the shallow layers (sp_pool_up_fwd), the
-                # interpolation-pooling matrix of the deep layers and its application (interp_matrix + sp_pool_mat_fwd)
-                ftags = ('sp_pool_up_fwd', 'sp_pool_mat_fwd', 'interp_matrix')
+                # The scatter-mean the STEP runs leads: tile-form pooling of the native-resolution layers
+                # (sp_pool_tile_kernel + combine), segment-form pooling of the coarse gather layers (sp_pool_up_fwd_kernel), the
+                # interpolation-pooling matrix of the deep layers and its application (interp_matrix + sp_pool_mat_fwd), on ITS OWN
+                # byte model; the materialised-map kernel of SURVEY 8(d) (never launched by the step) is the secondary figure.
+                ftags = ('sp_pool_up_fwd', 'sp_pool_mat_fwd', 'interp_matrix', 'sp_tiles')
                 f_in = sum(allk[t][0] for t in ftags if t in allk) / n_extra
                 f_alone = sum(iso[t][0] for t in ftags if t in iso) / 2 if iso is not None else None
                 dims, hh, ww = [], H, W
@@ -627,32 +620,47 @@ def worker(args):
                     if l in (1, 3, 6, 9):
                         hh, ww = hh // 2, ww // 2
                 own = 0.0
-                commuted = trainer.model.engine.commute_side
+                eng_ = trainer.model.engine
+                commuted = eng_.commute_side
                 for (h_, w_, c_) in dims:
                     matrix = (h_, w_) != (H, W) and h_ * w_ <= 4096
                     # read once: the side output -- or, for the gather layers with the side conv commuted behind the pooling,
                     # the conv output itself (twice the channels; the side output is never formed)
                     own += 4.0 * h_ * w_ * (c_ if (matrix or not commuted) else 2 * c_)
-                    own += 0.0 if matrix else 4.0 * H * W                        # gather layers: the sorted pixel list
+                    if not matrix:              # gather layers: slot bytes of the tile form (native resolution) or the sorted pixel list
+                        own += 1.0 * H * W if ((h_, w_) == (H, W) and eng_.pool_tiles) else 4.0 * H * W
                 for (h_, w_) in sorted({(h_, w_) for (h_, w_, _) in dims if (h_, w_) != (H, W) and h_ * w_ <= 4096}):
                     own += 4 * 4.0 * g * g * h_ * w_                             # Wm and its transpose: written, then read
                 own = B * (own + 4.0 * g * g * 2112)
-                fused = {'kernels': 'sp_pool_up_fwd_kernel (7 shallow layers) + sp_interp_matrix_kernel + gemm_tn (6 deep layers)',
-                         'ms_per_step_in_step': round(f_in, 4), 'ms_per_step_alone': None if f_alone is None else round(f_alone, 4),
-                         'materialised_model': {'bytes': by, 'what': 'SURVEY 8(d): 2112*HW*4 + HW*4 + N*2112*4 per image -- the bytes of '
-                                                                     'the scatter-mean over a materialised feature map, which these '
-                                                                     'kernels never read: the fraction may exceed 1'},
-                         'own_model': {'bytes': own, 'what': 'what the pooling reads at native resolution (gather layers: the conv '
-                                                             'output, all C channels, the side conv being applied to the pooled rows; '
-                                                             'matrix layers: the side output) + pixel lists of the gather layers + '
-                                                             'the interpolation-pooling matrices (written and read) + N*2112*4'}}
-                for key, bts in (('materialised_model', by), ('own_model', own)):
-                    for nm, ms_ in (('in_step', f_in), ('alone', f_alone)):
-                        if ms_:
-                            gb = bts / (ms_ * 1e-3) / 1e9
-                            fused[key][f'gbs_{nm}'] = round(gb, 1)
-                            fused[key][f'frac_{nm}'] = round(gb / PEAK_HBM_GBS, 4)
-                out['roofline_scatter_mean']['fused'] = fused
+                sm = {'bound': 'hbm',
+                      'kernel': 'the scatter-mean of the training step: sp_pool_tile_kernel + combine (conv1_1, conv1_2 at native resolution), '
+                                'sp_pool_up_fwd_kernel (conv2_1 ... conv3_3, upsample fused), sp_interp_matrix_kernel + gemm_tn (the six deep layers)',
+                      'algorithmic_bytes': own,
+                      'bytes_what': 'what the pooling reads at the layers\' own resolution (gather layers: the conv output, all C channels, the '
+                                    'side conv being applied to the pooled rows; matrix layers: the side output) + slot bytes / pixel lists of '
+                                    'the gather layers + the interpolation-pooling matrices (written and read) + N*2112*4',
+                      'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'ms_per_step_in_step': round(f_in, 4),
+                      'ms_per_step_alone': None if f_alone is None else round(f_alone, 4)}
+                if f_alone:
+                    sm['achieved'] = round(own / (f_alone * 1e-3) / 1e9, 1)
+                    sm['frac'] = round(sm['achieved'] / PEAK_HBM_GBS, 4)
+                    sm['achieved_how'] = 'alone on the GPU (the single-stream extra steps); in the 3-stream step the launches share the GPU: in_step'
+                if f_in:
+                    sm['in_step'] = {'achieved': round(own / (f_in * 1e-3) / 1e9, 1), 'frac': round(own / (f_in * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)}
+                by = 4.0 * B * (2112 * H * W + H * W + g * g * 2112)
+                a = by / (pool_ms * 1e-3) / 1e9
+                sm_in = (rin or {}).get('scatter_mean', {})
+                sm['materialised'] = {
+                    'kernel': 'sp_pool_fwd_kernel: the scatter-mean over a materialised (HW x 2112) feature map (SURVEY 8(d)\'s byte model: '
+                              '2112*HW*4 + HW*4 + N*2112*4 per image); launched by bench.py after the timed region only',
+                    'achieved': round(a, 1), 'frac': round(a / PEAK_HBM_GBS, 4), 'frac_of_measured_copy_6290': round(a / 6290.0, 4),
+                    'traffic': sm_in.get('hbm_bytes_per_launch'),
+                    'traffic_how': (f"{rin['file']}: FETCH_SIZE x2 + WRITE_SIZE of sp_pool_fwd_kernel in the PMC passes over "
+                                    'this command') if sm_in else None,
+                    'avg_launch_us': round(pool_ms * 1e3, 2), 'algorithmic_bytes': by,
+                    'step_path_on_this_model': {k: round(by / (ms_ * 1e-3) / 1e9 / PEAK_HBM_GBS, 4) for k, ms_ in
+                                                (('frac_in_step', f_in), ('frac_alone', f_alone)) if ms_}}
+                out['roofline_scatter_mean'] = sm
         if use_dist:
             out['rank_time'] = rank_time              # spread of the per-rank wall time of the timed region
             out['collective'] = {'backend': backend, 'ranks': dist.get_world_size(),

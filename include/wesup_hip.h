@@ -345,16 +345,17 @@ int wesup_sp_pool_upsample_fwd(const float* s, const int32_t* pix_sorted, const 
                                const int32_t* seg_start, const int32_t* unit_row, float* sp_feat,
                                int B, int h, int w, int H, int W, int C, int ldo, int coff, int Kmax, int Umax,
                                void* ws, size_t ws_bytes, void* stream);
-/* The same fused upsample + scatter-mean (torch.mm over the upsampled side output, models/wesup.py:254-255,283-285) tile by
- * tile: the form the training step runs.  wesup_sp_tiles, once per label map: the image in 16 x 16-pixel tiles; per tile the rows
- * present (ascending) and every pixel's slot in that list; per row the box of tiles it touches; part rows handed out per tile.
+/* The scatter-mean of a side output at the image's OWN resolution (h == H, w == W: torch.mm over it, models/wesup.py:283-285)
+ * tile by tile: the form the training step runs for conv1_1 / conv1_2.  wesup_sp_tiles, once per label map: the image in
+ * 16 x 16-pixel tiles; per tile the rows present (ascending) and every pixel's slot in that list; per row the box of tiles it
+ * touches; part rows per tile (prefix sums).
  *   slot [B][HW] uint8, tile_ns / tile_base [B][ntile], tile_rows [B][ntile][256], alloc [B], row_flag [B][Kmax], bbox [B][Kmax][4]
  *   (ntile = ceil(H/16) * ceil(W/16)).
- * wesup_sp_pool_tiles_fwd, per side output s (B,h,w,C) (C = 32, 64, 128 or a multiple of 256; h == H or the upsampling factor
- * >= 1.67, wesup_sp_pool_tiles_supported): a block streams its tile's cells of s once, in raster order, into one partial sum per
- * (tile, row) -- every load address known up front --, a second launch adds a row's partial sums over its box of tiles in raster
- * order and scales by 1 / area into sp_feat[b][r][coff .. coff + C).  Bitwise reproducible.  Rows of tiles that hold more rows than
- * the part buffer has room for (wesup_sp_tiles_part_rows: 6 per tile + Kmax per image) are summed from their pixel lists instead. */
+ * wesup_sp_pool_tiles_fwd, per side output s (B,H,W,C) (C = 32, 64, 128 or a multiple of 256; wesup_sp_pool_tiles_supported): a
+ * block streams its tile of s once, in raster order, into one partial sum per (tile, row) -- every load address known up front --,
+ * a second launch adds a row's partial sums over its box of tiles in raster order and scales by 1 / area into
+ * sp_feat[b][r][coff .. coff + C).  Bitwise reproducible.  Rows of tiles that hold more rows than the part buffer has room for
+ * (wesup_sp_tiles_part_rows: 6 per tile + Kmax per image) are summed from their pixel lists instead. */
 int wesup_sp_tiles_part_rows(int H, int W, int Kmax);
 int wesup_sp_tiles(const int32_t* new_row, int B, int H, int W, int Kmax, uint8_t* slot, int32_t* tile_ns, int32_t* tile_base,
                    int32_t* tile_rows, int32_t* alloc, int32_t* row_flag, int32_t* bbox, void* stream);

@@ -1052,8 +1052,7 @@ def test_sp_pool_skewed_maps_multi_segment_rows(ops, H, W, g):
 
 # ---------------------------------------------------------------- fused upsample + scatter-mean, tile by tile (round 5)
 def _tile_pool_cases(H, W):
-    return [(H, W, 32, 0), (H, W, 64, 32), (H // 2, W // 2, 64, 64), (H // 2, W // 2, 128, 128), (H // 4, W // 4, 128, 128),
-            (H // 4, W // 4, 256, 0), (max(1, H // 8), max(1, W // 8), 512, 256)]
+    return [(H, W, 32, 0), (H, W, 64, 32), (H, W, 128, 128), (H, W, 256, 0), (H, W, 512, 256), (H // 2, W // 2, 64, 64)]
 
 
 @pytest.mark.parametrize('B,H,W,g', [(2, 32, 32, 4), (1, 96, 80, 7), (2, 120, 136, 9), (1, 53, 47, 5)])
@@ -1091,7 +1090,7 @@ def test_sp_pool_tiles_equals_the_pixel_list_form(ops, B, H, W, g):
     C = 768
     for (h, w, Cs, coff) in _tile_pool_cases(H, W):
         if not ops.sp_pool_tiles_supported(h, w, H, W, Cs):
-            assert (h, w) != (H, W) and h * 1.6 > H                     # only upsampling factors below 1.67 are left to the other form
+            assert (h, w) != (H, W) or Cs == 512                        # the tile form is for native resolution (coarse layers: pixel lists)
             continue
         sl = rnd(B, h, w, Cs, seed=9).to(d)
         want = torch.zeros(B, Kmax, C, device=d)
@@ -1099,7 +1098,8 @@ def test_sp_pool_tiles_equals_the_pixel_list_form(ops, B, H, W, g):
         got = torch.full((B, Kmax, C), 7.0, device=d)
         ops.sp_pool_tiles_fwd(sl, m, got, coff)
         assert rel_err(got[..., coff:coff + Cs], want[..., coff:coff + Cs]) < 1e-5
-        assert float((got[..., :coff] - 7).abs().max() if coff else 0.0) == 0.0 and float((got[..., coff + Cs:] - 7).abs().max()) == 0.0
+        rest = torch.cat([got[..., :coff], got[..., coff + Cs:]], dim=-1)
+        assert rest.numel() == 0 or float((rest - 7).abs().max()) == 0.0          # nothing outside the slice is touched
         got2 = torch.zeros(B, Kmax, C, device=d)
         ops.sp_pool_tiles_fwd(sl, m, got2, coff)
         assert torch.equal(got[..., coff:coff + Cs], got2[..., coff:coff + Cs])
@@ -1124,7 +1124,7 @@ def test_sp_pool_tiles_rows_that_do_not_fit_take_the_pixel_lists(ops):
     assert int(t.alloc.min()) > ops._lib.load().wesup_sp_tiles_part_rows(H, W, H)       # more rows asked for than there are
     flagged = int(t.row_flag.sum())
     assert 0 < flagged <= B * H and int((t.tile_base < 0).sum()) > 0
-    for (h, w, Cs) in [(H, W, 64), (H // 2, W // 2, 128), (H // 4, W // 4, 256)]:
+    for (h, w, Cs) in [(H, W, 64), (H, W, 32), (H, W, 256)]:
         sl = rnd(B, h, w, Cs, seed=4).to(d)
         want = torch.zeros(B, H, Cs, device=d)
         ops.sp_pool_upsample_fwd(sl, m, want, 0)

@@ -16,7 +16,7 @@
 // (Round 4 ran this as two launches whose first ended in ONE block per image summing nchunk x Kmax x (1 + C) strided words and
 // re-walking them for the sort bases: 0.23 ms in the configs[1] step, 4.4 ms at the 1024 x 1024 shard, on the stream the first
 // pooling waits for -- and the class counts in LDS capped Kmax at 13 312.  Now:)
-//   0. sp_zero: the per-image sums (area and class counts by id, largest id, status) are zeroed;
+//   0. sp_zero: the per-image sums (area and class counts by id) and the per-chunk {largest id, status} words are zeroed;
 //   1. sp_hist_kernel, one block per 2048-pixel chunk: histogram and class counts of the chunk in LDS (class counts as 16-bit
 //      halves: a chunk has 2048 pixels), the histogram row stored for the counting sort, every non-zero entry ADDED to the
 //      image's sums with integer atomics (exact in any order: the result does not depend on the arrival order);
@@ -52,7 +52,7 @@ struct SpPre {
     int HW, C, Kmax, nchunk, Umax;
     int nslice;              // blocks of SP_SCAN_COLS ids per image in launch 2
     int32_t* chunk_hist;     // [B][nchunk][Kmax]: histogram, then the chunk's start inside the pixel list of each id
-    int32_t* img_info;       // [B][2] {largest id + 1, status bits}     | zeroed by launch 0, summed by launch 1
+    int32_t* chunk_info;     // [B][nchunk][2] {largest id + 1, status bits} of the chunk | zeroed by launch 0, summed by launch 1
     int32_t* cnt;            // [B][Kmax * C] class counts by id         |
     int32_t* area_old;       // [B][Kmax] pixels by id                   |
     int32_t *n_sp, *n_l, *perm, *inv_perm, *area_new, *row_start, *status, *seg_start, *unit_row;
@@ -86,14 +86,15 @@ __global__ __launch_bounds__(1024) void sp_hist_kernel(const SpPre p) {
                     atomicAdd(&lcnt[e >> 1], 1 << (16 * (e & 1)));          // (a chunk has 2048 pixels: no carry into the other half)
                 }
     }
-    // wave-level reduction of the two scalars, one atomic per wave
+    // the chunk's largest id and status: wave-level reduction, then one atomic per wave on the CHUNK's own words (sixteen waves of
+    // every chunk block adding to one word per image serialised 65 K atomics on a cache line at 8 x 1024^2: 0.65 ms)
     for (int off = 32; off > 0; off >>= 1) {
         lmax = max(lmax, __shfl_xor(lmax, off));
         bad |= __shfl_xor(bad, off);
     }
     if ((tid & 63) == 0) {
-        if (lmax) atomicMax(&p.img_info[2 * b], lmax);
-        if (bad) atomicOr(&p.img_info[2 * b + 1], 1);
+        if (lmax) atomicMax(&p.chunk_info[((long)b * p.nchunk + g) * 2], lmax);
+        if (bad) atomicOr(&p.chunk_info[((long)b * p.nchunk + g) * 2 + 1], 1);
     }
     __syncthreads();
     int32_t* oh = p.chunk_hist + ((long)b * p.nchunk + g) * Kmax;
@@ -121,8 +122,28 @@ __device__ void sp_order_image(const SpPre& p, int b, int* sh /*[1024]*/) {
     const bool has_mask = p.mask != nullptr;
     const int32_t* cnt = p.cnt + (long)b * Kmax * C;
     const int32_t* area_old = p.area_old + (long)b * Kmax;
-    const int n = min(p.img_info[2 * b], Kmax);
-    const int stat = p.img_info[2 * b + 1];
+    // largest id and status over the chunks
+    int lm = 0, stat = 0;
+    for (int g = tid; g < p.nchunk; g += 1024) {
+        lm = max(lm, p.chunk_info[((long)b * p.nchunk + g) * 2]);
+        stat |= p.chunk_info[((long)b * p.nchunk + g) * 2 + 1];
+    }
+    sh[tid] = lm;
+    __syncthreads();
+    for (int off = 512; off > 0; off >>= 1) {
+        if (tid < off) sh[tid] = max(sh[tid], sh[tid + off]);
+        __syncthreads();
+    }
+    const int n = min(sh[0], Kmax);
+    __syncthreads();
+    sh[tid] = stat;
+    __syncthreads();
+    for (int off = 512; off > 0; off >>= 1) {
+        if (tid < off) sh[tid] |= sh[tid + off];
+        __syncthreads();
+    }
+    stat = sh[0];
+    __syncthreads();
     const int per = (Kmax + 1023) / 1024;
     const int i0 = min(Kmax, tid * per), i1 = min(Kmax, i0 + per);
     int nlab = 0;
@@ -315,7 +336,7 @@ extern "C" size_t wesup_sp_preprocess_workspace_bytes(int B, int HW, int C, int 
     const size_t nchunk = (HW + SP_CHUNK - 1) / SP_CHUNK;
     const size_t Cc = C > 0 ? C : 1;
     size_t bytes = align_up((size_t)B * nchunk * Kmax * 4, 256);     // chunk_hist / chunk_base
-    bytes += align_up((size_t)B * (2 + Kmax * (1 + Cc)) * 4, 256);    // {largest id + 1, status}, class counts, areas by id
+    bytes += align_up((size_t)B * (nchunk * 2 + Kmax * (1 + Cc)) * 4, 256);      // {largest id + 1, status} per chunk, class counts, areas by id
     return bytes;
 }
 
@@ -339,10 +360,10 @@ extern "C" int wesup_sp_preprocess(const int32_t* labels, const uint8_t* mask, i
     SpPre p = {};
     char* w = (char*)ws;
     p.chunk_hist = (int32_t*)w; w += align_up((size_t)B * nchunk * Kmax * 4, 256);
-    p.img_info = (int32_t*)w;
-    p.cnt = p.img_info + (size_t)2 * B;
+    p.chunk_info = (int32_t*)w;
+    p.cnt = p.chunk_info + (size_t)B * nchunk * 2;
     p.area_old = p.cnt + (size_t)B * Kmax * C;
-    const long sums = (long)B * (2 + (long)Kmax * (1 + C));
+    const long sums = (long)B * ((long)nchunk * 2 + (long)Kmax * (1 + C));
     p.labels = labels; p.mask = mask; p.HW = HW; p.C = C; p.Kmax = Kmax; p.nchunk = nchunk; p.Umax = Umax;
     p.nslice = (Kmax + SP_SCAN_COLS - 1) / SP_SCAN_COLS;
     p.n_sp = n_sp; p.n_l = n_l; p.perm = perm; p.inv_perm = inv_perm; p.area_new = area_new; p.row_start = row_start;
@@ -355,7 +376,7 @@ extern "C" int wesup_sp_preprocess(const int32_t* labels, const uint8_t* mask, i
                                                             hipFuncAttributeMaxDynamicSharedMemorySize, SP_MAX_K * 4);
         if (attr2 != hipSuccess) return WESUP_ERR_LAUNCH;
     }
-    WESUP_LAUNCH(sp_zero_kernel, dim3((unsigned)((sums + 255) / 256)), dim3(256), 0, st, p.img_info, sums);
+    WESUP_LAUNCH(sp_zero_kernel, dim3((unsigned)((sums + 255) / 256)), dim3(256), 0, st, p.chunk_info, sums);
     WESUP_LAUNCH(sp_hist_kernel, dim3(nchunk, B), dim3(1024), lds, st, p);
     WESUP_LAUNCH(sp_scan_order_kernel, dim3(p.nslice + 1, B), dim3(1024), 0, st, p);
     WESUP_LAUNCH(sp_place_kernel, dim3(nchunk, B), dim3(64), (size_t)Kmax * 4, st, labels, p.chunk_hist, inv_perm, row_start, HW,
@@ -585,8 +606,14 @@ __global__ __launch_bounds__(256) void sp_pool_up_fwd_kernel(const float* __rest
     if (!ident) {
         unsigned long long* cell = cellbuf[threadIdx.x >> 6];
         int y0 = 1 << 30, y1 = -1, x0 = 1 << 30, x1 = -1;
-        for (int j = j0 + lane; j < j1; j += 64) {
-            const int p = list[j];
+        // the lane's pixels of the segment (<= SP_SEG / 64), loaded once, all loads in flight together, for both passes
+        int pl[SP_SEG / 64];
+#pragma unroll
+        for (int k = 0; k < SP_SEG / 64; ++k) pl[k] = (j0 + lane + 64 * k < j1) ? list[j0 + lane + 64 * k] : -1;
+#pragma unroll
+        for (int k = 0; k < SP_SEG / 64; ++k) {
+            const int p = pl[k];
+            if (p < 0) continue;
             const int Y = fast_div(p, dW), X = p - Y * W;
             const Lerp2 ly = lerp2_of(Y, sh, h), lx = lerp2_of(X, sw, w);
             y0 = min(y0, ly.i0); y1 = max(y1, ly.i1);
@@ -604,8 +631,10 @@ __global__ __launch_bounds__(256) void sp_pool_up_fwd_kernel(const float* __rest
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
             __builtin_amdgcn_wave_barrier();
             const float FX = 1099511627776.f;      // 2^40
-            for (int j = j0 + lane; j < j1; j += 64) {
-                const int p = list[j];
+#pragma unroll
+            for (int k = 0; k < SP_SEG / 64; ++k) {
+                const int p = pl[k];
+                if (p < 0) continue;
                 const int Y = fast_div(p, dW), X = p - Y * W;
                 const Lerp2 ly = lerp2_of(Y, sh, h), lx = lerp2_of(X, sw, w);
                 const int a0 = (ly.i0 - y0) * bw - x0, a1 = (ly.i1 - y0) * bw - x0;
@@ -737,27 +766,28 @@ extern "C" int wesup_sp_pool_upsample_fwd(const float* s, const int32_t* pix_sor
     return WESUP_OK;
 }
 
-// ------------------------------------------------------------------ the same scatter-mean, tile by tile (round 5)
-// The segment form above walks a superpixel's pixel list: list -> pixel -> (four cells of) s, a chain of dependent loads per lane
-// group, and for a coarse s it rebuilds the per-cell weights of every segment in every layer.  Alone that reads at 2.5 TB/s; beside
-// the other streams of the training step, where a load takes several times as long, it fell to 0.9 TB/s (configs[1]) and 0.5 TB/s
-// (the 120 x 120 layers).  Here the image is cut into 16 x 16-pixel tiles and a block streams ITS part of s in raster order --
-// every load address is known up front, a thread's loads are all issued before the first use --:
+// ------------------------------------------------------------------ the same scatter-mean at NATIVE resolution, tile by tile (round 5)
+// The segment form above walks a superpixel's pixel list: list -> pixel -> row of s, a chain of two dependent loads per lane group.
+// With few waves per CU -- 4 x 480 x 480: one round of ~4000 waves -- that chain is what the kernel waits for (conv1_1 / conv1_2's
+// outputs, the two largest reads of the pooling: 2.5 TB/s alone).  For a layer at the image's own resolution (h == H, w == W: no
+// interpolation) the image is cut into 16 x 16-pixel tiles instead and a block streams ITS 64 KB of s in raster order -- every load
+// address is known up front, a thread issues its sixteen loads before the first use --:
 //   * wesup_sp_tiles (once per step): per tile the rows (superpixels) present, ascending, and each pixel's slot in that list;
-//     a first part row per tile (bump allocation per image: the ORDER of the tiles in the part buffer is arbitrary, its content
-//     is not), and per row the box of tiles it touches;
-//   * sp_pool_tile_kernel (per layer): the tile's cells of s -- its own pixels at native resolution, the <= 12 x 12 cells under
-//     it for a coarse s, whose bilinear weights are summed per (cell, slot) in LDS as 2^-40 fixed point (integer atomics: exact in
-//     any order) -- are loaded once, coalesced, and accumulated per slot in a fixed order: one partial sum per (tile, slot);
+//     a first part row per tile (prefix sums over the tiles), and per row the box of tiles it touches;
+//   * sp_pool_tile_kernel (per layer): the tile's pixels are loaded once, coalesced, and accumulated per slot in a fixed order: one
+//     partial sum per (tile, slot);
 //   * sp_pool_tile_combine_kernel (per layer): one wave per row adds the row's partial sums over its box of tiles in raster order
 //     and scales by 1 / area.
-// Bitwise reproducible (every order is fixed), no float atomics.  A label map whose tiles hold more rows than the part buffer
-// has room for (6 per tile + Kmax per image: superpixels far smaller than a tile) marks the rows of the tiles that did not fit;
-// the combine kernel sums such a row from its pixel list instead (the slow, general form) -- no host decision anywhere.
+// Bitwise reproducible (every order is fixed), no float atomics.  4.1 TB/s at 4 x 480 x 480 (58 against 95 us per layer), 4.6 TB/s at
+// 8 x 1024 x 1024, where the segment form has waves enough and reads at 5.6 TB/s.  Coarse layers keep the segment form: a tile
+// form of them (the <= 12 x 12 cells under a tile, bilinear weights summed per (cell, slot) in LDS) was built and measured in round
+// 5 -- the weight table of every tile costs more than the short chains it removes (tools/pool_micro.py, profiles/r05_pool_micro.txt).
+// A label map whose tiles hold more rows than the part buffer has room for (6 per tile + Kmax per image: superpixels far smaller
+// than a tile) marks the rows of the tiles that did not fit; the combine kernel sums such a row from its pixel list instead (the
+// slow, general form) -- no host decision anywhere.
 #define SPT 16                 // tile edge, full-resolution pixels
-#define SPT_SLOTS 16           // slots accumulated per pass over the tile's cells
-#define SPT_CB 8               // cells in flight per thread
-#define SPT_CMAX 12            // coarse cells per dimension under one tile (upsampling factor >= 1.5)
+#define SPT_SLOTS 8            // slots accumulated per pass over the tile's cells
+#define SPT_CB 16              // cells in flight per thread
 struct SpTiles {
     const int32_t* new_row;    // [B][HW]
     int H, W, Kmax, nty, ntx, cap;      // cap: part rows per image
@@ -765,14 +795,13 @@ struct SpTiles {
     int32_t* tile_ns;          // [B][ntile] rows present
     int32_t* tile_base;        // [B][ntile] first part row, -1: did not fit
     int32_t* tile_rows;        // [B][ntile][256] the rows, ascending
-    int32_t* alloc;            // [B] part rows handed out            | initialised by sp_tiles_init_kernel
-    int32_t* row_flag;         // [B][Kmax] 1: a tile of the row did not fit |
-    int32_t* bbox;             // [B][Kmax][4] ty0, ty1, tx0, tx1     |
+    int32_t* alloc;            // [B] part rows asked for (sp_tiles_scan_kernel)
+    int32_t* row_flag;         // [B][Kmax] 1: a tile of the row did not fit | initialised by sp_tiles_init_kernel
+    int32_t* bbox;             // [B][Kmax][4] ty0, ty1, tx0, tx1            |
 };
 __global__ void sp_tiles_init_kernel(const SpTiles p, int B) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (long)B * p.Kmax) return;
-    if (i < B) p.alloc[i] = 0;
     p.row_flag[i] = 0;
     p.bbox[4 * i + 0] = 0x7fffffff; p.bbox[4 * i + 1] = -1; p.bbox[4 * i + 2] = 0x7fffffff; p.bbox[4 * i + 3] = -1;
 }
@@ -781,7 +810,6 @@ __global__ __launch_bounds__(256) void sp_tiles_kernel(const SpTiles p) {
     __shared__ int wpre[SP_MAX_K / 32];
     __shared__ int scan[256];
     __shared__ int srows[256];
-    __shared__ int sbase;
     const int b = blockIdx.z, ty = blockIdx.y, tx = blockIdx.x, tid = threadIdx.x;
     const int tile = ty * p.ntx + tx, ntile = p.nty * p.ntx;
     const int words = (p.Kmax + 31) >> 5;
@@ -817,12 +845,7 @@ __global__ __launch_bounds__(256) void sp_tiles_kernel(const SpTiles p) {
             srows[run++] = i * 32 + bit;          // (ns <= 256: a tile has 256 pixels)
         }
     }
-    if (tid == 0) {
-        const int base = atomicAdd(&p.alloc[b], ns);
-        sbase = (base + ns <= p.cap) ? base : -1;
-        p.tile_ns[(long)b * ntile + tile] = ns;
-        p.tile_base[(long)b * ntile + tile] = sbase;
-    }
+    if (tid == 0) p.tile_ns[(long)b * ntile + tile] = ns;
     __syncthreads();
     if (inside) p.slot[pix] = r >= 0 ? (uint8_t)(wpre[r >> 5] + __popc(bits[r >> 5] & ((1u << (r & 31)) - 1u))) : (uint8_t)255;
     if (tid < ns) {
@@ -830,8 +853,29 @@ __global__ __launch_bounds__(256) void sp_tiles_kernel(const SpTiles p) {
         p.tile_rows[((long)b * ntile + tile) * 256 + tid] = rr;
         int32_t* bb = p.bbox + ((long)b * p.Kmax + rr) * 4;
         atomicMin(&bb[0], ty); atomicMax(&bb[1], ty); atomicMin(&bb[2], tx); atomicMax(&bb[3], tx);
-        if (sbase < 0) p.row_flag[(long)b * p.Kmax + rr] = 1;
     }
+}
+// part rows per tile: the exclusive prefix of tile_ns over the image's tiles (raster order); a tile whose rows end beyond the
+// capacity gets -1 and marks its rows.  One block per image.
+__global__ __launch_bounds__(1024) void sp_tiles_scan_kernel(const SpTiles p) {
+    __shared__ int sh[1024];
+    const int b = blockIdx.x, tid = threadIdx.x, ntile = p.nty * p.ntx;
+    const int per = (ntile + 1023) / 1024;
+    const int i0 = min(ntile, tid * per), i1 = min(ntile, i0 + per);
+    const int32_t* ns = p.tile_ns + (long)b * ntile;
+    int sum = 0;
+    for (int i = i0; i < i1; ++i) sum += ns[i];
+    int total;
+    int run = block_excl_scan(sum, &total, sh);
+    for (int i = i0; i < i1; ++i) {
+        const int n = ns[i];
+        const bool fits = run + n <= p.cap;
+        p.tile_base[(long)b * ntile + i] = fits ? run : -1;
+        if (!fits)
+            for (int k = 0; k < n; ++k) p.row_flag[(long)b * p.Kmax + p.tile_rows[((long)b * ntile + i) * 256 + k]] = 1;
+        run += n;
+    }
+    if (tid == 0) p.alloc[b] = total;
 }
 extern "C" int wesup_sp_tiles_part_rows(int H, int W, int Kmax) {
     return (H > 0 && W > 0 && Kmax > 0) ? 6 * ceil_div(H, SPT) * ceil_div(W, SPT) + Kmax : 0;
@@ -851,149 +895,89 @@ extern "C" int wesup_sp_tiles(const int32_t* new_row, int B, int H, int W, int K
     hipStream_t st = (hipStream_t)stream;
     WESUP_LAUNCH(sp_tiles_init_kernel, dim3((unsigned)(((long)B * Kmax + 255) / 256)), dim3(256), 0, st, p, B);
     WESUP_LAUNCH(sp_tiles_kernel, dim3(p.ntx, p.nty, B), dim3(256), 0, st, p);
+    WESUP_LAUNCH(sp_tiles_scan_kernel, dim3(B), dim3(1024), 0, st, p);
     WESUP_CHECK_LAUNCH();
     return WESUP_OK;
 }
 
 struct SpPoolTile {
-    const float* s;            // (B, h, w, lds) the side output / conv output at its own resolution, channel offset applied
+    const float* s;            // (B, H, W, lds) the side output / conv output, channel offset applied
     float* part;               // [B][cap][C]
     float* out;                // (B, Kmax, ldo), channel offset applied
     const uint8_t* slot;
     const int32_t *tile_ns, *tile_base, *tile_rows, *row_flag, *bbox;
     const int32_t *pix_sorted, *row_start;
-    int h, w, H, W, lds, ldo, Kmax, nty, ntx, cap;
-    float sh, sw;
-    FastDiv dW;
+    int H, W, lds, ldo, Kmax, nty, ntx, cap;
 };
-WESUP_NO_PADDING(SpPoolTile, 11 * 8 + 10 * 4 + 2 * 4 + 16);
-// NQ = C / 4 lanes cover the channels of one cell; G = 256 / NQ lane groups walk the tile's cells g, g + G, ...
-template <int NQ, bool IDENT>
+// NQ = C / 4 lanes cover the channels of one pixel; G = 256 / NQ lane groups walk the tile's pixels g, g + G, ...
+template <int NQ>
 __global__ __launch_bounds__(256) void sp_pool_tile_kernel(const SpPoolTile p) {
     constexpr int G = 256 / NQ, C = 4 * NQ;
-    constexpr int WPW = NQ >= 64 ? 1 : 64 / NQ;       // lane groups per wave
+    constexpr int NS = SPT_SLOTS, CB = SPT_CB;
     __shared__ short sslot[256];
-    __shared__ unsigned long long wq[IDENT ? 1 : SPT_CMAX * SPT_CMAX * SPT_SLOTS];
-    __shared__ __attribute__((aligned(16))) float wf[IDENT ? 4 : SPT_CMAX * SPT_CMAX * SPT_SLOTS];
-    __shared__ __attribute__((aligned(16))) float red[4][4][NQ * 4];          // [slot of the quartet][wave][channel]
+    __shared__ __attribute__((aligned(16))) float red[NS][4][C];          // [slot of the pass][wave][channel]
     const int b = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x;
     const int ntile = p.nty * p.ntx;
     const int ns = p.tile_ns[(long)b * ntile + tile], base = p.tile_base[(long)b * ntile + tile];
     if (ns == 0 || base < 0) return;                  // (block-uniform)
     const int ty = tile / p.ntx, tx = tile - ty * p.ntx;
     const int Y0 = ty * SPT, X0 = tx * SPT;
-    const int Y1 = min(p.H - 1, Y0 + SPT - 1), X1 = min(p.W - 1, X0 + SPT - 1);
-    const int py = Y0 + (tid >> 4), px = X0 + (tid & 15);
-    const bool inside = py <= Y1 && px <= X1;
-    const int myslot = inside ? (int)p.slot[(long)b * p.H * p.W + (long)py * p.W + px] : -1;
-    sslot[tid] = (short)myslot;
-    int cy0, cx0, ncy, ncx;
-    Lerp2 ly = {0, 0, 1.f, 0.f}, lx = {0, 0, 1.f, 0.f};
-    if (IDENT) {
-        cy0 = Y0; cx0 = X0; ncy = Y1 - Y0 + 1; ncx = X1 - X0 + 1;
-    } else {
-        cy0 = lerp2_of(Y0, p.sh, p.h).i0; cx0 = lerp2_of(X0, p.sw, p.w).i0;
-        ncy = lerp2_of(Y1, p.sh, p.h).i1 - cy0 + 1; ncx = lerp2_of(X1, p.sw, p.w).i1 - cx0 + 1;
-        if (inside) { ly = lerp2_of(py, p.sh, p.h); lx = lerp2_of(px, p.sw, p.w); }
-    }
-    const int ncell = ncy * ncx;
+    const int ncy = min(p.H - Y0, SPT), ncx = min(p.W - X0, SPT);
+    const int py = tid >> 4, px = tid & 15;
+    sslot[tid] = (py < ncy && px < ncx) ? (short)p.slot[(long)b * p.H * p.W + (long)(Y0 + py) * p.W + X0 + px] : (short)-1;
     const int q = tid % NQ, g = tid / NQ, wave = tid >> 6, lane = tid & 63;
-    const float* sb = p.s + (long)b * p.h * p.w * p.lds + 4 * q;
+    const float* sb = p.s + ((long)b * p.H * p.W + (long)Y0 * p.W + X0) * p.lds + 4 * q;
     __syncthreads();
-    for (int s0 = 0; s0 < ns; s0 += SPT_SLOTS) {
-        const int nsc = min(SPT_SLOTS, ns - s0);
-        if (!IDENT) {
-            // per (cell, slot) the sum of the bilinear weights of the tile's pixels of that slot
-            for (int i = tid; i < ncell * SPT_SLOTS; i += 256) wq[i] = 0ull;
-            __syncthreads();
-            const int sl = myslot - s0;
-            if (inside && sl >= 0 && sl < nsc) {
-                const float FX = 1099511627776.f;      // 2^40
-                const int a0 = ((ly.i0 - cy0) * ncx - cx0) * SPT_SLOTS + sl, a1 = ((ly.i1 - cy0) * ncx - cx0) * SPT_SLOTS + sl;
-                atomicAdd(&wq[a0 + lx.i0 * SPT_SLOTS], (unsigned long long)(ly.l0 * lx.l0 * FX + 0.5f));
-                atomicAdd(&wq[a0 + lx.i1 * SPT_SLOTS], (unsigned long long)(ly.l0 * lx.l1 * FX + 0.5f));
-                atomicAdd(&wq[a1 + lx.i0 * SPT_SLOTS], (unsigned long long)(ly.l1 * lx.l0 * FX + 0.5f));
-                atomicAdd(&wq[a1 + lx.i1 * SPT_SLOTS], (unsigned long long)(ly.l1 * lx.l1 * FX + 0.5f));
-            }
-            __syncthreads();
-            for (int i = tid; i < ncell * SPT_SLOTS; i += 256) wf[i] = (float)wq[i] * (1.f / 1099511627776.f);
-            __syncthreads();
-        }
-        float4 acc[SPT_SLOTS];
+    for (int s0 = 0; s0 < ns; s0 += NS) {
+        const int nsc = min(NS, ns - s0);
+        float4 acc[NS];
 #pragma unroll
-        for (int k = 0; k < SPT_SLOTS; ++k) acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int c0 = g; c0 < ncell; c0 += G * SPT_CB) {
-            float4 v[SPT_CB];
-            int cc[SPT_CB];
+        for (int k = 0; k < NS; ++k) acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int c0 = g; c0 < ncy * SPT; c0 += G * CB) {
+            float4 v[CB];
+            // every load of the batch before the first use (pixel c of the tile: row c >> 4, column c & 15)
 #pragma unroll
-            for (int k = 0; k < SPT_CB; ++k) {
+            for (int k = 0; k < CB; ++k) {
                 const int c = c0 + k * G;
-                const int cy = c / ncx, cx = c - cy * ncx;
-                cc[k] = c < ncell ? (IDENT ? cy * SPT + cx : c) : -1;
                 v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (c < ncell) v[k] = ld4(sb + ((long)(cy0 + cy) * p.w + cx0 + cx) * p.lds);
+                if (c < ncy * SPT && (c & 15) < ncx) v[k] = ld4(sb + ((c >> 4) * p.W + (c & 15)) * p.lds);
             }
 #pragma unroll
-            for (int k = 0; k < SPT_CB; ++k) {
-                if (cc[k] < 0) continue;
-                if (IDENT) {
-                    const int sl = (int)sslot[cc[k]] - s0;
+            for (int k = 0; k < CB; ++k) {
+                const int c = c0 + k * G;
+                const int sl = c < ncy * SPT ? (int)sslot[c] - s0 : -1;          // (-1 - s0 < 0 for pixels beyond the image)
 #pragma unroll
-                    for (int j = 0; j < SPT_SLOTS; ++j)
-                        if (j < nsc) {
-                            const float m = sl == j ? 1.f : 0.f;
-                            acc[j].x = fmaf(m, v[k].x, acc[j].x); acc[j].y = fmaf(m, v[k].y, acc[j].y);
-                            acc[j].z = fmaf(m, v[k].z, acc[j].z); acc[j].w = fmaf(m, v[k].w, acc[j].w);
-                        }
-                } else {
-                    const float* wr = wf + cc[k] * SPT_SLOTS;
-#pragma unroll
-                    for (int j4 = 0; j4 < SPT_SLOTS; j4 += 4)
-                        if (j4 < nsc) {
-                            const float4 w4 = ld4(wr + j4);
-                            const float ww[4] = {w4.x, w4.y, w4.z, w4.w};
-#pragma unroll
-                            for (int jj = 0; jj < 4; ++jj) {
-                                acc[j4 + jj].x = fmaf(ww[jj], v[k].x, acc[j4 + jj].x); acc[j4 + jj].y = fmaf(ww[jj], v[k].y, acc[j4 + jj].y);
-                                acc[j4 + jj].z = fmaf(ww[jj], v[k].z, acc[j4 + jj].z); acc[j4 + jj].w = fmaf(ww[jj], v[k].w, acc[j4 + jj].w);
-                            }
-                        }
-                }
+                for (int j = 0; j < NS; ++j)
+                    if (j < nsc) {
+                        const float m = sl == j ? 1.f : 0.f;
+                        acc[j].x = fmaf(m, v[k].x, acc[j].x); acc[j].y = fmaf(m, v[k].y, acc[j].y);
+                        acc[j].z = fmaf(m, v[k].z, acc[j].z); acc[j].w = fmaf(m, v[k].w, acc[j].w);
+                    }
             }
         }
-        // the lane groups of a wave by a fixed xor tree, the four waves through LDS in wave order, four slots at a time
+        // the lane groups of a wave by a fixed xor tree, then the four waves through LDS in wave order
 #pragma unroll
-        for (int j = 0; j < SPT_SLOTS; ++j)
+        for (int j = 0; j < NS; ++j)
             if (j < nsc) {
 #pragma unroll
                 for (int off = NQ; off < 64; off <<= 1) {
                     acc[j].x += __shfl_xor(acc[j].x, off); acc[j].y += __shfl_xor(acc[j].y, off);
                     acc[j].z += __shfl_xor(acc[j].z, off); acc[j].w += __shfl_xor(acc[j].w, off);
                 }
+                if (lane < NQ) st4(&red[j][wave][4 * lane], acc[j]);
             }
+        __syncthreads();
+        for (int i = tid; i < nsc * NQ; i += 256) {
+            const int j = i / NQ, qq = i - j * NQ;
+            float4 t = ld4(&red[j][0][4 * qq]);
 #pragma unroll
-        for (int j4 = 0; j4 < SPT_SLOTS; j4 += 4) {
-            if (j4 >= nsc) break;
-#pragma unroll
-            for (int jj = 0; jj < 4; ++jj)
-                if (j4 + jj < nsc && lane < NQ) st4(&red[jj][wave][4 * lane], acc[j4 + jj]);
-            __syncthreads();
-            for (int i = tid; i < 4 * NQ; i += 256) {
-                const int jj = i / NQ, qq = i - jj * NQ;
-                if (j4 + jj < nsc) {
-                    float4 t = ld4(&red[jj][0][4 * qq]);
-                    if (NQ < 64 || true) {
-#pragma unroll
-                        for (int wv = 1; wv < 4; ++wv) {
-                            const float4 u = ld4(&red[jj][wv][4 * qq]);
-                            t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
-                        }
-                    }
-                    st4(p.part + ((long)b * p.cap + base + s0 + j4 + jj) * C + 4 * qq, t);
-                }
+            for (int wv = 1; wv < 4; ++wv) {
+                const float4 u = ld4(&red[j][wv][4 * qq]);
+                t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
             }
-            __syncthreads();
+            st4(p.part + ((long)b * p.cap + base + s0 + j) * C + 4 * qq, t);
         }
+        if (s0 + NS < ns) __syncthreads();
     }
 }
 // one wave per row: the partial sums of the row's tiles in raster order (or, for a row some tile of which did not fit, the row's
@@ -1043,17 +1027,10 @@ __global__ __launch_bounds__(256) void sp_pool_tile_combine_kernel(const SpPoolT
         }
     } else if (j1 > j0) {
         const int32_t* list = p.pix_sorted + (long)b * p.H * p.W;
-        const float* base = p.s + (long)b * p.h * p.w * p.lds + 4 * cl;
+        const float* base = p.s + (long)b * p.H * p.W * p.lds + 4 * cl;
         for (int j = j0 + grp; j < j1; j += PPW) {
-            const int pp = list[j];
-            const int Y = fast_div(pp, p.dW), X = pp - Y * p.W;
-            const Lerp2 ly = lerp2_of(Y, p.sh, p.h), lx = lerp2_of(X, p.sw, p.w);
-            const float4 v00 = ld4(base + ((long)ly.i0 * p.w + lx.i0) * p.lds), v01 = ld4(base + ((long)ly.i0 * p.w + lx.i1) * p.lds);
-            const float4 v10 = ld4(base + ((long)ly.i1 * p.w + lx.i0) * p.lds), v11 = ld4(base + ((long)ly.i1 * p.w + lx.i1) * p.lds);
-            acc.x += ly.l0 * (lx.l0 * v00.x + lx.l1 * v01.x) + ly.l1 * (lx.l0 * v10.x + lx.l1 * v11.x);
-            acc.y += ly.l0 * (lx.l0 * v00.y + lx.l1 * v01.y) + ly.l1 * (lx.l0 * v10.y + lx.l1 * v11.y);
-            acc.z += ly.l0 * (lx.l0 * v00.z + lx.l1 * v01.z) + ly.l1 * (lx.l0 * v10.z + lx.l1 * v11.z);
-            acc.w += ly.l0 * (lx.l0 * v00.w + lx.l1 * v01.w) + ly.l1 * (lx.l0 * v10.w + lx.l1 * v11.w);
+            const float4 v = ld4(base + (long)list[j] * p.lds);
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
         }
 #pragma unroll
         for (int off = NQ; off < 64; off <<= 1) {
@@ -1066,12 +1043,9 @@ __global__ __launch_bounds__(256) void sp_pool_tile_combine_kernel(const SpPoolT
 extern "C" size_t wesup_sp_pool_tiles_workspace_bytes(int B, int H, int W, int C, int Kmax) {
     return (B > 0 && C > 0) ? (size_t)B * wesup_sp_tiles_part_rows(H, W, Kmax) * (C < 256 ? C : 256) * sizeof(float) : 0;
 }
-// 1 = wesup_sp_pool_tiles_fwd covers this level: the tile's cells of a coarse s must fit SPT_CMAX per dimension
+// 1 = wesup_sp_pool_tiles_fwd covers this level: native resolution only (see above)
 extern "C" int wesup_sp_pool_tiles_supported(int h, int w, int H, int W, int C) {
-    if (h <= 0 || w <= 0 || H < h || W < w || (C != 32 && C != 64 && C != 128 && (C % 256))) return 0;
-    if (h == H && w == W) return 1;
-    const double shd = H > 1 ? (double)(h - 1) / (H - 1) : 0.0, swd = W > 1 ? (double)(w - 1) / (W - 1) : 0.0;
-    return ((SPT - 1) * shd + 3.0 <= SPT_CMAX && (SPT - 1) * swd + 3.0 <= SPT_CMAX) ? 1 : 0;
+    return (h > 0 && w > 0 && h == H && w == W && (C == 32 || C == 64 || C == 128 || (C > 0 && C % 256 == 0))) ? 1 : 0;
 }
 extern "C" int wesup_sp_pool_tiles_fwd(const float* s, const uint8_t* slot, const int32_t* tile_ns, const int32_t* tile_base,
                                        const int32_t* tile_rows, const int32_t* row_flag, const int32_t* bbox,
@@ -1084,22 +1058,19 @@ extern "C" int wesup_sp_pool_tiles_fwd(const float* s, const uint8_t* slot, cons
     SpPoolTile p = {};
     p.part = (float*)ws; p.slot = slot; p.tile_ns = tile_ns; p.tile_base = tile_base; p.tile_rows = tile_rows; p.row_flag = row_flag;
     p.bbox = bbox; p.pix_sorted = pix_sorted; p.row_start = row_start;
-    p.h = h; p.w = w; p.H = H; p.W = W; p.lds = C; p.ldo = ldo; p.Kmax = Kmax; p.nty = ceil_div(H, SPT); p.ntx = ceil_div(W, SPT);
+    p.H = H; p.W = W; p.lds = C; p.ldo = ldo; p.Kmax = Kmax; p.nty = ceil_div(H, SPT); p.ntx = ceil_div(W, SPT);
     p.cap = wesup_sp_tiles_part_rows(H, W, Kmax);
-    p.sh = H > 1 ? (float)(h - 1) / (float)(H - 1) : 0.f; p.sw = W > 1 ? (float)(w - 1) / (float)(W - 1) : 0.f;
-    p.dW = make_fastdiv(W);
-    const bool ident = h == H && w == W;
+    if ((long)H * W * C >= (1l << 31)) return WESUP_ERR_INVALID;       // (32-bit element offsets inside an image)
     hipStream_t st = (hipStream_t)stream;
     const dim3 gt((unsigned)(p.nty * p.ntx), B), gc(ceil_div(Kmax, 4), B);
-    // a wave's 64 lanes cover 256 channels of a cell: wider maps go in slabs of 256 channels (cell stride C)
+    // a wave's 64 lanes cover 256 channels of a pixel: wider maps go in slabs of 256 channels (pixel stride C)
     for (int c0 = 0; c0 < C; c0 += 256) {
         const int cw = C - c0 < 256 ? C - c0 : 256;
         p.s = s + c0; p.out = sp_feat + coff + c0;
-#define WESUP_LAUNCH_PT(NQ_)                                                                                   \
-        do {                                                                                                   \
-            if (ident) WESUP_LAUNCH((sp_pool_tile_kernel<NQ_, true>), gt, dim3(256), 0, st, p);                \
-            else WESUP_LAUNCH((sp_pool_tile_kernel<NQ_, false>), gt, dim3(256), 0, st, p);                     \
-            WESUP_LAUNCH(sp_pool_tile_combine_kernel<NQ_>, gc, dim3(256), 0, st, p);                           \
+#define WESUP_LAUNCH_PT(NQ_)                                                              \
+        do {                                                                              \
+            WESUP_LAUNCH(sp_pool_tile_kernel<NQ_>, gt, dim3(256), 0, st, p);              \
+            WESUP_LAUNCH(sp_pool_tile_combine_kernel<NQ_>, gc, dim3(256), 0, st, p);      \
         } while (0)
         switch (cw) {
             case 32: WESUP_LAUNCH_PT(8); break;

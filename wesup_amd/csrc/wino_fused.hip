@@ -63,6 +63,15 @@ __device__ __forceinline__ f32x4 fma4(float s, f32x4 a, f32x4 b) {
     return r;
 }
 
+// WESUP_FUSED_TRACE (tools/probes/fused_phases.hip includes this file with it defined; never set for the library): every block
+// leaves {start, end of the products, end} in 100 MHz ticks (s_memrealtime: one clock for all XCDs) and its HW_REG_HW_ID / XCC_ID behind.
+#ifdef WESUP_FUSED_TRACE
+__device__ unsigned long long* g_fused_trace = nullptr;
+#define FUSED_TRACE(...) __VA_ARGS__
+#else
+#define FUSED_TRACE(...)
+#endif
+
 template <int N>
 __device__ __forceinline__ void glds_wait_n() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
@@ -80,6 +89,7 @@ __global__ __launch_bounds__(128 * TW, 2) void wino4_gemm_out_kernel(const Fused
     constexpr int ES = 8 * 64 + 4;                           // epilogue image: floats per tile (2 rows x 4 columns x 64 channels, padded)
     extern __shared__ __attribute__((aligned(16))) float smem[];      // ring of RING stages; the epilogue image reuses it
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    FUSED_TRACE(const unsigned long long tr0 = __builtin_amdgcn_s_memrealtime();)
     // Block order.  The channel blocks of one tile set read the same rows of V, the tile sets of one channel block the
     // same filter planes.  The grid is walked XCD by XCD with the channel block fastest: the N / 64 readers of a tile set sit
     // behind one L2 at the same time and V comes from HBM once (tile-set fastest, the hardware order, re-read it N / 64
@@ -141,6 +151,22 @@ __global__ __launch_bounds__(128 * TW, 2) void wino4_gemm_out_kernel(const Fused
     __syncthreads();
     int cur = 0, s = 0;
     const int arow = (16 * wa + l15) * 64, brow = TILES * 64 + (32 * wb + l15) * 64;
+    // Fragment double buffering ACROSS the stages: the reads of group g + 1 fly under the 8 MFMAs of group g, and the reads of the
+    // next stage's first group under those of this stage's last -- the end-of-stage barrier sits in front of the last group's MFMAs
+    // (every read of buf[cur] has landed by then).  A wave that has its SIMD's matrix pipe to itself -- its neighbour block in the
+    // epilogue: half of the time at 4 x 480 x 480, nearly always once a grid has many rounds (tools/probes/fused_phases.hip) -- is
+    // otherwise exposed to an LDS round trip per group, ~500 of the 1024 cycles of a stage.  (Left alone the compiler sinks the
+    // reads of a group behind the MFMAs of the one before -- it reuses the fragment registers --: the sched_barriers pin them.)
+    float4 fa[2], fb0[2], fb1[2];
+    auto load_frag = [&](int buf, int g, int sl) {        // lane (row, kq) holds k = 16 g + 4 kq + t, t = step within the group
+        const int ch = ((4 * g + kq) ^ l15) << 2;
+        const float* as = smem + buf * STG + arow;
+        const float* bs = smem + buf * STG + brow;
+        fa[sl] = ld4(as + ch);
+        fb0[sl] = ld4(bs + ch);
+        fb1[sl] = ld4(bs + 16 * 64 + ch);
+    };
+    load_frag(0, 0, 0);
     for (int xi = 0; xi < 6; ++xi) {
         f32x4 Z[4][2];
 #pragma unroll
@@ -150,23 +176,21 @@ __global__ __launch_bounds__(128 * TW, 2) void wino4_gemm_out_kernel(const Fused
             f32x4 acc0 = zero4, acc1 = zero4;
 #pragma unroll
             for (int c = 0; c < KC; ++c, ++s) {
-                const float* as = smem + cur * STG + arow;
-                const float* bs = smem + cur * STG + brow;
-                // fragment double buffering: the reads of group g + 1 fly under the 8 MFMAs of group g
-                float4 fa[2], fb0[2], fb1[2];
-                auto load_frag = [&](int g, int sl) {        // lane (row, kq) holds k = 16 g + 4 kq + t, t = step within the group
-                    const int ch = ((4 * g + kq) ^ l15) << 2;
-                    fa[sl] = ld4(as + ch);
-                    fb0[sl] = ld4(bs + ch);
-                    fb1[sl] = ld4(bs + 16 * 64 + ch);
-                };
-                load_frag(0, 0);
                 const int nxt = cur == 0 ? RING - 1 : cur - 1;      // (cur + RING - 1) % RING: everybody left that buffer before the last barrier
                 if (s + RING - 1 < S) stage(s + RING - 1, nxt);
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const int sl = g & 1;
-                    if (g + 1 < 4) load_frag(g + 1, sl ^ 1);
+                    if (g + 1 < 4) {
+                        load_frag(cur, g + 1, sl ^ 1);
+                    } else {
+                        if (s + RING - 1 < S) glds_wait_n<INFL>();      // stage s + 1 has landed, the stages behind it may still fly
+                        else glds_wait();
+                        __syncthreads();                // ... for everybody; every wave has read all of buf[cur]
+                        cur = cur == RING - 1 ? 0 : cur + 1;
+                        if (s + 1 < S) load_frag(cur, 0, sl ^ 1);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
                     acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[sl].x, fb0[sl].x, acc0, 0, 0, 0);
                     acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[sl].x, fb1[sl].x, acc1, 0, 0, 0);
                     acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[sl].y, fb0[sl].y, acc0, 0, 0, 0);
@@ -176,10 +200,6 @@ __global__ __launch_bounds__(128 * TW, 2) void wino4_gemm_out_kernel(const Fused
                     acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[sl].w, fb0[sl].w, acc0, 0, 0, 0);
                     acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[sl].w, fb1[sl].w, acc1, 0, 0, 0);
                 }
-                if (s + RING - 1 < S) glds_wait_n<INFL>();      // stage s + 1 has landed, the stages behind it may still fly
-                else glds_wait();
-                __syncthreads();                // ... for everybody; every wave is done reading buf[cur]
-                cur = cur == RING - 1 ? 0 : cur + 1;
             }
             // (.) A over the row of positions: Z[jj] += A^T[jj][nu] M_(xi, nu)
             if constexpr (WinoAT<0, nu>::v != 0.f) { Z[0][0] = fma4(WinoAT<0, nu>::v, acc0, Z[0][0]); Z[0][1] = fma4(WinoAT<0, nu>::v, acc1, Z[0][1]); }
@@ -205,6 +225,7 @@ __global__ __launch_bounds__(128 * TW, 2) void wino4_gemm_out_kernel(const Fused
         }
     }
 
+    FUSED_TRACE(const unsigned long long tr1 = __builtin_amdgcn_s_memrealtime(); unsigned long long trE[4] = {0, 0, 0, 0};)
     // ---- epilogue through LDS, two output rows of every tile per pass.  D of a 16x16 block: lane (l15, kq), component r =
     // row 4 kq + r, column l15 -- this lane owns tiles 16 wa + 4 kq + r at channels 32 wb + 16 j + l15.  The image
     // E[tile][row & 1][column][channel] (tile stride padded by 4 floats: the four kq groups land 16 banks apart) is read
@@ -228,35 +249,60 @@ __global__ __launch_bounds__(128 * TW, 2) void wino4_gemm_out_kernel(const Fused
                     for (int jj = 0; jj < 4; ++jj)
                         smem[(16 * wa + 4 * kq + r) * ES + (4 * i2 + jj) * 64 + 32 * wb + 16 * j + l15] = Y[2 * ip + i2][jj][j][r];
         __syncthreads();
+        FUSED_TRACE(trE[2 * ip] = __builtin_amdgcn_s_memrealtime();)          // the image of this row pair is in LDS
         const int i = 2 * ip + (slot >> 2), jj = slot & 3;
         // The y forms that READ something per pixel (sign bits, the old gradient, a gathered side-gradient row): four pixels at a
         // time, every load of a level issued before the first use -- out-of-image pixels are clamped and predicated instead of
         // skipped, so that nothing divergent stands between the loads.
         const bool batched = !up.dst && !p.mask && !(p.gat.src && p.gat.area) && (p.mask_bits || p.accum || p.gat.src);
+        // Every form below: a wave walks ITS tiles (TILES / NW of the block's), its lanes = (column of the tile row, channel quad).
+        // The tile's decomposition, the row's pixel base and every 64-bit address part are wave-uniform -- scalar instructions --
+        // and a lane adds one constant 32-bit offset.  (Round 5: beside a block that is in its products the epilogue's VECTOR
+        // instructions wait for gaps in the neighbour's MFMA stream, ~40 cycles each -- tools/probes/coexec.hip, fused_phases.hip:
+        // the epilogue lasted as long as the products --; with a thread per (pixel, quad) of sixteen different tiles every store
+        // cost ~45 vector instructions of index arithmetic.)
+        constexpr int TPW = TILES / NW;
+        const int wv = __builtin_amdgcn_readfirstlane(wave);
+        const int cc = lane >> 4;                                  // column of the tile row this lane handles
+        const unsigned vq = (unsigned)(cc * p.N + 4 * q4);        // ... as an element offset from the row's first pixel
+        // item j of a wave's pass: tile wv TPW + (j >> 1), row 2 ip + (j & 1) of it; wave-uniform
+        struct Item { long pix0; int b, h; bool ok; };
+        auto item = [&](int j) {
+            Item it;
+            long tile = (long)t0 + wv * TPW + (j >> 1);
+            it.ok = tile < p.T;
+            tile = it.ok ? tile : p.T - 1;
+            const int bi = fast_div((int)tile, p.dTw);
+            const int tj = (int)tile - bi * p.Tw;
+            it.b = fast_div(bi, p.dTh);
+            const int ti = bi - it.b * p.Th;
+            it.h = 4 * ti + 2 * ip + (j & 1);
+            it.ok = it.ok && it.h < p.H;
+            it.h = min(it.h, p.H - 1);
+            it.pix0 = ((long)it.b * p.H + it.h) * p.W + 4 * tj;        // the row's first pixel of the tile, batch-wide index
+            return it;
+        };
+        // The y forms that READ something per pixel (sign bits, the old gradient, a gathered side-gradient row): four items at a
+        // time, every load of a level issued before the first use -- rows and columns outside the image are clamped and
+        // predicated instead of skipped, so that nothing divergent stands between the loads.
         if (batched) {
+            const int wmax = p.W - 1;
 #pragma unroll 1
-            for (int it0 = 0; it0 < 16; it0 += 4) {
-                long off[4]; bool ok[4]; unsigned mb[4]; float4 old[4]; int row[4];
+            for (int j0 = 0; j0 < 2 * TPW; j0 += 4) {
+                bool ok[4]; unsigned mb[4]; float4 old[4]; int row[4]; long off0[4];
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    const int tl = (NW / 2) * (it0 + k) + tsel;
-                    long tile = (long)t0 + tl;
-                    ok[k] = tile < p.T;
-                    tile = ok[k] ? tile : p.T - 1;
-                    const int bi = fast_div((int)tile, p.dTw);
-                    const int tj = (int)tile - bi * p.Tw;
-                    const int b = fast_div(bi, p.dTh);
-                    const int ti = bi - b * p.Th;
-                    int h = 4 * ti + i, w = 4 * tj + jj;
-                    ok[k] = ok[k] && h < p.H && w < p.W;
-                    h = min(h, p.H - 1); w = min(w, p.W - 1);
-                    const long pix = ((long)b * p.H + h) * p.W + w;
-                    off[k] = pix * p.N + n0 + 4 * q4;
-                    mb[k] = p.mask_bits ? p.mask_bits[pix * (p.N >> 2) + (n0 >> 2) + q4] : 15u;
+                    const Item it = item(j0 + k);
+                    const int w0 = (int)(it.pix0 - ((long)it.b * p.H + it.h) * p.W);      // 4 tj
+                    const int dw = min(cc, wmax - w0);                                      // column clamped into the image
+                    ok[k] = it.ok && w0 + cc <= wmax;
+                    off0[k] = it.pix0 * p.N + n0;
+                    const unsigned vqc = (unsigned)(dw * p.N + 4 * q4);
+                    mb[k] = p.mask_bits ? (p.mask_bits + it.pix0 * (p.N >> 2) + (n0 >> 2))[dw * (p.N >> 2) + q4] : 15u;
                     old[k] = make_float4(0.f, 0.f, 0.f, 0.f);
                     row[k] = 0;
-                    if (p.gat.src) row[k] = p.gat.row[pix] + b * p.gat.Kmax;       // (pix = b * HW + the pixel of image b)
-                    else if (p.accum) old[k] = ld4(p.y + off[k]);
+                    if (p.gat.src) row[k] = (p.gat.row + it.pix0)[dw] + it.b * p.gat.Kmax;       // (pix = b * HW + the pixel of image b)
+                    else if (p.accum) old[k] = ld4(p.y + off0[k] + vqc);
                 }
                 if (p.gat.src) {
 #pragma unroll
@@ -264,13 +310,13 @@ __global__ __launch_bounds__(128 * TW, 2) void wino4_gemm_out_kernel(const Fused
                 }
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    const int tl = (NW / 2) * (it0 + k) + tsel;
-                    const float4 e = ld4(smem + tl * ES + slot * 64 + 4 * q4);
+                    const int tl = wv * TPW + ((j0 + k) >> 1);
+                    const float4 e = ld4(smem + tl * ES + (4 * ((j0 + k) & 1) + cc) * 64 + 4 * q4);
                     float4 v = make_float4(e.x + bv.x, e.y + bv.y, e.z + bv.z, e.w + bv.w);
                     v.x = (mb[k] & 1) ? v.x : 0.f; v.y = (mb[k] & 2) ? v.y : 0.f;
                     v.z = (mb[k] & 4) ? v.z : 0.f; v.w = (mb[k] & 8) ? v.w : 0.f;
                     v = make_float4(v.x + old[k].x, v.y + old[k].y, v.z + old[k].z, v.w + old[k].w);
-                    if (ok[k]) st4s(p.y + off[k], v, p.nt);
+                    if (ok[k]) st4s(p.y + off0[k] + vq, v, p.nt);
                 }
             }
         }
@@ -280,95 +326,120 @@ __global__ __launch_bounds__(128 * TW, 2) void wino4_gemm_out_kernel(const Fused
         const bool ubatched = up.dst && p.up_code && !p.mask && !p.mask_bits && !(p.gat.src && p.gat.area);
         if (ubatched) {
             const long rs = (long)p.Wu * p.N;
+            const int wmax = p.W - 1;
 #pragma unroll 1
-            for (int it0 = 0; it0 < 16; it0 += 2) {
+            for (int j0 = 0; j0 < 2 * TPW; j0 += 2) {
                 long o00[2]; bool ok[2]; unsigned code[2]; int row[2][4]; float4 val[2][4];
 #pragma unroll
                 for (int k = 0; k < 2; ++k) {
-                    const int tl = (NW / 2) * (it0 + k) + tsel;
-                    long tile = (long)t0 + tl;
-                    ok[k] = tile < p.T;
-                    tile = ok[k] ? tile : p.T - 1;
-                    const int bi = fast_div((int)tile, p.dTw);
-                    const int tj = (int)tile - bi * p.Tw;
-                    const int b = fast_div(bi, p.dTh);
-                    const int ti = bi - b * p.Th;
-                    int h = 4 * ti + i, w = 4 * tj + jj;
-                    ok[k] = ok[k] && h < p.H && w < p.W;
-                    h = min(h, p.H - 1); w = min(w, p.W - 1);
-                    code[k] = p.up_code[(((long)b * p.H + h) * p.W + w) * (p.N >> 2) + (n0 >> 2) + q4];
-                    const long pix00 = ((long)b * p.Hu + 2 * h) * p.Wu + 2 * w;          // window's first pixel, batch-wide index
-                    o00[k] = pix00 * p.N + n0 + 4 * q4;
+                    const Item it = item(j0 + k);
+                    const int w0 = (int)(it.pix0 - ((long)it.b * p.H + it.h) * p.W);
+                    const int dw = min(cc, wmax - w0);
+                    ok[k] = it.ok && w0 + cc <= wmax;
+                    code[k] = (p.up_code + it.pix0 * (p.N >> 2) + (n0 >> 2))[dw * (p.N >> 2) + q4];
+                    const long pix00 = ((long)it.b * p.Hu + 2 * it.h) * p.Wu + 2 * w0;          // the row's first window, batch-wide index (uniform)
+                    o00[k] = pix00 * p.N + n0;
 #pragma unroll
                     for (int q = 0; q < 4; ++q)
-                        row[k][q] = p.gat.src ? p.gat.row[pix00 + (q >> 1) * p.Wu + (q & 1)] + b * p.gat.Kmax : 0;
+                        row[k][q] = p.gat.src ? (p.gat.row + pix00 + (q >> 1) * p.Wu + (q & 1))[2 * dw] + it.b * p.gat.Kmax : 0;
                 }
 #pragma unroll
                 for (int k = 0; k < 2; ++k) {
                     const WinoPicks pk = wino_code_picks(code[k]);
+                    const unsigned vqu = (unsigned)(2 * cc * p.N + 4 * q4);
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         val[k][q] = make_float4(0.f, 0.f, 0.f, 0.f);
                         if (p.gat.src) val[k][q] = ld4(p.gat.src + (long)row[k][q] * p.N + n0 + 4 * q4);
                         else if (ok[k] && (pk.kx == q || pk.ky == q || pk.kz == q || pk.kw == q))
-                            val[k][q] = ld4(up.dst + o00[k] + (q >> 1) * rs + (q & 1) * p.N);
+                            val[k][q] = ld4(up.dst + o00[k] + (q >> 1) * rs + (q & 1) * p.N + vqu);
                     }
                 }
 #pragma unroll
                 for (int k = 0; k < 2; ++k) {
-                    const int tl = (NW / 2) * (it0 + k) + tsel;
-                    const float4 e = ld4(smem + tl * ES + slot * 64 + 4 * q4);
+                    const int tl = wv * TPW + ((j0 + k) >> 1);
+                    const float4 e = ld4(smem + tl * ES + (4 * ((j0 + k) & 1) + cc) * 64 + 4 * q4);
                     const float4 v = make_float4(e.x + bv.x, e.y + bv.y, e.z + bv.z, e.w + bv.w);
                     const WinoPicks pk = wino_code_picks(code[k]);
+                    const unsigned vqu = (unsigned)(2 * cc * p.N + 4 * q4);
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         const bool hit = pk.kx == q || pk.ky == q || pk.kz == q || pk.kw == q;
                         if (!ok[k] || (!p.gat.src && !hit)) continue;
                         float4 o = val[k][q];
                         o.x += pk.kx == q ? v.x : 0.f; o.y += pk.ky == q ? v.y : 0.f; o.z += pk.kz == q ? v.z : 0.f; o.w += pk.kw == q ? v.w : 0.f;
-                        float* dptr = up.dst + o00[k] + (q >> 1) * rs + (q & 1) * p.N;
+                        float* dptr = up.dst + o00[k] + (q >> 1) * rs + (q & 1) * p.N + vqu;
                         if (p.gat.src) st4s(dptr, o, p.nt); else st4(dptr, o);
                     }
                 }
             }
         }
-#pragma unroll 4
-        for (int it = (batched || ubatched) ? 16 : 0; it < 16; ++it) {
-            const int tl = (NW / 2) * it + tsel;
-            const long tile = (long)t0 + tl;
-            if (tile >= p.T) break;
-            const int bi = fast_div((int)tile, p.dTw);
-            const int tj = (int)tile - bi * p.Tw;
-            const int b = fast_div(bi, p.dTh);
-            const int ti = bi - b * p.Th;
-            const int h = 4 * ti + i, w = 4 * tj + jj;
-            if (h >= p.H || w >= p.W) continue;
-            const float4 e = ld4(smem + tl * ES + slot * 64 + 4 * q4);
-            float4 v = make_float4(e.x + bv.x, e.y + bv.y, e.z + bv.z, e.w + bv.w);
-            const long off = (((long)b * p.H + h) * p.W + w) * p.N + n0 + 4 * q4;
-            if (p.mask_bits) {
-                const unsigned mb = p.mask_bits[(((long)b * p.H + h) * p.W + w) * (p.N >> 2) + (n0 >> 2) + q4];
-                v.x = (mb & 1) ? v.x : 0.f; v.y = (mb & 2) ? v.y : 0.f;
-                v.z = (mb & 4) ? v.z : 0.f; v.w = (mb & 8) ? v.w : 0.f;
-            } else if (p.mask) {
-                const float4 mk = ld4(p.mask + off);
-                v.x = mk.x > 0.f ? v.x : 0.f; v.y = mk.y > 0.f ? v.y : 0.f;
-                v.z = mk.z > 0.f ? v.z : 0.f; v.w = mk.w > 0.f ? v.w : 0.f;
+        // The plain form (forward: y = result + bias): eight rows of four pixels at a time -- their LDS reads in flight together,
+        // one wait, then the adds and the stores (one row at a time it was a chain of read -> wait -> add -> store per row, each
+        // link stretched by the neighbour block's MFMA stream)
+        const bool plain = !batched && !ubatched && !p.mask && !up.dst && !p.gat.src && !p.accum;
+        if (plain) {
+#pragma unroll 1
+            for (int j0 = 0; j0 < 2 * TPW; j0 += 8) {
+                float4 e[8]; long off0[8]; bool ok[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const Item it = item(j0 + k);
+                    const int w0 = (int)(it.pix0 - ((long)it.b * p.H + it.h) * p.W);
+                    ok[k] = it.ok && w0 + cc < p.W;
+                    off0[k] = it.pix0 * p.N + n0;
+                    e[k] = ld4(smem + (wv * TPW + ((j0 + k) >> 1)) * ES + (4 * ((j0 + k) & 1) + cc) * 64 + 4 * q4);
+                }
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    if (ok[k]) st4s(p.y + off0[k] + vq, make_float4(e[k].x + bv.x, e[k].y + bv.y, e[k].z + bv.z, e[k].w + bv.w), p.nt);
             }
-            if (up.dst) {            // input gradient at pooled resolution: straight through the max-pool backward
-                if (p.gat.src) wino_unpool_gather(up, p.up_code, p.gat, b, h, w, p.N, n0 + 4 * q4, v, p.nt);
-                else wino_unpool_add(up, p.up_code, b, h, w, p.N, n0 + 4 * q4, v);
-                continue;
-            }
-            if (p.gat.src) {
-                const float4 old = wino_gather(p.gat, b, (long)h * p.W + w, p.N, n0 + 4 * q4);
-                v = make_float4(v.x + old.x, v.y + old.y, v.z + old.z, v.w + old.w);
-            } else if (p.accum) {
-                const float4 old = ld4(p.y + off);
-                v = make_float4(v.x + old.x, v.y + old.y, v.z + old.z, v.w + old.w);
-            }
-            st4s(p.y + off, v, p.nt);
         }
+        // The general form (dense float masks, the unpooling forms without codes, gathered rows that still need their areas)
+        if (!(batched || ubatched || plain)) {
+            for (int k = 0; k < TPW; ++k) {
+                const int tl = wv * TPW + k;
+                const long tile = (long)t0 + tl;
+                if (tile >= p.T) break;
+                const int bi = fast_div((int)tile, p.dTw);
+                const int tj = (int)tile - bi * p.Tw;
+                const int b = fast_div(bi, p.dTh);
+                const int ti = bi - b * p.Th;
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                    const int h = 4 * ti + 2 * ip + r, w = 4 * tj + cc;
+                    if (h >= p.H) continue;                            // (wave-uniform)
+                    const float4 e = ld4(smem + tl * ES + (4 * r + cc) * 64 + 4 * q4);
+                    if (w >= p.W) continue;
+                    float4 v = make_float4(e.x + bv.x, e.y + bv.y, e.z + bv.z, e.w + bv.w);
+                    const long pix0 = ((long)b * p.H + h) * p.W + 4 * tj;                 // the row's first pixel (uniform)
+                    const long off0 = pix0 * p.N + n0;
+                    if (p.mask_bits) {
+                        const unsigned mb = (p.mask_bits + pix0 * (p.N >> 2) + (n0 >> 2))[cc * (p.N >> 2) + q4];
+                        v.x = (mb & 1) ? v.x : 0.f; v.y = (mb & 2) ? v.y : 0.f;
+                        v.z = (mb & 4) ? v.z : 0.f; v.w = (mb & 8) ? v.w : 0.f;
+                    } else if (p.mask) {
+                        const float4 mk = ld4(p.mask + off0 + vq);
+                        v.x = mk.x > 0.f ? v.x : 0.f; v.y = mk.y > 0.f ? v.y : 0.f;
+                        v.z = mk.z > 0.f ? v.z : 0.f; v.w = mk.w > 0.f ? v.w : 0.f;
+                    }
+                    if (up.dst) {            // input gradient at pooled resolution: straight through the max-pool backward
+                        if (p.gat.src) wino_unpool_gather(up, p.up_code, p.gat, b, h, w, p.N, n0 + 4 * q4, v, p.nt);
+                        else wino_unpool_add(up, p.up_code, b, h, w, p.N, n0 + 4 * q4, v);
+                        continue;
+                    }
+                    if (p.gat.src) {
+                        const float4 old = wino_gather(p.gat, b, (long)h * p.W + w, p.N, n0 + 4 * q4);
+                        v = make_float4(v.x + old.x, v.y + old.y, v.z + old.z, v.w + old.w);
+                    } else if (p.accum) {
+                        const float4 old = ld4(p.y + off0 + vq);
+                        v = make_float4(v.x + old.x, v.y + old.y, v.z + old.z, v.w + old.w);
+                    }
+                    st4s(p.y + off0 + vq, v, p.nt);
+                }
+            }
+        }
+        FUSED_TRACE(trE[2 * ip + 1] = __builtin_amdgcn_s_memrealtime();)      // ... and its stores are issued
         if (p.y_pool) {              // forward only (v = Y + bias): the two pooled rows 2 ti + ip of every tile
             // thread = (tile, window column k, quad): TILES x 2 x 16 = 4 NT items
 #pragma unroll
@@ -401,6 +472,13 @@ __global__ __launch_bounds__(128 * TW, 2) void wino4_gemm_out_kernel(const Fused
         }
         if (ip == 0) __syncthreads();      // everybody has read the image before the second row pair overwrites it
     }
+    FUSED_TRACE(if (g_fused_trace && tid == 0) {
+        unsigned long long* t = g_fused_trace + 9 * (long)blockIdx.x;
+        t[0] = tr0; t[1] = tr1; t[2] = __builtin_amdgcn_s_memrealtime();
+        t[5] = trE[0]; t[6] = trE[1]; t[7] = trE[2]; t[8] = trE[3];
+        t[3] = __builtin_amdgcn_s_getreg((4 /*HW_REG_HW_ID*/) | (0 << 6) | (31 << 11));
+        t[4] = __builtin_amdgcn_s_getreg((20 /*HW_REG_XCC_ID*/) | (0 << 6) | (31 << 11));
+    })
 }
 
 // WESUP_WINO_FUSED: 0 = never, 1 = forward epilogues only (bias, pooled output), 2 = every epilogue (default)

@@ -178,9 +178,9 @@ class WesupEngine:
         # gradient -- in one pass over it on the main stream (ops.winograd_dual_transform): the gradient is read once instead of
         # once per stream and twelve launches go
         self.dual_transform = True
-        # The fused upsample + scatter-mean of the shallow layers tile by tile (ops.sp_pool_tiles_fwd: every tile of the image
-        # streams its cells of the layer's output once, in raster order) instead of superpixel by superpixel through the pixel
-        # lists (ops.sp_pool_upsample_fwd: chains of dependent loads, three to five times slower beside the other streams)
+        # The scatter-mean of the native-resolution layers (conv1_1, conv1_2: the two largest reads of the pooling) tile by tile
+        # (ops.sp_pool_tiles_fwd: every 16 x 16 tile of the image streams its pixels once, in raster order) instead of superpixel
+        # by superpixel through the pixel lists (ops.sp_pool_upsample_fwd: two dependent loads per step of a wave)
         self.pool_tiles = True
         # Orderings of the schedule that were measured once and are fixed (each is bit-neutral): the side-branch
         # work of layer l behind the input transform of layer l + 1; a layer's weight gradient behind its input gradient except
@@ -534,10 +534,12 @@ class WesupEngine:
                 ops.transpose_batched([(g.Wm[i], g.WmT[i]) for g in b.groups for i in range(B)])
                 T.end(tok, 0.0)
         fused = self.fuse_pool_fwd
-        tiles = fused and self.pool_tiles and any(b.group_of[l] is None for l in range(13))
+        tiles = fused and self.pool_tiles and any(b.group_of[l] is None and b.dims[l] == (H, W) for l in range(13))
         if tiles:
-            with self._OnSide(self):     # (the label maps' tile tables: once per step, for every shallow layer)
+            with self._OnSide(self):     # (the label maps' tile tables: once per step, for the native-resolution layers)
+                tok = T.begin('sp_tiles')
                 ops.sp_tiles(meta)
+                T.end(tok, 4.0 * B * H * W)
         pending_side = None              # the side-branch work of the previous layer, when it is queued behind this layer's transform
         cur, cur_relu = b.x0, False      # the layer's input tensor, and whether its ReLU is still to be applied on load
         b.x_in, b.x_relu = [None] * 13, [False] * 13

@@ -1098,7 +1098,7 @@ def sp_pool_tiles_supported(h, w, H, W, C):
 
 
 def sp_pool_tiles_fwd(s, meta, out, coff):
-    """sp_pool_upsample_fwd tile by tile (wesup_sp_pool_tiles_fwd; needs sp_tiles(meta) of this step's label maps)."""
+    """sp_pool_upsample_fwd of a native-resolution s tile by tile (wesup_sp_pool_tiles_fwd; needs sp_tiles(meta) of this step's label maps)."""
     _chk(s, name='s'); _chk(out, name='out')
     B, h, w, C = s.shape
     t = meta.tiles
