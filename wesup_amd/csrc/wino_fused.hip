@@ -226,14 +226,19 @@ __global__ __launch_bounds__(128 * TW, 2) void wino4_gemm_out_kernel(const Fused
     }
 
     FUSED_TRACE(const unsigned long long tr1 = __builtin_amdgcn_s_memrealtime(); unsigned long long trE[4] = {0, 0, 0, 0};)
-    // ---- epilogue through LDS, two output rows of every tile per pass.  D of a 16x16 block: lane (l15, kq), component r =
-    // row 4 kq + r, column l15 -- this lane owns tiles 16 wa + 4 kq + r at channels 32 wb + 16 j + l15.  The image
-    // E[tile][row & 1][column][channel] (tile stride padded by 4 floats: the four kq groups land 16 banks apart) is read
+    // (the thread's indices again, from a value the compiler cannot tie to the ones the products used: kept alive across the main
+    // loop for the epilogue's sake they cost the K = 256 instantiation a spilled register)
+    int tid_e = threadIdx.x;
+    asm volatile("" : "+v"(tid_e));
+    const int lane_e = tid_e & 63, wave_e = tid_e >> 6, wa_e = wave_e % TW, wb_e = wave_e / TW, l15_e = lane_e & 15, kq_e = lane_e >> 4;
+    // ---- epilogue through LDS, two output rows of every tile per pass.  D of a 16x16 block: lane_e (l15_e, kq_e), component r =
+    // row 4 kq_e + r, column l15_e -- this lane_e owns tiles 16 wa_e + 4 kq_e + r at channels 32 wb_e + 16 j + l15_e.  The image
+    // E[tile][row & 1][column][channel] (tile stride padded by 4 floats: the four kq_e groups land 16 banks apart) is read
     // back as 16-byte channel quads, a thread per (pixel, quad), so that bias / mask / accumulate / pooling / unpooling and
-    // the stores move 16 B per lane on 256-byte channel segments -- the output transform's own epilogue.
+    // the stores move 16 B per lane_e on 256-byte channel segments -- the output transform's own epilogue.
     const int Hp = p.H >> 1, Wp = p.W >> 1;
     const WinoUnpool up = {p.up_src, p.up_dst, p.Hu, p.Wu};
-    const int q4 = tid & 15, slot = (tid >> 4) & 7, tsel = tid >> 7;          // reader: channel quad, (row & 1, column), tile index mod NW / 2
+    const int q4 = tid_e & 15, slot = (tid_e >> 4) & 7, tsel = tid_e >> 7;          // reader: channel quad, (row & 1, column), tile index mod NW / 2
     float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
     if (p.bias) bv = ld4(p.bias + n0 + 4 * q4);
 #pragma unroll
@@ -247,7 +252,7 @@ __global__ __launch_bounds__(128 * TW, 2) void wino4_gemm_out_kernel(const Fused
                 for (int i2 = 0; i2 < 2; ++i2)
 #pragma unroll
                     for (int jj = 0; jj < 4; ++jj)
-                        smem[(16 * wa + 4 * kq + r) * ES + (4 * i2 + jj) * 64 + 32 * wb + 16 * j + l15] = Y[2 * ip + i2][jj][j][r];
+                        smem[(16 * wa_e + 4 * kq_e + r) * ES + (4 * i2 + jj) * 64 + 32 * wb_e + 16 * j + l15_e] = Y[2 * ip + i2][jj][j][r];
         __syncthreads();
         FUSED_TRACE(trE[2 * ip] = __builtin_amdgcn_s_memrealtime();)          // the image of this row pair is in LDS
         const int i = 2 * ip + (slot >> 2), jj = slot & 3;
@@ -255,17 +260,17 @@ __global__ __launch_bounds__(128 * TW, 2) void wino4_gemm_out_kernel(const Fused
         // time, every load of a level issued before the first use -- out-of-image pixels are clamped and predicated instead of
         // skipped, so that nothing divergent stands between the loads.
         const bool batched = !up.dst && !p.mask && !(p.gat.src && p.gat.area) && (p.mask_bits || p.accum || p.gat.src);
-        // Every form below: a wave walks ITS tiles (TILES / NW of the block's), its lanes = (column of the tile row, channel quad).
-        // The tile's decomposition, the row's pixel base and every 64-bit address part are wave-uniform -- scalar instructions --
-        // and a lane adds one constant 32-bit offset.  (Round 5: beside a block that is in its products the epilogue's VECTOR
+        // Every form below: a wave_e walks ITS tiles (TILES / NW of the block's), its lanes = (column of the tile row, channel quad).
+        // The tile's decomposition, the row's pixel base and every 64-bit address part are wave_e-uniform -- scalar instructions --
+        // and a lane_e adds one constant 32-bit offset.  (Round 5: beside a block that is in its products the epilogue's VECTOR
         // instructions wait for gaps in the neighbour's MFMA stream, ~40 cycles each -- tools/probes/coexec.hip, fused_phases.hip:
         // the epilogue lasted as long as the products --; with a thread per (pixel, quad) of sixteen different tiles every store
         // cost ~45 vector instructions of index arithmetic.)
         constexpr int TPW = TILES / NW;
-        const int wv = __builtin_amdgcn_readfirstlane(wave);
-        const int cc = lane >> 4;                                  // column of the tile row this lane handles
+        const int wv = __builtin_amdgcn_readfirstlane(wave_e);
+        const int cc = lane_e >> 4;                                  // column of the tile row this lane_e handles
         const unsigned vq = (unsigned)(cc * p.N + 4 * q4);        // ... as an element offset from the row's first pixel
-        // item j of a wave's pass: tile wv TPW + (j >> 1), row 2 ip + (j & 1) of it; wave-uniform
+        // item j of a wave_e's pass: tile wv TPW + (j >> 1), row 2 ip + (j & 1) of it; wave_e-uniform
         struct Item { long pix0; int b, h; bool ok; };
         auto item = [&](int j) {
             Item it;
@@ -408,7 +413,7 @@ __global__ __launch_bounds__(128 * TW, 2) void wino4_gemm_out_kernel(const Fused
 #pragma unroll
                 for (int r = 0; r < 2; ++r) {
                     const int h = 4 * ti + 2 * ip + r, w = 4 * tj + cc;
-                    if (h >= p.H) continue;                            // (wave-uniform)
+                    if (h >= p.H) continue;                            // (wave_e-uniform)
                     const float4 e = ld4(smem + tl * ES + (4 * r + cc) * 64 + 4 * q4);
                     if (w >= p.W) continue;
                     float4 v = make_float4(e.x + bv.x, e.y + bv.y, e.z + bv.z, e.w + bv.w);
@@ -444,7 +449,7 @@ __global__ __launch_bounds__(128 * TW, 2) void wino4_gemm_out_kernel(const Fused
             // thread = (tile, window column k, quad): TILES x 2 x 16 = 4 NT items
 #pragma unroll
             for (int it = 0; it < 4; ++it) {
-                const int item = it * NT + tid;
+                const int item = it * NT + tid_e;
                 const int q = item & 15, k = (item >> 4) & 1, tl = item >> 5;
                 const long tile = (long)t0 + tl;
                 if (tile >= p.T) continue;

@@ -261,6 +261,19 @@ class WesupEngine:
             self._edge(self._side(), torch.cuda.current_stream())
 
     # ------------------------------------------------------------------ buffers
+    BYTES_PER_PIXEL = 16 * 1024      # a training buffer set, generously (measured: 9.3 GiB at 4 x 480 x 480 = 10.6 KiB per pixel)
+
+    def _memory_short(self, pixels):
+        """The cache bounds above are counts; what ends a run is the allocator failing.  Before a set for a new shape is made: is
+        there room for it -- free device memory plus what torch's caching allocator holds unused?  If not the least recently used
+        sets go first (a co-resident job, a smaller GPU, or other tensors of the caller's have taken the room the bounds assume)."""
+        try:
+            free, _ = torch.cuda.mem_get_info(self.device)
+            idle = torch.cuda.memory_reserved(self.device) - torch.cuda.memory_allocated(self.device)
+        except Exception:
+            return False
+        return free + idle < pixels * self.BYTES_PER_PIXEL
+
     def _get_bufs(self, B, H, W, Kmax, train):
         key = (B, H, W, Kmax)
         b = self._bufs.get(key)
@@ -273,7 +286,8 @@ class WesupEngine:
             # evicted buffers go back to torch's caching allocator, which hands their blocks to the next shape.
             px = lambda k: k[0] * k[1] * k[2]
             while self._bufs and (len(self._bufs) >= max(1, self.max_cached_shapes)
-                                  or sum(px(k) for k in self._bufs) + px(key) > self.max_cached_pixels):
+                                  or sum(px(k) for k in self._bufs) + px(key) > self.max_cached_pixels
+                                  or self._memory_short(px(key))):
                 _, old = self._bufs.popitem(last=False)
                 if old is self._last:
                     self._last = None

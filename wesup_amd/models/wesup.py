@@ -359,6 +359,10 @@ class WESUP(nn.Module):
         self._grad_views = gv
         self._anchor = torch.zeros(1, device=dev, requires_grad=True)
         self.engine = WesupEngine(pv, gv, D=self.D)
+        # bounds of the per-shape buffer cache (engine.py _get_bufs): WESUP(..., max_cached_shapes=, max_cached_pixels=)
+        for k in ('max_cached_shapes', 'max_cached_pixels'):
+            if self.kwargs.get(k) is not None:
+                setattr(self.engine, k, int(self.kwargs[k]))
 
     def _publish_grads(self):
         for name, p in self._named:

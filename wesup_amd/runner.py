@@ -98,6 +98,7 @@ class StepRunner:
         self.replay = os.environ.get('WESUP_STEP_PLAN', '1') != '0' and trainer.kwargs.get('step_plan', True)
         self.stats = {'eager': 0, 'recorded': 0, 'replayed': 0, 'dropped': 0}
         self._cuts = None
+        self._routes = {}
 
     # ------------------------------------------------------------------ which iterations take this path
     def parse(self, phase, data):
@@ -149,8 +150,18 @@ class StepRunner:
                 ops._stream().value,
                 # the engine object itself (model.to(device) re-makes it and restarts buf_generation), the per-shape routing result
                 # and the process-wide rule behind it, the flat parameter / gradient / momentum buffers, the Winograd filter panels
-                id(eng), tuple(eng.route(B, H, W)), ops.winograd_fused_min_blocks(),
+                id(eng), self._route_of(eng, B, H, W), ops.winograd_fused_min_blocks(),
                 m._flat.data_ptr(), m._flat_grad.data_ptr(), o._vflat.data_ptr(), panels)
+
+    def _route_of(self, eng, B, H, W):
+        """eng.route(B, H, W) as a tuple, remembered per (routing rule, shape): thirteen calls of the rule per iteration otherwise."""
+        key = (id(eng), eng.route_fn, eng.conv_winograd, ops.winograd_fused_min_blocks(), B, H, W)
+        r = self._routes.get(key)
+        if r is None:
+            if len(self._routes) > 4 * MAX_STATES:
+                self._routes.clear()
+            r = self._routes[key] = tuple(eng.route(B, H, W))
+        return r
 
     # ------------------------------------------------------------------ the iteration
     def run(self, parsed):
