@@ -55,7 +55,7 @@ def parse_args(argv=None):
                                                                 'implicit-GEMM kernel (no Winograd-domain wgrad)')
     ap.add_argument('--side-before-pool', action='store_true', help='A/B: the shallow side convs in front of the upsample + superpixel mean, side outputs materialised (round 2 / early round 3 schedule)')
     ap.add_argument('--no-gather-epilogue', action='store_true', help='A/B: the side-branch gradient of conv1_1 / conv1_2 materialised (gather kernel) and accumulated into, instead of gathered by the dgrad epilogue')
-    ap.add_argument('--no-pool-tiles', action='store_true', help='A/B: the scatter-mean of the native-resolution layers through the pixel lists (segment form) instead of per 16 x 16 tile')
+    ap.add_argument('--pool-tiles', action='store_true', help='A/B: the scatter-mean of the native-resolution layers per 16 x 16 tile (wesup_sp_pool_tiles_fwd) instead of through the pixel lists (segment form)')
     ap.add_argument('--float-masks', action='store_true', help='A/B: the dgrad epilogues read the pre-ReLU conv outputs for the ReLU mask / the max-pool decisions instead of the sign bits / codes the forward leaves')
     ap.add_argument('--no-dual-transform', action='store_true', help='A/B: the input-gradient and weight-gradient transforms of a layer\'s output gradient as two launches on two streams (each reads the gradient)')
     ap.add_argument('--diag-skip', default='', help="TIMING-ONLY diagnostic (results are wrong): comma list of launch classes left out "
@@ -274,7 +274,7 @@ def worker(args):
     eng.wgrad_winograd = not args.direct_wgrad
     eng.commute_side = not args.side_before_pool
     eng.gather_side_grad = not args.no_gather_epilogue
-    eng.pool_tiles = not args.no_pool_tiles
+    eng.pool_tiles = args.pool_tiles
     eng.compact_masks = not args.float_masks
     eng.dual_transform = not args.no_dual_transform
     if use_dist and args.ddp_probe != 'pg':

@@ -346,7 +346,7 @@ int wesup_sp_pool_upsample_fwd(const float* s, const int32_t* pix_sorted, const 
                                int B, int h, int w, int H, int W, int C, int ldo, int coff, int Kmax, int Umax,
                                void* ws, size_t ws_bytes, void* stream);
 /* The scatter-mean of a side output at the image's OWN resolution (h == H, w == W: torch.mm over it, models/wesup.py:283-285)
- * tile by tile: the form the training step runs for conv1_1 / conv1_2.  wesup_sp_tiles, once per label map: the image in
+ * tile by tile (an alternative to wesup_sp_pool_upsample_fwd for such a layer: engine.pool_tiles).  wesup_sp_tiles, once per label map: the image in
  * 16 x 16-pixel tiles; per tile the rows present (ascending) and every pixel's slot in that list; per row the box of tiles it
  * touches; part rows per tile (prefix sums).
  *   slot [B][HW] uint8, tile_ns / tile_base [B][ntile], tile_rows [B][ntile][256], alloc [B], row_flag [B][Kmax], bbox [B][Kmax][4]

@@ -43,7 +43,7 @@ def make_trainer(weights, **kw):
 
 
 @pytest.mark.parametrize('name', CASES)
-@pytest.mark.parametrize('fused', [True, False, 'side_as_gemm', 'direct_convs', 'side_before_pool', 'gather_kernel', 'float_masks', 'two_transforms', 'pool_lists'])
+@pytest.mark.parametrize('fused', [True, False, 'side_as_gemm', 'direct_convs', 'side_before_pool', 'gather_kernel', 'float_masks', 'two_transforms', 'pool_tiles'])
 def test_step_matches_reference_golden(golden_dir, name, fused):
     from oracle import wesup_oracle as orc
     from wesup_amd.models.wesup import preprocess_label_maps, SuperpixelMaps
@@ -64,8 +64,8 @@ def test_step_matches_reference_golden(golden_dir, name, fused):
         model.engine.compact_masks = False
     if fused == 'two_transforms':     # the output gradient's two F(4x4) transforms as separate launches (default: one pass)
         model.engine.dual_transform = False
-    if fused == 'pool_lists':         # the native-resolution layers' scatter-mean through the pixel lists (default: per 16 x 16 tile)
-        model.engine.pool_tiles = False
+    if fused == 'pool_tiles':         # the native-resolution layers' scatter-mean per 16 x 16 tile (default: through the pixel lists)
+        model.engine.pool_tiles = True
     if fused == 'gather_kernel':      # the native-resolution side-branch gradients materialised by the gather kernel (default: gathered in the dgrad epilogue)
         model.engine.gather_side_grad = False
     fused = bool(fused)

@@ -124,37 +124,36 @@ extern "C" int wesup_classifier_bwd(const float* feat, const float* Wc, const fl
 }
 
 // ------------------------------------------------------------------ label propagation (models/wesup.py:99-139)
-__global__ void prop_init_kernel(const float* __restrict__ sp_labels, const int32_t* __restrict__ n_l,
-                                 float* __restrict__ y_all, int32_t* __restrict__ src_idx, float* __restrict__ max_sim,
-                                 int Kmax, int C, long total) {
-    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= total) return;
-    const long br = idx / C;
-    const int b = br / Kmax, r = br - (long)b * Kmax;
-    y_all[idx] = (r < n_l[b]) ? sp_labels[idx] : 0.f;
-    if (idx % C == 0) {
-        src_idx[br] = -1;
-        max_sim[br] = 0.f;
-    }
-}
-// One wave per unlabelled row i; lanes stride over labelled rows j (staged in LDS 256 at a time, row stride
-// D+1 floats so that lanes hit distinct banks).  d_ij = sum_k (f_j,k - f_i,k)^2 as a direct difference in
-// ascending k (not |a|^2+|b|^2-2ab: near-ties must not flip); W = expf(-d); the row maximum takes the FIRST
-// (lowest) labelled index on ties, as torch.max(dim=1) does; propagate iff W > threshold (strict).
+// One launch: a block owns PROP_ROWS consecutive rows of an image.  It first writes what every row has whatever happens next --
+// y_all = the row's own labels (labelled rows) or zeros, src_idx = -1, max_sim = 0 (a launch of its own until round 5) -- and
+// then, for its unlabelled rows, one wave per row: lanes stride over the labelled rows j (staged in LDS 256 at a time, row stride
+// D+1 floats so that lanes hit distinct banks).  d_ij = sum_k (f_j,k - f_i,k)^2 as a direct difference in ascending k (not
+// |a|^2+|b|^2-2ab: near-ties must not flip); W = expf(-d); the row maximum takes the FIRST (lowest) labelled index on ties, as
+// torch.max(dim=1) does; propagate iff W > threshold (strict).
 #define PROP_TILE 256
 #define PROP_ROWS 16
 __global__ __launch_bounds__(256) void prop_kernel(const float* __restrict__ feat, const float* __restrict__ sp_labels,
                                                    const int32_t* __restrict__ n_sp, const int32_t* __restrict__ n_l,
-                                                   float thr, float* __restrict__ y_all, int32_t* __restrict__ src_idx,
+                                                   float thr, int enable, float* __restrict__ y_all, int32_t* __restrict__ src_idx,
                                                    float* __restrict__ max_sim, int Kmax, int D, int C) {
     extern __shared__ float sh[];
     float* fl = sh;                               // [PROP_TILE][D+1]
     float* fi = sh + PROP_TILE * (D + 1);         // [PROP_ROWS][D]
     const int b = blockIdx.y;
     const int nl = n_l[b], ns = n_sp[b];
-    const int i_blk = nl + blockIdx.x * PROP_ROWS;
-    if (nl <= 0 || i_blk >= ns) return;           // uniform per block
+    const int i_blk = blockIdx.x * PROP_ROWS;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int e = tid; e < PROP_ROWS * C; e += 256) {
+        const int r = i_blk + e / C;
+        if (r < Kmax) y_all[((long)b * Kmax + i_blk) * C + e] = (r < nl) ? sp_labels[((long)b * Kmax + i_blk) * C + e] : 0.f;
+    }
+    if (tid < PROP_ROWS && i_blk + tid < Kmax) {
+        src_idx[(long)b * Kmax + i_blk + tid] = -1;
+        max_sim[(long)b * Kmax + i_blk + tid] = 0.f;
+    }
+    // rows of this block that take part in the propagation: unlabelled and present (uniform per block)
+    if (!enable || nl <= 0 || i_blk + PROP_ROWS <= nl || i_blk >= ns) return;
+    __syncthreads();                              // (the defaults above are written before a propagated row overwrites its own)
     const float* fb = feat + (long)b * Kmax * D;
     for (int e = tid; e < PROP_ROWS * D; e += 256) {
         const int rr = e / D, k = e - rr * D;
@@ -177,6 +176,8 @@ __global__ __launch_bounds__(256) void prop_kernel(const float* __restrict__ fea
         __syncthreads();
 #pragma unroll
         for (int q = 0; q < PROP_ROWS / 4; ++q) {
+            const int i = i_blk + wave * (PROP_ROWS / 4) + q;
+            if (i < nl || i >= ns) continue;      // (wave-uniform: a labelled or absent row)
             const float* f_i = fi + (wave * (PROP_ROWS / 4) + q) * D;
             for (int jj = lane; jj < nj; jj += 64) {
                 const float* f_j = fl + jj * (D + 1);
@@ -207,7 +208,7 @@ __global__ __launch_bounds__(256) void prop_kernel(const float* __restrict__ fea
             }
         }
         const int i = i_blk + wave * (PROP_ROWS / 4) + q;
-        if (lane == 0 && i < ns) {
+        if (lane == 0 && i >= nl && i < ns) {
             max_sim[(long)b * Kmax + i] = w;
             src_idx[(long)b * Kmax + i] = j;
             if (w > thr)
@@ -223,14 +224,9 @@ extern "C" int wesup_propagate(const float* feat, const float* sp_labels, const 
         D > 256 || C <= 0)
         return WESUP_ERR_INVALID;
     hipStream_t st = (hipStream_t)stream;
-    const long total = (long)B * Kmax * C;
-    WESUP_LAUNCH(prop_init_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, sp_labels, n_l, y_all,
-                       src_idx, max_sim, Kmax, C, total);
-    if (enable) {
-        const size_t lds = ((size_t)PROP_TILE * (D + 1) + (size_t)PROP_ROWS * D) * sizeof(float);
-        WESUP_LAUNCH(prop_kernel, dim3(ceil_div(Kmax, PROP_ROWS), B), dim3(256), lds, st, feat, sp_labels, n_sp, n_l,
-                           threshold, y_all, src_idx, max_sim, Kmax, D, C);
-    }
+    const size_t lds = ((size_t)PROP_TILE * (D + 1) + (size_t)PROP_ROWS * D) * sizeof(float);
+    WESUP_LAUNCH(prop_kernel, dim3(ceil_div(Kmax, PROP_ROWS), B), dim3(256), lds, st, feat, sp_labels, n_sp, n_l, threshold,
+                 enable, y_all, src_idx, max_sim, Kmax, D, C);
     WESUP_CHECK_LAUNCH();
     return WESUP_OK;
 }

@@ -24,6 +24,8 @@ few large RCCL calls launched while the rest of backward still runs.
 """
 from collections import OrderedDict
 
+import os
+
 import torch
 
 from . import ops
@@ -180,8 +182,11 @@ class WesupEngine:
         self.dual_transform = True
         # The scatter-mean of the native-resolution layers (conv1_1, conv1_2: the two largest reads of the pooling) tile by tile
         # (ops.sp_pool_tiles_fwd: every 16 x 16 tile of the image streams its pixels once, in raster order) instead of superpixel
-        # by superpixel through the pixel lists (ops.sp_pool_upsample_fwd: two dependent loads per step of a wave)
-        self.pool_tiles = True
+        # by superpixel through the pixel lists (ops.sp_pool_upsample_fwd: two dependent loads per step of a wave).  Alone on the
+        # GPU the tile form is faster at 4 x 480^2 (58 vs 95 us per layer) and slower at 8 x 1024^2 (473 vs 383 us); inside the
+        # step, beside the product kernels of the next layer, it is slower (128 vs 102 us per layer, 158 VGPRs per thread against
+        # 50: its blocks wait longer for room on a CU) and the step is 8.25 vs 8.22 ms in three alternating pairs
+        self.pool_tiles = False          # (default off: in the 3-stream step the tile form is 0.03 ms slower, profiles/r05_ab_pool_conv1.txt)
         # Orderings of the schedule that were measured once and are fixed (each is bit-neutral): the side-branch
         # work of layer l behind the input transform of layer l + 1; a layer's weight gradient behind its input gradient except
         # for the lowest trainable layer's neighbour; every G_l before the side convs' own weight gradients, those of the deep
@@ -548,8 +553,8 @@ class WesupEngine:
                 ops.transpose_batched([(g.Wm[i], g.WmT[i]) for g in b.groups for i in range(B)])
                 T.end(tok, 0.0)
         fused = self.fuse_pool_fwd
-        tiles = fused and self.pool_tiles and any(b.group_of[l] is None and b.dims[l] == (H, W) for l in range(13))
-        if tiles:
+        pool_tiles = fused and self.pool_tiles and any(b.group_of[l] is None and b.dims[l] == (H, W) for l in range(13))
+        if pool_tiles:
             with self._OnSide(self):     # (the label maps' tile tables: once per step, for the native-resolution layers)
                 tok = T.begin('sp_tiles')
                 ops.sp_tiles(meta)
@@ -632,7 +637,7 @@ class WesupEngine:
                 T.end(tok, 2.0 * B * h * w * co * ((3 if l == 0 else ci) * 9 + (co // 2 if side_in_conv else 0)))
             # side branch of this layer: 1x1 conv on the pre-ReLU tap, then either the fused upsample+scatter-mean
             # straight into the superpixel feature slice, or upsample into fm's channel slice
-            def side_work(l=l, ci=ci, co=co, h=h, w=w, off=off, ws=ws, commute=commute, s_l=s_l, s2d=s2d, side_in_conv=side_in_conv, tiles=tiles):
+            def side_work(l=l, ci=ci, co=co, h=h, w=w, off=off, ws=ws, commute=commute, s_l=s_l, s2d=s2d, side_in_conv=side_in_conv, pool_tiles=pool_tiles):
               with self._OnSide(self):
                 grp = b.groups[b.group_of[l]] if b.group_of[l] is not None else None
                 if ('side_fwd_shallow' in self._diag_skip and grp is None) or ('side_fwd_deep' in self._diag_skip and grp is not None):
@@ -641,7 +646,7 @@ class WesupEngine:
                     if b.ybar[l] is None:
                         b.ybar[l] = torch.empty(B, Kmax, co, dtype=torch.float32, device=self.device)
                     tok = T.begin('sp_pool_up_fwd')          # (commuted layers are the gather layers: no interpolation matrix)
-                    if tiles and ops.sp_pool_tiles_supported(h, w, H, W, co):
+                    if pool_tiles and ops.sp_pool_tiles_supported(h, w, H, W, co):
                         ops.sp_pool_tiles_fwd(b.y[l], meta, b.ybar[l], 0)
                     else:
                         ops.sp_pool_upsample_fwd(b.y[l], meta, b.ybar[l], 0)
@@ -665,7 +670,7 @@ class WesupEngine:
                         T.end(tok, 2.0 * B * Kmax * g.h * g.w * g.C)
                 elif fused:
                     tok = T.begin('sp_pool_up_fwd')
-                    if tiles and ops.sp_pool_tiles_supported(h, w, H, W, co // 2):
+                    if pool_tiles and ops.sp_pool_tiles_supported(h, w, H, W, co // 2):
                         ops.sp_pool_tiles_fwd(s_l, meta, b.sp_in, off)
                     else:
                         ops.sp_pool_upsample_fwd(s_l, meta, b.sp_in, off)
