@@ -403,7 +403,8 @@ int wesup_propagate(const float* feat, const float* sp_labels, const int32_t* n_
                     float threshold, int enable, float* y_all, int32_t* src_idx, float* max_sim,
                     int B, int Kmax, int D, int C, void* stream);
 /* _cross_entropy + compute_loss (models/wesup.py:66-96,492-531), per image then mean over images:
- * terms[b] = {sup_sum, sup_cnt, prop_sum, prop_cnt, prop_label_sum, loss_b, 0, 0}; loss[0] = mean_b loss_b */
+ * terms[b] = {sup_sum, sup_cnt, prop_sum, prop_cnt, prop_label_sum, loss_b, 0, 0}; loss[0] = mean_b loss_b = (sum over b in
+ * ascending order, in fp32) / B -- or loss == NULL: no second launch, the caller forms that mean from terms */
 int wesup_loss_fwd(const float* pred, const float* y_all, const int32_t* n_sp, const int32_t* n_l,
                    float eps, float prop_weight, float* terms, float* loss, int B, int Kmax, int C, void* stream);
 /* dpred = dloss[0] * d loss / d pred */

@@ -288,10 +288,12 @@ __global__ void loss_mean_kernel(const float* __restrict__ terms, float* __restr
 }
 extern "C" int wesup_loss_fwd(const float* pred, const float* y_all, const int32_t* n_sp, const int32_t* n_l, float eps,
                               float prop_weight, float* terms, float* loss, int B, int Kmax, int C, void* stream) {
-    if (!pred || !y_all || !n_sp || !n_l || !terms || !loss || B <= 0 || Kmax <= 0 || C <= 0) return WESUP_ERR_INVALID;
+    if (!pred || !y_all || !n_sp || !n_l || !terms || B <= 0 || Kmax <= 0 || C <= 0) return WESUP_ERR_INVALID;
     hipStream_t st = (hipStream_t)stream;
     WESUP_LAUNCH(loss_fwd_kernel, dim3(B), dim3(256), 0, st, pred, y_all, n_sp, n_l, eps, prop_weight, terms, Kmax, C);
-    WESUP_LAUNCH(loss_mean_kernel, dim3(1), dim3(64), 0, st, (const float*)terms, loss, B);
+    // (loss == NULL: the caller forms the mean of terms[b][5] itself -- the step runner does, on the host, from the block it
+    // reads back anyway: one launch less on the chain between forward and backward)
+    if (loss) WESUP_LAUNCH(loss_mean_kernel, dim3(1), dim3(64), 0, st, (const float*)terms, loss, B);
     WESUP_CHECK_LAUNCH();
     return WESUP_OK;
 }

@@ -272,12 +272,15 @@ class WesupEngine:
         """The cache bounds above are counts; what ends a run is the allocator failing.  Before a set for a new shape is made: is
         there room for it -- free device memory plus what torch's caching allocator holds unused?  If not the least recently used
         sets go first (a co-resident job, a smaller GPU, or other tensors of the caller's have taken the room the bounds assume)."""
+        need = pixels * self.BYTES_PER_PIXEL
         try:
             free, _ = torch.cuda.mem_get_info(self.device)
+            if free >= need:                  # (the common case, one driver query; torch's memory statistics cost 2 ms a call)
+                return False
             idle = torch.cuda.memory_reserved(self.device) - torch.cuda.memory_allocated(self.device)
         except Exception:
             return False
-        return free + idle < pixels * self.BYTES_PER_PIXEL
+        return free + idle < need
 
     def _get_bufs(self, B, H, W, Kmax, train):
         key = (B, H, W, Kmax)

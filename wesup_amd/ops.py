@@ -82,17 +82,35 @@ def _p(t):
 
 
 _ws_cache = {}
+_ws_first = {}         # key -> size of the first request
+_ws_retired = []       # buffers replaced by a growth: kept for a while (another stream's queued kernels may still use them)
 ws_generation = 0      # bumped whenever a workspace is (re)allocated: a recorded step plan holds the old addresses
 
 
 def workspace(nbytes, device, tag='default'):
-    """Grow-only byte workspace per (device, tag)."""
+    """Grow-only byte workspace per (device, tag).  The first request of a tag is served exactly (one-shape training pays nothing
+    extra).  The first time ANY workspace has to grow, the run is known to see several shapes: that workspace becomes twice what
+    is asked for and every other workspace of the device at least twice its first size, in one go.  Every growth bumps
+    ``ws_generation`` and with it drops every recorded step plan and every plan waiting for its twin; under multi-scale training
+    (utils/data.py:98-101: shapes within a factor 1.8 of each other in area) exact-fit growth did that once per new largest shape
+    and tag, spread over the first dozens of shapes -- a shape's first recording hardly ever met its twin."""
     global ws_generation
     key = (str(device), tag)
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
-        buf = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+        regrow = buf is not None
+        if regrow:
+            _ws_retired.append(_ws_cache.pop(key))
+        buf = None
+        _ws_first.setdefault(key, int(nbytes))
+        buf = torch.empty(max((2 if regrow else 1) * int(nbytes), 256), dtype=torch.uint8, device=device)
         _ws_cache[key] = buf
+        if regrow:
+            for k2 in [k for k in _ws_cache if k[0] == key[0] and k != key]:
+                if _ws_cache[k2].numel() < 2 * _ws_first.get(k2, 0):
+                    _ws_retired.append(_ws_cache.pop(k2))          # (its stream may still run kernels of this very walk on it)
+                    _ws_cache[k2] = torch.empty(2 * _ws_first[k2], dtype=torch.uint8, device=device)
+            del _ws_retired[:-64]
         ws_generation += 1
     return buf
 
@@ -1217,8 +1235,8 @@ def loss_fwd(pred, y_all, meta, eps, prop_weight, out=None):
     B, Kmax, C = pred.shape
     assert y_all.shape == (B, Kmax, C) and B == meta.B and Kmax == meta.Kmax
     if out is not None:
-        loss, terms = out
-        assert loss.numel() == 1 and terms.shape == (B, 8) and terms.is_contiguous()
+        loss, terms = out                  # (loss None: only the per-image terms; the caller forms their mean)
+        assert (loss is None or loss.numel() == 1) and terms.shape == (B, 8) and terms.is_contiguous()
     else:
         terms = torch.empty(B, 8, dtype=torch.float32, device=pred.device)
         loss = torch.empty(1, dtype=torch.float32, device=pred.device)

@@ -214,13 +214,21 @@ class StepRunner:
             self.stats['replayed'] += 1
         else:
             if st.cand is not None and st.sig != sig:       # settings changed since the first recording: it has no twin to wait for
+                if os.environ.get('WESUP_PLAN_DEBUG'):
+                    print('[step plan] candidate dropped, signature fields that differ:',
+                          [i for i, (x, y) in enumerate(zip(st.sig, sig)) if x != y])
                 st.cand = None
             # (the very first optimiser step of a run differs from every later one -- buf = g --: not worth recording)
             record = self.replay and not timing and st.count >= RECORD_AT and st.tries < MAX_RECORD_TRIES and not t.optimizer._first
             plan = _Plan() if record else None
+            ws_gen0 = ops.ws_generation
             host = self._walk(st, metrics, want_seg, plan)
             st.count += 1
-            if plan is not None:
+            if plan is not None and ops.ws_generation != ws_gen0:
+                # a workspace grew DURING this walk: the launches before that hold the old address, a recording nobody can match
+                plan, st.cand = None, None
+                self.stats['recorded'] += 1
+            elif plan is not None:
                 self.stats['recorded'] += 1
                 gens = (ops.ws_generation, eng.bufs_gen(B, H, W, st.y_all.shape[1]))
                 sig = self._signature(eng, B, H, W)           # the state the recording ENDED in (a first walk allocates the filter
@@ -228,6 +236,8 @@ class StepRunner:
                 if st.cand is not None and st.gens == gens and _lib.load().wesup_plan_diff(st.cand.h, plan.h) == 0:
                     st.plan, st.cand = plan, None
                 else:
+                    if st.cand is not None and st.gens != gens and os.environ.get('WESUP_PLAN_DEBUG'):
+                        print(f'[step plan] twin recorded under other generations {st.gens} -> {gens}')
                     if st.cand is not None and st.gens == gens:      # (a workspace that grew in between is nobody's failure)
                         st.tries += 1
                         if os.environ.get('WESUP_PLAN_DEBUG'):
@@ -276,8 +286,11 @@ class StepRunner:
                 ops.seg_metrics(pred, st.gt, out=st.seg)
             ops.propagate(feats, st.meta, float(kw.get('propagate_threshold')), enable=bool(kw.get('enable_propagation')),
                           out=(st.y_all, st.src, st.sim))
+            # (one rank: the mean over the images is formed on the host from the per-image terms of the read-back block, in the
+            # kernel's own order and precision -- no wesup_loss_mean launch on the chain; several ranks need the loss on the device
+            # for the NaN flag)
             ops.loss_fwd(sp_pred, st.y_all, st.meta, float(kw.get('epsilon')), float(kw.get('propagate_weight')),
-                         out=(st.loss, st.terms))
+                         out=(st.loss if multi else None, st.terms))
             if multi:
                 # A NaN loss on one rank must stop every rank (models/base.py _loss_flag): a MAX all-reduce of a flag on a
                 # stream of its own, the read-back copy behind it.  Host work (torch collectives), i.e. a cut of the plan.
@@ -343,7 +356,15 @@ class StepRunner:
         raw = st.host.numpy()
         f = raw[:st.n_f].astype(np.float64)
         cnt = raw[st.n_f:].view(np.int32).reshape(3, B)
-        host = {'loss': float(f[0]), 'terms': f[1:1 + 8 * B].reshape(B, 8), 'seg': f[1 + 8 * B:1 + 12 * B].reshape(B, 4),
+        if st.rb_event is not None:
+            loss = float(f[0])
+        else:                               # loss[0] = (sum of terms[b][5] over b ascending, fp32) / B, as loss_mean_kernel forms it
+            t32 = raw[1:1 + 8 * B].reshape(B, 8)
+            s32 = np.float32(0.0)
+            for b in range(B):
+                s32 = np.float32(s32 + t32[b, 5])
+            loss = float(np.float32(s32 / np.float32(B)))
+        host = {'loss': loss, 'terms': f[1:1 + 8 * B].reshape(B, 8), 'seg': f[1 + 8 * B:1 + 12 * B].reshape(B, 4),
                 'n_sp': cnt[0].astype(np.float64), 'n_l': cnt[1].astype(np.float64)}
         nan_anywhere = f[st.n_f - 1] if st.rb_event is not None else 0.0
         if math.isnan(host['loss']) or nan_anywhere > 0:
