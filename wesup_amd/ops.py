@@ -87,30 +87,38 @@ _ws_retired = []       # buffers replaced by a growth: kept for a while (another
 ws_generation = 0      # bumped whenever a workspace is (re)allocated: a recorded step plan holds the old addresses
 
 
+ws_headroom = 1        # 2 once the step runner has met a second shape (set_workspace_headroom): see workspace()
+
+
+def set_workspace_headroom(factor):
+    global ws_headroom
+    ws_headroom = max(1, int(factor))
+
+
 def workspace(nbytes, device, tag='default'):
-    """Grow-only byte workspace per (device, tag).  The first request of a tag is served exactly (one-shape training pays nothing
-    extra).  The first time ANY workspace has to grow, the run is known to see several shapes: that workspace becomes twice what
-    is asked for and every other workspace of the device at least twice its first size, in one go.  Every growth bumps
-    ``ws_generation`` and with it drops every recorded step plan and every plan waiting for its twin; under multi-scale training
-    (utils/data.py:98-101: shapes within a factor 1.8 of each other in area) exact-fit growth did that once per new largest shape
-    and tag, spread over the first dozens of shapes -- a shape's first recording hardly ever met its twin."""
+    """Grow-only byte workspace per (device, tag), served exactly while a run has one shape (``ws_headroom`` 1: the benchmark
+    configurations pay nothing extra).  Once the step runner has met a second shape it sets the headroom to 2: from then on a
+    workspace that has to grow becomes twice what is asked for and, in the same go, every other workspace of the device at least
+    twice its first size.  Every growth bumps ``ws_generation`` and with it drops every recorded step plan and every plan waiting
+    for its twin; under multi-scale training (utils/data.py:98-101: shapes within a factor 1.8 of each other in area) exact-fit
+    growth did that once per new largest shape and tag, spread over the first dozens of shapes -- a shape's first recording hardly
+    ever met its twin (3.4 -> 2.2 recordings per shape over the 94-shape rotation; the cold line itself moves with the box, 262 ... 297 img/s)."""
     global ws_generation
     key = (str(device), tag)
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
-        regrow = buf is not None
-        if regrow:
-            _ws_retired.append(_ws_cache.pop(key))
-        buf = None
+        regrow = buf is not None and ws_headroom > 1
+        buf = None                                       # (the tag's own stream orders the release behind its queued kernels)
+        _ws_cache.pop(key, None)
         _ws_first.setdefault(key, int(nbytes))
-        buf = torch.empty(max((2 if regrow else 1) * int(nbytes), 256), dtype=torch.uint8, device=device)
+        buf = torch.empty(max((ws_headroom if regrow else 1) * int(nbytes), 256), dtype=torch.uint8, device=device)
         _ws_cache[key] = buf
         if regrow:
             for k2 in [k for k in _ws_cache if k[0] == key[0] and k != key]:
-                if _ws_cache[k2].numel() < 2 * _ws_first.get(k2, 0):
-                    _ws_retired.append(_ws_cache.pop(k2))          # (its stream may still run kernels of this very walk on it)
-                    _ws_cache[k2] = torch.empty(2 * _ws_first[k2], dtype=torch.uint8, device=device)
-            del _ws_retired[:-64]
+                if _ws_cache[k2].numel() < ws_headroom * _ws_first.get(k2, 0):
+                    _ws_retired.append(_ws_cache.pop(k2))      # (ITS stream may still run kernels of this very walk on it)
+                    _ws_cache[k2] = torch.empty(ws_headroom * _ws_first[k2], dtype=torch.uint8, device=device)
+        del _ws_retired[:-64]
         ws_generation += 1
     return buf
 

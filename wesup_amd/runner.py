@@ -184,6 +184,8 @@ class StepRunner:
             while len(self.states) >= MAX_STATES:
                 self.states.pop(next(iter(self.states)))
             st = _State(B, H, W, C, Kmax, dev, mask is not None, want_seg)
+            if self.states:                           # a second shape: shared workspaces get headroom from now on (ops.workspace)
+                ops.set_workspace_headroom(2)
         self.states[key] = st                         # (most recently used last)
         if t.reducer is not None:
             t.reducer.reset()                         # nothing may be left over from an iteration that raised
