@@ -58,6 +58,7 @@ def parse_args(argv=None):
     ap.add_argument('--pool-tiles', action='store_true', help='A/B: the scatter-mean of the native-resolution layers per 16 x 16 tile (wesup_sp_pool_tiles_fwd) instead of through the pixel lists (segment form)')
     ap.add_argument('--float-masks', action='store_true', help='A/B: the dgrad epilogues read the pre-ReLU conv outputs for the ReLU mask / the max-pool decisions instead of the sign bits / codes the forward leaves')
     ap.add_argument('--no-dual-transform', action='store_true', help='A/B: the input-gradient and weight-gradient transforms of a layer\'s output gradient as two launches on two streams (each reads the gradient)')
+    ap.add_argument('--engine-set', default='', help='A/B: comma list of name=value engine switches (bool / int attributes of WesupEngine), e.g. late_bwd_pack=0')
     ap.add_argument('--diag-skip', default='', help="TIMING-ONLY diagnostic (results are wrong): comma list of launch classes left out "
                                                     "of the step after the warm-up (learning rate 0 from there on) -- 'wgrad' (conv weight gradients), 'side_wgrad', "
                                                     "'side_fwd_shallow' (pooling + side conv of conv1_1 .. conv3_3), 'side_fwd_deep' -- to see what they cost the step")
@@ -277,6 +278,10 @@ def worker(args):
     eng.pool_tiles = args.pool_tiles
     eng.compact_masks = not args.float_masks
     eng.dual_transform = not args.no_dual_transform
+    for kv in filter(None, args.engine_set.split(',')):
+        k, v = kv.split('=')
+        assert isinstance(getattr(eng, k), (bool, int)), k
+        setattr(eng, k, type(getattr(eng, k))(int(v)))
     if use_dist and args.ddp_probe != 'pg':
         trainer.enable_data_parallel(bucket_bytes=args.bucket_mb << 20)
 

@@ -710,6 +710,31 @@ def test_gemm_tn_batched(ops):
         assert rel_err(ops.gemm_tn(A[i], Bm[i]), ref[i]) < TOL
 
 
+def test_gemm_tn_one_split_stores_straight_into_a_strided_output(ops):
+    """Grids that fill the chip without a split (>= 600 tiles: the step's Wm^T g at 60 x 60, four images) run one split and the
+    kernel's epilogue stores into C itself -- no slab, no reduce launch (csrc/gemm.hip: tn_direct).  Row-strided outputs with
+    untouched neighbours, batched and single, M not a multiple of the tile."""
+    d = dev()
+    nb, K, M, N = 4, 640, 3600, 768
+    A = rnd(nb, K, M, seed=3).to(d)
+    Bm = rnd(nb, K, N, seed=4).to(d)
+    outbig = torch.full((nb, M, N + 64), 7.0, device=d)
+    out = outbig[:, :, 32:32 + N]
+    ops.gemm_tn_batched(A, Bm, out)
+    ref = torch.einsum('bkm,bkn->bmn', A.double().cpu(), Bm.double().cpu()).float()
+    assert rel_err(out, ref) < TOL
+    assert float((outbig[:, :, :32] - 7.0).abs().max()) == 0.0 and float((outbig[:, :, 32 + N:] - 7.0).abs().max()) == 0.0
+    K, M, N = 330, 4036, 2556                        # 32 x 20 tiles of 128 x 128, ragged edges in both directions
+    A1, B1 = rnd(K, M, seed=5).to(d), rnd(K, N, seed=6).to(d)
+    big = torch.full((M, N + 8), -3.0, device=d)
+    ops.gemm_tn(A1, B1, out=big[:, 4:4 + N])
+    assert rel_err(big[:, 4:4 + N], (A1.double().cpu().t() @ B1.double().cpu()).float()) < TOL
+    assert float((big[:, :4] + 3.0).abs().max()) == 0.0 and float((big[:, 4 + N:] + 3.0).abs().max()) == 0.0
+    cs = torch.empty(M, device=d)                    # with column sums the slab path stays (they sit behind the slabs)
+    out_cs = ops.gemm_tn(A1, B1, colsum=cs)
+    assert torch.equal(out_cs, big[:, 4:4 + N].contiguous()) and rel_err(cs, A1.double().cpu().sum(0).float()) < TOL
+
+
 def test_gemm_nt_group_one_launch_with_per_product_bias(ops):
     """wesup_gemm_nt_batched_bias through ops.gemm_nt_group: three side convs of one resolution (weights and biases views of
     one flat parameter buffer, outputs column slices of the side-feature matrix) in one launch -- the numbers of three

@@ -1135,6 +1135,12 @@ static TnPlan plan_tn(int M, int N, int K, int taps, int nbatch = 1) {
         // prefer fuller rounds; among equal fills prefer fewer splits (less slab traffic)
         if (fill > best + 0.02) { best = fill; S = cand; }
     }
+    // A grid that fills the chip's slots without splitting is not split at all (round 5): a fuller last round did not pay for
+    // S slabs written and read again (696 tiles of Wm^T g at 60 x 60: S = 2 bought 0.91 instead of 0.68 of three rounds and
+    // cost 176 MB and a reduce launch of its own on the way to the first input gradient); with S = 1 and no column sums the
+    // plain entries store straight into C.  WESUP_TN_S1_MIN_TILES moves the bound for the A/B (0: never).
+    static const int s1_min = [] { const char* e = getenv("WESUP_TN_S1_MIN_TILES"); return e ? atoi(e) : 600; }();
+    if (s1_min > 0 && tiles >= s1_min) S = 1;
     const int steps_per = ceil_div(ksteps, S);
     pl.k_per_split = steps_per * BK;
     pl.S = ceil_div(K, pl.k_per_split);
@@ -1187,6 +1193,10 @@ static int launch_tn(TnParams p, const TnPlan& pl, hipStream_t st, int nbatch = 
 }
 
 static size_t tn_slab_stride(int M, int Nslab) { return (size_t)M * Nslab + M; }    // products + column sums of A
+// the epilogue's 8-byte stores can go straight into C: one split, nothing summed behind the slabs, rows of C 8-byte aligned
+static bool tn_direct(const TnPlan& pl, const float* colsum_a, const float* C, int ldc) {
+    return pl.S == 1 && !colsum_a && (ldc % 2) == 0 && (((uintptr_t)C) & 7) == 0;
+}
 
 extern "C" size_t wesup_gemm_tn_workspace_bytes(int M, int N, int K) {
     if (M <= 0 || N <= 0 || K <= 0) return 0;
@@ -1207,6 +1217,11 @@ extern "C" int wesup_gemm_tn(const float* A, int lda, const float* B, int ldb, f
     p.relu_b = relu_b; p.H = 1; p.W = 1; p.dW = make_fastdiv(1); p.dH = make_fastdiv(1);
     p.slab_stride = (long)tn_slab_stride(M, pl.Nslab); p.want_colsum = colsum_a != nullptr; p.colsum_batch = -1;
     hipStream_t st = (hipStream_t)stream;
+    if (tn_direct(pl, colsum_a, C, ldc)) {          // one split, no column sums: the tiles are the result
+        p.slab = C; p.Nslab = ldc;
+        TnPlan pd = pl; pd.Nslab = ldc;
+        return launch_tn<0>(p, pd, st);
+    }
     int rc = launch_tn<0>(p, pl, st);
     if (rc) return rc;
     const long tot = (long)M * N;
@@ -1240,6 +1255,11 @@ extern "C" int wesup_gemm_tn_batched(const float* A, int lda, long strideA, cons
     p.slab_stride = (long)tn_slab_stride(M, pl.Nslab); p.want_colsum = 0; p.colsum_batch = -1;
     p.batchA = strideA; p.batchB = strideB; p.batch_slab = (long)pl.S * p.slab_stride;
     hipStream_t st = (hipStream_t)stream;
+    if (tn_direct(pl, nullptr, C, ldc) && strideC % 2 == 0) {
+        p.slab = C; p.batch_slab = strideC;
+        TnPlan pd = pl; pd.Nslab = ldc;
+        return launch_tn<0>(p, pd, st, nbatch);
+    }
     int rc = launch_tn<0>(p, pl, st, nbatch);
     if (rc) return rc;
     const long tot = (long)M * N;

@@ -123,6 +123,7 @@ class WesupEngine:
     WINOGRAD_CONV_MIN_CI = 64
     WINOGRAD_TILE = 4                    # m of F(m x m, 3x3) for those layers: 4 (default) or 2 (round 2's routing)
     DEEP_SIDE_WGRAD_AT = 2               # conv layer at which the deep layers' side-conv weight gradients are queued (conv2_1)
+    SHALLOW_G_AT = 13                    # conv layer at which the shallow layers' side-branch gradients are queued (13: at the head of the backward)
     WGRAD_EARLY_LAYERS = 1               # layers above the lowest trainable one whose weight gradient stays in front of the input gradient
 
     def __init__(self, params, grads, D=32):
@@ -191,6 +192,9 @@ class WesupEngine:
         # work of layer l behind the input transform of layer l + 1; a layer's weight gradient behind its input gradient except
         # for the lowest trainable layer's neighbour; every G_l before the side convs' own weight gradients, those of the deep
         # layers queued when the chain reaches conv2_1 (DEEP_SIDE_WGRAD_AT).
+        # the backward's share of the weight repacking (rotated filters, transposed side / fc weights) behind the forward's last
+        # pooling instead of at the head of the step (bench.py --engine-set late_bwd_pack=0 for the A/B)
+        self.late_bwd_pack = True
         self._diag_skip = set()          # TIMING-ONLY diagnostics (bench.py --diag-skip): classes of launches left out, results wrong
         self.route_fn = default_route    # (ci, co, h, w, B) -> 0 | 2 | 4, consulted per layer and shape
         self._route = None               # the 13 tile sizes of the current / most recent shape
@@ -205,7 +209,7 @@ class WesupEngine:
     # Ordering edges between the three streams go through the library's event pool (ops.sync_record / sync_wait: slots of a
     # fixed pool, so that a recorded step plan replays the same edges, csrc/plan.hip): fixed slots for marks that are waited
     # for later, a rotating range for "stream b goes on behind what stream a holds now".
-    SLOT_W0, SLOT_W, SLOT_G, SLOT_DS, SLOT_ROT0, SLOT_ROT_N = 0, 1, 2, 15, 64, 192       # G_l: 2 .. 14, ds_l: 15 .. 27
+    SLOT_W0, SLOT_W, SLOT_G, SLOT_DS, SLOT_WB, SLOT_ROT0, SLOT_ROT_N = 0, 1, 2, 15, 28, 64, 192       # G_l: 2 .. 14, ds_l: 15 .. 27
 
     def _edge(self, src, dst):
         """dst (torch stream) waits for everything queued so far on src."""
@@ -442,6 +446,7 @@ class WesupEngine:
             pk.wf, pk.wd = [], []
             pk.uf, pk.ud = [None] * 13, [None] * 13          # Winograd-domain filters, allocated on first use
             pk.wino = None
+            pk.bwd_todo, pk.bwd_ready = None, False
             for l, (ci, co) in enumerate(CONV_CH):
                 pk.wf.append(torch.empty(co, ops.conv3x3_kpad(ci), dtype=torch.float32, device=self.device))
                 pk.wd.append(None if l == 0 else torch.empty(ci, 9 * co, dtype=torch.float32, device=self.device))
@@ -469,7 +474,7 @@ class WesupEngine:
         if first_here:
             ops.pack_conv3x3_weight(self.p[f'backbone.{CONV_IDX[0]}.weight'], pk.wf[0], None, need_dgrad=False)
         with self._OnSide(self):
-            pk.ready0 = pk.ready = False
+            pk.ready0 = pk.ready = pk.bwd_ready = False
             fwd4, dg4 = [], []                     # F(4x4) layers: one launch for the forward filters, one for the rotated ones
             for l, idx in enumerate(CONV_IDX):
                 if l == 0 and first_here:
@@ -497,21 +502,39 @@ class WesupEngine:
             if self.two_streams:
                 ops.sync_record(self.SLOT_W)
                 pk.ready = True
-            if train:
-                if dg4:
-                    ops.winograd_pack_weights(dg4)
-                for l, idx in enumerate(CONV_IDX):
-                    if wino[l] == 4:
-                        continue
-                    if wino[l]:
-                        ops.winograd_pack_weight(self.p[f'backbone.{idx}.weight'], need_fwd=False, u_dgrad=pk.ud[l], m=wino[l])
-                    elif l > 0:
-                        ops.pack_conv3x3_weight(self.p[f'backbone.{idx}.weight'], None, pk.wd[l], need_fwd=False)
-                # the panels the input-gradient GEMMs of the side convs / fc layers read: 16 transposes, one launch
-                tr = [(self.p[f'side_conv{off}.weight'].view(CONV_CH[l][1] // 2, CONV_CH[l][1]), pk.sideT[l])
-                      for l, off in enumerate(SIDE_OFF)]
-                tr += [(self.p[f'fc_layers.{k}.weight'], pk.fcT[i]) for i, k in enumerate((0, 2, 4))]
-                ops.transpose_batched(tr)
+            # What only the backward reads -- the rotated F(4x4) filters of the input gradients, the dgrad panels of the direct
+            # layers, the transposed side / fc weights -- is not queued here: at the head of the step it shared the memory system
+            # with conv1_1 and conv1_2's input transform (0.4 GB written beside kernels the chain waits for).  forward() queues it
+            # behind its last pooling, where it runs beside the fc layers and the loss section (round 5).
+            pk.bwd_todo = (dg4, wino) if train else None
+            if train and not self.late_bwd_pack:
+                self._pack_weights_bwd(pk)
+        return pk
+
+    def _pack_weights_bwd(self, pk):
+        """The backward's share of the weight repacking (see _pack_weights), on the side stream; SLOT_WB marks its end."""
+        todo, pk.bwd_todo = pk.bwd_todo, None
+        if todo is None:
+            return
+        dg4, wino = todo
+        with self._OnSide(self):
+            if dg4:
+                ops.winograd_pack_weights(dg4)
+            for l, idx in enumerate(CONV_IDX):
+                if wino[l] == 4:
+                    continue
+                if wino[l]:
+                    ops.winograd_pack_weight(self.p[f'backbone.{idx}.weight'], need_fwd=False, u_dgrad=pk.ud[l], m=wino[l])
+                elif l > 0:
+                    ops.pack_conv3x3_weight(self.p[f'backbone.{idx}.weight'], None, pk.wd[l], need_fwd=False)
+            # the panels the input-gradient GEMMs of the side convs / fc layers read: 16 transposes, one launch
+            tr = [(self.p[f'side_conv{off}.weight'].view(CONV_CH[l][1] // 2, CONV_CH[l][1]), pk.sideT[l])
+                  for l, off in enumerate(SIDE_OFF)]
+            tr += [(self.p[f'fc_layers.{k}.weight'], pk.fcT[i]) for i, k in enumerate((0, 2, 4))]
+            ops.transpose_batched(tr)
+            if self.two_streams:
+                ops.sync_record(self.SLOT_WB)
+                pk.bwd_ready = True
         return pk
 
     def _wino(self, l):
@@ -699,6 +722,8 @@ class WesupEngine:
             else:
                 cur, cur_relu = b.y[l], True
         self._join_side()
+        if train:
+            self._pack_weights_bwd(pk)
         if not fused:
             tok = T.begin('sp_pool_fwd')
             ops.sp_pool_fwd(b.fm, meta, out=b.sp_in)
@@ -759,6 +784,8 @@ class WesupEngine:
         # is mostly idle), so only what that chain needs stays on it: the input-gradient GEMMs dfeat -> dh2 -> dh1 -> gsp.
         # The three weight-gradient GEMMs of the fc layers (the largest of the head: 2304 x 2112 x 1024) produce
         # parameter gradients only and go to the wgrad stream, where they run beside the chain.
+        if getattr(pk, 'bwd_ready', False):
+            ops.sync_wait(self.SLOT_WB)
         head_names = ['classifier.0.weight', 'classifier.0.bias'] + [f'fc_layers.{k}.{t}' for k in (0, 2, 4) for t in ('weight', 'bias')]
         tok = T.begin('mlp_bwd')
         ops.classifier_bwd(b.feats, p['classifier.0.weight'], b.sp_pred, dpred.reshape(R, 2),
@@ -850,7 +877,7 @@ class WesupEngine:
                         runs.append([l])
             return runs
 
-        if self.two_streams and self.fuse_pool_bwd:
+        def queue_shallow():
             # ... at the head of the wgrad stream, which has nothing to do until the first weight gradient is queued.
             # (A fourth stream of its own measured the same; with three engine streams + the RCCL stream the process
             # stays within the 4 hardware queues HIP maps streams onto by default -- a fifth stream aliases two of
@@ -876,6 +903,18 @@ class WesupEngine:
                         T.end(tok, 4.0 * B * (h * w * (CONV_CH[l][1] // 2) + H * W + Kmax * (CONV_CH[l][1] // 2)))
                         ds_ready[l] = self.SLOT_DS + l
                         ops.sync_record(ds_ready[l])
+
+        # Where the shallow layers' side-branch gradients are queued (wgrad stream): at its head (13), or when the dgrad chain
+        # reaches conv layer SHALLOW_G_AT -- only when every such layer is commuted (no ds_l the side loop below waits for) and
+        # lies below the layer in question.
+        shallow_at = 13
+        if self.two_streams and self.fuse_pool_bwd:
+            sh = [l for l in range(13) if b.group_of[l] is None]
+            if (8 <= self.SHALLOW_G_AT <= 12 and sh and all(self._commuted(b, l) for l in sh) and max(sh) < self.SHALLOW_G_AT - 1
+                    and lowest < self.SHALLOW_G_AT):
+                shallow_at = self.SHALLOW_G_AT
+            else:
+                queue_shallow()
         ds2ds = [None] * 13
 
         def side_wgrad(l):
@@ -961,6 +1000,8 @@ class WesupEngine:
             ci, co = CONV_CH[l]
             h, w = b.dims[l]
             idx = CONV_IDX[l]
+            if l == shallow_at:
+                queue_shallow()
             if g_ready[l] is not None:
                 ops.sync_wait(g_ready[l], main.cuda_stream)
             if late_side and l == late_at:
