@@ -710,6 +710,19 @@ def test_gemm_tn_batched(ops):
         assert rel_err(ops.gemm_tn(A[i], Bm[i]), ref[i]) < TOL
 
 
+@pytest.mark.parametrize('nb,M,N,K', [(36, 900, 512, 512), (36, 900, 256, 512), (36, 256, 512, 512), (9, 3604, 384, 64)])
+def test_gemm_nt_batched_shapes_of_the_k512_products(ops, nb, M, N, K):
+    """wesup_gemm_nt_batched on the shapes of the step's K = 512 Winograd products: the 36 products of conv4_x at 4 x 480^2 take the
+    128 x 64 tile three to a CU (2304 = 9 x 256 blocks, csrc/gemm.hip), conv5_x the 64 x 64 tile; ragged M."""
+    d = dev()
+    A = rnd(nb, M, K, seed=11).to(d)
+    Bw = rnd(nb, N, K, seed=12).to(d)
+    out = ops.gemm_nt_batched(A, Bw)
+    ref = torch.einsum('bmk,bnk->bmn', A.double().cpu(), Bw.double().cpu()).float()
+    assert rel_err(out, ref) < TOL
+    assert torch.equal(out, ops.gemm_nt_batched(A, Bw))
+
+
 def test_gemm_tn_one_split_stores_straight_into_a_strided_output(ops):
     """Grids that fill the chip without a split (>= 600 tiles: the step's Wm^T g at 60 x 60, four images) run one split and the
     kernel's epilogue stores into C itself -- no slab, no reduce launch (csrc/gemm.hip: tn_direct).  Row-strided outputs with

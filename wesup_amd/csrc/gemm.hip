@@ -1109,7 +1109,18 @@ struct TnPlan {
 
 static TnPlan plan_tn(int M, int N, int K, int taps, int nbatch = 1) {
     TnPlan pl;
-    const bool big = (M >= 128 && N >= 128);
+    bool big = (M >= 128 && N >= 128);
+    // Few output tiles under a long K (the deep side convs' weight gradients: 256 x 512 outputs over 14 400 / 3 600 pixels; the
+    // commuted ones: 128 x 256 over B*Kmax rows): eight 128 x 128 tiles needed 50 splits to fill the chip -- more slabs than the
+    // reduce kernel walks, so a fold launch (colsum_stage1: 130 - 200 us in the step for 26 MB) came on top.  64 x 64 tiles give
+    // four times the tiles: <= 32 splits fill the slots, no fold, four waves per SIMD hide the staging latency (round 5;
+    // WESUP_TN_SMALL_RULE=0: the old plan).
+    static const int small_rule = [] { const char* e = getenv("WESUP_TN_SMALL_RULE"); return e ? atoi(e) : 1; }();
+    if (big && small_rule) {
+        const long t128 = (long)ceil_div(M, 128) * ceil_div(N, 128) * taps * nbatch;
+        const int ks = ceil_div(K, BK), ms = ks / 8 > 32 ? 32 : (ks / 8 > 0 ? ks / 8 : 1);
+        if (t128 * ms < 384) big = false;
+    }
     pl.bm = big ? 128 : 64;
     pl.bn = big ? 128 : 64;
     pl.tiles_m = ceil_div(M, pl.bm);
@@ -1141,6 +1152,7 @@ static TnPlan plan_tn(int M, int N, int K, int taps, int nbatch = 1) {
     // plain entries store straight into C.  WESUP_TN_S1_MIN_TILES moves the bound for the A/B (0: never).
     static const int s1_min = [] { const char* e = getenv("WESUP_TN_S1_MIN_TILES"); return e ? atoi(e) : 600; }();
     if (s1_min > 0 && tiles >= s1_min) S = 1;
+    if (small_rule && S > 32 && (long)tiles * 32 >= 192) S = 32;        // no fold launch where 32 splits keep most CUs busy
     const int steps_per = ceil_div(ksteps, S);
     pl.k_per_split = steps_per * BK;
     pl.S = ceil_div(K, pl.k_per_split);
@@ -1490,7 +1502,15 @@ extern "C" int wesup_gemm_nt_batched(const float* A, int lda, long strideA, cons
     p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldmask = ldc;
     p.nbatch = nbatch; p.batchA = strideA; p.batchB = strideB; p.batchC = strideC;
     hipStream_t st = (hipStream_t)stream;
-    if (N > 64 && t128 >= 384) return launch_nt<4, 128, 128, 2, 2, 3, 2, false>(p, st);
+    if (N > 64 && t128 >= 384) {
+        // 128 x 64 tiles three to a CU instead of 128 x 128 two to a CU (round 5): the 36 products of conv4_x at 4 x 480^2
+        // (900 x 512 x 512 each) are 1152 tiles of the second kind -- 4.5 per CU: half the CUs run a fifth block alone -- and
+        // 2304 = 9 x 256 of the first; alone 186 -> 177 us (900 x 256 x 512: 107 -> 94), and no slower where the grid is many
+        // rounds deep (36 x 8192 x 512 x 512: 1179 -> 1168 us, 132 TF; tools/ntb_micro.py).  WESUP_NTB_SHAPE=0: the old rule.
+        static const int alt = [] { const char* e = getenv("WESUP_NTB_SHAPE"); return e ? atoi(e) : 2; }();
+        if (alt) return launch_nt<4, 128, 64, 2, 1, 3, 3, false>(p, st);
+        return launch_nt<4, 128, 128, 2, 2, 3, 2, false>(p, st);
+    }
     if (nt_three_stages(t64)) return launch_nt<4, 64, 64, 1, 1, 3, 3, false>(p, st);
     return launch_nt<4, 64, 64, 1, 1, 3, 2, false>(p, st);
 }
