@@ -59,6 +59,7 @@ def parse_args(argv=None):
     ap.add_argument('--float-masks', action='store_true', help='A/B: the dgrad epilogues read the pre-ReLU conv outputs for the ReLU mask / the max-pool decisions instead of the sign bits / codes the forward leaves')
     ap.add_argument('--no-dual-transform', action='store_true', help='A/B: the input-gradient and weight-gradient transforms of a layer\'s output gradient as two launches on two streams (each reads the gradient)')
     ap.add_argument('--engine-set', default='', help='A/B: comma list of name=value engine switches (bool / int attributes of WesupEngine), e.g. late_bwd_pack=0')
+    ap.add_argument('--trainer-set', default='', help='A/B: comma list of name=0|1 trainer switches (fuse_head, split_sgd, gc_freeze)')
     ap.add_argument('--diag-skip', default='', help="TIMING-ONLY diagnostic (results are wrong): comma list of launch classes left out "
                                                     "of the step after the warm-up (learning rate 0 from there on) -- 'wgrad' (conv weight gradients), 'side_wgrad', "
                                                     "'side_fwd_shallow' (pooling + side conv of conv1_1 .. conv3_3), 'side_fwd_deep' -- to see what they cost the step")
@@ -262,7 +263,8 @@ def worker(args):
     B, H, W, g = args.batch, args.size, args.size, args.grid
     weights = orc.make_weights(0, feat_scale=0.05)
     trainer = initialize_trainer('wesup', device=str(dev), max_superpixels=g * g, force_allreduce=args.force_ddp,
-                                 step_plan=not args.no_step_plan, native_step=not args.general_path)
+                                 step_plan=not args.no_step_plan, native_step=not args.general_path,
+                                 **{k: bool(int(v)) for k, v in (kv.split('=') for kv in filter(None, args.trainer_set.split(',')))})
     trainer.model.load_state_dict({k: torch.from_numpy(v) for k, v in weights.items()})
     trainer.optimizer, trainer.scheduler = trainer.get_default_optimizer()
     trainer.metric_funcs = [accuracy, dice]

@@ -411,6 +411,20 @@ int wesup_loss_fwd(const float* pred, const float* y_all, const int32_t* n_sp, c
 int wesup_loss_bwd(const float* pred, const float* y_all, const int32_t* n_sp, const int32_t* n_l,
                    const float* terms, const float* dloss, float eps, float prop_weight, float* dpred,
                    int B, int Kmax, int C, void* stream);
+/* ABI 5 -- the head of the training step in two launches instead of six (the chain between the fc layers' forward and their
+ * backward is a chain of launch latencies).  Bit-identical to the entries they combine.
+ * wesup_head_fwd  = wesup_classifier_fwd + wesup_propagate (both read feat (B*Kmax, D); pred (B*Kmax, 2)).
+ * wesup_head_bwd  = wesup_loss_fwd (terms only) + wesup_loss_bwd + the first kernel of wesup_classifier_bwd: terms (B, 8),
+ *                   dpred (B*Kmax, 2), dfeat (B*Kmax, D); Kmax % 64 == 0, C == 2; ws as wesup_classifier_bwd_workspace_bytes.
+ * wesup_classifier_bwd_finish: dWc (2, D), dbc (2) from the partial sums wesup_head_bwd left in ws -- on any stream behind it
+ *                   (models/wesup.py:66-139,229-232,492-531). */
+int wesup_head_fwd(const float* feat, const float* Wc, const float* bc, float* pred, const float* sp_labels,
+                   const int32_t* n_sp, const int32_t* n_l, float threshold, int enable, float* y_all, int32_t* src_idx,
+                   float* max_sim, int B, int Kmax, int D, int C, void* stream);
+int wesup_head_bwd(const float* feat, const float* Wc, const float* pred, const float* y_all, const int32_t* n_sp,
+                   const int32_t* n_l, const float* dloss, float eps, float prop_weight, float* terms, float* dpred,
+                   float* dfeat, int B, int Kmax, int D, int C, void* ws, size_t ws_bytes, void* stream);
+int wesup_classifier_bwd_finish(const void* ws, size_t ws_bytes, float* dWc, float* dbc, int R, int D, void* stream);
 /* generic _cross_entropy (models/wesup.py:66-96) on (n, C): out2[4] = {sum(-y log clamp(yhat) [* class_weights[c]]),
  * #rows with sum(y) > 0, loss = sum/#rows (0 if no row is labelled), 0}; class_weights (C,) or NULL (models/wesup.py:93-94) */
 int wesup_cross_entropy_fwd(const float* y_hat, const float* y_true, const float* class_weights, float eps, float* out2,

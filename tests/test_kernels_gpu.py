@@ -1003,6 +1003,41 @@ def test_propagate_and_loss(ops, seed, scale, ident):
         assert float(y_off[b, int(m.n_l[b]):].abs().sum()) == 0.0
 
 
+@pytest.mark.parametrize('seed,scale', [(1, 0.1), (2, 0.35)])
+def test_head_in_two_launches_equals_the_six_it_replaces_bit_for_bit(ops, seed, scale):
+    """wesup_head_fwd = classifier_fwd + propagate, wesup_head_bwd (+ classifier_bwd_finish) = loss_fwd + loss_bwd + classifier_bwd
+    (ABI 5, csrc/loss.hip): what the step runner launches between the fc layers' forward and backward.  Same numbers, bit for bit;
+    the oracle checks of the separate entries (test_propagate_and_loss, test_classifier) then hold for these too."""
+    d = dev()
+    B, H, W, g, D = 3, 64, 64, 6, 32
+    labs, masks = _sp_case(40 + seed, B, H, W, g)
+    Kmax = 64
+    m = ops.sp_preprocess(torch.from_numpy(labs).to(d), torch.from_numpy(masks).to(d), Kmax)
+    feat = F.relu(rnd(B, Kmax, D, seed=seed, scale=scale)).to(d)
+    Wc, bc = rnd(2, D, seed=seed + 7).to(d), rnd(2, seed=seed + 8).to(d)
+    R = B * Kmax
+    # the six launches
+    pred = ops.classifier_fwd(feat.view(R, D), Wc, bc)
+    y_all, src, sim = ops.propagate(feat, m, 0.8)
+    _, terms = ops.loss_fwd(pred.view(B, Kmax, 2), y_all, m, 1e-7, 0.5)
+    dloss = torch.tensor([1.0], device=d)
+    dpred = ops.loss_bwd(pred.view(B, Kmax, 2), y_all, m, terms, dloss, 1e-7, 0.5)
+    dfeat, dWc, dbc = ops.classifier_bwd(feat.view(R, D), Wc, pred, dpred.view(R, 2))
+    # the two (+ the reduce off the chain)
+    pred2 = torch.full((R, 2), 9.0, device=d)
+    out2 = (torch.full((B, Kmax, 2), 9.0, device=d), torch.full((B, Kmax), 9, dtype=torch.int32, device=d), torch.full((B, Kmax), 9.0, device=d))
+    ops.head_fwd(feat, Wc, bc, pred2, m, 0.8, out=out2)
+    assert torch.equal(pred2, pred) and torch.equal(out2[0], y_all) and torch.equal(out2[1], src) and torch.equal(out2[2], sim)
+    terms2, dpred2 = torch.full((B, 8), 9.0, device=d), torch.full((B, Kmax, 2), 9.0, device=d)
+    dfeat2, dWc2, dbc2 = torch.full((R, D), 9.0, device=d), torch.full((2, D), 9.0, device=d), torch.full((2,), 9.0, device=d)
+    ops.head_bwd(feat.view(R, D), Wc, pred2, out2[0], m, dloss, 1e-7, 0.5, terms2, dpred2, dfeat2)
+    ops.classifier_bwd_finish(R, D, dWc2, dbc2, d)
+    assert torch.equal(terms2, terms) and torch.equal(dpred2, dpred) and torch.equal(dfeat2, dfeat)
+    assert torch.equal(dWc2, dWc) and torch.equal(dbc2, dbc)
+    assert float(dpred.abs().max()) > 0 and float(dfeat.abs().max()) > 0
+    assert not ops.head_bwd_supported(100, 2) and not ops.head_bwd_supported(64, 3)
+
+
 def test_cross_entropy_generic(ops):
     from oracle import wesup_oracle as orc
     d = dev()

@@ -107,6 +107,9 @@ _SIGS = {
     'wesup_propagate': (c_int, 'ppppfipppiiiip'),
     'wesup_loss_fwd': (c_int, 'ppppffppiiip'),
     'wesup_loss_bwd': (c_int, 'ppppppffpiiip'),
+    'wesup_head_fwd': (c_int, 'pppppppfipppiiiip'),
+    'wesup_head_bwd': (c_int, 'pppppppffpppiiiipzp'),
+    'wesup_classifier_bwd_finish': (c_int, 'pzppiip'),
     'wesup_cross_entropy_fwd': (c_int, 'pppfpiip'),
     'wesup_cross_entropy_bwd': (c_int, 'pppppfpiip'),
     'wesup_sgd_step': (c_int, 'pppzffffip'),
@@ -149,7 +152,7 @@ _SIGS = {
 _T = {'p': c_void_p, 'i': c_int, 'f': c_float, 'z': c_size_t, 'l': ctypes.c_long}
 
 EXPORTS = sorted(_SIGS)
-ABI_VERSION = 4          # include/wesup_hip.h; a stale libwesup_hip.so with other signatures must not be called
+ABI_VERSION = 5          # include/wesup_hip.h; a stale libwesup_hip.so with other signatures must not be called
 
 _lib = None
 

@@ -47,6 +47,15 @@ extern "C" int wesup_classifier_fwd(const float* feat, const float* Wc, const fl
 
 // backward: dz = p * (dp - sum_c dp_c p_c); dfeat = (dz . Wc + extra) masked by feat > 0; partial dWc/dbc per 64 rows
 #define CLS_ROWS 64
+// The two sums of two products below are written with their one fused multiply-add spelled out: left to the compiler
+// (-ffp-contract=fast) either product may become the addend, and classifier_bwd_kernel and head_bwd_kernel -- which must agree
+// bit for bit -- are contracted separately.
+__device__ __forceinline__ void cls_dz(float p0, float p1, float d0, float d1, float& a, float& b) {
+    const float s = fmaf(d1, p1, d0 * p0);
+    a = p0 * (d0 - s);
+    b = p1 * (d1 - s);
+}
+__device__ __forceinline__ float cls_dfeat(float dz0, float dz1, float w0, float w1) { return fmaf(dz1, w1, dz0 * w0); }
 __global__ void classifier_bwd_kernel(const float* __restrict__ feat, const float* __restrict__ Wc,
                                       const float* __restrict__ pred, const float* __restrict__ dpred,
                                       const float* __restrict__ extra, float* __restrict__ dfeat,
@@ -60,9 +69,7 @@ __global__ void classifier_bwd_kernel(const float* __restrict__ feat, const floa
         if (r < R) {
             const float p0 = pred[2 * r], p1 = pred[2 * r + 1];
             const float d0 = dpred[2 * r], d1 = dpred[2 * r + 1];
-            const float s = d0 * p0 + d1 * p1;
-            a = p0 * (d0 - s);
-            b = p1 * (d1 - s);
+            cls_dz(p0, p1, d0, d1, a, b);
         }
         dz[tid][0] = a;
         dz[tid][1] = b;
@@ -73,7 +80,7 @@ __global__ void classifier_bwd_kernel(const float* __restrict__ feat, const floa
         const int rr = e / D, k = e - rr * D;
         const int r = r0 + rr;
         if (r < R) {
-            float g = dz[rr][0] * Wc[k] + dz[rr][1] * Wc[D + k];
+            float g = cls_dfeat(dz[rr][0], dz[rr][1], Wc[k], Wc[D + k]);
             if (extra) g += extra[(long)r * D + k];
             dfeat[(long)r * D + k] = feat[(long)r * D + k] > 0.f ? g : 0.f;
         }
@@ -86,7 +93,7 @@ __global__ void classifier_bwd_kernel(const float* __restrict__ feat, const floa
             const int c = e / D, k = e - c * D;
             for (int rr = 0; rr < CLS_ROWS; ++rr) {
                 const int r = r0 + rr;
-                if (r < R) s += dz[rr][c] * feat[(long)r * D + k];
+                if (r < R) s = fmaf(dz[rr][c], feat[(long)r * D + k], s);
             }
         } else {
             const int c = e - 2 * D;
@@ -135,7 +142,9 @@ extern "C" int wesup_classifier_bwd(const float* feat, const float* Wc, const fl
 __global__ __launch_bounds__(256) void prop_kernel(const float* __restrict__ feat, const float* __restrict__ sp_labels,
                                                    const int32_t* __restrict__ n_sp, const int32_t* __restrict__ n_l,
                                                    float thr, int enable, float* __restrict__ y_all, int32_t* __restrict__ src_idx,
-                                                   float* __restrict__ max_sim, int Kmax, int D, int C) {
+                                                   float* __restrict__ max_sim, int Kmax, int D, int C,
+                                                   const float* __restrict__ Wc, const float* __restrict__ bc,
+                                                   float* __restrict__ pred) {
     extern __shared__ float sh[];
     float* fl = sh;                               // [PROP_TILE][D+1]
     float* fi = sh + PROP_TILE * (D + 1);         // [PROP_ROWS][D]
@@ -150,6 +159,23 @@ __global__ __launch_bounds__(256) void prop_kernel(const float* __restrict__ fea
     if (tid < PROP_ROWS && i_blk + tid < Kmax) {
         src_idx[(long)b * Kmax + i_blk + tid] = -1;
         max_sim[(long)b * Kmax + i_blk + tid] = 0.f;
+    }
+    // wesup_head_fwd: the classifier + softmax of this block's rows rides along (classifier_fwd_kernel's arithmetic, row by row:
+    // a launch of its own on the chain between the fc layers and the loss otherwise)
+    if (pred && tid < PROP_ROWS && i_blk + tid < Kmax) {
+        const long r = (long)b * Kmax + i_blk + tid;
+        float z0 = bc[0], z1 = bc[1];
+        const float* f = feat + r * D;
+        for (int k = 0; k < D; ++k) {
+            const float v = f[k];
+            z0 = fmaf(v, Wc[k], z0);
+            z1 = fmaf(v, Wc[D + k], z1);
+        }
+        const float m = fmaxf(z0, z1);
+        const float e0 = expf(z0 - m), e1 = expf(z1 - m);
+        const float inv = 1.f / (e0 + e1);
+        pred[2 * r] = e0 * inv;
+        pred[2 * r + 1] = e1 * inv;
     }
     // rows of this block that take part in the propagation: unlabelled and present (uniform per block)
     if (!enable || nl <= 0 || i_blk + PROP_ROWS <= nl || i_blk >= ns) return;
@@ -226,7 +252,22 @@ extern "C" int wesup_propagate(const float* feat, const float* sp_labels, const 
     hipStream_t st = (hipStream_t)stream;
     const size_t lds = ((size_t)PROP_TILE * (D + 1) + (size_t)PROP_ROWS * D) * sizeof(float);
     WESUP_LAUNCH(prop_kernel, dim3(ceil_div(Kmax, PROP_ROWS), B), dim3(256), lds, st, feat, sp_labels, n_sp, n_l, threshold,
-                 enable, y_all, src_idx, max_sim, Kmax, D, C);
+                 enable, y_all, src_idx, max_sim, Kmax, D, C, (const float*)nullptr, (const float*)nullptr, (float*)nullptr);
+    WESUP_CHECK_LAUNCH();
+    return WESUP_OK;
+}
+// classifier + softmax (wesup_classifier_fwd) and label propagation (wesup_propagate) of the same features in ONE launch: both
+// read feat, neither reads the other's result.  pred (B*Kmax, 2).  Bit-identical to the two entries.
+extern "C" int wesup_head_fwd(const float* feat, const float* Wc, const float* bc, float* pred, const float* sp_labels,
+                              const int32_t* n_sp, const int32_t* n_l, float threshold, int enable, float* y_all,
+                              int32_t* src_idx, float* max_sim, int B, int Kmax, int D, int C, void* stream) {
+    if (!feat || !Wc || !bc || !pred || !sp_labels || !n_sp || !n_l || !y_all || !src_idx || !max_sim || B <= 0 || Kmax <= 0 ||
+        D <= 0 || D > 256 || C <= 0)
+        return WESUP_ERR_INVALID;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t lds = ((size_t)PROP_TILE * (D + 1) + (size_t)PROP_ROWS * D) * sizeof(float);
+    WESUP_LAUNCH(prop_kernel, dim3(ceil_div(Kmax, PROP_ROWS), B), dim3(256), lds, st, feat, sp_labels, n_sp, n_l, threshold,
+                 enable, y_all, src_idx, max_sim, Kmax, D, C, Wc, bc, pred);
     WESUP_CHECK_LAUNCH();
     return WESUP_OK;
 }
@@ -326,6 +367,115 @@ extern "C" int wesup_loss_bwd(const float* pred, const float* y_all, const int32
     const long total = (long)B * Kmax * C;
     WESUP_LAUNCH(loss_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, pred,
                        y_all, n_sp, n_l, terms, dloss, eps, prop_weight, dpred, B, Kmax, C, total);
+    WESUP_CHECK_LAUNCH();
+    return WESUP_OK;
+}
+
+// Loss, its gradient and the classifier's backward in ONE launch (wesup_loss_fwd + wesup_loss_bwd + wesup_classifier_bwd's first
+// kernel: three launches on the chain between the fc layers' forward and backward).  A block owns CLS_ROWS = 64 rows of one image
+// (Kmax % 64 == 0).  The per-image sums the gradient needs are a reduction over the whole image: every block of an image forms
+// them ITSELF, with loss_fwd_kernel's loop and tree -- the same numbers in every block, no hand-off between blocks; the image's
+// first block writes them to terms.  Then dpred of the block's rows (loss_bwd_kernel's expression) and classifier_bwd_kernel's
+// body on them.  Two classes (the classifier is Linear(D, 2)).  Bit-identical to the three entries.
+__global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__ feat, const float* __restrict__ Wc,
+                                                       const float* __restrict__ pred, const float* __restrict__ y_all,
+                                                       const int32_t* __restrict__ n_sp, const int32_t* __restrict__ n_l,
+                                                       const float* __restrict__ dloss, float eps, float prop_weight,
+                                                       float* __restrict__ terms, float* __restrict__ dpred,
+                                                       float* __restrict__ dfeat, float* __restrict__ part, int B, int Kmax,
+                                                       int D) {
+    constexpr int C = 2;
+    __shared__ float sh[256];
+    __shared__ float dz[CLS_ROWS][2];
+    const int tid = threadIdx.x;
+    const int r0 = blockIdx.x * CLS_ROWS;                 // first row (of B * Kmax) of this block
+    const int b = r0 / Kmax, i0 = r0 - b * Kmax;
+    const int ns = n_sp[b], nl = n_l[b];
+    float sup = 0.f, supc = 0.f, pro = 0.f, proc = 0.f, plab = 0.f;
+    for (int r = tid; r < ns; r += 256) {
+        float ys;
+        const float ce = ce_row(pred + ((long)b * Kmax + r) * C, y_all + ((long)b * Kmax + r) * C, C, eps, &ys);
+        if (r < nl) {
+            sup += ce;
+            supc += (ys > 0.f) ? 1.f : 0.f;
+        } else {
+            pro += ce;
+            proc += (ys > 0.f) ? 1.f : 0.f;
+            plab += ys;
+        }
+    }
+    sup = block_sum256(sup, sh);
+    supc = block_sum256(supc, sh);
+    pro = block_sum256(pro, sh);
+    proc = block_sum256(proc, sh);
+    plab = block_sum256(plab, sh);
+    if (tid == 0 && i0 == 0) {
+        float l = (supc > 0.f) ? sup / supc : 0.f;
+        if (nl < ns && proc > 0.f) l += prop_weight * (pro / proc);
+        float* t = terms + (long)b * 8;
+        t[0] = sup; t[1] = supc; t[2] = pro; t[3] = proc; t[4] = plab; t[5] = l; t[6] = 0.f; t[7] = 0.f;
+    }
+    // dpred of the block's rows, then dz = p * (dp - sum_c dp_c p_c)
+    if (tid < CLS_ROWS) {
+        const int r = i0 + tid;                           // row inside the image (< Kmax)
+        const long gr = (long)r0 + tid;
+        float g0 = 0.f, g1 = 0.f;
+        const float p0 = pred[2 * gr], p1 = pred[2 * gr + 1];
+        if (r < ns) {
+            float coef;
+            if (r < nl) coef = (supc > 0.f) ? 1.f / supc : 0.f;
+            else coef = (nl < ns && proc > 0.f) ? prop_weight / proc : 0.f;
+            if (p0 >= eps && p0 <= 1.f - eps) g0 = dloss[0] * (1.f / (float)B) * coef * (-y_all[2 * gr] / p0);
+            if (p1 >= eps && p1 <= 1.f - eps) g1 = dloss[0] * (1.f / (float)B) * coef * (-y_all[2 * gr + 1] / p1);
+        }
+        dpred[2 * gr] = g0;
+        dpred[2 * gr + 1] = g1;
+        float a, bq;
+        cls_dz(p0, p1, g0, g1, a, bq);
+        dz[tid][0] = a;
+        dz[tid][1] = bq;
+    }
+    __syncthreads();
+    for (int e = tid; e < CLS_ROWS * D; e += 256) {
+        const int rr = e / D, k = e - rr * D;
+        const long r = (long)r0 + rr;
+        const float g = cls_dfeat(dz[rr][0], dz[rr][1], Wc[k], Wc[D + k]);
+        dfeat[r * D + k] = feat[r * D + k] > 0.f ? g : 0.f;
+    }
+    float* pout = part + (long)blockIdx.x * (2 * D + 2);
+    for (int e = tid; e < 2 * D + 2; e += 256) {
+        float s = 0.f;
+        if (e < 2 * D) {
+            const int c = e / D, k = e - c * D;
+            for (int rr = 0; rr < CLS_ROWS; ++rr) s = fmaf(dz[rr][c], feat[((long)r0 + rr) * D + k], s);
+        } else {
+            const int c = e - 2 * D;
+            for (int rr = 0; rr < CLS_ROWS; ++rr) s += dz[rr][c];
+        }
+        pout[e] = s;
+    }
+}
+// ws: wesup_classifier_bwd_workspace_bytes(B * Kmax, D); it holds the per-block partial sums of the classifier's weight gradient
+// until wesup_classifier_bwd_finish adds them up (any stream behind this launch: nothing on the way to the fc layers' gradients
+// reads dWc / dbc).
+extern "C" int wesup_head_bwd(const float* feat, const float* Wc, const float* pred, const float* y_all, const int32_t* n_sp,
+                              const int32_t* n_l, const float* dloss, float eps, float prop_weight, float* terms, float* dpred,
+                              float* dfeat, int B, int Kmax, int D, int C, void* ws, size_t ws_bytes, void* stream) {
+    if (!feat || !Wc || !pred || !y_all || !n_sp || !n_l || !dloss || !terms || !dpred || !dfeat || !ws || B <= 0 || Kmax <= 0 ||
+        (Kmax % CLS_ROWS) || D <= 0 || C != 2)
+        return WESUP_ERR_INVALID;
+    const int R = B * Kmax;
+    if (ws_bytes < wesup_classifier_bwd_workspace_bytes(R, D)) return WESUP_ERR_WORKSPACE;
+    WESUP_LAUNCH(head_bwd_kernel, dim3(R / CLS_ROWS), dim3(256), 0, (hipStream_t)stream, feat, Wc, pred, y_all, n_sp, n_l, dloss,
+                 eps, prop_weight, terms, dpred, dfeat, (float*)ws, B, Kmax, D);
+    WESUP_CHECK_LAUNCH();
+    return WESUP_OK;
+}
+extern "C" int wesup_classifier_bwd_finish(const void* ws, size_t ws_bytes, float* dWc, float* dbc, int R, int D, void* stream) {
+    if (!ws || !dWc || !dbc || R <= 0 || D <= 0) return WESUP_ERR_INVALID;
+    if (ws_bytes < wesup_classifier_bwd_workspace_bytes(R, D)) return WESUP_ERR_WORKSPACE;
+    WESUP_LAUNCH(classifier_bwd_reduce, dim3(ceil_div(2 * D + 2, 64)), dim3(64), 0, (hipStream_t)stream, (const float*)ws, dWc,
+                 dbc, ceil_div(R, CLS_ROWS), D);
     WESUP_CHECK_LAUNCH();
     return WESUP_OK;
 }
@@ -477,7 +627,7 @@ extern "C" int wesup_seg_metrics(const float* pred, const uint8_t* mask, float* 
 }
 
 // ------------------------------------------------------------------ misc
-extern "C" int wesup_abi_version(void) { return 4; }
+extern "C" int wesup_abi_version(void) { return 5; }
 extern "C" const char* wesup_strerror(int code) {
     switch (code) {
         case WESUP_OK: return "ok";

@@ -202,6 +202,7 @@ class WesupEngine:
         self._wgrad_stream = None
         self.timer = KernelTimer()
         self.on_grads_ready = None       # callback(names) for the data-parallel layer
+        self.on_tail = None              # callback(wgrad stream, names of the last layer's parameters): see backward()
         self._rot = 0
         self.buf_generation = 0          # counts buffer sets ever created: a set's `gen` (a recorded step plan holds ITS addresses)
 
@@ -555,7 +556,7 @@ class WesupEngine:
         return self._OnSide(self)
 
     # ------------------------------------------------------------------ forward
-    def forward(self, img, meta, train=True, need_paint=True):
+    def forward(self, img, meta, train=True, need_paint=True, head=True):
         """img (B,3,H,W) fp32 on the GPU, meta = ops.sp_preprocess(...).  Returns (feats, sp_pred, pred)
         shaped (B,Kmax,D), (B,Kmax,2), (B,H,W); buffers are reused by the next call of the same shape."""
         B, _, H, W = img.shape
@@ -734,9 +735,12 @@ class WesupEngine:
         ops.gemm_nt(b.h1, p['fc_layers.2.weight'], p['fc_layers.2.bias'], out=b.h2, flags=ops.RELU_OUT)
         ops.gemm_nt(b.h2, p['fc_layers.4.weight'], p['fc_layers.4.bias'], out=b.feats, flags=ops.RELU_OUT)
         T.end(tok, 2.0 * R * (FM_CHANNELS * 1024 + 1024 * 1024 + 1024 * self.D))
-        ops.classifier_fwd(b.feats, p['classifier.0.weight'], p['classifier.0.bias'], b.sp_pred)
+        # head=False: the caller runs the classifier together with the label propagation (ops.head_fwd, the step runner) and
+        # paints behind it; sp_pred is then not yet filled when this returns
+        if head:
+            ops.classifier_fwd(b.feats, p['classifier.0.weight'], p['classifier.0.bias'], b.sp_pred)
         sp_pred3 = b.sp_pred.view(B, Kmax, 2)
-        if need_paint:
+        if need_paint and head:
             ops.paint_fwd(sp_pred3, meta, 1, out=b.pred)
         self.ctx = (b, pk, meta, B, H, W, Kmax) if train else None
         return b.feats.view(B, Kmax, self.D), sp_pred3, b.pred
@@ -764,7 +768,7 @@ class WesupEngine:
         return b.fm
 
     # ------------------------------------------------------------------ backward
-    def backward(self, dfeat_extra, dpred):
+    def backward(self, dfeat_extra, dpred, head_done=False):
         """dpred (B,Kmax,2) [and optional dfeat_extra (B,Kmax,D)]: gradients of the loss w.r.t. sp_pred /
         sp_features.  Writes every parameter gradient into self.g (overwrites)."""
         assert self.ctx is not None, 'backward without a training-mode forward'
@@ -788,11 +792,18 @@ class WesupEngine:
             ops.sync_wait(self.SLOT_WB)
         head_names = ['classifier.0.weight', 'classifier.0.bias'] + [f'fc_layers.{k}.{t}' for k in (0, 2, 4) for t in ('weight', 'bias')]
         tok = T.begin('mlp_bwd')
-        ops.classifier_bwd(b.feats, p['classifier.0.weight'], b.sp_pred, dpred.reshape(R, 2),
-                           None if dfeat_extra is None else dfeat_extra.reshape(R, D),
-                           b.dfeat, g['classifier.0.weight'], g['classifier.0.bias'])
+        # head_done: ops.head_bwd (loss + its gradient + the classifier's backward in one launch, the step runner) has written
+        # b.dfeat and left the partial sums of the classifier's weight gradient in its workspace; they are added up off the chain
+        if not head_done:
+            ops.classifier_bwd(b.feats, p['classifier.0.weight'], b.sp_pred, dpred.reshape(R, 2),
+                               None if dfeat_extra is None else dfeat_extra.reshape(R, D),
+                               b.dfeat, g['classifier.0.weight'], g['classifier.0.bias'])
+        else:
+            assert dfeat_extra is None
         gsp2d = b.gsp.view(R, FM_CHANNELS)
         off_chain = self.two_streams
+        if head_done and not off_chain:
+            ops.classifier_bwd_finish(R, D, g['classifier.0.weight'], g['classifier.0.bias'], self.device)
         if not off_chain:
             ops.gemm_tn(b.dfeat, b.h2, out=g['fc_layers.4.weight'], colsum=g['fc_layers.4.bias'])
         ops.gemm_nt(b.dfeat, pk.fcT[2], None, out=b.dh2, mask=b.h2)
@@ -807,6 +818,8 @@ class WesupEngine:
             wgs = self._wg()
             self._edge(torch.cuda.current_stream(), wgs)
             with self._On(wgs):
+                if head_done:
+                    ops.classifier_bwd_finish(R, D, g['classifier.0.weight'], g['classifier.0.bias'], self.device)
                 tok = T.begin('mlp_wgrad')
                 ops.gemm_tn(b.dfeat, b.h2, out=g['fc_layers.4.weight'], colsum=g['fc_layers.4.bias'], ws_tag='wgrad')
                 ops.gemm_tn(b.dh2, b.h1, out=g['fc_layers.2.weight'], colsum=g['fc_layers.2.bias'], ws_tag='wgrad')
@@ -1054,6 +1067,10 @@ class WesupEngine:
             # gradient instead of in front of it, its TN products run beside the NEXT layer's (memory-bound) transform rather
             # than beside this layer's products: 9.35 -> 9.20 ms.
             late_wgrad = wg is not None and dual and l > lowest + self.WGRAD_EARLY_LAYERS
+            if l == lowest and wg is not None and self.on_tail is not None and trainable[l]:
+                # every gradient but this layer's is queued (conv and fc weight gradients on wg, the side convs' on the side
+                # stream): the step runner puts the bulk of the optimiser step on wg here, beside the last input gradient
+                self.on_tail(wg, [f'backbone.{idx}.weight', f'backbone.{idx}.bias'])
             if not trainable[l] or 'wgrad' in self._diag_skip:
                 pass
             elif late_wgrad:

@@ -1263,6 +1263,44 @@ def loss_bwd(pred, y_all, meta, terms, dloss, eps, prop_weight, out=None):
     return out
 
 
+def head_fwd(feat, Wc, bc, pred, meta, threshold, enable=True, out=None):
+    """classifier_fwd + propagate in one launch (wesup_head_fwd): feat (B,Kmax,D) -> pred (B*Kmax,2) and (y_all, src_idx, max_sim)."""
+    _chk(feat, name='feat'); _chk(Wc, name='Wc'); _chk(bc, name='bc'); _chk(pred, name='pred')
+    B, Kmax, D = feat.shape
+    assert B == meta.B and Kmax == meta.Kmax and Wc.shape == (2, D) and bc.numel() == 2 and pred.numel() == B * Kmax * 2
+    y_all, src, sim = out
+    assert y_all.shape == (B, Kmax, meta.C) and src.shape == (B, Kmax) == sim.shape and src.dtype == torch.int32
+    tok = _tbegin('propagate')
+    _lib.call('wesup_head_fwd', _p(feat), _p(Wc), _p(bc), _p(pred), _p(meta.sp_labels), _p(meta.n_sp), _p(meta.n_l), float(threshold),
+              int(enable), _p(y_all), _p(src), _p(sim), B, Kmax, D, meta.C, _stream())
+    _tend(tok, 4.0 * B * Kmax * (D + 2 * meta.C + 2))
+    return y_all, src, sim
+
+
+def head_bwd_supported(Kmax, C):
+    return Kmax % 64 == 0 and C == 2
+
+
+def head_bwd(feat, Wc, pred, y_all, meta, dloss, eps, prop_weight, terms, dpred, dfeat):
+    """loss_fwd (terms) + loss_bwd (dpred) + the first kernel of classifier_bwd (dfeat, partial sums of dWc / dbc in the 'cls'
+    workspace) in one launch (wesup_head_bwd); classifier_bwd_finish adds the partial sums up."""
+    _chk(feat, name='feat'); _chk(pred, name='pred'); _chk(y_all, name='y_all'); _chk(dloss, name='dloss')
+    B, Kmax, C = y_all.shape
+    R, D = feat.shape
+    assert R == B * Kmax and pred.numel() == R * C and dpred.numel() == R * C and dfeat.shape == (R, D) and terms.shape == (B, 8)
+    assert head_bwd_supported(Kmax, C) and B == meta.B and Kmax == meta.Kmax
+    nb = _lib.load().wesup_classifier_bwd_workspace_bytes(R, D)
+    ws = workspace(nb, feat.device, 'cls')
+    _lib.call('wesup_head_bwd', _p(feat), _p(Wc), _p(pred), _p(y_all), _p(meta.n_sp), _p(meta.n_l), _p(dloss), float(eps),
+              float(prop_weight), _p(terms), _p(dpred), _p(dfeat), B, Kmax, D, C, _p(ws), nb, _stream())
+
+
+def classifier_bwd_finish(R, D, dWc, dbc, device):
+    nb = _lib.load().wesup_classifier_bwd_workspace_bytes(R, D)
+    ws = workspace(nb, device, 'cls')
+    _lib.call('wesup_classifier_bwd_finish', _p(ws), nb, _p(dWc), _p(dbc), R, D, _stream())
+
+
 def cross_entropy_fwd(y_hat, y_true, eps, class_weights=None):
     _chk(y_hat, name='y_hat'); _chk(y_true, name='y_true')
     n, C = y_hat.shape

@@ -50,12 +50,9 @@ class FusedSGD(torch.optim.SGD):
                 ranges.append([lo, hi])
         return ranges
 
-    @torch.no_grad()
-    def step(self, closure=None):
+    def _prepare(self):
         m = self.model
         self._sync_state_in()
-        g = self.param_groups[0]
-        lr, mu, wd = g['lr'], g['momentum'], g['weight_decay']
         m._ensure_engine()
         for name, p in m._named:                      # a gradient that is not the flat view (set by hand): adopt it
             if p.requires_grad and p.grad is not None and p.grad.data_ptr() != m._grad_views[name].data_ptr():
@@ -63,11 +60,54 @@ class FusedSGD(torch.optim.SGD):
         sig = tuple(p.requires_grad and p.grad is not None for _, p in m._named)
         if getattr(self, '_ranges_sig', None) != sig:
             self._ranges, self._ranges_sig = self._trainable_ranges(sig), sig
-        for lo, hi in self._ranges:                   # one launch per contiguous trainable range
+
+    def _launch(self, ranges):
+        m = self.model
+        g = self.param_groups[0]
+        lr, mu, wd = g['lr'], g['momentum'], g['weight_decay']
+        for lo, hi in ranges:                         # one launch per contiguous trainable range
             ops.sgd_step(m._flat[lo:hi], m._flat_grad[lo:hi], self._vflat[lo:hi], lr, mu, wd, self.grad_scale, self._first)
-        if mu != 0:
+
+    def _finish(self):
+        if self.param_groups[0]['momentum'] != 0:
             for p, view in self._views.items():
                 if p.requires_grad and p.grad is not None:
                     self.state[p]['momentum_buffer'] = view
         self._first = False
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        self._prepare()
+        self._launch(self._ranges)
+        self._finish()
         return None
+
+    # The step in two launches (the step runner, one rank): every parameter but those named in ``late`` as soon as their gradients
+    # are complete -- beside the end of the backward pass, on the stream the caller has made current -- and the rest behind it.
+    # The update is elementwise: the two parts together are step(), bit for bit.
+    @torch.no_grad()
+    def step_early(self, late):
+        m = self.model
+        self._prepare()
+        cut = sorted((m._offs[n], m._offs[n] + (dict(m._named)[n].numel() + 63) // 64 * 64) for n in late)
+        early, held = [], []
+        for lo, hi in self._ranges:
+            pos = lo
+            for a, b in cut:
+                a, b = max(a, lo), min(b, hi)
+                if a >= b:
+                    continue
+                if a > pos:
+                    early.append([pos, a])
+                held.append([a, b])
+                pos = b
+            if pos < hi:
+                early.append([pos, hi])
+        self._late = held
+        self._launch(early)
+
+    @torch.no_grad()
+    def step_late(self):
+        self._launch(self._late)
+        self._late = None
+        self._finish()

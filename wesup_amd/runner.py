@@ -98,6 +98,8 @@ class StepRunner:
         self.states = {}
         self.replay = os.environ.get('WESUP_STEP_PLAN', '1') != '0' and trainer.kwargs.get('step_plan', True)
         self.stats = {'eager': 0, 'recorded': 0, 'replayed': 0, 'dropped': 0}
+        self.fuse_head = bool(trainer.kwargs.get('fuse_head', True))      # (A/B: the six head launches of round 4)
+        self.split_sgd = bool(trainer.kwargs.get('split_sgd', True))      # (A/B: one optimiser launch behind the whole backward)
         # A shape's first walk allocates its buffer set, state and plan -- a few hundred long-lived Python objects -- and a
         # multi-scale epoch brings a new shape every other step: CPython's collector then runs full collections over everything
         # the process holds (268 K tracked objects with torch imported: 67 ms each, 2 ms per step averaged over 40 new shapes,
@@ -154,7 +156,7 @@ class StepRunner:
                 g['lr'], g['momentum'], g['weight_decay'], o.grad_scale, o._first,
                 tuple(p.requires_grad for _, p in t.model._named),
                 float(t.kwargs.get('propagate_threshold')), float(t.kwargs.get('propagate_weight')),
-                bool(t.kwargs.get('enable_propagation')), float(t.kwargs.get('epsilon')),
+                bool(t.kwargs.get('enable_propagation')), float(t.kwargs.get('epsilon')), self.fuse_head, self.split_sgd,
                 None if red is None else (id(red), t.world_size, red.bucket_elems, red.force),
                 ops._stream().value,
                 # the engine object itself (model.to(device) re-makes it and restarts buf_generation), the per-shape routing result
@@ -292,48 +294,86 @@ class StepRunner:
                                             n_sp_host=st.n_sp_host, into=st.meta, counts=st.rb_counts)
             eng.frozen = {n for n, p in model._named if not p.requires_grad}
             multi = red is not None and t.world_size > 1
-            feats, sp_pred, pred = eng.forward(st.img, st.meta, train=True, need_paint=multi)
+            # One rank: the head of the step -- classifier, label propagation, loss, its gradient, the classifier's backward: six
+            # launches on the chain between the fc layers' forward and backward -- in two (ops.head_fwd / head_bwd, bit-identical)
+            fuse = self.fuse_head and not multi and ops.head_bwd_supported(st.y_all.shape[1], st.y_all.shape[2])
+            feats, sp_pred, pred = eng.forward(st.img, st.meta, train=True, need_paint=multi, head=not fuse)
             if want_seg and multi:
                 ops.seg_metrics(pred, st.gt, out=st.seg)
-            ops.propagate(feats, st.meta, float(kw.get('propagate_threshold')), enable=bool(kw.get('enable_propagation')),
-                          out=(st.y_all, st.src, st.sim))
-            # (one rank: the mean over the images is formed on the host from the per-image terms of the read-back block, in the
-            # kernel's own order and precision -- no wesup_loss_mean launch on the chain; several ranks need the loss on the device
-            # for the NaN flag)
-            ops.loss_fwd(sp_pred, st.y_all, st.meta, float(kw.get('epsilon')), float(kw.get('propagate_weight')),
-                         out=(st.loss if multi else None, st.terms))
-            if multi:
-                # A NaN loss on one rank must stop every rank (models/base.py _loss_flag): a MAX all-reduce of a flag on a
-                # stream of its own, the read-back copy behind it.  Host work (torch collectives), i.e. a cut of the plan.
-                def nan_flag():
-                    f, aux = t._loss_flag(st.loss)
-                    with torch.cuda.stream(aux):
-                        st.rb_flag.copy_(f)
-                        st.host.copy_(st.rb, non_blocking=True)
-                        st.rb_event = torch.cuda.Event()
-                        st.rb_event.record()
-                self._cut(plan, nan_flag)
-            else:
-                # The segmentation metrics and the read-back are not on the way to the loss gradient: on the side stream (idle
-                # between the last pooling of the forward and the first side-branch gradient), behind the loss.
-                st.rb_event = None
-                with eng.side_stream():
+            if fuse:
+                b, P = eng._last, eng.p
+                ops.head_fwd(feats, P['classifier.0.weight'], P['classifier.0.bias'], b.sp_pred, st.meta,
+                             float(kw.get('propagate_threshold')), enable=bool(kw.get('enable_propagation')), out=(st.y_all, st.src, st.sim))
+                with eng.side_stream():                                   # (idle between the forward's last pooling and the backward)
                     ops.paint_fwd(sp_pred, st.meta, 1, out=pred)          # (the pixel-wise prediction: metrics and callers only)
                     if want_seg:
                         ops.seg_metrics(pred, st.gt, out=st.seg)
+                ops.head_bwd(b.feats, P['classifier.0.weight'], b.sp_pred, st.y_all, st.meta, st.one, float(kw.get('epsilon')),
+                             float(kw.get('propagate_weight')), st.terms, st.dpred, b.dfeat)
+                st.rb_event = None
+                with eng.side_stream():                                   # the read-back, behind the loss terms
                     _lib.call('wesup_copy_to_host', ctypes.c_void_p(st.host.data_ptr()), ops._p(st.rb), st.rb.numel() * 4, ops._stream())
                     ops.sync_record(RB_SLOT)
+            else:
+                ops.propagate(feats, st.meta, float(kw.get('propagate_threshold')), enable=bool(kw.get('enable_propagation')),
+                              out=(st.y_all, st.src, st.sim))
+                # (one rank: the mean over the images is formed on the host from the per-image terms of the read-back block, in the
+                # kernel's own order and precision -- no wesup_loss_mean launch on the chain; several ranks need the loss on the
+                # device for the NaN flag)
+                ops.loss_fwd(sp_pred, st.y_all, st.meta, float(kw.get('epsilon')), float(kw.get('propagate_weight')),
+                             out=(st.loss if multi else None, st.terms))
+                if multi:
+                    # A NaN loss on one rank must stop every rank (models/base.py _loss_flag): a MAX all-reduce of a flag on a
+                    # stream of its own, the read-back copy behind it.  Host work (torch collectives), i.e. a cut of the plan.
+                    def nan_flag():
+                        f, aux = t._loss_flag(st.loss)
+                        with torch.cuda.stream(aux):
+                            st.rb_flag.copy_(f)
+                            st.host.copy_(st.rb, non_blocking=True)
+                            st.rb_event = torch.cuda.Event()
+                            st.rb_event.record()
+                    self._cut(plan, nan_flag)
+                else:
+                    # The segmentation metrics and the read-back are not on the way to the loss gradient: on the side stream (idle
+                    # between the last pooling of the forward and the first side-branch gradient), behind the loss.
+                    st.rb_event = None
+                    with eng.side_stream():
+                        ops.paint_fwd(sp_pred, st.meta, 1, out=pred)      # (the pixel-wise prediction: metrics and callers only)
+                        if want_seg:
+                            ops.seg_metrics(pred, st.gt, out=st.seg)
+                        _lib.call('wesup_copy_to_host', ctypes.c_void_p(st.host.data_ptr()), ops._p(st.rb), st.rb.numel() * 4, ops._stream())
+                        ops.sync_record(RB_SLOT)
             if red is not None and red.profile:
                 red.t_backward = torch.cuda.Event(enable_timing=True)
                 red.t_backward.record()
-            ops.loss_bwd(sp_pred, st.y_all, st.meta, st.terms, st.one, float(kw.get('epsilon')),
-                         float(kw.get('propagate_weight')), out=st.dpred)
-            eng.backward(None, st.dpred)
+            if not fuse:
+                ops.loss_bwd(sp_pred, st.y_all, st.meta, st.terms, st.one, float(kw.get('epsilon')),
+                             float(kw.get('propagate_weight')), out=st.dpred)
+            # One rank: the optimiser step in two launches -- everything but the lowest layer's parameters on the weight-gradient
+            # stream as soon as those gradients are queued (beside conv1_2's input gradient, the last long kernel of the chain),
+            # conv1_1's 1 792 values behind its weight gradient: 60 us less at the end of the step.  The NaN check moves with it.
+            early = {}
+            if self.split_sgd and red is None:
+                def tail(wg, late):
+                    eng._edge(eng._side(), wg)
+                    early['host'] = self._cut(plan, lambda: self._wait_and_check(st))
+                    model._publish_grads()
+                    with eng._On(wg):
+                        t.optimizer.step_early(late)
+                eng.on_tail = tail
+            try:
+                eng.backward(None, st.dpred, head_done=fuse)
+            finally:
+                eng.on_tail = None
             if red is not None:
                 self._cut(plan, red.finish)
-            host = self._cut(plan, lambda: self._wait_and_check(st))
-            model._publish_grads()                            # p.grad = views of the flat gradient buffer (what step() looks at)
-            t.optimizer.step()
+            if early:
+                host = early['host']
+                t.optimizer.step_late()
+            else:
+                host = self._cut(plan, lambda: self._wait_and_check(st))
+                model._publish_grads()                        # p.grad = views of the flat gradient buffer (what step() looks at)
+                t.optimizer.step()
         finally:
             eng.on_grads_ready = saved_ready
             if plan is not None:
