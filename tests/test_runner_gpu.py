@@ -176,6 +176,34 @@ def test_interleaved_shapes_each_get_a_plan_and_keep_it():
     assert r.stats['dropped'] >= 3
 
 
+def test_clean_first_recordings_are_sealed_without_a_twin_once_two_shapes_are_confirmed():
+    """Multi-scale training's first epochs bring a new shape every other step (utils/data.py:98-101).  The first two shapes of a run
+    are recorded twice and compared node by node; after that a first recording during which no workspace grew and the signature
+    did not move is sealed at once: the shape's SECOND occurrence replays.  Bit-identical to a trainer that never replays; a
+    trainer with trust_first_recording_after=None keeps the twin for every shape."""
+    from oracle import wesup_oracle as orc
+    dev = torch.device('cuda:0')
+    weights = orc.make_weights(12, feat_scale=0.05)
+    shapes = [(1, 64, 64, 4), (1, 64, 48, 4), (1, 48, 48, 3), (1, 40, 56, 3), (1, 40, 40, 3)]      # (no later shape needs a larger workspace)
+    data = [_batches(1, *s, dev)[0] for s in shapes]
+    a = _trainer(weights, max_superpixels=16, step_plan=False)
+    b = _trainer(weights, max_superpixels=16)
+    c = _trainer(weights, max_superpixels=16, trust_first_recording_after=None)
+    order = [0, 0, 0, 1, 1, 1, 2, 2, 2, 3, 4, 3, 4, 3, 4, 0, 1, 2]
+    seen = {}
+    for k, i in enumerate(order):
+        before = b.step_runner().stats['replayed'] if k else 0
+        for t in (a, b, c):
+            t.train_one_iteration('train', *data[i])
+        assert torch.equal(_flat(a), _flat(b)) and torch.equal(_flat(a), _flat(c)), k
+        seen[i] = seen.get(i, 0) + 1
+        if i >= 2 and seen[i] == 2:          # the second occurrence of a shape that came after the two confirmed ones: a replay
+            assert b.step_runner().stats['replayed'] == before + 1, (k, b.step_runner().stats)
+    rb, rc = b.step_runner().stats, c.step_runner().stats
+    assert rb.get('trusted', 0) == 3 and rc.get('trusted', 0) == 0, (rb, rc)
+    assert rb['replayed'] == rc['replayed'] + 3, (rb, rc)
+
+
 def test_end_to_end_staging_feeds_the_same_step_as_the_general_path():
     """bench.py --end-to-end (and utils/data.py DevicePrefetcher): uint8 batch -> wesup_augment -> wesup_slic on a second stream,
     counts to pinned host memory, LabelMaps as the fourth element of the data tuple, the step through the runner (walked, recorded,

@@ -99,7 +99,10 @@ class FusedSGD(torch.optim.SGD):
                     continue
                 if a > pos:
                     early.append([pos, a])
-                held.append([a, b])
+                if held and held[-1][1] == a:             # (weight and bias of a layer are neighbours: one launch)
+                    held[-1][1] = b
+                else:
+                    held.append([a, b])
                 pos = b
             if pos < hi:
                 early.append([pos, hi])

@@ -39,6 +39,7 @@ from .utils import metrics as M
 RB_SLOT = 40          # event slot of the read-back copy (the engine uses 0 .. 27 and 64 ..)
 RECORD_AT = 0         # eager iterations of a shape before the first recording
 MAX_RECORD_TRIES = 4
+TRUST_AFTER = 2       # twin-confirmed shapes after which a clean first recording is sealed at once (None: never)
 MAX_STATES = 256      # shapes with a state (inputs, read-back block, plan) of their own, least recently used first out
 
 
@@ -98,6 +99,9 @@ class StepRunner:
         self.states = {}
         self.replay = os.environ.get('WESUP_STEP_PLAN', '1') != '0' and trainer.kwargs.get('step_plan', True)
         self.stats = {'eager': 0, 'recorded': 0, 'replayed': 0, 'dropped': 0}
+        self.confirmed = 0                # shapes whose first recording its twin has confirmed
+        ta = trainer.kwargs.get('trust_first_recording_after', TRUST_AFTER)
+        self.trust_after = None if (ta is None or os.environ.get('WESUP_PLAN_TRUST', '1') == '0') else int(ta)
         self.fuse_head = bool(trainer.kwargs.get('fuse_head', True))      # (A/B: the six head launches of round 4)
         self.split_sgd = bool(trainer.kwargs.get('split_sgd', True))      # (A/B: one optimiser launch behind the whole backward)
         # A shape's first walk allocates its buffer set, state and plan -- a few hundred long-lived Python objects -- and a
@@ -244,10 +248,21 @@ class StepRunner:
             elif plan is not None:
                 self.stats['recorded'] += 1
                 gens = (ops.ws_generation, eng.bufs_gen(B, H, W, st.y_all.shape[1]))
+                sig0 = sig
                 sig = self._signature(eng, B, H, W)           # the state the recording ENDED in (a first walk allocates the filter
                                                               # panels and clears the optimiser's first-step flag: the twin decides)
                 if st.cand is not None and st.gens == gens and _lib.load().wesup_plan_diff(st.cand.h, plan.h) == 0:
                     st.plan, st.cand = plan, None
+                    self.confirmed += 1
+                elif (self.trust_after is not None and self.confirmed >= self.trust_after and st.cand is None and sig == sig0):
+                    # A first recording is sealed without its twin once the run has confirmed TRUST_AFTER shapes twin by twin:
+                    # what made first recordings unrepeatable were addresses that moved during the walk -- a workspace that grew
+                    # (such a walk is discarded above), filter panels or optimiser state made on the way (the signature before and
+                    # behind the walk then differ) -- and a shape's own buffer set is allocated before the launches that use it.
+                    # Under multi-scale training (a new shape every other step in the first epochs) every shape's second
+                    # occurrence replays instead of walking again.
+                    st.plan = plan
+                    self.stats['trusted'] = self.stats.get('trusted', 0) + 1
                 else:
                     if st.cand is not None and st.gens != gens and os.environ.get('WESUP_PLAN_DEBUG'):
                         print(f'[step plan] twin recorded under other generations {st.gens} -> {gens}')
