@@ -38,8 +38,10 @@ else:
     rows.sort(key=lambda r: int(r['Start_Timestamp']))
     # last step = kernels after the last-but-one sgd_kernel
     sgd = [i for i, r in enumerate(rows) if 'sgd_kernel' in r['Kernel_Name']]
-    lo = sgd[-2] + 1
-    step = rows[lo:sgd[-1] + 1]
+    # (round 5: the optimiser step is two launches a few kernels apart -- a step ends with the LAST sgd_kernel of such a group)
+    ends = [i for k, i in enumerate(sgd) if k + 1 == len(sgd) or sgd[k + 1] - i > 40]
+    lo = ends[-2] + 1
+    step = rows[lo:ends[-1] + 1]
     t0 = int(step[0]['Start_Timestamp'])
     agg = {}
     for r in step:

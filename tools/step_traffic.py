@@ -24,8 +24,9 @@ def read(d, ctr):
 
 f, nf = read(sys.argv[1], 'FETCH_SIZE')
 w, _ = read(sys.argv[2], 'WRITE_SIZE')
-# steps: given, or 'auto' = the number of sgd_kernel launches in the run (one per training step)
-steps = int(sys.argv[3]) if len(sys.argv) > 3 and sys.argv[3] != 'auto' else (int(nf.get('sgd_kernel', 0)) or 3)
+# steps: given, or 'auto' = the number of prop_kernel launches in the run (one per training step)
+# (round 5: the optimiser step is two launches per step except the run's first, which is not split -- prop_kernel runs once per step)
+steps = int(sys.argv[3]) if len(sys.argv) > 3 and sys.argv[3] != 'auto' else (int(nf.get('prop_kernel', 0)) or int(nf.get('sgd_kernel', 0)) or 3)
 rows = sorted(((2 * f[k] + w[k]) * 1024 / steps, k) for k in set(f) | set(w))
 # kernels that are not part of the step (bench.py's roofline leg materialises the feature map once and pools it)
 extra = [r for r in rows if r[1].startswith(('sp_pool_fwd_kernel', 'upsample_fwd_kernel'))]
