@@ -390,10 +390,10 @@ def worker(args):
     for i in range(args.steps):
         # an event record fences its queue (events on the 25 conv launches of every step cost 3 % of the step, on every
         # kernel class 16 %): inside the timed region only every --event-every'th step carries events
-        timer.enabled = timing_on and i % args.event_every == 0
+        timer.enabled = timing_on and i % args.event_every == args.event_every // 2     # (not the region's first step: it follows the barrier)
         n_sampled += int(timer.enabled)
         if reducer is not None:                       # bucket launch offsets + exposed all-reduce tail of the same steps
-            reducer.profile = (i % args.event_every == 0)
+            reducer.profile = (i % args.event_every == args.event_every // 2)
         step(i)
         marks[i + 1].record()
     barrier()
