@@ -124,6 +124,19 @@ def test_plan_is_dropped_when_the_walk_changes_and_nan_raises_before_the_update(
     assert torch.equal(before, _flat(b))
     b.train_one_iteration('train', *data[1])                 # and the next clean iteration goes through
     assert np.isfinite(b.tracker.history['loss'][-1])
+    # The NaN check sits in front of the FIRST of the optimiser's two launches, i.e. inside the backward pass (round 5): the rest
+    # of that iteration's plan -- the stream joins at its end among it -- is not replayed.  The iterations behind it must not
+    # notice: the twin that never replays goes through the same sequence (its NaN iteration raises too) and stays bit-equal.
+    for i in range(5):
+        a.train_one_iteration('train', *data[i % 2])
+    with pytest.raises(ValueError, match='Loss is nan'):
+        a.train_one_iteration('train', *bad)
+    a.train_one_iteration('train', *data[1])
+    assert torch.equal(_flat(a), _flat(b))
+    for i in range(4):
+        a.train_one_iteration('train', *data[i % 2])
+        b.train_one_iteration('train', *data[i % 2])
+        assert torch.equal(_flat(a), _flat(b)), i
 
 
 def test_general_path_still_serves_what_the_runner_does_not_cover():
