@@ -89,7 +89,7 @@ def test_plan_is_dropped_when_the_walk_changes_and_nan_raises_before_the_update(
     weights = orc.make_weights(7, feat_scale=0.05)
     data = _batches(2, B, H, W, g, dev)
     a = _trainer(weights, max_superpixels=g * g, step_plan=False)
-    b = _trainer(weights, max_superpixels=g * g)
+    b = _trainer(weights, max_superpixels=g * g, trust_first_recording_after=None)      # (every recording waits for its twin: the counts below)
     for i in range(6):
         a.train_one_iteration('train', *data[i % 2])
         b.train_one_iteration('train', *data[i % 2])
@@ -190,7 +190,8 @@ def test_interleaved_shapes_each_get_a_plan_and_keep_it():
 
 
 def test_clean_first_recordings_are_sealed_without_a_twin_once_two_shapes_are_confirmed():
-    """Multi-scale training's first epochs bring a new shape every other step (utils/data.py:98-101).  The first two shapes of a run
+    """Multi-scale training's first epochs bring a new shape every other step (utils/data.py:98-101).  With
+    trust_first_recording_after=2 (the default is 1) the first two shapes of a run
     are recorded twice and compared node by node; after that a first recording during which no workspace grew and the signature
     did not move is sealed at once: the shape's SECOND occurrence replays.  Bit-identical to a trainer that never replays; a
     trainer with trust_first_recording_after=None keeps the twin for every shape."""
@@ -200,7 +201,7 @@ def test_clean_first_recordings_are_sealed_without_a_twin_once_two_shapes_are_co
     shapes = [(1, 64, 64, 4), (1, 64, 48, 4), (1, 48, 48, 3), (1, 40, 56, 3), (1, 40, 40, 3)]      # (no later shape needs a larger workspace)
     data = [_batches(1, *s, dev)[0] for s in shapes]
     a = _trainer(weights, max_superpixels=16, step_plan=False)
-    b = _trainer(weights, max_superpixels=16)
+    b = _trainer(weights, max_superpixels=16, trust_first_recording_after=2)
     c = _trainer(weights, max_superpixels=16, trust_first_recording_after=None)
     order = [0, 0, 0, 1, 1, 1, 2, 2, 2, 3, 4, 3, 4, 3, 4, 0, 1, 2]
     seen = {}

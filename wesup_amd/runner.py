@@ -39,7 +39,8 @@ from .utils import metrics as M
 RB_SLOT = 40          # event slot of the read-back copy (the engine uses 0 .. 27 and 64 ..)
 RECORD_AT = 0         # eager iterations of a shape before the first recording
 MAX_RECORD_TRIES = 4
-TRUST_AFTER = 2       # twin-confirmed shapes after which a clean first recording is sealed at once (None: never)
+TRUST_AFTER = 1       # twin-confirmed shapes after which a clean first recording is sealed at once (None: never).  (2 left 37 of 94
+                      # shapes of a cold multi-scale run to their twins: a second confirmation needs a second shape to recur.)
 MAX_STATES = 256      # shapes with a state (inputs, read-back block, plan) of their own, least recently used first out
 
 
@@ -255,7 +256,7 @@ class StepRunner:
                     st.plan, st.cand = plan, None
                     self.confirmed += 1
                 elif (self.trust_after is not None and self.confirmed >= self.trust_after and st.cand is None and sig == sig0):
-                    # A first recording is sealed without its twin once the run has confirmed TRUST_AFTER shapes twin by twin:
+                    # A first recording is sealed without its twin once the run has confirmed TRUST_AFTER shape(s) twin by twin:
                     # what made first recordings unrepeatable were addresses that moved during the walk -- a workspace that grew
                     # (such a walk is discarded above), filter panels or optimiser state made on the way (the signature before and
                     # behind the walk then differ) -- and a shape's own buffer set is allocated before the launches that use it.
@@ -264,6 +265,9 @@ class StepRunner:
                     st.plan = plan
                     self.stats['trusted'] = self.stats.get('trusted', 0) + 1
                 else:
+                    if os.environ.get('WESUP_PLAN_DEBUG') and st.cand is None and self.trust_after is not None:
+                        print(f'[step plan] first recording not sealed: confirmed {self.confirmed}, signature fields that moved '
+                              f'{[i for i, (x, y) in enumerate(zip(sig0 or (), sig)) if x != y]}')
                     if st.cand is not None and st.gens != gens and os.environ.get('WESUP_PLAN_DEBUG'):
                         print(f'[step plan] twin recorded under other generations {st.gens} -> {gens}')
                     if st.cand is not None and st.gens == gens:      # (a workspace that grew in between is nobody's failure)
