@@ -583,14 +583,7 @@ static int dispatch_nt_r(NtParams p, hipStream_t st, void* ws, size_t ws_bytes) 
     switch (c.shape) {
         case NT_BIG: return launch_nt<8, 256, 128, 2, 2, MODE, 1, RELU>(p, st, sk, ws);
         case NT_STD: return launch_nt<4, 128, 128, 2, 2, MODE, 2, RELU>(p, st, sk, ws);
-        case NT_N64:
-            // the image layer (MODE 2: one K-step per tile, a block is load latency + a 32 KiB store): three blocks per CU
-            // instead of two cover each other's waits (48 KiB of LDS each); WESUP_NT_IMG_MINB=2 for the A/B
-            if constexpr (MODE == 2) {
-                static const int three = [] { const char* e = getenv("WESUP_NT_IMG_MINB"); return (e && atoi(e) == 2) ? 0 : 1; }();
-                if (three) return launch_nt<4, 128, 64, 2, 1, MODE, 3, RELU>(p, st);
-            }
-            return launch_nt<4, 128, 64, 2, 1, MODE, 2, RELU>(p, st);
+        case NT_N64: return launch_nt<4, 128, 64, 2, 1, MODE, 2, RELU>(p, st);
         default:
             if (nt_three_stages((long)ceil_div(p.M, 64) * ceil_div(p.N, 64) * (p.nbatch > 1 ? p.nbatch : 1)) && (MODE == 0 || MODE == 3)) return launch_nt<4, 64, 64, 1, 1, MODE, 3, RELU>(p, st);
             return launch_nt<4, 64, 64, 1, 1, MODE, 2, RELU>(p, st);
