@@ -272,7 +272,9 @@ int wesup_gemm_nt(const float* A, int lda, const float* B, int ldb, const float*
                   int M, int N, int K, int flags, void* ws, size_t ws_bytes, void* stream);
 size_t wesup_gemm_tn_workspace_bytes(int M, int N, int K);
 /* colsum_a (optional, [M]): also out[m] = sum_k A[k][m] -- the bias gradient that goes with a weight gradient --
- * accumulated from the staged A tiles, so A is not read a second time */
+ * accumulated from the staged A tiles, so A is not read a second time.
+ * Round 5: a product whose tiles fill the chip without splitting K (>= 600 tiles) runs ONE split and, without colsum_a (C 8-byte
+ * aligned, ldc even), stores straight into C: no slab, no reduce launch; ws is still required (and may go unused). */
 int wesup_gemm_tn(const float* A, int lda, const float* B, int ldb, float* C, int ldc, float* colsum_a,
                   int M, int N, int K, int relu_b, void* ws, size_t ws_bytes, void* stream);
 /* nbatch products of one shape in one launch: C_b = A_b^T . B_b, element strides between batch entries */
