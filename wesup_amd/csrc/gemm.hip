@@ -1506,8 +1506,12 @@ extern "C" int wesup_gemm_nt_batched(const float* A, int lda, long strideA, cons
         // 128 x 64 tiles three to a CU instead of 128 x 128 two to a CU (round 5): the 36 products of conv4_x at 4 x 480^2
         // (900 x 512 x 512 each) are 1152 tiles of the second kind -- 4.5 per CU: half the CUs run a fifth block alone -- and
         // 2304 = 9 x 256 of the first; alone 186 -> 177 us (900 x 256 x 512: 107 -> 94), and no slower where the grid is many
-        // rounds deep (36 x 8192 x 512 x 512: 1179 -> 1168 us, 132 TF; tools/ntb_micro.py).  WESUP_NTB_SHAPE=0: the old rule.
+        // rounds deep (36 x 8192 x 512 x 512: 1179 -> 1168 us, 132 TF; tools/ntb_micro.py).  The transposed shape, 64 x 128, where
+        // it pads the problem less (M = 900: 960 rows of tiles instead of 1024): 177 -> 176 us alone, 7.92 -> 7.87 ms in the
+        // step (three alternating pairs).  WESUP_NTB_SHAPE=0: 128 x 128, 1: 128 x 64 always, 3: 64 x 128 always.
         static const int alt = [] { const char* e = getenv("WESUP_NTB_SHAPE"); return e ? atoi(e) : 2; }();
+        if (alt == 3 || (alt == 2 && (long)ceil_div(M, 64) * 64 * ceil_div(N, 128) * 128 < (long)ceil_div(M, 128) * 128 * ceil_div(N, 64) * 64))
+            return launch_nt<4, 64, 128, 1, 2, 3, 3, false>(p, st);
         if (alt) return launch_nt<4, 128, 64, 2, 1, 3, 3, false>(p, st);
         return launch_nt<4, 128, 128, 2, 2, 3, 2, false>(p, st);
     }
