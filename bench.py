@@ -386,16 +386,17 @@ def worker(args):
         trainer.model.engine._diag_skip = set(filter(None, args.diag_skip.split(',')))
         for gr in trainer.optimizer.param_groups:
             gr['lr'] = 0.0
+    ev_off = args.event_every // 2 if args.steps > args.event_every // 2 else 0      # a short run (--steps 5) still has one such step
     barrier()
     t0 = time.perf_counter()
     marks[0].record()
     for i in range(args.steps):
         # an event record fences its queue (events on the 25 conv launches of every step cost 3 % of the step, on every
         # kernel class 16 %): inside the timed region only every --event-every'th step carries events
-        timer.enabled = timing_on and i % args.event_every == args.event_every // 2     # (not the region's first step: it follows the barrier)
+        timer.enabled = timing_on and i % args.event_every == ev_off      # (not the region's first step where there is another)
         n_sampled += int(timer.enabled)
         if reducer is not None:                       # bucket launch offsets + exposed all-reduce tail of the same steps
-            reducer.profile = (i % args.event_every == args.event_every // 2)
+            reducer.profile = (i % args.event_every == ev_off)
         step(i)
         marks[i + 1].record()
     barrier()
