@@ -848,28 +848,15 @@ class WesupEngine:
             then G_l = the upsample + scatter-mean backward of dYbar_l, written straight into the conv's gradient buffer (all C
             channels) -- the layers of a coarse resolution in one launch (the scan of a cell's pixel window is shared)."""
             h, w = b.dims[ls[0]]
-            if any(b.dybar[l] is None for l in ls):
-                # (the layers of a run are equally wide: their dYbar behind each other, lowest layer first -- like their slices of gsp
-                # and their transposed side weights -- so that the run's products can be ONE batched launch)
-                if len({CONV_CH[l][1] for l in ls}) == 1:
-                    blk = torch.empty(len(ls), B, Kmax, CONV_CH[ls[0]][1], dtype=torch.float32, device=self.device)
-                    for i_, l in enumerate(sorted(ls)):
-                        b.dybar[l] = blk[i_]
-                else:
-                    for l in ls:
-                        b.dybar[l] = torch.empty(B, Kmax, CONV_CH[l][1], dtype=torch.float32, device=self.device)
-            asc = sorted(ls)
-            tok = T.begin('side_bwd')
-            grouped = len(asc) > 1 and ops.gemm_nt_group([gsp2d[:, SIDE_OFF[l]:SIDE_OFF[l] + CONV_CH[l][1] // 2] for l in asc],
-                                                         [pk.sideT[l] for l in asc], None,
-                                                         [b.dybar[l].view(R, CONV_CH[l][1]) for l in asc])
             for l in ls:
                 co, off = CONV_CH[l][1], SIDE_OFF[l]
-                if not grouped:
-                    ops.gemm_nt(gsp2d[:, off:off + co // 2], pk.sideT[l], None, out=b.dybar[l].view(R, co))
+                if b.dybar[l] is None:
+                    b.dybar[l] = torch.empty(B, Kmax, co, dtype=torch.float32, device=self.device)
+                tok = T.begin('side_bwd')
+                ops.gemm_nt(gsp2d[:, off:off + co // 2], pk.sideT[l], None, out=b.dybar[l].view(R, co))
                 if gat[l]:      # gathered per pixel by the epilogue of layer l + 1's input gradient: rows divided by their areas here, once
                     ops.scale_rows_by_area(b.dybar[l], meta.area_new)
-            T.end(tok, sum(2.0 * R * CONV_CH[l][1] * (CONV_CH[l][1] // 2) for l in ls))
+                T.end(tok, 2.0 * R * co * (co // 2))
             tok = T.begin('upsample_bwd')
             if (h, w) == (H, W) or sum(CONV_CH[l][1] for l in ls) > 768:
                 for l in ls:
