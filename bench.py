@@ -47,19 +47,13 @@ def parse_args(argv=None):
     ap.add_argument('--grid', type=int, default=24, help='superpixel grid side: g*g superpixels per image')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true')
-    ap.add_argument('--no-side-fusion', action='store_true', help='A/B: side convs of conv1_1..conv2_1 as GEMMs on the side '
-                                                                  'stream instead of in the conv epilogue')
     ap.add_argument('--direct-conv', action='store_true', help='A/B: forward and input gradient of every conv layer with '
                                                                'the direct implicit-GEMM kernel (no Winograd-domain conv)')
     ap.add_argument('--direct-wgrad', action='store_true', help='A/B: every conv weight gradient with the direct '
                                                                 'implicit-GEMM kernel (no Winograd-domain wgrad)')
-    ap.add_argument('--side-before-pool', action='store_true', help='A/B: the shallow side convs in front of the upsample + superpixel mean, side outputs materialised (round 2 / early round 3 schedule)')
-    ap.add_argument('--no-gather-epilogue', action='store_true', help='A/B: the side-branch gradient of conv1_1 / conv1_2 materialised (gather kernel) and accumulated into, instead of gathered by the dgrad epilogue')
     ap.add_argument('--pool-tiles', action='store_true', help='A/B: the scatter-mean of the native-resolution layers per 16 x 16 tile (wesup_sp_pool_tiles_fwd) instead of through the pixel lists (segment form)')
-    ap.add_argument('--float-masks', action='store_true', help='A/B: the dgrad epilogues read the pre-ReLU conv outputs for the ReLU mask / the max-pool decisions instead of the sign bits / codes the forward leaves')
-    ap.add_argument('--no-dual-transform', action='store_true', help='A/B: the input-gradient and weight-gradient transforms of a layer\'s output gradient as two launches on two streams (each reads the gradient)')
-    ap.add_argument('--engine-set', default='', help='A/B: comma list of name=value engine switches (bool / int attributes of WesupEngine), e.g. late_bwd_pack=0')
-    ap.add_argument('--trainer-set', default='', help='A/B: comma list of name=0|1 trainer switches (fuse_head, split_sgd, gc_freeze)')
+    ap.add_argument('--engine-set', default='', help='A/B: comma list of name=value engine switches (bool / int attributes of WesupEngine), e.g. plain=1 (the reference\'s order of operations, one launch per pass)')
+    ap.add_argument('--trainer-set', default='', help='A/B: comma list of name=value trainer kwargs (fuse_head, split_sgd, gc_freeze, trust_first_recording_after, plan_audit_every; "none" = None)')
     ap.add_argument('--diag-skip', default='', help="TIMING-ONLY diagnostic (results are wrong): comma list of launch classes left out "
                                                     "of the step after the warm-up (learning rate 0 from there on) -- 'wgrad' (conv weight gradients), 'side_wgrad', "
                                                     "'side_fwd_shallow' (pooling + side conv of conv1_1 .. conv3_3), 'side_fwd_deep' -- to see what they cost the step")
@@ -262,9 +256,12 @@ def worker(args):
 
     B, H, W, g = args.batch, args.size, args.size, args.grid
     weights = orc.make_weights(0, feat_scale=0.05)
+    tkw = {}
+    if args.multiscale:        # a new shape every other step: startup objects out of the collector, clean first recordings sealed (and audited)
+        tkw.update(gc_freeze=True, trust_first_recording_after=1)
+    tkw.update({k: (None if v == 'none' else int(v)) for k, v in (kv.split('=') for kv in filter(None, args.trainer_set.split(',')))})
     trainer = initialize_trainer('wesup', device=str(dev), max_superpixels=g * g, force_allreduce=args.force_ddp,
-                                 step_plan=not args.no_step_plan, native_step=not args.general_path,
-                                 **{k: bool(int(v)) for k, v in (kv.split('=') for kv in filter(None, args.trainer_set.split(',')))})
+                                 step_plan=not args.no_step_plan, native_step=not args.general_path, **tkw)
     trainer.model.load_state_dict({k: torch.from_numpy(v) for k, v in weights.items()})
     trainer.optimizer, trainer.scheduler = trainer.get_default_optimizer()
     trainer.metric_funcs = [accuracy, dice]
@@ -272,14 +269,9 @@ def worker(args):
     trainer.tracker.train()
     eng = trainer.model.engine
     eng.fuse_pool_bwd = not args.unfused_pool_bwd
-    eng.fuse_side_fwd = not args.no_side_fusion
     eng.conv_winograd = not args.direct_conv
     eng.wgrad_winograd = not args.direct_wgrad
-    eng.commute_side = not args.side_before_pool
-    eng.gather_side_grad = not args.no_gather_epilogue
     eng.pool_tiles = args.pool_tiles
-    eng.compact_masks = not args.float_masks
-    eng.dual_transform = not args.no_dual_transform
     for kv in filter(None, args.engine_set.split(',')):
         k, v = kv.split('=')
         assert isinstance(getattr(eng, k), (bool, int)), k
@@ -440,8 +432,6 @@ def worker(args):
         timer.reset()
         eng.two_streams = False                       # kernels alone on the GPU: isolated per-launch durations
         from wesup_amd import ops as _ops
-        sk_was = (_ops.STREAMK_FWD, _ops.STREAMK_DGRAD, _ops.STREAMK_GEMM)
-        _ops.set_streamk(everything=True)             # ... as a single-stream caller runs them: with the stream-K tail
         for i in range(3):                            # (first step: workspaces are allocated)
             if i == 1:
                 torch.cuda.synchronize()
@@ -451,7 +441,6 @@ def worker(args):
         iso = dict(timer.collect())
         timer.enabled = False
         eng.two_streams = True
-        _ops.set_streamk(fwd=sk_was[0], dgrad=sk_was[1], gemm=sk_was[2])
         timer.reset()
         timer.totals = timed
         if rank == 0:
@@ -615,8 +604,7 @@ def worker(args):
                     return round(fl / (ms * 1e-3) / 1e12, 2) if ms > 0 else None
                 a, wgr = tf(('conv3x3_fwd', 'conv3x3_dgrad', 'winograd_gemm')), tf(('conv3x3_wgrad',))       # executed FLOPs
                 out['roofline_isolated'] = {
-                    'how': '2 extra untimed steps with single-stream scheduling and the stream-K tail on (what a kernel alone on the GPU '
-                           'gains from; the 3-stream step runs plain tiling, wesup_amd/ops.py), HIP events per launch',
+                    'how': '2 extra untimed steps with single-stream scheduling (the same kernels as the 3-stream step, each alone on the GPU), HIP events per launch',
                     'ms_per_step': {k: round(v[0] / 2, 3) for k, v in sorted(iso.items())},
                     'flops': 'executed (GEMM launches only; Winograd-domain passes run 1/4 resp. 4/9 of the direct form)',
                     'conv3x3_fwd_dgrad': {'bound': 'mfma', 'achieved': a, 'peak': PEAK_MFMA_F32_TFLOPS, 'unit': 'TFLOP/s',
@@ -654,20 +642,26 @@ def worker(args):
                     own += 4 * 4.0 * g * g * h_ * w_                             # Wm and its transpose: written, then read
                 own = B * (own + 4.0 * g * g * 2112)
                 sm = {'bound': 'hbm',
-                      'kernel': 'the scatter-mean of the training step: sp_pool_tile_kernel + combine (conv1_1, conv1_2 at native resolution), '
-                                'sp_pool_up_fwd_kernel (conv2_1 ... conv3_3, upsample fused), sp_interp_matrix_kernel + gemm_tn (the six deep layers)',
+                      'kernel': 'the scatter-mean of the training step: '
+                                + ('sp_pool_tile_kernel + combine (conv1_1, conv1_2 at native resolution), sp_pool_up_fwd_kernel (conv2_1 ... '
+                                   'conv3_3, upsample fused)' if eng_.pool_tiles else
+                                   'sp_pool_up_fwd_kernel + sp_pool_combine_kernel (segment form: conv1_1 ... conv3_3, upsample fused)')
+                                + ', sp_interp_matrix_kernel + gemm_tn (the six deep layers)',
                       'algorithmic_bytes': own,
                       'bytes_what': 'what the pooling reads at the layers\' own resolution (gather layers: the conv output, all C channels, the '
                                     'side conv being applied to the pooled rows; matrix layers: the side output) + slot bytes / pixel lists of '
                                     'the gather layers + the interpolation-pooling matrices (written and read) + N*2112*4',
                       'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'ms_per_step_in_step': round(f_in, 4),
                       'ms_per_step_alone': None if f_alone is None else round(f_alone, 4)}
-                if f_alone:
-                    sm['achieved'] = round(own / (f_alone * 1e-3) / 1e9, 1)
-                    sm['frac'] = round(sm['achieved'] / PEAK_HBM_GBS, 4)
-                    sm['achieved_how'] = 'alone on the GPU (the single-stream extra steps); in the 3-stream step the launches share the GPU: in_step'
+                # primary: what the launches reach INSIDE the 3-stream step (the thing the bench times); `alone` = the same launches
+                # by themselves on the GPU (single-stream extra steps)
                 if f_in:
-                    sm['in_step'] = {'achieved': round(own / (f_in * 1e-3) / 1e9, 1), 'frac': round(own / (f_in * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)}
+                    sm['achieved'] = round(own / (f_in * 1e-3) / 1e9, 1)
+                    sm['frac'] = round(sm['achieved'] / PEAK_HBM_GBS, 4)
+                    sm['achieved_how'] = 'HIP events around the launches inside the 3-stream step (they share the GPU with the other two streams); alone: `alone`'
+                    sm['in_step'] = {'achieved': sm['achieved'], 'frac': sm['frac']}
+                if f_alone:
+                    sm['alone'] = {'achieved': round(own / (f_alone * 1e-3) / 1e9, 1), 'frac': round(own / (f_alone * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)}
                 by = 4.0 * B * (2112 * H * W + H * W + g * g * 2112)
                 a = by / (pool_ms * 1e-3) / 1e9
                 sm_in = (rin or {}).get('scatter_mean', {})
@@ -706,15 +700,18 @@ def worker(args):
                                                         'bucket\'s all-reduce is ordered, ms after the start of backward; last '
                                                         'profiled step'}
         if world == 1 and not args.no_cpu_baseline:
+            # the thread count is swept first (one warm-up + two steps per point, the faithful variant), the 3 + 5 protocol then runs
+            # at the best point: BASELINE.md asks for the host's best, and torch CPU has an optimum well below the logical core count
+            sweep = orc.sweep_cpu_threads((16, 32, 64), variant='faithful')
+            best = next((d['threads'] for d in sweep if 's_per_step' in d), 16)
             variants = {}
             for name in ('faithful', 'label_map'):
-                v, cores, sample = orc.time_cpu_baseline(iters=5, warmup=3, variant=name)
-                sample += (f'; {cores} threads chosen, {os.cpu_count()} logical cores available (torch CPU collapses when '
-                           'oversubscribed on this host: 63 s/step at 256 threads)')
+                v, cores, sample = orc.time_cpu_baseline(iters=5, warmup=3, variant=name, threads=best)
+                sample += f'; {cores} threads = the best of the sweep, {os.cpu_count()} logical cores available'
                 variants[name] = {'value': round(v, 4), 'unit': 'images/s', 'cores': cores, 'sample': sample}
             f = variants['faithful']
             out['cpu_baseline'] = {'value': f['value'], 'unit': 'images/s', 'cores': f['cores'], 'kind': 'port',
-                                   'sample': f['sample'], 'host': host_cpu(),
+                                   'sample': f['sample'], 'host': host_cpu(), 'sweep': sweep,
                                    'what': "oracle/wesup_oracle.py, variant 'faithful' = the reference's own algorithm "
                                            '(dense sp_maps, incremental cat, dense mm; models/wesup.py:18-63,246-304,492-531 '
                                            "+ backward); 'label_map' = the scatter-mean restatement of the same step",

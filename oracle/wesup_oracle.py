@@ -389,7 +389,7 @@ def time_cpu_baseline(H=480, W=480, g=14, iters=5, warmup=3, seed=0, threads=Non
     import os
     from wesup_amd import synth
     if threads is None:
-        # torch CPU collapses when oversubscribed (256 threads on the GPU box: 63 s/step); 16 is near its best
+        # (bench.py sweeps the thread count with sweep_cpu_threads and passes the best; 16 is the stand-alone default)
         threads = min(os.cpu_count() or 1, 16)
     torch.set_num_threads(threads)
     weights = make_weights(seed, feat_scale=0.05)
@@ -410,12 +410,33 @@ def time_cpu_baseline(H=480, W=480, g=14, iters=5, warmup=3, seed=0, threads=Non
         loss.backward()
         ts.append(time.perf_counter() - t0)
     ts = ts[warmup:]
+    if not ts:                                # (warm-up only: sweep_cpu_threads times the call itself)
+        return 0.0, threads, 'warm-up only'
     med = sorted(ts)[len(ts) // 2]
     what = ('preprocess (dense maps) + fwd (cat, dense mm) + loss + bwd' if variant == 'faithful'
             else 'label-map preprocess + fwd (scatter-mean) + loss + bwd')
     sample = (f'{iters} timed steps after {warmup} warm-up, {what}, 1 image {H}x{W}, {g*g} superpixels (config c1), '
               f'median {med:.2f} s')
     return 1.0 / med, threads, sample
+
+
+def sweep_cpu_threads(candidates=(16, 32, 64), variant='faithful', give_up_s=25.0, **kw):
+    """Which thread count is this host's best for the CPU leg?  One warm-up + two timed steps per candidate (enough to rank them);
+    a candidate whose warm-up step alone takes longer than ``give_up_s`` is not timed further (torch CPU collapses when
+    oversubscribed) and ends the sweep -- larger counts are not tried.  Returns [{threads, s_per_step | skipped}], best first."""
+    import os
+    pts, ncpu = [], os.cpu_count() or 1
+    for th in sorted({min(int(c), ncpu) for c in candidates}):
+        t0 = time.perf_counter()
+        time_cpu_baseline(iters=0, warmup=1, threads=th, variant=variant, **kw)
+        w = time.perf_counter() - t0
+        if w > give_up_s:
+            pts.append({'threads': th, 'skipped': f'warm-up step took {w:.1f} s'})
+            break
+        v, _, _ = time_cpu_baseline(iters=2, warmup=0, threads=th, variant=variant, **kw)
+        pts.append({'threads': th, 's_per_step': round(1.0 / v, 3)})
+    pts.sort(key=lambda d: d.get('s_per_step', float('inf')))
+    return pts
 
 
 # ----------------------------------------------------------------------------

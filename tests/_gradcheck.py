@@ -23,6 +23,13 @@ from oracle import wesup_oracle as orc
 
 POOLED = [l for l in range(12) if orc.POOL_AFTER[l]]
 
+# Budget of near-tie decisions (ReLU signs, pooling arg-max, fc ReLUs, propagation rows) that the GPU may take differently from the
+# fp64 evaluation, per million pre-activations of the case, and the floor for small cases.  Round 6: 10 x the worst rate observed on
+# the round's green run (profiles/r06_tolerances.json, class 'near-tie decisions differing from fp64'), instead of n_units // 20000
+# (= 50 per million: 12 000 at configs[1], where the observed count is a handful).  Every count is recorded through tests/_tol.py.
+NEAR_TIE_BUDGET_PER_M = 50.0
+NEAR_TIE_FLOOR = 8
+
 
 def _windows(t):
     """(1,C,H,W) -> (1,C,H//2,W//2,4) the 2x2 windows in torch's scan order (0,0),(0,1),(1,0),(1,1)."""
@@ -183,7 +190,15 @@ def check_gradients(model, weights, imgs, segs, masks, names=None, tol=1e-4, tie
     # a handful of near-tie decisions per million units is what fp32 rounding produces; thousands would be a kernel
     # regression hiding behind the tie tolerance
     n_units = sum(int(y.numel()) for y in ys)
-    assert named.total <= max(64, n_units // 20000), (named.total, n_units)
+    budget = max(NEAR_TIE_FLOOR, int(np.ceil(NEAR_TIE_BUDGET_PER_M * n_units / 1e6)))
+    import _tol
+    ok = _tol.within(case or 'unnamed', 'near-tie decisions differing from fp64 (count)', named.total, budget,
+                     f'units whose discrete decision (ReLU sign, pooling arg-max, fc ReLU, propagation row) the GPU takes differently from '
+                     f'the fp64 evaluation, every one verified to be a near-tie; budget = max({NEAR_TIE_FLOOR}, {NEAR_TIE_BUDGET_PER_M} per '
+                     f'million pre-activations)')
+    _tol.within(case or 'unnamed', 'near-tie decisions differing from fp64 (per million pre-activations)', named.total / (n_units / 1e6),
+                max(NEAR_TIE_BUDGET_PER_M, NEAR_TIE_FLOOR / (n_units / 1e6)), 'the same count as a rate')
+    assert ok, (named.total, budget, n_units)
     g32 = None
     if yardstick:
         _, g32, _ = forced_step(weights, imgs, segs, masks, ys, torch.float32, tie_tol, mlp_gpu=hs, pseudo_gpu=pseudo, **loss_kw)
@@ -205,4 +220,5 @@ def check_gradients(model, weights, imgs, segs, masks, names=None, tol=1e-4, tie
                 e_cpu = float((g32[k].double() - ref).abs().max()) / scale
                 _tol.within(case, 'torch CPU fp32 gradients vs fp64 (yardstick, no bar)', e_cpu, 1.0, 'the same measure for torch\'s own fp32 path')
     check_gradients.last_named = named
+    check_gradients.last_g64 = g64          # (callers that hold the reference's own fp32 gradients measure ITS distance from these)
     return worst, named.total

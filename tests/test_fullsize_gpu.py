@@ -25,6 +25,9 @@ import _tol                                 # noqa: E402
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-4
+# rows per image that the src / y_u comparison at configs[1] may leave out as near-ties (threshold or runner-up within 1e-5): 10 x the
+# worst count observed on round 6's green run (profiles/r06_tolerances.json), floor 4
+MASKED_ROWS_BUDGET = 40
 
 
 def rel_err(a, b):
@@ -118,21 +121,36 @@ def test_step_matches_the_reference_at_full_size(golden_dir, name):
     assert _tol.within(name, 'max_sim vs reference', rel_err(sim[0, n_l:K], fx['max_sim']), TOL, ref)
 
     loss.backward()
-    # every parameter gradient: norm against the reference's, elements against the reference's samples (the
-    # reference's own fp32 CPU gradients carry summation-order noise: conv1_1's dW sums 230 400 mixed-sign products per
-    # element, torch's CPU path is 3e-4 of the tensor's max away from fp64 there -- hence 1e-3 here) ...
+    # every parameter gradient against fp64 under the same ReLU / pooling decisions: 1e-4 of each tensor's max (fixed bar) ...
+    worst, n_named = _gradcheck.check_gradients(model, weights, fx['img'][None], fx['seg'][None], fx['mask'][None], case=name)
+    g64 = _gradcheck.check_gradients.last_g64
+    # ... and against the reference itself: the norm of every tensor, and 64 elements per tensor at north_star's 1e-4 of the
+    # tensor's max -- PER TENSOR, with one named reason for anything above it: the reference's own fp32 CPU gradient is that far
+    # from the fp64 evaluation at the very same elements (its sums carry summation-order noise -- conv1_1's dW adds 230 400
+    # mixed-sign products per element -- and it takes near-tie decisions its own way).  bar_k = 1e-4 + (the reference's own distance).
+    exceptions = []
     for k in [k[6:] for k in fx if k.startswith('gnorm.')]:
         g = model._grad_views[k]
         ref_norm = float(fx['gnorm.' + k])
         assert _tol.within(name, 'gradient norms vs reference (fp32 CPU)', abs(g.double().norm().item() - ref_norm) / ref_norm, 2e-4,
                            '| ||g|| - ||g_ref|| | / ||g_ref||, every parameter tensor'), k
-        samp = g.flatten()[::max(1, g.numel() // 64)][:64].cpu().numpy()
-        assert _tol.within(name, 'gradient samples vs reference (fp32 CPU)', np.abs(samp - fx['gsamp.' + k]).max() / float(fx['gmax.' + k]),
-                           1e-3, '64 elements per tensor, error / max |g_ref|; the reference\'s own fp32 sums carry up to 3e-4 '
-                                 '(conv1_1 dW: 230 400 mixed-sign products per element)'), k
-    # ... and against fp64 under the same ReLU / pooling decisions: 1e-4 of each tensor's max (fixed bar)
-    worst, n_named = _gradcheck.check_gradients(model, weights, fx['img'][None], fx['seg'][None], fx['mask'][None], case=name)
-    print(f'{name}: worst gradient error vs fp64 {worst:.2e}, {n_named} near-tie decisions differ')
+        step = max(1, g.numel() // 64)
+        samp = g.flatten()[::step][:64].cpu().numpy()
+        s64 = g64[k].flatten()[::step][:64].numpy()
+        gmax = float(fx['gmax.' + k])
+        ref_own = float(np.abs(fx['gsamp.' + k].astype(np.float64) - s64).max() / gmax)
+        err = float(np.abs(samp - fx['gsamp.' + k]).max() / gmax)
+        _tol.within(name, 'reference fp32 gradient samples vs fp64 (the reference\'s own distance; no bar)', ref_own, 1.0,
+                    'the same 64 elements: |g_ref - g64| / max |g_ref|, fp64 under the GPU\'s decisions')
+        if err > 1e-4:
+            exceptions.append((k, err, ref_own))
+        assert _tol.within(name, 'gradient samples vs reference (fp32 CPU), per-tensor bar', err, 1e-4 + ref_own,
+                           '64 elements per tensor, error / max |g_ref|; bar = 1e-4 + the reference\'s own distance from fp64 at '
+                           'the same elements (the one named reason for exceeding 1e-4)'), (k, err, ref_own)
+    _tol.within(name, 'gradient tensors above 1e-4 vs reference (count; each named with the reference\'s own fp64 distance)',
+                len(exceptions), len(exceptions), '; '.join(f'{k}: {e:.1e} (reference vs fp64 {r:.1e})' for k, e, r in exceptions) or 'none')
+    print(f'{name}: worst gradient error vs fp64 {worst:.2e}, {n_named} near-tie decisions differ; tensors above 1e-4 of the '
+          f'reference\'s samples: {[(k, f"{e:.1e}", f"ref own {r:.1e}") for k, e, r in exceptions]}')
 
 
 def test_config_c2_exactly_matches_the_oracle():
@@ -180,6 +198,10 @@ def test_config_c2_exactly_matches_the_oracle():
         top2 = W_ul.topk(2, dim=1).values
         near = ((max_sim - 0.8).abs() < 1e-5) | ((top2[:, 0] - top2[:, 1]).abs() < 1e-5)   # threshold / runner-up within rounding
         assert _tol.within('c2_exact', 'sp_features vs oracle', rel_err(feats[b, :n], outs[b]['sp_features']), TOL)
+        # (how many rows the comparison below leaves out: recorded, and bounded -- a kernel whose arg-max drifted would mask many)
+        assert _tol.within(f'c2_exact image {b}', 'propagation rows masked as near-ties before src / y_u are compared (count)',
+                           int(near.sum()), MASKED_ROWS_BUDGET, f'of {n - n_l} unlabelled rows; near = max_sim within 1e-5 of the threshold '
+                           'or of the runner-up'), (int(near.sum()), n - n_l)
         assert torch.equal(src[b, n_l:n].cpu().long()[~near], src_ref[~near])
         assert torch.equal(y_all[b, n_l:n].cpu()[~near], y_u[~near])
         assert torch.equal(bufs.pred[b].round().long().cpu(), outs[b]['pred'].detach().round().long())
@@ -262,13 +284,15 @@ def test_one_image_of_config_c5_matches_the_oracle():
     y_u, W_ul, max_sim, src_ref = orc.label_propagate(outs[0]['sp_features'], pp['sp_labels'], 0.8, return_aux=True)
     top2 = W_ul.topk(2, dim=1).values
     near = ((max_sim - 0.8).abs() < 1e-5) | ((top2[:, 0] - top2[:, 1]).abs() < 1e-5)     # threshold or runner-up within rounding
+    assert _tol.within('c5_one_image', 'propagation rows masked as near-ties before src / y_u are compared (count)', int(near.sum()),
+                       MASKED_ROWS_BUDGET * 5, f'of {n - n_l} unlabelled rows'), int(near.sum())
     assert torch.equal(src[0, n_l:n].cpu().long()[~near], src_ref[~near]) and torch.equal(y_all[0, n_l:n].cpu()[~near], y_u[~near])
     assert torch.equal(bufs.pred[0].round().long().cpu(), outs[0]['pred'].detach().round().long())
     del outs, ref_grads
-    worst, n_named = _gradcheck.check_gradients(model, weights, imgs, labs, pts, case='c2_exact')
+    worst, n_named = _gradcheck.check_gradients(model, weights, imgs, labs, pts, case='c5_one_image')
     new = {k: v.detach().cpu() for k, v in model.state_dict().items()}
     for k, v in ref_new.items():
-        assert _tol.within('c2_exact', 'updated parameters (SGD) vs oracle', rel_err(new[k], v), 1e-5), k
+        assert _tol.within('c5_one_image', 'updated parameters (SGD) vs oracle', rel_err(new[k], v), 1e-5), k
     print(f'c5 (one image): loss {hist["loss"][0]:.6f} (oracle {ref_loss:.6f}; {n_near} pseudo labels decided by a '
           f'near-tie), worst gradient error vs fp64 {worst:.2e}, {n_named} near-tie decisions differ')
     model.engine.release_buffers()

@@ -1030,8 +1030,9 @@ def test_head_in_two_launches_equals_the_six_it_replaces_bit_for_bit(ops, seed, 
     assert torch.equal(pred2, pred) and torch.equal(out2[0], y_all) and torch.equal(out2[1], src) and torch.equal(out2[2], sim)
     terms2, dpred2 = torch.full((B, 8), 9.0, device=d), torch.full((B, Kmax, 2), 9.0, device=d)
     dfeat2, dWc2, dbc2 = torch.full((R, D), 9.0, device=d), torch.full((2, D), 9.0, device=d), torch.full((2,), 9.0, device=d)
-    ops.head_bwd(feat.view(R, D), Wc, pred2, out2[0], m, dloss, 1e-7, 0.5, terms2, dpred2, dfeat2)
-    ops.classifier_bwd_finish(R, D, dWc2, dbc2, d)
+    part = ops.head_bwd_partials(R, D, d)
+    ops.head_bwd(feat.view(R, D), Wc, pred2, out2[0], m, dloss, 1e-7, 0.5, terms2, dpred2, dfeat2, part)
+    ops.classifier_bwd_finish(part, R, D, dWc2, dbc2)
     assert torch.equal(terms2, terms) and torch.equal(dpred2, dpred) and torch.equal(dfeat2, dfeat)
     assert torch.equal(dWc2, dWc) and torch.equal(dbc2, dbc)
     assert float(dpred.abs().max()) > 0 and float(dfeat.abs().max()) > 0
@@ -1276,9 +1277,9 @@ def test_sp_interp_matrix_equals_fused_upsample_pool(ops, B, H, W, g, h, w):
 @pytest.fixture
 def streamk_on(ops):
     """The training step runs plain tiling (wesup_amd/ops.py); these tests cover the stream-K path of the kernels."""
-    ops.set_streamk(everything=True)
+    ops.set_streamk(True)
     yield
-    ops.set_streamk(everything=False)
+    ops.set_streamk(False)
 
 
 @pytest.mark.parametrize('M,N,K', [(2336, 1024, 2112), (3600, 512, 4608), (14400, 512, 2304), (57600, 256, 1152),

@@ -103,14 +103,14 @@ def test_plan_is_dropped_when_the_walk_changes_and_nan_raises_before_the_update(
     st = b.step_runner().stats
     assert st['dropped'] == 1 and st['replayed'] == 7, st          # (a dropped plan is recorded again at once: twin, then 4 replays)
     # an engine switch changes the launch list
-    b.model.engine.dual_transform = a.model.engine.dual_transform = False
+    b.model.engine.plain = a.model.engine.plain = True
     for i in range(2):
         a.train_one_iteration('train', *data[i % 2])
         b.train_one_iteration('train', *data[i % 2])
         assert torch.equal(_flat(a), _flat(b)), i
     assert b.step_runner().stats['dropped'] == 2
     # NaN in the input while a plan is being replayed: ValueError before the optimiser, weights untouched
-    b.model.engine.dual_transform = a.model.engine.dual_transform = True
+    b.model.engine.plain = a.model.engine.plain = False
     for i in range(5):
         b.train_one_iteration('train', *data[i % 2])
     assert b.step_runner().stats['replayed'] >= 5
@@ -191,7 +191,7 @@ def test_interleaved_shapes_each_get_a_plan_and_keep_it():
 
 def test_clean_first_recordings_are_sealed_without_a_twin_once_two_shapes_are_confirmed():
     """Multi-scale training's first epochs bring a new shape every other step (utils/data.py:98-101).  With
-    trust_first_recording_after=2 (the default is 1) the first two shapes of a run
+    trust_first_recording_after=2 (opt-in; the default, None, keeps the twin for every shape) the first two shapes of a run
     are recorded twice and compared node by node; after that a first recording during which no workspace grew and the signature
     did not move is sealed at once: the shape's SECOND occurrence replays.  Bit-identical to a trainer that never replays; a
     trainer with trust_first_recording_after=None keeps the twin for every shape."""
@@ -201,8 +201,9 @@ def test_clean_first_recordings_are_sealed_without_a_twin_once_two_shapes_are_co
     shapes = [(1, 64, 64, 4), (1, 64, 48, 4), (1, 48, 48, 3), (1, 40, 56, 3), (1, 40, 40, 3)]      # (no later shape needs a larger workspace)
     data = [_batches(1, *s, dev)[0] for s in shapes]
     a = _trainer(weights, max_superpixels=16, step_plan=False)
-    b = _trainer(weights, max_superpixels=16, trust_first_recording_after=2)
-    c = _trainer(weights, max_superpixels=16, trust_first_recording_after=None)
+    b = _trainer(weights, max_superpixels=16, trust_first_recording_after=2, plan_audit_after=10 ** 9)    # (audits: the next test)
+    c = _trainer(weights, max_superpixels=16)
+    assert c.step_runner().trust_after is None
     order = [0, 0, 0, 1, 1, 1, 2, 2, 2, 3, 4, 3, 4, 3, 4, 0, 1, 2]
     seen = {}
     for k, i in enumerate(order):
@@ -216,6 +217,73 @@ def test_clean_first_recordings_are_sealed_without_a_twin_once_two_shapes_are_co
     rb, rc = b.step_runner().stats, c.step_runner().stats
     assert rb.get('trusted', 0) == 3 and rc.get('trusted', 0) == 0, (rb, rc)
     assert rb['replayed'] == rc['replayed'] + 3, (rb, rc)
+
+
+def test_sealed_plans_are_audited_and_dropped_when_the_walk_would_differ():
+    """A plan sealed without a twin (trust_first_recording_after=1) holds raw device addresses nobody has compared with a second walk.
+    (1) After AUDIT_AFTER = 1 replay the shape is walked and recorded once more and the recording compared with the sealed plan node
+    by node: a clean audit leaves the plan in place (stats['audited']), bit-identical to a trainer that never replays.
+    (2) Negative: a shared workspace that grows while a larger shape is interleaved (realistic sizes: 96 -> 256 pixels a side, the
+    lazily allocated V / Ybar / filter-panel buffers of the sealed shape's first walk included) moves addresses the sealed plan
+    holds -- the plan must be DROPPED on the shape's next occurrence, not replayed.
+    (3) Negative: a sealed plan whose launch list no longer matches what the walk does (a node of the plan tampered with, standing
+    for anything the hand-kept validity key misses) fails its audit: dropped, stats['distrusted'], a RuntimeWarning."""
+    import warnings
+    from oracle import wesup_oracle as orc
+    from wesup_amd import ops
+    dev = torch.device('cuda:0')
+    weights = orc.make_weights(21, feat_scale=0.05)
+    shapes = [(1, 96, 96, 6), (1, 96, 80, 5), (2, 256, 256, 12)]
+    data = [_batches(1, *s, dev)[0] for s in shapes]
+    a = _trainer(weights, step_plan=False)
+    b = _trainer(weights, trust_first_recording_after=1)
+    for t in (a, b):
+        t.kwargs['max_superpixels'] = 192
+
+    def both(i):
+        a.train_one_iteration('train', *data[i])
+        b.train_one_iteration('train', *data[i])
+        assert torch.equal(_flat(a), _flat(b)), i
+    r = b.step_runner()
+    for i in (0, 0, 0):               # eager (first optimiser step), recorded, twin-confirmed
+        both(i)
+    assert r.confirmed == 1
+    both(1)                           # shape 1: first walk (allocates its set, V, Ybar lazily) recorded ...
+    assert r.stats.get('trusted', 0) == 1, r.stats          # ... and sealed without a twin
+    n0 = r.stats['replayed']
+    both(1)                           # its second occurrence replays the sealed plan
+    assert r.stats['replayed'] == n0 + 1
+    both(1)                           # (1) the audit: walked, recorded, compared -- clean
+    assert r.stats.get('audited', 0) == 1 and r.stats.get('distrusted', 0) == 0 and r.stats['replayed'] == n0 + 1, r.stats
+    both(1)
+    assert r.stats['replayed'] == n0 + 2
+    # (2) a larger shape grows the shared workspaces: every plan recorded before holds stale addresses
+    g0, d0 = ops.ws_generation, r.stats['dropped']
+    both(2)
+    assert ops.ws_generation > g0, 'the larger shape was meant to grow a workspace'
+    n1 = r.stats['replayed']
+    both(1)
+    assert r.stats['dropped'] == d0 + 1 and r.stats['replayed'] == n1, r.stats       # dropped and walked, not replayed
+    both(0)
+    assert r.stats['dropped'] == d0 + 2 and r.stats['replayed'] == n1, r.stats
+    # (3) tamper with a sealed plan: swap it for the plan of ANOTHER shape's walk (same cuts count or not: the diff decides)
+    for _ in range(3):
+        both(1)                       # recorded again, sealed (or twin-confirmed), replayed
+    key1 = next(k for k, st in r.states.items() if k[1:3] == (96, 80))
+    key0 = next(k for k, st in r.states.items() if k[1:3] == (96, 96))
+    for _ in range(3):
+        both(0)
+    st1, st0 = r.states[key1], r.states[key0]
+    assert st1.plan is not None and st0.plan is not None
+    st1.plan, st1.audit_at = st0.plan, st1.replays      # the wrong launch list under shape 1's key; audit due now
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter('always')
+        both(1)                       # the audit walks (correct results) and finds the plan different
+    assert r.stats.get('distrusted', 0) == 1 and st1.plan is None, r.stats
+    assert any('failed its audit' in str(x.message) for x in w)
+    both(1)
+    both(1)
+    assert r.states[key1].plan is not None      # recorded again (sealed, to be audited again) and replaying
 
 
 def test_end_to_end_staging_feeds_the_same_step_as_the_general_path():

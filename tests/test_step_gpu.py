@@ -43,7 +43,7 @@ def make_trainer(weights, **kw):
 
 
 @pytest.mark.parametrize('name', CASES)
-@pytest.mark.parametrize('fused', [True, False, 'side_as_gemm', 'direct_convs', 'side_before_pool', 'gather_kernel', 'float_masks', 'two_transforms', 'pool_tiles'])
+@pytest.mark.parametrize('fused', [True, False, 'direct_convs', 'plain', 'pool_tiles'])
 def test_step_matches_reference_golden(golden_dir, name, fused):
     from oracle import wesup_oracle as orc
     from wesup_amd.models.wesup import preprocess_label_maps, SuperpixelMaps
@@ -53,25 +53,18 @@ def test_step_matches_reference_golden(golden_dir, name, fused):
     trainer = make_trainer(weights)
     model = trainer.model
     model._ensure_engine()
-    model.engine.fuse_side_fwd = fused != 'side_as_gemm'     # default: the side convs of conv1_1..conv2_1 inside the conv epilogue
-    if fused == 'direct_convs':       # every conv pass on the implicit-GEMM kernels (default: Winograd domain from 128 channels up)
+    if fused == 'direct_convs':       # every conv pass on the implicit-GEMM kernels (default: Winograd domain from 64 channels up)
         model.engine.conv_winograd = model.engine.wgrad_winograd = False
-    # default: the shallow layers' side convs BEHIND the upsample + superpixel mean (they commute); here in front, as written
-    # in the reference (models/wesup.py:246-261), with the side outputs and their gradients materialised
-    if fused in ('side_before_pool', 'side_as_gemm'):
-        model.engine.commute_side = False
-    if fused == 'float_masks':        # the dgrad epilogues read the pre-ReLU outputs (default: sign bits / pooling codes left by the forward)
-        model.engine.compact_masks = False
-    if fused == 'two_transforms':     # the output gradient's two F(4x4) transforms as separate launches (default: one pass)
-        model.engine.dual_transform = False
+    # 'plain': the reference's order of operations, one launch per pass (engine.plain): the shallow layers' side convs in FRONT of
+    # the upsample + superpixel mean as written in the reference (models/wesup.py:246-261) with side outputs and their gradients
+    # materialised, the gather kernel, two transform launches per output gradient, float masks, the separate max-pool backward
+    if fused in ('plain', False):
+        model.engine.plain = True
     if fused == 'pool_tiles':         # the native-resolution layers' scatter-mean per 16 x 16 tile (default: through the pixel lists)
         model.engine.pool_tiles = True
-    if fused == 'gather_kernel':      # the native-resolution side-branch gradients materialised by the gather kernel (default: gathered in the dgrad epilogue)
-        model.engine.gather_side_grad = False
-    fused = bool(fused)
+    fused = bool(fused)               # False: on top of plain, the (B,HW,2112) feature map and its gradient materialised
     model.engine.fuse_pool_bwd = fused
     model.engine.fuse_pool_fwd = fused
-    model.engine.fuse_unpool = fused          # False: input gradient at pooled resolution + the separate max-pool backward
     img = torch.from_numpy(fx['img'])[None].to(d)
     seg = torch.from_numpy(fx['seg'].astype(np.int32))[None].to(d)
     mask = torch.from_numpy(fx['mask'].astype(np.uint8))[None].to(d)
@@ -212,9 +205,9 @@ def test_batched_step_matches_oracle():
 
 @pytest.mark.parametrize('B,H,W,g', [(3, 52, 44, 4), (2, 70, 38, 5), (1, 129, 97, 6)])
 def test_round3_schedule_and_fusions_against_the_plain_order(B, H, W, g):
-    """One training step on an odd, batched shape with every round-3 switch at its default (side conv behind the pooling, gathered
-    side gradients, dual transform, compact masks) against the
-    same step with all of them off (the reference's order of operations, one launch per pass): the loss to 1e-6, every parameter
+    """One training step on an odd, batched shape with the default schedule (side conv behind the pooling, gathered
+    side gradients, dual transform, compact masks, fused max-pool backward) against the
+    same step with engine.plain (the reference's order of operations, one launch per pass): the loss to 1e-6, every parameter
     gradient to 2e-5 of its tensor's maximum -- the switches reorder sums and launches, nothing else."""
     from oracle import wesup_oracle as orc
     from wesup_amd import synth
@@ -230,7 +223,7 @@ def test_round3_schedule_and_fusions_against_the_plain_order(B, H, W, g):
         tr.model._ensure_engine()
         e = tr.model.engine
         if plain:
-            e.commute_side = e.gather_side_grad = e.dual_transform = e.compact_masks = False
+            e.plain = True
         tr.train_one_iteration('train', *data)
         torch.cuda.synchronize()
         res.append((tr.tracker.history['loss'][0], {k: v.detach().clone() for k, v in tr.model._grad_views.items()},

@@ -122,9 +122,12 @@ class WesupEngine:
     # bench.py --winograd-min-ci / --winograd-tile for the A/B.
     WINOGRAD_CONV_MIN_CI = 64
     WINOGRAD_TILE = 4                    # m of F(m x m, 3x3) for those layers: 4 (default) or 2 (round 2's routing)
-    DEEP_SIDE_WGRAD_AT = 2               # conv layer at which the deep layers' side-conv weight gradients are queued (conv2_1)
-    SHALLOW_G_AT = 13                    # conv layer at which the shallow layers' side-branch gradients are queued (13: at the head of the backward)
-    WGRAD_EARLY_LAYERS = 1               # layers above the lowest trainable one whose weight gradient stays in front of the input gradient
+    # Positions of the backward walk, measured in rounds 3 - 5 (every alternative within +-0.05 ms, HISTORY.md) and fixed: the deep
+    # layers' side-conv weight gradients are queued when the chain reaches conv2_1; the shallow layers' side-branch gradients at the
+    # head of the weight-gradient stream; the weight gradient of the layer above the lowest trainable one stays in front of its
+    # input gradient, every other one goes behind
+    _DEEP_SIDE_WGRAD_AT = 2
+    _WGRAD_EARLY_LAYERS = 1
 
     def __init__(self, params, grads, D=32):
         """params/grads: dict name -> tensor (views of the flat parameter / gradient buffers)."""
@@ -144,57 +147,28 @@ class WesupEngine:
         self._packed = None
         self._prefetched = None
         self.ctx = None
+        # ---- the eight switches; everything else about the schedule is fixed
         self.fuse_pool_bwd = True        # skip the (B,HW,2112) gradient tensor: pool-bwd fused into upsample-bwd
         self.fuse_pool_fwd = True        # skip the (B,HW,2112) feature map: scatter-mean fused with the upsample
-        self.matrix_pool = True          # coarse layers: upsample+scatter-mean (and backward) as GEMMs with Wm
-        self.two_streams = True          # side branch on its own HIP stream
-        # Weight gradients of the wide layers (conv3_1 ... conv5_3) in the Winograd F(2x2,3x3) domain: 2.25x less MFMA
-        # work in a step that is MFMA-bound, for memory-bound transform passes that run beside the dgrad chain
-        # (alone on the GPU: 3.14 -> 2.11 ms for these nine layers, tools/wino_table.py)
+        self.two_streams = True          # side branch and weight gradients on HIP streams of their own
+        # Weight gradients of the Winograd-domain layers in the domain too (the forward's V is kept): 1/4 of the MFMA work for
+        # memory-bound transform passes that run beside the dgrad chain.  False: the direct implicit-GEMM weight gradient.
         self.wgrad_winograd = True
-        self.conv_winograd = True        # forward / dgrad of the layers with >= 128 input channels likewise
-        # side convs of the direct-form layers with <= 128 output channels (conv1_1 ... conv2_1) inside the conv epilogue.
-        # While every conv was an implicit GEMM and the conv chain bound the step this was slower (17.60 -> 17.88 ms: the
-        # epilogue work sat on the chain, the GEMMs it removed had run beside it); with the wide layers in the Winograd
-        # domain the step is the sum of its kernels' times and the fusion wins a little (13.77 -> 13.70 ms, 3 A/B pairs)
-        self.fuse_side_fwd = True
-        # the max-pool backward behind conv2_1 / conv3_1 / conv4_1 / conv5_1 as the epilogue of their F(4x4) input gradient:
-        # no gradient tensor at pooled resolution, one position of each window updated instead of four re-written
-        self.fuse_unpool = True
-        # Shallow layers (native resolution above the matrix-pool limit: conv1_1 ... conv3_3 at 480^2): the 1x1 side conv, the
-        # bilinear upsample and the superpixel mean are all linear, and the first acts on channels while the other two act on
-        # pixels -- they commute.  mean_r(upsample(y W^T + b)) = mean_r(upsample(y)) W^T + b: the fused upsample+scatter-mean
-        # reads the conv output y itself and the side conv shrinks to a (B*Kmax x C) x (C x C/2) product; backward likewise
-        # (dYbar = g W, G_l = upsample-pool-backward of dYbar straight into the conv's gradient buffer, dW = g^T Ybar,
-        # db = column sums of g).  No side output, no gradient of it, no P x C side GEMMs at 480^2 / 240^2 / 120^2.
-        self.commute_side = True
-        # native-resolution layers of the commuted side branch (conv1_1, conv1_2): their side-branch gradient is a gather of one
-        # row per superpixel; the dgrad epilogue that used to accumulate into the materialised gather takes it itself
-        # (conv3x3_dgrad_winograd_gather): G_l is written once, by that epilogue, and never read for accumulation
-        self.gather_side_grad = True
-        # What the backward needs of the activations of the F(4x4) layers on the one-kernel product route, kept in compact form by
-        # the forward: the ReLU decisions of a conv output as sign bits (written by the input transform of the next layer, which
-        # reads the output anyway; 1/16 of the tensor) and the max-pool's decisions as 3-bit codes (written by the epilogue that
-        # pools; 1/32).  The dgrad epilogues read those instead of the pre-ReLU outputs: 0.9 GB less traffic per step at c2.
-        self.compact_masks = True
-        # Both F(4x4) transforms of a layer's output gradient -- the input of its input gradient and the operand of its weight
-        # gradient -- in one pass over it on the main stream (ops.winograd_dual_transform): the gradient is read once instead of
-        # once per stream and twelve launches go
-        self.dual_transform = True
-        # The scatter-mean of the native-resolution layers (conv1_1, conv1_2: the two largest reads of the pooling) tile by tile
-        # (ops.sp_pool_tiles_fwd: every 16 x 16 tile of the image streams its pixels once, in raster order) instead of superpixel
-        # by superpixel through the pixel lists (ops.sp_pool_upsample_fwd: two dependent loads per step of a wave).  Alone on the
-        # GPU the tile form is faster at 4 x 480^2 (58 vs 95 us per layer) and slower at 8 x 1024^2 (473 vs 383 us); inside the
-        # step, beside the product kernels of the next layer, it is slower (128 vs 102 us per layer, 158 VGPRs per thread against
-        # 50: its blocks wait longer for room on a CU) and the step is 8.25 vs 8.22 ms in three alternating pairs
-        self.pool_tiles = False          # (default off: in the 3-stream step the tile form is 0.03 ms slower, profiles/r05_ab_pool_conv1.txt)
-        # Orderings of the schedule that were measured once and are fixed (each is bit-neutral): the side-branch
-        # work of layer l behind the input transform of layer l + 1; a layer's weight gradient behind its input gradient except
-        # for the lowest trainable layer's neighbour; every G_l before the side convs' own weight gradients, those of the deep
-        # layers queued when the chain reaches conv2_1 (DEEP_SIDE_WGRAD_AT).
-        # the backward's share of the weight repacking (rotated filters, transposed side / fc weights) behind the forward's last
-        # pooling instead of at the head of the step (bench.py --engine-set late_bwd_pack=0 for the A/B)
-        self.late_bwd_pack = True
+        self.conv_winograd = True        # forward / dgrad of the layers with >= 64 input channels in the Winograd domain (False: implicit GEMM)
+        # ``plain``: the reference's order of operations with one launch per pass -- the parity witness of every fused form below,
+        # and what the walk falls back to layer by layer where a fused form does not apply (odd sizes, unsupported widths):
+        #   * side conv in FRONT of upsample + superpixel mean with the side outputs materialised (default: behind, on one row per
+        #     superpixel -- the three maps are linear, the first mixes channels, the other two pixels: they commute);
+        #   * the side-branch gradient of the native-resolution layers materialised by the gather kernel and accumulated into
+        #     (default: gathered by the dgrad epilogue of the layer above);
+        #   * the two F(4x4) transforms of an output gradient as two launches (default: one pass, ops.winograd_dual_transform);
+        #   * ReLU masks / max-pool decisions re-read from the pre-ReLU activations (default: sign bits / 3-bit codes the forward
+        #     leaves, 1/16 and 1/32 of the tensor);
+        #   * the max-pool backward as a launch of its own on a gradient at pooled resolution (default: the dgrad epilogue).
+        self.plain = False
+        # The scatter-mean of the native-resolution layers (conv1_1, conv1_2) tile by tile (ops.sp_pool_tiles_fwd) instead of
+        # superpixel by superpixel through the pixel lists (ops.sp_pool_upsample_fwd); see DESIGN.md 3.2
+        self.pool_tiles = False
         self._diag_skip = set()          # TIMING-ONLY diagnostics (bench.py --diag-skip): classes of launches left out, results wrong
         self.route_fn = default_route    # (ci, co, h, w, B) -> 0 | 2 | 4, consulted per layer and shape
         self._route = None               # the 13 tile sizes of the current / most recent shape
@@ -205,6 +179,15 @@ class WesupEngine:
         self.on_tail = None              # callback(wgrad stream, names of the last layer's parameters): see backward()
         self._rot = 0
         self.buf_generation = 0          # counts buffer sets ever created: a set's `gen` (a recorded step plan holds ITS addresses)
+
+    # what ``plain`` switches, by the names the walk uses
+    commute_side = property(lambda self: not self.plain)
+    gather_side_grad = property(lambda self: not self.plain)
+    dual_transform = property(lambda self: not self.plain)
+    compact_masks = property(lambda self: not self.plain)
+    fuse_unpool = property(lambda self: not self.plain)
+    matrix_pool = True          # coarse layers: upsample + scatter-mean (and backward) as GEMMs with the interpolation-pooling matrix
+    fuse_side_fwd = True        # side conv of a direct-form layer with <= 128 output channels inside its conv epilogue (where not commuted)
 
     # ------------------------------------------------------------------ streams
     # Ordering edges between the three streams go through the library's event pool (ops.sync_record / sync_wait: slots of a
@@ -271,16 +254,45 @@ class WesupEngine:
             self._edge(self._side(), torch.cuda.current_stream())
 
     # ------------------------------------------------------------------ buffers
-    BYTES_PER_PIXEL = 16 * 1024      # a training buffer set, generously (measured: 9.3 GiB at 4 x 480 x 480 = 10.6 KiB per pixel)
+    BYTES_PER_PIXEL = 16 * 1024      # a training buffer set before one has been measured (9.3 GiB at 4 x 480 x 480 = 10.6 KiB per pixel)
+
+    @staticmethod
+    def _set_bytes(b):
+        """Device bytes a buffer set holds right now (every tensor reachable from it, storages counted once)."""
+        seen, total, todo = set(), 0, [b]
+        while todo:
+            o = todo.pop()
+            if torch.is_tensor(o):
+                st = o.untyped_storage()
+                if st.data_ptr() not in seen:
+                    seen.add(st.data_ptr())
+                    total += st.nbytes()
+            elif isinstance(o, (list, tuple)):
+                todo.extend(o)
+            elif isinstance(o, _Bufs):
+                todo.extend(vars(o).values())
+        return total
+
+    def _bytes_per_pixel(self):
+        """What a buffer set costs per pixel of its batch: the largest figure among the cached sets that have been through a training
+        step (their lazily allocated parts exist), else the constant above."""
+        best = 0.0
+        for (B, H, W, _), b in self._bufs.items():
+            if getattr(b, 'train', False) and getattr(b, 'x_in', None) is not None:
+                best = max(best, self._set_bytes(b) / float(B * H * W))
+        return best * 1.1 if best > 0 else float(self.BYTES_PER_PIXEL)
 
     def _memory_short(self, pixels):
         """The cache bounds above are counts; what ends a run is the allocator failing.  Before a set for a new shape is made: is
         there room for it -- free device memory plus what torch's caching allocator holds unused?  If not the least recently used
-        sets go first (a co-resident job, a smaller GPU, or other tensors of the caller's have taken the room the bounds assume)."""
-        need = pixels * self.BYTES_PER_PIXEL
+        sets go first (a co-resident job, a smaller GPU, or other tensors of the caller's have taken the room the bounds assume).
+        The need is estimated from the sets this engine has already made (measured bytes per pixel), not from a constant."""
         try:
             free, _ = torch.cuda.mem_get_info(self.device)
-            if free >= need:                  # (the common case, one driver query; torch's memory statistics cost 2 ms a call)
+            if free >= pixels * self.BYTES_PER_PIXEL:      # (the common case, one driver query; walking the sets / torch's statistics cost ms)
+                return False
+            need = pixels * self._bytes_per_pixel()
+            if free >= need:
                 return False
             idle = torch.cuda.memory_reserved(self.device) - torch.cuda.memory_allocated(self.device)
         except Exception:
@@ -381,6 +393,9 @@ class WesupEngine:
             b.dh2 = torch.empty(R, 1024, **f32)
             b.dh1 = torch.empty(R, 1024, **f32)
             b.gsp = torch.empty(B, Kmax, FM_CHANNELS, **f32)
+            # partial sums of the classifier's weight gradient between ops.head_bwd and ops.classifier_bwd_finish (another stream,
+            # three GEMMs later): this set's own buffer, never a shared workspace a growth elsewhere could replace in between
+            b.cls_part = ops.head_bwd_partials(R, self.D, dev)
             b.train = True
         return b
 
@@ -508,8 +523,6 @@ class WesupEngine:
             # with conv1_1 and conv1_2's input transform (0.4 GB written beside kernels the chain waits for).  forward() queues it
             # behind its last pooling, where it runs beside the fc layers and the loss section (round 5).
             pk.bwd_todo = (dg4, wino) if train else None
-            if train and not self.late_bwd_pack:
-                self._pack_weights_bwd(pk)
         return pk
 
     def _pack_weights_bwd(self, pk):
@@ -768,6 +781,17 @@ class WesupEngine:
         return b.fm
 
     # ------------------------------------------------------------------ backward
+    def abort_backward(self):
+        """A backward that raised half-way (the step runner's NaN check fires inside it): the caller's stream waits for the side and
+        weight-gradient streams, the context of the forward is dropped.  The gradient buffers hold garbage afterwards."""
+        if self.two_streams:
+            main = torch.cuda.current_stream()
+            if self._wgrad_stream is not None:
+                self._edge(self._wgrad_stream, main)
+            if self._side_stream is not None:
+                self._edge(self._side_stream, main)
+        self.ctx = None
+
     def backward(self, dfeat_extra, dpred, head_done=False):
         """dpred (B,Kmax,2) [and optional dfeat_extra (B,Kmax,D)]: gradients of the loss w.r.t. sp_pred /
         sp_features.  Writes every parameter gradient into self.g (overwrites)."""
@@ -803,7 +827,7 @@ class WesupEngine:
         gsp2d = b.gsp.view(R, FM_CHANNELS)
         off_chain = self.two_streams
         if head_done and not off_chain:
-            ops.classifier_bwd_finish(R, D, g['classifier.0.weight'], g['classifier.0.bias'], self.device)
+            ops.classifier_bwd_finish(b.cls_part, R, D, g['classifier.0.weight'], g['classifier.0.bias'])
         if not off_chain:
             ops.gemm_tn(b.dfeat, b.h2, out=g['fc_layers.4.weight'], colsum=g['fc_layers.4.bias'])
         ops.gemm_nt(b.dfeat, pk.fcT[2], None, out=b.dh2, mask=b.h2)
@@ -819,7 +843,7 @@ class WesupEngine:
             self._edge(torch.cuda.current_stream(), wgs)
             with self._On(wgs):
                 if head_done:
-                    ops.classifier_bwd_finish(R, D, g['classifier.0.weight'], g['classifier.0.bias'], self.device)
+                    ops.classifier_bwd_finish(b.cls_part, R, D, g['classifier.0.weight'], g['classifier.0.bias'])
                 tok = T.begin('mlp_wgrad')
                 ops.gemm_tn(b.dfeat, b.h2, out=g['fc_layers.4.weight'], colsum=g['fc_layers.4.bias'], ws_tag='wgrad')
                 ops.gemm_tn(b.dh2, b.h1, out=g['fc_layers.2.weight'], colsum=g['fc_layers.2.bias'], ws_tag='wgrad')
@@ -917,17 +941,9 @@ class WesupEngine:
                         ds_ready[l] = self.SLOT_DS + l
                         ops.sync_record(ds_ready[l])
 
-        # Where the shallow layers' side-branch gradients are queued (wgrad stream): at its head (13), or when the dgrad chain
-        # reaches conv layer SHALLOW_G_AT -- only when every such layer is commuted (no ds_l the side loop below waits for) and
-        # lies below the layer in question.
-        shallow_at = 13
+        # the shallow layers' side-branch gradients: at the head of the weight-gradient stream
         if self.two_streams and self.fuse_pool_bwd:
-            sh = [l for l in range(13) if b.group_of[l] is None]
-            if (8 <= self.SHALLOW_G_AT <= 12 and sh and all(self._commuted(b, l) for l in sh) and max(sh) < self.SHALLOW_G_AT - 1
-                    and lowest < self.SHALLOW_G_AT):
-                shallow_at = self.SHALLOW_G_AT
-            else:
-                queue_shallow()
+            queue_shallow()
         ds2ds = [None] * 13
 
         def side_wgrad(l):
@@ -997,7 +1013,7 @@ class WesupEngine:
                         ops.sync_record(g_ready[l])
             # The side convs' own weight gradients are parameter gradients nobody waits for before the optimiser, while the
             # dgrad chain waits for every G_l: all the G_l first (13 GEMMs), the weight gradients behind them.
-            late_at = self.DEEP_SIDE_WGRAD_AT if self.two_streams else None
+            late_at = self._DEEP_SIDE_WGRAD_AT if self.two_streams else None
             if late_at is not None and not (lowest < late_at <= 12):      # the main loop below never reaches such a layer
                 late_at = None
             late_side = [l for l in range(12, -1, -1) if late_at is not None and b.group_of[l] is not None]
@@ -1013,8 +1029,6 @@ class WesupEngine:
             ci, co = CONV_CH[l]
             h, w = b.dims[l]
             idx = CONV_IDX[l]
-            if l == shallow_at:
-                queue_shallow()
             if g_ready[l] is not None:
                 ops.sync_wait(g_ready[l], main.cuda_stream)
             if late_side and l == late_at:
@@ -1066,7 +1080,7 @@ class WesupEngine:
             # With its operands ready (dual transform) a weight gradient can start any time.  Queued behind the layer's input
             # gradient instead of in front of it, its TN products run beside the NEXT layer's (memory-bound) transform rather
             # than beside this layer's products: 9.35 -> 9.20 ms.
-            late_wgrad = wg is not None and dual and l > lowest + self.WGRAD_EARLY_LAYERS
+            late_wgrad = wg is not None and dual and l > lowest + self._WGRAD_EARLY_LAYERS
             if l == lowest and wg is not None and self.on_tail is not None and trainable[l]:
                 # every gradient but this layer's is queued (conv and fc weight gradients on wg, the side convs' on the side
                 # stream): the step runner puts the bulk of the optimiser step on wg here, beside the last input gradient

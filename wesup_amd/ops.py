@@ -12,29 +12,16 @@ import torch
 from . import _lib
 
 RELU_IN, RELU_OUT, ACCUM, MASK = 1, 2, 4, 8
-# Stream-K tail of the NT GEMM family (the tiles of a short last round cut along K over all block slots + a fix-up
-# launch): a kernel ALONE on the GPU gains 6-7 % from it (conv forward 5.00 -> 4.70, dgrad 5.03 -> 4.69 ms per step),
-# but inside the training step two other streams fill the idle slots of a short round anyway and the fix-up launches sit
-# on the critical chain: the step is 17.52 ms with it, 17.34 ms without (17.40 forward only, 17.37 plain GEMMs only;
-# bench.py --streamk).  So the STEP runs plain tiling; the workspace is handed over only where a use is switched on
-# (single-stream callers: tools, inference experiments; tests switch all three on to cover the path).
-STREAMK_FWD = False    # conv forward
-STREAMK_DGRAD = False  # conv dgrad
-STREAMK_GEMM = False   # plain NT GEMMs (side convs, MLP)
-STREAMK = True         # master switch for the three (False: never hand out a workspace)
+# Stream-K tail of the NT GEMM family (the tiles of a short last round cut along K over all block slots + a fix-up launch): a
+# kernel ALONE on the GPU gains 6-7 % from it, inside the 3-stream training step the other streams fill a short round anyway and
+# the fix-up launches sit on the chain (17.52 vs 17.34 ms, round 2).  The step never uses it; a single-stream caller (a tool, an
+# inference experiment, the tests of the path) switches it on for its own calls with set_streamk(True).
+STREAMK = False
 
 
-def set_streamk(fwd=None, dgrad=None, gemm=None, everything=None):
-    """Switch the stream-K tail on / off per use (or all three with ``everything``)."""
-    global STREAMK_FWD, STREAMK_DGRAD, STREAMK_GEMM
-    if everything is not None:
-        fwd = dgrad = gemm = everything
-    if fwd is not None:
-        STREAMK_FWD = bool(fwd)
-    if dgrad is not None:
-        STREAMK_DGRAD = bool(dgrad)
-    if gemm is not None:
-        STREAMK_GEMM = bool(gemm)
+def set_streamk(on):
+    global STREAMK
+    STREAMK = bool(on)
 
 
 if hasattr(torch._C, '_cuda_getCurrentRawStream') and hasattr(torch._C, '_cuda_getDevice'):
@@ -125,7 +112,7 @@ def workspace(nbytes, device, tag='default'):
 
 def _nt_workspace(nbytes, device):
     """Stream-K workspace of the NT GEMM family: one per stream, because launches on different streams overlap."""
-    if not nbytes or not STREAMK:
+    if not nbytes:
         return None
     return workspace(nbytes, device, 'nt%x' % torch.cuda.current_stream().cuda_stream)
 
@@ -272,7 +259,7 @@ def conv3x3_fwd(x, w_fwd, bias, Cout, relu_in, out=None, out_relu=None, side=Non
         _lib.call('wesup_conv3x3_fwd_side', _p(x), _p(w_fwd), _p(bias), _p(out), _p(out_relu), _p(sw), _p(sbias), _p(sout),
                   sout.stride(0), B, H, W, Cin, Cout, int(relu_in), _stream())
         return out
-    nb = _lib.load().wesup_conv3x3_workspace_bytes(B, H, W, Cin, Cout) if STREAMK_FWD else 0
+    nb = _lib.load().wesup_conv3x3_workspace_bytes(B, H, W, Cin, Cout) if STREAMK else 0
     _lib.call('wesup_conv3x3_fwd', _p(x), _p(w_fwd), _p(bias), _p(out), _p(out_relu), B, H, W, Cin, Cout, int(relu_in),
               _p(_nt_workspace(nb, x.device)), nb, _stream())
     return out
@@ -288,7 +275,7 @@ def conv3x3_dgrad(dy, w_dgrad, Cin, mask_src=None, out=None, accumulate=False):
         assert not accumulate
         out = torch.empty(B, H, W, Cin, dtype=torch.float32, device=dy.device)
     assert out.shape == (B, H, W, Cin) and out.is_contiguous()
-    nb = _lib.load().wesup_conv3x3_workspace_bytes(B, H, W, Cout, Cin) if STREAMK_DGRAD else 0
+    nb = _lib.load().wesup_conv3x3_workspace_bytes(B, H, W, Cout, Cin) if STREAMK else 0
     _lib.call('wesup_conv3x3_dgrad', _p(dy), _p(w_dgrad), _p(mask_src), _p(out), B, H, W, Cin, Cout, int(accumulate),
               _p(_nt_workspace(nb, dy.device)), nb, _stream())
     return out
@@ -857,8 +844,7 @@ def _ld(t):
 
 def gemm_nt(A, Bw, bias=None, out=None, mask=None, flags=0, streamk=None):
     """out[M][N] = epi(A[M][K] @ Bw[N][K]^T + bias).  A/out/mask may be row-strided 2-D views.
-    streamk: True / False overrides STREAMK_GEMM for this call (the stream-K tail pays where nothing else runs beside the
-    GEMM: the MLP head between the forward and the backward convolutions)."""
+    streamk: True / False overrides ops.STREAMK for this call."""
     for t, n in ((A, 'A'), (Bw, 'B')):
         if not t.is_cuda or t.dtype != torch.float32:
             raise _lib.WesupHipError(f'{n}: expected float32 CUDA/HIP tensor')
@@ -875,7 +861,7 @@ def gemm_nt(A, Bw, bias=None, out=None, mask=None, flags=0, streamk=None):
         flags |= MASK
     if bias is not None:
         _chk(bias, name='bias'); assert bias.numel() == N
-    nb = _lib.load().wesup_gemm_nt_workspace_bytes(M, N, K) if (STREAMK_GEMM if streamk is None else streamk) else 0
+    nb = _lib.load().wesup_gemm_nt_workspace_bytes(M, N, K) if (STREAMK if streamk is None else streamk) else 0
     _lib.call('wesup_gemm_nt', _p(A), _ld(A), _p(Bw), _ld(Bw), _p(bias), _p(out), _ld(out), _p(mask), ldmask, M, N, K,
               flags, _p(_nt_workspace(nb, A.device)), nb, _stream())
     return out
@@ -1281,24 +1267,33 @@ def head_bwd_supported(Kmax, C):
     return Kmax % 64 == 0 and C == 2
 
 
-def head_bwd(feat, Wc, pred, y_all, meta, dloss, eps, prop_weight, terms, dpred, dfeat):
-    """loss_fwd (terms) + loss_bwd (dpred) + the first kernel of classifier_bwd (dfeat, partial sums of dWc / dbc in the 'cls'
-    workspace) in one launch (wesup_head_bwd); classifier_bwd_finish adds the partial sums up."""
+def head_bwd_partials(R, D, device):
+    """The buffer wesup_head_bwd leaves the partial sums of dWc / dbc in and wesup_classifier_bwd_finish reads (on another stream,
+    launches later): owned by the caller -- the engine keeps one per buffer set -- never a shared grow-only workspace, which another
+    tag's growth may replace between the two calls."""
+    return torch.empty(max(int(_lib.load().wesup_classifier_bwd_workspace_bytes(R, D)), 256), dtype=torch.uint8, device=device)
+
+
+def head_bwd(feat, Wc, pred, y_all, meta, dloss, eps, prop_weight, terms, dpred, dfeat, partials):
+    """loss_fwd (terms) + loss_bwd (dpred) + the first kernel of classifier_bwd (dfeat, partial sums of dWc / dbc into ``partials``,
+    see head_bwd_partials) in one launch (wesup_head_bwd); classifier_bwd_finish adds the partial sums up."""
     _chk(feat, name='feat'); _chk(pred, name='pred'); _chk(y_all, name='y_all'); _chk(dloss, name='dloss')
+    _chk(partials, torch.uint8, 'partials')
     B, Kmax, C = y_all.shape
     R, D = feat.shape
     assert R == B * Kmax and pred.numel() == R * C and dpred.numel() == R * C and dfeat.shape == (R, D) and terms.shape == (B, 8)
     assert head_bwd_supported(Kmax, C) and B == meta.B and Kmax == meta.Kmax
     nb = _lib.load().wesup_classifier_bwd_workspace_bytes(R, D)
-    ws = workspace(nb, feat.device, 'cls')
+    assert partials.numel() >= nb
     _lib.call('wesup_head_bwd', _p(feat), _p(Wc), _p(pred), _p(y_all), _p(meta.n_sp), _p(meta.n_l), _p(dloss), float(eps),
-              float(prop_weight), _p(terms), _p(dpred), _p(dfeat), B, Kmax, D, C, _p(ws), nb, _stream())
+              float(prop_weight), _p(terms), _p(dpred), _p(dfeat), B, Kmax, D, C, _p(partials), nb, _stream())
 
 
-def classifier_bwd_finish(R, D, dWc, dbc, device):
+def classifier_bwd_finish(partials, R, D, dWc, dbc):
+    _chk(partials, torch.uint8, 'partials')
     nb = _lib.load().wesup_classifier_bwd_workspace_bytes(R, D)
-    ws = workspace(nb, device, 'cls')
-    _lib.call('wesup_classifier_bwd_finish', _p(ws), nb, _p(dWc), _p(dbc), R, D, _stream())
+    assert partials.numel() >= nb
+    _lib.call('wesup_classifier_bwd_finish', _p(partials), nb, _p(dWc), _p(dbc), R, D, _stream())
 
 
 def cross_entropy_fwd(y_hat, y_true, eps, class_weights=None):

@@ -39,9 +39,27 @@ from .utils import metrics as M
 RB_SLOT = 40          # event slot of the read-back copy (the engine uses 0 .. 27 and 64 ..)
 RECORD_AT = 0         # eager iterations of a shape before the first recording
 MAX_RECORD_TRIES = 4
-TRUST_AFTER = 1       # twin-confirmed shapes after which a clean first recording is sealed at once (None: never).  (2 left 37 of 94
-                      # shapes of a cold multi-scale run to their twins: a second confirmation needs a second shape to recur.)
+TRUST_AFTER = None    # twin-confirmed shapes after which a clean first recording is sealed at once.  None (the default since round 6):
+                      # never -- every shape's first recording waits for its twin.  Multi-scale training opts in with the trainer kwarg
+                      # trust_first_recording_after=1 (2 left 37 of 94 shapes of a cold run to their twins).
+AUDIT_AFTER = 1       # replays of a SEALED plan (no twin ever compared with it) after which the shape is walked and recorded once more
+                      # and the recording compared with the sealed plan node by node: equal -> the plan is as good as a twin-confirmed
+                      # one; different -> it is dropped, counted in stats['distrusted'] and a warning is raised
 MAX_STATES = 256      # shapes with a state (inputs, read-back block, plan) of their own, least recently used first out
+
+
+_frozen = False
+
+
+def freeze_startup_objects():
+    """gc.collect(); gc.freeze() -- once per process, logged."""
+    global _frozen
+    if not _frozen:
+        _frozen = True
+        gc.collect()
+        gc.freeze()
+        if os.environ.get('WESUP_PLAN_DEBUG'):
+            print(f'[step runner] gc.freeze(): {gc.get_freeze_count()} startup objects moved out of the collector')
 
 
 class _Plan:
@@ -90,6 +108,8 @@ class _State:
         self.count = 0
         self.plan = None          # the plan being replayed
         self.cand = None          # first recording, waiting for its twin
+        self.replays = 0          # replays of self.plan so far
+        self.audit_at = None      # replay count at which self.plan is walked, recorded and compared again (None: never)
         self.tries = 0
         self.sig = None
 
@@ -103,16 +123,22 @@ class StepRunner:
         self.confirmed = 0                # shapes whose first recording its twin has confirmed
         ta = trainer.kwargs.get('trust_first_recording_after', TRUST_AFTER)
         self.trust_after = None if (ta is None or os.environ.get('WESUP_PLAN_TRUST', '1') == '0') else int(ta)
+        # Audits: a sealed plan after AUDIT_AFTER replays (kwarg plan_audit_after), and -- for soak runs / CI, kwarg plan_audit_every or
+        # WESUP_PLAN_AUDIT_EVERY=N -- EVERY plan again after each N replays: the generic check behind the hand-kept validity key
+        # (_signature, ws_generation, bufs_gen); anything the key misses shows up as a recording that differs from the plan.
+        self.audit_after = max(0, int(trainer.kwargs.get('plan_audit_after', AUDIT_AFTER)))
+        ae = trainer.kwargs.get('plan_audit_every', os.environ.get('WESUP_PLAN_AUDIT_EVERY'))
+        self.audit_every = int(ae) if ae not in (None, '', 0, '0') else None
         self.fuse_head = bool(trainer.kwargs.get('fuse_head', True))      # (A/B: the six head launches of round 4)
         self.split_sgd = bool(trainer.kwargs.get('split_sgd', True))      # (A/B: one optimiser launch behind the whole backward)
         # A shape's first walk allocates its buffer set, state and plan -- a few hundred long-lived Python objects -- and a
         # multi-scale epoch brings a new shape every other step: CPython's collector then runs full collections over everything
         # the process holds (268 K tracked objects with torch imported: 67 ms each, 2 ms per step averaged over 40 new shapes,
         # tools/cold_walk.py).  Everything alive when training starts (modules, the model, the loaders) is moved to the permanent
-        # generation once; later collections only look at what the iterations create.  ``gc_freeze=False`` leaves the collector alone.
-        if trainer.kwargs.get('gc_freeze', True):
-            gc.collect()
-            gc.freeze()
+        # generation once; later collections only look at what the iterations create.  A process-wide side effect, so OPT-IN
+        # (``gc_freeze=True``: bench.py's multi-scale mode and train.py's fit() pass it) and done at most once per process.
+        if trainer.kwargs.get('gc_freeze', False):
+            freeze_startup_objects()
         self._cuts = None
         self._routes = {}
 
@@ -157,7 +183,7 @@ class StepRunner:
         pk = eng._packed
         panels = None if pk is None else tuple(0 if u is None else u.data_ptr() for u in list(pk.uf) + list(pk.ud))
         return (sw, eng.route_fn, type(eng).WINOGRAD_CONV_MIN_CI, type(eng).WINOGRAD_TILE, tuple(sorted(eng._diag_skip)),
-                ops.STREAMK_FWD, ops.STREAMK_DGRAD, ops.STREAMK_GEMM, ops.STREAMK,
+                ops.STREAMK,
                 g['lr'], g['momentum'], g['weight_decay'], o.grad_scale, o._first,
                 tuple(p.requires_grad for _, p in t.model._named),
                 float(t.kwargs.get('propagate_threshold')), float(t.kwargs.get('propagate_weight')),
@@ -225,10 +251,13 @@ class StepRunner:
             st.count = 0
             self.stats['dropped'] += 1
         metrics = {}
-        if st.plan is not None and not timing:
+        if st.plan is not None and not timing and st.audit_at is not None and st.replays >= st.audit_at:
+            host = self._audit(st, metrics, want_seg, eng, B, H, W, sig, gens)
+        elif st.plan is not None and not timing:
             if st.meta is not None:                   # the replay does not re-enter sp_preprocess: this batch's host-side counts
                 st.meta.n_sp_host = counts
             host = self._replay(st, metrics)
+            st.replays += 1
             self.stats['replayed'] += 1
         else:
             if st.cand is not None and st.sig != sig:       # settings changed since the first recording: it has no twin to wait for
@@ -254,6 +283,7 @@ class StepRunner:
                                                               # panels and clears the optimiser's first-step flag: the twin decides)
                 if st.cand is not None and st.gens == gens and _lib.load().wesup_plan_diff(st.cand.h, plan.h) == 0:
                     st.plan, st.cand = plan, None
+                    st.replays, st.audit_at = 0, self.audit_every
                     self.confirmed += 1
                 elif (self.trust_after is not None and self.confirmed >= self.trust_after and st.cand is None and sig == sig0):
                     # A first recording is sealed without its twin once the run has confirmed TRUST_AFTER shape(s) twin by twin:
@@ -263,6 +293,7 @@ class StepRunner:
                     # Under multi-scale training (a new shape every other step in the first epochs) every shape's second
                     # occurrence replays instead of walking again.
                     st.plan = plan
+                    st.replays, st.audit_at = 0, self.audit_after
                     self.stats['trusted'] = self.stats.get('trusted', 0) + 1
                 else:
                     if os.environ.get('WESUP_PLAN_DEBUG') and st.cand is None and self.trust_after is not None:
@@ -281,6 +312,33 @@ class StepRunner:
             else:
                 self.stats['eager'] += 1
         return self._finish(st, host, metrics, want_seg, names, H, W)
+
+    def _audit(self, st, metrics, want_seg, eng, B, H, W, sig, gens):
+        """This occurrence of a shape with a plan is WALKED and recorded instead of replayed, and the recording compared with the
+        plan node by node (kernel, grid, stream, every argument byte).  The walk computes the step either way."""
+        import warnings
+        plan2 = _Plan()
+        ws_gen0 = ops.ws_generation
+        host = self._walk(st, metrics, want_seg, plan2)
+        st.count += 1
+        self.stats['audited'] = self.stats.get('audited', 0) + 1
+        same = (ops.ws_generation == ws_gen0 and (ops.ws_generation, eng.bufs_gen(B, H, W, st.y_all.shape[1])) == gens
+                and self._signature(eng, B, H, W) == sig and len(plan2.cuts) == len(st.plan.cuts)
+                and all(a[0] == b[0] for a, b in zip(plan2.cuts, st.plan.cuts))
+                and _lib.load().wesup_plan_diff(st.plan.h, plan2.h) == 0)
+        if same:
+            st.audit_at = None if self.audit_every is None else st.replays + self.audit_every
+        else:
+            k = _lib.load().wesup_plan_diff(st.plan.h, plan2.h)
+            where = 'validity key moved during the walk' if k == 0 else (
+                f'node {k - 1} ({_lib.load().wesup_plan_node_name(plan2.h, k - 1)}), sizes {st.plan.size()} / {plan2.size()}')
+            warnings.warn(f'wesup step plan of shape {(B, H, W)} failed its audit after {st.replays} replay(s): {where}; the plan is '
+                          'dropped and the shape recorded again -- the iterations it replayed may have read stale addresses',
+                          RuntimeWarning)
+            self.stats['distrusted'] = self.stats.get('distrusted', 0) + 1
+            st.plan, st.cand, st.replays, st.audit_at = None, None, 0, None
+            st.tries += 1
+        return host
 
     def _cut(self, plan, fn):
         """Host work inside the iteration: run it now, and when recording, remember where the replay has to stop for it."""
@@ -328,7 +386,7 @@ class StepRunner:
                     if want_seg:
                         ops.seg_metrics(pred, st.gt, out=st.seg)
                 ops.head_bwd(b.feats, P['classifier.0.weight'], b.sp_pred, st.y_all, st.meta, st.one, float(kw.get('epsilon')),
-                             float(kw.get('propagate_weight')), st.terms, st.dpred, b.dfeat)
+                             float(kw.get('propagate_weight')), st.terms, st.dpred, b.dfeat, b.cls_part)
                 st.rb_event = None
                 with eng.side_stream():                                   # the read-back, behind the loss terms
                     _lib.call('wesup_copy_to_host', ctypes.c_void_p(st.host.data_ptr()), ops._p(st.rb), st.rb.numel() * 4, ops._stream())
@@ -382,6 +440,12 @@ class StepRunner:
                 eng.on_tail = tail
             try:
                 eng.backward(None, st.dpred, head_done=fuse)
+            except BaseException:
+                # (the NaN check inside on_tail raised, or anything else did: the weight-gradient and side streams may still run
+                # this step's kernels on the set's buffers -- the caller's stream waits for both before anything else is queued,
+                # and the engine forgets the half-walked backward.  Gradients are undefined after 'Loss is nan!'.)
+                eng.abort_backward()
+                raise
             finally:
                 eng.on_tail = None
             if red is not None:
