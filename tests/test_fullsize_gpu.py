@@ -27,7 +27,7 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-4
 # rows per image that the src / y_u comparison at configs[1] may leave out as near-ties (threshold or runner-up within 1e-5): 10 x the
 # worst count observed on round 6's green run (profiles/r06_tolerances.json), floor 4
-MASKED_ROWS_BUDGET = 40
+MASKED_ROWS_BUDGET = 10        # observed: 0 - 1 per image at configs[1], 4 of 2 420 at 1024^2 (budget there: 5 x this)
 
 
 def rel_err(a, b):

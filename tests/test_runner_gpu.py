@@ -232,6 +232,12 @@ def test_sealed_plans_are_audited_and_dropped_when_the_walk_would_differ():
     from oracle import wesup_oracle as orc
     from wesup_amd import ops
     dev = torch.device('cuda:0')
+    # the shared workspaces are grow-only per process: start from none, as a fresh training process does, so that the large shape
+    # below really has to grow them (earlier tests of this session have left larger ones behind)
+    torch.cuda.synchronize()
+    ops._ws_cache.clear(); ops._ws_first.clear()
+    ops.ws_generation += 1
+    ops.set_workspace_headroom(1)
     weights = orc.make_weights(21, feat_scale=0.05)
     shapes = [(1, 96, 96, 6), (1, 96, 80, 5), (2, 256, 256, 12)]
     data = [_batches(1, *s, dev)[0] for s in shapes]
