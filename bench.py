@@ -51,12 +51,11 @@ def parse_args(argv=None):
                                                                'the direct implicit-GEMM kernel (no Winograd-domain conv)')
     ap.add_argument('--direct-wgrad', action='store_true', help='A/B: every conv weight gradient with the direct '
                                                                 'implicit-GEMM kernel (no Winograd-domain wgrad)')
-    ap.add_argument('--pool-tiles', action='store_true', help='A/B: the scatter-mean of the native-resolution layers per 16 x 16 tile (wesup_sp_pool_tiles_fwd) instead of through the pixel lists (segment form)')
     ap.add_argument('--engine-set', default='', help='A/B: comma list of name=value engine switches (bool / int attributes of WesupEngine), e.g. plain=1 (the reference\'s order of operations, one launch per pass)')
     ap.add_argument('--trainer-set', default='', help='A/B: comma list of name=value trainer kwargs (fuse_head, split_sgd, gc_freeze, trust_first_recording_after, plan_audit_every; "none" = None)')
     ap.add_argument('--diag-skip', default='', help="TIMING-ONLY diagnostic (results are wrong): comma list of launch classes left out "
                                                     "of the step after the warm-up (learning rate 0 from there on) -- 'wgrad' (conv weight gradients), 'side_wgrad', "
-                                                    "'side_fwd_shallow' (pooling + side conv of conv1_1 .. conv3_3), 'side_fwd_deep' -- to see what they cost the step")
+                                                    "'side_fwd_shallow' (pooling + side conv of conv1_1 .. conv3_3), 'side_fwd_deep', 'tout' (output transforms of the K = 512 layers), 'tin' (forward input transforms), 'dual' (the backward's dual transforms) -- to see what they cost the step")
     ap.add_argument('--event-every', type=int, default=10, help='steps of the timed region that carry HIP events: every n-th')
     ap.add_argument('--timed-classes', default='conv3x3_fwd,conv3x3_dgrad,winograd_gemm',
                     help="kernel classes that get HIP events inside the timed region ('all', 'none' or a comma list); an "
@@ -271,7 +270,6 @@ def worker(args):
     eng.fuse_pool_bwd = not args.unfused_pool_bwd
     eng.conv_winograd = not args.direct_conv
     eng.wgrad_winograd = not args.direct_wgrad
-    eng.pool_tiles = args.pool_tiles
     for kv in filter(None, args.engine_set.split(',')):
         k, v = kv.split('=')
         assert isinstance(getattr(eng, k), (bool, int)), k
@@ -376,6 +374,7 @@ def worker(args):
         step(i)
     if args.diag_skip:            # TIMING-ONLY: classes of launches left out from here on (buffers keep the warm-up's values)
         trainer.model.engine._diag_skip = set(filter(None, args.diag_skip.split(',')))
+        _ops_t.DIAG = set(trainer.model.engine._diag_skip) & {'tin', 'tout'}
         for gr in trainer.optimizer.param_groups:
             gr['lr'] = 0.0
     ev_off = args.event_every // 2 if args.steps > args.event_every // 2 else 0      # a short run (--steps 5) still has one such step
@@ -620,7 +619,7 @@ def worker(args):
                 # (sp_pool_tile_kernel + combine), segment-form pooling of the coarse gather layers (sp_pool_up_fwd_kernel), the
                 # interpolation-pooling matrix of the deep layers and its application (interp_matrix + sp_pool_mat_fwd), on ITS OWN
                 # byte model; the materialised-map kernel of SURVEY 8(d) (never launched by the step) is the secondary figure.
-                ftags = ('sp_pool_up_fwd', 'sp_pool_mat_fwd', 'interp_matrix', 'sp_tiles')
+                ftags = ('sp_pool_up_fwd', 'sp_pool_mat_fwd', 'interp_matrix')
                 f_in = sum(allk[t][0] for t in ftags if t in allk) / n_extra
                 f_alone = sum(iso[t][0] for t in ftags if t in iso) / 2 if iso is not None else None
                 dims, hh, ww = [], H, W
@@ -636,16 +635,14 @@ def worker(args):
                     # read once: the side output -- or, for the gather layers with the side conv commuted behind the pooling,
                     # the conv output itself (twice the channels; the side output is never formed)
                     own += 4.0 * h_ * w_ * (c_ if (matrix or not commuted) else 2 * c_)
-                    if not matrix:              # gather layers: slot bytes of the tile form (native resolution) or the sorted pixel list
-                        own += 1.0 * H * W if ((h_, w_) == (H, W) and eng_.pool_tiles) else 4.0 * H * W
+                    if not matrix:              # gather layers: the sorted pixel list
+                        own += 4.0 * H * W
                 for (h_, w_) in sorted({(h_, w_) for (h_, w_, _) in dims if (h_, w_) != (H, W) and h_ * w_ <= 4096}):
                     own += 4 * 4.0 * g * g * h_ * w_                             # Wm and its transpose: written, then read
                 own = B * (own + 4.0 * g * g * 2112)
                 sm = {'bound': 'hbm',
                       'kernel': 'the scatter-mean of the training step: '
-                                + ('sp_pool_tile_kernel + combine (conv1_1, conv1_2 at native resolution), sp_pool_up_fwd_kernel (conv2_1 ... '
-                                   'conv3_3, upsample fused)' if eng_.pool_tiles else
-                                   'sp_pool_up_fwd_kernel + sp_pool_combine_kernel (segment form: conv1_1 ... conv3_3, upsample fused)')
+                                + 'sp_pool_up_fwd_kernel + sp_pool_combine_kernel (segment form: conv1_1 ... conv3_3, upsample fused)'
                                 + ', sp_interp_matrix_kernel + gemm_tn (the six deep layers)',
                       'algorithmic_bytes': own,
                       'bytes_what': 'what the pooling reads at the layers\' own resolution (gather layers: the conv output, all C channels, the '

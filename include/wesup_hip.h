@@ -347,26 +347,7 @@ int wesup_sp_pool_upsample_fwd(const float* s, const int32_t* pix_sorted, const 
                                const int32_t* seg_start, const int32_t* unit_row, float* sp_feat,
                                int B, int h, int w, int H, int W, int C, int ldo, int coff, int Kmax, int Umax,
                                void* ws, size_t ws_bytes, void* stream);
-/* The scatter-mean of a side output at the image's OWN resolution (h == H, w == W: torch.mm over it, models/wesup.py:283-285)
- * tile by tile (an alternative to wesup_sp_pool_upsample_fwd for such a layer: engine.pool_tiles).  wesup_sp_tiles, once per label map: the image in
- * 16 x 16-pixel tiles; per tile the rows present (ascending) and every pixel's slot in that list; per row the box of tiles it
- * touches; part rows per tile (prefix sums).
- *   slot [B][HW] uint8, tile_ns / tile_base [B][ntile], tile_rows [B][ntile][256], alloc [B], row_flag [B][Kmax], bbox [B][Kmax][4]
- *   (ntile = ceil(H/16) * ceil(W/16)).
- * wesup_sp_pool_tiles_fwd, per side output s (B,H,W,C) (C = 32, 64, 128 or a multiple of 256; wesup_sp_pool_tiles_supported): a
- * block streams its tile of s once, in raster order, into one partial sum per (tile, row) -- every load address known up front --,
- * a second launch adds a row's partial sums over its box of tiles in raster order and scales by 1 / area into
- * sp_feat[b][r][coff .. coff + C).  Bitwise reproducible.  Rows of tiles that hold more rows than the part buffer has room for
- * (wesup_sp_tiles_part_rows: 6 per tile + Kmax per image) are summed from their pixel lists instead. */
-int wesup_sp_tiles_part_rows(int H, int W, int Kmax);
-int wesup_sp_tiles(const int32_t* new_row, int B, int H, int W, int Kmax, uint8_t* slot, int32_t* tile_ns, int32_t* tile_base,
-                   int32_t* tile_rows, int32_t* alloc, int32_t* row_flag, int32_t* bbox, void* stream);
-size_t wesup_sp_pool_tiles_workspace_bytes(int B, int H, int W, int C, int Kmax);
-int wesup_sp_pool_tiles_supported(int h, int w, int H, int W, int C);
-int wesup_sp_pool_tiles_fwd(const float* s, const uint8_t* slot, const int32_t* tile_ns, const int32_t* tile_base,
-                            const int32_t* tile_rows, const int32_t* row_flag, const int32_t* bbox, const int32_t* pix_sorted,
-                            const int32_t* row_start, float* sp_feat, int B, int h, int w, int H, int W, int C, int ldo, int coff,
-                            int Kmax, void* ws, size_t ws_bytes, void* stream);
+
 /* the same linear map as a matrix over the h*w cells of a coarse side output:
  * Wm[b][r][q] = (1/area_r) sum_{p in row r} bilinear_ac weight of cell q at pixel p     ([B][Kmax][h*w], h*w <= 8192).
  * Then  sp_feat[b][:, slice] = Wm[b] . s[b]  and  ds[b] = Wm[b]^T . g[b][:, slice]  are wesup_gemm_tn calls

@@ -45,7 +45,7 @@ def test_ctypes_signatures_match_header(lib):
 
 def test_host_side_queries(lib):
     h = lib.load()
-    assert h.wesup_abi_version() == lib.ABI_VERSION == 5
+    assert h.wesup_abi_version() == lib.ABI_VERSION == 6
     assert h.wesup_conv3x3_kpad(3) == 64 and h.wesup_conv3x3_kpad(64) == 576 and h.wesup_conv3x3_kpad(512) == 4608
     assert h.wesup_strerror(0) == b'ok' and b'workspace' in h.wesup_strerror(-3)
     assert h.wesup_conv3x3_wgrad_workspace_bytes(4, 480, 480, 64, 64) > 0

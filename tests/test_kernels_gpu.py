@@ -1124,89 +1124,6 @@ def test_sp_pool_skewed_maps_multi_segment_rows(ops, H, W, g):
         assert rel_err(got[..., coff:coff + Cs], ref2[..., coff:coff + Cs]) < 1e-5
 
 
-# ---------------------------------------------------------------- fused upsample + scatter-mean, tile by tile (round 5)
-def _tile_pool_cases(H, W):
-    return [(H, W, 32, 0), (H, W, 64, 32), (H, W, 128, 128), (H, W, 256, 0), (H, W, 512, 256), (H // 2, W // 2, 64, 64)]
-
-
-@pytest.mark.parametrize('B,H,W,g', [(2, 32, 32, 4), (1, 96, 80, 7), (2, 120, 136, 9), (1, 53, 47, 5)])
-def test_sp_pool_tiles_equals_the_pixel_list_form(ops, B, H, W, g):
-    """wesup_sp_tiles + wesup_sp_pool_tiles_fwd against wesup_sp_pool_upsample_fwd (itself pinned to upsample_fwd + sp_pool_fwd and,
-    through them, to the oracle) and against the materialised form directly; tables checked against numpy; bitwise reproducible."""
-    d = dev()
-    labs, masks = _sp_case(17, B, H, W, g)
-    Kmax = g * g + 3
-    m = ops.sp_preprocess(torch.from_numpy(labs).to(d), torch.from_numpy(masks).to(d), Kmax)
-    t = ops.sp_tiles(m)
-    nty, ntx = (H + 15) // 16, (W + 15) // 16
-    new_row = m.new_row.cpu().numpy().reshape(B, H, W)
-    ns, rows, slot = t.tile_ns.cpu().numpy(), t.tile_rows.cpu().numpy(), t.slot.cpu().numpy().reshape(B, H, W)
-    base, bbox = t.tile_base.cpu().numpy(), t.bbox.cpu().numpy()
-    for b in range(B):
-        want_box = {}
-        for ty in range(nty):
-            for tx in range(ntx):
-                blk = new_row[b, ty * 16:(ty + 1) * 16, tx * 16:(tx + 1) * 16]
-                u = np.unique(blk)
-                ti = ty * ntx + tx
-                assert ns[b, ti] == len(u) and np.array_equal(rows[b, ti, :len(u)], u)
-                assert np.array_equal(u[slot[b, ty * 16:(ty + 1) * 16, tx * 16:(tx + 1) * 16]], blk)
-                for r in u:
-                    y0, y1, x0, x1 = want_box.get(r, (ty, ty, tx, tx))
-                    want_box[r] = (min(y0, ty), max(y1, ty), min(x0, tx), max(x1, tx))
-        for r, box in want_box.items():
-            assert tuple(bbox[b, r]) == box
-        # part rows handed out: every tile its own range, all inside the capacity
-        order = np.argsort(base[b])
-        assert base[b].min() == 0 and np.array_equal(base[b][order][1:], np.cumsum(ns[b][order])[:-1])
-        assert int(t.alloc[b]) == ns[b].sum() <= ops._lib.load().wesup_sp_tiles_part_rows(H, W, Kmax)
-    assert int(t.row_flag.abs().max()) == 0
-    C = 768
-    for (h, w, Cs, coff) in _tile_pool_cases(H, W):
-        if not ops.sp_pool_tiles_supported(h, w, H, W, Cs):
-            assert (h, w) != (H, W) or Cs == 512                        # the tile form is for native resolution (coarse layers: pixel lists)
-            continue
-        sl = rnd(B, h, w, Cs, seed=9).to(d)
-        want = torch.zeros(B, Kmax, C, device=d)
-        ops.sp_pool_upsample_fwd(sl, m, want, coff)
-        got = torch.full((B, Kmax, C), 7.0, device=d)
-        ops.sp_pool_tiles_fwd(sl, m, got, coff)
-        assert rel_err(got[..., coff:coff + Cs], want[..., coff:coff + Cs]) < 1e-5
-        rest = torch.cat([got[..., :coff], got[..., coff + Cs:]], dim=-1)
-        assert rest.numel() == 0 or float((rest - 7).abs().max()) == 0.0          # nothing outside the slice is touched
-        got2 = torch.zeros(B, Kmax, C, device=d)
-        ops.sp_pool_tiles_fwd(sl, m, got2, coff)
-        assert torch.equal(got[..., coff:coff + Cs], got2[..., coff:coff + Cs])
-        fm2 = torch.zeros(B, H, W, C, device=d)
-        ops.upsample_fwd(sl, fm2, coff)
-        ref2 = ops.sp_pool_fwd(fm2, m)
-        assert rel_err(got[..., coff:coff + Cs], ref2[..., coff:coff + Cs]) < 1e-5
-        n_sp = m.n_sp.cpu().tolist()
-        for b in range(B):
-            assert float(got[b, n_sp[b]:, coff:coff + Cs].abs().max()) == 0.0          # padded rows: zeros
-
-
-def test_sp_pool_tiles_rows_that_do_not_fit_take_the_pixel_lists(ops):
-    """One-pixel-high stripes across the image: every tile holds 16 rows, more than the part buffer has room for (6 per tile +
-    Kmax): the tiles that did not fit mark their rows, and the combine kernel sums those from the pixel lists -- same values."""
-    d = dev()
-    B, H, W = 2, 64, 80
-    labs = np.broadcast_to(np.arange(H, dtype=np.int32)[None, :, None], (B, H, W)).copy()
-    labs[1] = labs[1][::-1]                       # (any ids: rows are the reference's order of them)
-    m = ops.sp_preprocess(torch.from_numpy(labs).to(d), None, H)
-    t = ops.sp_tiles(m)
-    assert int(t.alloc.min()) > ops._lib.load().wesup_sp_tiles_part_rows(H, W, H)       # more rows asked for than there are
-    flagged = int(t.row_flag.sum())
-    assert 0 < flagged <= B * H and int((t.tile_base < 0).sum()) > 0
-    for (h, w, Cs) in [(H, W, 64), (H, W, 32), (H, W, 256)]:
-        sl = rnd(B, h, w, Cs, seed=4).to(d)
-        want = torch.zeros(B, H, Cs, device=d)
-        ops.sp_pool_upsample_fwd(sl, m, want, 0)
-        got = torch.zeros(B, H, Cs, device=d)
-        ops.sp_pool_tiles_fwd(sl, m, got, 0)
-        assert rel_err(got, want) < 1e-5
-
-
 @pytest.mark.parametrize('Kmax,C,ok', [(16384, 2, True), (16384, 3, True), (16384, 4, False), (13312, 4, True), (20000, 2, False)])
 def test_sp_preprocess_limits(ops, Kmax, C, ok):
     """The limits wesup_hip.h states: Kmax <= 16384 and Kmax * (2 + C) <= 81920 (round 4's form refused Kmax > 13312 with a 2-class

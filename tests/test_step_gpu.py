@@ -43,7 +43,7 @@ def make_trainer(weights, **kw):
 
 
 @pytest.mark.parametrize('name', CASES)
-@pytest.mark.parametrize('fused', [True, False, 'direct_convs', 'plain', 'pool_tiles'])
+@pytest.mark.parametrize('fused', [True, False, 'direct_convs', 'plain'])
 def test_step_matches_reference_golden(golden_dir, name, fused):
     from oracle import wesup_oracle as orc
     from wesup_amd.models.wesup import preprocess_label_maps, SuperpixelMaps
@@ -60,8 +60,6 @@ def test_step_matches_reference_golden(golden_dir, name, fused):
     # materialised, the gather kernel, two transform launches per output gradient, float masks, the separate max-pool backward
     if fused in ('plain', False):
         model.engine.plain = True
-    if fused == 'pool_tiles':         # the native-resolution layers' scatter-mean per 16 x 16 tile (default: through the pixel lists)
-        model.engine.pool_tiles = True
     fused = bool(fused)               # False: on top of plain, the (B,HW,2112) feature map and its gradient materialised
     model.engine.fuse_pool_bwd = fused
     model.engine.fuse_pool_fwd = fused

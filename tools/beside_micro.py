@@ -25,7 +25,6 @@ B, S, g = args.batch, args.size, args.grid
 labs = np.stack([synth.voronoi_labels(3 + b, S, S, g) for b in range(B)])
 Kmax = (g * g + 63) // 64 * 64
 m = ops.sp_preprocess(torch.from_numpy(labs).to(d), None, Kmax)
-ops.sp_tiles(m)
 s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
 
 
@@ -56,21 +55,17 @@ def product(K, N, div):
     return lambda: ops.winograd_gemm_output_transform(V, U, B, h, w, out=y)
 
 
-def pool(C, div, tiles):
+def pool(C, div):
     h = w = S // div
     s = torch.randn(B, h, w, C, device=d)
     out = torch.empty(B, Kmax, C, device=d)
-    fn = ops.sp_pool_tiles_fwd if tiles else ops.sp_pool_upsample_fwd
-    return lambda: fn(s, m, out, 0)
+    return lambda: ops.sp_pool_upsample_fwd(s, m, out, 0)
 
 
 print(f'# B={B} {S}x{S} g={g}; microseconds per pair of launches')
-for pname, pa, sname, pb in [('conv1_2 products (K=64)', product(64, 64, 1), 'pool conv1_1 (pixel lists)', pool(64, 1, False)),
-                             ('conv1_2 products (K=64)', product(64, 64, 1), 'pool conv1_1 (tiles)', pool(64, 1, True)),
-                             ('conv2_2 products (K=128)', product(128, 128, 2), 'pool conv2_1 (pixel lists)', pool(128, 2, False)),
-                             ('conv2_2 products (K=128)', product(128, 128, 2), 'pool conv2_1 (tiles)', pool(128, 2, True)),
-                             ('conv3_2 products (K=256)', product(256, 256, 4), 'pool conv3_1 (pixel lists)', pool(256, 4, False)),
-                             ('conv3_2 products (K=256)', product(256, 256, 4), 'pool conv3_1 (tiles)', pool(256, 4, True))]:
+for pname, pa, sname, pb in [('conv1_2 products (K=64)', product(64, 64, 1), 'pool conv1_1', pool(64, 1)),
+                             ('conv2_2 products (K=128)', product(128, 128, 2), 'pool conv2_1', pool(128, 2)),
+                             ('conv3_2 products (K=256)', product(256, 256, 4), 'pool conv3_1', pool(256, 4))]:
     for f in (pa, pb):
         f()
     a, b_, both = wall(pa, None, args.reps), wall(None, pb, args.reps), wall(pa, pb, args.reps)

@@ -92,11 +92,6 @@ _SIGS = {
     'wesup_sp_pool_bwd': (c_int, 'ppppiiiiip'),
     'wesup_sp_pool_upsample_fwd': (c_int, 'ppppppiiiiiiiiiipzp'),
     'wesup_sp_interp_matrix': (c_int, 'pppiiiiiip'),
-    'wesup_sp_tiles_part_rows': (c_int, 'iii'),
-    'wesup_sp_tiles': (c_int, 'piiii' + 'ppppppp' + 'p'),
-    'wesup_sp_pool_tiles_workspace_bytes': (c_size_t, 'iiiii'),
-    'wesup_sp_pool_tiles_supported': (c_int, 'iiiii'),
-    'wesup_sp_pool_tiles_fwd': (c_int, 'ppppppppp' + 'p' + 'iiiiiiiii' + 'pzp'),
     'wesup_paint_fwd': (c_int, 'pppiiiiip'),
     'wesup_slic_num_centers': (c_int, 'iii'),
     'wesup_slic_workspace_bytes': (c_size_t, 'iiii'),
@@ -152,7 +147,7 @@ _SIGS = {
 _T = {'p': c_void_p, 'i': c_int, 'f': c_float, 'z': c_size_t, 'l': ctypes.c_long}
 
 EXPORTS = sorted(_SIGS)
-ABI_VERSION = 5          # include/wesup_hip.h; a stale libwesup_hip.so with other signatures must not be called
+ABI_VERSION = 6          # include/wesup_hip.h; a stale libwesup_hip.so with other signatures must not be called
 
 _lib = None
 

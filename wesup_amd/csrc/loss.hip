@@ -627,7 +627,7 @@ extern "C" int wesup_seg_metrics(const float* pred, const uint8_t* mask, float* 
 }
 
 // ------------------------------------------------------------------ misc
-extern "C" int wesup_abi_version(void) { return 5; }
+extern "C" int wesup_abi_version(void) { return 6; }
 extern "C" const char* wesup_strerror(int code) {
     switch (code) {
         case WESUP_OK: return "ok";

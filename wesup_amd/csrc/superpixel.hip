@@ -572,6 +572,9 @@ __device__ __forceinline__ Lerp2 lerp2_of(int dst, float scale, int in) {
     return r;
 }
 #define SP_UP_UNROLL 4
+#ifndef SP_ID_UNROLL
+#define SP_ID_UNROLL 4          // native-resolution branch: row loads in flight per lane group
+#endif
 #define SP_CELL_CAP 1024          // cells of a segment's box of the coarse grid kept in LDS (8 KiB per wave)
 template <int LPP>
 __global__ __launch_bounds__(256) void sp_pool_up_fwd_kernel(const float* __restrict__ s, const int32_t* __restrict__ pix_sorted,
@@ -673,29 +676,40 @@ __global__ __launch_bounds__(256) void sp_pool_up_fwd_kernel(const float* __rest
         }
     }
     if (ident) {
-        // native resolution: the pixel's own row of s, SP_UP_UNROLL pixels in flight per lane group, added in list order
-        int j = j0 + grp;
-        for (; j + (SP_UP_UNROLL - 1) * PPW < j1; j += PPW * SP_UP_UNROLL) {
-            int pix[SP_UP_UNROLL];
+        // native resolution: the pixel's own row of s, added in list order.  The segment's pixel list (<= SP_SEG entries) is loaded
+        // ONCE, all loads in flight, one entry per lane and pass; a lane group then takes its pixel indices from those registers by
+        // shuffle -- the row loads no longer wait for a list load each (round 6: list -> pixel -> row was a chain of two dependent
+        // loads per step).  Same additions in the same order as before.
+        int pl[SP_SEG / 64];
 #pragma unroll
-            for (int u = 0; u < SP_UP_UNROLL; ++u) pix[u] = list[j + u * PPW];
-            float4 v[SP_UP_UNROLL];
+        for (int k = 0; k < SP_SEG / 64; ++k) pl[k] = (j0 + lane + 64 * k < j1) ? list[j0 + lane + 64 * k] : -1;
+        const int npass = (j1 - j0 + 63) >> 6;                       // wave-uniform
 #pragma unroll
-            for (int u = 0; u < SP_UP_UNROLL; ++u) v[u] = ld4(base + (long)pix[u] * lds);
+        for (int k = 0; k < SP_SEG / 64; ++k) {
+            if (k >= npass) break;
+            // the 64 entries of pass k: group grp takes entries grp, grp + PPW, ...; SP_ID_UNROLL row loads in flight per group
+#pragma unroll 1
+            for (int e0 = 0; e0 < 64; e0 += PPW * SP_ID_UNROLL) {
+                int pix[SP_ID_UNROLL];
+                float4 v[SP_ID_UNROLL];
 #pragma unroll
-            for (int u = 0; u < SP_UP_UNROLL; ++u) {
-                acc.x = fmaf(v[u].x, inv, acc.x);
-                acc.y = fmaf(v[u].y, inv, acc.y);
-                acc.z = fmaf(v[u].z, inv, acc.z);
-                acc.w = fmaf(v[u].w, inv, acc.w);
+                for (int u = 0; u < SP_ID_UNROLL; ++u) {
+                    const int e = e0 + u * PPW + grp;                // < 64 whenever PPW * SP_ID_UNROLL divides 64
+                    pix[u] = (PPW * SP_ID_UNROLL <= 64 || e < 64) ? __shfl(pl[k], e & 63) : -1;
+                }
+#pragma unroll
+                for (int u = 0; u < SP_ID_UNROLL; ++u) {
+                    v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (pix[u] >= 0) v[u] = ld4(base + (long)pix[u] * lds);
+                }
+#pragma unroll
+                for (int u = 0; u < SP_ID_UNROLL; ++u) {             // (an entry beyond the segment adds 0 * inv)
+                    acc.x = fmaf(v[u].x, inv, acc.x);
+                    acc.y = fmaf(v[u].y, inv, acc.y);
+                    acc.z = fmaf(v[u].z, inv, acc.z);
+                    acc.w = fmaf(v[u].w, inv, acc.w);
+                }
             }
-        }
-        for (; j < j1; j += PPW) {
-            const float4 v = ld4(base + (long)list[j] * lds);
-            acc.x = fmaf(v.x, inv, acc.x);
-            acc.y = fmaf(v.y, inv, acc.y);
-            acc.z = fmaf(v.z, inv, acc.z);
-            acc.w = fmaf(v.w, inv, acc.w);
         }
     } else if (!by_cell)
     for (int j = j0 + grp; j < j1; j += PPW) {
@@ -762,325 +776,6 @@ extern "C" int wesup_sp_pool_upsample_fwd(const float* s, const int32_t* pix_sor
                            seg_start, sp_feat, Kmax, Umax, cw / 4, ldo, coff + c0);
     }
 #undef WESUP_LAUNCH_PU
-    WESUP_CHECK_LAUNCH();
-    return WESUP_OK;
-}
-
-// ------------------------------------------------------------------ the same scatter-mean at NATIVE resolution, tile by tile (round 5)
-// The segment form above walks a superpixel's pixel list: list -> pixel -> row of s, a chain of two dependent loads per lane group.
-// With few waves per CU -- 4 x 480 x 480: one round of ~4000 waves -- that chain is what the kernel waits for (conv1_1 / conv1_2's
-// outputs, the two largest reads of the pooling: 2.5 TB/s alone).  For a layer at the image's own resolution (h == H, w == W: no
-// interpolation) the image is cut into 16 x 16-pixel tiles instead and a block streams ITS 64 KB of s in raster order -- every load
-// address is known up front, a thread issues its sixteen loads before the first use --:
-//   * wesup_sp_tiles (once per step): per tile the rows (superpixels) present, ascending, and each pixel's slot in that list;
-//     a first part row per tile (prefix sums over the tiles), and per row the box of tiles it touches;
-//   * sp_pool_tile_kernel (per layer): the tile's pixels are loaded once, coalesced, and accumulated per slot in a fixed order: one
-//     partial sum per (tile, slot);
-//   * sp_pool_tile_combine_kernel (per layer): one wave per row adds the row's partial sums over its box of tiles in raster order
-//     and scales by 1 / area.
-// Bitwise reproducible (every order is fixed), no float atomics.  4.1 TB/s at 4 x 480 x 480 (58 against 95 us per layer), 4.6 TB/s at
-// 8 x 1024 x 1024, where the segment form has waves enough and reads at 5.6 TB/s.  Coarse layers keep the segment form: a tile
-// form of them (the <= 12 x 12 cells under a tile, bilinear weights summed per (cell, slot) in LDS) was built and measured in round
-// 5 -- the weight table of every tile costs more than the short chains it removes (tools/pool_micro.py, profiles/r05_pool_micro.txt).
-// A label map whose tiles hold more rows than the part buffer has room for (6 per tile + Kmax per image: superpixels far smaller
-// than a tile) marks the rows of the tiles that did not fit; the combine kernel sums such a row from its pixel list instead (the
-// slow, general form) -- no host decision anywhere.
-#define SPT 16                 // tile edge, full-resolution pixels
-#define SPT_SLOTS 8            // slots accumulated per pass over the tile's cells
-#define SPT_CB 16              // cells in flight per thread
-struct SpTiles {
-    const int32_t* new_row;    // [B][HW]
-    int H, W, Kmax, nty, ntx, cap;      // cap: part rows per image
-    uint8_t* slot;             // [B][HW] the pixel's slot in its tile's row list
-    int32_t* tile_ns;          // [B][ntile] rows present
-    int32_t* tile_base;        // [B][ntile] first part row, -1: did not fit
-    int32_t* tile_rows;        // [B][ntile][256] the rows, ascending
-    int32_t* alloc;            // [B] part rows asked for (sp_tiles_scan_kernel)
-    int32_t* row_flag;         // [B][Kmax] 1: a tile of the row did not fit | initialised by sp_tiles_init_kernel
-    int32_t* bbox;             // [B][Kmax][4] ty0, ty1, tx0, tx1            |
-};
-__global__ void sp_tiles_init_kernel(const SpTiles p, int B) {
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (long)B * p.Kmax) return;
-    p.row_flag[i] = 0;
-    p.bbox[4 * i + 0] = 0x7fffffff; p.bbox[4 * i + 1] = -1; p.bbox[4 * i + 2] = 0x7fffffff; p.bbox[4 * i + 3] = -1;
-}
-__global__ __launch_bounds__(256) void sp_tiles_kernel(const SpTiles p) {
-    __shared__ uint32_t bits[SP_MAX_K / 32];
-    __shared__ int wpre[SP_MAX_K / 32];
-    __shared__ int scan[256];
-    __shared__ int srows[256];
-    const int b = blockIdx.z, ty = blockIdx.y, tx = blockIdx.x, tid = threadIdx.x;
-    const int tile = ty * p.ntx + tx, ntile = p.nty * p.ntx;
-    const int words = (p.Kmax + 31) >> 5;
-    for (int i = tid; i < words; i += 256) bits[i] = 0u;
-    __syncthreads();
-    const int y = ty * SPT + (tid >> 4), x = tx * SPT + (tid & 15);
-    const bool inside = y < p.H && x < p.W;
-    const long pix = (long)b * p.H * p.W + (long)y * p.W + x;
-    int r = inside ? p.new_row[pix] : -1;
-    if (r >= p.Kmax) r = -1;
-    if (r >= 0) atomicOr(&bits[r >> 5], 1u << (r & 31));
-    __syncthreads();
-    // exclusive prefix of the popcounts over the words: thread t owns the words [t per, (t + 1) per)
-    const int per = (words + 255) / 256;
-    int cnt = 0;
-    for (int i = tid * per; i < min(words, (tid + 1) * per); ++i) cnt += __popc(bits[i]);
-    scan[tid] = cnt;
-    __syncthreads();
-    for (int off = 1; off < 256; off <<= 1) {
-        const int t = (tid >= off) ? scan[tid - off] : 0;
-        __syncthreads();
-        scan[tid] += t;
-        __syncthreads();
-    }
-    const int ns = scan[255];
-    int run = scan[tid] - cnt;
-    for (int i = tid * per; i < min(words, (tid + 1) * per); ++i) {
-        wpre[i] = run;
-        uint32_t m = bits[i];
-        while (m) {
-            const int bit = __ffs(m) - 1;
-            m &= m - 1;
-            srows[run++] = i * 32 + bit;          // (ns <= 256: a tile has 256 pixels)
-        }
-    }
-    if (tid == 0) p.tile_ns[(long)b * ntile + tile] = ns;
-    __syncthreads();
-    if (inside) p.slot[pix] = r >= 0 ? (uint8_t)(wpre[r >> 5] + __popc(bits[r >> 5] & ((1u << (r & 31)) - 1u))) : (uint8_t)255;
-    if (tid < ns) {
-        const int rr = srows[tid];
-        p.tile_rows[((long)b * ntile + tile) * 256 + tid] = rr;
-        int32_t* bb = p.bbox + ((long)b * p.Kmax + rr) * 4;
-        atomicMin(&bb[0], ty); atomicMax(&bb[1], ty); atomicMin(&bb[2], tx); atomicMax(&bb[3], tx);
-    }
-}
-// part rows per tile: the exclusive prefix of tile_ns over the image's tiles (raster order); a tile whose rows end beyond the
-// capacity gets -1 and marks its rows.  One block per image.
-__global__ __launch_bounds__(1024) void sp_tiles_scan_kernel(const SpTiles p) {
-    __shared__ int sh[1024];
-    const int b = blockIdx.x, tid = threadIdx.x, ntile = p.nty * p.ntx;
-    const int per = (ntile + 1023) / 1024;
-    const int i0 = min(ntile, tid * per), i1 = min(ntile, i0 + per);
-    const int32_t* ns = p.tile_ns + (long)b * ntile;
-    int sum = 0;
-    for (int i = i0; i < i1; ++i) sum += ns[i];
-    int total;
-    int run = block_excl_scan(sum, &total, sh);
-    for (int i = i0; i < i1; ++i) {
-        const int n = ns[i];
-        const bool fits = run + n <= p.cap;
-        p.tile_base[(long)b * ntile + i] = fits ? run : -1;
-        if (!fits)
-            for (int k = 0; k < n; ++k) p.row_flag[(long)b * p.Kmax + p.tile_rows[((long)b * ntile + i) * 256 + k]] = 1;
-        run += n;
-    }
-    if (tid == 0) p.alloc[b] = total;
-}
-extern "C" int wesup_sp_tiles_part_rows(int H, int W, int Kmax) {
-    return (H > 0 && W > 0 && Kmax > 0) ? 6 * ceil_div(H, SPT) * ceil_div(W, SPT) + Kmax : 0;
-}
-extern "C" int wesup_sp_tiles(const int32_t* new_row, int B, int H, int W, int Kmax, uint8_t* slot, int32_t* tile_ns,
-                              int32_t* tile_base, int32_t* tile_rows, int32_t* alloc, int32_t* row_flag, int32_t* bbox,
-                              void* stream) {
-    if (!new_row || !slot || !tile_ns || !tile_base || !tile_rows || !alloc || !row_flag || !bbox || B <= 0 || B > 65535 || H <= 0 ||
-        W <= 0 || Kmax <= 0 || Kmax > SP_MAX_K)
-        return WESUP_ERR_INVALID;
-    SpTiles p = {};
-    p.new_row = new_row; p.H = H; p.W = W; p.Kmax = Kmax; p.nty = ceil_div(H, SPT); p.ntx = ceil_div(W, SPT);
-    p.cap = wesup_sp_tiles_part_rows(H, W, Kmax);
-    p.slot = slot; p.tile_ns = tile_ns; p.tile_base = tile_base; p.tile_rows = tile_rows; p.alloc = alloc; p.row_flag = row_flag;
-    p.bbox = bbox;
-    if (p.nty > 65535) return WESUP_ERR_INVALID;
-    hipStream_t st = (hipStream_t)stream;
-    WESUP_LAUNCH(sp_tiles_init_kernel, dim3((unsigned)(((long)B * Kmax + 255) / 256)), dim3(256), 0, st, p, B);
-    WESUP_LAUNCH(sp_tiles_kernel, dim3(p.ntx, p.nty, B), dim3(256), 0, st, p);
-    WESUP_LAUNCH(sp_tiles_scan_kernel, dim3(B), dim3(1024), 0, st, p);
-    WESUP_CHECK_LAUNCH();
-    return WESUP_OK;
-}
-
-struct SpPoolTile {
-    const float* s;            // (B, H, W, lds) the side output / conv output, channel offset applied
-    float* part;               // [B][cap][C]
-    float* out;                // (B, Kmax, ldo), channel offset applied
-    const uint8_t* slot;
-    const int32_t *tile_ns, *tile_base, *tile_rows, *row_flag, *bbox;
-    const int32_t *pix_sorted, *row_start;
-    int H, W, lds, ldo, Kmax, nty, ntx, cap;
-};
-// NQ = C / 4 lanes cover the channels of one pixel; G = 256 / NQ lane groups walk the tile's pixels g, g + G, ...
-template <int NQ>
-__global__ __launch_bounds__(256) void sp_pool_tile_kernel(const SpPoolTile p) {
-    constexpr int G = 256 / NQ, C = 4 * NQ;
-    constexpr int NS = SPT_SLOTS, CB = SPT_CB;
-    __shared__ short sslot[256];
-    __shared__ __attribute__((aligned(16))) float red[NS][4][C];          // [slot of the pass][wave][channel]
-    const int b = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x;
-    const int ntile = p.nty * p.ntx;
-    const int ns = p.tile_ns[(long)b * ntile + tile], base = p.tile_base[(long)b * ntile + tile];
-    if (ns == 0 || base < 0) return;                  // (block-uniform)
-    const int ty = tile / p.ntx, tx = tile - ty * p.ntx;
-    const int Y0 = ty * SPT, X0 = tx * SPT;
-    const int ncy = min(p.H - Y0, SPT), ncx = min(p.W - X0, SPT);
-    const int py = tid >> 4, px = tid & 15;
-    sslot[tid] = (py < ncy && px < ncx) ? (short)p.slot[(long)b * p.H * p.W + (long)(Y0 + py) * p.W + X0 + px] : (short)-1;
-    const int q = tid % NQ, g = tid / NQ, wave = tid >> 6, lane = tid & 63;
-    const float* sb = p.s + ((long)b * p.H * p.W + (long)Y0 * p.W + X0) * p.lds + 4 * q;
-    __syncthreads();
-    for (int s0 = 0; s0 < ns; s0 += NS) {
-        const int nsc = min(NS, ns - s0);
-        float4 acc[NS];
-#pragma unroll
-        for (int k = 0; k < NS; ++k) acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int c0 = g; c0 < ncy * SPT; c0 += G * CB) {
-            float4 v[CB];
-            // every load of the batch before the first use (pixel c of the tile: row c >> 4, column c & 15)
-#pragma unroll
-            for (int k = 0; k < CB; ++k) {
-                const int c = c0 + k * G;
-                v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (c < ncy * SPT && (c & 15) < ncx) v[k] = ld4(sb + ((c >> 4) * p.W + (c & 15)) * p.lds);
-            }
-#pragma unroll
-            for (int k = 0; k < CB; ++k) {
-                const int c = c0 + k * G;
-                const int sl = c < ncy * SPT ? (int)sslot[c] - s0 : -1;          // (-1 - s0 < 0 for pixels beyond the image)
-#pragma unroll
-                for (int j = 0; j < NS; ++j)
-                    if (j < nsc) {
-                        const float m = sl == j ? 1.f : 0.f;
-                        acc[j].x = fmaf(m, v[k].x, acc[j].x); acc[j].y = fmaf(m, v[k].y, acc[j].y);
-                        acc[j].z = fmaf(m, v[k].z, acc[j].z); acc[j].w = fmaf(m, v[k].w, acc[j].w);
-                    }
-            }
-        }
-        // the lane groups of a wave by a fixed xor tree, then the four waves through LDS in wave order
-#pragma unroll
-        for (int j = 0; j < NS; ++j)
-            if (j < nsc) {
-#pragma unroll
-                for (int off = NQ; off < 64; off <<= 1) {
-                    acc[j].x += __shfl_xor(acc[j].x, off); acc[j].y += __shfl_xor(acc[j].y, off);
-                    acc[j].z += __shfl_xor(acc[j].z, off); acc[j].w += __shfl_xor(acc[j].w, off);
-                }
-                if (lane < NQ) st4(&red[j][wave][4 * lane], acc[j]);
-            }
-        __syncthreads();
-        for (int i = tid; i < nsc * NQ; i += 256) {
-            const int j = i / NQ, qq = i - j * NQ;
-            float4 t = ld4(&red[j][0][4 * qq]);
-#pragma unroll
-            for (int wv = 1; wv < 4; ++wv) {
-                const float4 u = ld4(&red[j][wv][4 * qq]);
-                t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
-            }
-            st4(p.part + ((long)b * p.cap + base + s0 + j) * C + 4 * qq, t);
-        }
-        if (s0 + NS < ns) __syncthreads();
-    }
-}
-// one wave per row: the partial sums of the row's tiles in raster order (or, for a row some tile of which did not fit, the row's
-// pixel list sampled directly), times 1 / area
-template <int NQ>
-__global__ __launch_bounds__(256) void sp_pool_tile_combine_kernel(const SpPoolTile p) {
-    constexpr int C = 4 * NQ, PPW = 64 / NQ;
-    const int b = blockIdx.y, lane = threadIdx.x & 63;
-    const int r = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    if (r >= p.Kmax) return;
-    const int j0 = p.row_start[(long)b * (p.Kmax + 1) + r], j1 = p.row_start[(long)b * (p.Kmax + 1) + r + 1];
-    const float inv = j1 > j0 ? 1.f / (float)(j1 - j0) : 0.f;
-    const int ntile = p.nty * p.ntx;
-    const int grp = lane / NQ, cl = lane % NQ;
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (j1 > j0 && !p.row_flag[(long)b * p.Kmax + r]) {
-        const int32_t* bb = p.bbox + ((long)b * p.Kmax + r) * 4;
-        const int ty0 = bb[0], ty1 = bb[1], tx0 = bb[2], tx1 = bb[3];
-        const int bw = tx1 - tx0 + 1, nt = (ty1 - ty0 + 1) * bw;
-        // 64 tiles of the box at a time: a lane looks its tile's row list up (lists are a few entries long), then the wave adds the
-        // hits in tile order
-        for (int t0 = 0; t0 < nt; t0 += 64) {
-            const int t = t0 + lane;
-            int row_of_part = -1;
-            if (t < nt) {
-                const int tyy = ty0 + t / bw, txx = tx0 + t % bw;
-                const long ti = (long)b * ntile + (long)tyy * p.ntx + txx;
-                const int ns = p.tile_ns[ti], base = p.tile_base[ti];
-                const int32_t* rows = p.tile_rows + ti * 256;
-                int lo = 0, hi = ns;                         // ascending: binary search
-                while (lo < hi) {
-                    const int mid = (lo + hi) >> 1;
-                    if (rows[mid] < r) lo = mid + 1; else hi = mid;
-                }
-                if (lo < ns && rows[lo] == r) row_of_part = base + lo;
-            }
-            unsigned long long hit = __ballot(row_of_part >= 0);
-            while (hit) {
-                const int l = __ffsll((long long)hit) - 1;
-                hit &= hit - 1;
-                const int pr = __shfl(row_of_part, l);
-                if (grp == 0) {
-                    const float4 v = ld4(p.part + ((long)b * p.cap + pr) * C + 4 * cl);
-                    acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
-                }
-            }
-        }
-    } else if (j1 > j0) {
-        const int32_t* list = p.pix_sorted + (long)b * p.H * p.W;
-        const float* base = p.s + (long)b * p.H * p.W * p.lds + 4 * cl;
-        for (int j = j0 + grp; j < j1; j += PPW) {
-            const float4 v = ld4(base + (long)list[j] * p.lds);
-            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
-        }
-#pragma unroll
-        for (int off = NQ; off < 64; off <<= 1) {
-            acc.x += __shfl_xor(acc.x, off); acc.y += __shfl_xor(acc.y, off);
-            acc.z += __shfl_xor(acc.z, off); acc.w += __shfl_xor(acc.w, off);
-        }
-    }
-    if (grp == 0) st4(p.out + ((long)b * p.Kmax + r) * p.ldo + 4 * cl, make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv));
-}
-extern "C" size_t wesup_sp_pool_tiles_workspace_bytes(int B, int H, int W, int C, int Kmax) {
-    return (B > 0 && C > 0) ? (size_t)B * wesup_sp_tiles_part_rows(H, W, Kmax) * (C < 256 ? C : 256) * sizeof(float) : 0;
-}
-// 1 = wesup_sp_pool_tiles_fwd covers this level: native resolution only (see above)
-extern "C" int wesup_sp_pool_tiles_supported(int h, int w, int H, int W, int C) {
-    return (h > 0 && w > 0 && h == H && w == W && (C == 32 || C == 64 || C == 128 || (C > 0 && C % 256 == 0))) ? 1 : 0;
-}
-extern "C" int wesup_sp_pool_tiles_fwd(const float* s, const uint8_t* slot, const int32_t* tile_ns, const int32_t* tile_base,
-                                       const int32_t* tile_rows, const int32_t* row_flag, const int32_t* bbox,
-                                       const int32_t* pix_sorted, const int32_t* row_start, float* sp_feat, int B, int h, int w,
-                                       int H, int W, int C, int ldo, int coff, int Kmax, void* ws, size_t ws_bytes, void* stream) {
-    if (!s || !slot || !tile_ns || !tile_base || !tile_rows || !row_flag || !bbox || !pix_sorted || !row_start || !sp_feat || !ws ||
-        B <= 0 || B > 65535 || Kmax <= 0 || (ldo % 4) || (coff % 4) || coff + C > ldo || !wesup_sp_pool_tiles_supported(h, w, H, W, C))
-        return WESUP_ERR_INVALID;
-    if (ws_bytes < wesup_sp_pool_tiles_workspace_bytes(B, H, W, C, Kmax)) return WESUP_ERR_WORKSPACE;
-    SpPoolTile p = {};
-    p.part = (float*)ws; p.slot = slot; p.tile_ns = tile_ns; p.tile_base = tile_base; p.tile_rows = tile_rows; p.row_flag = row_flag;
-    p.bbox = bbox; p.pix_sorted = pix_sorted; p.row_start = row_start;
-    p.H = H; p.W = W; p.lds = C; p.ldo = ldo; p.Kmax = Kmax; p.nty = ceil_div(H, SPT); p.ntx = ceil_div(W, SPT);
-    p.cap = wesup_sp_tiles_part_rows(H, W, Kmax);
-    if ((long)H * W * C >= (1l << 31)) return WESUP_ERR_INVALID;       // (32-bit element offsets inside an image)
-    hipStream_t st = (hipStream_t)stream;
-    const dim3 gt((unsigned)(p.nty * p.ntx), B), gc(ceil_div(Kmax, 4), B);
-    // a wave's 64 lanes cover 256 channels of a pixel: wider maps go in slabs of 256 channels (pixel stride C)
-    for (int c0 = 0; c0 < C; c0 += 256) {
-        const int cw = C - c0 < 256 ? C - c0 : 256;
-        p.s = s + c0; p.out = sp_feat + coff + c0;
-#define WESUP_LAUNCH_PT(NQ_)                                                              \
-        do {                                                                              \
-            WESUP_LAUNCH(sp_pool_tile_kernel<NQ_>, gt, dim3(256), 0, st, p);              \
-            WESUP_LAUNCH(sp_pool_tile_combine_kernel<NQ_>, gc, dim3(256), 0, st, p);      \
-        } while (0)
-        switch (cw) {
-            case 32: WESUP_LAUNCH_PT(8); break;
-            case 64: WESUP_LAUNCH_PT(16); break;
-            case 128: WESUP_LAUNCH_PT(32); break;
-            case 256: WESUP_LAUNCH_PT(64); break;
-            default: return WESUP_ERR_INVALID;
-        }
-#undef WESUP_LAUNCH_PT
-    }
     WESUP_CHECK_LAUNCH();
     return WESUP_OK;
 }

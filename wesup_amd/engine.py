@@ -147,7 +147,7 @@ class WesupEngine:
         self._packed = None
         self._prefetched = None
         self.ctx = None
-        # ---- the eight switches; everything else about the schedule is fixed
+        # ---- the seven switches; everything else about the schedule is fixed
         self.fuse_pool_bwd = True        # skip the (B,HW,2112) gradient tensor: pool-bwd fused into upsample-bwd
         self.fuse_pool_fwd = True        # skip the (B,HW,2112) feature map: scatter-mean fused with the upsample
         self.two_streams = True          # side branch and weight gradients on HIP streams of their own
@@ -166,9 +166,6 @@ class WesupEngine:
         #     leaves, 1/16 and 1/32 of the tensor);
         #   * the max-pool backward as a launch of its own on a gradient at pooled resolution (default: the dgrad epilogue).
         self.plain = False
-        # The scatter-mean of the native-resolution layers (conv1_1, conv1_2) tile by tile (ops.sp_pool_tiles_fwd) instead of
-        # superpixel by superpixel through the pixel lists (ops.sp_pool_upsample_fwd); see DESIGN.md 3.2
-        self.pool_tiles = False
         self._diag_skip = set()          # TIMING-ONLY diagnostics (bench.py --diag-skip): classes of launches left out, results wrong
         self.route_fn = default_route    # (ci, co, h, w, B) -> 0 | 2 | 4, consulted per layer and shape
         self._route = None               # the 13 tile sizes of the current / most recent shape
@@ -593,12 +590,6 @@ class WesupEngine:
                 ops.transpose_batched([(g.Wm[i], g.WmT[i]) for g in b.groups for i in range(B)])
                 T.end(tok, 0.0)
         fused = self.fuse_pool_fwd
-        pool_tiles = fused and self.pool_tiles and any(b.group_of[l] is None and b.dims[l] == (H, W) for l in range(13))
-        if pool_tiles:
-            with self._OnSide(self):     # (the label maps' tile tables: once per step, for the native-resolution layers)
-                tok = T.begin('sp_tiles')
-                ops.sp_tiles(meta)
-                T.end(tok, 4.0 * B * H * W)
         pending_side = None              # the side-branch work of the previous layer, when it is queued behind this layer's transform
         cur, cur_relu = b.x0, False      # the layer's input tensor, and whether its ReLU is still to be applied on load
         b.x_in, b.x_relu = [None] * 13, [False] * 13
@@ -677,7 +668,7 @@ class WesupEngine:
                 T.end(tok, 2.0 * B * h * w * co * ((3 if l == 0 else ci) * 9 + (co // 2 if side_in_conv else 0)))
             # side branch of this layer: 1x1 conv on the pre-ReLU tap, then either the fused upsample+scatter-mean
             # straight into the superpixel feature slice, or upsample into fm's channel slice
-            def side_work(l=l, ci=ci, co=co, h=h, w=w, off=off, ws=ws, commute=commute, s_l=s_l, s2d=s2d, side_in_conv=side_in_conv, pool_tiles=pool_tiles):
+            def side_work(l=l, ci=ci, co=co, h=h, w=w, off=off, ws=ws, commute=commute, s_l=s_l, s2d=s2d, side_in_conv=side_in_conv):
               with self._OnSide(self):
                 grp = b.groups[b.group_of[l]] if b.group_of[l] is not None else None
                 if ('side_fwd_shallow' in self._diag_skip and grp is None) or ('side_fwd_deep' in self._diag_skip and grp is not None):
@@ -686,10 +677,7 @@ class WesupEngine:
                     if b.ybar[l] is None:
                         b.ybar[l] = torch.empty(B, Kmax, co, dtype=torch.float32, device=self.device)
                     tok = T.begin('sp_pool_up_fwd')          # (commuted layers are the gather layers: no interpolation matrix)
-                    if pool_tiles and ops.sp_pool_tiles_supported(h, w, H, W, co):
-                        ops.sp_pool_tiles_fwd(b.y[l], meta, b.ybar[l], 0)
-                    else:
-                        ops.sp_pool_upsample_fwd(b.y[l], meta, b.ybar[l], 0)
+                    ops.sp_pool_upsample_fwd(b.y[l], meta, b.ybar[l], 0)
                     T.end(tok, 4.0 * B * (h * w * co + H * W + Kmax * co))
                     tok = T.begin('side_fwd')
                     ops.gemm_nt(b.ybar[l].view(B * Kmax, co), ws, p[f'side_conv{off}.bias'],
@@ -710,10 +698,7 @@ class WesupEngine:
                         T.end(tok, 2.0 * B * Kmax * g.h * g.w * g.C)
                 elif fused:
                     tok = T.begin('sp_pool_up_fwd')
-                    if pool_tiles and ops.sp_pool_tiles_supported(h, w, H, W, co // 2):
-                        ops.sp_pool_tiles_fwd(s_l, meta, b.sp_in, off)
-                    else:
-                        ops.sp_pool_upsample_fwd(s_l, meta, b.sp_in, off)
+                    ops.sp_pool_upsample_fwd(s_l, meta, b.sp_in, off)
                     T.end(tok, 4.0 * B * (h * w * (co // 2) + H * W + Kmax * (co // 2)))
                 elif s_l is not None:
                     tok = T.begin('upsample_fwd')
@@ -1054,7 +1039,8 @@ class WesupEngine:
                     b.bpart[l] = torch.empty(ops.winograd_bias_rows(B, h, w, co), co, dtype=torch.float32, device=self.device)
                 v_dy = b.dV[:36 * Tl * co].view(36, Tl, co)
                 tok = T.begin('winograd_transform')
-                ops.winograd_dual_transform(b.G[l], v_dy, b.dM[l], b.bpart[l])
+                if 'dual' not in self._diag_skip:
+                    ops.winograd_dual_transform(b.G[l], v_dy, b.dM[l], b.bpart[l])
                 T.end(tok, 4.0 * (B * h * w + 2 * 36 * Tl) * co)
             def wgrad(ws_tag):
                 tok = T.begin('conv3x3_wgrad')

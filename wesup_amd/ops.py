@@ -35,6 +35,11 @@ else:                                                  # a torch build without t
         return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+# TIMING-ONLY diagnostics (bench.py --diag-skip, results wrong): 'tout' leaves out the separate output transforms of the K = 512
+# Winograd layers, 'tin' the input transforms of the forward -- what those launches cost the step
+DIAG = set()
+
+
 # Optional HIP-event timing of the kernel classes that are launched outside the engine's schedule (superpixel
 # preprocessing, label propagation + loss, SGD): bench.py hands the engine's KernelTimer over; None = no events.
 _timer = None
@@ -497,7 +502,7 @@ def _winograd_conv(inp, u, bias, mask_src, out, out_relu, v_keep, relu_in, accum
     hook = [after_transform]      # called once, when the (first) input transform has been queued
 
     def t_in(b0, nb_, st):
-        if not v_ready:
+        if not v_ready and 'tin' not in DIAG:
             _t_in(b0, nb_, st)
         if hook[0] is not None:
             hook[0]()
@@ -524,6 +529,8 @@ def _winograd_conv(inp, u, bias, mask_src, out, out_relu, v_keep, relu_in, accum
             timer.end(tok, 2.0 * P * tn * Cin * Cout)
 
     def t_out(b0, nb_, st):
+        if 'tout' in DIAG:
+            return
         tok = timer.begin('winograd_transform') if timer else None
         t0 = winograd_tiles(b0, H, W, m)
         sl = slice(b0, b0 + nb_)
@@ -1078,49 +1085,6 @@ def sp_pool_upsample_fwd(s, meta, out, coff):
     _lib.call('wesup_sp_pool_upsample_fwd', _p(s), _p(meta.pix_sorted), _p(meta.row_start), _p(meta.seg_start),
               _p(meta.unit_row), _p(out), B, h, w, meta.H, meta.W, C, out.shape[2], coff, meta.Kmax, meta.Umax, _p(ws), nb,
               _stream())
-    return out
-
-
-class _SpTiles:
-    __slots__ = ('slot', 'tile_ns', 'tile_base', 'tile_rows', 'alloc', 'row_flag', 'bbox', 'ntile')
-
-
-def sp_tiles(meta):
-    """The tile tables of the label maps of ``meta`` (wesup_sp_tiles): once per step, behind sp_preprocess on the same stream; the
-    buffers live with the meta (a recorded step plan holds their addresses)."""
-    B, H, W, Kmax = meta.B, meta.H, meta.W, meta.Kmax
-    t = meta.tiles
-    if t is None:
-        dev = meta.new_row.device
-        i32 = dict(dtype=torch.int32, device=dev)
-        t = _SpTiles()
-        t.ntile = ((H + 15) // 16) * ((W + 15) // 16)
-        t.slot = torch.empty(B, H * W, dtype=torch.uint8, device=dev)
-        t.tile_ns = torch.empty(B, t.ntile, **i32); t.tile_base = torch.empty(B, t.ntile, **i32)
-        t.tile_rows = torch.empty(B, t.ntile, 256, **i32)
-        t.alloc = torch.empty(B, **i32); t.row_flag = torch.empty(B, Kmax, **i32); t.bbox = torch.empty(B, Kmax, 4, **i32)
-        meta.tiles = t
-    _lib.call('wesup_sp_tiles', _p(meta.new_row), B, H, W, Kmax, _p(t.slot), _p(t.tile_ns), _p(t.tile_base), _p(t.tile_rows),
-              _p(t.alloc), _p(t.row_flag), _p(t.bbox), _stream())
-    return t
-
-
-def sp_pool_tiles_supported(h, w, H, W, C):
-    return bool(_lib.load().wesup_sp_pool_tiles_supported(h, w, H, W, C))
-
-
-def sp_pool_tiles_fwd(s, meta, out, coff):
-    """sp_pool_upsample_fwd of a native-resolution s tile by tile (wesup_sp_pool_tiles_fwd; needs sp_tiles(meta) of this step's label maps)."""
-    _chk(s, name='s'); _chk(out, name='out')
-    B, h, w, C = s.shape
-    t = meta.tiles
-    assert t is not None, 'sp_tiles(meta) first'
-    assert out.shape[:2] == (B, meta.Kmax) and B == meta.B and coff + C <= out.shape[2]
-    nb = _lib.load().wesup_sp_pool_tiles_workspace_bytes(B, meta.H, meta.W, C, meta.Kmax)
-    ws = workspace(nb, s.device, 'pool_up')
-    _lib.call('wesup_sp_pool_tiles_fwd', _p(s), _p(t.slot), _p(t.tile_ns), _p(t.tile_base), _p(t.tile_rows), _p(t.row_flag),
-              _p(t.bbox), _p(meta.pix_sorted), _p(meta.row_start), _p(out), B, h, w, meta.H, meta.W, C, out.shape[2], coff,
-              meta.Kmax, _p(ws), nb, _stream())
     return out
 
 

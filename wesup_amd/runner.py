@@ -183,7 +183,7 @@ class StepRunner:
         pk = eng._packed
         panels = None if pk is None else tuple(0 if u is None else u.data_ptr() for u in list(pk.uf) + list(pk.ud))
         return (sw, eng.route_fn, type(eng).WINOGRAD_CONV_MIN_CI, type(eng).WINOGRAD_TILE, tuple(sorted(eng._diag_skip)),
-                ops.STREAMK,
+                ops.STREAMK, tuple(sorted(ops.DIAG)),
                 g['lr'], g['momentum'], g['weight_decay'], o.grad_scale, o._first,
                 tuple(p.requires_grad for _, p in t.model._named),
                 float(t.kwargs.get('propagate_threshold')), float(t.kwargs.get('propagate_weight')),
