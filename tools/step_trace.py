@@ -27,6 +27,9 @@ if sys.argv[1] == 'run':
     trainer.tracker.train()
     trainer.model.engine.two_streams = len(sys.argv) > 2 and sys.argv[2] == 'multi'
     trainer.model.engine._diag_skip = set(filter(None, os.environ.get('WESUP_TRACE_SKIP', '').split(',')))      # timing-only
+    for kv in filter(None, os.environ.get('WESUP_TRACE_ENGINE_SET', '').split(',')):      # e.g. plain=1
+        k, v = kv.split('=')
+        setattr(trainer.model.engine, k, type(getattr(trainer.model.engine, k))(int(v)))
     imgs, labs, pts, pix = synth.make_batch(1, B, H, W, g)
     data = (torch.from_numpy(imgs).to(dev), torch.from_numpy(pix).to(dev), torch.from_numpy(pts).to(dev), torch.from_numpy(labs).to(dev))
     for _ in range(8):          # (the last iterations replay the recorded step plan: the host is out of the picture)
