@@ -136,7 +136,7 @@ class StepRunner:
         # the process holds (268 K tracked objects with torch imported: 67 ms each, 2 ms per step averaged over 40 new shapes,
         # tools/cold_walk.py).  Everything alive when training starts (modules, the model, the loaders) is moved to the permanent
         # generation once; later collections only look at what the iterations create.  A process-wide side effect, so OPT-IN
-        # (``gc_freeze=True``: bench.py's multi-scale mode and train.py's fit() pass it) and done at most once per process.
+        # (``gc_freeze=True``: bench.py's multi-scale mode and the ``python -m wesup_amd.train`` script pass it) and done at most once per process.
         if trainer.kwargs.get('gc_freeze', False):
             freeze_startup_objects()
         self._cuts = None
@@ -469,14 +469,20 @@ class StepRunner:
         plan = st.plan
         lib = _lib.load()
         pos, host = 0, None
-        for node, fn in plan.cuts:
-            if node > pos:
-                _lib.check(lib.wesup_plan_replay(plan.h, pos, node), 'wesup_plan_replay')
-            pos = node
-            r = fn()
-            if isinstance(r, dict):
-                host = r
-        _lib.check(lib.wesup_plan_replay(plan.h, pos, plan.size()), 'wesup_plan_replay')
+        try:
+            for node, fn in plan.cuts:
+                if node > pos:
+                    _lib.check(lib.wesup_plan_replay(plan.h, pos, node), 'wesup_plan_replay')
+                pos = node
+                r = fn()
+                if isinstance(r, dict):
+                    host = r
+            _lib.check(lib.wesup_plan_replay(plan.h, pos, plan.size()), 'wesup_plan_replay')
+        except BaseException:
+            # ('Loss is nan!' at the plan's cut, or a failed replay: the rest of the plan is not queued -- the caller's stream waits
+            # for what the side and weight-gradient streams already hold, as the walk does, engine.abort_backward)
+            self.t.model.engine.abort_backward()
+            raise
         self.t.model._publish_grads()
         self._publish(st)
         return host

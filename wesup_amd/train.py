@@ -77,4 +77,9 @@ if __name__ == '__main__':
     ap.add_argument('dataset_path')
     ap.add_argument('--model', default='wesup')
     args, rest = ap.parse_known_args()
-    fit(args.dataset_path, model=args.model, **parse_cli_kwargs(rest))
+    kw = parse_cli_kwargs(rest)
+    # The training SCRIPT (not the library) opts into the two process-wide / trust-based conveniences of the step runner: the
+    # reference trains multi-scale (utils/data.py:98-101: a new shape almost every step), where they pay (wesup_amd/runner.py)
+    kw.setdefault('gc_freeze', True)
+    kw.setdefault('trust_first_recording_after', 1)
+    fit(args.dataset_path, model=args.model, **kw)
