@@ -350,6 +350,33 @@ def worker(args):
             dist.barrier()
         torch.cuda.synchronize()
 
+    # What THIS box delivers, measured before the run (the pool's boxes differ by +-2.5 % for the same code): a 256 MiB
+    # device-to-device copy and one large plain NT GEMM of the library (4096^3), each alone on the GPU.  Context for comparing
+    # lines across runs, not part of any roofline figure.
+    box = None
+    if rank == 0 and not args.no_kernel_timing:
+        from wesup_amd import ops as _ops_b
+        src_ = torch.empty(256 << 20, dtype=torch.uint8, device=dev)
+        dst_ = torch.empty_like(src_)
+        A_ = torch.randn(4096, 4096, device=dev)
+        B_ = torch.randn(4096, 4096, device=dev)
+        C_ = torch.empty(4096, 4096, device=dev)
+
+        def _probe(fn, reps):
+            fn(); torch.cuda.synchronize()
+            e0_, e1_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0_.record()
+            for _ in range(reps):
+                fn()
+            e1_.record(); torch.cuda.synchronize()
+            return e0_.elapsed_time(e1_) / reps * 1e-3
+        t_copy = _probe(lambda: dst_.copy_(src_), 20)
+        t_gemm = _probe(lambda: _ops_b.gemm_nt(A_, B_, None, out=C_), 5)
+        box = {'copy_256MiB_gbs': round(2 * (256 << 20) / t_copy / 1e9, 1), 'gemm_nt_4096_cubed_tflops': round(2 * 4096.0 ** 3 / t_gemm / 1e12, 1),
+               'what': 'this box alone, before the run: device-to-device copy (read + write bytes / time) and wesup_gemm_nt 4096 x 4096 x 4096'}
+        del src_, dst_, A_, B_, C_
+        torch.cuda.empty_cache()
+
     timer = trainer.model.engine.timer
     from wesup_amd import ops as _ops_t
     _ops_t.set_timer(timer)                           # sp_preprocess / propagate / paint / sgd launch outside the engine
@@ -470,6 +497,7 @@ def worker(args):
             # how the warm-up + timed iterations were issued (wesup_amd/runner.py): walked in Python ('eager'; the first two of a
             # shape and every event-carrying one), walked and recorded, or replayed from the recorded step plan
             'step_plan': plan_stats,
+            'box': box,
             'memory': {'peak_allocated_gib': round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 2),
                        'reserved_gib': round(torch.cuda.memory_reserved(dev) / 2 ** 30, 2),
                        'cached_buffer_sets': len(trainer.model.engine._bufs)},
