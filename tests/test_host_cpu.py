@@ -189,3 +189,29 @@ def test_kernel_timer_replaces_an_impossible_pair():
     ms, n, work = tot['winograd_gemm']
     assert n == 3 and abs(ms - 6.45) < 1e-9
     assert T.pending == [] and len(T._free) == 18
+
+
+def test_step_runner_defaults_are_conservative_and_side_effect_free(monkeypatch):
+    """Round 6: a step runner made by the library does NOT freeze the host application's garbage collector, does NOT
+    seal first recordings without their twin, and audits sealed plans after one replay when a caller opts in; the engine exposes the
+    seven documented switches and nothing else that is boolean."""
+    import gc
+    from wesup_amd import runner
+    from wesup_amd.engine import WesupEngine
+    calls = []
+    monkeypatch.setattr(gc, 'freeze', lambda: calls.append('freeze'))
+    monkeypatch.setattr(runner, '_frozen', False)
+    t = initialize_trainer('wesup', device='cpu')
+    r = runner.StepRunner(t)
+    assert calls == [] and r.trust_after is None and r.audit_after == 1 and r.audit_every is None
+    t2 = initialize_trainer('wesup', device='cpu', gc_freeze=True, trust_first_recording_after=1, plan_audit_every=50)
+    r2 = runner.StepRunner(t2)
+    runner.StepRunner(t2)                                   # a second runner of the process does not freeze again
+    assert calls == ['freeze'] and r2.trust_after == 1 and r2.audit_every == 50
+    p = {'w': torch.zeros(4)}
+    eng = WesupEngine(p, {'w': torch.zeros(4)})
+    public_bools = sorted(k for k, v in vars(eng).items() if isinstance(v, bool) and not k.startswith('_'))
+    assert public_bools == ['conv_winograd', 'fuse_pool_bwd', 'fuse_pool_fwd', 'plain', 'two_streams', 'wgrad_winograd'], public_bools
+    assert eng.commute_side and eng.dual_transform and eng.compact_masks and eng.gather_side_grad and eng.fuse_unpool
+    eng.plain = True
+    assert not (eng.commute_side or eng.dual_transform or eng.compact_masks or eng.gather_side_grad or eng.fuse_unpool)
