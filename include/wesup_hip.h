@@ -35,7 +35,7 @@ extern "C" {
 #define WESUP_ACCUM 4      /* C += result */
 #define WESUP_MASK 8       /* result := mask > 0 ? result : 0 (ReLU backward) */
 
-int wesup_abi_version(void);
+int wesup_abi_version(void);   /* 6 (round 6: the tile-form pooling entries of ABI 5, wesup_sp_tiles / wesup_sp_pool_tiles_*, are gone) */
 /* The two debug entries only work in the debug build of the library (make -C wesup_amd/csrc debug ->
  * libwesup_hip_debug.so, GEMM kernels compiled with the in-kernel clock probe and the per-block trace); the shipped
  * library's kernels carry neither and both entries return WESUP_ERR_INVALID there.
