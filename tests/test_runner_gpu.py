@@ -223,8 +223,8 @@ def test_sealed_plans_are_audited_and_dropped_when_the_walk_would_differ():
     """A plan sealed without a twin (trust_first_recording_after=1) holds raw device addresses nobody has compared with a second walk.
     (1) After AUDIT_AFTER = 1 replay the shape is walked and recorded once more and the recording compared with the sealed plan node
     by node: a clean audit leaves the plan in place (stats['audited']), bit-identical to a trainer that never replays.
-    (2) Negative: a shared workspace that grows while a larger shape is interleaved (realistic sizes: 96 -> 256 pixels a side, the
-    lazily allocated V / Ybar / filter-panel buffers of the sealed shape's first walk included) moves addresses the sealed plan
+    (2) Negative: a shared workspace that grows while a larger shape is interleaved (realistic sizes: a 224 x 160 crop sealed beside a 256 x 256 one, then two
+    320 x 320 images; the lazily allocated V / Ybar / filter-panel buffers of the sealed shape's first walk included) moves addresses the sealed plan
     holds -- the plan must be DROPPED on the shape's next occurrence, not replayed.
     (3) Negative: a sealed plan whose launch list no longer matches what the walk does (a node of the plan tampered with, standing
     for anything the hand-kept validity key misses) fails its audit: dropped, stats['distrusted'], a RuntimeWarning."""
@@ -239,12 +239,12 @@ def test_sealed_plans_are_audited_and_dropped_when_the_walk_would_differ():
     ops.ws_generation += 1
     ops.set_workspace_headroom(1)
     weights = orc.make_weights(21, feat_scale=0.05)
-    shapes = [(1, 96, 96, 6), (1, 96, 80, 5), (2, 256, 256, 12)]
+    shapes = [(1, 256, 256, 12), (1, 224, 160, 10), (2, 320, 320, 14)]        # (the middle one: a GlaS crop at the reference's 0.3 - 0.4 scale)
     data = [_batches(1, *s, dev)[0] for s in shapes]
     a = _trainer(weights, step_plan=False)
     b = _trainer(weights, trust_first_recording_after=1)
     for t in (a, b):
-        t.kwargs['max_superpixels'] = 192
+        t.kwargs['max_superpixels'] = 256
 
     def both(i):
         a.train_one_iteration('train', *data[i])
@@ -275,8 +275,8 @@ def test_sealed_plans_are_audited_and_dropped_when_the_walk_would_differ():
     # (3) tamper with a sealed plan: swap it for the plan of ANOTHER shape's walk (same cuts count or not: the diff decides)
     for _ in range(3):
         both(1)                       # recorded again, sealed (or twin-confirmed), replayed
-    key1 = next(k for k, st in r.states.items() if k[1:3] == (96, 80))
-    key0 = next(k for k, st in r.states.items() if k[1:3] == (96, 96))
+    key1 = next(k for k, st in r.states.items() if k[1:3] == (224, 160))
+    key0 = next(k for k, st in r.states.items() if k[1:3] == (256, 256))
     for _ in range(3):
         both(0)
     st1, st0 = r.states[key1], r.states[key0]
